@@ -1,0 +1,216 @@
+"""Mint golden vectors by running the REAL reference (container only).
+
+TEST INFRASTRUCTURE ONLY.  Usage (from the repo root, needs /root/reference):
+
+    python -m oracle.make_golden            # writes tests/golden/*.pt
+
+The reference has no tests or known-answer vectors of its own, so these
+files are the pin: the unmodified reference modules (imported via oracle/ref_shim.py),
+weights from oracle/weights.py (name-keyed, reproducible), seeded inputs, and -- for the
+sampler -- noise injected by replacing the reference module's ``gumbel_noise``/``uniform``
+globals (phenaki_pytorch.py:69-70, 88-90) so the exact same U[0,1) draws can be fed to
+the oracle and to the HIP path.  Only OUTPUTS are stored (weights/inputs are regenerated).
+"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from oracle import ref_shim, weights  # noqa: E402
+from oracle.configs import TINY, FULL, build_reference  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+
+
+class Recorder:
+    """wraps the reference's sampling helpers to inject noise and record every step."""
+
+    def __init__(self, R, phenaki, noise_seed_base):
+        self.R, self.ph, self.base = R, phenaki, noise_seed_base
+        self.steps = []
+        self.cur = None
+        self.scene = 0
+
+    def install(self):
+        m = self.R.module
+        self._orig = (m.gumbel_noise, m.uniform, m.gumbel_sample)
+        rec = self
+
+        def gumbel_noise(t):
+            u = weights.uniform_noise(tuple(t.shape), rec.base + 100 * rec.scene + 2 * rec.cur['step'])
+            return -m.log(-m.log(u))
+
+        def uniform(shape, device):
+            return weights.uniform_noise(tuple(shape), rec.base + 100 * rec.scene + 2 * rec.cur['step'] + 1)
+
+        def gumbel_sample(t, temperature=1., dim=-1):
+            out = rec._orig[2](t, temperature=temperature, dim=dim)
+            rec.cur['pred'] = out.clone()
+            rec.cur['temperature'] = temperature
+            return out
+
+        m.gumbel_noise, m.uniform, m.gumbel_sample = gumbel_noise, uniform, gumbel_sample
+
+        mg, cr = self.ph.maskgit, self.ph.critic
+        self._mg_fwd = mg.forward_with_cond_scale
+
+        def mg_fwd(ids, **kw):
+            rec.cur = dict(step=len([s for s in rec.steps if s['scene'] == rec.scene]), scene=rec.scene)
+            rec.steps.append(rec.cur)
+            rec.cur['mg_input'] = ids.clone()
+            out = rec._mg_fwd(ids, **kw)
+            if rec.keep_logits:
+                rec.cur['logits'] = out.clone()
+            return out
+        mg.forward_with_cond_scale = mg_fwd
+        if cr is not None:
+            self._cr_fwd = cr.forward_with_cond_scale
+
+            def cr_fwd(ids, **kw):
+                rec.cur['critic_input'] = ids.clone()
+                out = rec._cr_fwd(ids, **kw)
+                rec.cur['critic_raw'] = out.clone()
+                return out
+            cr.forward_with_cond_scale = cr_fwd
+        return self
+
+    def uninstall(self):
+        m = self.R.module
+        m.gumbel_noise, m.uniform, m.gumbel_sample = self._orig
+        self.ph.maskgit.forward_with_cond_scale = self._mg_fwd
+        if self.ph.critic is not None:
+            self.ph.critic.forward_with_cond_scale = self._cr_fwd
+
+    keep_logits = False
+
+
+def cvivit_golden(R, cfgs, batch, frames, tag, subsample):
+    cv, _, _, _ = build_reference(R, cfgs, with_phenaki=False)
+    H, W = cfgs['cvivit']['image_size'], cfgs['cvivit']['image_size']
+    video = weights.synthetic_video(batch, frames, H, W, seed=0)
+    cap = {}
+    hook = cv.vq.project_in.register_forward_hook(lambda m, i, o: cap.__setitem__('proj', o.detach().clone()))
+    with torch.no_grad():
+        t0 = time.time()
+        ids = cv(video, return_only_codebook_ids=True)
+        t_enc = time.time() - t0
+        first = cv.to_patch_emb_first_frame(video[:, :, :1])
+        rest = cv.to_patch_emb(video[:, :, 1:])
+        patch_tokens = torch.cat((first, rest), dim=1)
+        enc_tokens = cv.encode(patch_tokens)
+        recon = cv.decode_from_codebook_indices(ids.flatten(1))
+        recon2 = cv(video, return_recons_only=True)
+    hook.remove()
+    assert torch.equal(recon, recon2)
+    out = dict(ids=ids, proj=cap['proj'], t_encode_ref_cpu=t_enc,
+               recon_sum=recon.double().sum().item(), recon_abs=recon.double().abs().sum().item())
+    if subsample:
+        out['patch_tokens_sub'] = patch_tokens[:, :, ::2, ::2, ::8].clone()
+        out['enc_tokens_sub'] = enc_tokens[:, :, ::2, ::2, ::8].clone()
+        out['recon_sub'] = recon[:, :, ::4, ::8, ::8].clone()
+    else:
+        out['patch_tokens'] = patch_tokens
+        out['enc_tokens'] = enc_tokens
+        out['recon'] = recon
+    torch.save(out, os.path.join(OUT, f'cvivit_{tag}.pt'))
+    print(f'cvivit_{tag}: ids {tuple(ids.shape)} encode {t_enc:.2f}s')
+
+
+def maskgit_golden(R, cfgs, batch, frames, ctx_len, tag, col_stride):
+    cv, mg, cr, _ = build_reference(R, cfgs, with_phenaki=False)
+    pt = cfgs['cvivit']['temporal_patch_size']
+    hw = cfgs['cvivit']['image_size'] // cfgs['cvivit']['patch_size']
+    patch_shape = (1 + (frames - 1) // pt, hw, hw)
+    n = patch_shape[0] * hw * hw
+    V = cfgs['maskgit']['num_tokens']
+    g = torch.Generator().manual_seed(77)
+    ids = torch.randint(0, V + 1, (batch, n), generator=g)
+    ids[:, ::3] = V  # mask id
+    ctx = weights.synthetic_context(batch, ctx_len, cfgs['maskgit']['dim_context'], seed=1, pad_last=3)
+    text_mask = (ctx != 0).any(-1)
+    with torch.no_grad():
+        cond = mg(ids, video_patch_shape=patch_shape, context=ctx, text_mask=text_mask, cond_drop_prob=0.)
+        null = mg(ids, video_patch_shape=patch_shape, context=ctx, text_mask=text_mask, cond_drop_prob=1.)
+        cfg = mg.forward_with_cond_scale(ids, video_patch_shape=patch_shape, context=ctx, text_mask=text_mask, cond_scale=5.)
+        embeds = mg(ids, video_patch_shape=patch_shape, context=ctx, text_mask=text_mask, return_embeds=True)
+        bias = mg.continuous_pos_bias(*patch_shape)
+        sc = cr.forward_with_cond_scale(ids, video_patch_shape=patch_shape, context=ctx, text_mask=text_mask, cond_scale=5.)
+        sc_cond = cr(ids, video_patch_shape=patch_shape, context=ctx, text_mask=text_mask, cond_drop_prob=0.)
+    out = dict(ids=ids, patch_shape=patch_shape, ctx_len=ctx_len,
+               cond=cond[:, :, ::col_stride].clone(), null=null[:, :, ::col_stride].clone(),
+               cfg=cfg[:, :, ::col_stride].clone(), cfg_argmax=cfg.argmax(-1), cfg_lse=cfg.logsumexp(-1),
+               embeds=embeds[:, :, ::max(1, col_stride // 64)].clone(), bias_sub=bias[:, ::7, ::5].clone(),
+               critic_cfg=sc, critic_cond=sc_cond, col_stride=col_stride)
+    torch.save(out, os.path.join(OUT, f'maskgit_{tag}.pt'))
+    print(f'maskgit_{tag}: logits {tuple(cfg.shape)}')
+
+
+def sample_golden(R, cfgs, batch, frames_list, prime_len, ctx_len, tag, keep_logits, with_critic=True, steps=None):
+    cv, mg, cr, ph = build_reference(R, cfgs, with_phenaki=True, with_critic=with_critic, steps=steps)
+    ctx = weights.synthetic_context(batch, ctx_len, cfgs['maskgit']['dim_context'], seed=2)
+    ph.encode_texts = lambda texts, output_device=None: ctx
+    rec = Recorder(R, ph, noise_seed_base=500)
+    rec.keep_logits = keep_logits
+    rec.install()
+    t0 = time.time()
+    try:
+        with torch.no_grad():
+            videos = []
+            prime = None
+            for si, nf in enumerate(frames_list):
+                rec.scene = si
+                v = ph.sample(texts=['x'] * batch, num_frames=nf, prime_frames=prime, cond_scale=5.)
+                videos.append(v)
+                prime = v[:, :, -prime_len:] if prime_len else None
+    finally:
+        rec.uninstall()
+    dt = time.time() - t0
+    out = dict(steps=rec.steps, frames_list=frames_list, prime_len=prime_len, ctx_len=ctx_len, batch=batch,
+               t_sample_ref_cpu=dt, with_critic=with_critic)
+    if keep_logits:
+        out['videos'] = videos
+    else:
+        out['videos_sub'] = [v[:, :, ::4, ::8, ::8].clone() for v in videos]
+        out['videos_sum'] = [v.double().sum().item() for v in videos]
+    torch.save(out, os.path.join(OUT, f'sample_{tag}.pt'))
+    print(f'sample_{tag}: {len(rec.steps)} step records, {dt:.1f}s')
+
+
+def keys_golden(R):
+    """state_dict contract: every key, shape and dtype of the reference modules."""
+    import json
+    out = {}
+    for tag, cfgs in (('tiny', TINY), ('full', FULL)):
+        cv, mg, cr, _ = build_reference(R, cfgs, with_phenaki=False)
+        for kind, m in (('cvivit', cv), ('maskgit', mg), ('critic', cr)):
+            out[f'{tag}.{kind}'] = {k: [list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()}
+    with open(os.path.join(OUT, 'state_dict_keys.json'), 'w') as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print('state_dict_keys.json written')
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    R = ref_shim.load()
+    torch.set_num_threads(os.cpu_count())
+    which = sys.argv[1:] or ['tiny', 'full']
+    if 'keys' in which or 'tiny' in which:
+        keys_golden(R)
+    if 'tiny' in which:
+        cvivit_golden(R, TINY, batch=2, frames=5, tag='tiny', subsample=False)
+        maskgit_golden(R, TINY, batch=2, frames=5, ctx_len=7, tag='tiny', col_stride=1)
+        sample_golden(R, TINY, batch=2, frames_list=[5], prime_len=0, ctx_len=6, tag='tiny', keep_logits=True)
+        sample_golden(R, TINY, batch=2, frames_list=[5], prime_len=0, ctx_len=6, tag='tiny_nocritic', keep_logits=True,
+                      with_critic=False)
+        sample_golden(R, TINY, batch=1, frames_list=[5, 4], prime_len=3, ctx_len=5, tag='tiny_primed', keep_logits=True)
+    if 'full' in which:
+        cvivit_golden(R, FULL, batch=2, frames=17, tag='full', subsample=True)
+        maskgit_golden(R, FULL, batch=1, frames=17, ctx_len=12, tag='full', col_stride=512)
+        sample_golden(R, FULL, batch=1, frames_list=[17], prime_len=0, ctx_len=12, tag='full', keep_logits=False)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,402 @@
+"""CPU oracle: a functional, plain-torch fp32 restatement of the reference hot path.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py) -- the product never imports this.
+
+Every function takes a flat ``state_dict`` (the reference's own key names) plus a key
+prefix and re-derives the arithmetic of the cited reference lines.  All paths are
+/root/reference/phenaki_pytorch/<file>:<line>.  Parity is pinned by
+tests/test_oracle_golden.py against tests/golden/*.pt, which oracle/make_golden.py
+produced by running the real reference.
+"""
+import math
+import torch
+import torch.nn.functional as F
+
+NEG_MAX = -torch.finfo(torch.float32).max
+
+
+# --------------------------------------------------------------------------- blocks
+
+def gamma_layernorm(sd, p, x):
+    """attention.py:29-36  LayerNorm with learned gamma and a zero ``beta`` buffer."""
+    return F.layer_norm(x, x.shape[-1:], sd[p + 'gamma'], sd[p + 'beta'])
+
+
+def feedforward(sd, p, x):
+    """attention.py:40-53  nn.LayerNorm -> Linear(d, 2*inner, no bias) -> x*gelu(gate) -> Linear(inner, d)."""
+    h = F.layer_norm(x, x.shape[-1:], sd[p + '0.weight'], sd[p + '0.bias'])
+    h = h @ sd[p + '1.weight'].t()
+    val, gate = h.chunk(2, dim=-1)
+    h = F.gelu(gate) * val
+    return h @ sd[p + '4.weight'].t()
+
+
+def peg(sd, p, x, shape, causal):
+    """attention.py:57-85.  ``x`` (N, n, d) is reinterpreted -- raw memory order -- as
+    (*shape, d) (line 73); depthwise 3x3x3 conv with zero padding, time pad (2,0) if causal
+    else (1,1); result reshaped back to x's shape (line 85)."""
+    orig = x.shape
+    v = x.reshape(*shape, -1).permute(0, 4, 1, 2, 3)
+    tpad = (2, 0) if causal else (1, 1)
+    v = F.pad(v, (1, 1, 1, 1, *tpad), value=0.)
+    v = F.conv3d(v, sd[p + 'dsconv.weight'], sd[p + 'dsconv.bias'], groups=v.shape[1])
+    return v.permute(0, 2, 3, 4, 1).reshape(orig)
+
+
+def alibi_slopes(heads):
+    """attention.py:205-216"""
+    def pow2(n):
+        start = 2 ** (-2 ** -(math.log2(n) - 3))
+        return [start * start ** i for i in range(n)]
+    if math.log2(heads).is_integer():
+        return pow2(heads)
+    c = 2 ** math.floor(math.log2(heads))
+    return pow2(c) + pow2(2 * c)[0::2][:heads - c]
+
+
+def alibi_bias(heads, i, j):
+    """attention.py:198-227: bias[h, a, b] = -|b - (j - i + a)| * slope_h."""
+    ia = torch.arange(j - i, j)
+    ja = torch.arange(j)
+    bias = -(ja[None, None, :] - ia[None, :, None]).abs()
+    return bias * torch.tensor(alibi_slopes(heads))[:, None, None]
+
+
+def attention(sd, p, x, *, heads, causal=False, mask=None, context=None, attn_bias=None, scale=8):
+    """attention.py:128-182, including its quirks: K/V of self-attention come from the
+    UN-normalised x (lines 140-144); null-kv rows are interleaved k,v,k,v (line 148);
+    l2norm of k happens after the null-k concat (line 153)."""
+    b = x.shape[0]
+    if context is not None:
+        context = gamma_layernorm(sd, p + 'context_norm.', context)
+    kv_in = context if context is not None else x
+    xn = gamma_layernorm(sd, p + 'norm.', x)
+    q = xn @ sd[p + 'to_q.weight'].t()
+    k, v = (kv_in @ sd[p + 'to_kv.weight'].t()).chunk(2, dim=-1)
+
+    def split(t):
+        return t.reshape(t.shape[0], t.shape[1], heads, -1).permute(0, 2, 1, 3)
+    q, k, v = split(q), split(k), split(v)
+
+    null_kv = sd[p + 'null_kv']                       # (h, 2*nn, dh)
+    nnull = null_kv.shape[1] // 2
+    nk = null_kv[:, 0::2].unsqueeze(0).expand(b, -1, -1, -1)
+    nv = null_kv[:, 1::2].unsqueeze(0).expand(b, -1, -1, -1)
+    k = torch.cat((nk, k), dim=-2)
+    v = torch.cat((nv, v), dim=-2)
+
+    q = F.normalize(q, dim=-1) * sd[p + 'q_scale']
+    k = F.normalize(k, dim=-1) * sd[p + 'k_scale']
+    sim = torch.einsum('bhid,bhjd->bhij', q, k) * scale
+    i, j = sim.shape[-2:]
+    if attn_bias is not None:
+        sim = sim + F.pad(attn_bias, (nnull, 0), value=0.)
+    if mask is not None:
+        m = F.pad(mask, (nnull, 0), value=True)
+        sim = sim.masked_fill(~m[:, None, None, :], NEG_MAX)
+    if causal:
+        sim = sim + alibi_bias(heads, i, j)
+        cm = torch.ones((i, j), dtype=torch.bool).triu(j - i + 1)
+        sim = sim.masked_fill(cm, NEG_MAX)
+    attn = sim.softmax(dim=-1)
+    out = torch.einsum('bhij,bhjd->bhid', attn, v)
+    out = out.permute(0, 2, 1, 3).reshape(b, i, -1)
+    return out @ sd[p + 'to_out.weight'].t()
+
+
+def continuous_position_bias(sd, p, dims, nlayers=2):
+    """attention.py:229-275 -> (heads, n, n)."""
+    pos = [torch.arange(d) for d in dims]
+    grid = torch.stack(torch.meshgrid(*pos, indexing='ij')).reshape(len(dims), -1).t()
+    rel = grid[:, None, :] - grid[None, :, :]
+    rel = torch.sign(rel) * torch.log(rel.abs() + 1)
+    h = rel.float()
+    for l in range(nlayers):
+        h = F.leaky_relu(h @ sd[f'{p}net.{l}.0.weight'].t() + sd[f'{p}net.{l}.0.bias'], 0.1)
+    h = h @ sd[f'{p}net.{nlayers}.weight'].t() + sd[f'{p}net.{nlayers}.bias']
+    return h.permute(2, 0, 1)
+
+
+def transformer(sd, p, x, *, depth, heads, causal=False, peg_on=False, peg_causal=False,
+                cross=False, video_shape=None, attn_bias=None, context=None,
+                self_attn_mask=None, cross_attn_context_mask=None):
+    """attention.py:311-332"""
+    for l in range(depth):
+        lp = f'{p}layers.{l}.'
+        if peg_on:
+            x = peg(sd, lp + '0.', x, video_shape, peg_causal) + x
+        x = attention(sd, lp + '1.', x, heads=heads, causal=causal, attn_bias=attn_bias, mask=self_attn_mask) + x
+        if cross and context is not None:
+            x = attention(sd, lp + '2.', x, heads=heads, context=context, mask=cross_attn_context_mask) + x
+        x = feedforward(sd, lp + '3.', x) + x
+    return gamma_layernorm(sd, p + 'norm_out.', x)
+
+
+# --------------------------------------------------------------------------- C-ViViT
+
+def cvivit_patch_embed(sd, cfg, video):
+    """cvivit.py:273-285, 542-549: (B,C,F,H,W) -> (B,T',H',W',dim); feature order (c pt p1 p2)."""
+    ph, pw = cfg['patch_size']
+    pt = cfg['temporal_patch_size']
+    b, c, f, H, W = video.shape
+    h, w = H // ph, W // pw
+
+    def emb(frames, tp, p):
+        t = frames.shape[2] // tp
+        pat = frames.reshape(b, c, t, tp, h, ph, w, pw).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(b, t, h, w, -1)
+        pat = F.layer_norm(pat, pat.shape[-1:], sd[p + '1.weight'], sd[p + '1.bias'])
+        pat = pat @ sd[p + '2.weight'].t() + sd[p + '2.bias']
+        return F.layer_norm(pat, pat.shape[-1:], sd[p + '3.weight'], sd[p + '3.bias'])
+
+    first = emb(video[:, :, :1], 1, 'to_patch_emb_first_frame.')
+    if f == 1:
+        return first
+    rest = emb(video[:, :, 1:], pt, 'to_patch_emb.')
+    return torch.cat((first, rest), dim=1)
+
+
+def _spatial(sd, cfg, p, tokens):
+    b, t, h, w, d = tokens.shape
+    bias = continuous_position_bias(sd, 'spatial_rel_pos_bias.', (h, w))
+    x = tokens.reshape(b * t, h * w, d)
+    x = transformer(sd, p, x, depth=cfg['spatial_depth'], heads=cfg['heads'], attn_bias=bias,
+                    video_shape=(b, t, h, w))
+    return x.reshape(b, t, h, w, d)
+
+
+def _temporal(sd, cfg, p, tokens):
+    b, t, h, w, d = tokens.shape
+    x = tokens.permute(0, 2, 3, 1, 4).reshape(b * h * w, t, d)
+    # NOTE the reference passes video_shape=(b,t,h,w) although x is ((b h w), t, d)
+    # (cvivit.py:456,468-470) -> the PEG sees a scrambled view; peg() reproduces it by
+    # reinterpreting the contiguous buffer.
+    x = transformer(sd, p, x.contiguous(), depth=cfg['temporal_depth'], heads=cfg['heads'], causal=True,
+                    peg_on=True, peg_causal=True, video_shape=(b, t, h, w))
+    return x.reshape(b, h, w, t, d).permute(0, 3, 1, 2, 4)
+
+
+def cvivit_encode(sd, cfg, tokens):
+    """cvivit.py:449-474 spatial then temporal."""
+    tokens = _spatial(sd, cfg, 'enc_spatial_transformer.', tokens)
+    return _temporal(sd, cfg, 'enc_temporal_transformer.', tokens)
+
+
+def lfq_project(sd, x):
+    """pre-sign projection of the LFQ (oracle/lfq.py); exposed for the margin audit."""
+    return x @ sd['vq.project_in.weight'].t() + sd['vq.project_in.bias']
+
+
+def lfq_ids(proj):
+    cd = proj.shape[-1]
+    mask = 2 ** torch.arange(cd - 1, -1, -1)
+    return ((proj > 0).long() * mask).sum(-1)
+
+
+def lfq_codes(sd, ids):
+    cd = sd['vq.project_in.weight'].shape[0]
+    mask = 2 ** torch.arange(cd - 1, -1, -1)
+    bits = ((ids[..., None] & mask) != 0).float()
+    return (bits * 2 - 1) @ sd['vq.project_out.weight'].t() + sd['vq.project_out.bias']
+
+
+def cvivit_tokenize(sd, cfg, video, return_proj=False):
+    """cvivit.py:518-574 with return_only_codebook_ids=True -> ids (B,T',H',W') int64."""
+    tokens = cvivit_patch_embed(sd, cfg, video)
+    tokens = cvivit_encode(sd, cfg, tokens)
+    b, t, h, w, d = tokens.shape
+    proj = lfq_project(sd, tokens.reshape(b, t * h * w, d))
+    ids = lfq_ids(proj).reshape(b, t, h, w)
+    return (ids, proj) if return_proj else ids
+
+
+def cvivit_decode(sd, cfg, tokens):
+    """cvivit.py:476-516 temporal then spatial, then to_pixels (un-patchify (c pt p1 p2))."""
+    ph, pw = cfg['patch_size']
+    pt = cfg['temporal_patch_size']
+    H, W = cfg['image_size']
+    h, w = H // ph, W // pw
+    if tokens.ndim == 3:
+        tokens = tokens.reshape(tokens.shape[0], -1, h, w, tokens.shape[-1])
+    b = tokens.shape[0]
+    tokens = _temporal(sd, cfg, 'dec_temporal_transformer.', tokens)
+    tokens = _spatial(sd, cfg, 'dec_spatial_transformer.', tokens)
+    c = cfg.get('channels', 3)
+    first = tokens[:, :1] @ sd['to_pixels_first_frame.0.weight'].t() + sd['to_pixels_first_frame.0.bias']
+    first = first.reshape(b, 1, h, w, c, 1, ph, pw).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(b, c, 1, H, W)
+    if tokens.shape[1] == 1:
+        return first
+    rest = tokens[:, 1:] @ sd['to_pixels.0.weight'].t() + sd['to_pixels.0.bias']
+    t = rest.shape[1]
+    rest = rest.reshape(b, t, h, w, c, pt, ph, pw).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(b, c, t * pt, H, W)
+    return torch.cat((first, rest), dim=2)
+
+
+def cvivit_decode_ids(sd, cfg, ids):
+    """cvivit.py:437-443 (LFQ branch)."""
+    return cvivit_decode(sd, cfg, lfq_codes(sd, ids))
+
+
+# --------------------------------------------------------------------------- MaskGit / critic
+
+def maskgit_embed(sd, ids):
+    n = ids.shape[1]
+    return sd['token_emb.weight'][ids] + sd['pos_emb.weight'][:n]
+
+
+def maskgit_forward(sd, cfg, ids, *, video_patch_shape, context=None, text_mask=None,
+                    video_mask=None, null_cond=False, return_embeds=False):
+    """phenaki_pytorch.py:163-213.  ``null_cond`` = cond_drop_prob 1.0 -> keep mask all False
+    (prob_mask_like(.., 0) -> zeros, lines 188-190)."""
+    b, n = ids.shape
+    if text_mask is None:
+        text_mask = torch.ones((b, n), dtype=torch.bool)
+    bias = continuous_position_bias(sd, 'continuous_pos_bias.', tuple(video_patch_shape))
+    if null_cond:
+        text_mask = torch.zeros_like(text_mask)
+    x = maskgit_embed(sd, ids)
+    x = transformer(sd, 'transformer.', x, depth=cfg['depth'], heads=cfg['heads'], peg_on=True,
+                    cross=not cfg.get('unconditional', False), video_shape=(b, *video_patch_shape),
+                    attn_bias=bias, context=context, self_attn_mask=video_mask,
+                    cross_attn_context_mask=text_mask)
+    if return_embeds:
+        return x
+    return x @ sd['to_logits.weight'].t() + sd['to_logits.bias']
+
+
+def maskgit_cfg(sd, cfg, ids, *, cond_scale, **kw):
+    """phenaki_pytorch.py:149-161"""
+    logits = maskgit_forward(sd, cfg, ids, null_cond=False, **kw)
+    if cond_scale == 1:
+        return logits
+    null = maskgit_forward(sd, cfg, ids, null_cond=True, **kw)
+    return null + (logits - null) * cond_scale
+
+
+def critic_forward(sd, cfg, ids, *, video_patch_shape, context=None, text_mask=None,
+                   video_mask=None, null_cond=False):
+    """phenaki_pytorch.py:265-302 (no CPB bias, no grad shrink; head Linear(dim,1))."""
+    b, n = ids.shape
+    if text_mask is None:
+        text_mask = torch.ones((b, n), dtype=torch.bool)
+    if context is not None and null_cond:
+        text_mask = torch.zeros_like(text_mask)
+    x = maskgit_embed(sd, ids)
+    x = transformer(sd, 'transformer.', x, depth=cfg['depth'], heads=cfg['heads'], peg_on=True,
+                    cross=cfg.get('has_cross_attn', False), video_shape=(b, *video_patch_shape),
+                    context=context, self_attn_mask=video_mask, cross_attn_context_mask=text_mask)
+    return (x @ sd['to_logits.0.weight'].t() + sd['to_logits.0.bias']).squeeze(-1)
+
+
+def critic_cfg(sd, cfg, ids, *, cond_scale, **kw):
+    """phenaki_pytorch.py:251-263"""
+    s = critic_forward(sd, cfg, ids, null_cond=False, **kw)
+    if cond_scale == 1:
+        return s
+    n = critic_forward(sd, cfg, ids, null_cond=True, **kw)
+    return n + (s - n) * cond_scale
+
+
+# --------------------------------------------------------------------------- sampling
+
+def mask_schedule(num_tokens, steps):
+    """phenaki_pytorch.py:484-486: k_s = round(n * cos(pi/2 * s/steps)).clamp(1), fp32, for s=1..steps-1."""
+    ks = [None]
+    for s in range(1, steps):
+        time = torch.full((1,), s / steps)
+        ks.append(int((num_tokens * torch.cos(time * math.pi * 0.5)).round().long().clamp(min=1).item()))
+    return ks
+
+
+def gumbel_argmax(logits, temperature, u):
+    """phenaki_pytorch.py:78-93 with the uniform noise ``u`` injected."""
+    g = -torch.log(-torch.log(u + 1e-10) + 1e-10)
+    return (logits / max(temperature, 1e-10) + g).argmax(dim=-1)
+
+
+def sample_step(mg, mg_cfg, cr, cr_cfg, *, step, steps, ids, mask, scores, prime_ids, patch_shape, context,
+                text_mask, cond_scale, starting_temperature, noise_K, anneal, gumbel_u, critic_u, mask_id,
+                return_logits=False):
+    """one iteration of the loop at phenaki_pytorch.py:478-550 (teacher-forceable)."""
+    b, n = ids.shape
+    out = {}
+    if step > 0 and scores is not None:
+        k = mask_schedule(n, steps)[step]
+        idx = scores.topk(k, dim=-1).indices
+        mask = torch.zeros((b, n)).scatter(1, idx, 1).bool()
+    ids = torch.where(mask, mask_id, ids)
+    out['masked_ids'], out['mask'] = ids.clone(), mask.clone()
+    inp = ids if prime_ids is None else torch.cat((prime_ids, ids), dim=-1)
+    logits = maskgit_cfg(mg, mg_cfg, inp, cond_scale=cond_scale, video_patch_shape=patch_shape,
+                         context=context, text_mask=text_mask)
+    if prime_ids is not None:
+        logits = logits[:, prime_ids.shape[1]:]
+    til = steps - (step + 1)
+    temperature = starting_temperature * (til / steps)
+    pred = gumbel_argmax(logits, temperature, gumbel_u)
+    ids = torch.where(mask, pred, ids)
+    out['pred'], out['ids'] = pred, ids
+    if return_logits:
+        out['logits'] = logits
+    new_scores = None
+    if step != steps - 1:
+        if cr is not None:
+            cin = ids if prime_ids is None else torch.cat((prime_ids, ids), dim=-1)
+            sc = critic_cfg(cr, cr_cfg, cin, cond_scale=cond_scale, video_patch_shape=patch_shape,
+                            context=context, text_mask=text_mask)
+            if prime_ids is not None:
+                sc = sc[:, prime_ids.shape[1]:]
+            mult = {'fixed': 1., 'decay': til / steps, 'increase': (step + 1) / steps}[anneal]
+            new_scores = sc + noise_K * (critic_u - 0.5) * mult
+        else:
+            probs = logits.softmax(dim=-1)
+            sc = 1 - probs.gather(2, pred[..., None]).squeeze(-1)
+            new_scores = torch.where(mask, sc, -1e4)
+    out['scores'] = new_scores
+    return out
+
+
+def sample(cv, cv_cfg, mg, mg_cfg, cr, cr_cfg, *, num_frames, batch_size, context=None, prime_frames=None,
+           steps=18, cond_scale=3., starting_temperature=0.9, noise_K=1., anneal='decay',
+           noise_fn=None, trace=None):
+    """phenaki_pytorch.py:418-560.  ``noise_fn(kind, step, shape)`` supplies U[0,1) noise
+    ('gumbel' (B,n,V) and 'critic' (B,n)); ``trace`` (a list) receives every step's record."""
+    prime_ids = None
+    prime_frames_n = 0
+    if prime_frames is not None:
+        prime_ids = cvivit_tokenize(cv, cv_cfg, prime_frames).flatten(1)
+        prime_frames_n = prime_frames.shape[2]
+    H, W = cv_cfg['image_size']
+    ph, pw = cv_cfg['patch_size']
+    per = (H // ph) * (W // pw)
+    pt = cv_cfg['temporal_patch_size']
+    if prime_frames is None:
+        n = per + (num_frames - 1) // pt * per
+        assert (num_frames - 1) % pt == 0
+    else:
+        assert num_frames % pt == 0
+        n = num_frames // pt * per
+    text_mask = None
+    if context is not None:
+        text_mask = (context != 0).any(dim=-1)
+    tot = num_frames + prime_frames_n
+    patch_shape = (1 + (tot - 1) // pt, H // ph, W // pw)
+    mask_id = mg_cfg['num_tokens']
+    ids = torch.full((batch_size, n), mask_id)
+    mask = torch.ones((batch_size, n), dtype=torch.bool)
+    scores = None
+    V = mg_cfg['num_tokens']
+    for step in range(steps):
+        gu = noise_fn('gumbel', step, (batch_size, n, V))
+        cu = noise_fn('critic', step, (batch_size, n)) if (cr is not None and step != steps - 1) else None
+        rec = sample_step(mg, mg_cfg, cr, cr_cfg, step=step, steps=steps, ids=ids, mask=mask, scores=scores,
+                          prime_ids=prime_ids, patch_shape=patch_shape, context=context, text_mask=text_mask,
+                          cond_scale=cond_scale, starting_temperature=starting_temperature, noise_K=noise_K,
+                          anneal=anneal, gumbel_u=gu, critic_u=cu, mask_id=mask_id)
+        ids, mask, scores = rec['ids'], rec['mask'], rec['scores']
+        if trace is not None:
+            trace.append(rec)
+    full = ids if prime_ids is None else torch.cat((prime_ids, ids), dim=-1)
+    video = cvivit_decode_ids(cv, cv_cfg, full)
+    if prime_frames is not None:
+        video = video[:, :, prime_frames_n:]
+    return video, ids

@@ -1,0 +1,96 @@
+"""Pins oracle/phenaki_oracle.py (the CPU restatement) to golden vectors minted from the REAL
+reference by oracle/make_golden.py.  CPU only."""
+import os
+
+import pytest
+import torch
+
+from oracle import phenaki_oracle as O
+from oracle import weights
+from oracle.configs import TINY, FULL, oracle_cfgs, state_dicts
+
+torch.set_grad_enabled(False)
+
+
+def load(golden_dir, name):
+    path = os.path.join(golden_dir, name)
+    if not os.path.exists(path):
+        pytest.skip(f'{name} not generated')
+    return torch.load(path, weights_only=False)
+
+
+def close(a, b, rtol=1e-4):
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item()
+    assert err <= rtol * scale, f'max err {err:.3e} vs scale {scale:.3e}'
+
+
+@pytest.mark.parametrize('tag,cfgs,batch,frames', [('tiny', TINY, 2, 5)])
+def test_cvivit_matches_reference(golden_dir, tag, cfgs, batch, frames):
+    g = load(golden_dir, f'cvivit_{tag}.pt')
+    cv, _, _ = state_dicts(tag)
+    cvc, _, _ = oracle_cfgs(cfgs)
+    H = cfgs['cvivit']['image_size']
+    video = weights.synthetic_video(batch, frames, H, H, seed=0)
+    tok = O.cvivit_patch_embed(cv, cvc, video)
+    close(tok, g['patch_tokens'])
+    enc = O.cvivit_encode(cv, cvc, tok)
+    close(enc, g['enc_tokens'])
+    ids, proj = O.cvivit_tokenize(cv, cvc, video, return_proj=True)
+    close(proj, g['proj'])
+    assert torch.equal(ids, g['ids'])
+    rec = O.cvivit_decode_ids(cv, cvc, ids.flatten(1))
+    close(rec, g['recon'])
+
+
+def test_maskgit_and_critic_match_reference(golden_dir):
+    g = load(golden_dir, 'maskgit_tiny.pt')
+    _, mg, cr = state_dicts('tiny')
+    _, mgc, crc = oracle_cfgs(TINY)
+    ids = g['ids']
+    ctx = weights.synthetic_context(ids.shape[0], g['ctx_len'], TINY['maskgit']['dim_context'], seed=1, pad_last=3)
+    tm = (ctx != 0).any(-1)
+    kw = dict(video_patch_shape=g['patch_shape'], context=ctx, text_mask=tm)
+    close(O.maskgit_forward(mg, mgc, ids, **kw), g['cond'])
+    close(O.maskgit_forward(mg, mgc, ids, null_cond=True, **kw), g['null'])
+    cfg = O.maskgit_cfg(mg, mgc, ids, cond_scale=5., **kw)
+    close(cfg, g['cfg'])
+    assert torch.equal(cfg.argmax(-1), g['cfg_argmax'])
+    close(O.critic_cfg(cr, crc, ids, cond_scale=5., **kw), g['critic_cfg'])
+    close(O.critic_forward(cr, crc, ids, **kw), g['critic_cond'])
+    bias = O.continuous_position_bias(mg, 'continuous_pos_bias.', g['patch_shape'])
+    close(bias[:, ::7, ::5], g['bias_sub'])
+
+
+def _noise_fn(base, scene):
+    def fn(kind, step, shape):
+        return weights.uniform_noise(tuple(shape), base + 100 * scene + 2 * step + (1 if kind == 'critic' else 0))
+    return fn
+
+
+@pytest.mark.parametrize('tag,with_critic', [('tiny', True), ('tiny_nocritic', False), ('tiny_primed', True)])
+def test_sample_matches_reference_free_running(golden_dir, tag, with_critic):
+    """tiny configs are robust enough that the free-running loop reproduces every step's ids."""
+    g = load(golden_dir, f'sample_{tag}.pt')
+    cv, mg, cr = state_dicts('tiny')
+    cvc, mgc, crc = oracle_cfgs(TINY)
+    if not with_critic:
+        cr = None
+    batch = g['batch']
+    ctx = weights.synthetic_context(batch, g['ctx_len'], TINY['maskgit']['dim_context'], seed=2)
+    prime = None
+    for scene, nf in enumerate(g['frames_list']):
+        trace = []
+        video, ids = O.sample(cv, cvc, mg, mgc, cr, crc, num_frames=nf, batch_size=batch, context=ctx,
+                              prime_frames=prime, steps=TINY['steps'], cond_scale=5.,
+                              noise_fn=_noise_fn(500, scene), trace=trace)
+        recs = [s for s in g['steps'] if s['scene'] == scene]
+        assert len(recs) == len(trace)
+        for r, t in zip(recs, trace):
+            npr = r['mg_input'].shape[1] - t['masked_ids'].shape[1]
+            assert torch.equal(r['mg_input'][:, npr:], t['masked_ids']), f"step {r['step']} input ids differ"
+            assert torch.equal(r['pred'], t['pred']), f"step {r['step']} pred differs"
+            if 'critic_input' in r:
+                assert torch.equal(r['critic_input'][:, npr:], t['ids'])
+        close(video, g['videos'][scene])
+        prime = video[:, :, -g['prime_len']:] if g['prime_len'] else None
