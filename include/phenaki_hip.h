@@ -1,0 +1,120 @@
+/* phenaki_hip.h -- C ABI of libphenaki_hip.so, the MI355X (gfx950) kernels behind the Phenaki hot path.
+ *
+ * The reference (lucidrains/phenaki-pytorch) has no FFI: its boundary is the Python nn.Module surface
+ * (CViViT / MaskGit / TokenCritic / Phenaki).  This library is what those modules' forward passes bind
+ * in the MI355X build (phenaki_pytorch_amd/_lib.py, ctypes); every entry point names the reference
+ * expression it replaces (paths relative to /root/reference/phenaki_pytorch/).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers owned by the caller; kernels never allocate or free;
+ *   - `stream` is a hipStream_t (0 = default stream); every call is asynchronous on it, no hidden syncs;
+ *   - return value: 0 on success, negative on error (no exceptions cross this boundary):
+ *       PK_EINVAL (-1) bad shape/size/flag, PK_EALIGN (-2) pointer/stride alignment, PK_ELAUNCH (-3) HIP launch error;
+ *   - `dtype`: 0 = exact f32 (f32 MFMA, bit-for-bit an fmaf chain), 1 = bf16 MFMA inputs with f32 accumulation.
+ *     "T" below means float for dtype 0 and bf16 (uint16 storage, round-to-nearest-even) for dtype 1;
+ *   - activations in HBM are f32 unless a parameter says T; rows are row-major with an explicit leading
+ *     dimension (ld*, in elements);
+ *   - dim_head is fixed at 64 in the attention kernels.
+ */
+#ifndef PHENAKI_HIP_H
+#define PHENAKI_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PK_OK 0
+#define PK_EINVAL (-1)
+#define PK_EALIGN (-2)
+#define PK_ELAUNCH (-3)
+
+/* C = act(A @ W^T + bias) (+ res).  Replaces every nn.Linear on the path: attention.py:50-52 (FeedForward,
+ * act 1 = GEGLU on interleaved (value, gate) column pairs -> C is [M][N/2]), attention.py:117-119 (to_q/to_kv/to_out),
+ * attention.py:243-252 (CPB MLP, act 2 = LeakyReLU(0.1)), cvivit.py:276,283 (patch embed), cvivit.py:328,333
+ * (to_pixels), phenaki_pytorch.py:147 (to_logits).
+ * A [M][lda] is f32 (a_is_f32) or T; W [N][ldw] is T; bias [N] f32 or NULL; res [M][ldr] f32 or NULL;
+ * C is f32 (out_is_f32) or T; a_rows (or NULL) gathers A rows: logical row m reads A[a_rows[m]]. */
+int pk_gemm(int dtype, int a_is_f32, const void* A, int lda, const void* W, int ldw, int M, int N, int K,
+            const float* bias, const float* res, int ldr, void* C, int ldc, int out_is_f32, int act,
+            const int* a_rows, void* stream);
+
+/* y = LayerNorm(x) * gamma (+ beta), eps inside the sqrt, biased variance.  attention.py:29-36 (gamma-only
+ * LayerNorm, beta NULL or the zero buffer), attention.py:47 and cvivit.py:277,284 (nn.LayerNorm).
+ * out (T if out_kind == 1 else f32) and/or out2 (f32) receive y.  grp > 0 remaps OUTPUT rows
+ * r -> (r / grp) * gstride + goff + r % grp  (the first-frame / rest-frames concat of cvivit.py:549). */
+int pk_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps, void* out, int ldo,
+                 int out_kind, float* out2, int ldo2, int M, int D, int grp, int gstride, int goff, void* stream);
+
+/* cvivit.py:273-285: Rearrange 'b c (t pt) (h p1) (w p2) -> b t h w (c pt p1 p2)' of frames [f0, f0 + nt*pt) of the
+ * (B,C,F,H,W) f32 video, fused with nn.LayerNorm(P), P = C*pt*ph*pw; out[(b,t,h,w)][P] is T (out_kind 1) or f32. */
+int pk_patchify_ln(const float* video, int B, int C, int F, int H, int W, int f0, int nt, int pt, int ph, int pw,
+                   const float* weight, const float* bias, float eps, void* out, int ldo, int out_kind, void* stream);
+
+/* cvivit.py:326-334: Rearrange 'b t h w (c pt p1 p2) -> b c (t pt) (h p1) (w p2)' into frames [f0, f0 + nt*pt). */
+int pk_unpatchify(const float* pix, int ldp, float* video, int B, int C, int F, int H, int W, int f0, int nt,
+                  int pt, int ph, int pw, void* stream);
+
+/* attention.py:57-85 + residual of attention.py:323: out = x + bias + depthwise_conv3d_3x3x3(zero-padded x) on the
+ * channels-last (B,T,H,W,D) reinterpretation of the token buffer; time pad (2,0) if causal else (1,1).
+ * wt is dsconv.weight (D,1,3,3,3) pre-transposed to [27][D].  Not in-place. */
+int pk_peg(const float* x, const float* wt, const float* bias, float* out, int B, int T, int H, int W, int D,
+           int causal, void* stream);
+
+/* LFQ (vector-quantize-pytorch, un-vendored; call sites cvivit.py:570 and :439; restated in oracle/lfq.py).
+ * encode: proj = x @ Wp^T + bp (f32), ids = sum_k (proj_k > 0) << (cd-1-k); proj (M x cd) optional output.
+ * decode: out = (bit ? +1 : -1) @ Wo^T + bo,  Wo is [D][cd]. */
+int pk_lfq_encode(const float* x, int ldx, const float* wp, const float* bp, long long* ids, float* proj,
+                  int M, int D, int cd, void* stream);
+int pk_lfq_decode(const long long* ids, const float* wo, const float* bo, float* out, int M, int D, int cd, void* stream);
+
+/* phenaki_pytorch.py:194-197, 290-291: out[r] = token_emb[ids[r]] + pos_emb[r % n]. */
+int pk_embed(const long long* ids, const float* tok, const float* pos, float* out, int rows, int n, int D, void* stream);
+
+/* attention.py:257-272 first CPB layer: out[(i,j)][D] = leaky_relu(W0 @ (sign(rel) log(|rel|+1)) + b0, 0.1) over the
+ * flattened (d0,d1,d2) grid; nd = 2 uses (d1,d2) with d0 = 1. */
+int pk_cpb_input(const float* w0, const float* b0, float* out, int d0, int d1, int d2, int nd, int D, void* stream);
+
+/* attention.py:146-157: head split, null-kv prepend, l2norm (k after the concat), q/k scales, sim scale folded in q;
+ * writes Qp [S][h][nq_pad][64], Kp [S][h][nk_pad][64], Vt [S][h][64][nk_pad] in T. pk_attn_pads gives the pads.
+ * kv == NULL prepares the query side only (cross-attention K/V cached across sampling steps). */
+int pk_attn_pads(int nq, int n_kv, int nnull, int* nq_pad, int* nk_pad);
+int pk_attn_prep(int dtype, const float* q, int ldq, const float* kv, int ldkv, const float* null_kv,
+                 const float* q_scale, const float* k_scale, float scale, void* Qp, void* Kp, void* Vt,
+                 int S, int h, int nq, int n_kv, int nnull, void* stream);
+
+/* attention.py:157-182: softmax(sim + bias (+ key mask, + ALiBi, causal)) @ v, heads merged: O[(s,i)][hh*64 + d].
+ * bias[hh][i][j] is over the real (non-null) keys; kmask [S][n_kv] uint8 (1 = keep); slopes [h] with causal. */
+int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void* Vt, const float* bias, long bias_hstride,
+                int bias_ld, const unsigned char* kmask, const float* slopes, int causal, void* O, int ldo,
+                int out_is_f32, int S, int h, int nq, int n_kv, int nnull, void* stream);
+
+/* phenaki_pytorch.py:155-161 applied to the trunk outputs: e = null + (cond - null) * scale for the non-prime
+ * positions; x rows are [cond sequences | null sequences] of n_tot tokens; rows (or NULL) selects output rows
+ * (flat b * (n_tot - n_prime) + i). */
+int pk_cfg_mix(const float* x, int ldx, int nb, int n_tot, int n_prime, const int* rows, int nrows, float scale,
+               int has_null, void* out, int ldo, int out_is_f32, int D, void* stream);
+
+/* phenaki_pytorch.py:213 + 88-93 + 506-509 + 547-550, never materialising logits: per row
+ * pred = argmax(logits / max(T,1e-10) + gumbel(U)), optional (max, sum exp) for 1 - softmax[pred].
+ * U != NULL: PARITY mode, uniform noise read from U[row][V]; U == NULL: counter-hash noise from `seed`.
+ * partials: 5 * pk_vocab_ntiles(V) * M 4-byte words of workspace consumed by pk_vocab_reduce, which writes
+ * pred[r], ids[r] = where(mask[r], pred, ids[r]) and scores[r] = where(mask[r], 1 - p, -1e4). */
+int pk_vocab_ntiles(int V);
+int pk_vocab_sample(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, int M, int V, int D,
+                    float temperature, const float* U, const int* rows, unsigned long long seed, int need_lse,
+                    void* partials, void* stream);
+int pk_vocab_reduce(const void* partials, int M, int V, const int* rows, const unsigned char* mask, long long* ids,
+                    long long* pred, float* scores, int need_lse, void* stream);
+
+/* phenaki_pytorch.py:488-491: mask = zeros.scatter(1, scores.topk(k).indices, 1).bool(); ids = where(mask, mask_id, ids). */
+int pk_topk_mask(const float* scores, int B, int n, int k, long long mask_id, unsigned char* mask, long long* ids,
+                 void* stream);
+
+/* phenaki_pytorch.py:246-263, 523-545: critic head Linear(dim,1) + CFG mix + noise_mult * (u - 0.5), prime dropped. */
+int pk_critic_head(const float* x, int ldx, const float* w, const float* b, int D, int nb, int n_tot, int n_prime,
+                   int has_null, float scale, const float* u, float noise_mult, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,13 @@
+"""phenaki_pytorch_amd -- the Phenaki inference hot path (C-ViViT tokenizer + MaskGIT sampler) on MI355X (gfx950).
+
+Drop-in names of lucidrains/phenaki-pytorch's public interface (phenaki_pytorch/__init__.py:1-4) for the
+inference path: same constructor signatures, state_dict keys and .forward/.encode/.decode/.sample surfaces;
+the compute is hand-written HIP in libphenaki_hip.so (build: `python -m phenaki_pytorch_amd.build`).
+"""
+from .attention import set_compute_dtype
+from .cvivit import CViViT
+from .phenaki import MaskGit, TokenCritic, SelfCritic, Phenaki, make_video
+from .dist import shard_batch, sample_sharded, make_video_sharded
+
+__all__ = ['CViViT', 'MaskGit', 'TokenCritic', 'SelfCritic', 'Phenaki', 'make_video', 'set_compute_dtype',
+           'shard_batch', 'sample_sharded', 'make_video_sharded']

@@ -1,0 +1,207 @@
+"""ctypes binding of libphenaki_hip.so (include/phenaki_hip.h).
+
+The product has NO CPU fallback: importing this module is harmless, but the first kernel call without the
+built library (python -m phenaki_pytorch_amd.build) or without a HIP device raises.
+PyTorch is used only as the owner of device memory and of the current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libphenaki_hip.so')
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+_L = ctypes.c_long
+_LL = ctypes.c_longlong
+_ULL = ctypes.c_ulonglong
+
+# name -> argtypes, kept in the order of include/phenaki_hip.h (tests check every symbol is exported)
+SIGNATURES = {
+    'pk_gemm': [_I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P],
+    'pk_layernorm': [_P, _I, _P, _P, _F, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    'pk_patchify_ln': [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _I, _I, _P],
+    'pk_unpatchify': [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'pk_peg': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    'pk_lfq_encode': [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P],
+    'pk_lfq_decode': [_P, _P, _P, _P, _I, _I, _I, _P],
+    'pk_embed': [_P, _P, _P, _P, _I, _I, _I, _P],
+    'pk_cpb_input': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'pk_attn_pads': [_I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)],
+    'pk_attn_prep': [_I, _P, _I, _P, _I, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'pk_attn_fwd': [_I, _P, _P, _P, _P, _L, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    'pk_cfg_mix': [_P, _I, _I, _I, _I, _P, _I, _F, _I, _P, _I, _I, _I, _P],
+    'pk_vocab_ntiles': [_I],
+    'pk_vocab_sample': [_I, _P, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P, _ULL, _I, _P, _P],
+    'pk_vocab_reduce': [_P, _I, _I, _P, _P, _P, _P, _P, _I, _P],
+    'pk_topk_mask': [_P, _I, _I, _I, _LL, _P, _P, _P],
+    'pk_critic_head': [_P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P, _F, _P, _P],
+}
+
+_ERR = {-1: 'PK_EINVAL (bad shape/size/flag)', -2: 'PK_EALIGN (pointer/stride alignment)', -3: 'PK_ELAUNCH (HIP launch failed)'}
+
+_lib = None
+
+
+def load():
+    """dlopen the library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f'{LIB_PATH} is missing: run `python -m phenaki_pytorch_amd.build` '
+                               '(the MI355X build has no CPU / eager fallback)')
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = _I
+        _lib = lib
+    return _lib
+
+
+def _check(rc, name):
+    if rc != 0:
+        raise RuntimeError(f'{name} failed: {_ERR.get(rc, rc)}')
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(t, name='tensor'):
+    if not t.is_cuda:
+        raise RuntimeError(f'{name} is on {t.device}: the MI355X build runs on HIP devices only (no CPU fallback)')
+
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GEGLU, ACT_LEAKY = 0, 1, 2
+
+
+def tdtype(dtype):
+    return torch.bfloat16 if dtype == BF16 else torch.float32
+
+
+# ----------------------------------------------------------------------------- wrappers
+
+def gemm(dtype, A, W, M, N, K, *, C, bias=None, res=None, act=ACT_NONE, a_rows=None, lda=None, ldc=None):
+    """C = act(A @ W^T + bias) (+ res).  A: (.., K) f32 or T rows; W: (N, Kpad) T; C preallocated."""
+    a_is_f32 = 1 if A.dtype == torch.float32 else 0
+    out_is_f32 = 1 if C.dtype == torch.float32 else 0
+    lda = A.stride(-2) if lda is None else lda
+    ldc = C.stride(-2) if ldc is None else ldc
+    ldr = res.stride(-2) if res is not None else 0
+    rc = load().pk_gemm(dtype, a_is_f32, ptr(A), lda, ptr(W), W.stride(0), M, N, K, ptr(bias), ptr(res), ldr,
+                        ptr(C), ldc, out_is_f32, act, ptr(a_rows), stream())
+    _check(rc, 'pk_gemm')
+    return C
+
+
+def layernorm(x, gamma, beta, M, D, *, out=None, out2=None, eps=1e-5, remap=(0, 0, 0), ldx=None):
+    out_kind = 1 if (out is not None and out.dtype == torch.bfloat16) else 0
+    rc = load().pk_layernorm(ptr(x), x.stride(-2) if ldx is None else ldx, ptr(gamma), ptr(beta), eps,
+                             ptr(out), out.stride(-2) if out is not None else 0, out_kind,
+                             ptr(out2), out2.stride(-2) if out2 is not None else 0, M, D, *remap, stream())
+    _check(rc, 'pk_layernorm')
+
+
+def patchify_ln(video, f0, nt, pt, ph, pw, weight, bias, out, eps=1e-5):
+    B, C, F, H, W = video.shape
+    rc = load().pk_patchify_ln(ptr(video), B, C, F, H, W, f0, nt, pt, ph, pw, ptr(weight), ptr(bias), eps,
+                               ptr(out), out.stride(0), 1 if out.dtype == torch.bfloat16 else 0, stream())
+    _check(rc, 'pk_patchify_ln')
+
+
+def unpatchify(pix, video, f0, nt, pt, ph, pw):
+    B, C, F, H, W = video.shape
+    rc = load().pk_unpatchify(ptr(pix), pix.stride(0), ptr(video), B, C, F, H, W, f0, nt, pt, ph, pw, stream())
+    _check(rc, 'pk_unpatchify')
+
+
+def peg(x, wt, bias, out, B, T, H, W, D, causal):
+    rc = load().pk_peg(ptr(x), ptr(wt), ptr(bias), ptr(out), B, T, H, W, D, 1 if causal else 0, stream())
+    _check(rc, 'pk_peg')
+
+
+def lfq_encode(x, wp, bp, ids, proj, M, D, cd):
+    rc = load().pk_lfq_encode(ptr(x), x.stride(-2), ptr(wp), ptr(bp), ptr(ids), ptr(proj), M, D, cd, stream())
+    _check(rc, 'pk_lfq_encode')
+
+
+def lfq_decode(ids, wo, bo, out, M, D, cd):
+    rc = load().pk_lfq_decode(ptr(ids), ptr(wo), ptr(bo), ptr(out), M, D, cd, stream())
+    _check(rc, 'pk_lfq_decode')
+
+
+def embed(ids, tok, pos, out, rows, n, D):
+    rc = load().pk_embed(ptr(ids), ptr(tok), ptr(pos), ptr(out), rows, n, D, stream())
+    _check(rc, 'pk_embed')
+
+
+def cpb_input(w0, b0, out, dims, D):
+    nd = len(dims)
+    d = (1,) * (3 - nd) + tuple(dims)
+    rc = load().pk_cpb_input(ptr(w0), ptr(b0), ptr(out), d[0], d[1], d[2], nd, D, stream())
+    _check(rc, 'pk_cpb_input')
+
+
+def attn_pads(nq, n_kv, nnull):
+    a, b = _I(0), _I(0)
+    _check(load().pk_attn_pads(nq, n_kv, nnull, ctypes.byref(a), ctypes.byref(b)), 'pk_attn_pads')
+    return a.value, b.value
+
+
+def attn_prep(dtype, q, kv, null_kv, q_scale, k_scale, scale, Qp, Kp, Vt, S, h, nq, n_kv, nnull):
+    rc = load().pk_attn_prep(dtype, ptr(q), q.stride(-2), ptr(kv), kv.stride(-2) if kv is not None else 0, ptr(null_kv) if nnull else None,
+                             ptr(q_scale), ptr(k_scale), scale, ptr(Qp), ptr(Kp), ptr(Vt), S, h, nq, n_kv, nnull, stream())
+    _check(rc, 'pk_attn_prep')
+
+
+def attn_fwd(dtype, Qp, Kp, Vt, O, S, h, nq, n_kv, nnull, *, bias=None, kmask=None, slopes=None, causal=False):
+    if bias is not None:
+        bh, bld = bias.stride(0), bias.stride(1)
+    else:
+        bh, bld = 0, 0
+    rc = load().pk_attn_fwd(dtype, ptr(Qp), ptr(Kp), ptr(Vt), ptr(bias), bh, bld, ptr(kmask), ptr(slopes),
+                            1 if causal else 0, ptr(O), O.stride(-2), 1 if O.dtype == torch.float32 else 0,
+                            S, h, nq, n_kv, nnull, stream())
+    _check(rc, 'pk_attn_fwd')
+
+
+def cfg_mix(x, nb, n_tot, n_prime, rows, nrows, scale, has_null, out, D):
+    rc = load().pk_cfg_mix(ptr(x), x.stride(-2), nb, n_tot, n_prime, ptr(rows), nrows, scale, 1 if has_null else 0,
+                           ptr(out), out.stride(-2), 1 if out.dtype == torch.float32 else 0, D, stream())
+    _check(rc, 'pk_cfg_mix')
+
+
+def vocab_ntiles(V):
+    return load().pk_vocab_ntiles(V)
+
+
+def vocab_sample(dtype, A, W, bias, M, V, D, temperature, U, rows, seed, need_lse, partials):
+    rc = load().pk_vocab_sample(dtype, ptr(A), A.stride(-2), ptr(W), W.stride(0), ptr(bias), M, V, D, temperature,
+                                ptr(U), ptr(rows), seed & 0xFFFFFFFFFFFFFFFF, 1 if need_lse else 0, ptr(partials), stream())
+    _check(rc, 'pk_vocab_sample')
+
+
+def vocab_reduce(partials, M, V, rows, mask, ids, pred, scores, need_lse):
+    rc = load().pk_vocab_reduce(ptr(partials), M, V, ptr(rows), ptr(mask), ptr(ids), ptr(pred), ptr(scores),
+                                1 if need_lse else 0, stream())
+    _check(rc, 'pk_vocab_reduce')
+
+
+def topk_mask(scores, B, n, k, mask_id, mask, ids):
+    rc = load().pk_topk_mask(ptr(scores), B, n, k, mask_id, ptr(mask), ptr(ids), stream())
+    _check(rc, 'pk_topk_mask')
+
+
+def critic_head(x, w, b, D, nb, n_tot, n_prime, has_null, scale, u, noise_mult, out):
+    rc = load().pk_critic_head(ptr(x), x.stride(-2), ptr(w), ptr(b), D, nb, n_tot, n_prime, 1 if has_null else 0, scale,
+                               ptr(u), noise_mult, ptr(out), stream())
+    _check(rc, 'pk_critic_head')

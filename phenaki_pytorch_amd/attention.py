@@ -1,0 +1,410 @@
+"""Transformer building blocks with the reference's module tree / state_dict keys
+(/root/reference/phenaki_pytorch/attention.py:29-332) whose forward passes run on libphenaki_hip.so.
+
+Every activation that lives in HBM between kernels is a 2-D f32 (rows, dim) buffer; the GEMM / attention
+operands are bf16 (`compute_dtype = 'bf16'`, f32 accumulation) or exact f32 (`'fp32'`).
+There is no eager fallback: tensors must be on a HIP device.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import _lib as L
+
+_DTYPES = {'fp32': L.F32, 'float32': L.F32, 'f32': L.F32, 'bf16': L.BF16, 'bfloat16': L.BF16}
+
+
+def exists(v):
+    return v is not None
+
+
+def default(v, d):
+    return v if exists(v) else d
+
+
+def resolve_dtype(name):
+    if name not in _DTYPES:
+        raise ValueError(f'compute dtype must be one of {sorted(_DTYPES)}, got {name!r}')
+    return _DTYPES[name]
+
+
+def set_compute_dtype(module, name):
+    """'fp32' (exact f32 MFMA; the reference's default precision) or 'bf16' (bf16 MFMA operands, f32 accumulation)."""
+    resolve_dtype(name)
+    for m in module.modules():
+        m._pk_compute_dtype = name
+    return module
+
+
+def compute_dtype_of(module):
+    return resolve_dtype(getattr(module, '_pk_compute_dtype', 'fp32'))
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class PackCache:
+    """device-side packed copies of a module's weights, rebuilt when a source parameter changes."""
+
+    def __init__(self):
+        self.store = {}
+
+    def get(self, key, params, build):
+        stamp = tuple((p.data_ptr(), p._version, p.device) for p in params)
+        hit = self.store.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        with torch.no_grad():
+            val = build()
+        self.store[key] = (stamp, val)
+        return val
+
+
+def _cache(module):
+    c = module.__dict__.get('_pk_cache')
+    if c is None:
+        c = PackCache()
+        module.__dict__['_pk_cache'] = c
+    return c
+
+
+def pack_linear_weight(w, dtype):
+    """(N, K) f32 -> (N, Kpad) T with K zero-padded to the 16-byte quantum of T."""
+    q = 8 if dtype == L.BF16 else 4
+    n, k = w.shape
+    kp = round_up(k, q)
+    out = torch.zeros((n, kp), device=w.device, dtype=L.tdtype(dtype))
+    out[:, :k] = w.detach().to(out.dtype)
+    return out
+
+
+def linear_weight(lin, dtype):
+    return _cache(lin).get(('w', dtype), [lin.weight], lambda: pack_linear_weight(lin.weight, dtype))
+
+
+def f32c(t):
+    return t.detach().float().contiguous()
+
+
+# --------------------------------------------------------------------------- modules
+
+class LayerNorm(nn.Module):
+    """attention.py:29-36 : learned gamma, zero `beta` buffer (persistent -> in the state_dict)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.ones(dim))
+        self.register_buffer('beta', torch.zeros(dim))
+
+    def run(self, x2d, out=None, out2=None):
+        M, D = x2d.shape
+        L.layernorm(x2d, self.gamma, self.beta, M, D, out=out, out2=out2)
+
+    def forward(self, x):
+        L.require_device(x, 'x')
+        x2 = x.reshape(-1, x.shape[-1]).float().contiguous()
+        out = torch.empty_like(x2)
+        self.run(x2, out=out)
+        return out.reshape(x.shape)
+
+
+class GEGLU(nn.Module):
+    """attention.py:40-43 (placeholder module: the activation is fused into the first FeedForward GEMM's epilogue)."""
+
+    def forward(self, x):
+        raise RuntimeError('GEGLU runs fused inside FeedForward on the MI355X build')
+
+
+class FeedForwardSeq(nn.Sequential):
+    """attention.py:45-53 : Sequential(nn.LayerNorm, Linear(d, 2*inner, no bias), GEGLU, Dropout, Linear(inner, d, no bias)).
+    run(): LN -> GEMM with interleaved (value, gate) rows + GEGLU epilogue -> GEMM + residual."""
+
+    def _packed(self, dtype):
+        lin1, lin2 = self[1], self[4]
+
+        def build():
+            inner = lin2.weight.shape[1]
+            q = 8 if dtype == L.BF16 else 4
+            ip = round_up(inner, q)
+            w1 = lin1.weight.detach()
+            d = w1.shape[1]
+            w1p = torch.zeros((2 * ip, d), device=w1.device, dtype=torch.float32)
+            w1p[0:2 * inner:2] = w1[:inner]          # value rows  (x, gate = chunk(2))
+            w1p[1:2 * inner:2] = w1[inner:]          # gate rows
+            w2p = torch.zeros((lin2.weight.shape[0], ip), device=w1.device, dtype=torch.float32)
+            w2p[:, :inner] = lin2.weight.detach()
+            return pack_linear_weight(w1p, dtype), pack_linear_weight(w2p, dtype), ip
+        return _cache(self).get(('ff', dtype), [lin1.weight, lin2.weight], build)
+
+    def run(self, x2d, dtype):
+        """x2d (M, D) f32 -> ff(x) + x  (M, D) f32"""
+        M, D = x2d.shape
+        w1p, w2p, ip = self._packed(dtype)
+        td = L.tdtype(dtype)
+        ln = self[0]
+        xn = torch.empty((M, D), device=x2d.device, dtype=td)
+        L.layernorm(x2d, ln.weight, ln.bias, M, D, out=xn, eps=ln.eps)
+        hmid = torch.empty((M, ip), device=x2d.device, dtype=td)
+        L.gemm(dtype, xn, w1p, M, 2 * ip, D, C=hmid, act=L.ACT_GEGLU)
+        out = torch.empty_like(x2d)
+        L.gemm(dtype, hmid, w2p, M, D, ip, C=out, res=x2d)
+        return out
+
+    def forward(self, x):
+        L.require_device(x, 'x')
+        x2 = x.reshape(-1, x.shape[-1]).float().contiguous()
+        return (self.run(x2, compute_dtype_of(self)) - x2).reshape(x.shape)
+
+
+def FeedForward(dim, mult=4, dropout=0.):
+    inner_dim = int(mult * (2 / 3) * dim)
+    return FeedForwardSeq(
+        nn.LayerNorm(dim),
+        nn.Linear(dim, inner_dim * 2, bias=False),
+        GEGLU(),
+        nn.Dropout(dropout),
+        nn.Linear(inner_dim, dim, bias=False),
+    )
+
+
+class PEG(nn.Module):
+    """attention.py:57-85 : depthwise Conv3d(dim, dim, 3, groups=dim) on the raw (b,t,h,w,d) reinterpretation."""
+
+    def __init__(self, dim, causal=False):
+        super().__init__()
+        self.causal = causal
+        self.dsconv = nn.Conv3d(dim, dim, 3, groups=dim)
+
+    def _packed(self):
+        w = self.dsconv.weight
+        return _cache(self).get('wt', [w], lambda: w.detach().float().reshape(w.shape[0], 27).t().contiguous())
+
+    def run(self, x2d, shape):
+        """x2d (M, D) f32 contiguous, shape (b,t,h,w) with b*t*h*w == M -> peg(x) + x"""
+        b, t, h, w = shape
+        M, D = x2d.shape
+        assert b * t * h * w == M, 'PEG shape does not match the token buffer'
+        out = torch.empty_like(x2d)
+        L.peg(x2d, self._packed(), self.dsconv.bias, out, b, t, h, w, D, self.causal)
+        return out
+
+    def forward(self, x, shape=None):
+        L.require_device(x, 'x')
+        needs_shape = x.ndim == 3
+        assert not (needs_shape and not exists(shape))
+        if not needs_shape:
+            shape = tuple(x.shape[:-1])
+        x2 = x.reshape(-1, x.shape[-1]).float().contiguous()
+        return (self.run(x2, tuple(shape)) - x2).reshape(x.shape)
+
+
+class AlibiPositionalBias(nn.Module):
+    """attention.py:186-227 : per-head slopes; the bias itself is generated inside the attention kernel."""
+
+    def __init__(self, heads):
+        super().__init__()
+        self.heads = heads
+        slopes = torch.tensor(self._get_slopes(heads), dtype=torch.float32).reshape(heads, 1, 1)
+        self.register_buffer('slopes', slopes, persistent=False)
+
+    @staticmethod
+    def _get_slopes(heads):
+        def pow2_slopes(n):
+            start = 2 ** (-2 ** -(math.log2(n) - 3))
+            return [start * start ** i for i in range(n)]
+        if math.log2(heads).is_integer():
+            return pow2_slopes(heads)
+        c = 2 ** math.floor(math.log2(heads))
+        return pow2_slopes(c) + pow2_slopes(2 * c)[0::2][:heads - c]
+
+
+class ContinuousPositionBias(nn.Module):
+    """attention.py:229-275 : MLP over log-spaced relative positions -> (heads, n, n).
+    The MLP always runs in exact f32 (the reference forces rel_pos.float()), and the result is cached per
+    (weights, dims): the weights are frozen during sampling, the reference recomputes it every forward."""
+
+    def __init__(self, *, dim, heads, num_dims=2, layers=2, log_dist=True, cache_rel_pos=False):
+        super().__init__()
+        assert log_dist, 'only log_dist = True (the reference default) is built'
+        self.num_dims = num_dims
+        self.log_dist = log_dist
+        self.net = nn.ModuleList([])
+        self.net.append(nn.Sequential(nn.Linear(num_dims, dim), nn.LeakyReLU(0.1)))
+        for _ in range(layers - 1):
+            self.net.append(nn.Sequential(nn.Linear(dim, dim), nn.LeakyReLU(0.1)))
+        self.net.append(nn.Linear(dim, heads))
+        self.cache_rel_pos = cache_rel_pos
+
+    def forward(self, *dimensions, device=None):
+        assert len(dimensions) == self.num_dims
+        params = list(self.parameters())
+        L.require_device(params[0], 'ContinuousPositionBias parameters')
+        return _cache(self).get(('bias', tuple(dimensions)), params, lambda: self._compute(dimensions))
+
+    def _compute(self, dims):
+        dev = self.net[0][0].weight.device
+        n = 1
+        for d in dims:
+            n *= d
+        first = self.net[0][0]
+        D = first.weight.shape[0]
+        rows = n * n
+        h = torch.empty((rows, D), device=dev, dtype=torch.float32)
+        L.cpb_input(f32c(first.weight), f32c(first.bias), h, dims, D)
+        for layer in list(self.net)[1:-1]:
+            lin = layer[0]
+            nxt = torch.empty((rows, lin.weight.shape[0]), device=dev, dtype=torch.float32)
+            L.gemm(L.F32, h, pack_linear_weight(lin.weight, L.F32), rows, lin.weight.shape[0], lin.weight.shape[1],
+                   C=nxt, bias=f32c(lin.bias), act=L.ACT_LEAKY)
+            h = nxt
+        last = self.net[-1]
+        heads = last.weight.shape[0]
+        out = torch.empty((rows, heads), device=dev, dtype=torch.float32)
+        L.gemm(L.F32, h, pack_linear_weight(last.weight, L.F32), rows, heads, last.weight.shape[1], C=out, bias=f32c(last.bias))
+        return out.reshape(n, n, heads).permute(2, 0, 1).contiguous()
+
+
+class Attention(nn.Module):
+    """attention.py:89-182."""
+
+    def __init__(self, dim, dim_context=None, dim_head=64, heads=8, causal=False, num_null_kv=0,
+                 norm_context=True, dropout=0., scale=8):
+        super().__init__()
+        assert dim_head == 64, 'the MI355X attention kernels are built for dim_head = 64 (the reference default)'
+        self.heads = heads
+        self.causal = causal
+        self.scale = scale
+        inner_dim = dim_head * heads
+        dim_context = default(dim_context, dim)
+        if causal:
+            self.rel_pos_bias = AlibiPositionalBias(heads=heads)
+        self.attn_dropout = nn.Dropout(dropout)
+        self.norm = LayerNorm(dim)
+        self.context_norm = LayerNorm(dim_context) if norm_context else nn.Identity()
+        self.num_null_kv = num_null_kv
+        self.null_kv = nn.Parameter(torch.randn(heads, 2 * num_null_kv, dim_head))
+        self.to_q = nn.Linear(dim, inner_dim, bias=False)
+        self.to_kv = nn.Linear(dim_context, inner_dim * 2, bias=False)
+        self.q_scale = nn.Parameter(torch.ones(dim_head))
+        self.k_scale = nn.Parameter(torch.ones(dim_head))
+        self.to_out = nn.Linear(inner_dim, dim, bias=False)
+
+    # -- key/value side: step-invariant for cross-attention, so callers may cache the result
+    def project_kv(self, kv_src2d, S, n_kv, dtype, is_context):
+        """kv_src2d: (S*n_kv, dim_kv) f32.  Self-attention passes the UN-normalised x (attention.py:140-144);
+        cross-attention passes the raw context, normalised here by context_norm."""
+        dev = kv_src2d.device
+        td = L.tdtype(dtype)
+        inner = self.to_q.weight.shape[0]
+        Mk, Dk = kv_src2d.shape
+        if is_context and isinstance(self.context_norm, LayerNorm):
+            src = torch.empty((Mk, Dk), device=dev, dtype=td)
+            self.context_norm.run(kv_src2d, out=src)
+        else:
+            src = kv_src2d
+        kv = torch.empty((Mk, 2 * inner), device=dev, dtype=torch.float32)
+        L.gemm(dtype, src, linear_weight(self.to_kv, dtype), Mk, 2 * inner, Dk, C=kv)
+        return kv
+
+    def run(self, x2d, S, n, dtype, *, context2d=None, n_ctx=None, attn_bias=None, kmask=None, kv_cache=None):
+        """x2d (S*n, D) f32 -> attention(x) + x.  kmask: (S, n_kv) uint8/bool over the real keys or None."""
+        dev = x2d.device
+        td = L.tdtype(dtype)
+        M, D = x2d.shape
+        h = self.heads
+        inner = self.to_q.weight.shape[0]
+        nnull = self.num_null_kv
+        is_cross = context2d is not None
+        n_kv = n_ctx if is_cross else n
+
+        xn = torch.empty((M, D), device=dev, dtype=td)
+        self.norm.run(x2d, out=xn)
+        q = torch.empty((M, inner), device=dev, dtype=torch.float32)
+        L.gemm(dtype, xn, linear_weight(self.to_q, dtype), M, inner, D, C=q)
+
+        nq_pad, nk_pad = L.attn_pads(n, n_kv, nnull)
+        Qp = torch.empty((S * h * nq_pad * 64,), device=dev, dtype=td)
+        cached = kv_cache.get(id(self)) if (kv_cache is not None and is_cross) else None
+        if cached is None:
+            kv = self.project_kv(context2d if is_cross else x2d, S, n_kv, dtype, is_cross)
+            Kp = torch.empty((S * h * nk_pad * 64,), device=dev, dtype=td)
+            Vt = torch.empty((S * h * nk_pad * 64,), device=dev, dtype=td)
+            L.attn_prep(dtype, q, kv, self.null_kv, self.q_scale, self.k_scale, float(self.scale), Qp, Kp, Vt, S, h, n, n_kv, nnull)
+            if kv_cache is not None and is_cross:
+                kv_cache[id(self)] = (Kp, Vt)
+        else:
+            Kp, Vt = cached      # step-invariant context: only the query side is prepared again
+            L.attn_prep(dtype, q, None, self.null_kv, self.q_scale, self.k_scale, float(self.scale), Qp, None, None, S, h, n, n_kv, nnull)
+        o = torch.empty((M, inner), device=dev, dtype=td)
+        slopes = self.rel_pos_bias.slopes if self.causal else None
+        L.attn_fwd(dtype, Qp, Kp, Vt, o, S, h, n, n_kv, nnull, bias=attn_bias, kmask=kmask, slopes=slopes, causal=self.causal)
+        out = torch.empty_like(x2d)
+        L.gemm(dtype, o, linear_weight(self.to_out, dtype), M, D, inner, C=out, res=x2d)
+        return out
+
+    def forward(self, x, mask=None, context=None, attn_bias=None):
+        L.require_device(x, 'x')
+        S, n, D = x.shape
+        x2 = x.reshape(S * n, D).float().contiguous()
+        ctx2, n_ctx = None, None
+        if exists(context):
+            n_ctx = context.shape[1]
+            ctx2 = context.reshape(S * n_ctx, context.shape[-1]).float().contiguous()
+        km = mask.to(torch.uint8).contiguous() if exists(mask) else None
+        ab = attn_bias.float().contiguous() if exists(attn_bias) else None
+        out = self.run(x2, S, n, compute_dtype_of(self), context2d=ctx2, n_ctx=n_ctx, attn_bias=ab, kmask=km)
+        return (out - x2).reshape(x.shape)
+
+
+class Transformer(nn.Module):
+    """attention.py:279-332 : per layer [PEG?, self Attention, cross Attention?, FeedForward], each + residual; norm_out."""
+
+    def __init__(self, dim, *, depth, dim_context=None, causal=False, dim_head=64, heads=8, ff_mult=4, peg=False,
+                 peg_causal=False, attn_num_null_kv=2, has_cross_attn=False, attn_dropout=0., ff_dropout=0.):
+        super().__init__()
+        self.layers = nn.ModuleList([])
+        for _ in range(depth):
+            self.layers.append(nn.ModuleList([
+                PEG(dim=dim, causal=peg_causal) if peg else None,
+                Attention(dim=dim, dim_head=dim_head, heads=heads, causal=causal, dropout=attn_dropout),
+                Attention(dim=dim, dim_head=dim_head, dim_context=dim_context, heads=heads, causal=False,
+                          num_null_kv=attn_num_null_kv, dropout=attn_dropout) if has_cross_attn else None,
+                FeedForward(dim=dim, mult=ff_mult, dropout=ff_dropout),
+            ]))
+        self.norm_out = LayerNorm(dim)
+
+    def run(self, x2d, S, n, dtype, *, video_shape=None, attn_bias=None, context2d=None, n_ctx=None,
+            self_attn_mask=None, cross_attn_context_mask=None, kv_cache=None, out=None, out_t=None):
+        """x2d (S*n, D) f32.  Writes norm_out(x) to `out` (f32) and/or `out_t` (T); returns `out` (allocated if both None)."""
+        x = x2d
+        for peg, self_attn, cross_attn, ff in self.layers:
+            if exists(peg):
+                x = peg.run(x, video_shape)
+            x = self_attn.run(x, S, n, dtype, attn_bias=attn_bias, kmask=self_attn_mask)
+            if exists(cross_attn) and exists(context2d):
+                x = cross_attn.run(x, S, n, dtype, context2d=context2d, n_ctx=n_ctx, kmask=cross_attn_context_mask,
+                                   kv_cache=kv_cache)
+            x = ff.run(x, dtype)
+        if out is None and out_t is None:
+            out = torch.empty_like(x)
+        self.norm_out.run(x, out=out_t, out2=out)
+        return out if out is not None else out_t
+
+    def forward(self, x, video_shape=None, attn_bias=None, context=None, self_attn_mask=None,
+                cross_attn_context_mask=None, _kv_cache=None):
+        L.require_device(x, 'x')
+        S, n, D = x.shape
+        x2 = x.reshape(S * n, D).float().contiguous()
+        ctx2, n_ctx = None, None
+        if exists(context):
+            n_ctx = context.shape[1]
+            ctx2 = context.reshape(S * n_ctx, context.shape[-1]).float().contiguous()
+        sm = self_attn_mask.to(torch.uint8).contiguous() if exists(self_attn_mask) else None
+        cm = cross_attn_context_mask.to(torch.uint8).contiguous() if exists(cross_attn_context_mask) else None
+        ab = attn_bias.float().contiguous() if exists(attn_bias) else None
+        out = self.run(x2, S, n, compute_dtype_of(self), video_shape=tuple(video_shape) if exists(video_shape) else None,
+                       attn_bias=ab, context2d=ctx2, n_ctx=n_ctx, self_attn_mask=sm, cross_attn_context_mask=cm,
+                       kv_cache=_kv_cache)
+        return out.reshape(S, n, D)

@@ -1,0 +1,291 @@
+// Cosine-sim multi-head attention of the reference (attention.py:128-182) as two kernels:
+//
+//  pk_attn_prep : head split, null-kv prepend (interleaved k,v,k,v rows of `null_kv`, attention.py:148),
+//                 l2norm of q and of k AFTER the null-k concat (attention.py:153), * q_scale / k_scale,
+//                 * scale (8, attention.py:157, folded into q), V stored TRANSPOSED per head.
+//                 Layouts written (T = bf16 | f32):
+//                   Qp [S][h][nq_pad][64]   Kp [S][h][nk_pad][64]   Vt [S][h][64][nk_pad]
+//                 nk = nnull + n_kv, pads are zero-filled.
+//  pk_attn_fwd  : softmax(Qp Kp^T + bias (+ALiBi, causal, key mask)) V, flash-style, LDS-free:
+//                 one wave owns 16*QF query rows; per 32-key tile it computes S^T = K Q^T and
+//                 O^T = V^T P^T with MFMA, so every softmax statistic of query row (lane & 15) is
+//                 lane-local up to a 4-lane-group shuffle, and P never leaves registers
+//                 (the S^T accumulator layout IS the P^T operand layout under the key permutation
+//                 key = (j >> 2)*16 + g*4 + (j & 3) that V^T's fragment loads use too).
+// dim_head is fixed at 64 (the reference default; every BASELINE config).
+// Roofline: MFMA for n = 576 (4*nq*nk*64 flops per head), L1/L2 operand-fetch bound at small QF.
+#include "common.hpp"
+
+namespace pk {
+
+constexpr int DH = 64;
+
+struct PrepArgs {
+    const float* q; int ldq;        // [S*nq][ldq], head hh at columns hh*64
+    const float* kv; int ldkv;      // [S*n_kv][ldkv], k at columns [0, h*64), v at [h*64, 2*h*64)
+    const float* null_kv;           // [h][2*nnull][64] or null
+    const float* q_scale;           // [64]
+    const float* k_scale;           // [64]
+    void* Qp; void* Kp; void* Vt;
+    int S, h, nq, n_kv, nnull, nq_pad, nk_pad;
+    float scale;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void prep_q_kernel(const PrepArgs p) {
+    // one wave per (s, hh, i) including pad rows
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long total = (long)p.S * p.h * p.nq_pad;
+    if (r >= total) return;
+    const int i = (int)(r % p.nq_pad);
+    const long sh = r / p.nq_pad;
+    const int hh = (int)(sh % p.h), s = (int)(sh / p.h);
+    float v = 0.f;
+    if (i < p.nq) {
+        const float x = p.q[((size_t)s * p.nq + i) * p.ldq + hh * DH + lane];
+        const float ss = wave_sum(x * x);
+        v = x / fmaxf(sqrtf(ss), 1e-12f) * p.q_scale[lane] * p.scale;     // F.normalize eps = 1e-12
+    }
+    store_elem(reinterpret_cast<T*>(p.Qp) + (size_t)r * DH + lane, v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void prep_kv_kernel(const PrepArgs p) {
+    // one block per (s, hh, 64-key tile)
+    __shared__ float vt[64][65];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tiles = p.nk_pad / 64 + ((p.nk_pad % 64) ? 1 : 0);
+    const int kt = blockIdx.x % tiles;
+    const int sh = blockIdx.x / tiles;
+    const int hh = sh % p.h, s = sh / p.h;
+    const int nk = p.nnull + p.n_kv;
+    T* Kp = reinterpret_cast<T*>(p.Kp) + (size_t)sh * p.nk_pad * DH;
+    T* Vt = reinterpret_cast<T*>(p.Vt) + (size_t)sh * DH * p.nk_pad;
+    for (int jj = wave; jj < 64; jj += 4) {
+        const int key = kt * 64 + jj;
+        float kx = 0.f, vx = 0.f;
+        if (key < p.nnull) {
+            kx = p.null_kv[((size_t)hh * 2 * p.nnull + 2 * key) * DH + lane];
+            vx = p.null_kv[((size_t)hh * 2 * p.nnull + 2 * key + 1) * DH + lane];
+        } else if (key < nk) {
+            const float* row = p.kv + ((size_t)s * p.n_kv + (key - p.nnull)) * p.ldkv;
+            kx = row[hh * DH + lane];
+            vx = row[p.h * DH + hh * DH + lane];
+        }
+        const float ss = wave_sum(kx * kx);
+        const float kn = key < nk ? kx / fmaxf(sqrtf(ss), 1e-12f) * p.k_scale[lane] : 0.f;
+        if (key < p.nk_pad) store_elem(Kp + (size_t)key * DH + lane, kn);
+        vt[jj][lane] = vx;
+    }
+    __syncthreads();
+    // transposed store: thread -> (d = tid >> 2, 16 consecutive keys)
+    const int d = threadIdx.x >> 2, j0 = (threadIdx.x & 3) * 16;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        const int key = kt * 64 + j0 + q4 * 4;
+        if (key < p.nk_pad) {   // nk_pad % 4 == 0
+            const f32x4 o = f32x4{vt[j0 + q4 * 4 + 0][d], vt[j0 + q4 * 4 + 1][d], vt[j0 + q4 * 4 + 2][d], vt[j0 + q4 * 4 + 3][d]};
+            store4(Vt + (size_t)d * p.nk_pad + key, o);
+        }
+    }
+}
+
+struct AttnArgs {
+    const void* Qp; const void* Kp; const void* Vt;
+    const float* bias; long bias_hstride; int bias_ld;   // bias[hh][i][j] over REAL keys j, or null
+    const unsigned char* kmask;                            // [S][n_kv] (1 = keep) over real keys, or null
+    const float* slopes;                                   // ALiBi slopes [h] (causal layers), or null
+    void* O; int ldo; int out_f32;                         // O[(s*nq + i)][hh*64 + d]
+    int S, h, nq, n_kv, nnull, nq_pad, nk_pad, causal;
+};
+
+__device__ __forceinline__ void load_vt(Frag<bf16>& f, const bf16* row, int kb, int g) {
+    const u32x2 a = *reinterpret_cast<const u32x2*>(row + kb + g * 4);
+    const u32x2 b = *reinterpret_cast<const u32x2*>(row + kb + 16 + g * 4);
+    f.v = u32x4{a[0], a[1], b[0], b[1]};
+}
+__device__ __forceinline__ void load_vt(Frag<float>& f, const float* row, int kb, int g) {
+    f.lo = *reinterpret_cast<const f32x4*>(row + kb + g * 4);
+    f.hi = *reinterpret_cast<const f32x4*>(row + kb + 16 + g * 4);
+}
+
+template <typename T, int QF>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
+    const int qtiles = p.nq_pad / (16 * QF);
+    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= (long)p.S * p.h * qtiles) return;
+    const int qt = (int)(wid % qtiles);
+    const int sh = (int)(wid / qtiles);
+    const int hh = sh % p.h, s = sh / p.h;
+    const int q0 = qt * 16 * QF;
+    const int nk = p.nnull + p.n_kv;
+
+    const T* Qp = reinterpret_cast<const T*>(p.Qp) + ((size_t)sh * p.nq_pad + q0) * DH;
+    const T* Kp = reinterpret_cast<const T*>(p.Kp) + (size_t)sh * p.nk_pad * DH;
+    const T* Vt = reinterpret_cast<const T*>(p.Vt) + (size_t)sh * DH * p.nk_pad;
+
+    Frag<T> fq[QF][2];
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) frag_load(fq[qf][c], Qp + (size_t)(qf * 16 + lr) * DH + c * 32 + g * 8);
+
+    float m[QF], l[QF];
+    f32x4 o[QF][4];
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) {
+        m[qf] = -INFINITY; l[qf] = 0.f;
+#pragma unroll
+        for (int df = 0; df < 4; ++df) o[qf][df] = f32x4{0, 0, 0, 0};
+    }
+    const float slope = (p.causal && p.slopes) ? p.slopes[hh] : 0.f;
+    const float* bias = p.bias ? p.bias + (size_t)hh * p.bias_hstride : nullptr;
+    const unsigned char* km = p.kmask ? p.kmask + (size_t)s * p.n_kv : nullptr;
+    const int coff = p.n_kv - p.nq;                         // causal diagonal offset (attention.py:172)
+
+    for (int kb = 0; kb < p.nk_pad; kb += 32) {
+        f32x4 st[QF][2];
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) { st[qf][0] = f32x4{0, 0, 0, 0}; st[qf][1] = st[qf][0]; }
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                Frag<T> fk;
+                frag_load(fk, Kp + (size_t)(kb + f * 16 + lr) * DH + c * 32 + g * 8);
+#pragma unroll
+                for (int qf = 0; qf < QF; ++qf) st[qf][f] = mma(fk, fq[qf][c], st[qf][f]);
+            }
+        const bool plain = (kb + 32 <= nk) && !km && !p.causal && !bias;
+        float pr[QF][8];
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+            const int qi = q0 + qf * 16 + lr;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float sv = st[qf][f][r];
+                    if (!plain) {
+                        const int key = kb + f * 16 + g * 4 + r;
+                        const int j = key - p.nnull;
+                        if (key >= nk) sv = -INFINITY;               // tile padding: contributes exactly 0
+                        else {
+                            if (bias && j >= 0 && qi < p.nq) sv += bias[(size_t)qi * p.bias_ld + j];
+                            bool masked = km && j >= 0 && !km[j];
+                            if (p.causal && j >= 0) {
+                                const int dj = j - (qi + coff);
+                                sv -= fabsf((float)dj) * slope;
+                                masked = masked || dj > 0;
+                            }
+                            if (masked) sv = NEG_MAX;
+                        }
+                    }
+                    pr[qf][f * 4 + r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m[qf], mx);               // finite: every 32-key tile holds >= 1 real key
+            const float alpha = __expf(m[qf] - mn);
+            float ls = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { pr[qf][e] = __expf(pr[qf][e] - mn); ls += pr[qf][e]; }
+            l[qf] = l[qf] * alpha + ls;
+            m[qf] = mn;
+#pragma unroll
+            for (int df = 0; df < 4; ++df) o[qf][df] *= alpha;
+        }
+        Frag<T> fp[QF];
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) frag_from_f32(fp[qf], pr[qf]);
+#pragma unroll
+        for (int df = 0; df < 4; ++df) {
+            Frag<T> fv;
+            load_vt(fv, Vt + (size_t)(df * 16 + lr) * p.nk_pad, kb, g);
+#pragma unroll
+            for (int qf = 0; qf < QF; ++qf) o[qf][df] = mma(fv, fp[qf], o[qf][df]);
+        }
+    }
+    float* Of = reinterpret_cast<float*>(p.O);
+    T* Ot = reinterpret_cast<T*>(p.O);
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) {
+        float lt = l[qf];
+        lt += __shfl_xor(lt, 16, 64);
+        lt += __shfl_xor(lt, 32, 64);
+        const float inv = 1.0f / lt;
+        const int qi = q0 + qf * 16 + lr;
+        if (qi < p.nq) {
+#pragma unroll
+            for (int df = 0; df < 4; ++df) {
+                const size_t off = ((size_t)s * p.nq + qi) * p.ldo + hh * DH + df * 16 + g * 4;
+                const f32x4 v = o[qf][df] * inv;
+                if (p.out_f32) store4(Of + off, v); else store4(Ot + off, v);
+            }
+        }
+    }
+}
+
+}  // namespace pk
+using namespace pk;
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// sizes (in elements of T) the caller must allocate: Qp = S*h*nq_pad*64, Kp = S*h*nk_pad*64, Vt = same as Kp
+extern "C" int pk_attn_pads(int nq, int n_kv, int nnull, int* nq_pad, int* nk_pad) {
+    if (nq <= 0 || n_kv <= 0 || nnull < 0 || !nq_pad || !nk_pad) return PK_EINVAL;
+    *nq_pad = round_up(nq, nq >= 128 ? 32 : 16);
+    *nk_pad = round_up(nnull + n_kv, 32);
+    return PK_OK;
+}
+
+extern "C" int pk_attn_prep(int dtype, const float* q, int ldq, const float* kv, int ldkv, const float* null_kv,
+                            const float* q_scale, const float* k_scale, float scale,
+                            void* Qp, void* Kp, void* Vt, int S, int h, int nq, int n_kv, int nnull, void* stream) {
+    if (!q || !q_scale || !Qp || S <= 0 || h <= 0) return PK_EINVAL;
+    if (kv && (!k_scale || !Kp || !Vt)) return PK_EINVAL;      // kv == NULL: query side only (cached K/V)
+    if (kv && nnull > 0 && !null_kv) return PK_EINVAL;
+    int nq_pad, nk_pad;
+    if (int rc = pk_attn_pads(nq, n_kv, nnull, &nq_pad, &nk_pad)) return rc;
+    PrepArgs p{q, ldq, kv, ldkv, null_kv, q_scale, k_scale, Qp, Kp, Vt, S, h, nq, n_kv, nnull, nq_pad, nk_pad, scale};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long qrows = (long)S * h * nq_pad;
+    const int tiles = (nk_pad + 63) / 64;
+    if (dtype == 1) {
+        hipLaunchKernelGGL((prep_q_kernel<bf16>), dim3((unsigned)((qrows + 3) / 4)), dim3(256), 0, s, p);
+        if (kv) hipLaunchKernelGGL((prep_kv_kernel<bf16>), dim3((unsigned)(S * h * tiles)), dim3(256), 0, s, p);
+    } else if (dtype == 0) {
+        hipLaunchKernelGGL((prep_q_kernel<float>), dim3((unsigned)((qrows + 3) / 4)), dim3(256), 0, s, p);
+        if (kv) hipLaunchKernelGGL((prep_kv_kernel<float>), dim3((unsigned)(S * h * tiles)), dim3(256), 0, s, p);
+    } else return PK_EINVAL;
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+extern "C" int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void* Vt,
+                           const float* bias, long bias_hstride, int bias_ld, const unsigned char* kmask,
+                           const float* slopes, int causal, void* O, int ldo, int out_is_f32,
+                           int S, int h, int nq, int n_kv, int nnull, void* stream) {
+    if (!Qp || !Kp || !Vt || !O || S <= 0 || h <= 0) return PK_EINVAL;
+    if (ldo & 3) return PK_EALIGN;
+    int nq_pad, nk_pad;
+    if (int rc = pk_attn_pads(nq, n_kv, nnull, &nq_pad, &nk_pad)) return rc;
+    AttnArgs a{Qp, Kp, Vt, bias, bias_hstride, bias_ld, kmask, slopes, O, ldo, out_is_f32, S, h, nq, n_kv, nnull, nq_pad, nk_pad, causal};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int QF = nq >= 128 ? 2 : 1;
+    const long waves = (long)S * h * (nq_pad / (16 * QF));
+    dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    if (dtype == 1) {
+        if (QF == 2) hipLaunchKernelGGL((attn_fwd_kernel<bf16, 2>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<bf16, 1>), grid, block, 0, s, a);
+    } else if (dtype == 0) {
+        if (QF == 2) hipLaunchKernelGGL((attn_fwd_kernel<float, 2>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<float, 1>), grid, block, 0, s, a);
+    } else return PK_EINVAL;
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}

@@ -1,0 +1,128 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) Phenaki hot-path kernels.
+//
+// Conventions used by every kernel in this directory:
+//   * wavefront = 64 lanes, written as the literal 64 everywhere;
+//   * "fragment chunk" = a 16 x 32 (row x k) slice of an MFMA operand held by one wave:
+//       lane l holds row (l & 15), logical k = (l >> 4) * 8 + j, j = 0..7  (8 elements per lane).
+//     For bf16 that is exactly one v_mfma_f32_16x16x32_bf16 operand; for exact-f32 mode the same
+//     8 elements feed eight v_mfma_f32_16x16x4_f32 (step j uses k-set {g*8+j : g = 0..3}).  Both
+//     operands of a product always use the SAME lane->k map, so any such permutation is exact.
+//   * accumulators follow the gfx950 C/D map: reg r of lane l = D[row = (l >> 4) * 4 + r][col = l & 15].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+typedef u16 u16x8 __attribute__((ext_vector_type(8)));
+typedef u16 u16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+struct bf16 { u16 v; };   // storage-only bf16 (round-to-nearest-even from f32, like torch)
+
+__device__ __forceinline__ u16 f2bf(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    u += 0x7fffu + ((u >> 16) & 1u);          // RNE; NaN payloads are not a concern on this path
+    return (u16)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(u16 h) {
+    return __builtin_bit_cast(float, (uint32_t)h << 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// ---- per-type fragment chunk -------------------------------------------------------------
+template <typename T> struct Frag;
+template <> struct Frag<bf16> { u32x4 v; };                 // 8 bf16
+template <> struct Frag<float> { f32x4 lo, hi; };           // 8 f32 (k = g*8 + 0..3 | 4..7)
+
+// acc += A_chunk (rows i) x B_chunk (cols j) over the chunk's 32 logical k
+__device__ __forceinline__ f32x4 mma(const Frag<bf16>& a, const Frag<bf16>& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a.v),
+                                                    __builtin_bit_cast(bf16x8_t, b.v), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma(const Frag<float>& a, const Frag<float>& b, f32x4 c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[j], b.lo[j], c, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[j], b.hi[j], c, 0, 0, 0);
+    return c;
+}
+
+// 8 contiguous elements at p (16-byte aligned for bf16, 32-byte span for f32) -> fragment chunk
+__device__ __forceinline__ void frag_load(Frag<bf16>& f, const bf16* p) {
+    f.v = *reinterpret_cast<const u32x4*>(p);
+}
+__device__ __forceinline__ void frag_load(Frag<float>& f, const float* p) {
+    f.lo = *reinterpret_cast<const f32x4*>(p);
+    f.hi = *reinterpret_cast<const f32x4*>(p + 4);
+}
+__device__ __forceinline__ void frag_zero(Frag<bf16>& f) { f.v = u32x4{0, 0, 0, 0}; }
+__device__ __forceinline__ void frag_zero(Frag<float>& f) { f.lo = f32x4{0, 0, 0, 0}; f.hi = f.lo; }
+
+// build a fragment chunk from 8 f32 values (register-resident P of the attention kernel)
+__device__ __forceinline__ void frag_from_f32(Frag<bf16>& f, const float (&x)[8]) {
+    f.v = u32x4{pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(x[4], x[5]), pack_bf2(x[6], x[7])};
+}
+__device__ __forceinline__ void frag_from_f32(Frag<float>& f, const float (&x)[8]) {
+    f.lo = f32x4{x[0], x[1], x[2], x[3]};
+    f.hi = f32x4{x[4], x[5], x[6], x[7]};
+}
+
+// scalar store/convert helpers
+__device__ __forceinline__ void store_elem(float* p, float v) { *p = v; }
+__device__ __forceinline__ void store_elem(bf16* p, float v) { p->v = f2bf(v); }
+__device__ __forceinline__ float load_elem(const float* p) { return *p; }
+__device__ __forceinline__ float load_elem(const bf16* p) { return bf2f(p->v); }
+
+__device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void store4(bf16* p, f32x4 v) {
+    *reinterpret_cast<u32x2*>(p) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+}
+__device__ __forceinline__ void store2(float* p, float a, float b) { *reinterpret_cast<f32x2*>(p) = f32x2{a, b}; }
+__device__ __forceinline__ void store2(bf16* p, float a, float b) { *reinterpret_cast<uint32_t*>(p) = pack_bf2(a, b); }
+
+// ---- wave reductions (64 lanes) ----------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact erf GELU (torch F.gelu default)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// ---- counter-based uniform noise shared by the sampler kernels and their tests -------------
+// u = hash(seed, stream, index) mapped to [0, 1) with 24 bits, the same granularity torch's
+// float uniform_ has.  tests/ re-implement this in numpy to feed the identical noise to the oracle.
+__device__ __host__ __forceinline__ uint32_t mix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+__device__ __host__ __forceinline__ float uniform24(uint32_t seed_lo, uint32_t seed_hi, uint32_t idx_lo, uint32_t idx_hi) {
+    uint32_t h = mix32(idx_lo ^ seed_lo);
+    h = mix32(h + 0x9e3779b9u * (idx_hi + 1u) + seed_hi);
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+constexpr float NEG_MAX = -3.402823466e+38f;   // -finfo(float32).max, the reference's mask fill value
+
+}  // namespace pk
+
+#define PK_OK 0
+#define PK_EINVAL (-1)       // bad shape / size argument
+#define PK_EALIGN (-2)       // pointer or stride alignment violated
+#define PK_ELAUNCH (-3)      // hipGetLastError() after the launch was not hipSuccess
+
+#define PK_CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return PK_ELAUNCH; } while (0)

@@ -1,0 +1,229 @@
+// Small HBM-bound kernels of the hot path: PEG depthwise conv, LFQ encode/decode, token+position
+// embedding, continuous-position-bias input layer, critic score head.
+#include "common.hpp"
+
+namespace pk {
+
+// ---- PEG (reference attention.py:57-85): depthwise 3x3x3 conv over a channels-last (B,T,H,W,D) view
+// of the token buffer, zero padding, time pad (2,0) if causal else (1,1), bias, + residual (attention.py:323).
+// wt is the conv weight pre-transposed to [27][D] (tap-major) so channel loads are 16-byte vectors.
+__global__ __launch_bounds__(256) void peg_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                  const float* __restrict__ bias, float* __restrict__ out,
+                                                  int B, int T, int H, int W, int D, int tfront, long total_vec) {
+    const int dv = D >> 2;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total_vec; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % dv) * 4;
+        long p = idx / dv;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H); p /= H;
+        const int t = (int)(p % T); const int b = (int)(p / T);
+        f32x4 acc = *reinterpret_cast<const f32x4*>(bias + c);
+        f32x4 center = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            const int ts = t + dt - tfront;
+            if (ts < 0 || ts >= T) continue;
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh) {
+                const int hs = h + dh - 1;
+                if (hs < 0 || hs >= H) continue;
+#pragma unroll
+                for (int dw = 0; dw < 3; ++dw) {
+                    const int ws = w + dw - 1;
+                    if (ws < 0 || ws >= W) continue;
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + ((((size_t)b * T + ts) * H + hs) * W + ws) * D + c);
+                    const f32x4 kv = *reinterpret_cast<const f32x4*>(wt + (size_t)((dt * 3 + dh) * 3 + dw) * D + c);
+                    acc += xv * kv;
+                    if (ts == t && hs == h && ws == w) center = xv;
+                }
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + ((((size_t)b * T + t) * H + h) * W + w) * D + c) = acc + center;
+    }
+}
+
+// ---- LFQ (vector-quantize-pytorch LFQ restated in oracle/lfq.py; call sites cvivit.py:570, :439)
+// encode: proj = x @ Wp^T + bp (f32, one wave per token), ids = sum_k (proj_k > 0) << (cd-1-k)  (MSB first)
+template <int CD>
+__global__ __launch_bounds__(256) void lfq_encode_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ wp,
+                                                         const float* __restrict__ bp, long long* __restrict__ ids,
+                                                         float* __restrict__ proj, int M, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float part[CD];
+#pragma unroll
+    for (int k = 0; k < CD; ++k) part[k] = 0.f;
+    const float* xr = x + (size_t)row * ldx;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + c);
+#pragma unroll
+        for (int k = 0; k < CD; ++k) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + (size_t)k * D + c);
+            part[k] += (xv[0] * wv[0] + xv[1] * wv[1]) + (xv[2] * wv[2] + xv[3] * wv[3]);
+        }
+    }
+    long long id = 0;
+#pragma unroll
+    for (int k = 0; k < CD; ++k) {
+        const float v = wave_sum(part[k]) + bp[k];
+        if (proj && lane == 0) proj[(size_t)row * CD + k] = v;
+        id |= (long long)(v > 0.f ? 1 : 0) << (CD - 1 - k);
+    }
+    if (lane == 0) ids[row] = id;
+}
+
+// decode: codes = (+1 | -1 per bit, MSB first) @ Wo^T + bo ; wo is [D][cd]
+__global__ __launch_bounds__(256) void lfq_decode_kernel(const long long* __restrict__ ids, const float* __restrict__ wo,
+                                                         const float* __restrict__ bo, float* __restrict__ out,
+                                                         int M, int D, int cd) {
+    const long total = (long)M * D;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int d = (int)(idx % D);
+        const long long id = ids[idx / D];
+        float acc = 0.f;
+        for (int k = 0; k < cd; ++k) {
+            const float sgn = ((id >> (cd - 1 - k)) & 1) ? 1.f : -1.f;
+            acc += sgn * wo[(size_t)d * cd + k];
+        }
+        out[idx] = acc + bo[d];
+    }
+}
+
+// ---- token + position embedding (reference phenaki_pytorch.py:194-197, :290-291)
+__global__ __launch_bounds__(256) void embed_kernel(const long long* __restrict__ ids, const float* __restrict__ tok,
+                                                    const float* __restrict__ pos, float* __restrict__ out,
+                                                    int n, int D, long total_vec) {
+    const int dv = D >> 2;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total_vec; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % dv) * 4;
+        const long r = idx / dv;
+        const int i = (int)(r % n);
+        const long long id = ids[r];
+        const f32x4 a = *reinterpret_cast<const f32x4*>(pos + (size_t)i * D + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(tok + (size_t)id * D + c);
+        *reinterpret_cast<f32x4*>(out + (size_t)r * D + c) = a + b;
+    }
+}
+
+// ---- ContinuousPositionBias input layer (reference attention.py:257-272): for every (i, j) of the
+// flattened 'ij' meshgrid, rel = pos_i - pos_j, v = sign(rel) * log(|rel| + 1), h = leaky_relu(W0 v + b0, 0.1)
+__global__ __launch_bounds__(256) void cpb_input_kernel(const float* __restrict__ w0, const float* __restrict__ b0,
+                                                        float* __restrict__ out, int d0, int d1, int d2, int nd, int D, long total) {
+    const int n = d0 * d1 * d2;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % D);
+        const long pr = idx / D;
+        const int j = (int)(pr % n), i = (int)(pr / n);
+        int pi[3] = {i / (d1 * d2), (i / d2) % d1, i % d2};
+        int pj[3] = {j / (d1 * d2), (j / d2) % d1, j % d2};
+        float acc = b0[c];
+        for (int a = 0; a < nd; ++a) {
+            const int q = 3 - nd + a;                      // nd == 2 uses the trailing (h, w) axes
+            const float rel = (float)(pi[q] - pj[q]);
+            const float sg = rel > 0.f ? 1.f : (rel < 0.f ? -1.f : 0.f);
+            acc += w0[(size_t)c * nd + a] * (sg * logf(fabsf(rel) + 1.f));
+        }
+        out[idx] = acc > 0.f ? acc : 0.1f * acc;
+    }
+}
+
+// ---- critic score head (reference phenaki_pytorch.py:246-263, 523-545):
+//   s[r] = x[r] . w + b ;  out[b][i] = null + (cond - null) * scale  + noise_mult * (u - 0.5)
+// rows are laid out [cond sequences | null sequences]; prime positions are dropped (i >= n_prime).
+__global__ __launch_bounds__(256) void critic_head_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                          const float* __restrict__ bptr, int D, int nb, int n_tot, int n_prime, int has_null,
+                                                          float scale, const float* __restrict__ u, float noise_mult,
+                                                          float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int n = n_tot - n_prime;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);     // r indexes (batch, i) of the OUTPUT
+    if (r >= nb * n) return;
+    const int bi = r / n, i = r % n + n_prime;
+    const float b = bptr ? bptr[0] : 0.f;
+    auto dot = [&](const float* xr) {
+        float s = 0.f;
+        for (int c = lane * 4; c < D; c += 256) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + c);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c);
+            s += (xv[0] * wv[0] + xv[1] * wv[1]) + (xv[2] * wv[2] + xv[3] * wv[3]);
+        }
+        return wave_sum(s) + b;
+    };
+    float s = dot(x + ((size_t)bi * n_tot + i) * ldx);
+    if (has_null) {
+        const float sn = dot(x + ((size_t)(nb + bi) * n_tot + i) * ldx);
+        s = sn + (s - sn) * scale;
+    }
+    if (u) s += noise_mult * (u[r] - 0.5f);
+    if (lane == 0) out[r] = s;
+}
+
+}  // namespace pk
+using namespace pk;
+
+static inline int nblocks(long total) { long b = (total + 255) / 256; return (int)(b < 16384 ? (b > 0 ? b : 1) : 16384); }
+#define STREAM(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int pk_peg(const float* x, const float* wt, const float* bias, float* out, int B, int T, int H, int W, int D,
+                      int causal, void* stream) {
+    if (!x || !wt || !bias || !out || B <= 0 || T <= 0 || H <= 0 || W <= 0 || D <= 0) return PK_EINVAL;
+    if (D & 3) return PK_EALIGN;
+    if (x == out) return PK_EINVAL;                      // stencil: not in-place
+    const long total = (long)B * T * H * W * (D >> 2);
+    hipLaunchKernelGGL(peg_kernel, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), x, wt, bias, out, B, T, H, W, D, causal ? 2 : 1, total);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+extern "C" int pk_lfq_encode(const float* x, int ldx, const float* wp, const float* bp, long long* ids, float* proj,
+                             int M, int D, int cd, void* stream) {
+    if (!x || !wp || !bp || !ids || M <= 0 || D <= 0) return PK_EINVAL;
+    if ((D & 3) || (ldx & 3)) return PK_EALIGN;
+    dim3 grid((M + 3) / 4), block(256);
+    hipStream_t s = STREAM(stream);
+    switch (cd) {
+#define PK_CASE(N) case N: hipLaunchKernelGGL((lfq_encode_kernel<N>), grid, block, 0, s, x, ldx, wp, bp, ids, proj, M, D); break;
+        PK_CASE(4) PK_CASE(6) PK_CASE(8) PK_CASE(10) PK_CASE(12) PK_CASE(13) PK_CASE(14) PK_CASE(16) PK_CASE(18)
+#undef PK_CASE
+        default: return PK_EINVAL;
+    }
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+extern "C" int pk_lfq_decode(const long long* ids, const float* wo, const float* bo, float* out, int M, int D, int cd, void* stream) {
+    if (!ids || !wo || !bo || !out || M <= 0 || D <= 0 || cd <= 0 || cd > 62) return PK_EINVAL;
+    hipLaunchKernelGGL(lfq_decode_kernel, dim3(nblocks((long)M * D)), dim3(256), 0, STREAM(stream), ids, wo, bo, out, M, D, cd);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+extern "C" int pk_embed(const long long* ids, const float* tok, const float* pos, float* out, int rows, int n, int D, void* stream) {
+    if (!ids || !tok || !pos || !out || rows <= 0 || n <= 0 || D <= 0) return PK_EINVAL;
+    if (D & 3) return PK_EALIGN;
+    const long total = (long)rows * (D >> 2);
+    hipLaunchKernelGGL(embed_kernel, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), ids, tok, pos, out, n, D, total);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+extern "C" int pk_cpb_input(const float* w0, const float* b0, float* out, int d0, int d1, int d2, int nd, int D, void* stream) {
+    if (!w0 || !b0 || !out || d0 <= 0 || d1 <= 0 || d2 <= 0 || nd < 1 || nd > 3 || D <= 0) return PK_EINVAL;
+    const long n = (long)d0 * d1 * d2;
+    const long total = n * n * D;
+    hipLaunchKernelGGL(cpb_input_kernel, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), w0, b0, out, d0, d1, d2, nd, D, total);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+extern "C" int pk_critic_head(const float* x, int ldx, const float* w, const float* b, int D, int nb, int n_tot, int n_prime,
+                              int has_null, float scale, const float* u, float noise_mult, float* out, void* stream) {
+    if (!x || !w || !out || D <= 0 || nb <= 0 || n_tot <= n_prime || n_prime < 0) return PK_EINVAL;
+    if ((D & 3) || (ldx & 3)) return PK_EALIGN;
+    const int rows = nb * (n_tot - n_prime);
+    hipLaunchKernelGGL(critic_head_kernel, dim3((rows + 3) / 4), dim3(256), 0, STREAM(stream), x, ldx, w, b, D, nb, n_tot, n_prime,
+                       has_null, scale, u, noise_mult, out);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}

@@ -1,0 +1,145 @@
+// LDS-tiled MFMA GEMM main loop shared by every projection on the Phenaki hot path:
+//   acc[m][n] = sum_k A[m][k] * W[n][k]        (W is an nn.Linear weight, row-major [N][K])
+//
+// Tile: BM = 32*TM rows x BN = 32*TN cols per 256-thread workgroup (4 waves as 2 x 2), k-tile of
+// 128 bytes per row (64 bf16 / 32 f32).  Staging is global -> registers -> LDS with the next
+// k-tile's global loads issued before the current tile's MFMAs (one barrier per k-tile, two LDS
+// stages).  LDS rows are 128 B = 8 slots of 16 B, slot index XOR (row & 7): ds_write_b128 (8-lane
+// groups = one row) and ds_read_b128 (the gfx950 16-lane groups) are both conflict-free for bf16.
+//
+// The product is computed transposed (the weight tile is the MFMA "A" operand), so that lane l ends
+// up holding 4 CONSECUTIVE output columns of one output row:
+//   acc[i][j][r] = C[m0 + wm*16*TM + i*16 + (l & 15)][n0 + wn*16*TN + j*16 + (l >> 4)*4 + r]
+// which makes the epilogue's bias/residual loads and stores 16-byte vectors and puts a GEGLU
+// (value, gate) pair in one lane.
+#pragma once
+#include "common.hpp"
+
+namespace pk {
+
+struct GemmOperands {
+    const void* A;      // [M][lda]   f32 or T
+    const void* W;      // [N][ldw]   T
+    const int* a_rows;  // optional gather: logical row m reads physical row a_rows[m]
+    int lda, ldw;
+    int M, N, K;
+};
+
+template <typename T, typename TA> struct RawSlot;                    // one thread's 16-B LDS slot, pre-conversion
+template <typename T> struct RawSlot<T, T> { u32x4 v; };
+template <> struct RawSlot<bf16, float> { f32x4 a, b; };
+
+template <typename T>
+__device__ __forceinline__ void raw_load(RawSlot<T, T>& r, const T* p, bool ok) {
+    r.v = ok ? *reinterpret_cast<const u32x4*>(p) : u32x4{0, 0, 0, 0};
+}
+__device__ __forceinline__ void raw_load(RawSlot<bf16, float>& r, const float* p, bool ok) {
+    if (ok) { r.a = *reinterpret_cast<const f32x4*>(p); r.b = *reinterpret_cast<const f32x4*>(p + 4); }
+    else { r.a = f32x4{0, 0, 0, 0}; r.b = r.a; }
+}
+template <typename T>
+__device__ __forceinline__ u32x4 raw_pack(const RawSlot<T, T>& r) { return r.v; }
+__device__ __forceinline__ u32x4 raw_pack(const RawSlot<bf16, float>& r) {
+    return u32x4{pack_bf2(r.a[0], r.a[1]), pack_bf2(r.a[2], r.a[3]), pack_bf2(r.b[0], r.b[1]), pack_bf2(r.b[2], r.b[3])};
+}
+
+__device__ __forceinline__ void lds_frag(Frag<bf16>& f, const char* tile, int row, int chunk, int g) {
+    const int slot = (chunk * 4 + g) ^ (row & 7);
+    f.v = *reinterpret_cast<const u32x4*>(tile + row * 128 + (slot << 4));
+}
+__device__ __forceinline__ void lds_frag(Frag<float>& f, const char* tile, int row, int /*chunk*/, int g) {
+    const int s0 = (2 * g) ^ (row & 7), s1 = (2 * g + 1) ^ (row & 7);
+    f.lo = *reinterpret_cast<const f32x4*>(tile + row * 128 + (s0 << 4));
+    f.hi = *reinterpret_cast<const f32x4*>(tile + row * 128 + (s1 << 4));
+}
+
+template <typename T, typename TA, int TM, int TN>
+struct GemmTile {
+    static constexpr int BM = 32 * TM, BN = 32 * TN;
+    static constexpr int EPS = 16 / (int)sizeof(T);      // elements per 16-B slot
+    static constexpr int BK = 8 * EPS;                   // elements per k-tile
+    static constexpr int CH = BK / 32;                   // fragment chunks per k-tile
+    static constexpr int SMEM = 2 * (BM + BN) * 128;
+
+    // acc must be zero-initialised by the caller
+    static __device__ __forceinline__ void run(const GemmOperands& p, int m0, int n0, char* smem, f32x4 (&acc)[TM][TN]) {
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, lr = lane & 15;
+        char* sA[2] = {smem, smem + (BM + BN) * 128};
+        char* sW[2] = {smem + BM * 128, smem + (BM + BN) * 128 + BM * 128};
+
+        const TA* A = reinterpret_cast<const TA*>(p.A);
+        const T* W = reinterpret_cast<const T*>(p.W);
+
+        // per-thread slot assignment: slot s = tid + i*256 -> row = s >> 3, column slot = s & 7
+        const int sl = tid & 7;
+        const TA* a_src[TM];
+        bool a_ok[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = (tid >> 3) + i * 32;
+            int gm = m0 + row;
+            a_ok[i] = gm < p.M;
+            if (a_ok[i] && p.a_rows) gm = p.a_rows[gm];
+            a_src[i] = A + (size_t)(a_ok[i] ? gm : 0) * p.lda + sl * EPS;
+        }
+        const T* w_src[TN];
+        bool w_ok[TN];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int row = (tid >> 3) + i * 32;
+            const int gn = n0 + row;
+            w_ok[i] = gn < p.N;
+            w_src[i] = W + (size_t)(w_ok[i] ? gn : 0) * p.ldw + sl * EPS;
+        }
+
+        RawSlot<T, TA> ra[TM];
+        RawSlot<T, T> rw[TN];
+        auto gload = [&](int k0) {
+            const bool kok = (k0 + sl * EPS) < p.K;     // K is a multiple of EPS (checked on the host)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) raw_load(ra[i], a_src[i] + k0, a_ok[i] && kok);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) raw_load(rw[i], w_src[i] + k0, w_ok[i] && kok);
+        };
+        auto lstore = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = (tid >> 3) + i * 32;
+                *reinterpret_cast<u32x4*>(sA[buf] + row * 128 + ((sl ^ (row & 7)) << 4)) = raw_pack(ra[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int row = (tid >> 3) + i * 32;
+                *reinterpret_cast<u32x4*>(sW[buf] + row * 128 + ((sl ^ (row & 7)) << 4)) = raw_pack(rw[i]);
+            }
+        };
+
+        const int nt = (p.K + BK - 1) / BK;
+        gload(0);
+        lstore(0);
+        __syncthreads();
+        for (int t = 0; t < nt; ++t) {
+            const int buf = t & 1;
+            if (t + 1 < nt) gload((t + 1) * BK);
+            const char* a = sA[buf];
+            const char* w = sW[buf];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                Frag<T> fa[TM], fw[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) lds_frag(fa[i], a, wm * 16 * TM + i * 16 + lr, c, g);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) lds_frag(fw[j], w, wn * 16 * TN + j * 16 + lr, c, g);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mma(fw[j], fa[i], acc[i][j]);
+            }
+            if (t + 1 < nt) lstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+};
+
+}  // namespace pk

@@ -1,0 +1,269 @@
+// MaskGIT sampling-step kernels (reference phenaki_pytorch.py:478-550):
+//
+//  pk_cfg_mix      : e = null + (cond - null) * scale on the 512-d trunk outputs.  Classifier-free guidance is
+//                    linear in the logits (phenaki_pytorch.py:155-161) and to_logits is linear, so mixing BEFORE
+//                    the vocab head gives the same logits with ONE 65 536-wide GEMM instead of two.
+//  pk_vocab_sample : logits = e @ W^T + b never touch HBM: the GEMM epilogue adds gumbel noise
+//                    (phenaki_pytorch.py:88-93), keeps per-row (best noisy value, index, raw logit) and, when no
+//                    critic is used, the online-softmax (max, sum exp) needed for 1 - softmax[pred] (:547-550);
+//                    one partial per (row, 128-column tile).
+//  pk_vocab_reduce : folds the partials, writes pred ids, ids = where(mask, pred, ids) (:509) and the
+//                    confidence scores where(mask, 1 - p, -1e4).
+//  pk_topk_mask    : mask = top-k(scores) per row (:488-489) and ids = where(mask, mask_id, ids) (:491).
+// Noise: PARITY mode reads U[0,1) from memory (the tests inject the oracle's draws) and uses logf / true
+// division exactly like the reference expression; FAST mode draws U from the counter hash in common.hpp.
+#include "gemm_core.hpp"
+
+namespace pk {
+
+__global__ __launch_bounds__(256) void cfg_mix_kernel(const float* __restrict__ x, int ldx, int nb, int n_tot, int n_prime,
+                                                      const int* __restrict__ rows, int nrows, float scale, int has_null,
+                                                      void* __restrict__ out, int ldo, int out_f32, int D) {
+    // output row r <- logical (b, i): rows ? rows[r] (flat b*n + i over the NON-prime positions) : r
+    const int dv = D >> 2;
+    const int n = n_tot - n_prime;
+    const long total = (long)nrows * dv;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % dv) * 4;
+        const int r = (int)(idx / dv);
+        const int lr = rows ? rows[r] : r;
+        const int b = lr / n, i = lr % n + n_prime;
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + ((size_t)b * n_tot + i) * ldx + c);
+        if (has_null) {
+            const f32x4 nv = *reinterpret_cast<const f32x4*>(x + ((size_t)(nb + b) * n_tot + i) * ldx + c);
+            v = nv + (v - nv) * scale;
+        }
+        if (out_f32) store4(reinterpret_cast<float*>(out) + (size_t)r * ldo + c, v);
+        else store4(reinterpret_cast<bf16*>(out) + (size_t)r * ldo + c, v);
+    }
+}
+
+struct VocabArgs {
+    const float* bias;       // [V]
+    const float* U;          // PARITY: uniform noise [M][V]; FAST: unused
+    const int* rows;         // optional: output row r is logical row rows[r] (noise / partial indexing)
+    float temp;              // max(temperature, 1e-10)
+    uint32_t seed_lo, seed_hi;
+    int need_lse;
+    int ntiles;
+    // partials, SoA [ntiles][M]
+    float* p_val; int* p_idx; float* p_logit; float* p_max; float* p_sum;
+};
+
+template <typename T, bool PARITY>
+__global__ __launch_bounds__(256) void vocab_sample_kernel(const GemmOperands p, const VocabArgs e) {
+    using Tile = GemmTile<T, T, 4, 4>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int m0 = blockIdx.x * Tile::BM, n0 = blockIdx.y * Tile::BN;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    Tile::run(p, m0, n0, smem, acc);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, lr = lane & 15;
+    // LDS scratch (the GEMM stages are dead after run()'s final barrier): [wn][128 rows][5 words]
+    float* red = reinterpret_cast<float*>(smem);
+    const int V = p.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ml = wm * 64 + i * 16 + lr;
+        const int m = m0 + ml;
+        const bool mok = m < p.M;
+        const long lrow = mok ? (e.rows ? e.rows[m] : m) : 0;
+        float best = -INFINITY, blog = 0.f, lmax = -INFINITY;
+        int bidx = 0x7fffffff;
+        float lg[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + g * 4;
+            f32x4 bv = f32x4{0, 0, 0, 0}, uv = f32x4{0.5f, 0.5f, 0.5f, 0.5f};
+            if (n < V) bv = *reinterpret_cast<const f32x4*>(e.bias + n);         // V % 4 == 0 (host check)
+            if (PARITY) { if (mok && n < V) uv = *reinterpret_cast<const f32x4*>(e.U + (size_t)lrow * V + n); }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nn = n + r;
+                const float logit = acc[i][j][r] + bv[r];
+                float noisy;
+                if (PARITY) {
+                    const float gum = -logf(-logf(uv[r] + 1e-10f) + 1e-10f);
+                    noisy = logit / e.temp + gum;
+                } else {
+                    const uint64_t gi = (uint64_t)lrow * (uint64_t)V + (uint64_t)nn;
+                    const float u = uniform24(e.seed_lo, e.seed_hi, (uint32_t)gi, (uint32_t)(gi >> 32));
+                    const float gum = -__logf(-__logf(u + 1e-10f) + 1e-10f);
+                    noisy = logit * (1.0f / e.temp) + gum;
+                }
+                const bool ok = nn < V;
+                lg[j * 4 + r] = ok ? logit : -INFINITY;
+                if (ok && (noisy > best)) { best = noisy; bidx = nn; blog = logit; }   // ascending nn: first max wins
+                if (ok) lmax = fmaxf(lmax, logit);
+            }
+        }
+        float lsum = 0.f;
+        if (e.need_lse) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) lsum += __expf(lg[q] - lmax);              // exp(-inf) = 0 for padding
+        }
+        // combine the 4 lane groups holding the same row
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const float ob = __shfl_xor(best, off, 64), ol = __shfl_xor(blog, off, 64);
+            const int oi = __shfl_xor(bidx, off, 64);
+            if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; blog = ol; }
+            const float om = __shfl_xor(lmax, off, 64), os = __shfl_xor(lsum, off, 64);
+            const float nm = fmaxf(lmax, om);
+            if (e.need_lse) lsum = (lmax == -INFINITY ? 0.f : lsum * __expf(lmax - nm)) + (om == -INFINITY ? 0.f : os * __expf(om - nm));
+            lmax = nm;
+        }
+        if (g == 0) {
+            float* rr = red + ((size_t)wn * 128 + ml) * 5;
+            rr[0] = best; rr[1] = __builtin_bit_cast(float, bidx); rr[2] = blog; rr[3] = lmax; rr[4] = lsum;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int ml = threadIdx.x, m = m0 + ml;
+        if (m < p.M) {
+            const float* a = red + (size_t)ml * 5;
+            const float* b = red + ((size_t)128 + ml) * 5;
+            float best = a[0], blog = a[2], lmax = a[3], lsum = a[4];
+            int bidx = __builtin_bit_cast(int, a[1]);
+            const int oi = __builtin_bit_cast(int, b[1]);
+            if (b[0] > best || (b[0] == best && oi < bidx)) { best = b[0]; bidx = oi; blog = b[2]; }
+            const float nm = fmaxf(lmax, b[3]);
+            if (e.need_lse) lsum = (lmax == -INFINITY ? 0.f : lsum * __expf(lmax - nm)) + (b[3] == -INFINITY ? 0.f : b[4] * __expf(b[3] - nm));
+            lmax = nm;
+            const size_t o = (size_t)blockIdx.y * p.M + m;
+            e.p_val[o] = best; e.p_idx[o] = bidx; e.p_logit[o] = blog; e.p_max[o] = lmax; e.p_sum[o] = lsum;
+        }
+    }
+}
+
+// one thread per row: fold ntiles partials; optionally scatter through rows[] into the (B, n) state
+__global__ __launch_bounds__(256) void vocab_reduce_kernel(const float* __restrict__ p_val, const int* __restrict__ p_idx,
+                                                           const float* __restrict__ p_logit, const float* __restrict__ p_max,
+                                                           const float* __restrict__ p_sum, int ntiles, int M,
+                                                           const int* __restrict__ rows, const unsigned char* __restrict__ mask,
+                                                           long long* __restrict__ ids, long long* __restrict__ pred,
+                                                           float* __restrict__ scores, int need_lse) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float best = -INFINITY, blog = 0.f, lmax = -INFINITY, lsum = 0.f;
+    int bidx = 0x7fffffff;
+    for (int t = 0; t < ntiles; ++t) {
+        const size_t o = (size_t)t * M + m;
+        const float v = p_val[o];
+        const int ix = p_idx[o];
+        if (v > best || (v == best && ix < bidx)) { best = v; bidx = ix; blog = p_logit[o]; }
+        if (need_lse) {
+            const float om = p_max[o], os = p_sum[o];
+            const float nm = fmaxf(lmax, om);
+            lsum = (lmax == -INFINITY ? 0.f : lsum * __expf(lmax - nm)) + (om == -INFINITY ? 0.f : os * __expf(om - nm));
+            lmax = nm;
+        }
+    }
+    const int r = rows ? rows[m] : m;
+    if (pred) pred[r] = bidx;
+    const bool mk = mask ? mask[r] != 0 : true;
+    if (ids && mk) ids[r] = bidx;
+    if (scores && need_lse) scores[r] = mk ? 1.0f - __expf(blog - lmax) / lsum : -1e4f;
+}
+
+// mask = top-k of scores per row (ties: lower index first), ids = where(mask, mask_id, ids)
+__global__ __launch_bounds__(256) void topk_mask_kernel(const float* __restrict__ scores, int n, int k, long long mask_id,
+                                                        unsigned char* __restrict__ mask, long long* __restrict__ ids) {
+    extern __shared__ float sc[];
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < n; i += 256) sc[i] = scores[(size_t)b * n + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float v = sc[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const float w = sc[j];
+            rank += (w > v || (w == v && j < i)) ? 1 : 0;
+        }
+        const bool sel = rank < k;
+        mask[(size_t)b * n + i] = sel ? 1 : 0;
+        if (sel) ids[(size_t)b * n + i] = mask_id;
+    }
+}
+
+}  // namespace pk
+using namespace pk;
+
+static inline int nblocks(long total) { long b = (total + 255) / 256; return (int)(b < 16384 ? (b > 0 ? b : 1) : 16384); }
+#define STREAM(s) reinterpret_cast<hipStream_t>(s)
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int pk_cfg_mix(const float* x, int ldx, int nb, int n_tot, int n_prime, const int* rows, int nrows,
+                          float scale, int has_null, void* out, int ldo, int out_is_f32, int D, void* stream) {
+    if (!x || !out || nb <= 0 || n_tot <= n_prime || n_prime < 0 || nrows <= 0 || D <= 0) return PK_EINVAL;
+    if ((D & 3) || (ldx & 3) || (ldo & 3)) return PK_EALIGN;
+    hipLaunchKernelGGL(cfg_mix_kernel, dim3(nblocks((long)nrows * (D >> 2))), dim3(256), 0, STREAM(stream),
+                       x, ldx, nb, n_tot, n_prime, rows, nrows, scale, has_null, out, ldo, out_is_f32, D);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+extern "C" int pk_vocab_ntiles(int V) { return (V + 127) / 128; }
+
+// workspace: 5 arrays of ntiles*M 4-byte words, passed as one buffer `partials` of 5*ntiles*M words
+extern "C" int pk_vocab_sample(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias,
+                               int M, int V, int D, float temperature, const float* U, const int* rows,
+                               unsigned long long seed, int need_lse, void* partials, void* stream) {
+    if (!A || !W || !bias || !partials || M <= 0 || V <= 0 || D <= 0) return PK_EINVAL;
+    if (dtype != 0 && dtype != 1) return PK_EINVAL;
+    const int eps = dtype == 1 ? 8 : 4;
+    if ((V & 3) || (D % eps) || (lda % eps) || (ldw % eps) || !al16(A) || !al16(W) || !al16(bias) || (U && !al16(U))) return PK_EALIGN;
+    const int ntiles = pk_vocab_ntiles(V);
+    GemmOperands p{A, W, nullptr, lda, ldw, M, V, D};
+    VocabArgs e;
+    e.bias = bias; e.U = U; e.rows = rows;
+    e.temp = temperature > 1e-10f ? temperature : 1e-10f;
+    e.seed_lo = (uint32_t)seed; e.seed_hi = (uint32_t)(seed >> 32);
+    e.need_lse = need_lse; e.ntiles = ntiles;
+    const size_t sz = (size_t)ntiles * M;
+    e.p_val = reinterpret_cast<float*>(partials);
+    e.p_idx = reinterpret_cast<int*>(partials) + sz;
+    e.p_logit = reinterpret_cast<float*>(partials) + 2 * sz;
+    e.p_max = reinterpret_cast<float*>(partials) + 3 * sz;
+    e.p_sum = reinterpret_cast<float*>(partials) + 4 * sz;
+    dim3 grid((M + 127) / 128, ntiles), block(256);
+    hipStream_t s = STREAM(stream);
+    if (dtype == 1) {
+        constexpr int SM = GemmTile<bf16, bf16, 4, 4>::SMEM;
+        if (U) hipLaunchKernelGGL((vocab_sample_kernel<bf16, true>), grid, block, SM, s, p, e);
+        else hipLaunchKernelGGL((vocab_sample_kernel<bf16, false>), grid, block, SM, s, p, e);
+    } else {
+        constexpr int SM = GemmTile<float, float, 4, 4>::SMEM;
+        if (U) hipLaunchKernelGGL((vocab_sample_kernel<float, true>), grid, block, SM, s, p, e);
+        else hipLaunchKernelGGL((vocab_sample_kernel<float, false>), grid, block, SM, s, p, e);
+    }
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+extern "C" int pk_vocab_reduce(const void* partials, int M, int V, const int* rows, const unsigned char* mask,
+                               long long* ids, long long* pred, float* scores, int need_lse, void* stream) {
+    if (!partials || M <= 0 || V <= 0) return PK_EINVAL;
+    const int ntiles = pk_vocab_ntiles(V);
+    const size_t sz = (size_t)ntiles * M;
+    const float* f = reinterpret_cast<const float*>(partials);
+    hipLaunchKernelGGL(vocab_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, STREAM(stream),
+                       f, reinterpret_cast<const int*>(partials) + sz, f + 2 * sz, f + 3 * sz, f + 4 * sz, ntiles, M,
+                       rows, mask, ids, pred, scores, need_lse);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+extern "C" int pk_topk_mask(const float* scores, int B, int n, int k, long long mask_id, unsigned char* mask,
+                            long long* ids, void* stream) {
+    if (!scores || !mask || !ids || B <= 0 || n <= 0 || k < 0 || n > 12288) return PK_EINVAL;
+    hipLaunchKernelGGL(topk_mask_kernel, dim3(B), dim3(256), n * sizeof(float), STREAM(stream), scores, n, k, mask_id, mask, ids);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}

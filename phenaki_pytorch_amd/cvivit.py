@@ -1,0 +1,300 @@
+"""C-ViViT video tokenizer, inference surface of /root/reference/phenaki_pytorch/cvivit.py:226-583, on MI355X kernels.
+
+Same constructor signature, attribute names and state_dict keys as the reference `CViViT`; `forward(...,
+return_only_codebook_ids=True)`, `forward(..., return_recons_only=True)`, `encode`, `decode`,
+`decode_from_codebook_indices` and the shape helpers run here.  The VQGAN training branch
+(discriminator / VGG / losses, cvivit.py:585-671) is out of scope for this build and raises.
+"""
+import copy
+from pathlib import Path
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from .attention import (ContinuousPositionBias, Transformer, compute_dtype_of, exists, linear_weight,
+                        set_compute_dtype)
+from .quantize import LFQ
+
+
+def pair(val):
+    ret = (val, val) if not isinstance(val, tuple) else val
+    assert len(ret) == 2
+    return ret
+
+
+def divisible_by(numer, denom):
+    return (numer % denom) == 0
+
+
+class _Rearrange(nn.Identity):
+    """placeholder keeping the reference's nn.Sequential indices (the einops Rearrange has no parameters;
+    the layout change is fused into pk_patchify_ln / pk_unpatchify)."""
+
+
+class CViViT(nn.Module):
+    def __init__(self, *, dim, codebook_size, image_size, patch_size, temporal_patch_size, spatial_depth,
+                 temporal_depth, discr_base_dim=16, dim_head=64, heads=8, channels=3, use_vgg_and_gan=True,
+                 vgg=None, discr_attn_res_layers=(16,), use_hinge_loss=True, attn_dropout=0., ff_dropout=0.,
+                 lookup_free_quantization=True, lookup_free_quantization_kwargs: dict = {}):
+        super().__init__()
+        self.image_size = pair(image_size)
+        self.patch_size = pair(patch_size)
+        patch_height, patch_width = self.patch_size
+        self.temporal_patch_size = temporal_patch_size
+        self.channels = channels
+        self.dim = dim
+
+        self.spatial_rel_pos_bias = ContinuousPositionBias(dim=dim, heads=heads)
+
+        image_height, image_width = self.image_size
+        assert (image_height % patch_height) == 0 and (image_width % patch_width) == 0
+
+        p1 = channels * patch_width * patch_height
+        p2 = p1 * temporal_patch_size
+        self.to_patch_emb_first_frame = nn.Sequential(_Rearrange(), nn.LayerNorm(p1), nn.Linear(p1, dim), nn.LayerNorm(dim))
+        self.to_patch_emb = nn.Sequential(_Rearrange(), nn.LayerNorm(p2), nn.Linear(p2, dim), nn.LayerNorm(dim))
+
+        spatial_kwargs = dict(dim=dim, dim_head=dim_head, heads=heads, attn_dropout=attn_dropout,
+                              ff_dropout=ff_dropout, causal=False, peg=False)
+        temporal_kwargs = dict(dim=dim, dim_head=dim_head, heads=heads, attn_dropout=attn_dropout,
+                               ff_dropout=ff_dropout, causal=True, peg=True, peg_causal=True)
+
+        self.enc_spatial_transformer = Transformer(depth=spatial_depth, **spatial_kwargs)
+        self.enc_temporal_transformer = Transformer(depth=temporal_depth, **temporal_kwargs)
+
+        self.lookup_free_quantization = lookup_free_quantization
+        if lookup_free_quantization:
+            self.vq = LFQ(dim=dim, codebook_size=codebook_size, **lookup_free_quantization_kwargs)
+        else:
+            raise NotImplementedError('lookup_free_quantization = False (cosine-sim VectorQuantize) is not built yet; '
+                                      'the reference default and every BASELINE config use LFQ')
+
+        self.dec_spatial_transformer = Transformer(depth=spatial_depth, **spatial_kwargs)
+        self.dec_temporal_transformer = Transformer(depth=temporal_depth, **temporal_kwargs)
+
+        self.to_pixels_first_frame = nn.Sequential(nn.Linear(dim, p1), _Rearrange())
+        self.to_pixels = nn.Sequential(nn.Linear(dim, p2), _Rearrange())
+
+        # VQGAN training branch (cvivit.py:336-363) is not part of the inference hot path
+        self.vgg = None
+        self.discr = None
+        self.use_vgg_and_gan = use_vgg_and_gan
+        self.use_hinge_loss = use_hinge_loss
+
+    # ---------------------------------------------------------------- host-side helpers (cvivit.py:365-447)
+
+    def set_compute_dtype(self, name):
+        return set_compute_dtype(self, name)
+
+    def calculate_video_token_mask(self, videos, video_frame_mask):
+        *_, h, w = videos.shape
+        ph, pw = self.patch_size
+        assert torch.all(((video_frame_mask.sum(dim=-1) - 1) % self.temporal_patch_size) == 0), \
+            'number of frames must be divisible by temporal patch size, subtracting off the first frame'
+        first, rest = video_frame_mask[:, :1], video_frame_mask[:, 1:]
+        rest = rest.reshape(rest.shape[0], -1, self.temporal_patch_size)
+        video_mask = torch.cat((first, rest.any(dim=-1)), dim=-1)
+        return video_mask.repeat_interleave((h // ph) * (w // pw), dim=-1)
+
+    def get_video_patch_shape(self, num_frames, include_first_frame=True):
+        patch_frames = 0
+        if include_first_frame:
+            num_frames -= 1
+            patch_frames += 1
+        patch_frames += (num_frames // self.temporal_patch_size)
+        return (patch_frames, *self.patch_height_width)
+
+    @property
+    def image_num_tokens(self):
+        return int(self.image_size[0] / self.patch_size[0]) * int(self.image_size[1] / self.patch_size[1])
+
+    def frames_per_num_tokens(self, num_tokens):
+        tokens_per_frame = self.image_num_tokens
+        assert (num_tokens % tokens_per_frame) == 0, f'number of tokens must be divisible by number of tokens per frame {tokens_per_frame}'
+        assert (num_tokens > 0)
+        pseudo_frames = num_tokens // tokens_per_frame
+        return (pseudo_frames - 1) * self.temporal_patch_size + 1
+
+    def num_tokens_per_frames(self, num_frames, include_first_frame=True):
+        image_num_tokens = self.image_num_tokens
+        total_tokens = 0
+        if include_first_frame:
+            num_frames -= 1
+            total_tokens += image_num_tokens
+        assert (num_frames % self.temporal_patch_size) == 0
+        return total_tokens + int(num_frames / self.temporal_patch_size) * image_num_tokens
+
+    def copy_for_eval(self):
+        device = next(self.parameters()).device
+        for m in self.modules():                      # packed device weights are rebuilt lazily, never copied
+            m.__dict__.pop('_pk_cache', None)
+        vae_copy = copy.deepcopy(self)
+        if vae_copy.use_vgg_and_gan:
+            vae_copy.discr = None
+            vae_copy.vgg = None
+        vae_copy.eval()
+        return vae_copy.to(device)
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        # reference checkpoints may carry the GAN / VGG parts (cvivit.py:35-49, 336-363): not used here
+        sd = {k: v for k, v in state_dict.items() if not (k.startswith('vgg.') or k.startswith('discr.'))}
+        return super().load_state_dict(sd, *args, **kwargs)
+
+    def load(self, path):
+        path = Path(path)
+        assert path.exists()
+        pt = torch.load(str(path))
+        self.load_state_dict(pt)
+
+    @property
+    def patch_height_width(self):
+        return self.image_size[0] // self.patch_size[0], self.image_size[1] // self.patch_size[1]
+
+    # ---------------------------------------------------------------- kernels-backed pieces (2-D f32 token buffers)
+
+    def _patch_embed(self, video):
+        """(B,C,F,H,W) f32 -> tokens (B*T'*h*w, dim) f32 in (b t h w) row order (cvivit.py:542-549)."""
+        dt = compute_dtype_of(self)
+        td = L.tdtype(dt)
+        B, C, F, H, W = video.shape
+        ph, pw = self.patch_size
+        h, w = self.patch_height_width
+        hw = h * w
+        pt = self.temporal_patch_size
+        nt = (F - 1) // pt
+        T = 1 + nt
+        dev = video.device
+        tokens = torch.empty((B * T * hw, self.dim), device=dev, dtype=torch.float32)
+
+        def group(seq, f0, ntg, ptg, goff):
+            ln1, lin, ln2 = seq[1], seq[2], seq[3]
+            P = C * ptg * ph * pw
+            rows = B * ntg * hw
+            patches = torch.empty((rows, P), device=dev, dtype=td)
+            L.patchify_ln(video, f0, ntg, ptg, ph, pw, ln1.weight, ln1.bias, patches, eps=ln1.eps)
+            tmp = torch.empty((rows, self.dim), device=dev, dtype=torch.float32)
+            L.gemm(dt, patches, linear_weight(lin, dt), rows, self.dim, P, C=tmp, bias=lin.bias)
+            L.layernorm(tmp, ln2.weight, ln2.bias, rows, self.dim, out2=tokens, eps=ln2.eps, remap=(ntg * hw, T * hw, goff))
+
+        group(self.to_patch_emb_first_frame, 0, 1, 1, 0)
+        if nt > 0:
+            group(self.to_patch_emb, 1, nt, pt, hw)
+        return tokens, T
+
+    def _spatial(self, transformer, x2d, B, T):
+        h, w = self.patch_height_width
+        bias = self.spatial_rel_pos_bias(h, w)
+        return transformer.run(x2d, B * T, h * w, compute_dtype_of(self), video_shape=(B, T, h, w), attn_bias=bias)
+
+    def _temporal(self, transformer, x2d, B, T):
+        h, w = self.patch_height_width
+        hw = h * w
+        D = x2d.shape[-1]
+        xt = x2d.view(B, T, hw, D).transpose(1, 2).contiguous().view(B * hw * T, D)       # 'b t h w d -> (b h w) t d'
+        # NOTE: video_shape stays (b, t, h, w) although rows are ((b h w), t): the reference's PEG sees that
+        # scrambled view (cvivit.py:456,468-470) and so must we.
+        out = transformer.run(xt, B * hw, T, compute_dtype_of(self), video_shape=(B, T, h, w))
+        return out.view(B, hw, T, D).transpose(1, 2).contiguous().view(B * T * hw, D)
+
+    def _encode2d(self, tokens2d, B, T):
+        x = self._spatial(self.enc_spatial_transformer, tokens2d, B, T)
+        return self._temporal(self.enc_temporal_transformer, x, B, T)
+
+    def _decode2d(self, tokens2d, B, T):
+        """tokens (B*T*h*w, dim) f32 -> video (B, C, 1 + (T-1)*pt, H, W) f32 (cvivit.py:476-516)."""
+        dt = compute_dtype_of(self)
+        x = self._temporal(self.dec_temporal_transformer, tokens2d, B, T)
+        x = self._spatial(self.dec_spatial_transformer, x, B, T)
+        h, w = self.patch_height_width
+        hw = h * w
+        ph, pw = self.patch_size
+        pt = self.temporal_patch_size
+        C = self.channels
+        dev = x.device
+        F = 1 + (T - 1) * pt
+        H, W = self.image_size
+        video = torch.empty((B, C, F, H, W), device=dev, dtype=torch.float32)
+        base = torch.arange(B, device=dev, dtype=torch.int32)[:, None] * (T * hw)
+
+        def group(seq, f0, ntg, ptg, row0):
+            lin = seq[0]
+            P = C * ptg * ph * pw
+            rows = B * ntg * hw
+            idx = (base + torch.arange(row0, row0 + ntg * hw, device=dev, dtype=torch.int32)[None, :]).reshape(-1).contiguous()
+            pix = torch.empty((rows, P), device=dev, dtype=torch.float32)
+            L.gemm(dt, x, linear_weight(lin, dt), rows, P, self.dim, C=pix, bias=lin.bias, a_rows=idx)
+            L.unpatchify(pix, video, f0, ntg, ptg, ph, pw)
+
+        group(self.to_pixels_first_frame, 0, 1, 1, 0)
+        if T > 1:
+            group(self.to_pixels, 1, T - 1, pt, hw)
+        return video
+
+    # ---------------------------------------------------------------- public surface (cvivit.py:437-583)
+
+    def decode_from_codebook_indices(self, indices):
+        L.require_device(indices, 'indices')
+        B = indices.shape[0]
+        hw = self.image_num_tokens
+        flat = indices.reshape(B, -1)
+        assert flat.shape[1] % hw == 0
+        T = flat.shape[1] // hw
+        codes = self.vq.codes_2d(flat.reshape(-1).long())
+        return self._decode2d(codes, B, T)
+
+    def encode(self, tokens):
+        L.require_device(tokens, 'tokens')
+        B, T, h, w, D = tokens.shape
+        out = self._encode2d(tokens.reshape(-1, D).float().contiguous(), B, T)
+        return out.view(B, T, h, w, D)
+
+    def decode(self, tokens):
+        L.require_device(tokens, 'tokens')
+        B = tokens.shape[0]
+        h, w = self.patch_height_width
+        D = tokens.shape[-1]
+        if tokens.ndim == 3:
+            T = tokens.shape[1] // (h * w)
+        else:
+            T = tokens.shape[1]
+        return self._decode2d(tokens.reshape(-1, D).float().contiguous(), B, T)
+
+    def tokenize(self, video, return_proj=False):
+        """ids (B, T', h, w) int64 [and the pre-sign LFQ projection (B, n, cd), used by the parity margin audit]."""
+        tokens, T = self._patch_embed(video)
+        B = video.shape[0]
+        tokens = self._encode2d(tokens, B, T)
+        h, w = self.patch_height_width
+        if return_proj:
+            ids, proj = self.vq.encode_ids(tokens, return_proj=True)
+            return ids.view(B, T, h, w), proj.view(B, T * h * w, -1)
+        return self.vq.encode_ids(tokens).view(B, T, h, w)
+
+    @torch.no_grad()
+    def forward(self, video, mask=None, return_recons=False, return_recons_only=False, return_discr_loss=False,
+                apply_grad_penalty=True, return_only_codebook_ids=False):
+        assert video.ndim in {4, 5}
+        is_image = video.ndim == 4
+        if is_image:
+            video = video.unsqueeze(2)
+            assert not exists(mask)
+        b, c, f, *image_dims = video.shape
+        assert tuple(image_dims) == self.image_size
+        assert not exists(mask) or mask.shape[-1] == f
+        assert divisible_by(f - 1, self.temporal_patch_size), \
+            f'number of frames ({f}) minus one ({f - 1}) must be divisible by temporal patch size ({self.temporal_patch_size})'
+        L.require_device(video, 'video')
+        video = video.float().contiguous()
+
+        if return_only_codebook_ids:
+            return self.tokenize(video)
+
+        if not return_recons_only:
+            raise NotImplementedError('the VQGAN training losses (cvivit.py:585-671) are outside the MI355X inference build; '
+                                      'use return_only_codebook_ids=True or return_recons_only=True')
+        tokens, T = self._patch_embed(video)
+        tokens = self._encode2d(tokens, b, T)
+        ids = self.vq.encode_ids(tokens)
+        recon = self._decode2d(self.vq.codes_2d(ids), b, T)
+        return recon.squeeze(2) if is_image else recon

@@ -1,0 +1,458 @@
+"""MaskGit / TokenCritic / SelfCritic / Phenaki / make_video with the reference's surfaces
+(/root/reference/phenaki_pytorch/phenaki_pytorch.py:105-560, 691-714) on the MI355X kernels.
+
+What changes relative to the reference's op sequence (results are the same up to f32 rounding):
+  * cond and null passes of classifier-free guidance run as ONE batch of 2B sequences;
+  * CFG is applied to the 512-d trunk output before the (linear) vocab head, so the 65 536-wide GEMM runs once;
+  * the sampler never materialises logits: gumbel-argmax / softmax confidence live in the GEMM epilogue;
+  * cross-attention K/V of the (step-invariant) text context and the position bias are computed once per sample();
+  * the mask schedule k_s is data independent and precomputed on the host (no per-step .item() sync).
+`Phenaki.forward` (the training loss, phenaki_pytorch.py:562-687) is outside this inference build.
+"""
+import math
+from functools import partial
+from typing import List
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from .attention import (ContinuousPositionBias, Transformer, compute_dtype_of, exists, default, linear_weight,
+                        set_compute_dtype)
+from .cvivit import CViViT
+from .t5 import t5_encode_text, get_encoded_dim, DEFAULT_T5_NAME
+
+
+def cast_tuple(val, length=1):
+    return val if isinstance(val, tuple) else (val,) * length
+
+
+def eval_decorator(fn):
+    def inner(model, *args, **kwargs):
+        was_training = model.training
+        model.eval()
+        out = fn(model, *args, **kwargs)
+        model.train(was_training)
+        return out
+    return inner
+
+
+def uniform(shape, device):
+    return torch.zeros(shape, device=device).float().uniform_(0, 1)
+
+
+def prob_mask_like(shape, prob, device):
+    if prob == 1:
+        return torch.ones(shape, device=device, dtype=torch.bool)
+    elif prob == 0:
+        return torch.zeros(shape, device=device, dtype=torch.bool)
+    return torch.zeros(shape, device=device).float().uniform_(0, 1) < prob
+
+
+def mask_schedule(num_tokens, steps):
+    """k_s = round(n * cos(pi/2 * s/steps)).clamp(1) in f32, s = 1..steps-1 (phenaki_pytorch.py:484-486), on the host."""
+    ks = [None]
+    for s in range(1, steps):
+        time = torch.full((1,), s / steps)
+        ks.append(int((num_tokens * torch.cos(time * math.pi * 0.5)).round().long().clamp(min=1).item()))
+    return ks
+
+
+def _u8(mask):
+    return None if mask is None else mask.to(torch.uint8).contiguous()
+
+
+class _TokenTrunk(nn.Module):
+    """shared plumbing of MaskGit / TokenCritic: ids -> embeddings -> Transformer -> norm_out rows."""
+
+    def _embed(self, ids2d):
+        S, n = ids2d.shape
+        D = self.token_emb.weight.shape[1]
+        x = torch.empty((S * n, D), device=ids2d.device, dtype=torch.float32)
+        L.embed(ids2d.contiguous(), self.token_emb.weight, self.pos_emb.weight, x, S * n, n, D)
+        return x
+
+    def _trunk(self, ids2d, video_patch_shape, *, context=None, text_mask=None, video_mask=None, attn_bias=None,
+               use_cross=True, kv_cache=None):
+        """ids2d (S, n) int64 -> norm_out(transformer(emb)) as (S*n, D) f32"""
+        L.require_device(ids2d, 'token ids')
+        S, n = ids2d.shape
+        x = self._embed(ids2d.long())
+        ctx2, n_ctx = None, None
+        if use_cross and exists(context):
+            n_ctx = context.shape[1]
+            ctx2 = context.reshape(S * n_ctx, context.shape[-1]).float().contiguous()
+        return self.transformer.run(x, S, n, compute_dtype_of(self), video_shape=(S, *video_patch_shape),
+                                    attn_bias=attn_bias, context2d=ctx2, n_ctx=n_ctx, self_attn_mask=_u8(video_mask),
+                                    cross_attn_context_mask=_u8(text_mask) if ctx2 is not None else None,
+                                    kv_cache=kv_cache)
+
+    def set_compute_dtype(self, name):
+        return set_compute_dtype(self, name)
+
+
+class MaskGit(_TokenTrunk):
+    def __init__(self, *, dim, num_tokens, max_seq_len, gradient_shrink_alpha=0.1, heads=8, dim_head=64,
+                 unconditional=False, attn_dropout=0., ff_dropout=0., **kwargs):
+        super().__init__()
+        self.dim = dim
+        self.mask_id = num_tokens
+        self.unconditional = unconditional
+        self.token_emb = nn.Embedding(num_tokens + 1, dim)      # last token is used as mask_id
+        self.max_seq_len = max_seq_len
+        self.pos_emb = nn.Embedding(max_seq_len, dim)
+        self.gradient_shrink_alpha = gradient_shrink_alpha      # identity in value (forward only)
+        self.continuous_pos_bias = ContinuousPositionBias(dim=dim_head, heads=heads, num_dims=3)
+        self.transformer = Transformer(dim=dim, attn_num_null_kv=2, has_cross_attn=not self.unconditional,
+                                       dim_head=dim_head, heads=heads, attn_dropout=attn_dropout,
+                                       ff_dropout=ff_dropout, peg=True, **kwargs)
+        self.to_logits = nn.Linear(dim, num_tokens)
+
+    def _prepare(self, x, text_mask, video_patch_shape):
+        assert x.ndim in {2, 4}, 'video token ids must be of shape (batch, seq) or (batch, frame, height, width)'
+        if x.ndim == 4:
+            video_patch_shape = x.shape[1:]
+            x = x.reshape(x.shape[0], -1)
+        b, n = x.shape
+        assert exists(video_patch_shape), 'video patch shape must be given'
+        assert n <= self.max_seq_len, f'the video token sequence length you are passing in ({n}) is greater than the `max_seq_len` ({self.max_seq_len}) set on your `MaskGit`'
+        return x, tuple(video_patch_shape)
+
+    def embeds(self, x, *, video_patch_shape, context=None, text_mask=None, video_mask=None, null_rows=0, kv_cache=None):
+        """norm_out rows (S*n, D) f32 for S = x.shape[0] sequences; the LAST `null_rows` sequences get an all-False
+        text mask (cond_drop_prob = 1, phenaki_pytorch.py:188-190)."""
+        S, n = x.shape
+        if exists(context) and not exists(text_mask):
+            text_mask = torch.ones(context.shape[:2], device=x.device, dtype=torch.bool)
+        if exists(text_mask) and null_rows:
+            text_mask = text_mask.clone()
+            text_mask[S - null_rows:] = False
+        bias = self.continuous_pos_bias(*video_patch_shape)
+        return self._trunk(x, video_patch_shape, context=context, text_mask=text_mask, video_mask=video_mask,
+                           attn_bias=bias, use_cross=not self.unconditional, kv_cache=kv_cache)
+
+    def _logits(self, e2d, rows, S, n):
+        dt = compute_dtype_of(self)
+        V = self.to_logits.weight.shape[0]
+        out = torch.empty((rows, V), device=e2d.device, dtype=torch.float32)
+        L.gemm(dt, e2d, linear_weight(self.to_logits, dt), rows, V, self.dim, C=out, bias=self.to_logits.bias)
+        return out.view(S, n, V)
+
+    @torch.no_grad()
+    def forward_with_cond_scale(self, *args, cond_scale=3, **kwargs):
+        if cond_scale == 1:
+            return self.forward(*args, cond_drop_prob=0., **kwargs)
+        x = args[0]
+        kwargs = dict(kwargs)
+        x, vps = self._prepare(x, kwargs.get('text_mask'), kwargs.pop('video_patch_shape', None))
+        b, n = x.shape
+        context, text_mask, video_mask = kwargs.get('context'), kwargs.get('text_mask'), kwargs.get('video_mask')
+        rep = lambda t: None if t is None else torch.cat((t, t), dim=0)
+        e = self.embeds(torch.cat((x, x), dim=0), video_patch_shape=vps, context=rep(context), text_mask=rep(text_mask),
+                        video_mask=rep(video_mask), null_rows=b)
+        dt = compute_dtype_of(self)
+        mixed = torch.empty((b * n, self.dim), device=x.device, dtype=L.tdtype(dt))
+        L.cfg_mix(e, b, n, 0, None, b * n, float(cond_scale), True, mixed, self.dim)
+        return self._logits(mixed, b * n, b, n)
+
+    @torch.no_grad()
+    def forward(self, x, cond_drop_prob=0., text_mask=None, video_mask=None, video_patch_shape=None,
+                return_embeds=False, **kwargs):
+        x, vps = self._prepare(x, text_mask, video_patch_shape)
+        b, n = x.shape
+        context = kwargs.pop('context', None)
+        assert not kwargs, f'unexpected arguments {sorted(kwargs)}'
+        if exists(context) and not exists(text_mask):
+            text_mask = torch.ones(context.shape[:2], device=x.device, dtype=torch.bool)
+        if cond_drop_prob > 0 and exists(text_mask):
+            keep_mask = prob_mask_like((b,), 1 - cond_drop_prob, device=x.device)
+            text_mask = keep_mask[:, None] & text_mask
+        e = self.embeds(x, video_patch_shape=vps, context=context, text_mask=text_mask, video_mask=video_mask)
+        if return_embeds:
+            return e.view(b, n, self.dim)
+        return self._logits(e, b * n, b, n)
+
+
+class TokenCritic(_TokenTrunk):
+    def __init__(self, *, dim, num_tokens, max_seq_len, has_cross_attn=False, attn_dropout=0., ff_dropout=0., **kwargs):
+        super().__init__()
+        self.has_cross_attn = has_cross_attn
+        self.mask_id = num_tokens
+        self.token_emb = nn.Embedding(num_tokens + 1, dim)
+        self.pos_emb = nn.Embedding(max_seq_len, dim)
+        self.transformer = Transformer(dim=dim, peg=True, attn_dropout=attn_dropout, ff_dropout=ff_dropout,
+                                       has_cross_attn=has_cross_attn, **kwargs)
+        self.to_logits = nn.Sequential(nn.Linear(dim, 1), nn.Identity())
+
+    def head(self):
+        lin = self.to_logits[0]
+        return lin.weight.reshape(-1), lin.bias
+
+    def embeds(self, x, *, video_patch_shape, context=None, text_mask=None, video_mask=None, null_rows=0, kv_cache=None):
+        S = x.shape[0]
+        if exists(context) and not exists(text_mask):
+            text_mask = torch.ones(context.shape[:2], device=x.device, dtype=torch.bool)
+        if exists(text_mask) and exists(context) and null_rows:
+            text_mask = text_mask.clone()
+            text_mask[S - null_rows:] = False
+        return self._trunk(x, video_patch_shape, context=context, text_mask=text_mask, video_mask=video_mask,
+                           use_cross=self.has_cross_attn, kv_cache=kv_cache)
+
+    def _scores(self, x, video_patch_shape, context, text_mask, video_mask, cond_scale, with_null):
+        b, n = x.shape
+        rep = lambda t: None if t is None else torch.cat((t, t), dim=0)
+        if with_null:
+            e = self.embeds(torch.cat((x, x), dim=0), video_patch_shape=video_patch_shape, context=rep(context),
+                            text_mask=rep(text_mask), video_mask=rep(video_mask), null_rows=b)
+        else:
+            e = self.embeds(x, video_patch_shape=video_patch_shape, context=context, text_mask=text_mask, video_mask=video_mask)
+        w, bias = self.head()
+        out = torch.empty((b, n), device=x.device, dtype=torch.float32)
+        L.critic_head(e, w, bias, e.shape[1], b, n, 0, with_null, float(cond_scale), None, 0., out)
+        return out
+
+    @staticmethod
+    def _flatten(x, video_patch_shape):
+        if exists(video_patch_shape):
+            vps = tuple(video_patch_shape)
+        else:
+            vps = tuple(x.shape[1:])
+        return x.reshape(x.shape[0], -1), vps
+
+    @torch.no_grad()
+    def forward_with_cond_scale(self, *args, cond_scale=3, **kwargs):
+        kwargs = dict(kwargs)
+        x, vps = self._flatten(args[0], kwargs.pop('video_patch_shape', None))
+        context = kwargs.get('context')
+        with_null = cond_scale != 1 and exists(context)      # without context both passes are identical
+        return self._scores(x, vps, context, kwargs.get('text_mask'), kwargs.get('video_mask'), cond_scale, with_null)
+
+    @torch.no_grad()
+    def forward(self, x, text_mask=None, cond_drop_prob=None, context=None, video_mask=None, video_patch_shape=None, **kwargs):
+        x, vps = self._flatten(x, video_patch_shape)
+        b = x.shape[0]
+        if exists(context) and not exists(text_mask):
+            text_mask = torch.ones(context.shape[:2], device=x.device, dtype=torch.bool)
+        if exists(context) and exists(cond_drop_prob) and cond_drop_prob > 0:
+            keep_mask = prob_mask_like((b,), 1 - cond_drop_prob, device=x.device)
+            text_mask = keep_mask[:, None] & text_mask
+        return self._scores(x, vps, context, text_mask, video_mask, 1., False)
+
+
+class SelfCritic(nn.Module):
+    """phenaki_pytorch.py:306-336 : MaskGit embeddings -> Linear(dim, 1)."""
+
+    def __init__(self, maskgit: MaskGit):
+        super().__init__()
+        self.maskgit = maskgit
+        self.to_pred = nn.Sequential(nn.Linear(maskgit.dim, 1), nn.Identity())
+        self.has_cross_attn = not maskgit.unconditional
+
+    def head(self):
+        lin = self.to_pred[0]
+        return lin.weight.reshape(-1), lin.bias
+
+    def embeds(self, x, **kw):
+        return self.maskgit.embeds(x, **kw)
+
+    @torch.no_grad()
+    def forward_with_cond_scale(self, *args, cond_scale=3, **kwargs):
+        kwargs = dict(kwargs)
+        x, vps = self.maskgit._prepare(args[0], kwargs.get('text_mask'), kwargs.pop('video_patch_shape', None))
+        b, n = x.shape
+        context, text_mask, video_mask = kwargs.get('context'), kwargs.get('text_mask'), kwargs.get('video_mask')
+        with_null = cond_scale != 1
+        rep = lambda t: None if t is None else torch.cat((t, t), dim=0)
+        if with_null:
+            e = self.maskgit.embeds(torch.cat((x, x), dim=0), video_patch_shape=vps, context=rep(context),
+                                    text_mask=rep(text_mask), video_mask=rep(video_mask), null_rows=b)
+        else:
+            e = self.maskgit.embeds(x, video_patch_shape=vps, context=context, text_mask=text_mask, video_mask=video_mask)
+        w, bias = self.head()
+        out = torch.empty((b, n), device=x.device, dtype=torch.float32)
+        L.critic_head(e, w, bias, e.shape[1], b, n, 0, with_null, float(cond_scale), None, 0., out)
+        return out
+
+    @torch.no_grad()
+    def forward(self, x, *args, **kwargs):
+        embeds = self.maskgit(x, *args, return_embeds=True, **kwargs)
+        b, n, d = embeds.shape
+        w, bias = self.head()
+        out = torch.empty((b, n), device=x.device, dtype=torch.float32)
+        L.critic_head(embeds.reshape(b * n, d), w, bias, d, b, n, 0, False, 1., None, 0., out)
+        return out
+
+
+class Phenaki(nn.Module):
+    def __init__(self, *, maskgit: MaskGit, cvivit: CViViT, critic=None, steps=18, t5_name=DEFAULT_T5_NAME,
+                 sample_temperature=0., text_embed_dim=None, cond_drop_prob=0.25, max_text_len=128,
+                 self_token_critic=False, critic_loss_weight=1., critic_noise_anneal_schedule='decay',
+                 critic_train_sample_temperature=1.):
+        super().__init__()
+        assert isinstance(maskgit, MaskGit) and isinstance(cvivit, CViViT)
+        assert critic is None or isinstance(critic, (TokenCritic, SelfCritic))
+        self.cvivit = cvivit.copy_for_eval()
+        self.maskgit = maskgit
+        self.unconditional = maskgit.unconditional
+        self.mask_id = maskgit.mask_id
+        assert not (self_token_critic and exists(critic))
+        if self_token_critic:
+            critic = SelfCritic(maskgit)
+        if exists(critic):
+            critic = critic.eval()
+        assert not exists(critic) or self_token_critic or (not maskgit.unconditional) == critic.has_cross_attn
+        self.critic = critic
+        self.critic_noise_anneal_schedule = critic_noise_anneal_schedule
+        self.critic_loss_weight = critic_loss_weight
+        self.critic_train_sample_temperature = critic_train_sample_temperature
+        self.steps = steps
+        self.sample_temperature = sample_temperature
+        text_embed_dim = default(text_embed_dim, get_encoded_dim(t5_name) if text_embed_dim is None else None)
+        self.encode_texts = partial(t5_encode_text, name=t5_name)
+        self.text_embed_dim = text_embed_dim
+        self.max_text_len = max_text_len
+        assert cond_drop_prob > 0.
+        self.cond_drop_prob = cond_drop_prob
+
+    def set_compute_dtype(self, name):
+        return set_compute_dtype(self, name)
+
+    def sample_images(self, *, texts=None, batch_size=1, cond_scale=3., starting_temperature=0.9, noise_K=1.):
+        video = self.sample(texts=texts, num_frames=1, cond_scale=cond_scale, starting_temperature=starting_temperature,
+                            noise_K=noise_K)
+        return video.squeeze(2)
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError('Phenaki.forward (the training loss, phenaki_pytorch.py:562-687) is outside the MI355X '
+                                  'inference build; .sample / .sample_images / make_video are the supported surfaces')
+
+    @eval_decorator
+    @torch.no_grad()
+    def sample(self, *, num_frames, texts=None, prime_frames=None, batch_size=1, cond_scale=3.,
+               starting_temperature=0.9, noise_K=1., _noise_fn=None, _trace=None, _return_ids=False):
+        """phenaki_pytorch.py:418-560.  `_noise_fn(kind, step, shape)` (tests) injects the U[0,1) draws of the
+        reference run ('gumbel' (B,n,V) and 'critic' (B,n), device f32 tensors); without it the gumbel noise comes
+        from the in-kernel counter hash seeded from torch's default generator."""
+        device = next(self.parameters()).device
+        L.require_device(next(self.parameters()), 'Phenaki parameters')
+        mg, critic = self.maskgit, self.critic
+        dt = compute_dtype_of(mg)
+
+        has_prime = exists(prime_frames)
+        prime_token_ids = None
+        prime_token_length = 0
+        prime_num_frames = 0
+        if has_prime:
+            prime_token_ids = self.cvivit(prime_frames, return_only_codebook_ids=True)
+            prime_token_ids = prime_token_ids.reshape(prime_token_ids.shape[0], -1)
+            prime_token_length = prime_token_ids.shape[-1]
+            prime_num_frames = prime_frames.shape[2]
+
+        num_tokens = self.cvivit.num_tokens_per_frames(num_frames, include_first_frame=not has_prime)
+
+        text_embeds = text_mask = None
+        if exists(texts):
+            if isinstance(texts, str):
+                texts = [texts]
+            text_embeds = self.encode_texts(texts, output_device=device)
+            text_embeds = text_embeds.to(device).float()
+            text_mask = torch.any(text_embeds != 0, dim=-1)
+            batch_size = len(texts)
+
+        patch_shape = self.cvivit.get_video_patch_shape(num_frames + prime_num_frames, include_first_frame=True)
+        B, n = batch_size, num_tokens
+        n_tot = n + prime_token_length
+        V = mg.to_logits.weight.shape[0]
+        D = mg.dim
+
+        ids = torch.full((B, n), self.mask_id, device=device, dtype=torch.int64)
+        mask = torch.ones((B, n), device=device, dtype=torch.uint8)
+        scores = torch.empty((B, n), device=device, dtype=torch.float32)
+        pred = torch.empty((B, n), device=device, dtype=torch.int64)
+        have_scores = False
+        ks = mask_schedule(n, self.steps)
+
+        has_ctx = exists(text_embeds) and not mg.unconditional
+        with_null = has_ctx and cond_scale != 1
+        rep = lambda t: None if t is None else (torch.cat((t, t), dim=0) if with_null else t)
+        ctx_r, tm_r = rep(text_embeds) if has_ctx else None, rep(text_mask) if has_ctx else None
+        mg_cache, cr_cache = {}, {}
+        w_logits = linear_weight(mg.to_logits, dt)
+        partials = torch.empty((5 * L.vocab_ntiles(V) * B * n,), device=device, dtype=torch.float32)
+        mixed = torch.empty((B * n, D), device=device, dtype=L.tdtype(dt))
+        seed_base = int(torch.randint(0, 2 ** 62, (1,)).item()) if _noise_fn is None else 0
+        need_lse = not exists(critic)
+
+        for step in range(self.steps):
+            is_first_step = step == 0
+            is_last_step = step == (self.steps - 1)
+            steps_til_x0 = self.steps - (step + 1)
+
+            if not is_first_step and have_scores:
+                L.topk_mask(scores, B, n, ks[step], self.mask_id, mask, ids)     # mask + ids = where(mask, mask_id, ids)
+
+            rec = None
+            if _trace is not None:
+                rec = dict(step=step, masked_ids=ids.clone(), mask=mask.bool().clone())
+
+            inp = ids if not has_prime else torch.cat((prime_token_ids, ids), dim=-1)
+            e = mg.embeds(rep(inp), video_patch_shape=patch_shape, context=ctx_r, text_mask=tm_r,
+                          null_rows=B if with_null else 0, kv_cache=mg_cache)
+            L.cfg_mix(e, B, n_tot, prime_token_length, None, B * n, float(cond_scale), with_null, mixed, D)
+
+            temperature = starting_temperature * (steps_til_x0 / self.steps)
+            U = _noise_fn('gumbel', step, (B, n, V)) if _noise_fn is not None else None
+            L.vocab_sample(dt, mixed, w_logits, mg.to_logits.bias, B * n, V, D, float(temperature), U, None,
+                           (seed_base + step * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF, need_lse, partials)
+            L.vocab_reduce(partials, B * n, V, None, mask, ids, pred, scores if need_lse else None, need_lse)
+            if rec is not None:
+                rec.update(pred=pred.clone(), ids=ids.clone())
+
+            if not is_last_step:
+                if exists(critic):
+                    cin = ids if not has_prime else torch.cat((prime_token_ids, ids), dim=-1)
+                    c_has_ctx = exists(text_embeds) and critic.has_cross_attn
+                    c_null = c_has_ctx and cond_scale != 1 if not isinstance(critic, SelfCritic) else cond_scale != 1
+                    crep = lambda t: None if t is None else (torch.cat((t, t), dim=0) if c_null else t)
+                    ce = critic.embeds(crep(cin), video_patch_shape=patch_shape,
+                                       context=crep(text_embeds) if c_has_ctx else None,
+                                       text_mask=crep(text_mask) if c_has_ctx else None,
+                                       null_rows=B if c_null else 0, kv_cache=cr_cache)
+                    if self.critic_noise_anneal_schedule == 'fixed':
+                        noise_multiplier = 1.
+                    elif self.critic_noise_anneal_schedule == 'decay':
+                        noise_multiplier = steps_til_x0 / self.steps
+                    elif self.critic_noise_anneal_schedule == 'increase':
+                        noise_multiplier = (step + 1) / self.steps
+                    else:
+                        raise ValueError('invalid critic noise anneal schedule name')
+                    u = _noise_fn('critic', step, (B, n)) if _noise_fn is not None else uniform((B, n), device)
+                    w, bias = critic.head()
+                    L.critic_head(ce, w, bias, ce.shape[1], B, n_tot, prime_token_length, c_null,
+                                  float(cond_scale), u.contiguous(), float(noise_K * noise_multiplier), scores)
+                have_scores = True
+                if rec is not None:
+                    rec['scores'] = scores.clone()
+            if rec is not None:
+                _trace.append(rec)
+
+        full = ids if not has_prime else torch.cat((prime_token_ids, ids), dim=-1)
+        video = self.cvivit.decode_from_codebook_indices(full)
+        if has_prime:
+            video = video[:, :, prime_num_frames:]
+        return (video, ids) if _return_ids else video
+
+
+def make_video(phenaki: Phenaki, texts: List[str], num_frames, prime_lengths):
+    """phenaki_pytorch.py:691-714 : autoregressive scene chaining with K primed frames."""
+    num_scenes = len(texts)
+    num_frames = cast_tuple(num_frames, num_scenes)
+    prime_lengths = cast_tuple(prime_lengths, num_scenes - 1)
+    prime_lengths = (*prime_lengths, 0)       # last scene needs no priming
+    video_prime = None
+    scenes = []
+    for text, scene_num_frames, next_scene_prime_length in zip(texts, num_frames, prime_lengths):
+        video = phenaki.sample(texts=text, prime_frames=video_prime, num_frames=scene_num_frames)
+        scenes.append(video)
+        video_prime = video[:, :, -next_scene_prime_length:]
+    return torch.cat(scenes, dim=2), scenes

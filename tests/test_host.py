@@ -1,0 +1,177 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/phenaki_hip.h declares, the module tree
+reproduces the reference's state_dict contract, host-side logic (shape helpers, mask schedule, asserts, sharding),
+and the world_size-2 gloo path of the batch-sharded sampler.  No kernel is launched here."""
+import json
+import os
+import re
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import phenaki_oracle as O
+from oracle.configs import TINY, FULL
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def built_lib():
+    from phenaki_pytorch_amd import build, _lib
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    from phenaki_pytorch_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'phenaki_hip.h')).read()
+    declared = set(re.findall(r'^int (pk_\w+)\(', header, flags=re.M))
+    assert len(declared) >= 18
+    assert declared == set(_lib.SIGNATURES), f'header / binding mismatch: {declared ^ set(_lib.SIGNATURES)}'
+    for name in declared:
+        assert hasattr(built_lib, name), f'{name} is declared but not exported'
+    # argument counts of the ctypes table follow the header
+    for name in declared:
+        proto = re.search(r'^int ' + name + r'\((.*?)\);', header, flags=re.M | re.S).group(1)
+        nargs = len([a for a in proto.split(',') if a.strip()])
+        assert nargs == len(_lib.SIGNATURES[name]), f'{name}: header has {nargs} args, binding {len(_lib.SIGNATURES[name])}'
+
+
+def test_pure_host_entry_points(built_lib):
+    from phenaki_pytorch_amd import _lib
+    assert _lib.vocab_ntiles(65536) == 512 and _lib.vocab_ntiles(256) == 2
+    assert _lib.attn_pads(576, 576, 0) == (576, 576)
+    assert _lib.attn_pads(9, 9, 0) == (16, 32)
+    assert _lib.attn_pads(64, 12, 2) == (64, 32)
+    assert _lib.attn_pads(640, 640, 0) == (640, 640)
+    with pytest.raises(RuntimeError, match='PK_EINVAL'):
+        _lib.attn_pads(0, 5, 0)
+
+
+def test_no_cpu_fallback():
+    import phenaki_pytorch_amd as P
+    cv = P.CViViT(use_vgg_and_gan=False, **TINY['cvivit'])
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        cv(torch.randn(1, 3, 5, 64, 64), return_only_codebook_ids=True)
+    # the product never imports the oracle (test infrastructure only)
+    pkg = os.path.join(ROOT, 'phenaki_pytorch_amd')
+    for f in os.listdir(pkg):
+        if f.endswith('.py'):
+            src = open(os.path.join(pkg, f)).read()
+            assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), f'{f} imports the oracle'
+
+
+@pytest.mark.parametrize('tag,cfgs', [('tiny', TINY), ('full', FULL)])
+def test_state_dict_contract(golden_dir, tag, cfgs):
+    import phenaki_pytorch_amd as P
+    keys = json.load(open(os.path.join(golden_dir, 'state_dict_keys.json')))
+    with torch.device('meta'):
+        mods = dict(cvivit=P.CViViT(use_vgg_and_gan=False, **cfgs['cvivit']), maskgit=P.MaskGit(**cfgs['maskgit']),
+                    critic=P.TokenCritic(**cfgs['critic']))
+    for kind, m in mods.items():
+        ref = keys[f'{tag}.{kind}']
+        got = {k: [list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()}
+        assert got == ref, f'{kind}: {set(got) ^ set(ref)}'
+
+
+def test_reference_checkpoint_with_gan_keys_loads():
+    import phenaki_pytorch_amd as P
+    cv = P.CViViT(use_vgg_and_gan=False, **TINY['cvivit'])
+    sd = dict(cv.state_dict())
+    sd['discr.blocks.0.weight'] = torch.zeros(3)
+    sd['vgg.features.0.weight'] = torch.zeros(3)
+    cv.load_state_dict(sd)
+
+
+def test_shape_helpers_and_schedule():
+    import phenaki_pytorch_amd as P
+    from phenaki_pytorch_amd.phenaki import mask_schedule
+    cv = P.CViViT(use_vgg_and_gan=False, **{**TINY['cvivit'], 'image_size': 256, 'patch_size': 32})
+    assert cv.image_num_tokens == 64 and cv.patch_height_width == (8, 8)
+    assert cv.get_video_patch_shape(17) == (9, 8, 8)
+    assert cv.get_video_patch_shape(19 + 5) == (12, 8, 8)
+    assert cv.num_tokens_per_frames(17) == 576
+    assert cv.num_tokens_per_frames(14, include_first_frame=False) == 448
+    with pytest.raises(AssertionError):
+        cv.num_tokens_per_frames(16)
+    assert mask_schedule(576, 18)[1:] == [574, 567, 556, 541, 522, 499, 472, 441, 407, 370, 330, 288, 243, 197, 149, 100, 50]
+    assert mask_schedule(448, 18)[1:] == [446, 441, 433, 421, 406, 388, 367, 343, 317, 288, 257, 224, 189, 153, 116, 78, 39]
+    assert mask_schedule(576, 18) == O.mask_schedule(576, 18)
+    fm = torch.ones(2, 5, dtype=torch.bool)
+    fm[1, 3:] = False
+    tm = cv.calculate_video_token_mask(torch.zeros(2, 3, 5, 256, 256), fm)
+    assert tm.shape == (2, 3 * 64) and tm[0].all() and tm[1, :128].all() and not tm[1, 128:].any()
+
+
+def test_phenaki_constructor_contract():
+    import phenaki_pytorch_amd as P
+    cv = P.CViViT(use_vgg_and_gan=False, **TINY['cvivit'])
+    mg = P.MaskGit(**TINY['maskgit'])
+    cr = P.TokenCritic(**TINY['critic'])
+    ph = P.Phenaki(maskgit=mg, cvivit=cv, critic=cr)
+    assert ph.text_embed_dim == 768 and ph.steps == 18 and ph.mask_id == 256
+    assert ph.cvivit is not cv and not ph.cvivit.training           # copy_for_eval (phenaki_pytorch.py:361)
+    with pytest.raises(AssertionError):
+        P.Phenaki(maskgit=mg, cvivit=cv, critic=P.TokenCritic(**{**TINY['critic'], 'has_cross_attn': False}))
+    with pytest.raises(AssertionError):
+        P.Phenaki(maskgit=mg, cvivit=cv, cond_drop_prob=0.)
+    with pytest.raises(AssertionError):
+        mg(torch.zeros(1, 3, dtype=torch.long))                     # video patch shape must be given
+    with pytest.raises(AssertionError):
+        mg(torch.zeros(1, 500, dtype=torch.long), video_patch_shape=(5, 10, 10))   # n > max_seq_len
+    with pytest.raises(NotImplementedError):
+        ph(torch.zeros(1))
+
+
+def test_shard_batch_partitions():
+    from phenaki_pytorch_amd.dist import shard_batch
+    for n, ws in [(32, 8), (8, 8), (10, 4), (3, 2), (7, 3)]:
+        parts = [shard_batch(n, r, ws) for r in range(ws)]
+        assert parts[0][0] == 0 and parts[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+        assert max(h - l for l, h in parts) - min(h - l for l, h in parts) <= 1
+
+
+class _FakePhenaki:
+    """stands in for the GPU sampler: the 'video' encodes which text produced it, so the gather order is checkable."""
+
+    def sample(self, *, num_frames, texts=None, prime_frames=None, batch_size=1, **kw):
+        vals = torch.tensor([float(t) for t in texts])
+        v = vals[:, None, None, None, None].expand(len(texts), 3, num_frames, 4, 4).clone()
+        if prime_frames is not None:
+            v = v + prime_frames[:, :, -1:].mean(dim=(1, 2, 3, 4), keepdim=True) * 0.001
+        return v
+
+
+def _worker(rank, ws, port, n_items, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=ws)
+    sys.path.insert(0, ROOT)
+    from phenaki_pytorch_amd.dist import sample_sharded, make_video_sharded, shard_batch
+    texts = [str(i) for i in range(n_items)]
+    full = sample_sharded(_FakePhenaki(), num_frames=5, texts=texts)
+    local = sample_sharded(_FakePhenaki(), num_frames=5, texts=texts, gather=False)
+    lo, hi = shard_batch(n_items, rank, ws)
+    ok = full.shape == (n_items, 3, 5, 4, 4) and torch.equal(full[:, 0, 0, 0, 0], torch.arange(n_items).float())
+    ok = ok and local.shape[0] == hi - lo and torch.equal(local, full[lo:hi])
+    mv = make_video_sharded(_FakePhenaki(), [[str(i), str(i + 100)] for i in range(n_items)], (5, 4), 3)
+    ok = ok and mv.shape == (n_items, 3, 9, 4, 4) and torch.allclose(mv[:, 0, 0, 0, 0], torch.arange(n_items).float())
+    ok = ok and torch.allclose(mv[:, 0, 5, 0, 0], torch.arange(n_items).float() + 100 + torch.arange(n_items).float() * 0.001, atol=1e-4)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_items', [4, 5])
+def test_sharded_sampling_world_size_2_gloo(n_items):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + n_items
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_items, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]

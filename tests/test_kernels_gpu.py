@@ -1,0 +1,351 @@
+"""Per-kernel parity: every C-ABI entry point of libphenaki_hip.so against the CPU oracle / the torch f32
+expression of the reference op it replaces.  Needs a real MI355X (-m gpu)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import phenaki_oracle as O
+from tests.util import close, uniform24_np
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope='module')
+def L():
+    from phenaki_pytorch_amd import _lib
+    _lib.load()
+    assert torch.cuda.is_available(), 'these tests need the HIP device (no CPU fallback exists)'
+    return _lib
+
+
+def g(seed):
+    gen = torch.Generator().manual_seed(seed)
+    return gen
+
+
+def bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+
+@pytest.mark.parametrize('M,N,K', [(300, 200, 96), (257, 512, 512), (1000, 2048, 512), (64, 8, 64), (77, 2, 128), (130, 1, 64)])
+@pytest.mark.parametrize('mode', ['f32', 'bf16', 'bf16_af32'])
+def test_gemm_plain_bias_res(L, M, N, K, mode):
+    A = torch.randn(M, K, generator=g(1))
+    W = torch.randn(N, K, generator=g(2)) / math.sqrt(K)
+    bias = torch.randn(N, generator=g(3))
+    res = torch.randn(M, N, generator=g(4))
+    if mode == 'f32':
+        dt, Ad, Wd, ref = L.F32, A.cuda(), W.cuda(), A @ W.t() + bias + res
+        tol = 2e-5
+    else:
+        dt = L.BF16
+        Wd = W.cuda().to(torch.bfloat16)
+        Ad = A.cuda() if mode == 'bf16_af32' else A.cuda().to(torch.bfloat16)
+        ref = bf(A) @ bf(W).t() + bias + res
+        tol = 2e-5
+    C = torch.empty(M, N, device='cuda')
+    L.gemm(dt, Ad, Wd, M, N, K, C=C, bias=bias.cuda(), res=res.cuda())
+    close(C, ref, tol, f'gemm {mode} {M}x{N}x{K}')
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_gemm_geglu_leaky_gather_and_T_output(L, mode):
+    M, K, inner = 333, 128, 344
+    A = torch.randn(M, K, generator=g(5))
+    W = torch.randn(2 * inner, K, generator=g(6)) / math.sqrt(K)
+    dt = L.F32 if mode == 'f32' else L.BF16
+    td = L.tdtype(dt)
+    cast = (lambda t: t) if mode == 'f32' else bf
+    h = cast(A) @ cast(W).t()
+    val, gate = h[:, 0::2], h[:, 1::2]                     # interleaved (value, gate) columns
+    ref = F.gelu(gate) * val
+    C = torch.empty(M, inner, device='cuda', dtype=td)
+    L.gemm(dt, A.cuda().to(td), W.cuda().to(td), M, 2 * inner, K, C=C, act=L.ACT_GEGLU)
+    close(C.float(), cast(ref) if mode == 'bf16' else ref, 1e-5 if mode == 'f32' else 8e-3, 'geglu')
+    # leaky relu + bias, f32 out
+    b = torch.randn(2 * inner, generator=g(7))
+    C2 = torch.empty(M, 2 * inner, device='cuda')
+    L.gemm(dt, A.cuda().to(td), W.cuda().to(td), M, 2 * inner, K, C=C2, bias=b.cuda(), act=L.ACT_LEAKY)
+    close(C2, F.leaky_relu(h + b, 0.1), 2e-5, 'leaky')
+    # row gather
+    idx = torch.randperm(M, generator=g(8))[:100].int()
+    C3 = torch.empty(100, 2 * inner, device='cuda')
+    L.gemm(dt, A.cuda().to(td), W.cuda().to(td), 100, 2 * inner, K, C=C3, a_rows=idx.cuda())
+    close(C3, h[idx.long()], 2e-5, 'gather')
+
+
+def test_gemm_rejects_bad_arguments(L):
+    A = torch.randn(8, 10, device='cuda')
+    W = torch.randn(8, 10, device='cuda')
+    C = torch.empty(8, 8, device='cuda')
+    with pytest.raises(RuntimeError, match='PK_EALIGN'):
+        L.gemm(L.F32, A, W, 8, 8, 10, C=C)                # K = 10 is not a multiple of 4 f32
+    with pytest.raises(RuntimeError, match='PK_EINVAL'):
+        L.gemm(L.F32, A, W, 0, 8, 8, C=C)
+
+
+# ------------------------------------------------------------------------------------------ norms / patch / peg / lfq / embed
+
+@pytest.mark.parametrize('M,D', [(37, 128), (1000, 512), (5, 768), (9, 96), (3, 3072)])
+def test_layernorm(L, M, D):
+    x = torch.randn(M, D, generator=g(9)) * 3 + 1
+    gamma = 1 + 0.1 * torch.randn(D, generator=g(10))
+    beta = 0.1 * torch.randn(D, generator=g(11))
+    ref = F.layer_norm(x, (D,), gamma, beta)
+    out = torch.empty(M, D, device='cuda')
+    outb = torch.empty(M, D, device='cuda', dtype=torch.bfloat16)
+    L.layernorm(x.cuda(), gamma.cuda(), beta.cuda(), M, D, out=outb, out2=out)
+    close(out, ref, 1e-5, 'layernorm f32')
+    close(outb.float(), ref, 5e-3, 'layernorm bf16')
+    out3 = torch.zeros(2 * M + 7, D, device='cuda')
+    L.layernorm(x.cuda(), gamma.cuda(), None, M, D, out2=out3[:2 * M], remap=(1, 2, 1))
+    close(out3[1:2 * M:2], F.layer_norm(x, (D,), gamma, None), 1e-5, 'layernorm remap')
+    assert out3[0:2 * M:2].abs().max().item() == 0
+
+
+@pytest.mark.parametrize('B,C,Fr,H,W,pt,ph,pw', [(2, 3, 5, 64, 64, 2, 16, 16), (1, 3, 3, 256, 256, 2, 32, 32), (2, 3, 1, 32, 64, 2, 8, 16)])
+def test_patchify_ln_and_unpatchify(L, B, C, Fr, H, W, pt, ph, pw):
+    video = torch.randn(B, C, Fr, H, W, generator=g(12))
+    h, w = H // ph, W // pw
+    vd = video.cuda()
+
+    def ref_patches(frames, tp):
+        t = frames.shape[2] // tp
+        return frames.reshape(B, C, t, tp, h, ph, w, pw).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B * t * h * w, -1)
+
+    groups = [(0, 1, 1)] + ([(1, (Fr - 1) // pt, pt)] if Fr > 1 else [])
+    recon = torch.zeros_like(vd)
+    for f0, nt, tp in groups:
+        P = C * tp * ph * pw
+        wgt = 1 + 0.1 * torch.randn(P, generator=g(13))
+        b = 0.1 * torch.randn(P, generator=g(14))
+        pat = ref_patches(video[:, :, f0:f0 + nt * tp], tp)
+        ref = F.layer_norm(pat, (P,), wgt, b)
+        out = torch.empty(B * nt * h * w, P, device='cuda')
+        L.patchify_ln(vd, f0, nt, tp, ph, pw, wgt.cuda(), b.cuda(), out)
+        close(out, ref, 1e-5, f'patchify_ln f0={f0}')
+        L.unpatchify(pat.cuda().contiguous(), recon, f0, nt, tp, ph, pw)
+    assert torch.equal(recon.cpu(), video), 'unpatchify(patchify(video)) must reproduce the video bit-exactly'
+
+
+@pytest.mark.parametrize('causal', [False, True])
+def test_peg(L, causal):
+    B, T, H, W, D = 2, 5, 4, 4, 128
+    x = torch.randn(B * T * H * W, D, generator=g(15))
+    sd = {'dsconv.weight': torch.randn(D, 1, 3, 3, 3, generator=g(16)) * 0.2, 'dsconv.bias': torch.randn(D, generator=g(17)) * 0.1}
+    ref = O.peg(sd, '', x.reshape(B, T * H * W, D), (B, T, H, W), causal).reshape(-1, D) + x
+    wt = sd['dsconv.weight'].reshape(D, 27).t().contiguous().cuda()
+    out = torch.empty_like(x, device='cuda')
+    L.peg(x.cuda(), wt, sd['dsconv.bias'].cuda(), out, B, T, H, W, D, causal)
+    close(out, ref, 1e-5, 'peg')
+
+
+def test_lfq_encode_decode(L):
+    M, D, cd = 777, 512, 16
+    x = torch.randn(M, D, generator=g(18))
+    sd = {'vq.project_in.weight': torch.randn(cd, D, generator=g(19)) / math.sqrt(D), 'vq.project_in.bias': torch.randn(cd, generator=g(20)) * 0.05,
+          'vq.project_out.weight': torch.randn(D, cd, generator=g(21)) / 4, 'vq.project_out.bias': torch.randn(D, generator=g(22)) * 0.05}
+    proj_ref = O.lfq_project(sd, x)
+    ids_ref = O.lfq_ids(proj_ref)
+    ids = torch.empty(M, device='cuda', dtype=torch.int64)
+    proj = torch.empty(M, cd, device='cuda')
+    L.lfq_encode(x.cuda(), sd['vq.project_in.weight'].cuda(), sd['vq.project_in.bias'].cuda(), ids, proj, M, D, cd)
+    close(proj, proj_ref, 1e-5, 'lfq proj')
+    safe = (proj_ref.abs() > 1e-4).all(dim=-1)
+    assert torch.equal(ids.cpu()[safe], ids_ref[safe]), 'LFQ ids differ on tokens whose margin exceeds 1e-4'
+    assert safe.float().mean() > 0.95
+    out = torch.empty(M, D, device='cuda')
+    L.lfq_decode(ids_ref.cuda(), sd['vq.project_out.weight'].cuda(), sd['vq.project_out.bias'].cuda(), out, M, D, cd)
+    close(out, O.lfq_codes(sd, ids_ref), 1e-5, 'lfq codes')
+
+
+def test_embed(L):
+    V, n, D, S = 257, 20, 128, 3
+    tok, pos = torch.randn(V, D, generator=g(23)), torch.randn(64, D, generator=g(24))
+    ids = torch.randint(0, V, (S, n), generator=g(25))
+    out = torch.empty(S * n, D, device='cuda')
+    L.embed(ids.cuda(), tok.cuda(), pos.cuda(), out, S * n, n, D)
+    assert torch.equal(out.cpu(), (tok[ids] + pos[:n]).reshape(S * n, D))
+
+
+@pytest.mark.parametrize('dims,D,heads', [((3, 4, 4), 64, 2), ((8, 8), 128, 8), ((2, 3, 5), 64, 8)])
+def test_continuous_position_bias(L, dims, D, heads):
+    from phenaki_pytorch_amd.attention import ContinuousPositionBias
+    m = ContinuousPositionBias(dim=D, heads=heads, num_dims=len(dims))
+    sd = {('cpb.' + k): v for k, v in m.state_dict().items()}
+    ref = O.continuous_position_bias(sd, 'cpb.', dims)
+    out = m.cuda()(*dims)
+    close(out, ref, 1e-4, 'cpb')
+
+
+# ------------------------------------------------------------------------------------------ attention / transformer
+
+def _attn_module(dim, heads, causal, nnull, dim_context=None, seed=30):
+    from phenaki_pytorch_amd.attention import Attention
+    torch.manual_seed(seed)
+    m = Attention(dim=dim, heads=heads, causal=causal, num_null_kv=nnull, dim_context=dim_context)
+    with torch.no_grad():
+        m.q_scale.copy_(1 + 0.1 * torch.randn(64))
+        m.k_scale.copy_(1 + 0.1 * torch.randn(64))
+        m.norm.gamma.copy_(1 + 0.1 * torch.randn(dim))
+        if dim_context:
+            m.context_norm.gamma.copy_(1 + 0.1 * torch.randn(dim_context))
+    return m
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('case', ['spatial_bias', 'causal_alibi', 'cross_null_mask', 'self_mask_long'])
+def test_attention_block(L, dtype, case):
+    from phenaki_pytorch_amd.attention import set_compute_dtype
+    dim, heads = 128, 2
+    S, n = 3, 64
+    ctx = None
+    kw = {}
+    if case == 'spatial_bias':
+        m = _attn_module(dim, heads, False, 0)
+        kw['attn_bias'] = torch.randn(heads, n, n, generator=g(31))
+    elif case == 'causal_alibi':
+        S, n = 7, 9
+        m = _attn_module(dim, heads, True, 0)
+    elif case == 'cross_null_mask':
+        m = _attn_module(dim, heads, False, 2, dim_context=96)
+        Lc = 13
+        ctx = torch.randn(S, Lc, 96, generator=g(32))
+        mask = torch.ones(S, Lc, dtype=torch.bool)
+        mask[1, 5:] = False
+        mask[2, :] = False                                  # the CFG null branch: only the null keys remain
+        kw['mask'] = mask
+    else:
+        S, n = 2, 200
+        m = _attn_module(dim, heads, False, 0)
+        mask = torch.rand(S, n, generator=g(33)) > 0.3
+        kw['mask'] = mask
+        kw['attn_bias'] = torch.randn(heads, n, n, generator=g(34))
+    x = torch.randn(S, n, dim, generator=g(35))
+    sd = {('a.' + k): v for k, v in m.state_dict().items()}
+    ref = O.attention(sd, 'a.', x, heads=heads, causal=m.causal, context=ctx, **kw)
+    m = set_compute_dtype(m.cuda(), dtype)
+    out = m(x.cuda(), context=ctx.cuda() if ctx is not None else None, mask=kw['mask'].cuda() if 'mask' in kw else None,
+            attn_bias=kw['attn_bias'].cuda() if 'attn_bias' in kw else None)
+    close(out, ref, 1e-4 if dtype == 'fp32' else 3e-2, f'attention {case} {dtype}')
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_transformer_with_peg_cross_and_ff(L, dtype):
+    from phenaki_pytorch_amd.attention import Transformer, set_compute_dtype
+    from oracle import weights
+    dim, heads, depth = 128, 2, 2
+    m = Transformer(dim=dim, depth=depth, heads=heads, dim_context=96, peg=True, has_cross_attn=True)
+    weights.fill_module(m, salt=9)
+    sd = {('t.' + k): v.clone() for k, v in m.state_dict().items()}
+    S, vs = 2, (3, 4, 4)
+    n = 48
+    x = torch.randn(S, n, dim, generator=g(36))
+    ctx = torch.randn(S, 7, 96, generator=g(37))
+    cmask = torch.ones(S, 7, dtype=torch.bool)
+    cmask[1, 4:] = False
+    ref = O.transformer(sd, 't.', x, depth=depth, heads=heads, peg_on=True, cross=True, video_shape=(S, *vs),
+                        context=ctx, cross_attn_context_mask=cmask)
+    m = set_compute_dtype(m.cuda(), dtype)
+    out = m(x.cuda(), video_shape=(S, *vs), context=ctx.cuda(), cross_attn_context_mask=cmask.cuda())
+    close(out, ref, 1e-4 if dtype == 'fp32' else 3e-2, f'transformer {dtype}')
+
+
+# ------------------------------------------------------------------------------------------ sampler kernels
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('M,V,D', [(150, 256, 128), (300, 4096, 512)])
+def test_vocab_sample_parity_mode(L, mode, M, V, D):
+    e = torch.randn(M, D, generator=g(40))
+    W = torch.randn(V, D, generator=g(41)) / math.sqrt(D) * 3
+    b = torch.randn(V, generator=g(42)) * 0.1
+    U = torch.rand(M, V, generator=g(43))
+    dt = L.F32 if mode == 'f32' else L.BF16
+    td = L.tdtype(dt)
+    cast = (lambda t: t) if mode == 'f32' else bf
+    logits = cast(e) @ cast(W).t() + b
+    T = 0.45
+    noisy = logits / T + (-torch.log(-torch.log(U + 1e-10) + 1e-10))
+    pred_ref = noisy.argmax(-1)
+    score_ref = 1 - logits.softmax(-1).gather(1, pred_ref[:, None]).squeeze(1)
+    mask = (torch.rand(M, generator=g(44)) > 0.4)
+    ids0 = torch.randint(0, V, (M,), generator=g(45))
+    partials = torch.empty(5 * L.vocab_ntiles(V) * M, device='cuda')
+    L.vocab_sample(dt, e.cuda().to(td), W.cuda().to(td), b.cuda(), M, V, D, T, U.cuda(), None, 0, True, partials)
+    ids = ids0.clone().cuda()
+    pred = torch.empty(M, device='cuda', dtype=torch.int64)
+    scores = torch.empty(M, device='cuda')
+    L.vocab_reduce(partials, M, V, None, mask.to(torch.uint8).cuda(), ids, pred, scores, True)
+    top2 = noisy.topk(2, dim=-1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 1e-4 * noisy.abs().max()      # near-ties may flip with the summation order
+    assert safe.float().mean() > 0.98
+    assert torch.equal(pred.cpu()[safe], pred_ref[safe]), 'gumbel-argmax ids differ outside near-ties'
+    same = pred.cpu() == pred_ref
+    exp_ids = torch.where(mask, pred.cpu(), ids0)
+    assert torch.equal(ids.cpu(), exp_ids)
+    exp_scores = torch.where(mask, score_ref, torch.full_like(score_ref, -1e4))
+    close(scores.cpu()[same], exp_scores[same], 1e-4, 'confidence scores')
+
+
+def test_vocab_sample_fast_mode_matches_its_numpy_twin(L):
+    M, V, D = 130, 512, 128
+    e = torch.randn(M, D, generator=g(46))
+    W = torch.randn(V, D, generator=g(47)) / math.sqrt(D) * 3
+    b = torch.zeros(V)
+    seed = 0x1234567890ABCDEF
+    partials = torch.empty(5 * L.vocab_ntiles(V) * M, device='cuda')
+    preds = []
+    for _ in range(2):
+        L.vocab_sample(L.F32, e.cuda(), W.cuda(), b.cuda(), M, V, D, 0.7, None, None, seed, False, partials)
+        pred = torch.empty(M, device='cuda', dtype=torch.int64)
+        L.vocab_reduce(partials, M, V, None, None, None, pred, None, False)
+        preds.append(pred.cpu())
+    assert torch.equal(preds[0], preds[1]), 'FAST mode must be deterministic for a fixed seed'
+    idx = np.arange(M * V, dtype=np.uint64)
+    U = torch.from_numpy(uniform24_np(seed, idx)).reshape(M, V)
+    assert 0.45 < U.mean() < 0.55 and U.min() >= 0 and U.max() < 1
+    noisy = (e @ W.t() + b) / 0.7 + (-torch.log(-torch.log(U + 1e-10) + 1e-10))
+    top2 = noisy.topk(2, dim=-1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 1e-3 * noisy.abs().max()
+    assert safe.float().mean() > 0.95
+    assert torch.equal(preds[0][safe], noisy.argmax(-1)[safe])
+    L.vocab_sample(L.F32, e.cuda(), W.cuda(), b.cuda(), M, V, D, 0.7, None, None, seed + 1, False, partials)
+    pred2 = torch.empty(M, device='cuda', dtype=torch.int64)
+    L.vocab_reduce(partials, M, V, None, None, None, pred2, None, False)
+    assert (pred2.cpu() != preds[0]).float().mean() > 0.2, 'a different seed must change the draws'
+
+
+@pytest.mark.parametrize('B,n,k', [(3, 48, 1), (3, 48, 47), (2, 576, 288), (1, 1024, 50)])
+def test_topk_mask(L, B, n, k):
+    scores = torch.randn(B, n, generator=g(48))
+    ids0 = torch.randint(0, 100, (B, n), generator=g(49))
+    idx = scores.topk(k, dim=-1).indices
+    mask_ref = torch.zeros(B, n).scatter(1, idx, 1).bool()
+    mask = torch.zeros(B, n, device='cuda', dtype=torch.uint8)
+    ids = ids0.clone().cuda()
+    L.topk_mask(scores.cuda(), B, n, k, 100, mask, ids)
+    assert torch.equal(mask.cpu().bool(), mask_ref)
+    assert torch.equal(ids.cpu(), torch.where(mask_ref, 100, ids0))
+
+
+def test_cfg_mix_and_critic_head(L):
+    nb, n_tot, n_prime, D = 2, 10, 3, 128
+    x = torch.randn(2 * nb * n_tot, D, generator=g(50))
+    xc, xn = x[:nb * n_tot].reshape(nb, n_tot, D), x[nb * n_tot:].reshape(nb, n_tot, D)
+    ref = (xn + (xc - xn) * 5.)[:, n_prime:].reshape(-1, D)
+    out = torch.empty(nb * (n_tot - n_prime), D, device='cuda')
+    L.cfg_mix(x.cuda(), nb, n_tot, n_prime, None, nb * (n_tot - n_prime), 5., True, out, D)
+    close(out, ref, 1e-6, 'cfg mix')
+    w, b = torch.randn(D, generator=g(51)), torch.randn(1, generator=g(52))
+    u = torch.rand(nb, n_tot - n_prime, generator=g(53))
+    sc, sn = xc @ w + b, xn @ w + b
+    ref_s = (sn + (sc - sn) * 5.)[:, n_prime:] + 0.5 * (u - 0.5)
+    outs = torch.empty(nb, n_tot - n_prime, device='cuda')
+    L.critic_head(x.cuda(), w.cuda(), b.cuda(), D, nb, n_tot, n_prime, True, 5., u.cuda(), 0.5, outs)
+    close(outs, ref_s, 1e-5, 'critic head')

@@ -1,0 +1,201 @@
+"""Module-level parity of the HIP path (through the reference's nn.Module surfaces) against
+ (a) the committed golden vectors minted from the REAL reference (tests/golden/*.pt, tiny configs), and
+ (b) the CPU oracle on the same seeded inputs at BASELINE.json's full configuration.
+Needs a real MI355X (-m gpu).  Tolerances: token ids / mask indices bit-exact (ids audited by decision margin),
+logits / pixels within 1e-3 relative (north star); bf16 mode is checked at its own documented tolerance."""
+import os
+
+import pytest
+import torch
+
+from oracle import phenaki_oracle as O
+from oracle import weights
+from oracle.configs import TINY, FULL, oracle_cfgs, state_dicts
+from tests.util import close, ids_equal_with_margin, load_product, noise_fn_cuda
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def golden(golden_dir, name):
+    path = os.path.join(golden_dir, name)
+    if not os.path.exists(path):
+        pytest.skip(f'{name} not generated')
+    return torch.load(path, weights_only=False)
+
+
+# ------------------------------------------------------------------------------------------ C-ViViT
+
+def test_cvivit_tiny_matches_reference_golden(golden_dir):
+    g = golden(golden_dir, 'cvivit_tiny.pt')
+    cv, _, _, _ = load_product('tiny', TINY)
+    video = weights.synthetic_video(2, 5, 64, 64, seed=0).cuda()
+    tok, T = cv._patch_embed(video)
+    close(tok.view(2, T, 4, 4, -1), g['patch_tokens'], 1e-3, 'patch tokens')
+    enc = cv.encode(g['patch_tokens'].cuda())
+    close(enc, g['enc_tokens'], 1e-3, 'encoded tokens')
+    ids, proj = cv.tokenize(video, return_proj=True)
+    close(proj, g['proj'], 1e-3, 'lfq projection')
+    ids_equal_with_margin(ids, g['ids'], g['proj'])
+    assert torch.equal(cv(video, return_only_codebook_ids=True), ids)
+    rec = cv.decode_from_codebook_indices(g['ids'].flatten(1).cuda())
+    close(rec, g['recon'], 1e-3, 'reconstruction')
+    rec2 = cv(video, return_recons_only=True)
+    if torch.equal(ids.cpu(), g['ids']):
+        close(rec2, g['recon'], 1e-3, 'forward(return_recons_only)')
+    # 4-D image input (cvivit.py:532-534)
+    img_ids = cv(video[:, :, 0], return_only_codebook_ids=True)
+    assert torch.equal(img_ids, cv(video[:, :, :1], return_only_codebook_ids=True))
+
+
+@pytest.mark.parametrize('dtype,tol,min_agree', [('fp32', 1e-3, 1.0), ('bf16', 5e-2, 0.85)])
+def test_cvivit_full_config_matches_oracle(dtype, tol, min_agree):
+    """BASELINE configs[1] geometry (dim 512, 256x256, patch 32, tpatch 2, depth 4+4) at B=2."""
+    cv_sd, _, _ = state_dicts('full')
+    cvc, _, _ = oracle_cfgs(FULL)
+    cv, _, _, _ = load_product('full', FULL, dtype=dtype)
+    video = weights.synthetic_video(2, 17, 256, 256, seed=0)
+    ids_ref, proj_ref = O.cvivit_tokenize(cv_sd, cvc, video, return_proj=True)
+    ids, proj = cv.tokenize(video.cuda(), return_proj=True)
+    assert ids.shape == (2, 9, 8, 8) and ids.dtype == torch.int64
+    close(proj, proj_ref, tol, f'lfq projection {dtype}')
+    if dtype == 'fp32':
+        ids_equal_with_margin(ids, ids_ref, proj_ref)
+    agree = (ids.cpu() == ids_ref).float().mean().item()
+    assert agree >= min_agree, f'{dtype}: only {agree:.3f} of ids agree with the f32 oracle'
+    rec_ref = O.cvivit_decode_ids(cv_sd, cvc, ids_ref.flatten(1))
+    rec = cv.decode_from_codebook_indices(ids_ref.flatten(1).cuda())
+    assert rec.shape == (2, 3, 17, 256, 256)
+    close(rec, rec_ref, tol, f'decoded pixels {dtype}')
+
+
+def test_cvivit_asserts_match_reference():
+    cv, _, _, _ = load_product('tiny', TINY)
+    with pytest.raises(AssertionError):
+        cv(torch.randn(1, 3, 4, 64, 64).cuda(), return_only_codebook_ids=True)      # (f - 1) % tpatch != 0
+    with pytest.raises(AssertionError):
+        cv(torch.randn(1, 3, 5, 32, 64).cuda(), return_only_codebook_ids=True)      # wrong image size
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        cv(torch.randn(1, 3, 5, 64, 64), return_only_codebook_ids=True)
+
+
+# ------------------------------------------------------------------------------------------ MaskGit / critic
+
+def test_maskgit_and_critic_tiny_match_reference_golden(golden_dir):
+    g = golden(golden_dir, 'maskgit_tiny.pt')
+    _, mg, cr, _ = load_product('tiny', TINY)
+    ids = g['ids'].cuda()
+    ctx = weights.synthetic_context(ids.shape[0], g['ctx_len'], TINY['maskgit']['dim_context'], seed=1, pad_last=3).cuda()
+    tm = (ctx != 0).any(-1)
+    kw = dict(video_patch_shape=g['patch_shape'], context=ctx, text_mask=tm)
+    close(mg(ids, cond_drop_prob=0., **kw), g['cond'], 1e-3, 'cond logits')
+    close(mg(ids, cond_drop_prob=1., **kw), g['null'], 1e-3, 'null logits')
+    cfg = mg.forward_with_cond_scale(ids, cond_scale=5., **kw)
+    close(cfg, g['cfg'], 1e-3, 'cfg logits')
+    close(mg(ids, return_embeds=True, **kw), g['embeds'], 1e-3, 'embeds')
+    close(mg.continuous_pos_bias(*g['patch_shape'])[:, ::7, ::5], g['bias_sub'], 1e-3, 'cpb')
+    close(cr.forward_with_cond_scale(ids, cond_scale=5., **kw), g['critic_cfg'], 1e-3, 'critic cfg')
+    close(cr(ids, cond_drop_prob=0., **kw), g['critic_cond'], 1e-3, 'critic cond')
+    # 4-D ids (phenaki_pytorch.py:175-177)
+    ids4 = ids.view(ids.shape[0], *g['patch_shape'])
+    close(mg(ids4, context=ctx, text_mask=tm), g['cond'], 1e-3, '4-d ids')
+
+
+@pytest.mark.parametrize('dtype,tol', [('fp32', 1e-3), ('bf16', 6e-2)])
+def test_maskgit_full_config_matches_oracle(dtype, tol):
+    """BASELINE configs[2] geometry: dim 512, depth 6, vocab 65 536, n = 576, cross-attention on a 12-token context."""
+    _, mg_sd, cr_sd = state_dicts('full')
+    _, mgc, crc = oracle_cfgs(FULL)
+    _, mg, cr, _ = load_product('full', FULL, dtype=dtype)
+    gen = torch.Generator().manual_seed(77)
+    ids = torch.randint(0, 65537, (1, 576), generator=gen)
+    ids[:, ::3] = 65536
+    ctx = weights.synthetic_context(1, 12, 768, seed=1, pad_last=3)
+    tm = (ctx != 0).any(-1)
+    kw = dict(video_patch_shape=(9, 8, 8), context=ctx, text_mask=tm)
+    ref = O.maskgit_cfg(mg_sd, mgc, ids, cond_scale=5., **kw)
+    kwd = dict(video_patch_shape=(9, 8, 8), context=ctx.cuda(), text_mask=tm.cuda())
+    out = mg.forward_with_cond_scale(ids.cuda(), cond_scale=5., **kwd)
+    assert out.shape == (1, 576, 65536)
+    close(out, ref, tol, f'cfg logits {dtype}')
+    if dtype == 'fp32':
+        top2 = ref.topk(2, dim=-1).values
+        safe = (top2[..., 0] - top2[..., 1]) > 1e-3 * ref.abs().max()
+        assert torch.equal(out.argmax(-1).cpu()[safe], ref.argmax(-1)[safe])
+    sref = O.critic_cfg(cr_sd, crc, ids, cond_scale=5., **kw)
+    close(cr.forward_with_cond_scale(ids.cuda(), cond_scale=5., **kwd), sref, tol, f'critic scores {dtype}')
+
+
+# ------------------------------------------------------------------------------------------ Phenaki.sample
+
+@pytest.mark.parametrize('tag,with_critic', [('tiny', True), ('tiny_nocritic', False), ('tiny_primed', True)])
+def test_sample_tiny_free_running_matches_reference_golden(golden_dir, tag, with_critic):
+    """every step's masked input ids, predicted ids and the final pixels of the REAL reference run
+    (same weights, same injected U[0,1) draws) are reproduced by the fused HIP sampler."""
+    g = golden(golden_dir, f'sample_{tag}.pt')
+    _, _, _, ph = load_product('tiny', TINY, with_critic=with_critic)
+    batch = g['batch']
+    ctx = weights.synthetic_context(batch, g['ctx_len'], TINY['maskgit']['dim_context'], seed=2).cuda()
+    ph.encode_texts = lambda texts, output_device=None: ctx
+    prime = None
+    for scene, nf in enumerate(g['frames_list']):
+        trace = []
+        video = ph.sample(texts=['x'] * batch, num_frames=nf, prime_frames=prime, cond_scale=5.,
+                          _noise_fn=noise_fn_cuda(500, scene), _trace=trace)
+        recs = [s for s in g['steps'] if s['scene'] == scene]
+        assert len(recs) == len(trace)
+        for r, t in zip(recs, trace):
+            npr = r['mg_input'].shape[1] - t['masked_ids'].shape[1]
+            assert torch.equal(r['mg_input'][:, npr:], t['masked_ids'].cpu()), f"scene {scene} step {r['step']}: masked input ids differ"
+            assert torch.equal(r['pred'], t['pred'].cpu()), f"scene {scene} step {r['step']}: predicted ids differ"
+            if 'critic_input' in r:
+                assert torch.equal(r['critic_input'][:, npr:], t['ids'].cpu())
+        close(video, g['videos'][scene], 1e-3, f'scene {scene} pixels')
+        prime = video[:, :, -g['prime_len']:] if g['prime_len'] else None
+
+
+def test_sample_fast_mode_is_seeded_and_shapes_match_readme():
+    """README shape comments (README.md:108,116): (B, 3, num_frames, H, W); default noise path is deterministic
+    under torch.manual_seed and differs across seeds."""
+    _, _, _, ph = load_product('tiny', TINY)
+    ctx = weights.synthetic_context(2, 6, TINY['maskgit']['dim_context'], seed=2).cuda()
+    ph.encode_texts = lambda texts, output_device=None: ctx
+    torch.manual_seed(5)
+    v1, ids1 = ph.sample(texts=['a', 'b'], num_frames=5, cond_scale=5., _return_ids=True)
+    torch.manual_seed(5)
+    v2, ids2 = ph.sample(texts=['a', 'b'], num_frames=5, cond_scale=5., _return_ids=True)
+    torch.manual_seed(6)
+    v3, ids3 = ph.sample(texts=['a', 'b'], num_frames=5, cond_scale=5., _return_ids=True)
+    assert v1.shape == (2, 3, 5, 64, 64)
+    assert torch.equal(ids1, ids2) and torch.equal(v1, v2)
+    assert not torch.equal(ids1, ids3)
+    assert (ids1 != ph.mask_id).all() and (ids1 >= 0).all() and (ids1 < 256).all()
+    img = ph.sample_images(texts=['a', 'b'], cond_scale=5.)
+    assert img.shape == (2, 3, 64, 64)
+    from phenaki_pytorch_amd import make_video
+    whole, scenes = make_video(ph, texts=['a', 'b', 'c'], num_frames=(5, 4, 4), prime_lengths=3)
+    assert whole.shape == (1, 3, 13, 64, 64) and len(scenes) == 3
+
+
+def test_sample_full_config_two_steps_matches_oracle():
+    """full-size Phenaki.sample (n = 576, vocab 65 536, TokenCritic) teacher-checked over 2 steps against the oracle."""
+    cv_sd, mg_sd, cr_sd = state_dicts('full')
+    cvc, mgc, crc = oracle_cfgs(FULL)
+    _, _, _, ph = load_product('full', FULL, steps=2)
+    ctx = weights.synthetic_context(1, 12, 768, seed=2)
+    ph.encode_texts = lambda texts, output_device=None: ctx.cuda()
+
+    def nf_cpu(kind, step, shape):
+        return weights.uniform_noise(tuple(shape), 900 + 2 * step + (1 if kind == 'critic' else 0))
+
+    trace_ref, trace = [], []
+    vid_ref, ids_ref = O.sample(cv_sd, cvc, mg_sd, mgc, cr_sd, crc, num_frames=17, batch_size=1, context=ctx, steps=2,
+                                cond_scale=5., noise_fn=nf_cpu, trace=trace_ref)
+    vid, ids = ph.sample(texts=['x'], num_frames=17, cond_scale=5., _noise_fn=lambda k, s, sh: nf_cpu(k, s, sh).cuda(),
+                         _trace=trace, _return_ids=True)
+    for s, (a, b) in enumerate(zip(trace_ref, trace)):
+        agree = (a['pred'] == b['pred'].cpu()).float().mean().item()
+        assert agree >= 0.995, f'step {s}: only {agree:.4f} of predicted ids agree'
+        assert torch.equal(a['mask'], b['mask'].cpu()) or s > 0
+    if torch.equal(ids_ref, ids.cpu()):
+        close(vid, vid_ref, 1e-3, 'sampled pixels')

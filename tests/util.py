@@ -1,0 +1,91 @@
+"""helpers shared by the parity tests (CPU oracle vs HIP path)."""
+import numpy as np
+import torch
+
+from oracle import weights
+from oracle.configs import state_dicts
+
+
+def close(a, b, rtol=1e-3, what=''):
+    """max |a - b| <= rtol * max |b|  (the north-star tolerance is 1e-3 relative for logits / pixels)."""
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    assert a.shape == b.shape, f'{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}'
+    assert torch.isfinite(a).all(), f'{what}: non-finite values in the HIP result'
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item()
+    assert err <= rtol * scale, f'{what}: max err {err:.3e} > {rtol:g} * scale {scale:.3e} (rel {err / scale:.3e})'
+    return err / scale
+
+
+def ids_equal_with_margin(ids, ids_ref, proj_ref, tol=1e-4, what='ids'):
+    """LFQ ids are sign bits of `proj`: a mismatching id is a failure only if every differing bit had an oracle
+    pre-sign value with |value| > tol * max|proj| (SURVEY.md 7 'margin audit').  Returns the number of audited flips."""
+    ids = ids.cpu().reshape(-1)
+    ids_ref = ids_ref.cpu().reshape(-1)
+    proj = proj_ref.cpu().reshape(ids_ref.numel(), -1)
+    cd = proj.shape[-1]
+    bad = (ids != ids_ref).nonzero().flatten()
+    scale = proj.abs().max().item()
+    flips = 0
+    for i in bad.tolist():
+        diff = int(ids[i]) ^ int(ids_ref[i])
+        for k in range(cd):
+            if diff >> (cd - 1 - k) & 1:
+                v = abs(proj[i, k].item())
+                assert v <= tol * scale, f'{what}: token {i} bit {k} differs with oracle margin {v:.3e} (scale {scale:.3e})'
+                flips += 1
+    return flips
+
+
+def load_product(tag, cfgs, device='cuda', with_critic=True, steps=None, dtype='fp32'):
+    """product CViViT / MaskGit / TokenCritic / Phenaki filled with the name-keyed weights of oracle/weights.py."""
+    import phenaki_pytorch_amd as P
+    cv_sd, mg_sd, cr_sd = state_dicts(tag)
+    cv = P.CViViT(use_vgg_and_gan=False, **cfgs['cvivit'])
+    mg = P.MaskGit(**cfgs['maskgit'])
+    cr = P.TokenCritic(**cfgs['critic']) if with_critic else None
+    cv.load_state_dict(cv_sd)
+    mg.load_state_dict(mg_sd)
+    if cr is not None:
+        cr.load_state_dict(cr_sd)
+    cv, mg = cv.to(device).eval(), mg.to(device).eval()
+    if cr is not None:
+        cr = cr.to(device).eval()
+    ph = P.Phenaki(maskgit=mg, cvivit=cv, critic=cr, steps=steps or cfgs['steps'],
+                   text_embed_dim=cfgs['maskgit']['dim_context']).to(device).eval()
+    for m in (cv, mg, cr, ph):
+        if m is not None:
+            P.set_compute_dtype(m, dtype)
+    return cv, mg, cr, ph
+
+
+def noise_fn_cuda(base, scene=0):
+    def fn(kind, step, shape):
+        u = weights.uniform_noise(tuple(shape), base + 100 * scene + 2 * step + (1 if kind == 'critic' else 0))
+        return u.cuda()
+    return fn
+
+
+# ---- numpy twin of csrc/common.hpp mix32 / uniform24 (the FAST-mode sampler noise) -----------------
+
+def _mix32(h):
+    h = h.astype(np.uint32)
+    h ^= h >> np.uint32(16)
+    h = (h * np.uint32(0x85ebca6b)).astype(np.uint32)
+    h ^= h >> np.uint32(13)
+    h = (h * np.uint32(0xc2b2ae35)).astype(np.uint32)
+    h ^= h >> np.uint32(16)
+    return h
+
+
+def uniform24_np(seed, idx):
+    """idx: uint64 array of flat element indices (row * V + col); seed: python int (uint64)."""
+    with np.errstate(over='ignore'):
+        idx = idx.astype(np.uint64)
+        lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        hi = (idx >> np.uint64(32)).astype(np.uint32)
+        s_lo, s_hi = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
+        h = _mix32(lo ^ s_lo)
+        h = _mix32((h + np.uint32(0x9e3779b9) * (hi + np.uint32(1)) + s_hi).astype(np.uint32))
+        return (h >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
