@@ -13,6 +13,13 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'slow: CPU test that takes more than a few seconds')
 
 
+@pytest.fixture(scope='session', autouse=True)
+def _oracle_threads():
+    """the CPU oracle runs beside the GPU tests: keep torch's CPU backend off os.cpu_count() threads on GPU boxes."""
+    from oracle import hostcpu
+    return hostcpu.configure()
+
+
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')

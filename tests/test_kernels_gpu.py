@@ -92,7 +92,7 @@ def test_gemm_rejects_bad_arguments(L):
 
 # ------------------------------------------------------------------------------------------ norms / patch / peg / lfq / embed
 
-@pytest.mark.parametrize('M,D', [(37, 128), (1000, 512), (5, 768), (9, 96), (3, 3072)])
+@pytest.mark.parametrize('M,D', [(37, 128), (1000, 512), (5, 768), (9, 96), (3, 2048)])
 def test_layernorm(L, M, D):
     x = torch.randn(M, D, generator=g(9)) * 3 + 1
     gamma = 1 + 0.1 * torch.randn(D, generator=g(10))

@@ -94,3 +94,57 @@ def test_sample_matches_reference_free_running(golden_dir, tag, with_critic):
                 assert torch.equal(r['critic_input'][:, npr:], t['ids'])
         close(video, g['videos'][scene])
         prime = video[:, :, -g['prime_len']:] if g['prime_len'] else None
+
+
+# ---------------------------------------------------------------------------------------------------------
+# full BASELINE geometry (dim 512, 65 536 codes, 256x256, n = 576): goldens are sub-sampled outputs of the
+# REAL reference (oracle/make_golden.py full)
+
+def test_cvivit_full_matches_reference(golden_dir):
+    g = load(golden_dir, 'cvivit_full.pt')
+    cv, _, _ = state_dicts('full')
+    cvc, _, _ = oracle_cfgs(FULL)
+    video = weights.synthetic_video(2, 17, 256, 256, seed=0)
+    tok = O.cvivit_patch_embed(cv, cvc, video)
+    close(tok[:, :, ::2, ::2, ::8], g['patch_tokens_sub'])
+    enc = O.cvivit_encode(cv, cvc, tok)
+    close(enc[:, :, ::2, ::2, ::8], g['enc_tokens_sub'])
+    ids, proj = O.cvivit_tokenize(cv, cvc, video, return_proj=True)
+    close(proj, g['proj'])
+    assert torch.equal(ids, g['ids'])
+    rec = O.cvivit_decode_ids(cv, cvc, ids.flatten(1))
+    close(rec[:, :, ::4, ::8, ::8], g['recon_sub'])
+    assert abs(rec.double().sum().item() - g['recon_sum']) <= 1e-4 * g['recon_abs']
+
+
+def test_maskgit_full_matches_reference(golden_dir):
+    g = load(golden_dir, 'maskgit_full.pt')
+    _, mg, cr = state_dicts('full')
+    _, mgc, crc = oracle_cfgs(FULL)
+    ids = g['ids']
+    ctx = weights.synthetic_context(1, g['ctx_len'], 768, seed=1, pad_last=3)
+    tm = (ctx != 0).any(-1)
+    kw = dict(video_patch_shape=g['patch_shape'], context=ctx, text_mask=tm)
+    cs = g['col_stride']
+    cfg = O.maskgit_cfg(mg, mgc, ids, cond_scale=5., **kw)
+    close(cfg[:, :, ::cs], g['cfg'])
+    assert torch.equal(cfg.argmax(-1), g['cfg_argmax'])
+    close(cfg.logsumexp(-1), g['cfg_lse'])
+    close(O.critic_cfg(cr, crc, ids, cond_scale=5., **kw), g['critic_cfg'])
+
+
+@pytest.mark.slow
+def test_sample_full_matches_reference_free_running(golden_dir):
+    """all 18 steps of a full-size Phenaki.sample (TokenCritic, CFG 5) reproduce the reference's ids step by step."""
+    g = load(golden_dir, 'sample_full.pt')
+    cv, mg, cr = state_dicts('full')
+    cvc, mgc, crc = oracle_cfgs(FULL)
+    ctx = weights.synthetic_context(1, g['ctx_len'], 768, seed=2)
+    trace = []
+    video, ids = O.sample(cv, cvc, mg, mgc, cr, crc, num_frames=17, batch_size=1, context=ctx, steps=FULL['steps'],
+                          cond_scale=5., noise_fn=_noise_fn(500, 0), trace=trace)
+    assert len(trace) == len(g['steps']) == 18
+    for r, t in zip(g['steps'], trace):
+        assert torch.equal(r['mg_input'], t['masked_ids']), f"step {r['step']} input ids differ"
+        assert torch.equal(r['pred'], t['pred']), f"step {r['step']} pred differs"
+    close(video[:, :, ::4, ::8, ::8], g['videos_sub'][0])
