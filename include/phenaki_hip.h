@@ -38,12 +38,22 @@ int pk_gemm(int dtype, int a_is_f32, const void* A, int lda, const void* W, int 
             const float* bias, const float* res, int ldr, void* C, int ldc, int out_is_f32, int act,
             const int* a_rows, void* stream);
 
+/* pk_gemm with an explicit main-loop variant (0 = automatic; 1/2 = register-staged 64x64 / 128x128 tiles, 3..6 = LDS-DMA
+ * ring variants, see csrc/gemm.hip) and the number of physical rows behind a gathered A (bounds of the DMA descriptor).
+ * The DMA variants need A in T and ldw >= K rounded up to the k-tile (64 bf16 / 32 f32) with zero padding. */
+int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const void* W, int ldw, int M, int N, int K,
+               const float* bias, const float* res, int ldr, void* C, int ldc, int out_is_f32, int act,
+               const int* a_rows, int a_nrows, int variant, void* stream);
+
 /* y = LayerNorm(x) * gamma (+ beta), eps inside the sqrt, biased variance.  attention.py:29-36 (gamma-only
  * LayerNorm, beta NULL or the zero buffer), attention.py:47 and cvivit.py:277,284 (nn.LayerNorm).
- * out (T if out_kind == 1 else f32) and/or out2 (f32) receive y.  grp > 0 remaps OUTPUT rows
- * r -> (r / grp) * gstride + goff + r % grp  (the first-frame / rest-frames concat of cvivit.py:549). */
+ * out (T if out_kind == 1 else f32) and/or out2 (f32) receive y; raw (T, optional) receives x itself (the
+ * un-normalised K/V source of attention.py:140-144).  OUTPUT rows may be remapped: grp > 0:
+ * r -> (r / grp) * gstride + goff + r % grp  (the first-frame / rest-frames concat of cvivit.py:549); pb > 0: rows
+ * seen as (a, b, c), b < pb, c < pc, land at (a, c, b) ('b t (h w) <-> b (h w) t', cvivit.py:468,472,488,496). */
 int pk_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps, void* out, int ldo,
-                 int out_kind, float* out2, int ldo2, int M, int D, int grp, int gstride, int goff, void* stream);
+                 int out_kind, float* out2, int ldo2, void* raw, int ldraw, int M, int D, int grp, int gstride,
+                 int goff, int pb, int pc, void* stream);
 
 /* cvivit.py:273-285: Rearrange 'b c (t pt) (h p1) (w p2) -> b t h w (c pt p1 p2)' of frames [f0, f0 + nt*pt) of the
  * (B,C,F,H,W) f32 video, fused with nn.LayerNorm(P), P = C*pt*ph*pw; out[(b,t,h,w)][P] is T (out_kind 1) or f32. */

@@ -22,7 +22,8 @@ _ULL = ctypes.c_ulonglong
 # name -> argtypes, kept in the order of include/phenaki_hip.h (tests check every symbol is exported)
 SIGNATURES = {
     'pk_gemm': [_I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P],
-    'pk_layernorm': [_P, _I, _P, _P, _F, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    'pk_gemm_ex': [_I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P],
+    'pk_layernorm': [_P, _I, _P, _P, _F, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'pk_patchify_ln': [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _I, _I, _P],
     'pk_unpatchify': [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'pk_peg': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -90,24 +91,28 @@ def tdtype(dtype):
 
 # ----------------------------------------------------------------------------- wrappers
 
-def gemm(dtype, A, W, M, N, K, *, C, bias=None, res=None, act=ACT_NONE, a_rows=None, lda=None, ldc=None):
-    """C = act(A @ W^T + bias) (+ res).  A: (.., K) f32 or T rows; W: (N, Kpad) T; C preallocated."""
+def gemm(dtype, A, W, M, N, K, *, C, bias=None, res=None, act=ACT_NONE, a_rows=None, lda=None, ldc=None, variant=0):
+    """C = act(A @ W^T + bias) (+ res).  A: (rows, K) f32 or T; W: (N, Kpad) T; C preallocated.
+    a_rows gathers rows of A (A.shape[0] physical rows bound the DMA descriptor)."""
     a_is_f32 = 1 if A.dtype == torch.float32 else 0
     out_is_f32 = 1 if C.dtype == torch.float32 else 0
     lda = A.stride(-2) if lda is None else lda
     ldc = C.stride(-2) if ldc is None else ldc
     ldr = res.stride(-2) if res is not None else 0
-    rc = load().pk_gemm(dtype, a_is_f32, ptr(A), lda, ptr(W), W.stride(0), M, N, K, ptr(bias), ptr(res), ldr,
-                        ptr(C), ldc, out_is_f32, act, ptr(a_rows), stream())
-    _check(rc, 'pk_gemm')
+    rc = load().pk_gemm_ex(dtype, a_is_f32, ptr(A), lda, ptr(W), W.stride(0), M, N, K, ptr(bias), ptr(res), ldr,
+                           ptr(C), ldc, out_is_f32, act, ptr(a_rows), A.shape[0] if a_rows is not None else M, variant, stream())
+    _check(rc, 'pk_gemm_ex')
     return C
 
 
-def layernorm(x, gamma, beta, M, D, *, out=None, out2=None, eps=1e-5, remap=(0, 0, 0), ldx=None):
-    out_kind = 1 if (out is not None and out.dtype == torch.bfloat16) else 0
+def layernorm(x, gamma, beta, M, D, *, out=None, out2=None, raw=None, eps=1e-5, remap=(0, 0, 0), perm=(0, 0), ldx=None):
+    """out (T) / out2 (f32) <- LN(x); raw (T, same type as out) <- x.  remap / perm: output row maps (see the header)."""
+    tt = out if out is not None else raw
+    out_kind = 1 if (tt is not None and tt.dtype == torch.bfloat16) else 0
     rc = load().pk_layernorm(ptr(x), x.stride(-2) if ldx is None else ldx, ptr(gamma), ptr(beta), eps,
                              ptr(out), out.stride(-2) if out is not None else 0, out_kind,
-                             ptr(out2), out2.stride(-2) if out2 is not None else 0, M, D, *remap, stream())
+                             ptr(out2), out2.stride(-2) if out2 is not None else 0,
+                             ptr(raw), raw.stride(-2) if raw is not None else 0, M, D, *remap, *perm, stream())
     _check(rc, 'pk_layernorm')
 
 

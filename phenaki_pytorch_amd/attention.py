@@ -71,8 +71,9 @@ def _cache(module):
 
 
 def pack_linear_weight(w, dtype):
-    """(N, K) f32 -> (N, Kpad) T with K zero-padded to the 16-byte quantum of T."""
-    q = 8 if dtype == L.BF16 else 4
+    """(N, K) f32 -> (N, Kpad) T with K zero-padded to the GEMM k-tile (64 bf16 / 32 f32): the LDS-DMA main loop
+    relies on that zero padding to neutralise the K tail of A."""
+    q = 64 if dtype == L.BF16 else 32
     n, k = w.shape
     kp = round_up(k, q)
     out = torch.zeros((n, kp), device=w.device, dtype=L.tdtype(dtype))
@@ -320,7 +321,10 @@ class Attention(nn.Module):
         n_kv = n_ctx if is_cross else n
 
         xn = torch.empty((M, D), device=dev, dtype=td)
-        self.norm.run(x2d, out=xn)
+        # self-attention K/V come from the UN-normalised x (attention.py:140-144): in bf16 mode the same LN launch
+        # also emits x in bf16 so every GEMM operand is T and can be fed by LDS-DMA
+        xraw = torch.empty((M, D), device=dev, dtype=td) if (not is_cross and dtype == L.BF16) else None
+        L.layernorm(x2d, self.norm.gamma, self.norm.beta, M, D, out=xn, raw=xraw)
         q = torch.empty((M, inner), device=dev, dtype=torch.float32)
         L.gemm(dtype, xn, linear_weight(self.to_q, dtype), M, inner, D, C=q)
 
@@ -328,7 +332,7 @@ class Attention(nn.Module):
         Qp = torch.empty((S * h * nq_pad * 64,), device=dev, dtype=td)
         cached = kv_cache.get(id(self)) if (kv_cache is not None and is_cross) else None
         if cached is None:
-            kv = self.project_kv(context2d if is_cross else x2d, S, n_kv, dtype, is_cross)
+            kv = self.project_kv(context2d if is_cross else (xraw if xraw is not None else x2d), S, n_kv, dtype, is_cross)
             Kp = torch.empty((S * h * nk_pad * 64,), device=dev, dtype=td)
             Vt = torch.empty((S * h * nk_pad * 64,), device=dev, dtype=td)
             L.attn_prep(dtype, q, kv, self.null_kv, self.q_scale, self.k_scale, float(self.scale), Qp, Kp, Vt, S, h, n, n_kv, nnull)
@@ -376,8 +380,9 @@ class Transformer(nn.Module):
         self.norm_out = LayerNorm(dim)
 
     def run(self, x2d, S, n, dtype, *, video_shape=None, attn_bias=None, context2d=None, n_ctx=None,
-            self_attn_mask=None, cross_attn_context_mask=None, kv_cache=None, out=None, out_t=None):
-        """x2d (S*n, D) f32.  Writes norm_out(x) to `out` (f32) and/or `out_t` (T); returns `out` (allocated if both None)."""
+            self_attn_mask=None, cross_attn_context_mask=None, kv_cache=None, out=None, out_t=None, perm=(0, 0)):
+        """x2d (S*n, D) f32.  Writes norm_out(x) to `out` (f32) and/or `out_t` (T); returns `out` (allocated if both None).
+        perm = (pb, pc): the output rows are written transposed, (a, b, c) -> (a, c, b)."""
         x = x2d
         for peg, self_attn, cross_attn, ff in self.layers:
             if exists(peg):
@@ -389,7 +394,8 @@ class Transformer(nn.Module):
             x = ff.run(x, dtype)
         if out is None and out_t is None:
             out = torch.empty_like(x)
-        self.norm_out.run(x, out=out_t, out2=out)
+        M, D = x.shape
+        L.layernorm(x, self.norm_out.gamma, self.norm_out.beta, M, D, out=out_t, out2=out, perm=perm)
         return out if out is not None else out_t
 
     def forward(self, x, video_shape=None, attn_bias=None, context=None, self_attn_mask=None,

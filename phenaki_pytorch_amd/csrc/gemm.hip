@@ -2,7 +2,9 @@
 // 328,333, phenaki_pytorch.py:147) as one MFMA GEMM with a fused epilogue:
 //   C = act(A @ W^T + bias) (+ residual)        act in {none, GEGLU pair, LeakyReLU(0.1)}
 // Roofline: MFMA-bound (bf16 2.5 PFLOP/s dense, exact-f32 157 TFLOP/s); algorithmic flops 2*M*N*K.
-#include "gemm_core.hpp"
+// Two main loops share the epilogue: gemm_core.hpp (register-staged, converts f32 A on the fly) and
+// gemm_dma.hpp (LDS-DMA ring, A and W of the same type, W zero-padded along K to the k-tile).
+#include "gemm_dma.hpp"
 
 namespace pk {
 
@@ -18,30 +20,20 @@ struct GemmEpilogue {
     int vec_ok;          // N, ldc, ldr multiples of 4 and pointers 16-B aligned -> vector epilogue
 };
 
-template <typename T, typename TA, int TM, int TN>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmOperands p, const GemmEpilogue e) {
-    using Tile = GemmTile<T, TA, TM, TN>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int m0 = blockIdx.x * Tile::BM, n0 = blockIdx.y * Tile::BN;
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-    Tile::run(p, m0, n0, smem, acc);
-
+template <typename T, int TM, int TN, int WN = 2>
+__device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[TM][TN], int M, int N, const GemmEpilogue& e, int m0, int n0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, lr = lane & 15;
+    const int wm = wave / WN, wn = wave % WN, g = lane >> 4, lr = lane & 15;
     float* Cf = reinterpret_cast<float*>(e.C);
     T* Ct = reinterpret_cast<T*>(e.C);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * 16 * TM + i * 16 + lr;
-        if (m >= p.M) continue;
+        if (m >= M) continue;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * 16 * TN + j * 16 + g * 4;
-            if (n >= p.N) continue;
+            if (n >= N) continue;
             f32x4 v = acc[i][j];
             if (e.vec_ok) {
                 if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + n);
@@ -62,11 +54,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmOperands p, const G
                 // scalar path (N not a multiple of 4, e.g. heads = 2 or a 1-wide critic head)
                 for (int r = 0; r < 4; ++r) {
                     const int nn = n + r;
-                    if (nn >= p.N) break;
+                    if (nn >= N) break;
                     float x = v[r] + (e.bias ? e.bias[nn] : 0.f);
                     if (e.act == ACT_GEGLU) {
                         if (r & 1) continue;
-                        const float gate = (nn + 1 < p.N) ? v[r + 1] + (e.bias ? e.bias[nn + 1] : 0.f) : 0.f;
+                        const float gate = (nn + 1 < N) ? v[r + 1] + (e.bias ? e.bias[nn + 1] : 0.f) : 0.f;
                         x = gelu_erf(gate) * x;
                         const size_t o = (size_t)m * e.ldc + (nn >> 1);
                         if (e.out_f32) Cf[o] = x; else store_elem(Ct + o, x);
@@ -82,18 +74,71 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmOperands p, const G
     }
 }
 
-template <typename T, typename TA>
-static int launch_gemm(const GemmOperands& p, const GemmEpilogue& e, hipStream_t s) {
-    const long blocks128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    if (blocks128 >= 384) {
-        using Tile = GemmTile<T, TA, 4, 4>;
-        dim3 grid((p.M + Tile::BM - 1) / Tile::BM, (p.N + Tile::BN - 1) / Tile::BN);
-        hipLaunchKernelGGL((gemm_kernel<T, TA, 4, 4>), grid, dim3(256), Tile::SMEM, s, p, e);
+template <typename T, typename TA, int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmOperands p, const GemmEpilogue e) {
+    using Tile = GemmTile<T, TA, TM, TN>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int m0 = blockIdx.x * Tile::BM, n0 = blockIdx.y * Tile::BN;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    Tile::run(p, m0, n0, smem, acc);
+    gemm_epilogue<T, TM, TN>(acc, p.M, p.N, e, m0, n0);
+}
+
+template <typename T, int TM, int TN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(const GemmOperands p, const GemmEpilogue e, int a_nrows) {
+    using Tile = GemmDma<T, TM, TN, WM, WN, STAGES>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // XCD-aware tile map.  Workgroup b is observed to run on XCD b % 8 (speed only, never correctness); each XCD has a
+    // private 4 MiB L2.  XCD x owns a contiguous chunk of m-tiles and walks ALL n-tiles for it (m fastest), so its
+    // slice of A stays L2-resident while W streams through once per XCD, instead of every XCD thrashing on all of A.
+    const int MT = (p.M + Tile::BM - 1) / Tile::BM, cmax = (MT + 7) / 8;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int mstart = xcd * MT / 8, mcount = (xcd + 1) * MT / 8 - mstart;
+    const int ml = idx % cmax;
+    int m0, n0;
+    if (p.plain_map) {                                    // A/B reference order: m fastest over the whole grid
+        if ((int)blockIdx.x >= MT * ((p.N + Tile::BN - 1) / Tile::BN)) return;
+        m0 = (blockIdx.x % MT) * Tile::BM;
+        n0 = (blockIdx.x / MT) * Tile::BN;
     } else {
-        using Tile = GemmTile<T, TA, 2, 2>;
-        dim3 grid((p.M + Tile::BM - 1) / Tile::BM, (p.N + Tile::BN - 1) / Tile::BN);
-        hipLaunchKernelGGL((gemm_kernel<T, TA, 2, 2>), grid, dim3(256), Tile::SMEM, s, p, e);
+        if (ml >= mcount) return;                         // whole workgroup exits before any barrier
+        m0 = (mstart + ml) * Tile::BM;
+        n0 = (idx / cmax) * Tile::BN;
     }
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    Tile::run(p, a_nrows, m0, n0, smem, acc);
+    gemm_epilogue<T, TM, TN, WN>(acc, p.M, p.N, e, m0, n0);
+}
+
+template <typename T, typename TA, int TM, int TN>
+static int launch_v1(const GemmOperands& p, const GemmEpilogue& e, hipStream_t s) {
+    using Tile = GemmTile<T, TA, TM, TN>;
+    dim3 grid((p.M + Tile::BM - 1) / Tile::BM, (p.N + Tile::BN - 1) / Tile::BN);
+    hipLaunchKernelGGL((gemm_kernel<T, TA, TM, TN>), grid, dim3(256), Tile::SMEM, s, p, e);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+template <typename T, int TM, int TN, int STAGES, int WM = 2, int WN = 2>
+static int launch_dma(const GemmOperands& p, const GemmEpilogue& e, int a_nrows, hipStream_t s) {
+    using Tile = GemmDma<T, TM, TN, WM, WN, STAGES>;
+    static bool attr_set = false;
+    if (!attr_set && Tile::SMEM > 65536) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel<T, TM, TN, WM, WN, STAGES>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, Tile::SMEM) != hipSuccess) return PK_ELAUNCH;
+        attr_set = true;
+    }
+    const int MT = (p.M + Tile::BM - 1) / Tile::BM, NT = (p.N + Tile::BN - 1) / Tile::BN;
+    dim3 grid(8 * ((MT + 7) / 8) * NT);                   // see the XCD-aware tile map in the kernel
+    hipLaunchKernelGGL((gemm_dma_kernel<T, TM, TN, WM, WN, STAGES>), grid, dim3(64 * WM * WN), Tile::SMEM, s, p, e, a_nrows);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }
@@ -104,9 +149,12 @@ using namespace pk;
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-extern "C" int pk_gemm(int dtype, int a_is_f32, const void* A, int lda, const void* W, int ldw,
-                       int M, int N, int K, const float* bias, const float* res, int ldr,
-                       void* C, int ldc, int out_is_f32, int act, const int* a_rows, void* stream) {
+// variant: 0 = automatic; 1/2 = register-staged 64x64 / 128x128; 3/4 = DMA ring 64x64 / 128x128 (4 stages);
+//          5 = DMA 64x64 8 stages; 6 = DMA 128x128 3 stages     (explicit variants exist for tools/gemm_bench.py)
+extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const void* W, int ldw,
+                          int M, int N, int K, const float* bias, const float* res, int ldr,
+                          void* C, int ldc, int out_is_f32, int act, const int* a_rows, int a_nrows,
+                          int variant, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !C) return PK_EINVAL;
     if (dtype != 0 && dtype != 1) return PK_EINVAL;
     if (act < 0 || act > 2) return PK_EINVAL;
@@ -117,14 +165,78 @@ extern "C" int pk_gemm(int dtype, int a_is_f32, const void* A, int lda, const vo
     if (!al16(A) || !al16(W)) return PK_EALIGN;
     if (dtype == 0 && !a_is_f32) return PK_EINVAL;               // exact-f32 mode keeps everything f32
     if (act == ACT_GEGLU && (N & 1)) return PK_EINVAL;
+    if (a_rows && a_nrows <= 0) return PK_EINVAL;
+    if (!a_rows) a_nrows = M;
     GemmOperands p{A, W, a_rows, lda, ldw, M, N, K};
     GemmEpilogue e{bias, res, C, ldr, ldc, out_is_f32, act, 0};
-    const int out_el = out_is_f32 ? 4 : (dtype == 1 ? 2 : 4);
     bool v = (N % 4 == 0) && (ldc % 4 == 0) && al16(C) && (!bias || al16(bias)) && (!res || (al16(res) && ldr % 4 == 0));
     if (act == ACT_GEGLU) v = v && (ldc % 2 == 0) && ((reinterpret_cast<uintptr_t>(C) & 7) == 0);
-    (void)out_el;
     e.vec_ok = v ? 1 : 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == 1) return a_is_f32 ? launch_gemm<bf16, float>(p, e, s) : launch_gemm<bf16, bf16>(p, e, s);
-    return launch_gemm<float, float>(p, e, s);
+
+    // the DMA ring needs A in T, W zero-padded along K to the k-tile (the packers guarantee ldw >= round_up(K, BK)),
+    // and both matrices below 4 GiB (32-bit buffer offsets)
+    const int bk = dtype == 1 ? 64 : 32;
+    const int kpad = (K + bk - 1) / bk * bk;
+    const size_t el = dtype == 1 ? 2 : 4;
+    const bool dma_ok = !(dtype == 1 && a_is_f32) && ldw >= kpad &&
+                        (size_t)a_nrows * lda * el < 0xFFFFFFF0ull && (size_t)N * ldw * el < 0xFFFFFFF0ull;
+    const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    if (variant >= 100) { p.plain_map = 1; variant -= 100; }
+    if (variant == 0) {
+        if (!dma_ok) variant = blocks128 >= 384 ? 2 : 1;
+        // measured on MI355X (tools/gemm_bench.py, profiles/gemm_variants_r01.txt): the loop is bound by the L2 -> LDS
+        // fill rate, which grows with the number of co-resident workgroups -> shallow rings; 128x128 tiles (2x the
+        // flop/byte) only pay once there are enough of them to fill 256 CUs twice, or when K is long
+        else if (blocks128 >= 512 || (blocks128 >= 256 && K >= 1024)) variant = 9;    // 128x128, 2 stages (2 WG/CU)
+        else if (K >= 2048) variant = 3;                                              // 64x64, 4 stages (patch embed)
+        else variant = 8;                                                             // 64x64, 2 stages (5 WG/CU)
+    }
+    if (variant >= 3 && !dma_ok) return PK_EINVAL;
+    if (dtype == 1) {
+        switch (variant) {
+            case 1: return a_is_f32 ? launch_v1<bf16, float, 2, 2>(p, e, s) : launch_v1<bf16, bf16, 2, 2>(p, e, s);
+            case 2: return a_is_f32 ? launch_v1<bf16, float, 4, 4>(p, e, s) : launch_v1<bf16, bf16, 4, 4>(p, e, s);
+            case 3: return launch_dma<bf16, 2, 2, 4>(p, e, a_nrows, s);
+            case 4: return launch_dma<bf16, 4, 4, 4>(p, e, a_nrows, s);
+            case 5: return launch_dma<bf16, 2, 2, 8>(p, e, a_nrows, s);
+            case 6: return launch_dma<bf16, 4, 4, 3>(p, e, a_nrows, s);
+            case 7: return launch_dma<bf16, 2, 2, 3>(p, e, a_nrows, s);
+            case 8: return launch_dma<bf16, 2, 2, 2>(p, e, a_nrows, s);
+            case 9: return launch_dma<bf16, 4, 4, 2>(p, e, a_nrows, s);
+            case 10: return launch_dma<bf16, 4, 2, 3>(p, e, a_nrows, s);
+            case 11: return launch_dma<bf16, 2, 4, 3>(p, e, a_nrows, s);
+            case 12: return launch_dma<bf16, 4, 2, 4>(p, e, a_nrows, s);
+            case 13: return launch_dma<bf16, 4, 2, 3, 2, 4>(p, e, a_nrows, s);     // 128x128, 8 waves (2x4), wave tile 64x32
+            case 14: return launch_dma<bf16, 2, 4, 3, 4, 2>(p, e, a_nrows, s);     // 128x128, 8 waves (4x2), wave tile 32x64
+            case 15: return launch_dma<bf16, 4, 2, 4, 2, 4>(p, e, a_nrows, s);     // 128x128, 8 waves, 4 stages
+            case 16: return launch_dma<bf16, 4, 4, 2, 2, 4>(p, e, a_nrows, s);     // 128x256, 8 waves (2x4), 2 stages (96 KB)
+            case 17: return launch_dma<bf16, 4, 4, 3, 2, 4>(p, e, a_nrows, s);     // 128x256, 8 waves, 3 stages (144 KB)
+            default: return PK_EINVAL;
+        }
+    }
+    switch (variant) {
+        case 1: return launch_v1<float, float, 2, 2>(p, e, s);
+        case 2: return launch_v1<float, float, 4, 4>(p, e, s);
+        case 3: return launch_dma<float, 2, 2, 4>(p, e, a_nrows, s);
+        case 4: return launch_dma<float, 4, 4, 4>(p, e, a_nrows, s);
+        case 5: return launch_dma<float, 2, 2, 8>(p, e, a_nrows, s);
+        case 6: return launch_dma<float, 4, 4, 3>(p, e, a_nrows, s);
+        case 7: return launch_dma<float, 2, 2, 3>(p, e, a_nrows, s);
+        case 8: return launch_dma<float, 2, 2, 2>(p, e, a_nrows, s);
+        case 9: return launch_dma<float, 4, 4, 2>(p, e, a_nrows, s);
+        default: return PK_EINVAL;
+    }
+}
+
+extern "C" int pk_gemm(int dtype, int a_is_f32, const void* A, int lda, const void* W, int ldw,
+                       int M, int N, int K, const float* bias, const float* res, int ldr,
+                       void* C, int ldc, int out_is_f32, int act, const int* a_rows, void* stream) {
+    // without the physical row count of a gathered A the bounds-checked DMA path is not available: register-staged
+    if (a_rows) {
+        const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+        return pk_gemm_ex(dtype, a_is_f32, A, lda, W, ldw, M, N, K, bias, res, ldr, C, ldc, out_is_f32, act, a_rows,
+                          0x7fffffff / (lda > 0 ? lda : 1) / 4, blocks128 >= 384 ? 2 : 1, stream);
+    }
+    return pk_gemm_ex(dtype, a_is_f32, A, lda, W, ldw, M, N, K, bias, res, ldr, C, ldc, out_is_f32, act, nullptr, M, 0, stream);
 }

@@ -23,6 +23,7 @@ struct GemmOperands {
     const int* a_rows;  // optional gather: logical row m reads physical row a_rows[m]
     int lda, ldw;
     int M, N, K;
+    int plain_map;      // 1: row-major tile order (A/B benchmarking only); 0: XCD-aware tile map (DMA kernels)
 };
 
 template <typename T, typename TA> struct RawSlot;                    // one thread's 16-B LDS slot, pre-conversion

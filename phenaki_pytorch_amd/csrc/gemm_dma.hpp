@@ -1,0 +1,119 @@
+// DMA-fed MFMA GEMM main loop (second-generation core; same tile/fragment geometry and LDS image as gemm_core.hpp):
+//   acc[m][n] = sum_k A[m][k] * W[n][k],  A and W both of type T, W zero-padded along K to a multiple of BK.
+//
+// Operand tiles go HBM/L2 -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction, no VGPR round
+// trip) into a ring of STAGES k-tiles; STAGES-1 tiles are in flight ahead of the MFMAs, retired with counted
+// s_waitcnt vmcnt(N) + ONE raw s_barrier per k-tile (never __syncthreads(): it would drain the ring).
+// An LDS-DMA writes wave-uniform base + lane*16, so the 16-B-slot XOR swizzle (slot ^ (row & 7)) that makes
+// ds_read_b128 conflict-free is applied on the per-lane SOURCE address; the read side XORs the same way.
+// Rows past M / N and bytes past the end of a matrix are fetched through the buffer descriptor's bounds check
+// (they read as 0); the K tail of A multiplies the zero padding of W.
+#pragma once
+#include "gemm_core.hpp"
+
+namespace pk {
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// TM x TN MFMA tiles per wave, WM x WN waves per workgroup (64 * WM * WN threads)
+template <typename T, int TM, int TN, int WM, int WN, int STAGES>
+struct GemmDma {
+    static constexpr int NW = WM * WN;
+    static constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
+    static constexpr int IA = BM / (8 * NW), IW = BN / (8 * NW);   // DMA instructions per wave per k-tile (8 rows each)
+    static_assert(IA * 8 * NW == BM && IW * 8 * NW == BN, "tile rows must split evenly over the waves' 8-row DMA pieces");
+    static constexpr int EPS = 16 / (int)sizeof(T);
+    static constexpr int BK = 8 * EPS;
+    static constexpr int CH = BK / 32;
+    static constexpr int STAGE_BYTES = (BM + BN) * 128;
+    static constexpr int SMEM = STAGES * STAGE_BYTES;
+    static constexpr int IPW = IA + IW;
+    static_assert((STAGES - 2) * IPW <= 63, "vmcnt is a 6-bit counter");
+
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    template <int TILES> static __device__ __forceinline__ void wait_tiles() { wait_vmcnt<TILES * IPW>(); }
+
+    static __device__ __forceinline__ void wait_outstanding(int tiles) {
+        // `tiles` k-tiles issued after the one about to be consumed may stay in flight
+        switch (tiles) {
+            case 0: wait_tiles<0>(); break;
+            case 1: wait_tiles<1>(); break;
+            case 2: wait_tiles<(STAGES > 3 ? 2 : 0)>(); break;
+            case 3: wait_tiles<(STAGES > 4 ? 3 : 0)>(); break;
+            case 4: wait_tiles<(STAGES > 5 ? 4 : 0)>(); break;
+            case 5: wait_tiles<(STAGES > 6 ? 5 : 0)>(); break;
+            default: wait_tiles<(STAGES > 7 ? 6 : 0)>(); break;
+        }
+    }
+
+    // acc must be zero-initialised by the caller. a_nrows = number of physical rows behind p.A (for the bounds check)
+    static __device__ __forceinline__ void run(const GemmOperands& p, int a_nrows, int m0, int n0, char* smem, f32x4 (&acc)[TM][TN]) {
+        const int tid = threadIdx.x, lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int wm = wave / WN, wn = wave % WN, g = lane >> 4, lr = lane & 15;
+        constexpr int SZ = (int)sizeof(T);
+
+        const uint32_t bytesA = (uint32_t)a_nrows * (uint32_t)p.lda * SZ;
+        const uint32_t bytesW = (uint32_t)p.N * (uint32_t)p.ldw * SZ;
+        __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, bytesA, 0x00020000);
+        __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, bytesW, 0x00020000);
+
+        // per-lane source offsets (bytes) at k = 0; the k-tile advance goes through the scalar offset
+        const int srcslot = (lane & 7) ^ (lane >> 3);
+        uint32_t offA[IA], offW[IW];
+#pragma unroll
+        for (int i = 0; i < IA; ++i) {
+            const int row = (wave * IA + i) * 8 + (lane >> 3);
+            int gm = m0 + row;
+            const bool ok = gm < p.M;
+            if (ok && p.a_rows) gm = p.a_rows[gm];
+            offA[i] = ok ? (uint32_t)gm * (uint32_t)p.lda * SZ + srcslot * 16 : bytesA;
+        }
+#pragma unroll
+        for (int i = 0; i < IW; ++i) {
+            const int row = (wave * IW + i) * 8 + (lane >> 3);
+            const int gn = n0 + row;
+            offW[i] = gn < p.N ? (uint32_t)gn * (uint32_t)p.ldw * SZ + srcslot * 16 : bytesW;
+        }
+
+        auto issue = [&](int kt, int slot) {
+            char* base = smem + slot * STAGE_BYTES;
+            const int koff = kt * 128;
+#pragma unroll
+            for (int i = 0; i < IA; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(base + (wave * IA + i) * 1024), 16, offA[i], koff, 0, 0);
+#pragma unroll
+            for (int i = 0; i < IW; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(base + BM * 128 + (wave * IW + i) * 1024), 16, offW[i], koff, 0, 0);
+        };
+
+        const int nt = (p.K + BK - 1) / BK;
+        const int pre = nt < STAGES - 1 ? nt : STAGES - 1;
+        for (int s = 0; s < pre; ++s) issue(s, s);
+        for (int kt = 0; kt < nt; ++kt) {
+            const int issued = (kt + STAGES - 1 < nt) ? kt + STAGES - 1 : nt;      // tiles issued so far
+            wait_outstanding(issued - (kt + 1));
+            __builtin_amdgcn_s_barrier();                 // tile kt landed for every wave; everyone is done with tile kt-1
+            if (kt + STAGES - 1 < nt) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+            const char* a = smem + (kt % STAGES) * STAGE_BYTES;
+            const char* w = a + BM * 128;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                Frag<T> fa[TM], fw[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) lds_frag(fa[i], a, wm * 16 * TM + i * 16 + lr, c, g);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) lds_frag(fw[j], w, wn * 16 * TN + j * 16 + lr, c, g);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mma(fw[j], fa[i], acc[i][j]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                     // the ring is dead: callers may reuse smem
+    }
+};
+
+}  // namespace pk

@@ -5,20 +5,33 @@
 
 namespace pk {
 
+struct LnArgs {
+    const float* x; int ldx;
+    const float* gamma; const float* beta; float eps;
+    void* out; int ldo;            // T (bf16 | f32 by the template) or null
+    float* out2; int ldo2;         // f32 or null
+    void* raw; int ldraw;          // optional: x itself converted to T (the un-normalised K/V source, attention.py:140-144)
+    int M, D;
+    int grp, gstride, goff;        // output row remap r -> (r / grp) * gstride + goff + r % grp        (grp > 0)
+    int pb, pc;                    // output row remap (a, b, c) -> (a, c, b) over dims (M/(pb*pc), pb, pc) (pb > 0)
+};
+
 // one wave per row, D % 4 == 0, D <= 64*4*VMAX
 template <typename TO, int VMAX>
-__global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, int ldx,
-                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      float eps, TO* __restrict__ out, int ldo,
-                                                      float* __restrict__ out2, int ldo2, int M, int D,
-                                                      int grp, int gstride, int goff) {
+__global__ __launch_bounds__(256) void ln_rows_kernel(const LnArgs p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    // optional output row remap: input row r -> (r / grp) * gstride + goff + r % grp  (frame-group concat)
-    const int orow = grp > 0 ? (row / grp) * gstride + goff + row % grp : row;
-    const float* xr = x + (size_t)row * ldx;
-    const int nv = D >> 2;
+    if (row >= p.M) return;
+    int orow = row;
+    if (p.grp > 0) orow = (row / p.grp) * p.gstride + p.goff + row % p.grp;
+    else if (p.pb > 0) {
+        const int c = row % p.pc, b = (row / p.pc) % p.pb, a = row / (p.pc * p.pb);
+        orow = (a * p.pc + c) * p.pb + b;
+    }
+    const float* xr = p.x + (size_t)row * p.ldx;
+    TO* out = reinterpret_cast<TO*>(p.out);
+    TO* raw = reinterpret_cast<TO*>(p.raw);
+    const int nv = p.D >> 2;
     f32x4 v[VMAX];
     float s = 0.f;
 #pragma unroll
@@ -26,7 +39,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
         const int c = lane + i * 64;
         if (c < nv) { v[i] = *reinterpret_cast<const f32x4*>(xr + c * 4); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
     }
-    const float mean = wave_sum(s) / (float)D;
+    const float mean = wave_sum(s) / (float)p.D;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < VMAX; ++i) {
@@ -36,18 +49,19 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
             for (int r = 0; r < 4; ++r) { const float d = v[i][r] - mean; q += d * d; }
         }
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)p.D + p.eps);
 #pragma unroll
     for (int i = 0; i < VMAX; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
-            const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c * 4);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c * 4);
             f32x4 y;
 #pragma unroll
             for (int r = 0; r < 4; ++r) y[r] = (v[i][r] - mean) * rstd * gm[r];
-            if (beta) y += *reinterpret_cast<const f32x4*>(beta + c * 4);
-            if (out) store4(out + (size_t)orow * ldo + c * 4, y);
-            if (out2) store4(out2 + (size_t)orow * ldo2 + c * 4, y);
+            if (p.beta) y += *reinterpret_cast<const f32x4*>(p.beta + c * 4);
+            if (out) store4(out + (size_t)orow * p.ldo + c * 4, y);
+            if (p.out2) store4(p.out2 + (size_t)orow * p.ldo2 + c * 4, y);
+            if (raw) store4(raw + (size_t)orow * p.ldraw + c * 4, v[i]);
         }
     }
 }
@@ -55,23 +69,28 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
 }  // namespace pk
 using namespace pk;
 
-// out (f32 if out_kind == 0 else bf16) and/or out2 (always f32) receive LN(x) * gamma + beta.
-// grp > 0 remaps output rows: row r -> (r / grp) * gstride + goff + r % grp (cvivit.py:549 frame concat).
+// out / raw (f32 if out_kind == 0 else bf16) and/or out2 (always f32); out, out2 receive LN(x) * gamma + beta, raw
+// receives x itself.  Output rows may be remapped: grp > 0: r -> (r / grp) * gstride + goff + r % grp (cvivit.py:549
+// frame concat); pb > 0: rows seen as (a, b, c) with b < pb, c < pc are written at (a, c, b) -- the spatial <-> temporal
+// 'b t (h w) <-> b (h w) t' rearranges of cvivit.py:468,472,488,496.
 extern "C" int pk_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float eps,
-                            void* out, int ldo, int out_kind, float* out2, int ldo2, int M, int D,
-                            int grp, int gstride, int goff, void* stream) {
+                            void* out, int ldo, int out_kind, float* out2, int ldo2, void* raw, int ldraw,
+                            int M, int D, int grp, int gstride, int goff, int pb, int pc, void* stream) {
     if (M <= 0 || D <= 0 || !x || !gamma || (!out && !out2)) return PK_EINVAL;
-    if ((D & 3) || (ldx & 3) || (out && (ldo & 3)) || (out2 && (ldo2 & 3))) return PK_EALIGN;
+    if ((D & 3) || (ldx & 3) || (out && (ldo & 3)) || (out2 && (ldo2 & 3)) || (raw && (ldraw & 3))) return PK_EALIGN;
     if (D > 64 * 4 * 8) return PK_EINVAL;
+    if (pb > 0 && (pc <= 0 || M % (pb * pc))) return PK_EINVAL;
+    if (grp > 0 && pb > 0) return PK_EINVAL;
+    LnArgs p{x, ldx, gamma, beta, eps, out, ldo, out2, ldo2, raw, ldraw, M, D, grp, gstride, goff, pb, pc};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((M + 3) / 4), block(256);
     const bool small = D <= 64 * 4 * 2;
     if (out_kind == 0) {
-        if (small) hipLaunchKernelGGL((ln_rows_kernel<float, 2>), grid, block, 0, s, x, ldx, gamma, beta, eps, (float*)out, ldo, out2, ldo2, M, D, grp, gstride, goff);
-        else hipLaunchKernelGGL((ln_rows_kernel<float, 8>), grid, block, 0, s, x, ldx, gamma, beta, eps, (float*)out, ldo, out2, ldo2, M, D, grp, gstride, goff);
+        if (small) hipLaunchKernelGGL((ln_rows_kernel<float, 2>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((ln_rows_kernel<float, 8>), grid, block, 0, s, p);
     } else {
-        if (small) hipLaunchKernelGGL((ln_rows_kernel<bf16, 2>), grid, block, 0, s, x, ldx, gamma, beta, eps, (bf16*)out, ldo, out2, ldo2, M, D, grp, gstride, goff);
-        else hipLaunchKernelGGL((ln_rows_kernel<bf16, 8>), grid, block, 0, s, x, ldx, gamma, beta, eps, (bf16*)out, ldo, out2, ldo2, M, D, grp, gstride, goff);
+        if (small) hipLaunchKernelGGL((ln_rows_kernel<bf16, 2>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((ln_rows_kernel<bf16, 8>), grid, block, 0, s, p);
     }
     PK_CHECK_LAUNCH();
     return PK_OK;

@@ -12,7 +12,7 @@
 //  pk_topk_mask    : mask = top-k(scores) per row (:488-489) and ids = where(mask, mask_id, ids) (:491).
 // Noise: PARITY mode reads U[0,1) from memory (the tests inject the oracle's draws) and uses logf / true
 // division exactly like the reference expression; FAST mode draws U from the counter hash in common.hpp.
-#include "gemm_core.hpp"
+#include "gemm_dma.hpp"
 
 namespace pk {
 
@@ -52,7 +52,7 @@ struct VocabArgs {
 
 template <typename T, bool PARITY>
 __global__ __launch_bounds__(256) void vocab_sample_kernel(const GemmOperands p, const VocabArgs e) {
-    using Tile = GemmTile<T, T, 4, 4>;
+    using Tile = GemmDma<T, 4, 4, 2, 2, 2>;      // 128x128 tile, LDS-DMA ring of 2 (2 workgroups / CU): best for N = 65 536
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m0 = blockIdx.x * Tile::BM, n0 = blockIdx.y * Tile::BN;
     f32x4 acc[4][4];
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void vocab_sample_kernel(const GemmOperands p,
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-    Tile::run(p, m0, n0, smem, acc);
+    Tile::run(p, p.M, m0, n0, smem, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, lr = lane & 15;
@@ -220,6 +220,9 @@ extern "C" int pk_vocab_sample(int dtype, const void* A, int lda, const void* W,
     const int eps = dtype == 1 ? 8 : 4;
     if ((V & 3) || (D % eps) || (lda % eps) || (ldw % eps) || !al16(A) || !al16(W) || !al16(bias) || (U && !al16(U))) return PK_EALIGN;
     const int ntiles = pk_vocab_ntiles(V);
+    const int bk = dtype == 1 ? 64 : 32;                  // LDS-DMA main loop: W zero-padded along K to the k-tile
+    if (ldw < (D + bk - 1) / bk * bk) return PK_EINVAL;
+    if ((size_t)M * lda * (dtype == 1 ? 2 : 4) >= 0xFFFFFFF0ull || (size_t)V * ldw * (dtype == 1 ? 2 : 4) >= 0xFFFFFFF0ull) return PK_EINVAL;
     GemmOperands p{A, W, nullptr, lda, ldw, M, V, D};
     VocabArgs e;
     e.bias = bias; e.U = U; e.rows = rows;
@@ -235,11 +238,11 @@ extern "C" int pk_vocab_sample(int dtype, const void* A, int lda, const void* W,
     dim3 grid((M + 127) / 128, ntiles), block(256);
     hipStream_t s = STREAM(stream);
     if (dtype == 1) {
-        constexpr int SM = GemmTile<bf16, bf16, 4, 4>::SMEM;
+        constexpr int SM = GemmDma<bf16, 4, 4, 2, 2, 2>::SMEM;
         if (U) hipLaunchKernelGGL((vocab_sample_kernel<bf16, true>), grid, block, SM, s, p, e);
         else hipLaunchKernelGGL((vocab_sample_kernel<bf16, false>), grid, block, SM, s, p, e);
     } else {
-        constexpr int SM = GemmTile<float, float, 4, 4>::SMEM;
+        constexpr int SM = GemmDma<float, 4, 4, 2, 2, 2>::SMEM;
         if (U) hipLaunchKernelGGL((vocab_sample_kernel<float, true>), grid, block, SM, s, p, e);
         else hipLaunchKernelGGL((vocab_sample_kernel<float, false>), grid, block, SM, s, p, e);
     }

@@ -182,30 +182,35 @@ class CViViT(nn.Module):
             group(self.to_patch_emb, 1, nt, pt, hw)
         return tokens, T
 
-    def _spatial(self, transformer, x2d, B, T):
+    def _spatial(self, transformer, x2d, B, T, to_temporal=False, as_t=False):
+        """rows '(b t) (h w)'.  to_temporal: the final norm_out writes its rows as '(b h w) t' (cvivit.py:468) so the
+        temporal transformer needs no transpose pass; as_t: return the rows in the GEMM operand type."""
         h, w = self.patch_height_width
+        dt = compute_dtype_of(self)
         bias = self.spatial_rel_pos_bias(h, w)
-        return transformer.run(x2d, B * T, h * w, compute_dtype_of(self), video_shape=(B, T, h, w), attn_bias=bias)
+        out_t = torch.empty((x2d.shape[0], x2d.shape[1]), device=x2d.device, dtype=L.tdtype(dt)) if as_t else None
+        return transformer.run(x2d, B * T, h * w, dt, video_shape=(B, T, h, w), attn_bias=bias, out_t=out_t,
+                               perm=(T, h * w) if to_temporal else (0, 0))
 
-    def _temporal(self, transformer, x2d, B, T):
+    def _temporal(self, transformer, xt2d, B, T):
+        """rows '(b h w) t' in, '(b t) (h w)' out (the final norm_out writes transposed, cvivit.py:472,496).
+        NOTE: video_shape stays (b, t, h, w) although rows are ((b h w), t): the reference's PEG sees that
+        scrambled view (cvivit.py:456,468-470) and so must we."""
         h, w = self.patch_height_width
-        hw = h * w
-        D = x2d.shape[-1]
-        xt = x2d.view(B, T, hw, D).transpose(1, 2).contiguous().view(B * hw * T, D)       # 'b t h w d -> (b h w) t d'
-        # NOTE: video_shape stays (b, t, h, w) although rows are ((b h w), t): the reference's PEG sees that
-        # scrambled view (cvivit.py:456,468-470) and so must we.
-        out = transformer.run(xt, B * hw, T, compute_dtype_of(self), video_shape=(B, T, h, w))
-        return out.view(B, hw, T, D).transpose(1, 2).contiguous().view(B * T * hw, D)
+        return transformer.run(xt2d, B * h * w, T, compute_dtype_of(self), video_shape=(B, T, h, w), perm=(h * w, T))
 
     def _encode2d(self, tokens2d, B, T):
-        x = self._spatial(self.enc_spatial_transformer, tokens2d, B, T)
+        x = self._spatial(self.enc_spatial_transformer, tokens2d, B, T, to_temporal=True)
         return self._temporal(self.enc_temporal_transformer, x, B, T)
 
     def _decode2d(self, tokens2d, B, T):
         """tokens (B*T*h*w, dim) f32 -> video (B, C, 1 + (T-1)*pt, H, W) f32 (cvivit.py:476-516)."""
         dt = compute_dtype_of(self)
-        x = self._temporal(self.dec_temporal_transformer, tokens2d, B, T)
-        x = self._spatial(self.dec_spatial_transformer, x, B, T)
+        hw0 = self.image_num_tokens
+        D0 = tokens2d.shape[-1]
+        xt = tokens2d.view(B, T, hw0, D0).transpose(1, 2).contiguous().view(B * hw0 * T, D0)    # 'b t h w d -> (b h w) t d'
+        x = self._temporal(self.dec_temporal_transformer, xt, B, T)
+        x = self._spatial(self.dec_spatial_transformer, x, B, T, as_t=True)
         h, w = self.patch_height_width
         hw = h * w
         ph, pw = self.patch_size

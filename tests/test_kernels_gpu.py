@@ -80,6 +80,53 @@ def test_gemm_geglu_leaky_gather_and_T_output(L, mode):
     close(C3, h[idx.long()], 2e-5, 'gather')
 
 
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9] + [('bf16only', v) for v in range(10, 18)])
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('M,N,K', [(300, 200, 96), (1000, 520, 1368), (4608, 512, 512), (129, 2736, 512)])
+def test_gemm_main_loop_variants(L, variant, mode, M, N, K):
+    if isinstance(variant, tuple):
+        if mode != 'bf16':
+            pytest.skip('tuning variants are instantiated for bf16 only')
+        variant = variant[1]
+    """register-staged and LDS-DMA main loops (tile / ring-depth variants) agree with torch, incl. M/N/K tails, a row
+    gather, and the K tail handled by W's zero padding."""
+    A = torch.randn(M + 7, K, generator=g(60))
+    W = torch.randn(N, K, generator=g(61)) / math.sqrt(K)
+    bias = torch.randn(N, generator=g(62))
+    res = torch.randn(M, N, generator=g(63))
+    idx = torch.randperm(M + 7, generator=g(64))[:M].int()
+    dt = L.F32 if mode == 'f32' else L.BF16
+    td = L.tdtype(dt)
+    cast = (lambda t: t) if mode == 'f32' else bf
+    bk = 32 if mode == 'f32' else 64
+    Kp = (K + bk - 1) // bk * bk
+    Wp = torch.zeros(N, Kp)
+    Wp[:, :K] = W
+    ref = cast(A)[idx.long()] @ cast(W).t() + bias + res
+    C = torch.full((M, N), float('nan'), device='cuda')
+    L.gemm(dt, A.cuda().to(td), Wp.cuda().to(td), M, N, K, C=C, bias=bias.cuda(), res=res.cuda(), a_rows=idx.cuda(), variant=variant)
+    close(C, ref, 3e-5, f'gemm variant {variant} {mode} {M}x{N}x{K}')
+    C2 = torch.full((M, N), float('nan'), device='cuda')
+    L.gemm(dt, A.cuda().to(td), Wp.cuda().to(td), M, N, K, C=C2, variant=variant)
+    close(C2, cast(A)[:M] @ cast(W).t(), 3e-5, f'gemm variant {variant} {mode} plain')
+
+
+def test_layernorm_raw_copy_and_transposed_rows(L):
+    a, b, c, D = 3, 5, 7, 128
+    M = a * b * c
+    x = torch.randn(M, D, generator=g(65))
+    gamma = 1 + 0.1 * torch.randn(D, generator=g(66))
+    ref = F.layer_norm(x, (D,), gamma, None)
+    out = torch.empty(M, D, device='cuda', dtype=torch.bfloat16)
+    raw = torch.empty(M, D, device='cuda', dtype=torch.bfloat16)
+    out2 = torch.empty(M, D, device='cuda')
+    L.layernorm(x.cuda(), gamma.cuda(), None, M, D, out=out, out2=out2, raw=raw, perm=(b, c))
+    tr = lambda t: t.view(a, b, c, D).transpose(1, 2).reshape(M, D)
+    close(out2, tr(ref), 1e-5, 'perm f32')
+    close(out.float(), tr(ref), 5e-3, 'perm bf16')
+    assert torch.equal(raw.cpu(), tr(x).to(torch.bfloat16))
+
+
 def test_gemm_rejects_bad_arguments(L):
     A = torch.randn(8, 10, device='cuda')
     W = torch.randn(8, 10, device='cuda')
