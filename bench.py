@@ -83,11 +83,19 @@ def build_models(dtype, with_sampler):
     return load_product('full', FULL, device='cuda', dtype=dtype, with_critic=with_sampler)
 
 
+VARIANT_KERNEL = {1: 'gemm_kernel<T,TA,2,2>', 2: 'gemm_kernel<T,TA,4,4>', 3: 'gemm_dma_kernel<T,2,2,2,2,4>',
+                  8: 'gemm_dma_kernel<T,2,2,2,2,2>', 9: 'gemm_dma_kernel<T,4,4,2,2,2>'}
+
+
 class GemmProfiler:
-    """live HIP-event timing of every pk_gemm launch of one (untimed) pass, on the stream the kernels run on."""
+    """live HIP-event timing of the pk_gemm launches of one (untimed, eager) pass of the step, on the stream the
+    kernels run on: every launch of the pass is recorded with its live operands, then each one is re-issued REPS times
+    back to back between two HIP events (a per-launch event pair around a ~10 us kernel mostly measures the events).
+    Grouped by the kernel instantiation pk_gemm picked (the names rocprofv3 reports)."""
+    REPS = 20
 
     def __init__(self):
-        self.records = []
+        self.calls = []
 
     def __enter__(self):
         from phenaki_pytorch_amd import _lib
@@ -96,18 +104,9 @@ class GemmProfiler:
         prof = self
 
         def gemm(dtype, A, W, M, N, K, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = prof._orig(dtype, A, W, M, N, K, **kw)
-            e1.record()
-            tile = '4x4' if ((M + 127) // 128) * ((N + 127) // 128) >= 384 else '2x2'
-            a = 'float' if (dtype == _lib.BF16 and A.dtype == torch.float32) else ('bf16' if dtype == _lib.BF16 else 'float')
-            t = 'bf16' if dtype == _lib.BF16 else 'float'
-            prof.records.append((f'gemm_kernel<{t},{a},{tile}>', 2.0 * M * N * K, e0, e1))
-            return out
+            prof.calls.append((dtype, A, W, M, N, K, kw))
+            return prof._orig(dtype, A, W, M, N, K, **kw)
         _lib.gemm = gemm
-        for mod in list(sys.modules.values()):          # modules bound `L.gemm` through the module object: nothing to patch
-            pass
         return self
 
     def __exit__(self, *exc):
@@ -115,12 +114,24 @@ class GemmProfiler:
         torch.cuda.synchronize()
 
     def summary(self):
-        by = {}
-        for name, flops, e0, e1 in self.records:
+        lib, by = self._lib, {}
+        for dtype, A, W, M, N, K, kw in self.calls:
+            a_is_f32 = 1 if A.dtype == torch.float32 else 0
+            rows = A.shape[0] if kw.get('a_rows') is not None else M
+            v = lib.load().pk_gemm_auto_variant(dtype, a_is_f32, M, N, K, A.stride(-2), W.stride(0), rows)
+            t = 'pk::bf16' if dtype == lib.BF16 else 'float'
+            name = VARIANT_KERNEL.get(v, f'variant{v}').replace('TA', 'float' if a_is_f32 else t).replace('T', t)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self._orig(dtype, A, W, M, N, K, **kw)
+            e0.record()
+            for _ in range(self.REPS):
+                self._orig(dtype, A, W, M, N, K, **kw)
+            e1.record()
+            torch.cuda.synchronize()
             d = by.setdefault(name, [0, 0.0, 0.0])
             d[0] += 1
-            d[1] += flops
-            d[2] += e0.elapsed_time(e1) * 1e-3
+            d[1] += 2.0 * M * N * K
+            d[2] += e0.elapsed_time(e1) * 1e-3 / self.REPS
         return {k: dict(launches=v[0], flops=v[1], seconds=v[2]) for k, v in by.items()}
 
 

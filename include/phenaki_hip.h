@@ -44,6 +44,8 @@ int pk_gemm(int dtype, int a_is_f32, const void* A, int lda, const void* W, int 
 int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const void* W, int ldw, int M, int N, int K,
                const float* bias, const float* res, int ldr, void* C, int ldc, int out_is_f32, int act,
                const int* a_rows, int a_nrows, int variant, void* stream);
+/* the variant `0 = automatic` resolves to for a shape (host-only helper; used to label kernels in bench.py) */
+int pk_gemm_auto_variant(int dtype, int a_is_f32, int M, int N, int K, int lda, int ldw, int a_nrows);
 
 /* y = LayerNorm(x) * gamma (+ beta), eps inside the sqrt, biased variance.  attention.py:29-36 (gamma-only
  * LayerNorm, beta NULL or the zero buffer), attention.py:47 and cvivit.py:277,284 (nn.LayerNorm).

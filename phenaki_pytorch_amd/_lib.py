@@ -23,6 +23,7 @@ _ULL = ctypes.c_ulonglong
 SIGNATURES = {
     'pk_gemm': [_I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P],
     'pk_gemm_ex': [_I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P],
+    'pk_gemm_auto_variant': [_I, _I, _I, _I, _I, _I, _I, _I],
     'pk_layernorm': [_P, _I, _P, _P, _F, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'pk_patchify_ln': [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _I, _I, _P],
     'pk_unpatchify': [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],

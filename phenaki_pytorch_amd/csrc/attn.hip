@@ -31,62 +31,76 @@ struct PrepArgs {
     float scale;
 };
 
+// 16 lanes per (sequence, head, row): each lane owns 4 consecutive head dims (one 16-byte load), the row's
+// sum of squares is a 4-step xor-shuffle inside the 16-lane group.
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+    return v;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void prep_q_kernel(const PrepArgs p) {
-    // one wave per (s, hh, i) including pad rows
-    const int lane = threadIdx.x & 63;
-    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l16 = threadIdx.x & 15;
+    const long r = (long)blockIdx.x * 16 + (threadIdx.x >> 4);          // row index over (s, hh, i) incl. pad rows
     const long total = (long)p.S * p.h * p.nq_pad;
     if (r >= total) return;
     const int i = (int)(r % p.nq_pad);
     const long sh = r / p.nq_pad;
     const int hh = (int)(sh % p.h), s = (int)(sh / p.h);
-    float v = 0.f;
+    f32x4 v = f32x4{0, 0, 0, 0};
     if (i < p.nq) {
-        const float x = p.q[((size_t)s * p.nq + i) * p.ldq + hh * DH + lane];
-        const float ss = wave_sum(x * x);
-        v = x / fmaxf(sqrtf(ss), 1e-12f) * p.q_scale[lane] * p.scale;     // F.normalize eps = 1e-12
+        const f32x4 x = *reinterpret_cast<const f32x4*>(p.q + ((size_t)s * p.nq + i) * p.ldq + hh * DH + l16 * 4);
+        const float ss = group16_sum((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]));
+        const float inv = p.scale / fmaxf(sqrtf(ss), 1e-12f);               // F.normalize eps = 1e-12
+        const f32x4 qs = *reinterpret_cast<const f32x4*>(p.q_scale + l16 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = x[e] * inv * qs[e];
     }
-    store_elem(reinterpret_cast<T*>(p.Qp) + (size_t)r * DH + lane, v);
+    store4(reinterpret_cast<T*>(p.Qp) + (size_t)r * DH + l16 * 4, v);
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void prep_kv_kernel(const PrepArgs p) {
-    // one block per (s, hh, 64-key tile)
+    // one block per (s, hh, 64-key tile); thread -> (key = tid >> 4 (+16 per pass), 4 head dims)
     __shared__ float vt[64][65];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tiles = p.nk_pad / 64 + ((p.nk_pad % 64) ? 1 : 0);
+    const int l16 = threadIdx.x & 15;
+    const int tiles = (p.nk_pad + 63) / 64;
     const int kt = blockIdx.x % tiles;
     const int sh = blockIdx.x / tiles;
     const int hh = sh % p.h, s = sh / p.h;
     const int nk = p.nnull + p.n_kv;
     T* Kp = reinterpret_cast<T*>(p.Kp) + (size_t)sh * p.nk_pad * DH;
     T* Vt = reinterpret_cast<T*>(p.Vt) + (size_t)sh * DH * p.nk_pad;
-    for (int jj = wave; jj < 64; jj += 4) {
+    const int kend = (p.nk_pad - kt * 64) < 64 ? (p.nk_pad - kt * 64) : 64;   // keys of this tile that exist in the padded image
+    const f32x4 ks = *reinterpret_cast<const f32x4*>(p.k_scale + l16 * 4);
+    for (int jj = threadIdx.x >> 4; jj < kend; jj += 16) {
         const int key = kt * 64 + jj;
-        float kx = 0.f, vx = 0.f;
+        f32x4 kx = f32x4{0, 0, 0, 0}, vx = kx;
         if (key < p.nnull) {
-            kx = p.null_kv[((size_t)hh * 2 * p.nnull + 2 * key) * DH + lane];
-            vx = p.null_kv[((size_t)hh * 2 * p.nnull + 2 * key + 1) * DH + lane];
+            kx = *reinterpret_cast<const f32x4*>(p.null_kv + ((size_t)hh * 2 * p.nnull + 2 * key) * DH + l16 * 4);
+            vx = *reinterpret_cast<const f32x4*>(p.null_kv + ((size_t)hh * 2 * p.nnull + 2 * key + 1) * DH + l16 * 4);
         } else if (key < nk) {
             const float* row = p.kv + ((size_t)s * p.n_kv + (key - p.nnull)) * p.ldkv;
-            kx = row[hh * DH + lane];
-            vx = row[p.h * DH + hh * DH + lane];
+            kx = *reinterpret_cast<const f32x4*>(row + hh * DH + l16 * 4);
+            vx = *reinterpret_cast<const f32x4*>(row + p.h * DH + hh * DH + l16 * 4);
         }
-        const float ss = wave_sum(kx * kx);
-        const float kn = key < nk ? kx / fmaxf(sqrtf(ss), 1e-12f) * p.k_scale[lane] : 0.f;
-        if (key < p.nk_pad) store_elem(Kp + (size_t)key * DH + lane, kn);
-        vt[jj][lane] = vx;
+        const float ss = group16_sum((kx[0] * kx[0] + kx[1] * kx[1]) + (kx[2] * kx[2] + kx[3] * kx[3]));
+        const float inv = key < nk ? 1.0f / fmaxf(sqrtf(ss), 1e-12f) : 0.f;
+        f32x4 kn;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { kn[e] = kx[e] * inv * ks[e]; vt[jj][l16 * 4 + e] = vx[e]; }
+        store4(Kp + (size_t)key * DH + l16 * 4, kn);
     }
     __syncthreads();
     // transposed store: thread -> (d = tid >> 2, 16 consecutive keys)
     const int d = threadIdx.x >> 2, j0 = (threadIdx.x & 3) * 16;
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
-        const int key = kt * 64 + j0 + q4 * 4;
-        if (key < p.nk_pad) {   // nk_pad % 4 == 0
-            const f32x4 o = f32x4{vt[j0 + q4 * 4 + 0][d], vt[j0 + q4 * 4 + 1][d], vt[j0 + q4 * 4 + 2][d], vt[j0 + q4 * 4 + 3][d]};
-            store4(Vt + (size_t)d * p.nk_pad + key, o);
+        const int jl = j0 + q4 * 4;
+        if (jl < kend) {   // nk_pad % 4 == 0
+            const f32x4 o = f32x4{vt[jl + 0][d], vt[jl + 1][d], vt[jl + 2][d], vt[jl + 3][d]};
+            store4(Vt + (size_t)d * p.nk_pad + kt * 64 + jl, o);
         }
     }
 }
@@ -98,6 +112,7 @@ struct AttnArgs {
     const float* slopes;                                   // ALiBi slopes [h] (causal layers), or null
     void* O; int ldo; int out_f32;                         // O[(s*nq + i)][hh*64 + d]
     int S, h, nq, n_kv, nnull, nq_pad, nk_pad, causal;
+    int bias_vec;                                          // bias rows are 16-byte loadable (nnull == 0, aligned strides)
 };
 
 __device__ __forceinline__ void load_vt(Frag<bf16>& f, const bf16* row, int kb, int g) {
@@ -158,12 +173,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
                 for (int qf = 0; qf < QF; ++qf) st[qf][f] = mma(fk, fq[qf][c], st[qf][f]);
             }
-        const bool plain = (kb + 32 <= nk) && !km && !p.causal && !bias;
+        // whole-tile fast paths (wave-uniform): a full tile of real keys with no key mask / causal structure needs no
+        // per-element work; the additive bias of such a tile is one 16-byte load per 4 keys (nnull == 0, aligned rows)
+        const bool simple = (kb + 32 <= nk) && !km && !p.causal;
+        const bool vbias = bias && simple && p.bias_vec;
+        const bool plain = simple && (!bias || vbias);
         float pr[QF][8];
 #pragma unroll
         for (int qf = 0; qf < QF; ++qf) {
             const int qi = q0 + qf * 16 + lr;
             float mx = -INFINITY;
+            if (vbias && qi < p.nq) {
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+                    st[qf][f] += *reinterpret_cast<const f32x4*>(bias + (size_t)qi * p.bias_ld + kb + f * 16 + g * 4);
+            }
 #pragma unroll
             for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -251,15 +275,17 @@ extern "C" int pk_attn_prep(int dtype, const float* q, int ldq, const float* kv,
     if (kv && nnull > 0 && !null_kv) return PK_EINVAL;
     int nq_pad, nk_pad;
     if (int rc = pk_attn_pads(nq, n_kv, nnull, &nq_pad, &nk_pad)) return rc;
+    auto mis = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) != 0; };
+    if ((ldq & 3) || mis(q) || mis(q_scale) || (kv && ((ldkv & 3) || mis(kv) || mis(k_scale) || (nnull > 0 && mis(null_kv))))) return PK_EALIGN;
     PrepArgs p{q, ldq, kv, ldkv, null_kv, q_scale, k_scale, Qp, Kp, Vt, S, h, nq, n_kv, nnull, nq_pad, nk_pad, scale};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long qrows = (long)S * h * nq_pad;
     const int tiles = (nk_pad + 63) / 64;
     if (dtype == 1) {
-        hipLaunchKernelGGL((prep_q_kernel<bf16>), dim3((unsigned)((qrows + 3) / 4)), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((prep_q_kernel<bf16>), dim3((unsigned)((qrows + 15) / 16)), dim3(256), 0, s, p);
         if (kv) hipLaunchKernelGGL((prep_kv_kernel<bf16>), dim3((unsigned)(S * h * tiles)), dim3(256), 0, s, p);
     } else if (dtype == 0) {
-        hipLaunchKernelGGL((prep_q_kernel<float>), dim3((unsigned)((qrows + 3) / 4)), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((prep_q_kernel<float>), dim3((unsigned)((qrows + 15) / 16)), dim3(256), 0, s, p);
         if (kv) hipLaunchKernelGGL((prep_kv_kernel<float>), dim3((unsigned)(S * h * tiles)), dim3(256), 0, s, p);
     } else return PK_EINVAL;
     PK_CHECK_LAUNCH();
@@ -274,7 +300,9 @@ extern "C" int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void
     if (ldo & 3) return PK_EALIGN;
     int nq_pad, nk_pad;
     if (int rc = pk_attn_pads(nq, n_kv, nnull, &nq_pad, &nk_pad)) return rc;
-    AttnArgs a{Qp, Kp, Vt, bias, bias_hstride, bias_ld, kmask, slopes, O, ldo, out_is_f32, S, h, nq, n_kv, nnull, nq_pad, nk_pad, causal};
+    AttnArgs a{Qp, Kp, Vt, bias, bias_hstride, bias_ld, kmask, slopes, O, ldo, out_is_f32, S, h, nq, n_kv, nnull, nq_pad, nk_pad, causal, 0};
+    a.bias_vec = (bias && nnull == 0 && (bias_ld & 3) == 0 && (bias_hstride & 3) == 0 &&
+                  (reinterpret_cast<uintptr_t>(bias) & 15) == 0) ? 1 : 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int QF = nq >= 128 ? 2 : 1;
     const long waves = (long)S * h * (nq_pad / (16 * QF));

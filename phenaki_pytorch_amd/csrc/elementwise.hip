@@ -42,6 +42,52 @@ __global__ __launch_bounds__(256) void peg_kernel(const float* __restrict__ x, c
     }
 }
 
+// same stencil, one thread per (b, t, h, 4 channels) producing the whole W-row: every input row segment is loaded once
+// and reused by its 3 taps, and the 27 weight vectors are loaded once per thread (3x fewer L2 reads than peg_kernel)
+template <int WW>
+__global__ __launch_bounds__(256) void peg_row_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                      const float* __restrict__ bias, float* __restrict__ out,
+                                                      int B, int T, int H, int D, int tfront, long total) {
+    const int dv = D >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % dv) * 4;
+    long p = idx / dv;
+    const int h = (int)(p % H); p /= H;
+    const int t = (int)(p % T); const int b = (int)(p / T);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c);
+    f32x4 acc[WW];
+#pragma unroll
+    for (int w = 0; w < WW; ++w) acc[w] = bv;
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt) {
+        const int ts = t + dt - tfront;
+        if (ts < 0 || ts >= T) continue;
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            const int hs = h + dh - 1;
+            if (hs < 0 || hs >= H) continue;
+            const float* row = x + (((size_t)b * T + ts) * H + hs) * WW * D + c;
+            f32x4 xr[WW];
+#pragma unroll
+            for (int w = 0; w < WW; ++w) xr[w] = *reinterpret_cast<const f32x4*>(row + (size_t)w * D);
+            const f32x4 k0 = *reinterpret_cast<const f32x4*>(wt + (size_t)((dt * 3 + dh) * 3 + 0) * D + c);
+            const f32x4 k1 = *reinterpret_cast<const f32x4*>(wt + (size_t)((dt * 3 + dh) * 3 + 1) * D + c);
+            const f32x4 k2 = *reinterpret_cast<const f32x4*>(wt + (size_t)((dt * 3 + dh) * 3 + 2) * D + c);
+#pragma unroll
+            for (int w = 0; w < WW; ++w) {
+                if (w > 0) acc[w] += xr[w - 1] * k0;
+                acc[w] += xr[w] * k1;
+                if (w + 1 < WW) acc[w] += xr[w + 1] * k2;
+                if (dt == tfront && dh == 1) acc[w] += xr[w];            // + residual (attention.py:323)
+            }
+        }
+    }
+    float* orow = out + (((size_t)b * T + t) * H + h) * WW * D + c;
+#pragma unroll
+    for (int w = 0; w < WW; ++w) *reinterpret_cast<f32x4*>(orow + (size_t)w * D) = acc[w];
+}
+
 // ---- LFQ (vector-quantize-pytorch LFQ restated in oracle/lfq.py; call sites cvivit.py:570, :439)
 // encode: proj = x @ Wp^T + bp (f32, one wave per token), ids = sum_k (proj_k > 0) << (cd-1-k)  (MSB first)
 template <int CD>
@@ -171,7 +217,12 @@ extern "C" int pk_peg(const float* x, const float* wt, const float* bias, float*
     if (D & 3) return PK_EALIGN;
     if (x == out) return PK_EINVAL;                      // stencil: not in-place
     const long total = (long)B * T * H * W * (D >> 2);
-    hipLaunchKernelGGL(peg_kernel, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), x, wt, bias, out, B, T, H, W, D, causal ? 2 : 1, total);
+    const long rows = (long)B * T * H * (D >> 2);
+    const dim3 rgrid((unsigned)((rows + 255) / 256));
+    if (W == 8) hipLaunchKernelGGL((peg_row_kernel<8>), rgrid, dim3(256), 0, STREAM(stream), x, wt, bias, out, B, T, H, D, causal ? 2 : 1, rows);
+    else if (W == 4) hipLaunchKernelGGL((peg_row_kernel<4>), rgrid, dim3(256), 0, STREAM(stream), x, wt, bias, out, B, T, H, D, causal ? 2 : 1, rows);
+    else if (W == 16) hipLaunchKernelGGL((peg_row_kernel<16>), rgrid, dim3(256), 0, STREAM(stream), x, wt, bias, out, B, T, H, D, causal ? 2 : 1, rows);
+    else hipLaunchKernelGGL(peg_kernel, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), x, wt, bias, out, B, T, H, W, D, causal ? 2 : 1, total);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

@@ -149,6 +149,32 @@ using namespace pk;
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// the DMA ring needs A in T, W zero-padded along K to the k-tile (the packers guarantee ldw >= round_up(K, BK)),
+// and both matrices below 4 GiB (32-bit buffer offsets)
+static bool dma_possible(int dtype, int a_is_f32, int N, int K, int lda, int ldw, int a_nrows) {
+    const int bk = dtype == 1 ? 64 : 32;
+    const int kpad = (K + bk - 1) / bk * bk;
+    const size_t el = dtype == 1 ? 2 : 4;
+    return !(dtype == 1 && a_is_f32) && ldw >= kpad &&
+           (size_t)a_nrows * lda * el < 0xFFFFFFF0ull && (size_t)N * ldw * el < 0xFFFFFFF0ull;
+}
+
+// measured on MI355X (tools/gemm_bench.py, profiles/gemm_variants_r01.txt): the loop is bound by the L2 -> LDS fill
+// rate, which grows with the number of co-resident workgroups -> shallow rings; 128x128 tiles (2x the flop/byte) only
+// pay once there are enough of them to fill 256 CUs twice, or when K is long
+static int auto_variant(int dtype, int a_is_f32, int M, int N, int K, int lda, int ldw, int a_nrows) {
+    const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    if (!dma_possible(dtype, a_is_f32, N, K, lda, ldw, a_nrows)) return blocks128 >= 384 ? 2 : 1;
+    if (blocks128 >= 512 || (blocks128 >= 256 && K >= 1024)) return 9;      // 128x128, 2 stages (2 WG/CU)
+    if (K >= 2048) return 3;                                                // 64x64, 4 stages (patch embed)
+    return 8;                                                               // 64x64, 2 stages (5 WG/CU)
+}
+
+// which main loop pk_gemm picks for a shape (1/2 register-staged 64x64 / 128x128; 3, 8 DMA 64x64 4 / 2 stages; 9 DMA 128x128)
+extern "C" int pk_gemm_auto_variant(int dtype, int a_is_f32, int M, int N, int K, int lda, int ldw, int a_nrows) {
+    return auto_variant(dtype, a_is_f32, M, N, K, lda, ldw, a_nrows);
+}
+
 // variant: 0 = automatic; 1/2 = register-staged 64x64 / 128x128; 3/4 = DMA ring 64x64 / 128x128 (4 stages);
 //          5 = DMA 64x64 8 stages; 6 = DMA 128x128 3 stages     (explicit variants exist for tools/gemm_bench.py)
 extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const void* W, int ldw,
@@ -174,24 +200,9 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
     e.vec_ok = v ? 1 : 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
-    // the DMA ring needs A in T, W zero-padded along K to the k-tile (the packers guarantee ldw >= round_up(K, BK)),
-    // and both matrices below 4 GiB (32-bit buffer offsets)
-    const int bk = dtype == 1 ? 64 : 32;
-    const int kpad = (K + bk - 1) / bk * bk;
-    const size_t el = dtype == 1 ? 2 : 4;
-    const bool dma_ok = !(dtype == 1 && a_is_f32) && ldw >= kpad &&
-                        (size_t)a_nrows * lda * el < 0xFFFFFFF0ull && (size_t)N * ldw * el < 0xFFFFFFF0ull;
-    const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    const bool dma_ok = dma_possible(dtype, a_is_f32, N, K, lda, ldw, a_nrows);
     if (variant >= 100) { p.plain_map = 1; variant -= 100; }
-    if (variant == 0) {
-        if (!dma_ok) variant = blocks128 >= 384 ? 2 : 1;
-        // measured on MI355X (tools/gemm_bench.py, profiles/gemm_variants_r01.txt): the loop is bound by the L2 -> LDS
-        // fill rate, which grows with the number of co-resident workgroups -> shallow rings; 128x128 tiles (2x the
-        // flop/byte) only pay once there are enough of them to fill 256 CUs twice, or when K is long
-        else if (blocks128 >= 512 || (blocks128 >= 256 && K >= 1024)) variant = 9;    // 128x128, 2 stages (2 WG/CU)
-        else if (K >= 2048) variant = 3;                                              // 64x64, 4 stages (patch embed)
-        else variant = 8;                                                             // 64x64, 2 stages (5 WG/CU)
-    }
+    if (variant == 0) variant = auto_variant(dtype, a_is_f32, M, N, K, lda, ldw, a_nrows);
     if (variant >= 3 && !dma_ok) return PK_EINVAL;
     if (dtype == 1) {
         switch (variant) {

@@ -142,24 +142,44 @@ __global__ __launch_bounds__(256) void vocab_sample_kernel(const GemmOperands p,
     }
 }
 
-// one thread per row: fold ntiles partials; optionally scatter through rows[] into the (B, n) state
+// fold the per-tile partials: a workgroup owns 32 consecutive rows (coalesced 128-byte reads of the [tile][row]
+// partial arrays), its 8 thread groups stride over the tiles and meet in LDS; then the (B, n) state is updated,
+// optionally scattered through rows[]
 __global__ __launch_bounds__(256) void vocab_reduce_kernel(const float* __restrict__ p_val, const int* __restrict__ p_idx,
                                                            const float* __restrict__ p_logit, const float* __restrict__ p_max,
                                                            const float* __restrict__ p_sum, int ntiles, int M,
                                                            const int* __restrict__ rows, const unsigned char* __restrict__ mask,
                                                            long long* __restrict__ ids, long long* __restrict__ pred,
                                                            float* __restrict__ scores, int need_lse) {
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    if (m >= M) return;
+    __shared__ float red[8][32][5];
+    const int rr = threadIdx.x & 31, tg = threadIdx.x >> 5;
+    const int m = blockIdx.x * 32 + rr;
     float best = -INFINITY, blog = 0.f, lmax = -INFINITY, lsum = 0.f;
     int bidx = 0x7fffffff;
-    for (int t = 0; t < ntiles; ++t) {
-        const size_t o = (size_t)t * M + m;
-        const float v = p_val[o];
-        const int ix = p_idx[o];
-        if (v > best || (v == best && ix < bidx)) { best = v; bidx = ix; blog = p_logit[o]; }
+    if (m < M) {
+        for (int t = tg; t < ntiles; t += 8) {
+            const size_t o = (size_t)t * M + m;
+            const float v = p_val[o];
+            const int ix = p_idx[o];
+            if (v > best || (v == best && ix < bidx)) { best = v; bidx = ix; blog = p_logit[o]; }
+            if (need_lse) {
+                const float om = p_max[o], os = p_sum[o];
+                const float nm = fmaxf(lmax, om);
+                lsum = (lmax == -INFINITY ? 0.f : lsum * __expf(lmax - nm)) + (om == -INFINITY ? 0.f : os * __expf(om - nm));
+                lmax = nm;
+            }
+        }
+    }
+    red[tg][rr][0] = best; red[tg][rr][1] = __builtin_bit_cast(float, bidx); red[tg][rr][2] = blog;
+    red[tg][rr][3] = lmax; red[tg][rr][4] = lsum;
+    __syncthreads();
+    if (tg != 0 || m >= M) return;
+    for (int q = 1; q < 8; ++q) {
+        const float v = red[q][rr][0];
+        const int ix = __builtin_bit_cast(int, red[q][rr][1]);
+        if (v > best || (v == best && ix < bidx)) { best = v; bidx = ix; blog = red[q][rr][2]; }
         if (need_lse) {
-            const float om = p_max[o], os = p_sum[o];
+            const float om = red[q][rr][3], os = red[q][rr][4];
             const float nm = fmaxf(lmax, om);
             lsum = (lmax == -INFINITY ? 0.f : lsum * __expf(lmax - nm)) + (om == -INFINITY ? 0.f : os * __expf(om - nm));
             lmax = nm;
@@ -256,7 +276,7 @@ extern "C" int pk_vocab_reduce(const void* partials, int M, int V, const int* ro
     const int ntiles = pk_vocab_ntiles(V);
     const size_t sz = (size_t)ntiles * M;
     const float* f = reinterpret_cast<const float*>(partials);
-    hipLaunchKernelGGL(vocab_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, STREAM(stream),
+    hipLaunchKernelGGL(vocab_reduce_kernel, dim3((M + 31) / 32), dim3(256), 0, STREAM(stream),
                        f, reinterpret_cast<const int*>(partials) + sz, f + 2 * sz, f + 3 * sz, f + 4 * sz, ntiles, M,
                        rows, mask, ids, pred, scores, need_lse);
     PK_CHECK_LAUNCH();
