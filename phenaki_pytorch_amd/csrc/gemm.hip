@@ -88,9 +88,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmOperands p, const G
     gemm_epilogue<T, TM, TN>(acc, p.M, p.N, e, m0, n0);
 }
 
-template <typename T, int TM, int TN, int WM, int WN, int STAGES>
+template <typename T, int TM, int TN, int WM, int WN, int STAGES, int ROWB>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(const GemmOperands p, const GemmEpilogue e, int a_nrows) {
-    using Tile = GemmDma<T, TM, TN, WM, WN, STAGES>;
+    using Tile = GemmDma<T, TM, TN, WM, WN, STAGES, ROWB>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware tile map.  Workgroup b is observed to run on XCD b % 8 (speed only, never correctness); each XCD has a
     // private 4 MiB L2.  XCD x owns a contiguous chunk of m-tiles and walks ALL n-tiles for it (m fastest), so its
@@ -127,18 +127,18 @@ static int launch_v1(const GemmOperands& p, const GemmEpilogue& e, hipStream_t s
     return PK_OK;
 }
 
-template <typename T, int TM, int TN, int STAGES, int WM = 2, int WN = 2>
+template <typename T, int TM, int TN, int STAGES, int WM = 2, int WN = 2, int ROWB = 128>
 static int launch_dma(const GemmOperands& p, const GemmEpilogue& e, int a_nrows, hipStream_t s) {
-    using Tile = GemmDma<T, TM, TN, WM, WN, STAGES>;
+    using Tile = GemmDma<T, TM, TN, WM, WN, STAGES, ROWB>;
     static bool attr_set = false;
     if (!attr_set && Tile::SMEM > 65536) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel<T, TM, TN, WM, WN, STAGES>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel<T, TM, TN, WM, WN, STAGES, ROWB>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, Tile::SMEM) != hipSuccess) return PK_ELAUNCH;
         attr_set = true;
     }
     const int MT = (p.M + Tile::BM - 1) / Tile::BM, NT = (p.N + Tile::BN - 1) / Tile::BN;
     dim3 grid(8 * ((MT + 7) / 8) * NT);                   // see the XCD-aware tile map in the kernel
-    hipLaunchKernelGGL((gemm_dma_kernel<T, TM, TN, WM, WN, STAGES>), grid, dim3(64 * WM * WN), Tile::SMEM, s, p, e, a_nrows);
+    hipLaunchKernelGGL((gemm_dma_kernel<T, TM, TN, WM, WN, STAGES, ROWB>), grid, dim3(64 * WM * WN), Tile::SMEM, s, p, e, a_nrows);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }
@@ -165,7 +165,7 @@ static bool dma_possible(int dtype, int a_is_f32, int N, int K, int lda, int ldw
 static int auto_variant(int dtype, int a_is_f32, int M, int N, int K, int lda, int ldw, int a_nrows) {
     const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (!dma_possible(dtype, a_is_f32, N, K, lda, ldw, a_nrows)) return blocks128 >= 384 ? 2 : 1;
-    if (blocks128 >= 512 || (blocks128 >= 256 && K >= 1024)) return 9;      // 128x128, 2 stages (2 WG/CU)
+    if (blocks128 >= 512 || (blocks128 >= 256 && K >= 1024)) return 24;     // 128x128, 8 waves, 2 stages (16 waves/CU)
     if (K >= 2048) return 3;                                                // 64x64, 4 stages (patch embed)
     return 8;                                                               // 64x64, 2 stages (5 WG/CU)
 }
@@ -223,6 +223,19 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
             case 15: return launch_dma<bf16, 4, 2, 4, 2, 4>(p, e, a_nrows, s);     // 128x128, 8 waves, 4 stages
             case 16: return launch_dma<bf16, 4, 4, 2, 2, 4>(p, e, a_nrows, s);     // 128x256, 8 waves (2x4), 2 stages (96 KB)
             case 17: return launch_dma<bf16, 4, 4, 3, 2, 4>(p, e, a_nrows, s);     // 128x256, 8 waves, 3 stages (144 KB)
+            case 18: return launch_dma<bf16, 4, 4, 2, 2, 2, 64>(p, e, a_nrows, s);  // 128x128, k-tile 32, 2 stages (32 KB: 5 WG/CU)
+            case 19: return launch_dma<bf16, 4, 4, 3, 2, 2, 64>(p, e, a_nrows, s);  // 128x128, k-tile 32, 3 stages (48 KB: 3 WG/CU)
+            case 20: return launch_dma<bf16, 4, 4, 4, 2, 2, 64>(p, e, a_nrows, s);  // 128x128, k-tile 32, 4 stages (64 KB: 2 WG/CU)
+            case 21: return launch_dma<bf16, 2, 2, 2, 2, 2, 64>(p, e, a_nrows, s);  // 64x64,   k-tile 32, 2 stages (16 KB)
+            case 22: return launch_dma<bf16, 4, 2, 2, 2, 2, 64>(p, e, a_nrows, s);  // 128x64,  k-tile 32, 2 stages (24 KB: 6 WG/CU)
+            case 23: return launch_dma<bf16, 4, 4, 2, 2, 4, 64>(p, e, a_nrows, s);  // 128x256, 8 waves, k-tile 32, 2 stages (48 KB)
+            case 24: return launch_dma<bf16, 4, 2, 2, 2, 4>(p, e, a_nrows, s);      // 128x128, 8 waves (2x4), 2 stages (64 KB: 16 waves/CU)
+            case 25: return launch_dma<bf16, 4, 2, 2, 2, 4, 64>(p, e, a_nrows, s);  // 128x128, 8 waves, k-tile 32, 2 stages (32 KB: 32 waves/CU)
+            case 26: return launch_dma<bf16, 2, 2, 2, 4, 4>(p, e, a_nrows, s);      // 128x128, 16 waves (4x4), 2 stages (64 KB: 32 waves/CU)
+            case 27: return launch_dma<bf16, 2, 4, 2, 4, 2>(p, e, a_nrows, s);      // 128x128, 8 waves (4x2), 2 stages (64 KB)
+            case 28: return launch_dma<bf16, 4, 4, 2, 4, 2>(p, e, a_nrows, s);      // 256x128, 8 waves (4x2), 2 stages (96 KB)
+            case 29: return launch_dma<bf16, 4, 4, 2, 4, 4, 64>(p, e, a_nrows, s);  // 256x256, 16 waves, k-tile 32, 2 stages (64 KB: 2 WG/CU)
+            case 30: return launch_dma<bf16, 4, 4, 3, 4, 4, 64>(p, e, a_nrows, s);  // 256x256, 16 waves, k-tile 32, 3 stages (96 KB)
             default: return PK_EINVAL;
         }
     }
@@ -236,6 +249,7 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
         case 7: return launch_dma<float, 2, 2, 3>(p, e, a_nrows, s);
         case 8: return launch_dma<float, 2, 2, 2>(p, e, a_nrows, s);
         case 9: return launch_dma<float, 4, 4, 2>(p, e, a_nrows, s);
+        case 24: return launch_dma<float, 4, 2, 2, 2, 4>(p, e, a_nrows, s);
         default: return PK_EINVAL;
     }
 }

@@ -4,8 +4,11 @@
 // Operand tiles go HBM/L2 -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction, no VGPR round
 // trip) into a ring of STAGES k-tiles; STAGES-1 tiles are in flight ahead of the MFMAs, retired with counted
 // s_waitcnt vmcnt(N) + ONE raw s_barrier per k-tile (never __syncthreads(): it would drain the ring).
-// An LDS-DMA writes wave-uniform base + lane*16, so the 16-B-slot XOR swizzle (slot ^ (row & 7)) that makes
-// ds_read_b128 conflict-free is applied on the per-lane SOURCE address; the read side XORs the same way.
+// An LDS-DMA writes wave-uniform base + lane*16, so the 16-B-slot XOR swizzle that makes ds_read_b128 conflict-free
+// is applied on the per-lane SOURCE address; the read side XORs the same way.
+//   ROWB = 128 (k-tile of 64 bf16 / 32 f32): slot ^ (row & 7)
+//   ROWB = 64  (k-tile of 32 bf16; half the LDS per stage -> 5 workgroups of a 128x128 tile per CU):
+//               slot ^ {0,2,3,1}[(row >> 2) & 3]   (conflict-free for the gfx950 ds_read_b128 16-lane groups)
 // Rows past M / N and bytes past the end of a matrix are fetched through the buffer descriptor's bounds check
 // (they read as 0); the K tail of A multiplies the zero padding of W.
 #pragma once
@@ -15,17 +18,26 @@ namespace pk {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// TM x TN MFMA tiles per wave, WM x WN waves per workgroup (64 * WM * WN threads)
-template <typename T, int TM, int TN, int WM, int WN, int STAGES>
+__device__ __forceinline__ int swz64(int rowq) { return (0x78 >> (2 * rowq)) & 3; }        // {0,2,3,1}[rowq], two bits each
+
+__device__ __forceinline__ void lds_frag64(Frag<bf16>& f, const char* tile, int row, int g) {
+    const int slot = g ^ swz64((row >> 2) & 3);
+    f.v = *reinterpret_cast<const u32x4*>(tile + row * 64 + (slot << 4));
+}
+
+// TM x TN MFMA tiles per wave, WM x WN waves per workgroup (64 * WM * WN threads), ROWB bytes of k per LDS row
+template <typename T, int TM, int TN, int WM, int WN, int STAGES, int ROWB = 128>
 struct GemmDma {
+    static_assert(ROWB == 128 || (ROWB == 64 && sizeof(T) == 2), "64-byte k-tiles are built for bf16 only");
     static constexpr int NW = WM * WN;
     static constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
-    static constexpr int IA = BM / (8 * NW), IW = BN / (8 * NW);   // DMA instructions per wave per k-tile (8 rows each)
-    static_assert(IA * 8 * NW == BM && IW * 8 * NW == BN, "tile rows must split evenly over the waves' 8-row DMA pieces");
-    static constexpr int EPS = 16 / (int)sizeof(T);
-    static constexpr int BK = 8 * EPS;
+    static constexpr int RPI = 1024 / ROWB;                             // rows per DMA wave-instruction
+    static constexpr int SLOTS = ROWB / 16;
+    static constexpr int IA = BM / (RPI * NW), IW = BN / (RPI * NW);    // DMA instructions per wave per k-tile
+    static_assert(IA * RPI * NW == BM && IW * RPI * NW == BN, "tile rows must split evenly over the waves' DMA pieces");
+    static constexpr int BK = ROWB / (int)sizeof(T);
     static constexpr int CH = BK / 32;
-    static constexpr int STAGE_BYTES = (BM + BN) * 128;
+    static constexpr int STAGE_BYTES = (BM + BN) * ROWB;
     static constexpr int SMEM = STAGES * STAGE_BYTES;
     static constexpr int IPW = IA + IW;
     static_assert((STAGES - 2) * IPW <= 63, "vmcnt is a 6-bit counter");
@@ -59,12 +71,14 @@ struct GemmDma {
         __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, bytesA, 0x00020000);
         __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, bytesW, 0x00020000);
 
-        // per-lane source offsets (bytes) at k = 0; the k-tile advance goes through the scalar offset
-        const int srcslot = (lane & 7) ^ (lane >> 3);
+        // per-lane source offsets (bytes) at k = 0; the k-tile advance goes through the scalar offset.
+        // lane -> (row within the instruction's RPI rows, 16-byte slot); the slot is swizzled on the SOURCE side
+        const int lrow = lane / SLOTS, lslot = lane % SLOTS;
+        const int srcslot = ROWB == 128 ? (lslot ^ (lrow & 7)) : (lslot ^ swz64((lrow >> 2) & 3));
         uint32_t offA[IA], offW[IW];
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
-            const int row = (wave * IA + i) * 8 + (lane >> 3);
+            const int row = (wave * IA + i) * RPI + lrow;
             int gm = m0 + row;
             const bool ok = gm < p.M;
             if (ok && p.a_rows) gm = p.a_rows[gm];
@@ -72,20 +86,20 @@ struct GemmDma {
         }
 #pragma unroll
         for (int i = 0; i < IW; ++i) {
-            const int row = (wave * IW + i) * 8 + (lane >> 3);
+            const int row = (wave * IW + i) * RPI + lrow;
             const int gn = n0 + row;
             offW[i] = gn < p.N ? (uint32_t)gn * (uint32_t)p.ldw * SZ + srcslot * 16 : bytesW;
         }
 
         auto issue = [&](int kt, int slot) {
             char* base = smem + slot * STAGE_BYTES;
-            const int koff = kt * 128;
+            const int koff = kt * ROWB;
 #pragma unroll
             for (int i = 0; i < IA; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(base + (wave * IA + i) * 1024), 16, offA[i], koff, 0, 0);
 #pragma unroll
             for (int i = 0; i < IW; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(base + BM * 128 + (wave * IW + i) * 1024), 16, offW[i], koff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(base + BM * ROWB + (wave * IW + i) * 1024), 16, offW[i], koff, 0, 0);
         };
 
         const int nt = (p.K + BK - 1) / BK;
@@ -97,14 +111,21 @@ struct GemmDma {
             __builtin_amdgcn_s_barrier();                 // tile kt landed for every wave; everyone is done with tile kt-1
             if (kt + STAGES - 1 < nt) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
             const char* a = smem + (kt % STAGES) * STAGE_BYTES;
-            const char* w = a + BM * 128;
+            const char* w = a + BM * ROWB;
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 Frag<T> fa[TM], fw[TN];
+                if constexpr (ROWB == 128) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) lds_frag(fa[i], a, wm * 16 * TM + i * 16 + lr, c, g);
+                    for (int i = 0; i < TM; ++i) lds_frag(fa[i], a, wm * 16 * TM + i * 16 + lr, c, g);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) lds_frag(fw[j], w, wn * 16 * TN + j * 16 + lr, c, g);
+                    for (int j = 0; j < TN; ++j) lds_frag(fw[j], w, wn * 16 * TN + j * 16 + lr, c, g);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) lds_frag64(fa[i], a, wm * 16 * TM + i * 16 + lr, g);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) lds_frag64(fw[j], w, wn * 16 * TN + j * 16 + lr, g);
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll

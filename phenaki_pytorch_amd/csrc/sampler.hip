@@ -50,35 +50,42 @@ struct VocabArgs {
     float* p_val; int* p_idx; float* p_logit; float* p_max; float* p_sum;
 };
 
+// vocab-head tile: 128 rows x 128 vocabulary columns, 8 waves as 2 (rows) x 4 (cols), wave tile 64 x 32, LDS-DMA ring of 2
+// (64 KB -> 2 workgroups = 16 waves per CU): the best main loop for N = 65 536 in tools/gemm_bench.py that exists for
+// both operand types
+constexpr int VTM = 4, VTN = 2, VWM = 2, VWN = 4;
+template <typename T> using VocabTile = GemmDma<T, VTM, VTN, VWM, VWN, 2>;
+
 template <typename T, bool PARITY>
-__global__ __launch_bounds__(256) void vocab_sample_kernel(const GemmOperands p, const VocabArgs e) {
-    using Tile = GemmDma<T, 4, 4, 2, 2, 2>;      // 128x128 tile, LDS-DMA ring of 2 (2 workgroups / CU): best for N = 65 536
+__global__ __launch_bounds__(64 * VWM * VWN) void vocab_sample_kernel(const GemmOperands p, const VocabArgs e) {
+    using Tile = VocabTile<T>;
+    static_assert(Tile::BM == 128 && Tile::BN == 128, "partials are laid out per 128-column tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m0 = blockIdx.x * Tile::BM, n0 = blockIdx.y * Tile::BN;
-    f32x4 acc[4][4];
+    f32x4 acc[VTM][VTN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < VTM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+        for (int j = 0; j < VTN; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
     Tile::run(p, p.M, m0, n0, smem, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1, g = lane >> 4, lr = lane & 15;
+    const int wm = wave / VWN, wn = wave % VWN, g = lane >> 4, lr = lane & 15;
     // LDS scratch (the GEMM stages are dead after run()'s final barrier): [wn][128 rows][5 words]
     float* red = reinterpret_cast<float*>(smem);
     const int V = p.N;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ml = wm * 64 + i * 16 + lr;
+    for (int i = 0; i < VTM; ++i) {
+        const int ml = wm * 16 * VTM + i * 16 + lr;
         const int m = m0 + ml;
         const bool mok = m < p.M;
         const long lrow = mok ? (e.rows ? e.rows[m] : m) : 0;
         float best = -INFINITY, blog = 0.f, lmax = -INFINITY;
         int bidx = 0x7fffffff;
-        float lg[16];
+        float lg[4 * VTN];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + g * 4;
+        for (int j = 0; j < VTN; ++j) {
+            const int n = n0 + wn * 16 * VTN + j * 16 + g * 4;
             f32x4 bv = f32x4{0, 0, 0, 0}, uv = f32x4{0.5f, 0.5f, 0.5f, 0.5f};
             if (n < V) bv = *reinterpret_cast<const f32x4*>(e.bias + n);         // V % 4 == 0 (host check)
             if (PARITY) { if (mok && n < V) uv = *reinterpret_cast<const f32x4*>(e.U + (size_t)lrow * V + n); }
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(256) void vocab_sample_kernel(const GemmOperands p,
         float lsum = 0.f;
         if (e.need_lse) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) lsum += __expf(lg[q] - lmax);              // exp(-inf) = 0 for padding
+            for (int q = 0; q < 4 * VTN; ++q) lsum += __expf(lg[q] - lmax);         // exp(-inf) = 0 for padding
         }
         // combine the 4 lane groups holding the same row
 #pragma unroll
@@ -128,14 +135,17 @@ __global__ __launch_bounds__(256) void vocab_sample_kernel(const GemmOperands p,
         const int ml = threadIdx.x, m = m0 + ml;
         if (m < p.M) {
             const float* a = red + (size_t)ml * 5;
-            const float* b = red + ((size_t)128 + ml) * 5;
             float best = a[0], blog = a[2], lmax = a[3], lsum = a[4];
             int bidx = __builtin_bit_cast(int, a[1]);
-            const int oi = __builtin_bit_cast(int, b[1]);
-            if (b[0] > best || (b[0] == best && oi < bidx)) { best = b[0]; bidx = oi; blog = b[2]; }
-            const float nm = fmaxf(lmax, b[3]);
-            if (e.need_lse) lsum = (lmax == -INFINITY ? 0.f : lsum * __expf(lmax - nm)) + (b[3] == -INFINITY ? 0.f : b[4] * __expf(b[3] - nm));
-            lmax = nm;
+#pragma unroll
+            for (int q = 1; q < VWN; ++q) {
+                const float* b = red + ((size_t)q * 128 + ml) * 5;
+                const int oi = __builtin_bit_cast(int, b[1]);
+                if (b[0] > best || (b[0] == best && oi < bidx)) { best = b[0]; bidx = oi; blog = b[2]; }
+                const float nm = fmaxf(lmax, b[3]);
+                if (e.need_lse) lsum = (lmax == -INFINITY ? 0.f : lsum * __expf(lmax - nm)) + (b[3] == -INFINITY ? 0.f : b[4] * __expf(b[3] - nm));
+                lmax = nm;
+            }
             const size_t o = (size_t)blockIdx.y * p.M + m;
             e.p_val[o] = best; e.p_idx[o] = bidx; e.p_logit[o] = blog; e.p_max[o] = lmax; e.p_sum[o] = lsum;
         }
@@ -255,14 +265,14 @@ extern "C" int pk_vocab_sample(int dtype, const void* A, int lda, const void* W,
     e.p_logit = reinterpret_cast<float*>(partials) + 2 * sz;
     e.p_max = reinterpret_cast<float*>(partials) + 3 * sz;
     e.p_sum = reinterpret_cast<float*>(partials) + 4 * sz;
-    dim3 grid((M + 127) / 128, ntiles), block(256);
+    dim3 grid((M + 127) / 128, ntiles), block(64 * VWM * VWN);
     hipStream_t s = STREAM(stream);
     if (dtype == 1) {
-        constexpr int SM = GemmDma<bf16, 4, 4, 2, 2, 2>::SMEM;
+        constexpr int SM = VocabTile<bf16>::SMEM;
         if (U) hipLaunchKernelGGL((vocab_sample_kernel<bf16, true>), grid, block, SM, s, p, e);
         else hipLaunchKernelGGL((vocab_sample_kernel<bf16, false>), grid, block, SM, s, p, e);
     } else {
-        constexpr int SM = GemmDma<float, 4, 4, 2, 2, 2>::SMEM;
+        constexpr int SM = VocabTile<float>::SMEM;
         if (U) hipLaunchKernelGGL((vocab_sample_kernel<float, true>), grid, block, SM, s, p, e);
         else hipLaunchKernelGGL((vocab_sample_kernel<float, false>), grid, block, SM, s, p, e);
     }

@@ -24,8 +24,8 @@ SHAPES = [  # (M, N, K, note)
     (9216, 512, 1368, 'maskgit FF2'),
     (4608, 65536, 512, 'vocab head as plain GEMM'),
 ]
-VARIANTS = {3: 'd64s4', 103: 'd64s4/plain', 7: 'd64s3', 107: 'd64s3/plain', 8: 'd64s2', 108: 'd64s2/plain', 9: 'd128s2', 109: 'd128s2/plain',
-            6: 'd128s3', 13: 'd128w8s3', 16: 'd128x256s2', 116: 'd128x256s2/plain', 17: 'd128x256s3', 117: 'd128x256s3/plain'}
+VARIANTS = {8: 'd64s2', 9: 'd128s2', 23: 'd128x256k32s2', 24: 'd128w8s2', 25: 'd128w8k32s2', 26: 'd128w16s2', 27: 'd128w8bs2',
+            28: 'd256x128w8s2', 29: 'd256w16k32s2', 30: 'd256w16k32s3'}
 
 
 def main():

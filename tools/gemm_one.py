@@ -1,0 +1,16 @@
+"""run a few launches of selected pk_gemm variants on one shape (target for rocprofv3 --pmc passes)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from phenaki_pytorch_amd import _lib as L
+M, N, K = [int(x) for x in sys.argv[1:4]]
+variants = [int(v) for v in sys.argv[4:]]
+L.load()
+Kp = (K + 63) // 64 * 64
+A = torch.randn(M, K, device='cuda').to(torch.bfloat16)
+W = torch.zeros(N, Kp, device='cuda', dtype=torch.bfloat16)
+W[:, :K] = (torch.randn(N, K, device='cuda') / K ** 0.5).to(torch.bfloat16)
+C = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+for v in variants:
+    for _ in range(5):
+        L.gemm(L.BF16, A, W, M, N, K, C=C, variant=v)
+torch.cuda.synchronize()
