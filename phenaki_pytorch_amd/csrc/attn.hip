@@ -14,6 +14,7 @@
 //                 key = (j >> 2)*16 + g*4 + (j & 3) that V^T's fragment loads use too).
 // dim_head is fixed at 64 (the reference default; every BASELINE config).
 // Roofline: MFMA for n = 576 (4*nq*nk*64 flops per head), L1/L2 operand-fetch bound at small QF.
+#include <cstdlib>
 #include "common.hpp"
 
 namespace pk {
@@ -160,33 +161,64 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     const unsigned char* km = p.kmask ? p.kmask + (size_t)s * p.n_kv : nullptr;
     const int coff = p.n_kv - p.nq;                         // causal diagonal offset (attention.py:172)
 
+    // software pipeline: the K fragments (and, on the vector-bias path, the bias vectors) of tile t+1 are requested
+    // before tile t's MFMAs and softmax, V^T of tile t at the top of the iteration -- the loop is operand-fetch bound
+    // (every wave streams K / V^T / bias through L1), so the loads must not sit behind the dependent MFMA chain
+    const bool vb_all = bias && p.bias_vec && !km && !p.causal;           // wave-uniform, loop-invariant
+    int qrow[QF];
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) { const int qi = q0 + qf * 16 + lr; qrow[qf] = qi < p.nq ? qi : p.nq - 1; }
+    auto load_k = [&](Frag<T> (&fk)[2][2], int kb) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) frag_load(fk[f][c], Kp + (size_t)(kb + f * 16 + lr) * DH + c * 32 + g * 8);
+    };
+    auto load_bias = [&](f32x4 (&bz)[QF][2], int kb) {
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf)
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+                bz[qf][f] = *reinterpret_cast<const f32x4*>(bias + (size_t)qrow[qf] * p.bias_ld + kb + f * 16 + g * 4);
+    };
+    Frag<T> fk[2][2];
+    f32x4 bz[QF][2];
+    load_k(fk, 0);
+    if (vb_all && 32 <= nk) load_bias(bz, 0);
+
     for (int kb = 0; kb < p.nk_pad; kb += 32) {
+        Frag<T> fv[4];
+#pragma unroll
+        for (int df = 0; df < 4; ++df) load_vt(fv[df], Vt + (size_t)(df * 16 + lr) * p.nk_pad, kb, g);
+        Frag<T> fkn[2][2];
+        f32x4 bzn[QF][2];
+        const bool has_next = kb + 32 < p.nk_pad;
+        if (has_next) {
+            load_k(fkn, kb + 32);
+            if (vb_all && kb + 64 <= nk) load_bias(bzn, kb + 32);
+        }
         f32x4 st[QF][2];
 #pragma unroll
         for (int qf = 0; qf < QF; ++qf) { st[qf][0] = f32x4{0, 0, 0, 0}; st[qf][1] = st[qf][0]; }
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                Frag<T> fk;
-                frag_load(fk, Kp + (size_t)(kb + f * 16 + lr) * DH + c * 32 + g * 8);
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int qf = 0; qf < QF; ++qf) st[qf][f] = mma(fk, fq[qf][c], st[qf][f]);
-            }
+                for (int qf = 0; qf < QF; ++qf) st[qf][f] = mma(fk[f][c], fq[qf][c], st[qf][f]);
         // whole-tile fast paths (wave-uniform): a full tile of real keys with no key mask / causal structure needs no
         // per-element work; the additive bias of such a tile is one 16-byte load per 4 keys (nnull == 0, aligned rows)
         const bool simple = (kb + 32 <= nk) && !km && !p.causal;
-        const bool vbias = bias && simple && p.bias_vec;
+        const bool vbias = vb_all && simple;
         const bool plain = simple && (!bias || vbias);
         float pr[QF][8];
 #pragma unroll
         for (int qf = 0; qf < QF; ++qf) {
             const int qi = q0 + qf * 16 + lr;
             float mx = -INFINITY;
-            if (vbias && qi < p.nq) {
+            if (vbias) {
 #pragma unroll
-                for (int f = 0; f < 2; ++f)
-                    st[qf][f] += *reinterpret_cast<const f32x4*>(bias + (size_t)qi * p.bias_ld + kb + f * 16 + g * 4);
+                for (int f = 0; f < 2; ++f) st[qf][f] += bz[qf][f];
             }
 #pragma unroll
             for (int f = 0; f < 2; ++f)
@@ -227,11 +259,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
         for (int qf = 0; qf < QF; ++qf) frag_from_f32(fp[qf], pr[qf]);
 #pragma unroll
-        for (int df = 0; df < 4; ++df) {
-            Frag<T> fv;
-            load_vt(fv, Vt + (size_t)(df * 16 + lr) * p.nk_pad, kb, g);
+        for (int df = 0; df < 4; ++df)
 #pragma unroll
-            for (int qf = 0; qf < QF; ++qf) o[qf][df] = mma(fv, fp[qf], o[qf][df]);
+            for (int qf = 0; qf < QF; ++qf) o[qf][df] = mma(fv[df], fp[qf], o[qf][df]);
+        if (has_next) {
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) fk[f][c] = fkn[f][c];
+#pragma unroll
+            for (int qf = 0; qf < QF; ++qf) { bz[qf][0] = bzn[qf][0]; bz[qf][1] = bzn[qf][1]; }
         }
     }
     float* Of = reinterpret_cast<float*>(p.O);
@@ -262,7 +299,7 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // sizes (in elements of T) the caller must allocate: Qp = S*h*nq_pad*64, Kp = S*h*nk_pad*64, Vt = same as Kp
 extern "C" int pk_attn_pads(int nq, int n_kv, int nnull, int* nq_pad, int* nk_pad) {
     if (nq <= 0 || n_kv <= 0 || nnull < 0 || !nq_pad || !nk_pad) return PK_EINVAL;
-    *nq_pad = round_up(nq, nq >= 128 ? 32 : 16);
+    *nq_pad = round_up(nq, nq >= 256 ? 64 : (nq >= 128 ? 32 : 16));
     *nk_pad = round_up(nnull + n_kv, 32);
     return PK_OK;
 }
@@ -304,11 +341,16 @@ extern "C" int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void
     a.bias_vec = (bias && nnull == 0 && (bias_ld & 3) == 0 && (bias_hstride & 3) == 0 &&
                   (reinterpret_cast<uintptr_t>(bias) & 15) == 0) ? 1 : 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int QF = nq >= 128 ? 2 : 1;
+    // query rows per wave: more rows amortise the K / V^T operand stream (the kernel is L1/L2 fetch bound); the
+    // exact-f32 path stops at 32 rows (register budget)
+    static const int qf_cap = [] { const char* e = getenv("PK_ATTN_MAX_QF"); return e ? atoi(e) : 2; }();   // tuning knob (4 measured slower: 146 vs 104 us)
+    int QF = (nq >= 256 && dtype == 1) ? 4 : (nq >= 128 ? 2 : 1);
+    if (QF > qf_cap && qf_cap >= 2) QF = 2;
     const long waves = (long)S * h * (nq_pad / (16 * QF));
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     if (dtype == 1) {
-        if (QF == 2) hipLaunchKernelGGL((attn_fwd_kernel<bf16, 2>), grid, block, 0, s, a);
+        if (QF == 4) hipLaunchKernelGGL((attn_fwd_kernel<bf16, 4>), grid, block, 0, s, a);
+        else if (QF == 2) hipLaunchKernelGGL((attn_fwd_kernel<bf16, 2>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((attn_fwd_kernel<bf16, 1>), grid, block, 0, s, a);
     } else if (dtype == 0) {
         if (QF == 2) hipLaunchKernelGGL((attn_fwd_kernel<float, 2>), grid, block, 0, s, a);
