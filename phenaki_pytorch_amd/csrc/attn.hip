@@ -291,6 +291,208 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     }
 }
 
+
+// LDS fragment reads of the staged tiles (see attn_fwd_lds_kernel): K tile [64 keys][128 B], 16-B slot ^ (row & 7);
+// V^T tile [64 dims][128 B = 64 keys], 16-B slot ^ ((row >> 1) & 7) which keeps the two 8-byte halves of a slot together
+__device__ __forceinline__ void lds_frag_k(Frag<bf16>& f, const char* tile, int row, int chunk, int g) {
+    const int slot = (chunk * 4 + g) ^ (row & 7);
+    f.v = *reinterpret_cast<const u32x4*>(tile + row * 128 + (slot << 4));
+}
+__device__ __forceinline__ void lds_frag_vt(Frag<bf16>& f, const char* tile, int row, int kc, int g) {
+    // elements j = 0..7 <-> key_local = kc*32 + (j >> 2)*16 + g*4 + (j & 3): two 8-byte reads at 8-byte slots kc*8 + g and kc*8 + 4 + g
+    const int x = (row >> 1) & 7;
+    const int s0 = kc * 8 + g, s1 = s0 + 4;
+    const int a0 = (((s0 >> 1) ^ x) << 4) | ((s0 & 1) << 3);
+    const int a1 = (((s1 >> 1) ^ x) << 4) | ((s1 & 1) << 3);
+    const u32x2 a = *reinterpret_cast<const u32x2*>(tile + row * 128 + a0);
+    const u32x2 b = *reinterpret_cast<const u32x2*>(tile + row * 128 + a1);
+    f.v = u32x4{a[0], a[1], b[0], b[1]};
+}
+
+// ---- LDS-staged variant (bf16): one workgroup = 4 waves = 64*QF query rows of ONE (sequence, head).  K and V^T tiles of
+// 64 keys are fetched once per workgroup in full 128-byte lines by LDS-DMA (buffer_load ... lds) into a 2-stage ring
+// and read back as MFMA fragments with ds_read_b128 / ds_read_b64 (XOR-swizzled on the DMA source side, conflict-free),
+// instead of every wave pulling fragment-shaped pieces (16 rows x 64 B per instruction) through the texture path.
+typedef __attribute__((address_space(3))) void* attn_lds_ptr;
+
+template <int QF>
+__global__ __launch_bounds__(256) void attn_fwd_lds_kernel(const AttnArgs p, uint32_t kv_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // 2 stages x (K 8 KB | V^T 8 KB)
+    constexpr int STAGE = 16384;
+    const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qblocks = (p.nq_pad + 64 * QF - 1) / (64 * QF);
+    const int qb = blockIdx.x % qblocks;
+    const int sh = blockIdx.x / qblocks;
+    const int hh = sh % p.h, s = sh / p.h;
+    const int q0 = (qb * 4 + wave) * 16 * QF;
+    const bool active = q0 < p.nq_pad;                                    // wave-uniform; idle waves still feed the ring
+    const int nk = p.nnull + p.n_kv;
+
+    __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Kp), 0, kv_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Vt), 0, kv_bytes, 0x00020000);
+    // DMA pieces: 8 rows x 128 B each.  K tile: rows = keys (row stride 128 B); V^T tile: rows = head dims (row stride
+    // nk_pad * 2 B).  Each wave issues 2 K pieces + 2 V^T pieces per tile.
+    const int prow = lane >> 3, pslot = lane & 7;
+    uint32_t offK[2], offV[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + prow;                        // 0..63
+        offK[i] = ((uint32_t)sh * p.nk_pad + row) * 128u + (uint32_t)((pslot ^ (row & 7)) * 16);
+        offV[i] = ((uint32_t)sh * 64u + row) * (uint32_t)p.nk_pad * 2u + (uint32_t)((pslot ^ ((row >> 1) & 7)) * 16);
+    }
+    auto issue = [&](int kb, int stage) {
+        char* base = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (attn_lds_ptr)(base + (wave * 2 + i) * 1024), 16, offK[i], kb * 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (attn_lds_ptr)(base + 8192 + (wave * 2 + i) * 1024), 16, offV[i], kb * 2, 0, 0);
+        }
+    };
+
+    const bf16* Qp = reinterpret_cast<const bf16*>(p.Qp) + ((size_t)sh * p.nq_pad + (active ? q0 : 0)) * DH;
+    Frag<bf16> fq[QF][2];
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) frag_load(fq[qf][c], Qp + (size_t)(qf * 16 + lr) * DH + c * 32 + g * 8);
+
+    float m[QF], l[QF];
+    f32x4 o[QF][4];
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) {
+        m[qf] = -INFINITY; l[qf] = 0.f;
+#pragma unroll
+        for (int df = 0; df < 4; ++df) o[qf][df] = f32x4{0, 0, 0, 0};
+    }
+    const float slope = (p.causal && p.slopes) ? p.slopes[hh] : 0.f;
+    const float* bias = p.bias ? p.bias + (size_t)hh * p.bias_hstride : nullptr;
+    const unsigned char* km = p.kmask ? p.kmask + (size_t)s * p.n_kv : nullptr;
+    const int coff = p.n_kv - p.nq;
+    const bool vb_all = bias && p.bias_vec && !km && !p.causal;
+    int qrow[QF];
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) { const int qi = q0 + qf * 16 + lr; qrow[qf] = qi < p.nq ? qi : p.nq - 1; }
+
+    const int ntiles = (p.nk_pad + 63) / 64;
+    issue(0, 0);
+    for (int t = 0; t < ntiles; ++t) {
+        const int kb = t * 64;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                     // tile t landed for all waves; everyone finished tile t-1
+        if (t + 1 < ntiles) issue(kb + 64, (t + 1) & 1);
+        if (!active) continue;
+        const char* kt = smem + (t & 1) * STAGE;
+        const char* vt = kt + 8192;
+        // bias vectors for this tile straight from global (16 B per lane per 4 keys), requested before the MFMAs
+        const bool simple = (kb + 64 <= nk) && !km && !p.causal;
+        const bool vbias = vb_all && simple;
+        const bool plain = simple && (!bias || vbias);
+        f32x4 bz[QF][4];
+        if (vbias) {
+#pragma unroll
+            for (int qf = 0; qf < QF; ++qf)
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+                    bz[qf][f] = *reinterpret_cast<const f32x4*>(bias + (size_t)qrow[qf] * p.bias_ld + kb + f * 16 + g * 4);
+        }
+        f32x4 st[QF][4];
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) st[qf][f] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                Frag<bf16> fk;
+                lds_frag_k(fk, kt, f * 16 + lr, c, g);
+#pragma unroll
+                for (int qf = 0; qf < QF; ++qf) st[qf][f] = mma(fk, fq[qf][c], st[qf][f]);
+            }
+        float pr[QF][16];
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+            const int qi = q0 + qf * 16 + lr;
+            float mx = -INFINITY;
+            if (vbias) {
+#pragma unroll
+                for (int f = 0; f < 4; ++f) st[qf][f] += bz[qf][f];
+            }
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float sv = st[qf][f][r];
+                    if (!plain) {
+                        const int key = kb + f * 16 + g * 4 + r;
+                        const int j = key - p.nnull;
+                        if (key >= nk) sv = -INFINITY;
+                        else {
+                            if (bias && j >= 0 && qi < p.nq) sv += bias[(size_t)qi * p.bias_ld + j];
+                            bool masked = km && j >= 0 && !km[j];
+                            if (p.causal && j >= 0) {
+                                const int dj = j - (qi + coff);
+                                sv -= fabsf((float)dj) * slope;
+                                masked = masked || dj > 0;
+                            }
+                            if (masked) sv = NEG_MAX;
+                        }
+                    }
+                    pr[qf][f * 4 + r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m[qf], mx);               // finite: every 64-key tile holds >= 1 real key
+            const float alpha = __expf(m[qf] - mn);
+            float ls = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { pr[qf][e] = __expf(pr[qf][e] - mn); ls += pr[qf][e]; }
+            l[qf] = l[qf] * alpha + ls;
+            m[qf] = mn;
+#pragma unroll
+            for (int df = 0; df < 4; ++df) o[qf][df] *= alpha;
+        }
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            Frag<bf16> fp[QF];
+#pragma unroll
+            for (int qf = 0; qf < QF; ++qf) {
+                const float (&src)[16] = pr[qf];
+                fp[qf].v = u32x4{pack_bf2(src[kc * 8 + 0], src[kc * 8 + 1]), pack_bf2(src[kc * 8 + 2], src[kc * 8 + 3]),
+                                 pack_bf2(src[kc * 8 + 4], src[kc * 8 + 5]), pack_bf2(src[kc * 8 + 6], src[kc * 8 + 7])};
+            }
+#pragma unroll
+            for (int df = 0; df < 4; ++df) {
+                Frag<bf16> fv;
+                lds_frag_vt(fv, vt, df * 16 + lr, kc, g);
+#pragma unroll
+                for (int qf = 0; qf < QF; ++qf) o[qf][df] = mma(fv, fp[qf], o[qf][df]);
+            }
+        }
+    }
+    if (!active) return;
+    float* Of = reinterpret_cast<float*>(p.O);
+    bf16* Ot = reinterpret_cast<bf16*>(p.O);
+#pragma unroll
+    for (int qf = 0; qf < QF; ++qf) {
+        float lt = l[qf];
+        lt += __shfl_xor(lt, 16, 64);
+        lt += __shfl_xor(lt, 32, 64);
+        const float inv = 1.0f / lt;
+        const int qi = q0 + qf * 16 + lr;
+        if (qi < p.nq) {
+#pragma unroll
+            for (int df = 0; df < 4; ++df) {
+                const size_t off = ((size_t)s * p.nq + qi) * p.ldo + hh * DH + df * 16 + g * 4;
+                const f32x4 v = o[qf][df] * inv;
+                if (p.out_f32) store4(Of + off, v); else store4(Ot + off, v);
+            }
+        }
+    }
+}
+
 }  // namespace pk
 using namespace pk;
 
@@ -348,6 +550,18 @@ extern "C" int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void
     if (QF > qf_cap && qf_cap >= 2) QF = 2;
     const long waves = (long)S * h * (nq_pad / (16 * QF));
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    static const int use_lds = [] { const char* e = getenv("PK_ATTN_LDS"); return e ? atoi(e) : 1; }();   // tuning knob
+    if (dtype == 1 && use_lds && nnull + n_kv >= 64 && nq >= 64 &&
+        (size_t)S * h * nk_pad * 128 < 0xFFFFFFF0ull) {
+        const int qf = nq >= 128 ? 2 : 1;
+        const int qblocks = (nq_pad + 64 * qf - 1) / (64 * qf);
+        const uint32_t kv_bytes = (uint32_t)((size_t)S * h * nk_pad * 128);
+        dim3 g2((unsigned)(S * h * qblocks));
+        if (qf == 2) hipLaunchKernelGGL((attn_fwd_lds_kernel<2>), g2, block, 32768, s, a, kv_bytes);
+        else hipLaunchKernelGGL((attn_fwd_lds_kernel<1>), g2, block, 32768, s, a, kv_bytes);
+        PK_CHECK_LAUNCH();
+        return PK_OK;
+    }
     if (dtype == 1) {
         if (QF == 4) hipLaunchKernelGGL((attn_fwd_kernel<bf16, 4>), grid, block, 0, s, a);
         else if (QF == 2) hipLaunchKernelGGL((attn_fwd_kernel<bf16, 2>), grid, block, 0, s, a);
