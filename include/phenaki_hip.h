@@ -79,6 +79,10 @@ int pk_lfq_encode(const float* x, int ldx, const float* wp, const float* bp, lon
                   int M, int D, int cd, void* stream);
 int pk_lfq_decode(const long long* ids, const float* wo, const float* bo, float* out, int M, int D, int cd, void* stream);
 
+/* rows of x scaled to unit l2 norm (F.normalize, eps 1e-12), out in T (out_kind 1) or f32: the query side of the cosine-sim
+ * VectorQuantize lookup (cvivit.py:321). */
+int pk_l2norm_rows(const float* x, int ldx, void* out, int ldo, int out_kind, int M, int D, void* stream);
+
 /* phenaki_pytorch.py:194-197, 290-291: out[r] = token_emb[ids[r]] + pos_emb[r % n]. */
 int pk_embed(const long long* ids, const float* tok, const float* pos, float* out, int rows, int n, int D, void* stream);
 
@@ -109,6 +113,8 @@ int pk_cfg_mix(const float* x, int ldx, int nb, int n_tot, int n_prime, const in
 /* phenaki_pytorch.py:213 + 88-93 + 506-509 + 547-550, never materialising logits: per row
  * pred = argmax(logits / max(T,1e-10) + gumbel(U)), optional (max, sum exp) for 1 - softmax[pred].
  * U != NULL: PARITY mode, uniform noise read from U[row][V]; U == NULL: counter-hash noise from `seed`.
+ * need_lse is a flag word: bit 0 = keep the softmax statistics, bit 1 = no noise at all (plain argmax of A @ W^T + bias:
+ * the cosine-sim codebook lookup of the VectorQuantize path, cvivit.py:321,568-570).
  * partials: 5 * pk_vocab_ntiles(V) * M 4-byte words of workspace consumed by pk_vocab_reduce, which writes
  * pred[r], ids[r] = where(mask[r], pred, ids[r]) and scores[r] = where(mask[r], 1 - p, -1e4). */
 int pk_vocab_ntiles(int V);

@@ -25,6 +25,7 @@ SIGNATURES = {
     'pk_gemm_ex': [_I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P],
     'pk_gemm_auto_variant': [_I, _I, _I, _I, _I, _I, _I, _I],
     'pk_layernorm': [_P, _I, _P, _P, _F, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'pk_l2norm_rows': [_P, _I, _P, _I, _I, _I, _I, _P],
     'pk_patchify_ln': [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _I, _I, _P],
     'pk_unpatchify': [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'pk_peg': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -190,9 +191,15 @@ def vocab_ntiles(V):
     return load().pk_vocab_ntiles(V)
 
 
-def vocab_sample(dtype, A, W, bias, M, V, D, temperature, U, rows, seed, need_lse, partials):
+def l2norm_rows(x, out, M, D):
+    rc = load().pk_l2norm_rows(ptr(x), x.stride(-2), ptr(out), out.stride(-2), 1 if out.dtype == torch.bfloat16 else 0, M, D, stream())
+    _check(rc, 'pk_l2norm_rows')
+
+
+def vocab_sample(dtype, A, W, bias, M, V, D, temperature, U, rows, seed, need_lse, partials, no_noise=False):
     rc = load().pk_vocab_sample(dtype, ptr(A), A.stride(-2), ptr(W), W.stride(0), ptr(bias), M, V, D, temperature,
-                                ptr(U), ptr(rows), seed & 0xFFFFFFFFFFFFFFFF, 1 if need_lse else 0, ptr(partials), stream())
+                                ptr(U), ptr(rows), seed & 0xFFFFFFFFFFFFFFFF, (1 if need_lse else 0) | (2 if no_noise else 0),
+                                ptr(partials), stream())
     _check(rc, 'pk_vocab_sample')
 
 

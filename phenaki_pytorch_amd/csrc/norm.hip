@@ -66,8 +66,39 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const LnArgs p) {
     }
 }
 
+// one wave per row: out = x / max(||x||_2, 1e-12)
+template <typename TO>
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, int ldx, TO* __restrict__ out, int ldo, int M, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * ldx;
+    float ss = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        store4(out + (size_t)row * ldo + c, v * inv);
+    }
+}
+
 }  // namespace pk
 using namespace pk;
+
+extern "C" int pk_l2norm_rows(const float* x, int ldx, void* out, int ldo, int out_kind, int M, int D, void* stream) {
+    if (!x || !out || M <= 0 || D <= 0) return PK_EINVAL;
+    if ((D & 3) || (ldx & 3) || (ldo & 3)) return PK_EALIGN;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((M + 3) / 4), block(256);
+    if (out_kind == 0) hipLaunchKernelGGL((l2norm_rows_kernel<float>), grid, block, 0, s, x, ldx, (float*)out, ldo, M, D);
+    else hipLaunchKernelGGL((l2norm_rows_kernel<bf16>), grid, block, 0, s, x, ldx, (bf16*)out, ldo, M, D);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
 
 // out / raw (f32 if out_kind == 0 else bf16) and/or out2 (always f32); out, out2 receive LN(x) * gamma + beta, raw
 // receives x itself.  Output rows may be remapped: grp > 0: r -> (r / grp) * gstride + goff + r % grp (cvivit.py:549

@@ -45,6 +45,7 @@ struct VocabArgs {
     float temp;              // max(temperature, 1e-10)
     uint32_t seed_lo, seed_hi;
     int need_lse;
+    int no_noise;            // 1: plain argmax of the logits (cosine-sim codebook lookup of the VectorQuantize path)
     int ntiles;
     // partials, SoA [ntiles][M]
     float* p_val; int* p_idx; float* p_logit; float* p_max; float* p_sum;
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(64 * VWM * VWN) void vocab_sample_kernel(const Gemm
                     const float gum = -__logf(-__logf(u + 1e-10f) + 1e-10f);
                     noisy = logit * (1.0f / e.temp) + gum;
                 }
+                if (e.no_noise) noisy = logit;
                 const bool ok = nn < V;
                 lg[j * 4 + r] = ok ? logit : -INFINITY;
                 if (ok && (noisy > best)) { best = noisy; bidx = nn; blog = logit; }   // ascending nn: first max wins
@@ -258,7 +260,7 @@ extern "C" int pk_vocab_sample(int dtype, const void* A, int lda, const void* W,
     e.bias = bias; e.U = U; e.rows = rows;
     e.temp = temperature > 1e-10f ? temperature : 1e-10f;
     e.seed_lo = (uint32_t)seed; e.seed_hi = (uint32_t)(seed >> 32);
-    e.need_lse = need_lse; e.ntiles = ntiles;
+    e.need_lse = need_lse & 1; e.no_noise = (need_lse >> 1) & 1; e.ntiles = ntiles;
     const size_t sz = (size_t)ntiles * M;
     e.p_val = reinterpret_cast<float*>(partials);
     e.p_idx = reinterpret_cast<int*>(partials) + sz;

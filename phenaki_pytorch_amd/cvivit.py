@@ -14,7 +14,7 @@ from torch import nn
 from . import _lib as L
 from .attention import (ContinuousPositionBias, Transformer, compute_dtype_of, exists, linear_weight,
                         set_compute_dtype)
-from .quantize import LFQ
+from .quantize import LFQ, VectorQuantize
 
 
 def pair(val):
@@ -67,8 +67,7 @@ class CViViT(nn.Module):
         if lookup_free_quantization:
             self.vq = LFQ(dim=dim, codebook_size=codebook_size, **lookup_free_quantization_kwargs)
         else:
-            raise NotImplementedError('lookup_free_quantization = False (cosine-sim VectorQuantize) is not built yet; '
-                                      'the reference default and every BASELINE config use LFQ')
+            self.vq = VectorQuantize(dim=dim, codebook_size=codebook_size, use_cosine_sim=True)
 
         self.dec_spatial_transformer = Transformer(depth=spatial_depth, **spatial_kwargs)
         self.dec_temporal_transformer = Transformer(depth=temporal_depth, **temporal_kwargs)
@@ -272,6 +271,7 @@ class CViViT(nn.Module):
         tokens = self._encode2d(tokens, B, T)
         h, w = self.patch_height_width
         if return_proj:
+            assert self.lookup_free_quantization, 'the pre-sign projection exists for LFQ only'
             ids, proj = self.vq.encode_ids(tokens, return_proj=True)
             return ids.view(B, T, h, w), proj.view(B, T * h * w, -1)
         return self.vq.encode_ids(tokens).view(B, T, h, w)

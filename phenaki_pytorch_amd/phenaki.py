@@ -381,6 +381,9 @@ class Phenaki(nn.Module):
         partials = torch.empty((5 * L.vocab_ntiles(V) * B * n,), device=device, dtype=torch.float32)
         mixed = torch.empty((B * n, D), device=device, dtype=L.tdtype(dt))
         seed_base = int(torch.randint(0, 2 ** 62, (1,)).item()) if _noise_fn is None else 0
+        if _noise_fn is None and torch.distributed.is_available() and torch.distributed.is_initialized():
+            # batch-sharded sampling: every rank draws from its own noise stream even under a common torch seed
+            seed_base = (seed_base + 0xD1B54A32D192ED03 * (torch.distributed.get_rank() + 1)) & 0x3FFFFFFFFFFFFFFF
         need_lse = not exists(critic)
 
         for step in range(self.steps):

@@ -58,3 +58,60 @@ class LFQ(nn.Module):
         ids = self.encode_ids(x2)
         q = self.codes_2d(ids)
         return q.reshape(b, n, d), ids.reshape(b, n), torch.zeros((), device=x.device)
+
+
+class _CosineSimCodebook(nn.Module):
+    """holder mirroring the library's `_codebook` sub-module: `embed` is (1, codebook_size, dim), unit-norm rows."""
+
+    def __init__(self, dim, codebook_size):
+        super().__init__()
+        embed = torch.nn.functional.normalize(torch.randn(1, codebook_size, dim), dim=-1)
+        self.register_buffer('initted', torch.tensor([True]))
+        self.register_buffer('cluster_size', torch.zeros(1, codebook_size))
+        self.register_buffer('embed_avg', embed.clone())
+        self.register_buffer('embed', embed)
+
+
+class VectorQuantize(nn.Module):
+    """`vector_quantize_pytorch.VectorQuantize(dim, codebook_size, use_cosine_sim=True)` at inference
+    (reference call sites cvivit.py:321 construct, :568-570 forward with `mask=`, :441 `.codebook[indices]`; the
+    package is not vendored -- published eval behaviour: l2-normalise the input, argmax of its dot product with the
+    unit-norm codebook, gather; restated in oracle/lfq.py).  The lookup is the vocab-head kernel in its no-noise mode
+    (one fused GEMM + argmax, the (M, 65536) similarity matrix is never written) and always runs in exact f32: ids are
+    an argmax over 65 536 cosine similarities."""
+
+    def __init__(self, *, dim, codebook_size, use_cosine_sim=True, **_unused):
+        super().__init__()
+        assert use_cosine_sim, 'only the cosine-sim codebook (the reference construction, cvivit.py:321) is built'
+        assert dim % 32 == 0 and codebook_size % 4 == 0
+        self.dim, self.codebook_size = dim, codebook_size
+        self._codebook = _CosineSimCodebook(dim, codebook_size)
+
+    @property
+    def codebook(self):
+        return self._codebook.embed[0]
+
+    def encode_ids(self, x2d, return_proj=False):
+        assert not return_proj, 'the margin audit projection exists for LFQ only'
+        L.require_device(x2d, 'tokens')
+        M, D = x2d.shape
+        V = self.codebook_size
+        xn = torch.empty_like(x2d)
+        L.l2norm_rows(x2d, xn, M, D)
+        cb = self.codebook.contiguous()
+        zero_bias = torch.zeros((V,), device=x2d.device, dtype=torch.float32)
+        partials = torch.empty((5 * L.vocab_ntiles(V) * M,), device=x2d.device, dtype=torch.float32)
+        L.vocab_sample(L.F32, xn, cb, zero_bias, M, V, D, 1.0, None, None, 0, False, partials, no_noise=True)
+        ids = torch.empty((M,), device=x2d.device, dtype=torch.int64)
+        L.vocab_reduce(partials, M, V, None, None, None, ids, None, False)
+        return ids
+
+    def codes_2d(self, ids_flat):
+        return self.codebook.index_select(0, ids_flat.reshape(-1).long())
+
+    def forward(self, x, mask=None, **_unused):
+        b, n, d = x.shape
+        x2 = x.reshape(b * n, d).float().contiguous()
+        ids = self.encode_ids(x2)
+        q = self.codes_2d(ids)
+        return q.reshape(b, n, d), ids.reshape(b, n), torch.zeros((), device=x.device)

@@ -79,6 +79,32 @@ def test_cvivit_asserts_match_reference():
         cv(torch.randn(1, 3, 5, 64, 64), return_only_codebook_ids=True)
 
 
+def test_vector_quantize_flag_path_matches_cosine_lookup():
+    """lookup_free_quantization=False (cvivit.py:321,441,568-570): cosine-sim codebook argmax + gather."""
+    import phenaki_pytorch_amd as P
+    import torch.nn.functional as F
+    cfg = {**TINY['cvivit'], 'codebook_size': 4096}
+    torch.manual_seed(3)
+    cv = P.CViViT(use_vgg_and_gan=False, lookup_free_quantization=False, **cfg)
+    assert tuple(cv.vq.codebook.shape) == (4096, 128)
+    cv = cv.cuda().eval()
+    x = torch.randn(2, 80, 128, generator=torch.Generator().manual_seed(4))
+    q, ids, aux = cv.vq(x.cuda())
+    cb = cv.vq.codebook.cpu()
+    sim = F.normalize(x, dim=-1) @ F.normalize(cb, dim=-1).t()
+    top2 = sim.topk(2, dim=-1).values
+    safe = (top2[..., 0] - top2[..., 1]) > 1e-5
+    assert safe.float().mean() > 0.99
+    assert torch.equal(ids.cpu()[safe], sim.argmax(-1)[safe])
+    assert torch.equal(q.cpu(), cb[ids.cpu()])
+    video = weights.synthetic_video(1, 5, 64, 64, seed=0).cuda()
+    tok = cv(video, return_only_codebook_ids=True)
+    assert tok.shape == (1, 3, 4, 4) and tok.dtype == torch.int64 and (tok >= 0).all() and (tok < 4096).all()
+    rec = cv.decode_from_codebook_indices(tok.flatten(1))
+    assert rec.shape == (1, 3, 5, 64, 64) and torch.isfinite(rec).all()
+    close(cv(video, return_recons_only=True), rec, 1e-5, 'vq reconstruction path')
+
+
 # ------------------------------------------------------------------------------------------ MaskGit / critic
 
 def test_maskgit_and_critic_tiny_match_reference_golden(golden_dir):
@@ -175,6 +201,30 @@ def test_sample_fast_mode_is_seeded_and_shapes_match_readme():
     from phenaki_pytorch_amd import make_video
     whole, scenes = make_video(ph, texts=['a', 'b', 'c'], num_frames=(5, 4, 4), prime_lengths=3)
     assert whole.shape == (1, 3, 13, 64, 64) and len(scenes) == 3
+
+
+def test_self_token_critic_and_unconditional_paths_run():
+    """Phenaki(self_token_critic=True) (phenaki_pytorch.py:306-336, 374-375) and an unconditional MaskGit sample."""
+    import phenaki_pytorch_amd as P
+    cv, mg, _, _ = load_product('tiny', TINY)
+    ph = P.Phenaki(maskgit=mg, cvivit=cv, self_token_critic=True, steps=4, text_embed_dim=96).cuda().eval()
+    assert isinstance(ph.critic, P.SelfCritic)
+    ctx = weights.synthetic_context(2, 6, 96, seed=2).cuda()
+    ph.encode_texts = lambda texts, output_device=None: ctx[:len(texts)]
+    v = ph.sample(texts=['a', 'b'], num_frames=5, cond_scale=3.)
+    assert v.shape == (2, 3, 5, 64, 64) and torch.isfinite(v).all()
+    ids = torch.randint(0, 256, (2, 48)).cuda()
+    s = ph.critic.forward_with_cond_scale(ids, video_patch_shape=(3, 4, 4), context=ctx, cond_scale=3.)
+    e = mg(ids, video_patch_shape=(3, 4, 4), context=ctx, return_embeds=True)
+    en = mg(ids, video_patch_shape=(3, 4, 4), context=ctx, cond_drop_prob=1., return_embeds=True)
+    w, b = ph.critic.to_pred[0].weight.reshape(-1), ph.critic.to_pred[0].bias
+    sc, sn = e @ w + b, en @ w + b
+    close(s, sn + (sc - sn) * 3., 1e-4, 'self-critic CFG scores')
+    mgu = P.MaskGit(**{**TINY['maskgit'], 'unconditional': True})
+    weights.fill_module(mgu, salt=2)
+    phu = P.Phenaki(maskgit=mgu.cuda().eval(), cvivit=cv, steps=3, text_embed_dim=96).cuda().eval()
+    vu = phu.sample(num_frames=5, batch_size=2)
+    assert vu.shape == (2, 3, 5, 64, 64) and torch.isfinite(vu).all()
 
 
 def test_sample_full_config_two_steps_matches_oracle():
