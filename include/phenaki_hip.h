@@ -104,6 +104,13 @@ int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void* Vt, const
                 int bias_ld, const unsigned char* kmask, const float* slopes, int causal, void* O, int ldo,
                 int out_is_f32, int S, int h, int nq, int n_kv, int nnull, void* stream);
 
+/* attention.py:128-182 for short self-attention sequences (n <= 64, no null keys: the C-ViViT spatial / temporal layers)
+ * straight from the projection outputs q [S*n][ldq], kv [S*n][ldkv]: one launch instead of pk_attn_prep + pk_attn_fwd;
+ * f32 arithmetic in both precision modes; O f32 (out_kind 0) or bf16 (1). */
+int pk_attn_small(const float* q, int ldq, const float* kv, int ldkv, const float* q_scale, const float* k_scale,
+                  float scale, const float* bias, long bias_hstride, int bias_ld, const unsigned char* kmask,
+                  const float* slopes, int causal, void* O, int ldo, int out_kind, int S, int h, int n, void* stream);
+
 /* phenaki_pytorch.py:155-161 applied to the trunk outputs: e = null + (cond - null) * scale for the non-prime
  * positions; x rows are [cond sequences | null sequences] of n_tot tokens; rows (or NULL) selects output rows
  * (flat b * (n_tot - n_prime) + i). */
@@ -124,9 +131,11 @@ int pk_vocab_sample(int dtype, const void* A, int lda, const void* W, int ldw, c
 int pk_vocab_reduce(const void* partials, int M, int V, const int* rows, const unsigned char* mask, long long* ids,
                     long long* pred, float* scores, int need_lse, void* stream);
 
-/* phenaki_pytorch.py:488-491: mask = zeros.scatter(1, scores.topk(k).indices, 1).bool(); ids = where(mask, mask_id, ids). */
+/* phenaki_pytorch.py:488-491: mask = zeros.scatter(1, scores.topk(k).indices, 1).bool(); ids = where(mask, mask_id, ids).
+ * rows_out (B*k int32, or NULL) receives the flat positions b*n + i of the masked tokens: only those rows need the vocab
+ * head in this step (pk_cfg_mix / pk_vocab_sample / pk_vocab_reduce take it as `rows`). */
 int pk_topk_mask(const float* scores, int B, int n, int k, long long mask_id, unsigned char* mask, long long* ids,
-                 void* stream);
+                 int* rows_out, void* stream);
 
 /* phenaki_pytorch.py:246-263, 523-545: critic head Linear(dim,1) + CFG mix + noise_mult * (u - 0.5), prime dropped. */
 int pk_critic_head(const float* x, int ldx, const float* w, const float* b, int D, int nb, int n_tot, int n_prime,

@@ -36,11 +36,12 @@ SIGNATURES = {
     'pk_attn_pads': [_I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)],
     'pk_attn_prep': [_I, _P, _I, _P, _I, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'pk_attn_fwd': [_I, _P, _P, _P, _P, _L, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    'pk_attn_small': [_P, _I, _P, _I, _P, _P, _F, _P, _L, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     'pk_cfg_mix': [_P, _I, _I, _I, _I, _P, _I, _F, _I, _P, _I, _I, _I, _P],
     'pk_vocab_ntiles': [_I],
     'pk_vocab_sample': [_I, _P, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P, _ULL, _I, _P, _P],
     'pk_vocab_reduce': [_P, _I, _I, _P, _P, _P, _P, _P, _I, _P],
-    'pk_topk_mask': [_P, _I, _I, _I, _LL, _P, _P, _P],
+    'pk_topk_mask': [_P, _I, _I, _I, _LL, _P, _P, _P, _P],
     'pk_critic_head': [_P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P, _F, _P, _P],
 }
 
@@ -181,6 +182,14 @@ def attn_fwd(dtype, Qp, Kp, Vt, O, S, h, nq, n_kv, nnull, *, bias=None, kmask=No
     _check(rc, 'pk_attn_fwd')
 
 
+def attn_small(q, kv, q_scale, k_scale, scale, O, S, h, n, *, bias=None, kmask=None, slopes=None, causal=False):
+    bh, bld = (bias.stride(0), bias.stride(1)) if bias is not None else (0, 0)
+    rc = load().pk_attn_small(ptr(q), q.stride(-2), ptr(kv), kv.stride(-2), ptr(q_scale), ptr(k_scale), scale, ptr(bias), bh, bld,
+                              ptr(kmask), ptr(slopes), 1 if causal else 0, ptr(O), O.stride(-2),
+                              1 if O.dtype == torch.bfloat16 else 0, S, h, n, stream())
+    _check(rc, 'pk_attn_small')
+
+
 def cfg_mix(x, nb, n_tot, n_prime, rows, nrows, scale, has_null, out, D):
     rc = load().pk_cfg_mix(ptr(x), x.stride(-2), nb, n_tot, n_prime, ptr(rows), nrows, scale, 1 if has_null else 0,
                            ptr(out), out.stride(-2), 1 if out.dtype == torch.float32 else 0, D, stream())
@@ -209,8 +218,8 @@ def vocab_reduce(partials, M, V, rows, mask, ids, pred, scores, need_lse):
     _check(rc, 'pk_vocab_reduce')
 
 
-def topk_mask(scores, B, n, k, mask_id, mask, ids):
-    rc = load().pk_topk_mask(ptr(scores), B, n, k, mask_id, ptr(mask), ptr(ids), stream())
+def topk_mask(scores, B, n, k, mask_id, mask, ids, rows_out=None):
+    rc = load().pk_topk_mask(ptr(scores), B, n, k, mask_id, ptr(mask), ptr(ids), ptr(rows_out), stream())
     _check(rc, 'pk_topk_mask')
 
 

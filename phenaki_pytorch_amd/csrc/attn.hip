@@ -493,6 +493,120 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(const AttnArgs p, uin
     }
 }
 
+
+// ---- small-sequence self-attention (n <= 64, no null keys): the C-ViViT spatial (n = 64) and temporal (n = 9..10)
+// layers.  ONE launch replaces prep_q + prep_kv + attn_fwd: a wave owns G = 64 / n whole sequences of one head, stages
+// the l2-normalised, k_scale'd keys and the values in LDS (f32), and every lane is one query row doing an f32 VALU
+// flash loop over its sequence's keys (the work is ~0.3 GFLOP per video; what matters here is launch count and fixed
+// cost, not MFMA).  Exact f32 arithmetic in both precision modes.
+struct SmallAttnArgs {
+    const float* q; int ldq;            // [S*n][ldq], head hh at columns hh*64
+    const float* kv; int ldkv;          // [S*n][ldkv], k at [0, h*64), v at [h*64, 2*h*64)
+    const float* q_scale; const float* k_scale; float scale;
+    const float* bias; long bias_hstride; int bias_ld;
+    const unsigned char* kmask;         // [S][n] or null
+    const float* slopes; int causal;
+    void* O; int ldo; int out_kind;     // 0: f32, 1: bf16
+    int S, h, n;
+};
+
+constexpr int SROW = 68;                // LDS row stride in floats (64 + 4: rows land on different banks)
+
+template <typename TO>
+__global__ __launch_bounds__(64) void attn_small_kernel(const SmallAttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];          // K^ [G*n][SROW] | V [G*n][SROW]
+    const int lane = threadIdx.x;
+    const int G = 64 / p.n;
+    const int groups = (p.S + G - 1) / G;
+    const int grp = blockIdx.x % groups, hh = blockIdx.x / groups;
+    const int s0 = grp * G;
+    const int nseq = (p.S - s0) < G ? (p.S - s0) : G;
+    const int rows = nseq * p.n;
+    float* Ks = sm;
+    float* Vs = sm + 64 * SROW;
+    // stage keys / values: 16 lanes per row (one 16-byte load each), 4 rows per pass
+    const int l16 = lane & 15;
+    const f32x4 ks = *reinterpret_cast<const f32x4*>(p.k_scale + l16 * 4);
+    for (int r = lane >> 4; r < ((rows + 3) & ~3); r += 4) {
+        f32x4 kx = f32x4{0, 0, 0, 0}, vx = kx;
+        if (r < rows) {
+            const float* row = p.kv + ((size_t)s0 * p.n + r) * p.ldkv;
+            kx = *reinterpret_cast<const f32x4*>(row + hh * DH + l16 * 4);
+            vx = *reinterpret_cast<const f32x4*>(row + p.h * DH + hh * DH + l16 * 4);
+        }
+        const float ss = group16_sum((kx[0] * kx[0] + kx[1] * kx[1]) + (kx[2] * kx[2] + kx[3] * kx[3]));
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        if (r < rows) {
+            f32x4 kn;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) kn[e] = kx[e] * inv * ks[e];
+            *reinterpret_cast<f32x4*>(Ks + r * SROW + l16 * 4) = kn;
+            *reinterpret_cast<f32x4*>(Vs + r * SROW + l16 * 4) = vx;
+        }
+    }
+    __syncthreads();
+    if (lane >= rows) return;
+    const int sl = lane / p.n, i = lane % p.n;                          // local sequence, query position
+    const int s = s0 + sl;
+    // q^ = l2norm(q) * q_scale * scale, kept in registers
+    f32x4 qv[16];
+    {
+        const float* qrow = p.q + ((size_t)s * p.n + i) * p.ldq + hh * DH;
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            qv[c] = *reinterpret_cast<const f32x4*>(qrow + c * 4);
+            ss += (qv[c][0] * qv[c][0] + qv[c][1] * qv[c][1]) + (qv[c][2] * qv[c][2] + qv[c][3] * qv[c][3]);
+        }
+        const float inv = p.scale / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const f32x4 qs = *reinterpret_cast<const f32x4*>(p.q_scale + c * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qv[c][e] *= inv * qs[e];
+        }
+    }
+    const float slope = (p.causal && p.slopes) ? p.slopes[hh] : 0.f;
+    const float* brow = p.bias ? p.bias + (size_t)hh * p.bias_hstride + (size_t)i * p.bias_ld : nullptr;
+    const unsigned char* km = p.kmask ? p.kmask + (size_t)s * p.n : nullptr;
+    const float* Kq = Ks + sl * p.n * SROW;
+    const float* Vq = Vs + sl * p.n * SROW;
+    float m = -INFINITY, l = 0.f;
+    f32x4 o[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) o[c] = f32x4{0, 0, 0, 0};
+    for (int j = 0; j < p.n; ++j) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const f32x4 kk = *reinterpret_cast<const f32x4*>(Kq + j * SROW + c * 4);
+            a0 += qv[c][0] * kk[0]; a1 += qv[c][1] * kk[1]; a2 += qv[c][2] * kk[2]; a3 += qv[c][3] * kk[3];
+        }
+        float sv = (a0 + a1) + (a2 + a3);
+        if (brow) sv += brow[j];
+        bool masked = km && !km[j];
+        if (p.causal) {
+            const int dj = j - i;
+            sv -= fabsf((float)dj) * slope;
+            masked = masked || dj > 0;
+        }
+        if (masked) sv = NEG_MAX;
+        const float mn = fmaxf(m, sv);
+        const float alpha = __expf(m - mn), pj = __expf(sv - mn);
+        l = l * alpha + pj;
+        m = mn;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(Vq + j * SROW + c * 4);
+            o[c] = o[c] * alpha + vv * pj;
+        }
+    }
+    const float inv = 1.0f / l;
+    TO* orow = reinterpret_cast<TO*>(p.O) + ((size_t)s * p.n + i) * p.ldo + hh * DH;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) store4(orow + c * 4, o[c] * inv);
+}
+
 }  // namespace pk
 using namespace pk;
 
@@ -570,6 +684,24 @@ extern "C" int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void
         if (QF == 2) hipLaunchKernelGGL((attn_fwd_kernel<float, 2>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((attn_fwd_kernel<float, 1>), grid, block, 0, s, a);
     } else return PK_EINVAL;
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+// attention.py:128-182 for short self-attention sequences (n <= 64, no null keys) straight from the projection outputs:
+// one launch instead of pk_attn_prep + pk_attn_fwd; f32 arithmetic; O is f32 (out_kind 0) or bf16 (1)
+extern "C" int pk_attn_small(const float* q, int ldq, const float* kv, int ldkv, const float* q_scale, const float* k_scale,
+                             float scale, const float* bias, long bias_hstride, int bias_ld, const unsigned char* kmask,
+                             const float* slopes, int causal, void* O, int ldo, int out_kind, int S, int h, int n, void* stream) {
+    if (!q || !kv || !q_scale || !k_scale || !O || S <= 0 || h <= 0 || n <= 0 || n > 64) return PK_EINVAL;
+    auto mis = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) != 0; };
+    if ((ldq & 3) || (ldkv & 3) || (ldo & 3) || mis(q) || mis(kv) || mis(q_scale) || mis(k_scale) || mis(O)) return PK_EALIGN;
+    SmallAttnArgs a{q, ldq, kv, ldkv, q_scale, k_scale, scale, bias, bias_hstride, bias_ld, kmask, slopes, causal, O, ldo, out_kind, S, h, n};
+    const int G = 64 / n, groups = (S + G - 1) / G;
+    const size_t lds = (size_t)2 * 64 * SROW * sizeof(float);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (out_kind == 0) hipLaunchKernelGGL((attn_small_kernel<float>), dim3((unsigned)(groups * h)), dim3(64), lds, s, a);
+    else hipLaunchKernelGGL((attn_small_kernel<bf16>), dim3((unsigned)(groups * h)), dim3(64), lds, s, a);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

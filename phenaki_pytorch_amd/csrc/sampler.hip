@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256) void vocab_reduce_kernel(const float* __restri
 
 // mask = top-k of scores per row (ties: lower index first), ids = where(mask, mask_id, ids)
 __global__ __launch_bounds__(256) void topk_mask_kernel(const float* __restrict__ scores, int n, int k, long long mask_id,
-                                                        unsigned char* __restrict__ mask, long long* __restrict__ ids) {
+                                                        unsigned char* __restrict__ mask, long long* __restrict__ ids,
+                                                        int* __restrict__ rows_out) {
     extern __shared__ float sc[];
     const int b = blockIdx.x;
     for (int i = threadIdx.x; i < n; i += 256) sc[i] = scores[(size_t)b * n + i];
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(256) void topk_mask_kernel(const float* __restrict_
         const bool sel = rank < k;
         mask[(size_t)b * n + i] = sel ? 1 : 0;
         if (sel) ids[(size_t)b * n + i] = mask_id;
+        if (sel && rows_out) rows_out[(size_t)b * k + rank] = b * n + i;     // compacted list of the masked positions
     }
 }
 
@@ -296,9 +298,9 @@ extern "C" int pk_vocab_reduce(const void* partials, int M, int V, const int* ro
 }
 
 extern "C" int pk_topk_mask(const float* scores, int B, int n, int k, long long mask_id, unsigned char* mask,
-                            long long* ids, void* stream) {
+                            long long* ids, int* rows_out, void* stream) {
     if (!scores || !mask || !ids || B <= 0 || n <= 0 || k < 0 || n > 12288) return PK_EINVAL;
-    hipLaunchKernelGGL(topk_mask_kernel, dim3(B), dim3(256), n * sizeof(float), STREAM(stream), scores, n, k, mask_id, mask, ids);
+    hipLaunchKernelGGL(topk_mask_kernel, dim3(B), dim3(256), n * sizeof(float), STREAM(stream), scores, n, k, mask_id, mask, ids, rows_out);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

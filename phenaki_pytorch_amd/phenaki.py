@@ -329,7 +329,7 @@ class Phenaki(nn.Module):
     @eval_decorator
     @torch.no_grad()
     def sample(self, *, num_frames, texts=None, prime_frames=None, batch_size=1, cond_scale=3.,
-               starting_temperature=0.9, noise_K=1., _noise_fn=None, _trace=None, _return_ids=False):
+               starting_temperature=0.9, noise_K=1., _noise_fn=None, _trace=None, _return_ids=False, _compact=None):
         """phenaki_pytorch.py:418-560.  `_noise_fn(kind, step, shape)` (tests) injects the U[0,1) draws of the
         reference run ('gumbel' (B,n,V) and 'critic' (B,n), device f32 tensors); without it the gumbel noise comes
         from the in-kernel counter hash seeded from torch's default generator."""
@@ -385,14 +385,21 @@ class Phenaki(nn.Module):
             # batch-sharded sampling: every rank draws from its own noise stream even under a common torch seed
             seed_base = (seed_base + 0xD1B54A32D192ED03 * (torch.distributed.get_rank() + 1)) & 0x3FFFFFFFFFFFFFFF
         need_lse = not exists(critic)
+        compact = (_trace is None) if _compact is None else bool(_compact)    # traces record the prediction at EVERY position
+        rows_buf = torch.empty((B * n,), device=device, dtype=torch.int32)
 
         for step in range(self.steps):
             is_first_step = step == 0
             is_last_step = step == (self.steps - 1)
             steps_til_x0 = self.steps - (step + 1)
 
+            rows, M = None, B * n
             if not is_first_step and have_scores:
-                L.topk_mask(scores, B, n, ks[step], self.mask_id, mask, ids)     # mask + ids = where(mask, mask_id, ids)
+                # mask + ids = where(mask, mask_id, ids); only the k_s re-masked positions need the vocab head this step
+                # (predictions elsewhere are discarded, phenaki_pytorch.py:509) -> compact row list for the head
+                if compact:
+                    rows, M = rows_buf, B * ks[step]
+                L.topk_mask(scores, B, n, ks[step], self.mask_id, mask, ids, rows)
 
             rec = None
             if _trace is not None:
@@ -401,13 +408,15 @@ class Phenaki(nn.Module):
             inp = ids if not has_prime else torch.cat((prime_token_ids, ids), dim=-1)
             e = mg.embeds(rep(inp), video_patch_shape=patch_shape, context=ctx_r, text_mask=tm_r,
                           null_rows=B if with_null else 0, kv_cache=mg_cache)
-            L.cfg_mix(e, B, n_tot, prime_token_length, None, B * n, float(cond_scale), with_null, mixed, D)
+            L.cfg_mix(e, B, n_tot, prime_token_length, rows, M, float(cond_scale), with_null, mixed, D)
 
             temperature = starting_temperature * (steps_til_x0 / self.steps)
             U = _noise_fn('gumbel', step, (B, n, V)) if _noise_fn is not None else None
-            L.vocab_sample(dt, mixed, w_logits, mg.to_logits.bias, B * n, V, D, float(temperature), U, None,
+            if need_lse and rows is not None:
+                scores.fill_(-1e4)                           # where(mask, 1 - p, -1e4): the rows outside the list
+            L.vocab_sample(dt, mixed, w_logits, mg.to_logits.bias, M, V, D, float(temperature), U, rows,
                            (seed_base + step * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF, need_lse, partials)
-            L.vocab_reduce(partials, B * n, V, None, mask, ids, pred, scores if need_lse else None, need_lse)
+            L.vocab_reduce(partials, M, V, rows, mask, ids, pred, scores if need_lse else None, need_lse)
             if rec is not None:
                 rec.update(pred=pred.clone(), ids=ids.clone())
 

@@ -283,6 +283,42 @@ def test_attention_block(L, dtype, case):
     close(out, ref, 1e-4 if dtype == 'fp32' else 3e-2, f'attention {case} {dtype}')
 
 
+@pytest.mark.parametrize('S,n,causal,has_bias', [(5, 64, False, True), (23, 9, True, False), (3, 10, True, False), (2, 17, False, True)])
+def test_attn_small_equals_prep_plus_flash_path(L, S, n, causal, has_bias):
+    """the fused short-sequence kernel (one launch) against the two-kernel MFMA path in exact-f32 mode and the oracle math."""
+    h = 2
+    q = torch.randn(S * n, h * 64, generator=g(70)).cuda()
+    kv = torch.randn(S * n, 2 * h * 64, generator=g(71)).cuda()
+    qs = (1 + 0.1 * torch.randn(64, generator=g(72))).cuda()
+    ks = (1 + 0.1 * torch.randn(64, generator=g(73))).cuda()
+    bias = torch.randn(h, n, n, generator=g(74)).cuda() if has_bias else None
+    slopes = torch.tensor([0.5, 0.25]).cuda() if causal else None
+    km = (torch.rand(S, n, generator=g(75)) > 0.2)
+    km[:, 0] = True
+    kmd = km.to(torch.uint8).cuda()
+    o1 = torch.empty(S * n, h * 64, device='cuda')
+    L.attn_small(q, kv, qs, ks, 8.0, o1, S, h, n, bias=bias, kmask=kmd, slopes=slopes, causal=causal)
+    nq_pad, nk_pad = L.attn_pads(n, n, 0)
+    Qp = torch.empty(S * h * nq_pad * 64, device='cuda')
+    Kp = torch.empty(S * h * nk_pad * 64, device='cuda')
+    Vt = torch.empty(S * h * nk_pad * 64, device='cuda')
+    L.attn_prep(L.F32, q, kv, None, qs, ks, 8.0, Qp, Kp, Vt, S, h, n, n, 0)
+    o2 = torch.empty(S * n, h * 64, device='cuda')
+    L.attn_fwd(L.F32, Qp, Kp, Vt, o2, S, h, n, n, 0, bias=bias, kmask=kmd, slopes=slopes, causal=causal)
+    close(o1, o2, 1e-5, 'attn_small vs prep+fwd')
+    # and the torch expression
+    qc, kc, vc = q.cpu().view(S, n, h, 64).transpose(1, 2), kv.cpu()[:, :h * 64].reshape(S, n, h, 64).transpose(1, 2), kv.cpu()[:, h * 64:].reshape(S, n, h, 64).transpose(1, 2)
+    sim = torch.einsum('shid,shjd->shij', F.normalize(qc, dim=-1) * qs.cpu(), F.normalize(kc, dim=-1) * ks.cpu()) * 8
+    if has_bias:
+        sim = sim + bias.cpu()
+    sim = sim.masked_fill(~km[:, None, None, :], -torch.finfo(torch.float32).max)
+    if causal:
+        sim = sim + O.alibi_bias(h, n, n) * 0 - (torch.arange(n)[None, :] - torch.arange(n)[:, None]).abs() * slopes.cpu()[:, None, None]
+        sim = sim.masked_fill(torch.ones(n, n, dtype=torch.bool).triu(1), -torch.finfo(torch.float32).max)
+    ref = torch.einsum('shij,shjd->shid', sim.softmax(-1), vc).transpose(1, 2).reshape(S * n, h * 64)
+    close(o1, ref, 1e-5, 'attn_small vs torch')
+
+
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
 def test_transformer_with_peg_cross_and_ff(L, dtype):
     from phenaki_pytorch_amd.attention import Transformer, set_compute_dtype
@@ -376,9 +412,12 @@ def test_topk_mask(L, B, n, k):
     mask_ref = torch.zeros(B, n).scatter(1, idx, 1).bool()
     mask = torch.zeros(B, n, device='cuda', dtype=torch.uint8)
     ids = ids0.clone().cuda()
-    L.topk_mask(scores.cuda(), B, n, k, 100, mask, ids)
+    rows = torch.full((B * k,), -1, device='cuda', dtype=torch.int32)
+    L.topk_mask(scores.cuda(), B, n, k, 100, mask, ids, rows)
     assert torch.equal(mask.cpu().bool(), mask_ref)
     assert torch.equal(ids.cpu(), torch.where(mask_ref, 100, ids0))
+    flat = (idx + torch.arange(B)[:, None] * n).reshape(-1)            # topk order = descending score = rank order
+    assert torch.equal(rows.cpu().long(), flat)
 
 
 def test_cfg_mix_and_critic_head(L):

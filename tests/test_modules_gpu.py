@@ -195,6 +195,9 @@ def test_sample_fast_mode_is_seeded_and_shapes_match_readme():
     assert v1.shape == (2, 3, 5, 64, 64)
     assert torch.equal(ids1, ids2) and torch.equal(v1, v2)
     assert not torch.equal(ids1, ids3)
+    torch.manual_seed(5)
+    v4, ids4 = ph.sample(texts=['a', 'b'], num_frames=5, cond_scale=5., _return_ids=True, _compact=False)
+    assert torch.equal(ids1, ids4), 'masked-row compaction of the vocab head must not change the sampled ids'
     assert (ids1 != ph.mask_id).all() and (ids1 >= 0).all() and (ids1 < 256).all()
     img = ph.sample_images(texts=['a', 'b'], cond_scale=5.)
     assert img.shape == (2, 3, 64, 64)

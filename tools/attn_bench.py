@@ -47,5 +47,24 @@ def main():
         print(f'{note:34s} prep {t_prep:7.1f} us   fwd {t_fwd:7.1f} us   {flops / t_fwd / 1e6:7.1f} TFLOP/s   (PK_ATTN_MAX_QF={os.environ.get("PK_ATTN_MAX_QF", "4")})', flush=True)
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and len(sys.argv) == 1:
     main()
+
+
+def small():
+    """the fused short-sequence kernel on the tokenizer shapes"""
+    L.load()
+    for S, n, causal, has_bias, note in [(72, 64, False, True, 'spatial'), (512, 9, True, False, 'temporal')]:
+        h = 8
+        q = torch.randn(S * n, h * 64, device='cuda')
+        kv = torch.randn(S * n, 2 * h * 64, device='cuda')
+        qs, ks = torch.ones(64, device='cuda'), torch.ones(64, device='cuda')
+        bias = torch.randn(h, n, n, device='cuda') if has_bias else None
+        slopes = torch.rand(h, device='cuda') if causal else None
+        O = torch.empty(S * n, h * 64, device='cuda', dtype=torch.bfloat16)
+        t = timeit(lambda: L.attn_small(q, kv, qs, ks, 8.0, O, S, h, n, bias=bias, slopes=slopes, causal=causal))
+        print(f'attn_small {note:10s} S={S} n={n}: {t:7.1f} us', flush=True)
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'small':
+    small()
