@@ -98,6 +98,14 @@ int pk_attn_prep(int dtype, const float* q, int ldq, const float* kv, int ldkv, 
                  const float* q_scale, const float* k_scale, float scale, void* Qp, void* Kp, void* Vt,
                  int S, int h, int nq, int n_kv, int nnull, void* stream);
 
+/* attention.py:142-157 in ONE launch (bf16): to_q (A = xq = LayerNorm(x)) and to_kv (A = xkv = the un-normalised x, or NULL
+ * for the query side only) as one MFMA GEMM whose epilogue does the head split, l2norm, q/k scales (sim scale folded in
+ * q) and the V transpose, writing Qp / Kp / Vt (layouts above) directly: the f32 q / kv matrices never reach HBM and
+ * pk_attn_prep is not needed.  Self-attention only on the kv side (no null keys); M = S * nseq rows. */
+int pk_qkv_project(const void* xq, const void* xkv, int ld, const void* wq, const void* wkv, int ldw, int S, int nseq,
+                   int h, int K, const float* q_scale, const float* k_scale, float scale, void* Qp, void* Kp, void* Vt,
+                   int nq_pad, int nk_pad, void* stream);
+
 /* attention.py:157-182: softmax(sim + bias (+ key mask, + ALiBi, causal)) @ v, heads merged: O[(s,i)][hh*64 + d].
  * bias[hh][i][j] is over the real (non-null) keys; kmask [S][n_kv] uint8 (1 = keep); slopes [h] with causal. */
 int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void* Vt, const float* bias, long bias_hstride,

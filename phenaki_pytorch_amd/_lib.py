@@ -35,6 +35,7 @@ SIGNATURES = {
     'pk_cpb_input': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     'pk_attn_pads': [_I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)],
     'pk_attn_prep': [_I, _P, _I, _P, _I, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'pk_qkv_project': [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P],
     'pk_attn_fwd': [_I, _P, _P, _P, _P, _L, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'pk_attn_small': [_P, _I, _P, _I, _P, _P, _F, _P, _L, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     'pk_cfg_mix': [_P, _I, _I, _I, _I, _P, _I, _F, _I, _P, _I, _I, _I, _P],
@@ -169,6 +170,12 @@ def attn_prep(dtype, q, kv, null_kv, q_scale, k_scale, scale, Qp, Kp, Vt, S, h, 
     rc = load().pk_attn_prep(dtype, ptr(q), q.stride(-2), ptr(kv), kv.stride(-2) if kv is not None else 0, ptr(null_kv) if nnull else None,
                              ptr(q_scale), ptr(k_scale), scale, ptr(Qp), ptr(Kp), ptr(Vt), S, h, nq, n_kv, nnull, stream())
     _check(rc, 'pk_attn_prep')
+
+
+def qkv_project(xq, xkv, wq, wkv, S, nseq, h, K, q_scale, k_scale, scale, Qp, Kp, Vt, nq_pad, nk_pad):
+    rc = load().pk_qkv_project(ptr(xq), ptr(xkv), xq.stride(-2), ptr(wq), ptr(wkv), wq.stride(0), S, nseq, h, K, ptr(q_scale),
+                                ptr(k_scale), scale, ptr(Qp), ptr(Kp), ptr(Vt), nq_pad, nk_pad, stream())
+    _check(rc, 'pk_qkv_project')
 
 
 def attn_fwd(dtype, Qp, Kp, Vt, O, S, h, nq, n_kv, nnull, *, bias=None, kmask=None, slopes=None, causal=False):

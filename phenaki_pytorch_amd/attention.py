@@ -325,11 +325,19 @@ class Attention(nn.Module):
         # also emits x in bf16 so every GEMM operand is T and can be fed by LDS-DMA
         xraw = torch.empty((M, D), device=dev, dtype=td) if (not is_cross and dtype == L.BF16) else None
         L.layernorm(x2d, self.norm.gamma, self.norm.beta, M, D, out=xn, raw=xraw)
-        q = torch.empty((M, inner), device=dev, dtype=torch.float32)
-        L.gemm(dtype, xn, linear_weight(self.to_q, dtype), M, inner, D, C=q)
-
         slopes = self.rel_pos_bias.slopes if self.causal else None
-        if not is_cross and nnull == 0 and n <= 16:
+        cached = kv_cache.get(id(self)) if (kv_cache is not None and is_cross) else None
+        small = not is_cross and nnull == 0 and n <= 16
+        # bf16: to_q / to_kv run as ONE GEMM launch whose epilogue writes the attention operand images directly
+        # (pk_qkv_project); available for self-attention (no null keys) and for cross-attention with cached K / V
+        fused = dtype == L.BF16 and not small and ((not is_cross and nnull == 0) or cached is not None)
+
+        q = None
+        if not fused:
+            q = torch.empty((M, inner), device=dev, dtype=torch.float32)
+            L.gemm(dtype, xn, linear_weight(self.to_q, dtype), M, inner, D, C=q)
+
+        if small:
             # very short sequences (C-ViViT temporal layers, n = 9..10): l2norm, scales, ALiBi, softmax and PV in ONE
             # launch straight from the projection outputs (measured: 21 us vs 26 us for prep + MFMA attention; at n = 64
             # the f32 VALU loop loses to the MFMA path, 59 us vs 25 us, so the spatial layers keep that)
@@ -343,8 +351,18 @@ class Attention(nn.Module):
 
         nq_pad, nk_pad = L.attn_pads(n, n_kv, nnull)
         Qp = torch.empty((S * h * nq_pad * 64,), device=dev, dtype=td)
-        cached = kv_cache.get(id(self)) if (kv_cache is not None and is_cross) else None
-        if cached is None:
+        if fused:
+            if is_cross:
+                Kp, Vt = cached
+                L.qkv_project(xn, None, linear_weight(self.to_q, dtype), None, S, n, h, D, self.q_scale, None, float(self.scale),
+                              Qp, None, None, nq_pad, nk_pad)
+            else:
+                Kp = torch.empty((S * h * nk_pad * 64,), device=dev, dtype=td)
+                # V^T pad columns multiply p = 0 and must be finite
+                Vt = (torch.zeros if nk_pad != n_kv else torch.empty)((S * h * nk_pad * 64,), device=dev, dtype=td)
+                L.qkv_project(xn, xraw, linear_weight(self.to_q, dtype), linear_weight(self.to_kv, dtype), S, n, h, D,
+                              self.q_scale, self.k_scale, float(self.scale), Qp, Kp, Vt, nq_pad, nk_pad)
+        elif cached is None:
             kv = self.project_kv(context2d if is_cross else (xraw if xraw is not None else x2d), S, n_kv, dtype, is_cross)
             Kp = torch.empty((S * h * nk_pad * 64,), device=dev, dtype=td)
             Vt = torch.empty((S * h * nk_pad * 64,), device=dev, dtype=td)

@@ -1,0 +1,110 @@
+// pk_qkv_project (bf16): to_q and to_kv (reference attention.py:142-146) as ONE MFMA GEMM launch whose epilogue is the whole
+// attention pre-processing of attention.py:146-157 -- head split, l2norm of every 64-wide head row, q_scale / k_scale,
+// the similarity scale folded into q, V stored transposed -- writing the operand images pk_attn_fwd consumes
+//   Qp [S][h][nq_pad][64]   Kp [S][h][nk_pad][64]   Vt [S][h][64][nk_pad]     (bf16)
+// so the f32 q / kv matrices never exist in HBM and pk_attn_prep's two launches disappear.
+// Tile: 64 rows x 64 columns = ONE head, 4 waves stacked along the rows (wave tile 16 x 64): a wave holds whole head rows,
+// the l2 norm is a 16-value in-lane sum plus a 4-lane-group shuffle.  Main loop: gemm_dma.hpp (LDS-DMA ring of 2).
+// Column tiles [0, h) are q heads (A = LayerNorm(x)), [h, 2h) k heads and [2h, 3h) v heads (A = the un-normalised x).
+#include "gemm_dma.hpp"
+
+namespace pk {
+
+struct QkvArgs {
+    const void* xq; const void* xkv;        // [M][ld] bf16; xkv may be null (query side only)
+    const void* wq; const void* wkv;        // [h*64][ldw], [2*h*64][ldw] bf16, K zero-padded to the k-tile
+    int ld, ldw;
+    int M, K, h, nseq;                      // M = S * nseq rows
+    const float* q_scale; const float* k_scale; float scale;
+    void* Qp; void* Kp; void* Vt;
+    int nq_pad, nk_pad;
+};
+
+using QkvTile = GemmDma<bf16, 1, 4, 4, 1, 2, 128>;
+
+__global__ __launch_bounds__(256) void qkv_project_kernel(const QkvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // XCD-aware tile map (see gemm.hip): XCD x owns a contiguous chunk of row tiles and walks all column tiles for it
+    const int MT = (a.M + 63) / 64, cmax = (MT + 7) / 8;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int mstart = xcd * MT / 8, mcount = (xcd + 1) * MT / 8 - mstart;
+    const int ml = idx % cmax;
+    if (ml >= mcount) return;
+    const int m0 = (mstart + ml) * 64;
+    const int nt = idx / cmax;                                  // 0..3h-1
+    const bool is_q = nt < a.h;
+    const int kind = is_q ? 0 : (nt < 2 * a.h ? 1 : 2);         // 0 q, 1 k, 2 v
+    const int hh = nt - kind * a.h;
+
+    GemmOperands p;
+    p.A = is_q ? a.xq : a.xkv;
+    p.W = is_q ? a.wq : a.wkv;
+    p.a_rows = nullptr;
+    p.lda = a.ld; p.ldw = a.ldw;
+    p.M = a.M; p.N = is_q ? a.h * 64 : 2 * a.h * 64; p.K = a.K;
+    p.plain_map = 0;
+    const int n0 = is_q ? hh * 64 : (kind == 1 ? hh * 64 : (a.h + hh) * 64);
+
+    f32x4 acc[1][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0, 0, 0, 0};
+    QkvTile::run(p, a.M, m0, n0, smem, acc);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, lr = lane & 15;
+    const int m = m0 + wave * 16 + lr;
+    if (m >= a.M) return;
+    const int s = m / a.nseq, pos = m % a.nseq;
+    const size_t sh = (size_t)s * a.h + hh;
+    if (kind == 2) {
+        // V^T: element (key = pos, d) -> Vt[sh][d][pos]
+        bf16* vt = reinterpret_cast<bf16*>(a.Vt) + sh * 64 * a.nk_pad + pos;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) store_elem(vt + (size_t)(j * 16 + g * 4 + r) * a.nk_pad, acc[0][j][r]);
+        return;
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ss += acc[0][j][r] * acc[0][j][r];
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    const float inv = (kind == 0 ? a.scale : 1.0f) / fmaxf(sqrtf(ss), 1e-12f);        // F.normalize eps = 1e-12
+    const float* sc = kind == 0 ? a.q_scale : a.k_scale;
+    bf16* dst = kind == 0 ? reinterpret_cast<bf16*>(a.Qp) + (sh * a.nq_pad + pos) * 64
+                          : reinterpret_cast<bf16*>(a.Kp) + (sh * a.nk_pad + pos) * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 scv = *reinterpret_cast<const f32x4*>(sc + j * 16 + g * 4);
+        f32x4 v = acc[0][j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= inv * scv[r];
+        store4(dst + j * 16 + g * 4, v);
+    }
+}
+
+}  // namespace pk
+using namespace pk;
+
+// bf16 only.  xq [M][ld] = LayerNorm(x) rows, xkv [M][ld] = x rows (or NULL: query side only); M = S * nseq.
+extern "C" int pk_qkv_project(const void* xq, const void* xkv, int ld, const void* wq, const void* wkv, int ldw,
+                              int S, int nseq, int h, int K, const float* q_scale, const float* k_scale, float scale,
+                              void* Qp, void* Kp, void* Vt, int nq_pad, int nk_pad, void* stream) {
+    if (!xq || !wq || !q_scale || !Qp || S <= 0 || nseq <= 0 || h <= 0 || K <= 0) return PK_EINVAL;
+    if (xkv && (!wkv || !k_scale || !Kp || !Vt)) return PK_EINVAL;
+    if (nq_pad < nseq || (xkv && nk_pad < nseq)) return PK_EINVAL;
+    auto mis = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) != 0; };
+    if ((K & 7) || (ld & 7) || (ldw & 7) || mis(xq) || mis(wq) || mis(q_scale) || mis(Qp) ||
+        (xkv && (mis(xkv) || mis(wkv) || mis(k_scale) || mis(Kp) || (nk_pad & 3)))) return PK_EALIGN;
+    if (ldw < (K + 63) / 64 * 64) return PK_EINVAL;             // W zero-padded along K to the 64-wide k-tile
+    const long M = (long)S * nseq;
+    if ((size_t)M * ld * 2 >= 0xFFFFFFF0ull) return PK_EINVAL;
+    QkvArgs a{xq, xkv, wq, wkv, ld, ldw, (int)M, K, h, nseq, q_scale, k_scale, scale, Qp, Kp, Vt, nq_pad, nk_pad};
+    const int MT = (int)((M + 63) / 64), NT = xkv ? 3 * h : h;
+    dim3 grid(8 * ((MT + 7) / 8) * NT);
+    hipLaunchKernelGGL(qkv_project_kernel, grid, dim3(256), QkvTile::SMEM, reinterpret_cast<hipStream_t>(stream), a);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}

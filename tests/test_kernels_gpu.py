@@ -319,6 +319,36 @@ def test_attn_small_equals_prep_plus_flash_path(L, S, n, causal, has_bias):
     close(o1, ref, 1e-5, 'attn_small vs torch')
 
 
+@pytest.mark.parametrize('S,n,h,D', [(3, 64, 2, 128), (2, 200, 8, 512), (5, 37, 2, 128)])
+def test_qkv_project_writes_the_attention_operand_images(L, S, n, h, D):
+    """the fused to_q / to_kv + head split + l2norm + scales + V transpose launch against GEMM -> pk_attn_prep."""
+    M = S * n
+    xn = torch.randn(M, D, generator=g(80)).to(torch.bfloat16)
+    xr = torch.randn(M, D, generator=g(81)).to(torch.bfloat16)
+    wq = (torch.randn(h * 64, D, generator=g(82)) / math.sqrt(D)).to(torch.bfloat16)
+    wkv = (torch.randn(2 * h * 64, D, generator=g(83)) / math.sqrt(D)).to(torch.bfloat16)
+    qs = (1 + 0.1 * torch.randn(64, generator=g(84))).cuda()
+    ks = (1 + 0.1 * torch.randn(64, generator=g(85))).cuda()
+    nq_pad, nk_pad = L.attn_pads(n, n, 0)
+    mk = lambda: torch.zeros(S * h * max(nq_pad, nk_pad) * 64, device='cuda', dtype=torch.bfloat16)
+    Qp, Kp, Vt, Qr, Kr, Vr = mk(), mk(), mk(), mk(), mk(), mk()
+    L.qkv_project(xn.cuda(), xr.cuda(), wq.cuda(), wkv.cuda(), S, n, h, D, qs, ks, 8.0, Qp, Kp, Vt, nq_pad, nk_pad)
+    q = (xn.float() @ wq.float().t()).cuda()
+    kv = (xr.float() @ wkv.float().t()).cuda()
+    L.attn_prep(L.BF16, q, kv, None, qs, ks, 8.0, Qr, Kr, Vr, S, h, n, n, 0)
+    nq_el, nk_el = S * h * nq_pad * 64, S * h * nk_pad * 64
+    q4, q4r = Qp[:nq_el].view(S, h, nq_pad, 64)[:, :, :n], Qr[:nq_el].view(S, h, nq_pad, 64)[:, :, :n]
+    k4, k4r = Kp[:nk_el].view(S, h, nk_pad, 64)[:, :, :n], Kr[:nk_el].view(S, h, nk_pad, 64)[:, :, :n]
+    v4, v4r = Vt[:nk_el].view(S, h, 64, nk_pad)[..., :n], Vr[:nk_el].view(S, h, 64, nk_pad)[..., :n]
+    close(q4.float(), q4r.float(), 1e-2, 'Qp')          # one bf16 ulp: the two paths sum the k loop in different orders
+    close(k4.float(), k4r.float(), 1e-2, 'Kp')
+    close(v4.float(), v4r.float(), 1e-2, 'Vt')
+    # query-only form (cross-attention with cached K / V)
+    Q2 = mk()
+    L.qkv_project(xn.cuda(), None, wq.cuda(), None, S, n, h, D, qs, None, 8.0, Q2, None, None, nq_pad, nk_pad)
+    assert torch.equal(Q2[:nq_el].view(S, h, nq_pad, 64)[:, :, :n], q4)
+
+
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
 def test_transformer_with_peg_cross_and_ff(L, dtype):
     from phenaki_pytorch_amd.attention import Transformer, set_compute_dtype
