@@ -83,10 +83,10 @@ def build_models(dtype, with_sampler):
     return load_product('full', FULL, device='cuda', dtype=dtype, with_critic=with_sampler)
 
 
-# template order: T, TM, TN, WM, WN, STAGES, ROWB (the names rocprofv3 prints)
-VARIANT_KERNEL = {1: 'gemm_kernel<T,TA,2,2>', 2: 'gemm_kernel<T,TA,4,4>', 3: 'gemm_dma_kernel<T,2,2,2,2,4,128>',
-                  8: 'gemm_dma_kernel<T,2,2,2,2,2,128>', 9: 'gemm_dma_kernel<T,4,4,2,2,2,128>',
-                  24: 'gemm_dma_kernel<T,4,2,2,4,2,128>'}
+# template order: T, TM, TN, WM, WN, STAGES, ROWB, PW (the names rocprofv3 prints)
+VARIANT_KERNEL = {1: 'gemm_kernel<T,TA,2,2>', 2: 'gemm_kernel<T,TA,4,4>', 3: 'gemm_dma_kernel<T,2,2,2,2,4,128,0>',
+                  8: 'gemm_dma_kernel<T,2,2,2,2,2,128,0>', 9: 'gemm_dma_kernel<T,4,4,2,2,2,128,0>',
+                  24: 'gemm_dma_kernel<T,4,2,2,4,2,128,0>', 33: 'gemm_dma_kernel<T,2,2,2,2,3,128,2>'}
 
 
 class GemmProfiler:

@@ -88,9 +88,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmOperands p, const G
     gemm_epilogue<T, TM, TN>(acc, p.M, p.N, e, m0, n0);
 }
 
-template <typename T, int TM, int TN, int WM, int WN, int STAGES, int ROWB>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(const GemmOperands p, const GemmEpilogue e, int a_nrows) {
-    using Tile = GemmDma<T, TM, TN, WM, WN, STAGES, ROWB>;
+template <typename T, int TM, int TN, int WM, int WN, int STAGES, int ROWB, int PW>
+__global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_dma_kernel(const GemmOperands p, const GemmEpilogue e, int a_nrows) {
+    using Tile = GemmDma<T, TM, TN, WM, WN, STAGES, ROWB, PW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware tile map.  Workgroup b is observed to run on XCD b % 8 (speed only, never correctness); each XCD has a
     // private 4 MiB L2.  XCD x owns a contiguous chunk of m-tiles and walks ALL n-tiles for it (m fastest), so its
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(const GemmOperan
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-    Tile::run(p, a_nrows, m0, n0, smem, acc);
+    if (!Tile::run(p, a_nrows, m0, n0, smem, acc)) return;      // producer waves hold no accumulators
     gemm_epilogue<T, TM, TN, WN>(acc, p.M, p.N, e, m0, n0);
 }
 
@@ -127,18 +127,18 @@ static int launch_v1(const GemmOperands& p, const GemmEpilogue& e, hipStream_t s
     return PK_OK;
 }
 
-template <typename T, int TM, int TN, int STAGES, int WM = 2, int WN = 2, int ROWB = 128>
+template <typename T, int TM, int TN, int STAGES, int WM = 2, int WN = 2, int ROWB = 128, int PW = 0>
 static int launch_dma(const GemmOperands& p, const GemmEpilogue& e, int a_nrows, hipStream_t s) {
-    using Tile = GemmDma<T, TM, TN, WM, WN, STAGES, ROWB>;
+    using Tile = GemmDma<T, TM, TN, WM, WN, STAGES, ROWB, PW>;
     static bool attr_set = false;
     if (!attr_set && Tile::SMEM > 65536) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel<T, TM, TN, WM, WN, STAGES, ROWB>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel<T, TM, TN, WM, WN, STAGES, ROWB, PW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, Tile::SMEM) != hipSuccess) return PK_ELAUNCH;
         attr_set = true;
     }
     const int MT = (p.M + Tile::BM - 1) / Tile::BM, NT = (p.N + Tile::BN - 1) / Tile::BN;
     dim3 grid(8 * ((MT + 7) / 8) * NT);                   // see the XCD-aware tile map in the kernel
-    hipLaunchKernelGGL((gemm_dma_kernel<T, TM, TN, WM, WN, STAGES, ROWB>), grid, dim3(64 * WM * WN), Tile::SMEM, s, p, e, a_nrows);
+    hipLaunchKernelGGL((gemm_dma_kernel<T, TM, TN, WM, WN, STAGES, ROWB, PW>), grid, dim3(Tile::THREADS), Tile::SMEM, s, p, e, a_nrows);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }
@@ -166,7 +166,7 @@ static int auto_variant(int dtype, int a_is_f32, int M, int N, int K, int lda, i
     const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (!dma_possible(dtype, a_is_f32, N, K, lda, ldw, a_nrows)) return blocks128 >= 384 ? 2 : 1;
     if (blocks128 >= 512 || (blocks128 >= 256 && K >= 1024)) return 24;     // 128x128, 8 waves, 2 stages (16 waves/CU)
-    if (K >= 2048) return 3;                                                // 64x64, 4 stages (patch embed)
+    if (K >= 2048) return dtype == 1 ? 33 : 3;      // long K (patch embed): 64x64, 3-stage ring fed by 2 producer waves (bf16) / 4 stages
     return 8;                                                               // 64x64, 2 stages (5 WG/CU)
 }
 
@@ -236,6 +236,16 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
             case 28: return launch_dma<bf16, 4, 4, 2, 4, 2>(p, e, a_nrows, s);      // 256x128, 8 waves (4x2), 2 stages (96 KB)
             case 29: return launch_dma<bf16, 4, 4, 2, 4, 4, 64>(p, e, a_nrows, s);  // 256x256, 16 waves, k-tile 32, 2 stages (64 KB: 2 WG/CU)
             case 30: return launch_dma<bf16, 4, 4, 3, 4, 4, 64>(p, e, a_nrows, s);  // 256x256, 16 waves, k-tile 32, 3 stages (96 KB)
+            // producer / consumer role split (PW producer waves feed the ring, the others only compute)
+            case 31: return launch_dma<bf16, 4, 4, 3, 2, 2, 128, 4>(p, e, a_nrows, s);  // 128x128, 4 consumers + 4 producers, 3 stages (96 KB)
+            case 32: return launch_dma<bf16, 4, 2, 3, 2, 4, 128, 4>(p, e, a_nrows, s);  // 128x128, 8 consumers + 4 producers, 3 stages
+            case 33: return launch_dma<bf16, 2, 2, 3, 2, 2, 128, 2>(p, e, a_nrows, s);  // 64x64, 4 consumers + 2 producers, 3 stages (48 KB)
+            case 34: return launch_dma<bf16, 2, 2, 3, 2, 2, 128, 1>(p, e, a_nrows, s);  // 64x64, 4 consumers + 1 producer, 3 stages
+            case 35: return launch_dma<bf16, 2, 2, 4, 2, 2, 128, 4>(p, e, a_nrows, s);  // 64x64, 4 + 4, 4 stages (64 KB)
+            case 36: return launch_dma<bf16, 4, 4, 4, 2, 2, 128, 4>(p, e, a_nrows, s);  // 128x128, 4 + 4, 4 stages (128 KB)
+            case 37: return launch_dma<bf16, 4, 4, 3, 2, 4, 128, 4>(p, e, a_nrows, s);  // 128x256, 8 consumers + 4 producers, 3 stages (144 KB)
+            case 38: return launch_dma<bf16, 4, 4, 2, 2, 2, 128, 4>(p, e, a_nrows, s);  // 128x128, 4 + 4, 2 stages (64 KB: 2 WG/CU)
+            case 39: return launch_dma<bf16, 2, 2, 2, 2, 2, 128, 2>(p, e, a_nrows, s);  // 64x64, 4 + 2, 2 stages (32 KB: 5 WG/CU)
             default: return PK_EINVAL;
         }
     }

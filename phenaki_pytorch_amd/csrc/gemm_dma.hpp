@@ -25,16 +25,23 @@ __device__ __forceinline__ void lds_frag64(Frag<bf16>& f, const char* tile, int 
     f.v = *reinterpret_cast<const u32x4*>(tile + row * 64 + (slot << 4));
 }
 
-// TM x TN MFMA tiles per wave, WM x WN waves per workgroup (64 * WM * WN threads), ROWB bytes of k per LDS row
-template <typename T, int TM, int TN, int WM, int WN, int STAGES, int ROWB = 128>
+// TM x TN MFMA tiles per wave, WM x WN compute waves per workgroup, ROWB bytes of k per LDS row.
+// PW = 0: every wave both feeds the ring and computes (64 * WM * WN threads).
+// PW > 0: role split -- PW extra PRODUCER waves (wave ids >= WM*WN) issue all the LDS-DMA pieces and wait for them, the
+//         WM*WN CONSUMER waves only do ds_read + MFMA (64 * (WM*WN + PW) threads).  A DMA issue stalls its wave for
+//         ~60-180 cycles while the texture path is busy; with the roles split that stall no longer sits in front of
+//         the consumer's MFMAs on the same SIMD (MI355X: separate waves issue independently).
+template <typename T, int TM, int TN, int WM, int WN, int STAGES, int ROWB = 128, int PW = 0>
 struct GemmDma {
     static_assert(ROWB == 128 || (ROWB == 64 && sizeof(T) == 2), "64-byte k-tiles are built for bf16 only");
     static constexpr int NW = WM * WN;
     static constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
     static constexpr int RPI = 1024 / ROWB;                             // rows per DMA wave-instruction
     static constexpr int SLOTS = ROWB / 16;
-    static constexpr int IA = BM / (RPI * NW), IW = BN / (RPI * NW);    // DMA instructions per wave per k-tile
-    static_assert(IA * RPI * NW == BM && IW * RPI * NW == BN, "tile rows must split evenly over the waves' DMA pieces");
+    static constexpr int NLW = PW > 0 ? PW : NW;                        // waves that issue DMA
+    static constexpr int THREADS = 64 * (NW + PW);
+    static constexpr int IA = BM / (RPI * NLW), IW = BN / (RPI * NLW);  // DMA instructions per loading wave per k-tile
+    static_assert(IA * RPI * NLW == BM && IW * RPI * NLW == BN, "tile rows must split evenly over the loading waves' DMA pieces");
     static constexpr int BK = ROWB / (int)sizeof(T);
     static constexpr int CH = BK / 32;
     static constexpr int STAGE_BYTES = (BM + BN) * ROWB;
@@ -59,11 +66,16 @@ struct GemmDma {
         }
     }
 
-    // acc must be zero-initialised by the caller. a_nrows = number of physical rows behind p.A (for the bounds check)
-    static __device__ __forceinline__ void run(const GemmOperands& p, int a_nrows, int m0, int n0, char* smem, f32x4 (&acc)[TM][TN]) {
+    // acc must be zero-initialised by the caller. a_nrows = number of physical rows behind p.A (for the bounds check).
+    // Returns true for the waves that hold accumulators (all of them when PW == 0); producer waves must skip the epilogue.
+    static __device__ __forceinline__ bool run(const GemmOperands& p, int a_nrows, int m0, int n0, char* smem, f32x4 (&acc)[TM][TN]) {
         const int tid = threadIdx.x, lane = tid & 63;
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int wm = wave / WN, wn = wave % WN, g = lane >> 4, lr = lane & 15;
+        const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const bool loads = PW == 0 || wave_all >= NW;
+        const bool computes = PW == 0 || wave_all < NW;
+        const int wave = PW == 0 ? wave_all : (loads ? wave_all - NW : 0);      // index among the loading waves
+        const int cw = computes ? wave_all : 0;                                 // index among the compute waves
+        const int wm = cw / WN, wn = cw % WN, g = lane >> 4, lr = lane & 15;
         constexpr int SZ = (int)sizeof(T);
 
         const uint32_t bytesA = (uint32_t)a_nrows * (uint32_t)p.lda * SZ;
@@ -104,12 +116,15 @@ struct GemmDma {
 
         const int nt = (p.K + BK - 1) / BK;
         const int pre = nt < STAGES - 1 ? nt : STAGES - 1;
-        for (int s = 0; s < pre; ++s) issue(s, s);
+        if (loads)
+            for (int s = 0; s < pre; ++s) issue(s, s);
+        if (PW > 0 && computes) __builtin_amdgcn_s_setprio(1);      // consumers win issue arbitration against their SIMD's producer
         for (int kt = 0; kt < nt; ++kt) {
             const int issued = (kt + STAGES - 1 < nt) ? kt + STAGES - 1 : nt;      // tiles issued so far
-            wait_outstanding(issued - (kt + 1));
+            if (loads) wait_outstanding(issued - (kt + 1));
             __builtin_amdgcn_s_barrier();                 // tile kt landed for every wave; everyone is done with tile kt-1
-            if (kt + STAGES - 1 < nt) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+            if (loads && kt + STAGES - 1 < nt) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+            if (!computes) continue;
             const char* a = smem + (kt % STAGES) * STAGE_BYTES;
             const char* w = a + BM * ROWB;
 #pragma unroll
@@ -134,6 +149,7 @@ struct GemmDma {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                     // the ring is dead: callers may reuse smem
+        return computes;
     }
 };
 

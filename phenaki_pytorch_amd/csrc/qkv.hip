@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void qkv_project_kernel(const QkvArgs a) {
     f32x4 acc[1][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0, 0, 0, 0};
-    QkvTile::run(p, a.M, m0, n0, smem, acc);
+    (void)QkvTile::run(p, a.M, m0, n0, smem, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, lr = lane & 15;
     const int m = m0 + wave * 16 + lr;

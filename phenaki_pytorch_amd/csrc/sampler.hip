@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64 * VWM * VWN) void vocab_sample_kernel(const Gemm
     for (int i = 0; i < VTM; ++i)
 #pragma unroll
         for (int j = 0; j < VTN; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-    Tile::run(p, p.M, m0, n0, smem, acc);
+    (void)Tile::run(p, p.M, m0, n0, smem, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / VWN, wn = wave % VWN, g = lane >> 4, lr = lane & 15;

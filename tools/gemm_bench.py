@@ -24,8 +24,8 @@ SHAPES = [  # (M, N, K, note)
     (9216, 512, 1368, 'maskgit FF2'),
     (4608, 65536, 512, 'vocab head as plain GEMM'),
 ]
-VARIANTS = {8: 'd64s2', 9: 'd128s2', 23: 'd128x256k32s2', 24: 'd128w8s2', 25: 'd128w8k32s2', 26: 'd128w16s2', 27: 'd128w8bs2',
-            28: 'd256x128w8s2', 29: 'd256w16k32s2', 30: 'd256w16k32s3'}
+VARIANTS = {8: 'd64s2', 24: 'd128w8s2', 31: 'pc128 4+4 s3', 32: 'pc128 8+4 s3', 33: 'pc64 4+2 s3', 34: 'pc64 4+1 s3', 35: 'pc64 4+4 s4',
+            36: 'pc128 4+4 s4', 37: 'pc128x256 8+4 s3', 38: 'pc128 4+4 s2', 39: 'pc64 4+2 s2'}
 
 
 def main():
