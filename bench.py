@@ -195,9 +195,28 @@ def bench_sample(ph, args, ws):
         ph.sample(texts=texts, num_frames=17, cond_scale=5.)
     barrier_sync(ws)
     dt = max_over_ranks(time.perf_counter() - t0, ws) / runs
-    return dict(metric='maskgit_sampled_tokens_per_sec', value=B * 576 * ws / dt, unit='tokens/s', seconds_per_sample_call=dt,
-                batch_per_gpu=B, steps=ph.steps, cond_scale=5.0, critic='TokenCritic depth 6 cross-attn', tokens_per_video=576,
-                noise='in-kernel counter hash (FAST mode)')
+    out = dict(metric='maskgit_sampled_tokens_per_sec', value=B * 576 * ws / dt, unit='tokens/s', seconds_per_sample_call=dt,
+               batch_per_gpu=B, steps=ph.steps, cond_scale=5.0, critic='TokenCritic depth 6 cross-attn', tokens_per_video=576,
+               noise='in-kernel counter hash (FAST mode)')
+    # roofline of this leg's dominant kernel (the MFMA GEMM at M = 2B*576 rows): 2 untimed sampling steps under the profiler
+    steps = ph.steps
+    try:
+        ph.steps = 2
+        with GemmProfiler() as prof:
+            ph.sample(texts=texts, num_frames=17, cond_scale=5.)
+        g = prof.summary()
+    finally:
+        ph.steps = steps
+    if g:
+        name, d = max(g.items(), key=lambda kv: kv[1]['seconds'])
+        ach = d['flops'] / d['seconds'] / 1e12
+        peak = PEAK_BF16_TFLOPS if args.dtype == 'bf16' else 157.3
+        out['roofline'] = {'bound': 'mfma', 'kernel': name, 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+                           'traffic': None, 'avg_launch_us': d['seconds'] / d['launches'] * 1e6,
+                           'algorithmic_flops_per_launch': d['flops'] / d['launches'],
+                           'all_gemm_variants': {k: {'launches': v['launches'], 'TFLOP/s': v['flops'] / v['seconds'] / 1e12,
+                                                     'us_total': v['seconds'] * 1e6} for k, v in g.items()}}
+    return out
 
 
 def cpu_baseline(args):
