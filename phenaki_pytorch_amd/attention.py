@@ -267,6 +267,28 @@ class ContinuousPositionBias(nn.Module):
         return out.reshape(n, n, heads).permute(2, 0, 1).contiguous()
 
 
+_VT_ZERO_WS = {}
+
+
+def _vt_buffer(numel, dev, td, padded):
+    """V^T operand image for pk_qkv_project.  Its pad columns (keys >= n) are multiplied by p = 0 and must stay finite;
+    pk_qkv_project never writes them, so ONE zero-initialised workspace per (device, size, dtype, stream) is handed out again
+    and again (layers run back to back on one stream) instead of a 17 MB fill launch per temporal layer.
+    Never cached while a hipGraph is being captured: capture-time allocations belong to the graph's private pool."""
+    if not padded:
+        return torch.empty((numel,), device=dev, dtype=td)
+    if torch.cuda.is_current_stream_capturing():
+        ws = _VT_ZERO_WS.get((dev, numel, td, torch.cuda.current_stream(dev).cuda_stream))
+        return ws if ws is not None else torch.zeros((numel,), device=dev, dtype=td)
+    key = (dev, numel, td, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _VT_ZERO_WS.get(key)
+    if ws is None:
+        if len(_VT_ZERO_WS) >= 8:
+            _VT_ZERO_WS.clear()
+        ws = _VT_ZERO_WS[key] = torch.zeros((numel,), device=dev, dtype=td)
+    return ws
+
+
 class Attention(nn.Module):
     """attention.py:89-182."""
 
@@ -361,7 +383,7 @@ class Attention(nn.Module):
             else:
                 Kp = torch.empty((S * h * nk_pad * 64,), device=dev, dtype=td)
                 # V^T pad columns multiply p = 0 and must be finite
-                Vt = (torch.zeros if nk_pad != n_kv else torch.empty)((S * h * nk_pad * 64,), device=dev, dtype=td)
+                Vt = _vt_buffer(S * h * nk_pad * 64, dev, td, padded=nk_pad != n_kv)
                 L.qkv_project(xn, xraw, linear_weight(self.to_q, dtype), linear_weight(self.to_kv, dtype), S, n, h, D,
                               self.q_scale, self.k_scale, float(self.scale), Qp, Kp, Vt, nq_pad, nk_pad)
         elif cached is None:

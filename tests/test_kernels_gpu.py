@@ -156,7 +156,8 @@ def test_layernorm(L, M, D):
     assert out3[0:2 * M:2].abs().max().item() == 0
 
 
-@pytest.mark.parametrize('B,C,Fr,H,W,pt,ph,pw', [(2, 3, 5, 64, 64, 2, 16, 16), (1, 3, 3, 256, 256, 2, 32, 32), (2, 3, 1, 32, 64, 2, 8, 16)])
+@pytest.mark.parametrize('B,C,Fr,H,W,pt,ph,pw', [(2, 3, 5, 64, 64, 2, 16, 16), (1, 3, 3, 256, 256, 2, 32, 32), (2, 3, 1, 32, 64, 2, 8, 16),
+                                                   (1, 3, 3, 128, 128, 2, 32, 16), (1, 3, 3, 64, 64, 2, 32, 4), (2, 1, 5, 64, 256, 2, 32, 64)])
 def test_patchify_ln_and_unpatchify(L, B, C, Fr, H, W, pt, ph, pw):
     video = torch.randn(B, C, Fr, H, W, generator=g(12))
     h, w = H // ph, W // pw
@@ -177,6 +178,9 @@ def test_patchify_ln_and_unpatchify(L, B, C, Fr, H, W, pt, ph, pw):
         out = torch.empty(B * nt * h * w, P, device='cuda')
         L.patchify_ln(vd, f0, nt, tp, ph, pw, wgt.cuda(), b.cuda(), out)
         close(out, ref, 1e-5, f'patchify_ln f0={f0}')
+        outb = torch.empty(B * nt * h * w, P, device='cuda', dtype=torch.bfloat16)
+        L.patchify_ln(vd, f0, nt, tp, ph, pw, wgt.cuda(), b.cuda(), outb)
+        close(outb.float(), ref, 5e-3, f'patchify_ln bf16 f0={f0}')
         L.unpatchify(pat.cuda().contiguous(), recon, f0, nt, tp, ph, pw)
     assert torch.equal(recon.cpu(), video), 'unpatchify(patchify(video)) must reproduce the video bit-exactly'
 

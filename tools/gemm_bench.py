@@ -32,8 +32,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--rounds', type=int, default=5)
+    ap.add_argument('--variants', type=str, default='', help='comma list, default all')
+    ap.add_argument('--res', action='store_true', help='add bias + f32 residual (the out-projection epilogue)')
     args = ap.parse_args()
     L.load()
+    global VARIANTS
+    if args.variants:
+        VARIANTS = {int(v): VARIANTS[int(v)] for v in args.variants.split(',')}
     out = {}
     for M, N, K, note in SHAPES:
         Kp = (K + 63) // 64 * 64
@@ -41,16 +46,19 @@ def main():
         W = torch.zeros(N, Kp, device='cuda', dtype=torch.bfloat16)
         W[:, :K] = (torch.randn(N, K, device='cuda') / K ** 0.5).to(torch.bfloat16)
         C = torch.empty(M, N, device='cuda', dtype=torch.float32 if N < 60000 else torch.bfloat16)
+        kw = {}
+        if args.res and C.dtype == torch.float32:
+            kw = dict(bias=torch.randn(N, device='cuda'), res=torch.randn(M, N, device='cuda'))
         times = {v: [] for v in VARIANTS}
         for v in VARIANTS:
-            L.gemm(L.BF16, A, W, M, N, K, C=C, variant=v)      # warm
+            L.gemm(L.BF16, A, W, M, N, K, C=C, variant=v, **kw)      # warm
         torch.cuda.synchronize()
         for _ in range(args.rounds):
             for v in VARIANTS:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(args.iters):
-                    L.gemm(L.BF16, A, W, M, N, K, C=C, variant=v)
+                    L.gemm(L.BF16, A, W, M, N, K, C=C, variant=v, **kw)
                 e1.record()
                 torch.cuda.synchronize()
                 times[v].append(e0.elapsed_time(e1) / args.iters * 1e-3)
