@@ -13,9 +13,16 @@
 // which makes the epilogue's bias/residual loads and stores 16-byte vectors and puts a GEGLU
 // (value, gate) pair in one lane.
 #pragma once
+#include <cstdlib>
 #include "common.hpp"
 
 namespace pk {
+
+// host: k-rotation default (PK_GEMM_KROT=0 switches it off for A/B measurements)
+static inline int krot_default() {
+    static const int v = getenv("PK_GEMM_KROT") ? atoi(getenv("PK_GEMM_KROT")) : 1;
+    return v;
+}
 
 struct GemmOperands {
     const void* A;      // [M][lda]   f32 or T
@@ -24,6 +31,7 @@ struct GemmOperands {
     int lda, ldw;
     int M, N, K;
     int plain_map;      // 1: row-major tile order (A/B benchmarking only); 0: XCD-aware tile map (DMA kernels)
+    int krot;           // 1: workgroup b walks the k-tiles starting at tile (b >> 3) % nt (DMA kernels; see gemm_dma.hpp)
 };
 
 template <typename T, typename TA> struct RawSlot;                    // one thread's 16-B LDS slot, pre-conversion

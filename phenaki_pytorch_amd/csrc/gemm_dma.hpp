@@ -103,9 +103,17 @@ struct GemmDma {
             offW[i] = gn < p.N ? (uint32_t)gn * (uint32_t)p.ldw * SZ + srcslot * 16 : bytesW;
         }
 
+        // k-rotation: every workgroup of a launch reads the SAME 128-byte column slab of A and W at the same time, and
+        // with power-of-two row strides (1 KiB for K = 512 bf16) a slab lives on a fraction of the L2 channels: the
+        // workgroups queue on those while the others idle.  Starting workgroup b at k-tile (b >> 3) % nt (b >> 3 = its
+        // index inside its XCD) spreads the concurrent slabs over all channels; the sum over k only changes order.
+        const int nt = (p.K + BK - 1) / BK;
+        const int rot = (p.krot && nt > 1) ? (int)(((blockIdx.x >> 3) + blockIdx.y) % (unsigned)nt) : 0;
         auto issue = [&](int kt, int slot) {
             char* base = smem + slot * STAGE_BYTES;
-            const int koff = kt * ROWB;
+            int kk = kt + rot;
+            if (kk >= nt) kk -= nt;
+            const int koff = kk * ROWB;
 #pragma unroll
             for (int i = 0; i < IA; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(base + (wave * IA + i) * 1024), 16, offA[i], koff, 0, 0);
@@ -114,7 +122,6 @@ struct GemmDma {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(base + BM * ROWB + (wave * IW + i) * 1024), 16, offW[i], koff, 0, 0);
         };
 
-        const int nt = (p.K + BK - 1) / BK;
         const int pre = nt < STAGES - 1 ? nt : STAGES - 1;
         if (loads)
             for (int s = 0; s < pre; ++s) issue(s, s);

@@ -32,13 +32,21 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const LnArgs p) {
     TO* out = reinterpret_cast<TO*>(p.out);
     TO* raw = reinterpret_cast<TO*>(p.raw);
     const int nv = p.D >> 2;
-    f32x4 v[VMAX];
+    f32x4 v[VMAX], gm[VMAX], bt[VMAX];
     float s = 0.f;
+    // every load (x, gamma, beta) is issued before the first store: stores retire through the same in-order vmcnt
 #pragma unroll
     for (int i = 0; i < VMAX; ++i) {
         const int c = lane + i * 64;
-        if (c < nv) { v[i] = *reinterpret_cast<const f32x4*>(xr + c * 4); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+        if (c < nv) {
+            v[i] = *reinterpret_cast<const f32x4*>(xr + c * 4);
+            gm[i] = *reinterpret_cast<const f32x4*>(p.gamma + c * 4);
+            bt[i] = p.beta ? *reinterpret_cast<const f32x4*>(p.beta + c * 4) : f32x4{0, 0, 0, 0};
+        }
     }
+#pragma unroll
+    for (int i = 0; i < VMAX; ++i)
+        if (lane + i * 64 < nv) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     const float mean = wave_sum(s) / (float)p.D;
     float q = 0.f;
 #pragma unroll
@@ -54,11 +62,9 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const LnArgs p) {
     for (int i = 0; i < VMAX; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
-            const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c * 4);
             f32x4 y;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) y[r] = (v[i][r] - mean) * rstd * gm[r];
-            if (p.beta) y += *reinterpret_cast<const f32x4*>(p.beta + c * 4);
+            for (int r = 0; r < 4; ++r) y[r] = (v[i][r] - mean) * rstd * gm[i][r] + bt[i][r];
             if (out) store4(out + (size_t)orow * p.ldo + c * 4, y);
             if (p.out2) store4(p.out2 + (size_t)orow * p.ldo2 + c * 4, y);
             if (raw) store4(raw + (size_t)orow * p.ldraw + c * 4, v[i]);

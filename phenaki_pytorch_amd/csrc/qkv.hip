@@ -18,6 +18,7 @@ struct QkvArgs {
     const float* q_scale; const float* k_scale; float scale;
     void* Qp; void* Kp; void* Vt;
     int nq_pad, nk_pad;
+    int krot;
 };
 
 using QkvTile = GemmDma<bf16, 1, 4, 4, 1, 2, 128>;
@@ -43,6 +44,7 @@ __global__ __launch_bounds__(256) void qkv_project_kernel(const QkvArgs a) {
     p.lda = a.ld; p.ldw = a.ldw;
     p.M = a.M; p.N = is_q ? a.h * 64 : 2 * a.h * 64; p.K = a.K;
     p.plain_map = 0;
+    p.krot = a.krot;
     const int n0 = is_q ? hh * 64 : (kind == 1 ? hh * 64 : (a.h + hh) * 64);
 
     f32x4 acc[1][4];
@@ -75,12 +77,14 @@ __global__ __launch_bounds__(256) void qkv_project_kernel(const QkvArgs a) {
     const float* sc = kind == 0 ? a.q_scale : a.k_scale;
     bf16* dst = kind == 0 ? reinterpret_cast<bf16*>(a.Qp) + (sh * a.nq_pad + pos) * 64
                           : reinterpret_cast<bf16*>(a.Kp) + (sh * a.nk_pad + pos) * 64;
+    f32x4 scv[4];                                               // all loads before the first store (in-order vmcnt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) scv[j] = *reinterpret_cast<const f32x4*>(sc + j * 16 + g * 4);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const f32x4 scv = *reinterpret_cast<const f32x4*>(sc + j * 16 + g * 4);
         f32x4 v = acc[0][j];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= inv * scv[r];
+        for (int r = 0; r < 4; ++r) v[r] *= inv * scv[j][r];
         store4(dst + j * 16 + g * 4, v);
     }
 }
@@ -101,7 +105,7 @@ extern "C" int pk_qkv_project(const void* xq, const void* xkv, int ld, const voi
     if (ldw < (K + 63) / 64 * 64) return PK_EINVAL;             // W zero-padded along K to the 64-wide k-tile
     const long M = (long)S * nseq;
     if ((size_t)M * ld * 2 >= 0xFFFFFFF0ull) return PK_EINVAL;
-    QkvArgs a{xq, xkv, wq, wkv, ld, ldw, (int)M, K, h, nseq, q_scale, k_scale, scale, Qp, Kp, Vt, nq_pad, nk_pad};
+    QkvArgs a{xq, xkv, wq, wkv, ld, ldw, (int)M, K, h, nseq, q_scale, k_scale, scale, Qp, Kp, Vt, nq_pad, nk_pad, 0};
     const int MT = (int)((M + 63) / 64), NT = xkv ? 3 * h : h;
     dim3 grid(8 * ((MT + 7) / 8) * NT);
     hipLaunchKernelGGL(qkv_project_kernel, grid, dim3(256), QkvTile::SMEM, reinterpret_cast<hipStream_t>(stream), a);

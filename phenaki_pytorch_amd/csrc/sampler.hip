@@ -257,7 +257,7 @@ extern "C" int pk_vocab_sample(int dtype, const void* A, int lda, const void* W,
     const int bk = dtype == 1 ? 64 : 32;                  // LDS-DMA main loop: W zero-padded along K to the k-tile
     if (ldw < (D + bk - 1) / bk * bk) return PK_EINVAL;
     if ((size_t)M * lda * (dtype == 1 ? 2 : 4) >= 0xFFFFFFF0ull || (size_t)V * ldw * (dtype == 1 ? 2 : 4) >= 0xFFFFFFF0ull) return PK_EINVAL;
-    GemmOperands p{A, W, nullptr, lda, ldw, M, V, D};
+    GemmOperands p{A, W, nullptr, lda, ldw, M, V, D, 0, krot_default()};
     VocabArgs e;
     e.bias = bias; e.U = U; e.rows = rows;
     e.temp = temperature > 1e-10f ? temperature : 1e-10f;

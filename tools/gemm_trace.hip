@@ -6,6 +6,7 @@
 #include "../phenaki_pytorch_amd/csrc/gemm.hip"
 #include <algorithm>
 #include <cstdio>
+#include <string>
 #include <vector>
 
 namespace pk {
@@ -53,7 +54,7 @@ static void run_case(const char* name, int M, int N, int K) {
     const int MT = (M + Tile::BM - 1) / Tile::BM, NT = (N + Tile::BN - 1) / Tile::BN;
     const int grid = 8 * ((MT + 7) / 8) * NT;
     hipMalloc(&tr, (size_t)grid * 32); hipMemset(tr, 0, (size_t)grid * 32);
-    GemmOperands p{A, W, nullptr, Kp, Kp, M, N, K, 0};
+    GemmOperands p{A, W, nullptr, Kp, Kp, M, N, K, 0, 0};
     GemmEpilogue e{nullptr, nullptr, C, 0, N, 1, ACT_NONE, 1};
     auto kern = traced_kernel<bf16, TM, TN, WM, WN, STAGES, MODE>;
     if (Tile::SMEM > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Tile::SMEM);
