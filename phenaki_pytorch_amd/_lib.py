@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libphenaki_hip.so')
+# PK_LIB_PATH: load another build of the same C ABI (A/B timing of two builds on one GPU box; never a fallback)
+LIB_PATH = os.environ.get('PK_LIB_PATH') or os.path.join(_HERE, 'libphenaki_hip.so')
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int

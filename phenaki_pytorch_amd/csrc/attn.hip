@@ -315,8 +315,8 @@ __device__ __forceinline__ void lds_frag_vt(Frag<bf16>& f, const char* tile, int
 // instead of every wave pulling fragment-shaped pieces (16 rows x 64 B per instruction) through the texture path.
 typedef __attribute__((address_space(3))) void* attn_lds_ptr;
 
-template <int QF>
-__global__ __launch_bounds__(256) void attn_fwd_lds_kernel(const AttnArgs p, uint32_t kv_bytes) {
+template <int QF, bool PF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (PF ? 4 : 5) : 3))) void attn_fwd_lds_kernel(const AttnArgs p, uint32_t kv_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];          // 2 stages x (K 8 KB | V^T 8 KB)
     constexpr int STAGE = 16384;
     const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
@@ -375,6 +375,17 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(const AttnArgs p, uin
     for (int qf = 0; qf < QF; ++qf) { const int qi = q0 + qf * 16 + lr; qrow[qf] = qi < p.nq ? qi : p.nq - 1; }
 
     const int ntiles = (p.nk_pad + 63) / 64;
+    // additive-bias vectors (16 B per lane per 4 keys, straight from global) are requested ONE TILE AHEAD: used right
+    // after the QK MFMAs of their own tile they left an L2 round trip exposed in every one of the nk/64 iterations
+    auto load_bz = [&](f32x4 (&b)[QF][4], int kb) {
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf)
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+                b[qf][f] = *reinterpret_cast<const f32x4*>(bias + (size_t)qrow[qf] * p.bias_ld + kb + f * 16 + g * 4);
+    };
+    f32x4 bz[QF][4];
+    if (PF && active && vb_all && 64 <= nk) load_bz(bz, 0);
     issue(0, 0);
     for (int t = 0; t < ntiles; ++t) {
         const int kb = t * 64;
@@ -384,18 +395,13 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(const AttnArgs p, uin
         if (!active) continue;
         const char* kt = smem + (t & 1) * STAGE;
         const char* vt = kt + 8192;
-        // bias vectors for this tile straight from global (16 B per lane per 4 keys), requested before the MFMAs
         const bool simple = (kb + 64 <= nk) && !km && !p.causal;
         const bool vbias = vb_all && simple;
         const bool plain = simple && (!bias || vbias);
-        f32x4 bz[QF][4];
-        if (vbias) {
-#pragma unroll
-            for (int qf = 0; qf < QF; ++qf)
-#pragma unroll
-                for (int f = 0; f < 4; ++f)
-                    bz[qf][f] = *reinterpret_cast<const f32x4*>(bias + (size_t)qrow[qf] * p.bias_ld + kb + f * 16 + g * 4);
-        }
+        const bool vbias_next = PF && vb_all && t + 1 < ntiles && kb + 128 <= nk;
+        f32x4 bzn[QF][4];
+        if (vbias_next) load_bz(bzn, kb + 64);
+        if (!PF && vbias) load_bz(bz, kb);
         f32x4 st[QF][4];
 #pragma unroll
         for (int qf = 0; qf < QF; ++qf)
@@ -470,6 +476,12 @@ __global__ __launch_bounds__(256) void attn_fwd_lds_kernel(const AttnArgs p, uin
 #pragma unroll
                 for (int qf = 0; qf < QF; ++qf) o[qf][df] = mma(fv, fp[qf], o[qf][df]);
             }
+        }
+        if (vbias_next) {
+#pragma unroll
+            for (int qf = 0; qf < QF; ++qf)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) bz[qf][f] = bzn[qf][f];
         }
     }
     if (!active) return;
@@ -667,12 +679,23 @@ extern "C" int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void
     static const int use_lds = [] { const char* e = getenv("PK_ATTN_LDS"); return e ? atoi(e) : 1; }();   // tuning knob
     if (dtype == 1 && use_lds && nnull + n_kv >= 64 && nq >= 64 &&
         (size_t)S * h * nk_pad * 128 < 0xFFFFFFF0ull) {
-        const int qf = nq >= 128 ? 2 : 1;
+        // measured on maskgit self-attention (S*h = 128, n = 576, bias): 16 query rows per wave + bias prefetch 41.2 us,
+        // 32 rows per wave 44.5 us (its prefetch spills: 77 us); with a single key tile (n = 64) there is nothing to
+        // prefetch and the leaner kernel (5 waves/SIMD) wins, 8.1 vs 11.3 us
+        static const int lds_qf = [] { const char* e = getenv("PK_ATTN_LDS_QF"); return e ? atoi(e) : 1; }();   // tuning knobs
+        static const int pf_env = [] { const char* e = getenv("PK_ATTN_PF"); return e ? atoi(e) : -1; }();
+        const int qf = lds_qf == 2 && nq >= 128 ? 2 : 1;
+        const bool pf = pf_env >= 0 ? pf_env != 0 : (qf == 1 && nk_pad >= 192);
         const int qblocks = (nq_pad + 64 * qf - 1) / (64 * qf);
         const uint32_t kv_bytes = (uint32_t)((size_t)S * h * nk_pad * 128);
         dim3 g2((unsigned)(S * h * qblocks));
-        if (qf == 2) hipLaunchKernelGGL((attn_fwd_lds_kernel<2>), g2, block, 32768, s, a, kv_bytes);
-        else hipLaunchKernelGGL((attn_fwd_lds_kernel<1>), g2, block, 32768, s, a, kv_bytes);
+        if (qf == 2) {
+            if (pf) hipLaunchKernelGGL((attn_fwd_lds_kernel<2, true>), g2, block, 32768, s, a, kv_bytes);
+            else hipLaunchKernelGGL((attn_fwd_lds_kernel<2, false>), g2, block, 32768, s, a, kv_bytes);
+        } else {
+            if (pf) hipLaunchKernelGGL((attn_fwd_lds_kernel<1, true>), g2, block, 32768, s, a, kv_bytes);
+            else hipLaunchKernelGGL((attn_fwd_lds_kernel<1, false>), g2, block, 32768, s, a, kv_bytes);
+        }
         PK_CHECK_LAUNCH();
         return PK_OK;
     }

@@ -20,82 +20,12 @@ struct GemmEpilogue {
     int vec_ok;          // N, ldc, ldr multiples of 4 and pointers 16-B aligned -> vector epilogue
 };
 
-// Vector path in two passes: bias / activation / residual LOADS for the whole wave tile first, STORES after.  On gfx950
-// stores retire through the same in-order vmcnt as loads, so a residual load issued after a store cannot be consumed
-// before that store has reached L2: the interleaved order cost +6 us on a 9216 x 512 residual GEMM (tools/gemm_trace.hip).
 template <typename T, int TM, int TN, int WN = 2>
 __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[TM][TN], int M, int N, const GemmEpilogue& e, int m0, int n0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN, g = lane >> 4, lr = lane & 15;
     float* Cf = reinterpret_cast<float*>(e.C);
     T* Ct = reinterpret_cast<T*>(e.C);
-    if (e.vec_ok) {
-        // loads are UNCONDITIONAL (indices clamped into the matrix; the null checks are wave-uniform and outside the
-        // loops): a load under a per-lane `if` gets its own basic block and s_waitcnt, serialising TM*TN load latencies
-        f32x4 out[TM][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) out[i][j] = acc[i][j];
-        if (e.bias) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * 16 * TN + j * 16 + g * 4;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(e.bias + (n < N ? n : N - 4));
-#pragma unroll
-                for (int i = 0; i < TM; ++i) out[i][j] += bv;
-            }
-        }
-        if (e.act == ACT_GEGLU) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const f32x4 v = out[i][j];
-                    out[i][j][0] = gelu_erf(v[1]) * v[0];
-                    out[i][j][1] = gelu_erf(v[3]) * v[2];
-                }
-        } else {
-            if (e.act == ACT_LEAKY) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) out[i][j][r] = out[i][j][r] > 0.f ? out[i][j][r] : 0.1f * out[i][j][r];
-            }
-            if (e.res) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int m = m0 + wm * 16 * TM + i * 16 + lr;
-                    const float* rrow = e.res + (size_t)(m < M ? m : M - 1) * e.ldr;
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const int n = n0 + wn * 16 * TN + j * 16 + g * 4;
-                        out[i][j] += *reinterpret_cast<const f32x4*>(rrow + (n < N ? n : N - 4));
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * 16 * TM + i * 16 + lr;
-            if (m >= M) continue;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * 16 * TN + j * 16 + g * 4;
-                if (n >= N) continue;
-                if (e.act == ACT_GEGLU) {
-                    const size_t o = (size_t)m * e.ldc + (n >> 1);
-                    if (e.out_f32) store2(Cf + o, out[i][j][0], out[i][j][1]); else store2(Ct + o, out[i][j][0], out[i][j][1]);
-                } else {
-                    const size_t o = (size_t)m * e.ldc + n;
-                    if (e.out_f32) store4(Cf + o, out[i][j]); else store4(Ct + o, out[i][j]);
-                }
-            }
-        }
-        return;
-    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * 16 * TM + i * 16 + lr;
@@ -104,24 +34,41 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[TM][TN], int M,
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * 16 * TN + j * 16 + g * 4;
             if (n >= N) continue;
-            const f32x4 v = acc[i][j];
-            // scalar path (N not a multiple of 4, e.g. heads = 2 or a 1-wide critic head)
-            for (int r = 0; r < 4; ++r) {
-                const int nn = n + r;
-                if (nn >= N) break;
-                float x = v[r] + (e.bias ? e.bias[nn] : 0.f);
+            f32x4 v = acc[i][j];
+            if (e.vec_ok) {
+                if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + n);
                 if (e.act == ACT_GEGLU) {
-                    if (r & 1) continue;
-                    const float gate = (nn + 1 < N) ? v[r + 1] + (e.bias ? e.bias[nn + 1] : 0.f) : 0.f;
-                    x = gelu_erf(gate) * x;
-                    const size_t o = (size_t)m * e.ldc + (nn >> 1);
-                    if (e.out_f32) Cf[o] = x; else store_elem(Ct + o, x);
-                    continue;
+                    const float o0 = gelu_erf(v[1]) * v[0], o1 = gelu_erf(v[3]) * v[2];
+                    const size_t o = (size_t)m * e.ldc + (n >> 1);
+                    if (e.out_f32) store2(Cf + o, o0, o1); else store2(Ct + o, o0, o1);
+                } else {
+                    if (e.act == ACT_LEAKY) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.1f * v[r];
+                    }
+                    if (e.res) v += *reinterpret_cast<const f32x4*>(e.res + (size_t)m * e.ldr + n);
+                    const size_t o = (size_t)m * e.ldc + n;
+                    if (e.out_f32) store4(Cf + o, v); else store4(Ct + o, v);
                 }
-                if (e.act == ACT_LEAKY) x = x > 0.f ? x : 0.1f * x;
-                if (e.res) x += e.res[(size_t)m * e.ldr + nn];
-                const size_t o = (size_t)m * e.ldc + nn;
-                if (e.out_f32) Cf[o] = x; else store_elem(Ct + o, x);
+            } else {
+                // scalar path (N not a multiple of 4, e.g. heads = 2 or a 1-wide critic head)
+                for (int r = 0; r < 4; ++r) {
+                    const int nn = n + r;
+                    if (nn >= N) break;
+                    float x = v[r] + (e.bias ? e.bias[nn] : 0.f);
+                    if (e.act == ACT_GEGLU) {
+                        if (r & 1) continue;
+                        const float gate = (nn + 1 < N) ? v[r + 1] + (e.bias ? e.bias[nn + 1] : 0.f) : 0.f;
+                        x = gelu_erf(gate) * x;
+                        const size_t o = (size_t)m * e.ldc + (nn >> 1);
+                        if (e.out_f32) Cf[o] = x; else store_elem(Ct + o, x);
+                        continue;
+                    }
+                    if (e.act == ACT_LEAKY) x = x > 0.f ? x : 0.1f * x;
+                    if (e.res) x += e.res[(size_t)m * e.ldr + nn];
+                    const size_t o = (size_t)m * e.ldc + nn;
+                    if (e.out_f32) Cf[o] = x; else store_elem(Ct + o, x);
+                }
             }
         }
     }
@@ -246,7 +193,7 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
     if (act == ACT_GEGLU && (N & 1)) return PK_EINVAL;
     if (a_rows && a_nrows <= 0) return PK_EINVAL;
     if (!a_rows) a_nrows = M;
-    // k-rotation measured +12..33 % on the 65536-wide vocab-head shape, -0..13 % on the N <= 2736 shapes (profiles/)
+    // k-rotation (gemm_dma.hpp): measured +12..33 % on the 65536-wide vocab-head shape, -0..13 % on the N <= 2736 shapes
     GemmOperands p{A, W, a_rows, lda, ldw, M, N, K, 0, N >= 8192 ? krot_default() : 0};
     GemmEpilogue e{bias, res, C, ldr, ldc, out_is_f32, act, 0};
     bool v = (N % 4 == 0) && (ldc % 4 == 0) && al16(C) && (!bias || al16(bias)) && (!res || (al16(res) && ldr % 4 == 0));

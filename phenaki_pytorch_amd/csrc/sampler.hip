@@ -208,22 +208,28 @@ __global__ __launch_bounds__(256) void vocab_reduce_kernel(const float* __restri
 __global__ __launch_bounds__(256) void topk_mask_kernel(const float* __restrict__ scores, int n, int k, long long mask_id,
                                                         unsigned char* __restrict__ mask, long long* __restrict__ ids,
                                                         int* __restrict__ rows_out) {
+    // grid (B, ceil(n / 64)): a workgroup ranks 64 positions of one batch row, 4 lanes per position each scanning a
+    // quarter of the row from LDS (B workgroups of 3 x n serial compares each took 47 us at B = 8, n = 576)
     extern __shared__ float sc[];
     const int b = blockIdx.x;
     for (int i = threadIdx.x; i < n; i += 256) sc[i] = scores[(size_t)b * n + i];
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const float v = sc[i];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) {
-            const float w = sc[j];
-            rank += (w > v || (w == v && j < i)) ? 1 : 0;
-        }
-        const bool sel = rank < k;
-        mask[(size_t)b * n + i] = sel ? 1 : 0;
-        if (sel) ids[(size_t)b * n + i] = mask_id;
-        if (sel && rows_out) rows_out[(size_t)b * k + rank] = b * n + i;     // compacted list of the masked positions
+    const int i = blockIdx.y * 64 + (threadIdx.x >> 2), part = threadIdx.x & 3;
+    const int q = (n + 3) >> 2;
+    const int j0 = part * q, j1 = j0 + q < n ? j0 + q : n;
+    const float v = i < n ? sc[i] : 0.f;
+    int rank = 0;
+    for (int j = j0; j < j1; ++j) {
+        const float w = sc[j];
+        rank += (w > v || (w == v && j < i)) ? 1 : 0;
     }
+    rank += __shfl_xor(rank, 1, 64);
+    rank += __shfl_xor(rank, 2, 64);
+    if (part != 0 || i >= n) return;
+    const bool sel = rank < k;
+    mask[(size_t)b * n + i] = sel ? 1 : 0;
+    if (sel) ids[(size_t)b * n + i] = mask_id;
+    if (sel && rows_out) rows_out[(size_t)b * k + rank] = b * n + i;         // compacted list of the masked positions
 }
 
 }  // namespace pk
@@ -300,7 +306,7 @@ extern "C" int pk_vocab_reduce(const void* partials, int M, int V, const int* ro
 extern "C" int pk_topk_mask(const float* scores, int B, int n, int k, long long mask_id, unsigned char* mask,
                             long long* ids, int* rows_out, void* stream) {
     if (!scores || !mask || !ids || B <= 0 || n <= 0 || k < 0 || n > 12288) return PK_EINVAL;
-    hipLaunchKernelGGL(topk_mask_kernel, dim3(B), dim3(256), n * sizeof(float), STREAM(stream), scores, n, k, mask_id, mask, ids, rows_out);
+    hipLaunchKernelGGL(topk_mask_kernel, dim3(B, (n + 63) / 64), dim3(256), n * sizeof(float), STREAM(stream), scores, n, k, mask_id, mask, ids, rows_out);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }
