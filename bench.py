@@ -137,6 +137,15 @@ class GemmProfiler:
         return {k: dict(launches=v[0], flops=v[1], seconds=v[2]) for k, v in by.items()}
 
 
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch of the encode leg's dominant kernel.  PMC counters need their own rocprofv3 passes (they cannot
+    be collected from inside this process), so this is the committed measurement of exactly this configuration
+    (profiles/gemm_hbm_pmc_r01.txt: mean of the 8 to_out + 8 FF2 launches of a step), or None for any other."""
+    if kernel == 'gemm_dma_kernel<pk::bf16,2,2,2,2,2,128,0>' and args.dtype == 'bf16' and args.batch == 8:
+        return 35.57e6
+    return None
+
+
 def bench_encode(cv, args, ws):
     from oracle import weights
     B = args.batch
@@ -283,7 +292,10 @@ def main():
         ach = d['flops'] / d['seconds'] / 1e12
         peak = PEAK_BF16_TFLOPS if args.dtype == 'bf16' else 157.3
         result['roofline'] = {'bound': 'mfma', 'kernel': name, 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                              'traffic': None, 'launches_per_step': d['launches'],
+                              'traffic': pmc_traffic(name, args), 'traffic_unit': 'HBM bytes per launch',
+                              'traffic_source': 'profiles/gemm_hbm_pmc_r01.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, '
+                                                'gfx950 x2 read correction); null when the run is not that configuration',
+                              'launches_per_step': d['launches'],
                               'avg_launch_us': d['seconds'] / d['launches'] * 1e6,
                               'algorithmic_flops_per_launch': d['flops'] / d['launches'],
                               'all_gemm_variants': {k: {'launches': v['launches'], 'TFLOP/s': v['flops'] / v['seconds'] / 1e12,
