@@ -165,7 +165,10 @@ static bool dma_possible(int dtype, int a_is_f32, int N, int K, int lda, int ldw
 static int auto_variant(int dtype, int a_is_f32, int M, int N, int K, int lda, int ldw, int a_nrows) {
     const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (!dma_possible(dtype, a_is_f32, N, K, lda, ldw, a_nrows)) return blocks128 >= 384 ? 2 : 1;
-    if (blocks128 >= 512 || (blocks128 >= 256 && K >= 1024)) return 24;     // 128x128, 8 waves, 2 stages (16 waves/CU)
+    // 128x128 once there are >= 256 of them (one per CU): measured in the sampling loop (M = 9216: to_out 288 tiles) +2.5 %
+    // tokens/s over a 512 threshold; at 144 tiles (M = 4608, N = 512) the 64x64 kernel wins by 9 % (same-box A/B)
+    static const long t128 = getenv("PK_GEMM_T128") ? atol(getenv("PK_GEMM_T128")) : 256;      // tuning knob
+    if (blocks128 >= t128) return 24;                                       // 128x128, 8 waves, 2 stages (16 waves/CU)
     if (K >= 2048) return dtype == 1 ? 33 : 3;      // long K (patch embed): 64x64, 3-stage ring fed by 2 producer waves (bf16) / 4 stages
     return 8;                                                               // 64x64, 2 stages (5 WG/CU)
 }
