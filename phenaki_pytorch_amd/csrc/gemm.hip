@@ -250,6 +250,8 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
             case 37: return launch_dma<bf16, 4, 4, 3, 2, 4, 128, 4>(p, e, a_nrows, s);  // 128x256, 8 consumers + 4 producers, 3 stages (144 KB)
             case 38: return launch_dma<bf16, 4, 4, 2, 2, 2, 128, 4>(p, e, a_nrows, s);  // 128x128, 4 + 4, 2 stages (64 KB: 2 WG/CU)
             case 39: return launch_dma<bf16, 2, 2, 2, 2, 2, 128, 2>(p, e, a_nrows, s);  // 64x64, 4 + 2, 2 stages (32 KB: 5 WG/CU)
+            case 40: return launch_dma<bf16, 4, 2, 2>(p, e, a_nrows, s);                 // 128x64, 4 waves, 2 stages (48 KB: 3 WG/CU)
+            case 41: return launch_dma<bf16, 2, 4, 2>(p, e, a_nrows, s);                 // 64x128, 4 waves, 2 stages (48 KB: 3 WG/CU)
             default: return PK_EINVAL;
         }
     }
