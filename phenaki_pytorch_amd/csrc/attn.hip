@@ -292,21 +292,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 }
 
 
-// LDS fragment reads of the staged tiles (see attn_fwd_lds_kernel): K tile [64 keys][128 B], 16-B slot ^ (row & 7);
-// V^T tile [64 dims][128 B = 64 keys], 16-B slot ^ ((row >> 1) & 7) which keeps the two 8-byte halves of a slot together
+// LDS fragment reads of the staged tiles (see attn_fwd_lds_kernel).
+// The keys of a 64-key tile are fed to the QK MFMAs in a PERMUTED order: row i = 4*g' + r' of 16-key block f is key
+//   kperm(f, i) = (f >> 1)*32 + g'*8 + (f & 1)*4 + r'
+// so that after S^T = K Q^T lane group g holds, for each 32-key chunk kc, the EIGHT CONSECUTIVE keys kc*32 + g*8 + 0..7
+// (blocks f = 2kc and 2kc+1, r = 0..3).  The P^T operand of the PV MFMA then pairs with 16 contiguous bytes of a V^T
+// row: ONE ds_read_b128 per fragment instead of two 8-byte pieces 32 B apart (which the compiler fused into
+// ds_read2_b64 -- 16-lane groups over 32 banks -- and which conflicted 2-way: SQ_LDS_BANK_CONFLICT was 38 % of
+// SQ_LDS_IDX_ACTIVE).  The contraction order over keys is irrelevant as long as P^T and V^T agree.
+// K tile [64 keys][128 B]: 16-B slot ^ ksw(row), ksw chosen so the permuted rows of every ds_read_b128 lane group hit
+// distinct banks; V^T tile [64 dims][128 B = 64 keys]: slot ^ (row & 7) as in the GEMM.
+__device__ __forceinline__ int attn_kperm(int f, int i) { return (f >> 1) * 32 + (i >> 2) * 8 + (f & 1) * 4 + (i & 3); }
+__device__ __forceinline__ int attn_ksw(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
 __device__ __forceinline__ void lds_frag_k(Frag<bf16>& f, const char* tile, int row, int chunk, int g) {
-    const int slot = (chunk * 4 + g) ^ (row & 7);
+    const int slot = (chunk * 4 + g) ^ attn_ksw(row);
     f.v = *reinterpret_cast<const u32x4*>(tile + row * 128 + (slot << 4));
 }
 __device__ __forceinline__ void lds_frag_vt(Frag<bf16>& f, const char* tile, int row, int kc, int g) {
-    // elements j = 0..7 <-> key_local = kc*32 + (j >> 2)*16 + g*4 + (j & 3): two 8-byte reads at 8-byte slots kc*8 + g and kc*8 + 4 + g
-    const int x = (row >> 1) & 7;
-    const int s0 = kc * 8 + g, s1 = s0 + 4;
-    const int a0 = (((s0 >> 1) ^ x) << 4) | ((s0 & 1) << 3);
-    const int a1 = (((s1 >> 1) ^ x) << 4) | ((s1 & 1) << 3);
-    const u32x2 a = *reinterpret_cast<const u32x2*>(tile + row * 128 + a0);
-    const u32x2 b = *reinterpret_cast<const u32x2*>(tile + row * 128 + a1);
-    f.v = u32x4{a[0], a[1], b[0], b[1]};
+    const int slot = (kc * 4 + g) ^ (row & 7);              // keys kc*32 + g*8 + 0..7 of head dim `row`
+    f.v = *reinterpret_cast<const u32x4*>(tile + row * 128 + (slot << 4));
 }
 
 // ---- LDS-staged variant (bf16): one workgroup = 4 waves = 64*QF query rows of ONE (sequence, head).  K and V^T tiles of
@@ -338,8 +342,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = (wave * 2 + i) * 8 + prow;                        // 0..63
-        offK[i] = ((uint32_t)sh * p.nk_pad + row) * 128u + (uint32_t)((pslot ^ (row & 7)) * 16);
-        offV[i] = ((uint32_t)sh * 64u + row) * (uint32_t)p.nk_pad * 2u + (uint32_t)((pslot ^ ((row >> 1) & 7)) * 16);
+        offK[i] = ((uint32_t)sh * p.nk_pad + row) * 128u + (uint32_t)((pslot ^ attn_ksw(row)) * 16);
+        offV[i] = ((uint32_t)sh * 64u + row) * (uint32_t)p.nk_pad * 2u + (uint32_t)((pslot ^ (row & 7)) * 16);
     }
     auto issue = [&](int kb, int stage) {
         char* base = smem + stage * STAGE;
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
         for (int qf = 0; qf < QF; ++qf)
 #pragma unroll
             for (int f = 0; f < 4; ++f)
-                b[qf][f] = *reinterpret_cast<const f32x4*>(bias + (size_t)qrow[qf] * p.bias_ld + kb + f * 16 + g * 4);
+                b[qf][f] = *reinterpret_cast<const f32x4*>(bias + (size_t)qrow[qf] * p.bias_ld + kb + attn_kperm(f, g * 4));
     };
     f32x4 bz[QF][4];
     if (PF && active && vb_all && 64 <= nk) load_bz(bz, 0);
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 Frag<bf16> fk;
-                lds_frag_k(fk, kt, f * 16 + lr, c, g);
+                lds_frag_k(fk, kt, attn_kperm(f, lr), c, g);
 #pragma unroll
                 for (int qf = 0; qf < QF; ++qf) st[qf][f] = mma(fk, fq[qf][c], st[qf][f]);
             }
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
                 for (int r = 0; r < 4; ++r) {
                     float sv = st[qf][f][r];
                     if (!plain) {
-                        const int key = kb + f * 16 + g * 4 + r;
+                        const int key = kb + attn_kperm(f, g * 4 + r);
                         const int j = key - p.nnull;
                         if (key >= nk) sv = -INFINITY;
                         else {
