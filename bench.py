@@ -229,6 +229,30 @@ def bench_sample(ph, args, ws):
     return out
 
 
+def bench_objective(ph, args, ws):
+    """SURVEY.md 8f row 1, first slice: Phenaki.forward -- the VALUE of the training objective (masked cross entropy without
+    logits + token-critic BCE) on B videos' worth of token ids; videos/sec.  Reported beside the two headline legs."""
+    from oracle import weights
+    B = args.sample_batch
+    ctx = weights.synthetic_context(B, 12, 768, seed=1).cuda()
+    g = torch.Generator(device='cpu')
+    g.manual_seed(4)
+    ids = torch.randint(0, 65536, (B, 9, 8, 8), generator=g).cuda()
+    torch.manual_seed(0)
+    ph(video_codebook_ids=ids, text_embeds=ctx)                 # warm-up
+    barrier_sync(ws)
+    runs = 5
+    t0 = time.perf_counter()
+    for _ in range(runs):
+        loss = ph(video_codebook_ids=ids, text_embeds=ctx)
+    barrier_sync(ws)
+    dt = max_over_ranks(time.perf_counter() - t0, ws) / runs
+    return dict(metric='phenaki_forward_objective_videos_per_sec', value=B * ws / dt, unit='videos/s', ms_per_call=dt * 1e3,
+                batch_per_gpu=B, tokens_per_video=576, loss=float(loss),
+                note='forward value only (no autograd graph): MaskGit trunk + vocab head with fused gumbel sampling and '
+                     'cross entropy (logits never written) + TokenCritic trunk + BCE; random-init weights, random ids')
+
+
 def cpu_baseline(args):
     """the CPU oracle (port of the reference algorithm) on a bounded sample: B = 2 videos per call, repeated for
     ~cpu_seconds; frames/sec on this box's host cores."""
@@ -303,6 +327,7 @@ def main():
                                                         'us_total': v['seconds'] * 1e6} for k, v in gemms.items()}}
     if not args.no_sample:
         result['sample'] = bench_sample(ph, args, ws)
+        result['objective'] = bench_objective(ph, args, ws)
     if rank == 0 and ws == 1 and not args.no_cpu:
         result['cpu_baseline'] = cpu_baseline(args)
     if rank == 0:

@@ -139,6 +139,12 @@ int pk_vocab_sample(int dtype, const void* A, int lda, const void* W, int ldw, c
 int pk_vocab_reduce(const void* partials, int M, int V, const int* rows, const unsigned char* mask, long long* ids,
                     long long* pred, float* scores, int need_lse, void* stream);
 
+/* The masked-token cross entropy of phenaki_pytorch.py:640-643 without the logits: after a pk_vocab_sample call with
+ * need_lse bit 0 set, loss[m] = logsumexp_v(logits[m][:]) - logits[m][targets[r]] with r = rows ? rows[m] : m, where the
+ * target logit is the dot product of row m of A with row targets[r] of W (+ bias) -- same A / W / bias as that call. */
+int pk_vocab_ce(int dtype, const void* partials, int M, int V, const void* A, int lda, const void* W, int ldw,
+                const float* bias, int D, const long long* targets, const int* rows, float* loss, void* stream);
+
 /* phenaki_pytorch.py:488-491: mask = zeros.scatter(1, scores.topk(k).indices, 1).bool(); ids = where(mask, mask_id, ids).
  * rows_out (B*k int32, or NULL) receives the flat positions b*n + i of the masked tokens: only those rows need the vocab
  * head in this step (pk_cfg_mix / pk_vocab_sample / pk_vocab_reduce take it as `rows`). */

@@ -179,6 +179,59 @@ def sample_golden(R, cfgs, batch, frames_list, prime_len, ctx_len, tag, keep_log
     print(f'sample_{tag}: {len(rec.steps)} step records, {dt:.1f}s')
 
 
+def forward_golden(R, cfgs, batch, frames, ctx_len, tag):
+    """Phenaki.forward (the training objective, value only) of the real reference with its three random draws replaced
+    by deterministic ones (torch.randint / torch.rand patched for the duration of the call, gumbel_noise as in the
+    sampler goldens), so the oracle and the HIP path can be fed the same draws."""
+    cv, mg, cr, ph = build_reference(R, cfgs, with_phenaki=True, with_critic=True)
+    m = R.module
+    H = cfgs['cvivit']['image_size']
+    video = weights.synthetic_video(batch, frames, H, H, seed=5)
+    ctx = weights.synthetic_context(batch, ctx_len, cfgs['maskgit']['dim_context'], seed=3, pad_last=2)
+    steps = cfgs['steps']
+    rand_step = (torch.arange(batch) * 2 + 1) % steps
+    rec = {}
+    orig = (torch.randint, torch.rand, m.gumbel_noise, m.gumbel_sample)
+
+    def randint(low, high, size, **kw):
+        assert (low, high, tuple(size)) == (0, steps, (batch,))
+        return rand_step.clone()
+
+    pt = cfgs['cvivit']['temporal_patch_size']
+    hw = H // cfgs['cvivit']['patch_size']
+    n = (1 + (frames - 1) // pt) * hw * hw
+    perm_noise = weights.uniform_noise((batch, n), 700)                 # drawn BEFORE torch.rand is patched
+    gumbel_u = weights.uniform_noise((batch, n, cfgs['maskgit']['num_tokens']), 701)
+
+    def rand(size, **kw):
+        assert tuple(size) == (batch, n)
+        return perm_noise.clone()
+
+    def gumbel_noise(t):
+        assert tuple(t.shape) == tuple(gumbel_u.shape)
+        return -m.log(-m.log(gumbel_u))
+
+    def gumbel_sample(t, temperature=1., dim=-1):
+        out = orig[3](t, temperature=temperature, dim=dim)
+        rec['pred'] = out.clone()
+        return out
+
+    torch.randint, torch.rand, m.gumbel_noise, m.gumbel_sample = randint, rand, gumbel_noise, gumbel_sample
+    try:
+        with torch.no_grad():
+            ids = cv(video, return_only_codebook_ids=True)
+            total = ph(video, text_embeds=ctx)
+            gen = ph(video_codebook_ids=ids, text_embeds=ctx, only_train_generator=True)
+            crit = ph(video_codebook_ids=ids, text_embeds=ctx, only_train_critic=True)
+    finally:
+        torch.randint, torch.rand, m.gumbel_noise, m.gumbel_sample = orig
+    out = dict(ids=ids, loss=total, loss_generator=gen, loss_critic=crit, pred=rec['pred'], rand_step=rand_step,
+               batch=batch, frames=frames, ctx_len=ctx_len, critic_loss_weight=ph.critic_loss_weight,
+               critic_temperature=ph.critic_train_sample_temperature)
+    torch.save(out, os.path.join(OUT, f'forward_{tag}.pt'))
+    print(f'forward_{tag}: loss {float(total):.6f} = generator {float(gen):.6f} + w * critic {float(crit):.6f}')
+
+
 def keys_golden(R):
     """state_dict contract: every key, shape and dtype of the reference modules."""
     import json
@@ -206,6 +259,8 @@ def main():
         sample_golden(R, TINY, batch=2, frames_list=[5], prime_len=0, ctx_len=6, tag='tiny_nocritic', keep_logits=True,
                       with_critic=False)
         sample_golden(R, TINY, batch=1, frames_list=[5, 4], prime_len=3, ctx_len=5, tag='tiny_primed', keep_logits=True)
+    if 'tiny' in which or 'forward' in which:
+        forward_golden(R, TINY, batch=3, frames=5, ctx_len=6, tag='tiny')
     if 'full' in which:
         cvivit_golden(R, FULL, batch=2, frames=17, tag='full', subsample=True)
         maskgit_golden(R, FULL, batch=1, frames=17, ctx_len=12, tag='full', col_stride=512)

@@ -400,3 +400,50 @@ def sample(cv, cv_cfg, mg, mg_cfg, cr, cr_cfg, *, num_frames, batch_size, contex
     if prime_frames is not None:
         video = video[:, :, prime_frames_n:]
     return video, ids
+
+
+# --------------------------------------------------------------------------- training objective (value only)
+
+def mask_subset_with_prob(mask, prob, perm_noise):
+    """phenaki_pytorch.py:43-55 with the U[0,1) draw of its torch.rand injected as ``perm_noise`` (batch, seq)."""
+    b, n = mask.shape
+    num_tokens = mask.sum(dim=-1)
+    num_pads = n - num_tokens
+    num_masked = (prob * num_tokens).round().clamp(min=1)
+    idx = perm_noise.argsort(dim=-1)
+    idx = idx - num_pads[:, None]
+    idx = idx.masked_fill(idx < 0, n)
+    return idx < num_masked[:, None]
+
+
+def phenaki_forward_loss(mg, mg_cfg, cr, cr_cfg, ids, *, patch_shape, context, steps, rand_step, perm_noise, gumbel_u,
+                         mask_id, critic_loss_weight=1., critic_temperature=1., video_mask=None,
+                         only_train_generator=False, only_train_critic=False):
+    """Phenaki.forward (phenaki_pytorch.py:562-687), forward value only, with its three random draws injected:
+    rand_step = torch.randint(0, steps, (b,)) (:620), perm_noise = the torch.rand of get_mask_subset_with_prob (:626),
+    gumbel_u = the uniform noise of gumbel_sample (:653).  cond_drop_prob is 0 on this path (the reference shadows
+    the argument with `cond_drop_prob = 0` at :594 before the default() at :606)."""
+    import torch.nn.functional as F
+    b, n = ids.shape
+    text_mask = torch.any(context != 0, dim=-1) if context is not None else None              # :601
+    mask_token_prob = torch.cos(rand_step * math.pi * 0.5 / steps)                              # :621
+    vm = video_mask if video_mask is not None else torch.ones((b, n), dtype=torch.bool)
+    mask_token_mask = mask_subset_with_prob(vm, mask_token_prob, perm_noise)
+    masked_input = torch.where(mask_token_mask, mask_id, ids)
+    logits = maskgit_forward(mg, mg_cfg, masked_input, video_patch_shape=patch_shape, context=context,
+                             text_mask=text_mask, video_mask=video_mask)
+    out = dict(mask=mask_token_mask, logits=logits)
+    ce = F.cross_entropy(logits[mask_token_mask], ids[mask_token_mask])                          # :640-643
+    out['ce'] = ce
+    if cr is None or only_train_generator:
+        out['loss'] = ce
+        return out
+    pred = gumbel_argmax(logits, critic_temperature, gumbel_u)                                    # :653
+    critic_input = torch.where(mask_token_mask, pred, ids)
+    crit = critic_forward(cr, cr_cfg, critic_input, video_patch_shape=patch_shape, context=context,
+                          text_mask=text_mask, video_mask=video_mask)
+    labels = (ids != pred).float()
+    critic_loss = F.binary_cross_entropy_with_logits(crit, labels)                                # :673-676
+    out.update(pred=pred, critic_logits=crit, critic_loss=critic_loss)
+    out['loss'] = critic_loss if only_train_critic else ce + critic_loss * critic_loss_weight
+    return out

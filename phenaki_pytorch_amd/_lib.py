@@ -43,6 +43,7 @@ SIGNATURES = {
     'pk_vocab_ntiles': [_I],
     'pk_vocab_sample': [_I, _P, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P, _ULL, _I, _P, _P],
     'pk_vocab_reduce': [_P, _I, _I, _P, _P, _P, _P, _P, _I, _P],
+    'pk_vocab_ce': [_I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P],
     'pk_topk_mask': [_P, _I, _I, _I, _LL, _P, _P, _P, _P],
     'pk_critic_head': [_P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P, _F, _P, _P],
 }
@@ -224,6 +225,13 @@ def vocab_reduce(partials, M, V, rows, mask, ids, pred, scores, need_lse):
     rc = load().pk_vocab_reduce(ptr(partials), M, V, ptr(rows), ptr(mask), ptr(ids), ptr(pred), ptr(scores),
                                 1 if need_lse else 0, stream())
     _check(rc, 'pk_vocab_reduce')
+
+
+def vocab_ce(dtype, partials, M, V, A, W, bias, D, targets, rows, loss):
+    """loss[m] = lse(logits[m]) - logits[m][targets[rows[m]]] from the partials of vocab_sample(..., need_lse=True)."""
+    rc = load().pk_vocab_ce(dtype, ptr(partials), M, V, ptr(A), A.stride(-2), ptr(W), W.stride(0), ptr(bias), D,
+                            ptr(targets), ptr(rows), ptr(loss), stream())
+    _check(rc, 'pk_vocab_ce')
 
 
 def topk_mask(scores, B, n, k, mask_id, mask, ids, rows_out=None):

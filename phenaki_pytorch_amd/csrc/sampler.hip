@@ -204,6 +204,36 @@ __global__ __launch_bounds__(256) void vocab_reduce_kernel(const float* __restri
     if (scores && need_lse) scores[r] = mk ? 1.0f - __expf(blog - lmax) / lsum : -1e4f;
 }
 
+// cross entropy of the vocab head WITHOUT the logits (the masked-token objective, phenaki_pytorch.py:640-643): one wave per
+// row folds the (max, sum exp) partials pk_vocab_sample left per 128-column tile into lse, and takes the target logit as
+// the dot product of the row with ONE row of W (+ bias): loss[m] = lse - logit[target]
+template <typename T>
+__global__ __launch_bounds__(256) void vocab_ce_kernel(const float* __restrict__ p_max, const float* __restrict__ p_sum, int ntiles, int M,
+                                                       const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
+                                                       const float* __restrict__ bias, int D, const long long* __restrict__ targets,
+                                                       const int* __restrict__ rows, float* __restrict__ loss) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    float lmax = -INFINITY, lsum = 0.f;
+    for (int t = lane; t < ntiles; t += 64) {
+        const size_t o = (size_t)t * M + m;
+        const float om = p_max[o], os = p_sum[o];
+        const float nm = fmaxf(lmax, om);
+        lsum = (lmax == -INFINITY ? 0.f : lsum * __expf(lmax - nm)) + (om == -INFINITY ? 0.f : os * __expf(om - nm));
+        lmax = nm;
+    }
+    const float gmax = wave_max(lmax);
+    const float gsum = wave_sum(lmax == -INFINITY ? 0.f : lsum * __expf(lmax - gmax));
+    const long long tgt = targets[rows ? rows[m] : m];
+    const T* a = A + (size_t)m * lda;
+    const T* w = W + (size_t)tgt * ldw;
+    float dot = 0.f;
+    for (int c = lane; c < D; c += 64) dot += load_elem(a + c) * load_elem(w + c);
+    dot = wave_sum(dot);
+    if (lane == 0) loss[m] = (gmax + logf(gsum)) - (dot + bias[tgt]);
+}
+
 // mask = top-k of scores per row (ties: lower index first), ids = where(mask, mask_id, ids)
 __global__ __launch_bounds__(256) void topk_mask_kernel(const float* __restrict__ scores, int n, int k, long long mask_id,
                                                         unsigned char* __restrict__ mask, long long* __restrict__ ids,
@@ -299,6 +329,25 @@ extern "C" int pk_vocab_reduce(const void* partials, int M, int V, const int* ro
     hipLaunchKernelGGL(vocab_reduce_kernel, dim3((M + 31) / 32), dim3(256), 0, STREAM(stream),
                        f, reinterpret_cast<const int*>(partials) + sz, f + 2 * sz, f + 3 * sz, f + 4 * sz, ntiles, M,
                        rows, mask, ids, pred, scores, need_lse);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+// loss[m] = logsumexp_v(logits[m][v]) - logits[m][targets[r]], r = rows ? rows[m] : m, from the partials of a pk_vocab_sample
+// call made with need_lse bit 0 set on the SAME A / W / bias (phenaki_pytorch.py:640-643 F.cross_entropy, reduction left to
+// the caller).  targets must be < V.
+extern "C" int pk_vocab_ce(int dtype, const void* partials, int M, int V, const void* A, int lda, const void* W, int ldw,
+                           const float* bias, int D, const long long* targets, const int* rows, float* loss, void* stream) {
+    if (!partials || !A || !W || !bias || !targets || !loss || M <= 0 || V <= 0 || D <= 0) return PK_EINVAL;
+    if (dtype != 0 && dtype != 1) return PK_EINVAL;
+    const int ntiles = pk_vocab_ntiles(V);
+    const size_t sz = (size_t)ntiles * M;
+    const float* f = reinterpret_cast<const float*>(partials);
+    const dim3 grid((M + 3) / 4);
+    if (dtype == 1) hipLaunchKernelGGL((vocab_ce_kernel<bf16>), grid, dim3(256), 0, STREAM(stream), f + 3 * sz, f + 4 * sz, ntiles, M,
+                                       reinterpret_cast<const bf16*>(A), lda, reinterpret_cast<const bf16*>(W), ldw, bias, D, targets, rows, loss);
+    else hipLaunchKernelGGL((vocab_ce_kernel<float>), grid, dim3(256), 0, STREAM(stream), f + 3 * sz, f + 4 * sz, ntiles, M,
+                            reinterpret_cast<const float*>(A), lda, reinterpret_cast<const float*>(W), ldw, bias, D, targets, rows, loss);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

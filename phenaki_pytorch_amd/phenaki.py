@@ -7,7 +7,8 @@ What changes relative to the reference's op sequence (results are the same up to
   * the sampler never materialises logits: gumbel-argmax / softmax confidence live in the GEMM epilogue;
   * cross-attention K/V of the (step-invariant) text context and the position bias are computed once per sample();
   * the mask schedule k_s is data independent and precomputed on the host (no per-step .item() sync).
-`Phenaki.forward` (the training loss, phenaki_pytorch.py:562-687) is outside this inference build.
+`Phenaki.forward` (phenaki_pytorch.py:562-687) returns the VALUE of the training objective (no autograd graph): masked-token
+cross entropy without logits (pk_vocab_sample statistics + pk_vocab_ce) + the token-critic BCE.
 """
 import math
 from functools import partial
@@ -322,9 +323,95 @@ class Phenaki(nn.Module):
                             noise_K=noise_K)
         return video.squeeze(2)
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError('Phenaki.forward (the training loss, phenaki_pytorch.py:562-687) is outside the MI355X '
-                                  'inference build; .sample / .sample_images / make_video are the supported surfaces')
+    @torch.no_grad()
+    def forward(self, videos=None, *, texts=None, video_codebook_ids=None, video_frame_mask=None, text_embeds=None,
+                cond_drop_prob=None, only_train_generator=False, only_train_critic=False, _draws=None):
+        """phenaki_pytorch.py:562-687 -- the VALUE of the training objective (masked-token cross entropy + weighted
+        token-critic BCE).  Forward only: the result carries no autograd graph (the backward kernels are SURVEY.md 8f
+        "next").  The 65 536-way logits are never written: pk_vocab_sample draws the critic's input ids and leaves the
+        softmax statistics, pk_vocab_ce turns them into per-row losses.  As in the reference, `cond_drop_prob` has no
+        effect on this path (it is shadowed by `cond_drop_prob = 0` at :594).
+        _draws (tests): dict(rand_step (b,), perm_noise (b,n) U[0,1), gumbel_u (b,n,V) U[0,1)) replaces the three
+        random draws of the reference (:620, :626 -> :43-55, :653)."""
+        assert not (only_train_generator and only_train_critic)
+        assert exists(videos) ^ exists(video_codebook_ids), 'either raw video or video codebook ids must be given'
+        assert not (exists(videos) and not exists(self.cvivit)), 'cvivit must be provided if one wants to encode the videos live during training'
+        assert (exists(text_embeds) ^ exists(texts)) ^ self.unconditional, \
+            'either raw text of text embeds must be given, and if unconditional, none should be given'
+        assert not (exists(text_embeds) and text_embeds.shape[-1] != self.text_embed_dim), 'text embedding dimension is not correct'
+        mg, critic = self.maskgit, self.critic
+        if not exists(video_codebook_ids):
+            assert videos.ndim in {4, 5}
+            if videos.ndim == 4:
+                videos = videos.unsqueeze(2)
+            video_codebook_ids = self.cvivit(videos, return_only_codebook_ids=True)
+        L.require_device(video_codebook_ids, 'video_codebook_ids')
+        assert video_codebook_ids.ndim == 4, 'video codebook ids must be (batch, frames, height, width): MaskGit takes the patch shape from it'
+        device = video_codebook_ids.device
+        patch_shape = tuple(video_codebook_ids.shape[1:])
+
+        text_mask = None
+        if not self.unconditional:
+            if not exists(text_embeds):
+                text_embeds = self.encode_texts(texts, output_device=device)
+            text_embeds = text_embeds.to(device).float()
+            text_mask = torch.any(text_embeds != 0, dim=-1)
+
+        video_mask = None
+        if exists(video_frame_mask):
+            video_mask = self.cvivit.calculate_video_token_mask(videos, video_frame_mask=video_frame_mask)
+
+        ids = video_codebook_ids.reshape(video_codebook_ids.shape[0], -1).long().contiguous()
+        b, n = ids.shape
+        draws = _draws or {}
+        rand_step = draws['rand_step'].to(device) if 'rand_step' in draws else torch.randint(0, self.steps, (b,), device=device)
+        mask_token_prob = torch.cos(rand_step * math.pi * 0.5 / self.steps)
+        vm = video_mask if exists(video_mask) else torch.ones((b, n), device=device, dtype=torch.bool)
+        # get_mask_subset_with_prob (phenaki_pytorch.py:43-55)
+        num_tokens = vm.sum(dim=-1)
+        num_masked = (mask_token_prob * num_tokens).round().clamp(min=1)
+        perm_noise = draws['perm_noise'].to(device) if 'perm_noise' in draws else torch.rand((b, n), device=device)
+        perm = perm_noise.argsort(dim=-1) - (n - num_tokens)[:, None]
+        perm = perm.masked_fill(perm < 0, n)
+        mask_token_mask = perm < num_masked[:, None]
+        masked_input = torch.where(mask_token_mask, self.mask_id, ids)
+
+        dt = compute_dtype_of(mg)
+        D, V = mg.dim, mg.to_logits.weight.shape[0]
+        e = mg.embeds(masked_input, video_patch_shape=patch_shape, context=text_embeds, text_mask=text_mask, video_mask=video_mask)
+        # rows of the vocab head: the critic's labels compare the ids with the gumbel-sampled prediction at EVERY position
+        # (phenaki_pytorch.py:653,671), so with a critic the head runs on all b*n rows; the generator-only objective needs
+        # the masked rows only (>= 1 per sample, clamp(min=1) above)
+        need_critic = exists(critic) and not only_train_generator
+        flat_mask = mask_token_mask.reshape(-1)
+        rows = None if need_critic else flat_mask.nonzero().reshape(-1).int()
+        M = b * n if need_critic else rows.numel()
+        mixed = torch.empty((M, D), device=device, dtype=L.tdtype(dt))
+        L.cfg_mix(e, b, n, 0, rows, M, 1.0, False, mixed, D)                    # (gather the rows,) cast to T
+        w_logits = linear_weight(mg.to_logits, dt)
+        partials = torch.empty((5 * L.vocab_ntiles(V) * M,), device=device, dtype=torch.float32)
+        U = draws['gumbel_u'].to(device).float().contiguous() if 'gumbel_u' in draws else None
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if U is None else 0
+        L.vocab_sample(dt, mixed, w_logits, mg.to_logits.bias, M, V, D, float(self.critic_train_sample_temperature), U, rows,
+                       seed, True, partials)
+        loss = None
+        if not only_train_critic:
+            loss_rows = torch.empty((M,), device=device, dtype=torch.float32)
+            L.vocab_ce(dt, partials, M, V, mixed, w_logits, mg.to_logits.bias, D, ids.reshape(-1), rows, loss_rows)
+            loss = (loss_rows[flat_mask] if need_critic else loss_rows).mean()
+        if not need_critic:
+            return loss
+        pred = torch.empty((b * n,), device=device, dtype=torch.long)
+        L.vocab_reduce(partials, M, V, None, None, None, pred, None, False)
+        pred = pred.view(b, n)
+        critic_input = torch.where(mask_token_mask, pred, ids)
+        crit = critic(critic_input.view(b, *patch_shape), video_mask=video_mask, cond_drop_prob=0., text_mask=text_mask,
+                      context=text_embeds)
+        labels = (ids != pred).float()
+        critic_loss = torch.nn.functional.binary_cross_entropy_with_logits(crit.reshape(b, n), labels)
+        if only_train_critic:
+            return critic_loss
+        return loss + critic_loss * self.critic_loss_weight
 
     @eval_decorator
     @torch.no_grad()

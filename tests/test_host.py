@@ -121,8 +121,15 @@ def test_phenaki_constructor_contract():
         mg(torch.zeros(1, 3, dtype=torch.long))                     # video patch shape must be given
     with pytest.raises(AssertionError):
         mg(torch.zeros(1, 500, dtype=torch.long), video_patch_shape=(5, 10, 10))   # n > max_seq_len
-    with pytest.raises(NotImplementedError):
-        ph(torch.zeros(1))
+    # Phenaki.forward keeps the reference's argument asserts (phenaki_pytorch.py:574-579) and never falls back to the CPU
+    with pytest.raises(AssertionError):
+        ph(torch.zeros(1, 3, 5, 64, 64), video_codebook_ids=torch.zeros(1, 3, 4, 4, dtype=torch.long), texts=['a'])
+    with pytest.raises(AssertionError):
+        ph(video_codebook_ids=torch.zeros(1, 3, 4, 4, dtype=torch.long))            # neither texts nor text_embeds
+    with pytest.raises(AssertionError):
+        ph(video_codebook_ids=torch.zeros(1, 3, 4, 4, dtype=torch.long), text_embeds=torch.zeros(1, 4, 5))   # wrong text dim
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ph(video_codebook_ids=torch.zeros(1, 3, 4, 4, dtype=torch.long), text_embeds=torch.zeros(1, 4, 768))
 
 
 def test_shard_batch_partitions():

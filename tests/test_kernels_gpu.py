@@ -410,6 +410,34 @@ def test_vocab_sample_parity_mode(L, mode, M, V, D):
     close(scores.cpu()[same], exp_scores[same], 1e-4, 'confidence scores')
 
 
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('M,V,D,with_rows', [(130, 512, 128, False), (77, 1000, 96, True), (300, 65536, 512, True)])
+def test_vocab_ce_matches_cross_entropy(L, mode, M, V, D, with_rows):
+    """pk_vocab_sample(need_lse) + pk_vocab_ce == F.cross_entropy(reduction='none') of the never-written logits, with and
+    without the row indirection (targets live in the full (B*n) array), V tails that do not fill the last 128-wide tile."""
+    e = torch.randn(M, D, generator=g(50))
+    W = torch.randn(V, D, generator=g(51)) / math.sqrt(D) * 3
+    b = torch.randn(V, generator=g(52)) * 0.1
+    dt = L.F32 if mode == 'f32' else L.BF16
+    td = L.tdtype(dt)
+    cast = (lambda t: t) if mode == 'f32' else bf
+    logits = cast(e) @ cast(W).t() + b
+    total = 2 * M + 5
+    rows = torch.randperm(total, generator=g(53))[:M].int() if with_rows else None
+    targets_full = torch.randint(0, V, (total,), generator=g(54))
+    tg = targets_full[rows.long()] if with_rows else targets_full[:M]
+    ref = F.cross_entropy(logits, tg, reduction='none')
+    q = 64 if mode == 'bf16' else 32
+    Wp = torch.zeros(V, (D + q - 1) // q * q)
+    Wp[:, :D] = W
+    partials = torch.empty(5 * L.vocab_ntiles(V) * M, device='cuda')
+    A, Wd = e.cuda().to(td), Wp.cuda().to(td)
+    L.vocab_sample(dt, A, Wd, b.cuda(), M, V, D, 1.0, None, rows.cuda() if with_rows else None, 7, True, partials)
+    loss = torch.full((M,), float('nan'), device='cuda')
+    L.vocab_ce(dt, partials, M, V, A, Wd, b.cuda(), D, targets_full.cuda(), rows.cuda() if with_rows else None, loss)
+    close(loss, ref, 2e-5 if mode == 'f32' else 2e-3, f'vocab_ce {mode} V={V}')
+
+
 def test_vocab_sample_fast_mode_matches_its_numpy_twin(L):
     M, V, D = 130, 512, 128
     e = torch.randn(M, D, generator=g(46))

@@ -315,3 +315,60 @@ def test_sample_full_free_running_matches_reference_golden(golden_dir):
     assert matched >= 6
     if matched == 18:
         close(video[:, :, ::4, ::8, ::8], g['videos_sub'][0], 1e-3, 'sampled pixels')
+
+
+@pytest.mark.parametrize('dtype,tol', [('fp32', 2e-4), ('bf16', 3e-2)])
+def test_forward_objective_tiny_matches_reference_golden(golden_dir, dtype, tol):
+    """Phenaki.forward (the training objective, value only) against the REAL reference's losses with the reference's
+    three random draws injected: total, generator-only and critic-only; in f32 the gumbel-sampled critic inputs
+    (hence the critic labels) are the reference's own."""
+    g = torch.load(os.path.join(golden_dir, 'forward_tiny.pt'), weights_only=False)
+    cv, mg, cr, ph = load_product('tiny', TINY, dtype=dtype)
+    batch, frames = g['batch'], g['frames']
+    H = TINY['cvivit']['image_size']
+    video = weights.synthetic_video(batch, frames, H, H, seed=5).cuda()
+    ctx = weights.synthetic_context(batch, g['ctx_len'], TINY['maskgit']['dim_context'], seed=3, pad_last=2).cuda()
+    own_ids = cv(video, return_only_codebook_ids=True).cpu()
+    same_ids = torch.equal(own_ids, g['ids'])
+    if dtype == 'fp32':
+        assert (own_ids == g['ids']).float().mean().item() >= 0.99      # LFQ sign bits: audited by margin in the C-ViViT tests
+    ids = g['ids'].cuda()                                      # teacher-forced: the reference's own token ids
+    n = ids[0].numel()
+    draws = dict(rand_step=g['rand_step'], perm_noise=weights.uniform_noise((batch, n), 700),
+                 gumbel_u=weights.uniform_noise((batch, n, TINY['maskgit']['num_tokens']), 701))
+    total = ph(video_codebook_ids=ids, text_embeds=ctx, _draws=draws)
+    gen = ph(video_codebook_ids=ids, text_embeds=ctx, only_train_generator=True, _draws=draws)
+    crit = ph(video_codebook_ids=ids, text_embeds=ctx, only_train_critic=True, _draws=draws)
+    for name, got, ref in (('total', total, g['loss']), ('generator', gen, g['loss_generator']), ('critic', crit, g['loss_critic'])):
+        assert abs(float(got) - float(ref)) <= tol * abs(float(ref)), f'{name}: {float(got)} vs reference {float(ref)}'
+    if dtype == 'fp32' and same_ids:
+        via_video = ph(video, text_embeds=ctx, _draws=draws)   # encodes the video live, as the reference call did
+        assert abs(float(via_video) - float(g['loss'])) <= tol * abs(float(g['loss']))
+    # FAST mode (in-kernel noise, device RNG for the masking draws): runs, finite, seeded
+    torch.manual_seed(11)
+    a = ph(video_codebook_ids=ids, texts=None, text_embeds=ctx)
+    torch.manual_seed(11)
+    b2 = ph(video_codebook_ids=ids, texts=None, text_embeds=ctx)
+    assert torch.isfinite(a) and float(a) == float(b2)
+
+
+@pytest.mark.parametrize('dtype,tol', [('fp32', 1e-3), ('bf16', 3e-2)])
+def test_forward_objective_full_config_matches_oracle(dtype, tol):
+    """BASELINE geometry (dim 512, depth 6 + 6, vocab 65 536, n = 576): Phenaki.forward against the CPU oracle with the
+    same three draws -- the cross entropy comes from the fused vocab head (the (1,576,65536) logits are never written)."""
+    _, mg_sd, cr_sd = state_dicts('full')
+    _, mgc, crc = oracle_cfgs(FULL)
+    _, _, _, ph = load_product('full', FULL, dtype=dtype)
+    gen = torch.Generator().manual_seed(78)
+    ids = torch.randint(0, 65536, (1, 576), generator=gen)
+    ctx = weights.synthetic_context(1, 12, 768, seed=1, pad_last=3)
+    draws = dict(rand_step=torch.tensor([7]), perm_noise=weights.uniform_noise((1, 576), 710),
+                 gumbel_u=weights.uniform_noise((1, 576, 65536), 711))
+    ref = O.phenaki_forward_loss(mg_sd, mgc, cr_sd, crc, ids, patch_shape=(9, 8, 8), context=ctx, steps=FULL['steps'],
+                                 mask_id=65536, **draws)
+    kw = dict(video_codebook_ids=ids.view(1, 9, 8, 8).cuda(), text_embeds=ctx.cuda(), _draws=draws)
+    gen_loss = ph(only_train_generator=True, **kw)
+    assert abs(float(gen_loss) - float(ref['ce'])) <= tol * float(ref['ce']), (float(gen_loss), float(ref['ce']))
+    total = ph(**kw)
+    assert abs(float(total) - float(ref['loss'])) <= tol * float(ref['loss']), (float(total), float(ref['loss']))
+

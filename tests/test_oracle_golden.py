@@ -148,3 +148,30 @@ def test_sample_full_matches_reference_free_running(golden_dir):
         assert torch.equal(r['mg_input'], t['masked_ids']), f"step {r['step']} input ids differ"
         assert torch.equal(r['pred'], t['pred']), f"step {r['step']} pred differs"
     close(video[:, :, ::4, ::8, ::8], g['videos_sub'][0])
+
+
+def test_forward_objective_matches_reference(golden_dir):
+    """Phenaki.forward (phenaki_pytorch.py:562-687, value only): the oracle restatement with the three injected draws
+    reproduces the real reference's total / generator-only / critic-only losses and its gumbel-sampled ids."""
+    g = load(golden_dir, 'forward_tiny.pt')
+    cfgs = TINY
+    _, mg, cr = state_dicts('tiny')
+    _, mgc, crc = oracle_cfgs(cfgs)
+    batch, frames = g['batch'], g['frames']
+    hw = cfgs['cvivit']['image_size'] // cfgs['cvivit']['patch_size']
+    patch_shape = (1 + (frames - 1) // cfgs['cvivit']['temporal_patch_size'], hw, hw)
+    ids = g['ids'].reshape(batch, -1)
+    n = ids.shape[1]
+    ctx = weights.synthetic_context(batch, g['ctx_len'], cfgs['maskgit']['dim_context'], seed=3, pad_last=2)
+    kw = dict(patch_shape=patch_shape, context=ctx, steps=cfgs['steps'], rand_step=g['rand_step'],
+              perm_noise=weights.uniform_noise((batch, n), 700),
+              gumbel_u=weights.uniform_noise((batch, n, cfgs['maskgit']['num_tokens']), 701),
+              mask_id=cfgs['maskgit']['num_tokens'], critic_loss_weight=g['critic_loss_weight'],
+              critic_temperature=g['critic_temperature'])
+    out = O.phenaki_forward_loss(mg, mgc, cr, crc, ids, **kw)
+    assert torch.equal(out['pred'], g['pred'].reshape(batch, n))
+    assert abs(float(out['loss']) - float(g['loss'])) < 1e-5
+    assert abs(float(out['ce']) - float(g['loss_generator'])) < 1e-5
+    assert abs(float(out['critic_loss']) - float(g['loss_critic'])) < 1e-5
+    assert float(O.phenaki_forward_loss(mg, mgc, cr, crc, ids, only_train_generator=True, **kw)['loss']) == float(out['ce'])
+    assert float(O.phenaki_forward_loss(mg, mgc, cr, crc, ids, only_train_critic=True, **kw)['loss']) == float(out['critic_loss'])
