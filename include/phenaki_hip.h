@@ -66,6 +66,13 @@ int pk_patchify_ln(const float* video, int B, int C, int F, int H, int W, int f0
 int pk_unpatchify(const float* pix, int ldp, float* video, int B, int C, int F, int H, int W, int f0, int nt,
                   int pt, int ph, int pw, void* stream);
 
+/* Numerator of the reconstruction loss of cvivit.py:585-591 (F.mse_loss(video, recon), optionally over the frames a
+ * (B, F) mask keeps): partials[i], i < PK_SQDIFF_BLOCKS, are per-workgroup double sums of (a - b)^2 over two contiguous
+ * (B, C, F, H, W) f32 videos; the caller adds them and divides by the kept element count. */
+#define PK_SQDIFF_BLOCKS 1024
+int pk_sqdiff_partials(const float* a, const float* b, const unsigned char* fmask, int B, int C, int F, int H, int W,
+                       double* partials, void* stream);
+
 /* attention.py:57-85 + residual of attention.py:323: out = x + bias + depthwise_conv3d_3x3x3(zero-padded x) on the
  * channels-last (B,T,H,W,D) reinterpretation of the token buffer; time pad (2,0) if causal else (1,1).
  * wt is dsconv.weight (D,1,3,3,3) pre-transposed to [27][D].  Not in-place. */

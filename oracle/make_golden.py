@@ -232,6 +232,24 @@ def forward_golden(R, cfgs, batch, frames, ctx_len, tag):
     print(f'forward_{tag}: loss {float(total):.6f} = generator {float(gen):.6f} + w * critic {float(crit):.6f}')
 
 
+def recon_loss_golden(R, cfgs, tag):
+    """CViViT.forward's default return with use_vgg_and_gan=False: the reconstruction MSE (cvivit.py:585-627), plain, with a
+    frame mask, with return_recons, and for a 4-D image batch."""
+    cv, _, _, _ = build_reference(R, cfgs, with_phenaki=False)
+    H = cfgs['cvivit']['image_size']
+    video = weights.synthetic_video(2, 5, H, H, seed=6)
+    mask = torch.tensor([[True] * 5, [True] * 3 + [False] * 2])
+    with torch.no_grad():
+        loss = cv(video)
+        loss_masked = cv(video, mask=mask)
+        loss_r, recon = cv(video, return_recons=True)
+        loss_img = cv(video[:, :, 0])
+    assert float(loss_r) == float(loss)
+    out = dict(loss=loss, loss_masked=loss_masked, loss_image=loss_img, mask=mask, recon_sum=recon.double().sum().item())
+    torch.save(out, os.path.join(OUT, f'recon_loss_{tag}.pt'))
+    print(f'recon_loss_{tag}: {float(loss):.6f} masked {float(loss_masked):.6f} image {float(loss_img):.6f}')
+
+
 def keys_golden(R):
     """state_dict contract: every key, shape and dtype of the reference modules."""
     import json
@@ -261,6 +279,7 @@ def main():
         sample_golden(R, TINY, batch=1, frames_list=[5, 4], prime_len=3, ctx_len=5, tag='tiny_primed', keep_logits=True)
     if 'tiny' in which or 'forward' in which:
         forward_golden(R, TINY, batch=3, frames=5, ctx_len=6, tag='tiny')
+        recon_loss_golden(R, TINY, tag='tiny')
     if 'full' in which:
         cvivit_golden(R, FULL, batch=2, frames=17, tag='full', subsample=True)
         maskgit_golden(R, FULL, batch=1, frames=17, ctx_len=12, tag='full', col_stride=512)

@@ -236,6 +236,20 @@ def cvivit_decode_ids(sd, cfg, ids):
     return cvivit_decode(sd, cfg, lfq_codes(sd, ids))
 
 
+def cvivit_recon_loss(sd, cfg, video, mask=None):
+    """cvivit.py:518-627 with use_vgg_and_gan=False: video -> ids -> decode -> F.mse_loss(video, recon), over the frames
+    `mask` (b, f) keeps (variable-length training, :585-589) or over everything.  4-D image input gets a frame axis."""
+    import torch.nn.functional as F
+    if video.ndim == 4:
+        video = video.unsqueeze(2)
+    ids = cvivit_tokenize(sd, cfg, video)
+    recon = cvivit_decode_ids(sd, cfg, ids.flatten(1))
+    if mask is None:
+        return F.mse_loss(video, recon)
+    el = F.mse_loss(video, recon, reduction='none')
+    return el[mask[:, None, :].expand(-1, video.shape[1], -1)].mean()
+
+
 # --------------------------------------------------------------------------- MaskGit / critic
 
 def maskgit_embed(sd, ids):

@@ -29,6 +29,7 @@ SIGNATURES = {
     'pk_l2norm_rows': [_P, _I, _P, _I, _I, _I, _I, _P],
     'pk_patchify_ln': [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _I, _I, _P],
     'pk_unpatchify': [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'pk_sqdiff_partials': [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     'pk_peg': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'pk_lfq_encode': [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P],
     'pk_lfq_decode': [_P, _P, _P, _P, _I, _I, _I, _P],
@@ -133,6 +134,16 @@ def unpatchify(pix, video, f0, nt, pt, ph, pw):
     B, C, F, H, W = video.shape
     rc = load().pk_unpatchify(ptr(pix), pix.stride(0), ptr(video), B, C, F, H, W, f0, nt, pt, ph, pw, stream())
     _check(rc, 'pk_unpatchify')
+
+
+def sqdiff_sum(a, b, frame_mask=None):
+    """sum((a - b)^2) over the frames `frame_mask` (B, F) keeps (all if None) of two (B, C, F, H, W) f32 videos -> 0-d f64."""
+    B, C, F, H, W = a.shape
+    lib = load()
+    partials = torch.empty((1024,), device=a.device, dtype=torch.float64)            # PK_SQDIFF_BLOCKS
+    fm = frame_mask.to(torch.uint8).contiguous() if frame_mask is not None else None
+    _check(lib.pk_sqdiff_partials(ptr(a), ptr(b), ptr(fm), B, C, F, H, W, ptr(partials), stream()), 'pk_sqdiff_partials')
+    return partials.sum()
 
 
 def peg(x, wt, bias, out, B, T, H, W, D, causal):

@@ -106,6 +106,33 @@ __global__ __launch_bounds__(256) void unpatchify_kernel(const float* __restrict
     }
 }
 
+
+// sum over kept frames of (a - b)^2 for two (B, C, F, H, W) f32 videos (cvivit.py:585-591 F.mse_loss numerator): every
+// workgroup folds a grid-stride slice into ONE double partial (deterministic: fixed slice per workgroup, fixed tree), the
+// caller adds the <= 1024 partials.  fmask (B*F bytes, 1 = keep) or null.
+__global__ __launch_bounds__(256) void sqdiff_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             const unsigned char* __restrict__ fmask, int C, int F, long hw4,
+                                                             long total4, double* __restrict__ partials) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
+        if (fmask) {
+            const long plane = idx / hw4;                      // (b*C + c)*F + f
+            const int f = (int)(plane % F);
+            const long bb = plane / ((long)C * F);
+            if (!fmask[bb * F + f]) continue;
+        }
+        const f32x4 x = *reinterpret_cast<const f32x4*>(a + idx * 4), y = *reinterpret_cast<const f32x4*>(b + idx * 4);
+        const f32x4 d = x - y;
+        acc += (double)((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 }  // namespace pk
 using namespace pk;
 
@@ -152,3 +179,18 @@ extern "C" int pk_unpatchify(const float* pix, int ldp, float* video, int B, int
     PK_CHECK_LAUNCH();
     return PK_OK;
 }
+
+// partials[0 .. PK_SQDIFF_BLOCKS = 1024) <- per-workgroup sums of (a - b)^2 over the frames fmask keeps (NULL: all) of two contiguous
+// (B, C, F, H, W) f32 videos, H*W a multiple of 4; the reconstruction-MSE numerator of cvivit.py:585-591.
+extern "C" int pk_sqdiff_partials(const float* a, const float* b, const unsigned char* fmask, int B, int C, int F, int H, int W,
+                                  double* partials, void* stream) {
+    if (!a || !b || !partials || B <= 0 || C <= 0 || F <= 0 || H <= 0 || W <= 0) return PK_EINVAL;
+    if (((long)H * W) & 3) return PK_EALIGN;
+    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) return PK_EALIGN;
+    const long hw4 = (long)H * W / 4, total4 = (long)B * C * F * hw4;
+    hipLaunchKernelGGL(sqdiff_partial_kernel, dim3(1024), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       a, b, fmask, C, F, hw4, total4, partials);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+

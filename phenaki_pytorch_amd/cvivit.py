@@ -2,8 +2,9 @@
 
 Same constructor signature, attribute names and state_dict keys as the reference `CViViT`; `forward(...,
 return_only_codebook_ids=True)`, `forward(..., return_recons_only=True)`, `encode`, `decode`,
-`decode_from_codebook_indices` and the shape helpers run here.  The VQGAN training branch
-(discriminator / VGG / losses, cvivit.py:585-671) is out of scope for this build and raises.
+`decode_from_codebook_indices` and the shape helpers run here; with `use_vgg_and_gan=False` the default `forward(video)`
+returns the VALUE of the reconstruction loss (cvivit.py:585-627, no autograd graph).  The discriminator / VGG / adaptive-
+weight branches (cvivit.py:604-671) need autograd, are out of scope for this build and raise.
 """
 import copy
 from pathlib import Path
@@ -295,11 +296,25 @@ class CViViT(nn.Module):
         if return_only_codebook_ids:
             return self.tokenize(video)
 
-        if not return_recons_only:
-            raise NotImplementedError('the VQGAN training losses (cvivit.py:585-671) are outside the MI355X inference build; '
-                                      'use return_only_codebook_ids=True or return_recons_only=True')
+        if not return_recons_only and (return_discr_loss or self.use_vgg_and_gan):
+            raise NotImplementedError('the discriminator / VGG / adaptive-weight losses (cvivit.py:604-671) need autograd and are '
+                                      'outside the MI355X build; the reconstruction loss (use_vgg_and_gan=False), '
+                                      'return_only_codebook_ids=True and return_recons_only=True are supported')
         tokens, T = self._patch_embed(video)
         tokens = self._encode2d(tokens, b, T)
         ids = self.vq.encode_ids(tokens)
         recon = self._decode2d(self.vq.codes_2d(ids), b, T)
-        return recon.squeeze(2) if is_image else recon
+        returned_recon = recon.squeeze(2) if is_image else recon
+        if return_recons_only:
+            return returned_recon
+        # cvivit.py:585-627 with use_vgg_and_gan = False: the VALUE of the reconstruction loss (no autograd graph),
+        # F.mse_loss over all pixels or over the frames `mask` (b, f) keeps
+        if exists(mask):
+            L.require_device(mask, 'mask')
+            count = mask.sum().double() * (c * image_dims[0] * image_dims[1])
+        else:
+            count = float(video.numel())
+        recon_loss = (L.sqdiff_sum(video, recon.contiguous(), mask) / count).float()
+        if return_recons:
+            return recon_loss, returned_recon
+        return recon_loss

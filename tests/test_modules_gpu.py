@@ -372,3 +372,31 @@ def test_forward_objective_full_config_matches_oracle(dtype, tol):
     total = ph(**kw)
     assert abs(float(total) - float(ref['loss'])) <= tol * float(ref['loss']), (float(total), float(ref['loss']))
 
+
+@pytest.mark.parametrize('dtype,tol', [('fp32', 1e-3), ('bf16', 3e-2)])
+def test_cvivit_reconstruction_loss_matches_reference_golden(golden_dir, dtype, tol):
+    """CViViT.forward's default return with use_vgg_and_gan=False (cvivit.py:585-627, value only) against the real
+    reference: plain MSE, MSE over the frames a (b, f) mask keeps, the (loss, recon) pair, and a 4-D image batch;
+    the GAN / VGG branches still refuse loudly."""
+    g = golden(golden_dir, 'recon_loss_tiny.pt')
+    cv, _, _, _ = load_product('tiny', TINY, dtype=dtype, with_critic=False)
+    H = TINY['cvivit']['image_size']
+    video = weights.synthetic_video(2, 5, H, H, seed=6).cuda()
+    rel = lambda a, b: abs(float(a) - float(b)) / abs(float(b))
+    assert rel(cv(video), g['loss']) <= tol
+    assert rel(cv(video, mask=g['mask'].cuda()), g['loss_masked']) <= tol
+    loss, recon = cv(video, return_recons=True)
+    assert rel(loss, g['loss']) <= tol and recon.shape == video.shape
+    assert abs(recon.double().sum().item() - g['recon_sum']) <= tol * max(1.0, abs(g['recon_sum'])) * 50
+    assert rel(cv(video[:, :, 0]), g['loss_image']) <= tol
+    with pytest.raises(NotImplementedError):
+        cv(video, return_discr_loss=True)
+    # the kernel alone against torch, with a mask that drops whole frames
+    a, b = torch.randn(2, 3, 5, 16, 24, device='cuda'), torch.randn(2, 3, 5, 16, 24, device='cuda')
+    m = torch.tensor([[1, 1, 0, 1, 0], [0, 1, 1, 1, 1]], dtype=torch.bool, device='cuda')
+    from phenaki_pytorch_amd import _lib as L
+    ref_all = ((a - b).double() ** 2).sum()
+    ref_m = (((a - b).double() ** 2) * m[:, None, :, None, None]).sum()
+    assert abs(float(L.sqdiff_sum(a, b)) - float(ref_all)) <= 1e-6 * float(ref_all)
+    assert abs(float(L.sqdiff_sum(a, b, m)) - float(ref_m)) <= 1e-6 * float(ref_m)
+

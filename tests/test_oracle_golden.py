@@ -175,3 +175,15 @@ def test_forward_objective_matches_reference(golden_dir):
     assert abs(float(out['critic_loss']) - float(g['loss_critic'])) < 1e-5
     assert float(O.phenaki_forward_loss(mg, mgc, cr, crc, ids, only_train_generator=True, **kw)['loss']) == float(out['ce'])
     assert float(O.phenaki_forward_loss(mg, mgc, cr, crc, ids, only_train_critic=True, **kw)['loss']) == float(out['critic_loss'])
+
+
+def test_recon_loss_matches_reference(golden_dir):
+    """CViViT.forward's default return with use_vgg_and_gan=False (cvivit.py:585-627): plain, frame-masked and 4-D image MSE."""
+    g = load(golden_dir, 'recon_loss_tiny.pt')
+    cv, _, _ = state_dicts('tiny')
+    cvc, _, _ = oracle_cfgs(TINY)
+    H = TINY['cvivit']['image_size']
+    video = weights.synthetic_video(2, 5, H, H, seed=6)
+    assert abs(float(O.cvivit_recon_loss(cv, cvc, video)) - float(g['loss'])) < 1e-5
+    assert abs(float(O.cvivit_recon_loss(cv, cvc, video, mask=g['mask'])) - float(g['loss_masked'])) < 1e-5
+    assert abs(float(O.cvivit_recon_loss(cv, cvc, video[:, :, 0])) - float(g['loss_image'])) < 1e-5
