@@ -76,11 +76,49 @@ def max_over_ranks(x, ws):
     return float(t.item())
 
 
+# BASELINE.json configs[1..2]: C-ViViT dim 512 / codebook 65 536 / 256x256 / patch 32 / temporal patch 2 / depth 4+4;
+# MaskGit and TokenCritic dim 512 / depth 6 / 8 heads / T5-base context (768); 18 sampling steps
+BASELINE_CFG = dict(
+    cvivit=dict(dim=512, codebook_size=65536, image_size=256, patch_size=32, temporal_patch_size=2,
+                spatial_depth=4, temporal_depth=4, dim_head=64, heads=8),
+    maskgit=dict(dim=512, num_tokens=65536, max_seq_len=1024, depth=6, heads=8, dim_head=64, dim_context=768),
+    critic=dict(dim=512, num_tokens=65536, max_seq_len=1024, depth=6, heads=8, dim_head=64, dim_context=768,
+                has_cross_attn=True),
+    steps=18,
+)
+
+
 def build_models(dtype, with_sampler):
-    """random-init weights of the BASELINE architecture (name-keyed, reproducible; no checkpoints offline)."""
-    from oracle.configs import FULL
-    from tests.util import load_product
-    return load_product('full', FULL, device='cuda', dtype=dtype, with_critic=with_sampler)
+    """random-init weights of the BASELINE architecture (the modules' own default initialisers under a fixed seed; no
+    checkpoints offline).  The GPU legs of this file use the product package only -- nothing under oracle/ or tests/."""
+    import phenaki_pytorch_amd as P
+    torch.manual_seed(0)
+    cv = P.CViViT(use_vgg_and_gan=False, **BASELINE_CFG['cvivit'])
+    mg = P.MaskGit(**BASELINE_CFG['maskgit']) if with_sampler else None
+    cr = P.TokenCritic(**BASELINE_CFG['critic']) if with_sampler else None
+    cv = cv.cuda().eval()
+    ph = None
+    if with_sampler:
+        mg, cr = mg.cuda().eval(), cr.cuda().eval()
+        ph = P.Phenaki(maskgit=mg, cvivit=cv, critic=cr, steps=BASELINE_CFG['steps'],
+                       text_embed_dim=BASELINE_CFG['maskgit']['dim_context']).cuda().eval()
+    for m in (cv, mg, cr, ph):
+        if m is not None:
+            P.set_compute_dtype(m, dtype)
+    return cv, mg, cr, ph
+
+
+def synthetic_video(batch, frames, size, seed):
+    g = torch.Generator(device='cpu')
+    g.manual_seed(1000 + seed)
+    return torch.randn(batch, 3, frames, size, size, generator=g)
+
+
+def synthetic_context(batch, length, dim, seed):
+    """stands in for the cached T5 encoder output (no all-zero rows: every context token is real)"""
+    g = torch.Generator(device='cpu')
+    g.manual_seed(2000 + seed)
+    return torch.randn(batch, length, dim, generator=g)
 
 
 # template order: T, TM, TN, WM, WN, STAGES, ROWB, PW (the names rocprofv3 prints)
@@ -147,9 +185,8 @@ def pmc_traffic(kernel, args):
 
 
 def bench_encode(cv, args, ws):
-    from oracle import weights
     B = args.batch
-    video = weights.synthetic_video(B, 17, 256, 256, seed=int(os.environ.get('RANK', 0))).cuda()
+    video = synthetic_video(B, 17, 256, seed=int(os.environ.get('RANK', 0))).cuda()
     # the metric's own entry point: CViViT.forward(video, return_only_codebook_ids=True)
     step = lambda: cv(video, return_only_codebook_ids=True)
     ids = step()                                   # builds the packed weights / bias caches
@@ -191,9 +228,8 @@ def bench_encode(cv, args, ws):
 def bench_sample(ph, args, ws):
     """configs[2]: 18-step MaskGIT sampling (CFG scale 5, TokenCritic) with frozen random C-ViViT codes and a cached
     (random) T5 context; tokens/sec = B * 576 / wall time of Phenaki.sample (including the final decode)."""
-    from oracle import weights
     B = args.sample_batch
-    ctx = weights.synthetic_context(B, 12, 768, seed=1).cuda()
+    ctx = synthetic_context(B, 12, 768, seed=1).cuda()
     ph.encode_texts = lambda texts, output_device=None: ctx
     texts = ['x'] * B
     torch.manual_seed(0)
@@ -232,9 +268,8 @@ def bench_sample(ph, args, ws):
 def bench_objective(ph, args, ws):
     """SURVEY.md 8f row 1, first slice: Phenaki.forward -- the VALUE of the training objective (masked cross entropy without
     logits + token-critic BCE) on B videos' worth of token ids; videos/sec.  Reported beside the two headline legs."""
-    from oracle import weights
     B = args.sample_batch
-    ctx = weights.synthetic_context(B, 12, 768, seed=1).cuda()
+    ctx = synthetic_context(B, 12, 768, seed=1).cuda()
     g = torch.Generator(device='cpu')
     g.manual_seed(4)
     ids = torch.randint(0, 65536, (B, 9, 8, 8), generator=g).cuda()
