@@ -90,6 +90,17 @@ __device__ __forceinline__ void store4(bf16* p, f32x4 v) {
 __device__ __forceinline__ void store2(float* p, float a, float b) { *reinterpret_cast<f32x2*>(p) = f32x2{a, b}; }
 __device__ __forceinline__ void store2(bf16* p, float a, float b) { *reinterpret_cast<uint32_t*>(p) = pack_bf2(a, b); }
 
+// ---- XCD-contiguous workgroup order -------------------------------------------------------
+// Workgroup b of a launch is observed to run on XCD b % 8, each XCD with a private 4 MB L2 (speed only, never
+// correctness).  A kernel whose NEIGHBOURING workgroups share data (the PEG stencil rows) launches 8 * per workgroups and
+// walks them in this order, so XCD x owns the x-th contiguous eighth of the work and the shared rows are fetched over the
+// fabric once instead of (up to) eight times.  vb >= the real count: exit.  (Measured neutral, and not used, for the
+// q-blocks of one attention head and for the vocab-head tiles: their shared operands are served by the Infinity Cache.)
+__device__ __forceinline__ long xcd_contiguous_block(unsigned b, unsigned nblocks_padded) {
+    return (long)(b & 7u) * (nblocks_padded >> 3) + (b >> 3);
+}
+__host__ __device__ inline unsigned xcd_padded_grid(long nblocks) { return (unsigned)(8 * ((nblocks + 7) / 8)); }
+
 // ---- wave reductions (64 lanes) ----------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
