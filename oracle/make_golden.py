@@ -245,7 +245,7 @@ def recon_loss_golden(R, cfgs, tag):
         loss_r, recon = cv(video, return_recons=True)
         loss_img = cv(video[:, :, 0])
     assert float(loss_r) == float(loss)
-    out = dict(loss=loss, loss_masked=loss_masked, loss_image=loss_img, mask=mask, recon_sum=recon.double().sum().item())
+    out = dict(loss=loss.clone(), loss_masked=loss_masked.clone(), loss_image=loss_img.clone(), mask=mask, recon_sum=recon.double().sum().item())
     torch.save(out, os.path.join(OUT, f'recon_loss_{tag}.pt'))
     print(f'recon_loss_{tag}: {float(loss):.6f} masked {float(loss_masked):.6f} image {float(loss_img):.6f}')
 
