@@ -677,7 +677,7 @@ extern "C" int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void
     // exact-f32 path stops at 32 rows (register budget)
     static const int qf_cap = [] { const char* e = getenv("PK_ATTN_MAX_QF"); return e ? atoi(e) : 2; }();   // tuning knob (4 measured slower: 146 vs 104 us)
     int QF = (nq >= 256 && dtype == 1) ? 4 : (nq >= 128 ? 2 : 1);
-    if (QF > qf_cap && qf_cap >= 2) QF = 2;
+    if (QF > qf_cap && qf_cap >= 1) QF = qf_cap >= 2 ? 2 : 1;
     const long waves = (long)S * h * (nq_pad / (16 * QF));
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     static const int use_lds = [] { const char* e = getenv("PK_ATTN_LDS"); return e ? atoi(e) : 1; }();   // tuning knob

@@ -116,6 +116,58 @@ __global__ __launch_bounds__(256) void peg_v4_kernel(const float* __restrict__ x
     for (int w = 0; w < WW; ++w) *reinterpret_cast<f32x4*>(orow + (size_t)w * D) = acc[w];
 }
 
+// V5 = V4 with the W-row split in two: one thread per (b,t,h, 4 of the 8 columns, 4 channels) -> twice the threads,
+// 6 instead of 8 column loads per row fetch (halo), XCD-contiguous order
+template <int WW, int WO>
+__global__ __launch_bounds__(256) void peg_v5_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                     const float* __restrict__ bias, float* __restrict__ out,
+                                                     int B, int T, int H, int D, int tfront, long total) {
+    constexpr int NSEG = WW / WO;
+    const int dv = D >> 2;
+    const long idx = xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % dv) * 4;
+    long p = idx / dv;
+    const int w0 = (int)(p % NSEG) * WO; p /= NSEG;
+    const int h = (int)(p % H); p /= H;
+    const int t = (int)(p % T); const int b = (int)(p / T);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c);
+    const f32x4 zero = f32x4{0, 0, 0, 0};
+    f32x4 acc[WO];
+#pragma unroll
+    for (int o = 0; o < WO; ++o) acc[o] = bv;
+    const bool lv = w0 > 0, rv = w0 + WO < WW;
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt) {
+        const int ts = t + dt - tfront;
+        if (ts < 0 || ts >= T) continue;
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            const int hs = h + dh - 1;
+            if (hs < 0 || hs >= H) continue;
+            const float* row = x + (((size_t)b * T + ts) * H + hs) * WW * D + c;
+            f32x4 xr[WO + 2];
+            xr[0] = lv ? *reinterpret_cast<const f32x4*>(row + (size_t)(w0 - 1) * D) : zero;
+#pragma unroll
+            for (int o = 0; o < WO; ++o) xr[o + 1] = *reinterpret_cast<const f32x4*>(row + (size_t)(w0 + o) * D);
+            xr[WO + 1] = rv ? *reinterpret_cast<const f32x4*>(row + (size_t)(w0 + WO) * D) : zero;
+            const f32x4 k0 = *reinterpret_cast<const f32x4*>(wt + (size_t)((dt * 3 + dh) * 3 + 0) * D + c);
+            const f32x4 k1 = *reinterpret_cast<const f32x4*>(wt + (size_t)((dt * 3 + dh) * 3 + 1) * D + c);
+            const f32x4 k2 = *reinterpret_cast<const f32x4*>(wt + (size_t)((dt * 3 + dh) * 3 + 2) * D + c);
+#pragma unroll
+            for (int o = 0; o < WO; ++o) {
+                acc[o] += xr[o] * k0;
+                acc[o] += xr[o + 1] * k1;
+                acc[o] += xr[o + 2] * k2;
+                if (dt == tfront && dh == 1) acc[o] += xr[o + 1];
+            }
+        }
+    }
+    float* orow = out + ((((size_t)b * T + t) * H + h) * WW + w0) * D + c;
+#pragma unroll
+    for (int o = 0; o < WO; ++o) *reinterpret_cast<f32x4*>(orow + (size_t)o * D) = acc[o];
+}
+
 }  // namespace pk
 
 template <typename F>
@@ -161,6 +213,16 @@ int main() {
             hipMemcpy(b2.data(), out2, n * 4, hipMemcpyDeviceToHost);
             double e4 = 0; for (size_t i = 0; i < n; ++i) e4 = std::max(e4, (double)fabsf(a[i] - b2[i]));
             printf("V4 XCD-contiguous order %.1f us (maxdiff %.1e) | ", t4, e4);
+            for (int wo : {4, 2}) {
+                const long rows5 = rows * (8 / wo);
+                const dim3 g5(8 * (((rows5 + 255) / 256 + 7) / 8));
+                float t5;
+                if (wo == 4) t5 = timeit([&] { hipLaunchKernelGGL((pk::peg_v5_kernel<8, 4>), g5, dim3(256), 0, 0, x, wt, bias, out2, B, T, H, D, tf, rows5); });
+                else t5 = timeit([&] { hipLaunchKernelGGL((pk::peg_v5_kernel<8, 2>), g5, dim3(256), 0, 0, x, wt, bias, out2, B, T, H, D, tf, rows5); });
+                hipMemcpy(b2.data(), out2, n * 4, hipMemcpyDeviceToHost);
+                double e5 = 0; for (size_t i = 0; i < n; ++i) e5 = std::max(e5, (double)fabsf(a[i] - b2[i]));
+                printf("V5 split W in %d + XCD order %.1f us (maxdiff %.1e) | ", 8 / wo, t5, e5);
+            }
             printf("B=%2d T=%d H=%d W=%d D=%d causal=%d | V0 row kernel %.1f us | V1 slab-of-3 clamped %.1f us (maxdiff %.1e) | V2 all 72 loads first %.1f us (maxdiff %.1e) | V3 thread per token %.1f us | %.1f MB in+out\n",
                    B, T, H, W, D, causal, t0, t1, e1, t2, e2, t3, 2.0 * n * 4 / 1e6);
         }
