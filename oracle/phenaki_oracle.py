@@ -14,6 +14,47 @@ import torch.nn.functional as F
 
 NEG_MAX = -torch.finfo(torch.float32).max
 
+# --------------------------------------------------------------------------- precision mode
+# 'fp32' (default): the reference's own arithmetic.
+# 'bf16': the SAME algorithm with every MFMA operand of the product's bf16 mode rounded to bf16 (round-to-nearest-even)
+# at exactly the points where the HIP kernels round (SURVEY.md 7 "compare against an oracle run at the same precision
+# with the same rounding points"): GEMM inputs (LayerNorm outputs, the un-normalised x feeding self-attention K/V, the
+# GEGLU output, the attention output, the CFG-mixed embeddings, the LayerNorm'ed patches) and weights; the attention
+# operand images q^ = l2norm(q)*q_scale*scale, k^ = l2norm(k)*k_scale, v; and the softmax numerators p = exp(s - m)
+# of the flash loop, tile by tile (64 keys for n >= 64 self/cross attention with >= 64 keys, else 32) with the running
+# maximum the kernels use.  Accumulation, residual stream, LayerNorm statistics, softmax, position bias, PEG, LFQ and
+# the critic head stay f32, as in the product.  No reference run pins this mode (the reference under bf16 autocast
+# rounds at other points); it is derived from the f32 oracle, which IS pinned, by inserting roundings only.
+_PRECISION = ['fp32']
+
+
+class precision:
+    def __init__(self, mode):
+        assert mode in ('fp32', 'bf16')
+        self.mode = mode
+
+    def __enter__(self):
+        _PRECISION.append(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        _PRECISION.pop()
+
+
+def is_bf16():
+    return _PRECISION[-1] == 'bf16'
+
+
+def _r(x):
+    """round to bf16 (RNE, like v_cvt_pk_bf16_f32 / torch) in bf16 mode; identity in fp32 mode"""
+    return x.to(torch.bfloat16).float() if is_bf16() else x
+
+
+def _lin(x, w):
+    """x @ w^T with both MFMA operands in the compute type, f32 accumulation"""
+    return _r(x) @ _r(w).t()
+
+
 
 # --------------------------------------------------------------------------- blocks
 
@@ -25,10 +66,10 @@ def gamma_layernorm(sd, p, x):
 def feedforward(sd, p, x):
     """attention.py:40-53  nn.LayerNorm -> Linear(d, 2*inner, no bias) -> x*gelu(gate) -> Linear(inner, d)."""
     h = F.layer_norm(x, x.shape[-1:], sd[p + '0.weight'], sd[p + '0.bias'])
-    h = h @ sd[p + '1.weight'].t()
+    h = _lin(h, sd[p + '1.weight'])
     val, gate = h.chunk(2, dim=-1)
     h = F.gelu(gate) * val
-    return h @ sd[p + '4.weight'].t()
+    return _lin(h, sd[p + '4.weight'])
 
 
 def peg(sd, p, x, shape, causal):
@@ -71,8 +112,8 @@ def attention(sd, p, x, *, heads, causal=False, mask=None, context=None, attn_bi
         context = gamma_layernorm(sd, p + 'context_norm.', context)
     kv_in = context if context is not None else x
     xn = gamma_layernorm(sd, p + 'norm.', x)
-    q = xn @ sd[p + 'to_q.weight'].t()
-    k, v = (kv_in @ sd[p + 'to_kv.weight'].t()).chunk(2, dim=-1)
+    q = _lin(xn, sd[p + 'to_q.weight'])
+    k, v = _lin(kv_in, sd[p + 'to_kv.weight']).chunk(2, dim=-1)
 
     def split(t):
         return t.reshape(t.shape[0], t.shape[1], heads, -1).permute(0, 2, 1, 3)
@@ -85,8 +126,11 @@ def attention(sd, p, x, *, heads, causal=False, mask=None, context=None, attn_bi
     k = torch.cat((nk, k), dim=-2)
     v = torch.cat((nv, v), dim=-2)
 
-    q = F.normalize(q, dim=-1) * sd[p + 'q_scale']
-    k = F.normalize(k, dim=-1) * sd[p + 'k_scale']
+    # bf16 mode: the kernels fold the similarity scale into q^ before rounding it (a power of two commutes with the
+    # rounding); q^, k^ and v are the bf16 operand images the attention kernel reads
+    q = _r(F.normalize(q, dim=-1) * sd[p + 'q_scale'])
+    k = _r(F.normalize(k, dim=-1) * sd[p + 'k_scale'])
+    v = _r(v)
     sim = torch.einsum('bhid,bhjd->bhij', q, k) * scale
     i, j = sim.shape[-2:]
     if attn_bias is not None:
@@ -98,10 +142,32 @@ def attention(sd, p, x, *, heads, causal=False, mask=None, context=None, attn_bi
         sim = sim + alibi_bias(heads, i, j)
         cm = torch.ones((i, j), dtype=torch.bool).triu(j - i + 1)
         sim = sim.masked_fill(cm, NEG_MAX)
-    attn = sim.softmax(dim=-1)
-    out = torch.einsum('bhij,bhjd->bhid', attn, v)
+    if is_bf16():
+        out = _flash_bf16(sim, v, 64 if (i >= 64 and j >= 64) else 32)
+    else:
+        attn = sim.softmax(dim=-1)
+        out = torch.einsum('bhij,bhjd->bhid', attn, v)
     out = out.permute(0, 2, 1, 3).reshape(b, i, -1)
-    return out @ sd[p + 'to_out.weight'].t()
+    return _lin(out, sd[p + 'to_out.weight'])
+
+
+def _flash_bf16(sim, v, tk):
+    """the product's flash loop (csrc/attn.hip) restated: keys in tiles of `tk`; per tile mn = max(m, tile max),
+    p = exp(s - mn) in f32; the row sum l accumulates the UN-rounded p while the PV product takes bf16(p) (f32
+    accumulation); o and l are rescaled by exp(m - mn); output o / l."""
+    b, h, i, j = sim.shape
+    m = torch.full((b, h, i), float('-inf'))
+    l = torch.zeros((b, h, i))
+    o = torch.zeros((b, h, i, v.shape[-1]))
+    for t0 in range(0, j, tk):
+        s = sim[..., t0:t0 + tk]
+        mn = torch.maximum(m, s.amax(dim=-1))
+        alpha = torch.exp(m - mn)
+        pt = torch.exp(s - mn[..., None])
+        l = l * alpha + pt.sum(dim=-1)
+        o = o * alpha[..., None] + torch.einsum('bhij,bhjd->bhid', _r(pt), v[..., t0:t0 + tk, :])
+        m = mn
+    return o / l[..., None]
 
 
 def continuous_position_bias(sd, p, dims, nlayers=2):
@@ -145,7 +211,7 @@ def cvivit_patch_embed(sd, cfg, video):
         t = frames.shape[2] // tp
         pat = frames.reshape(b, c, t, tp, h, ph, w, pw).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(b, t, h, w, -1)
         pat = F.layer_norm(pat, pat.shape[-1:], sd[p + '1.weight'], sd[p + '1.bias'])
-        pat = pat @ sd[p + '2.weight'].t() + sd[p + '2.bias']
+        pat = _lin(pat, sd[p + '2.weight']) + sd[p + '2.bias']
         return F.layer_norm(pat, pat.shape[-1:], sd[p + '3.weight'], sd[p + '3.bias'])
 
     first = emb(video[:, :, :1], 1, 'to_patch_emb_first_frame.')
@@ -221,11 +287,11 @@ def cvivit_decode(sd, cfg, tokens):
     tokens = _temporal(sd, cfg, 'dec_temporal_transformer.', tokens)
     tokens = _spatial(sd, cfg, 'dec_spatial_transformer.', tokens)
     c = cfg.get('channels', 3)
-    first = tokens[:, :1] @ sd['to_pixels_first_frame.0.weight'].t() + sd['to_pixels_first_frame.0.bias']
+    first = _lin(tokens[:, :1], sd['to_pixels_first_frame.0.weight']) + sd['to_pixels_first_frame.0.bias']
     first = first.reshape(b, 1, h, w, c, 1, ph, pw).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(b, c, 1, H, W)
     if tokens.shape[1] == 1:
         return first
-    rest = tokens[:, 1:] @ sd['to_pixels.0.weight'].t() + sd['to_pixels.0.bias']
+    rest = _lin(tokens[:, 1:], sd['to_pixels.0.weight']) + sd['to_pixels.0.bias']
     t = rest.shape[1]
     rest = rest.reshape(b, t, h, w, c, pt, ph, pw).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(b, c, t * pt, H, W)
     return torch.cat((first, rest), dim=2)
@@ -274,11 +340,18 @@ def maskgit_forward(sd, cfg, ids, *, video_patch_shape, context=None, text_mask=
                     cross_attn_context_mask=text_mask)
     if return_embeds:
         return x
-    return x @ sd['to_logits.weight'].t() + sd['to_logits.bias']
+    return _lin(x, sd['to_logits.weight']) + sd['to_logits.bias']
 
 
 def maskgit_cfg(sd, cfg, ids, *, cond_scale, **kw):
     """phenaki_pytorch.py:149-161"""
+    if is_bf16() and cond_scale != 1:
+        # the product mixes the 512-d trunk outputs (CFG is linear in the logits and to_logits is linear), rounds the mix to
+        # bf16 and runs ONE vocab-head GEMM (csrc/sampler.hip pk_cfg_mix)
+        kw = {k: v for k, v in kw.items() if k != 'return_embeds'}
+        e = maskgit_forward(sd, cfg, ids, null_cond=False, return_embeds=True, **kw)
+        en = maskgit_forward(sd, cfg, ids, null_cond=True, return_embeds=True, **kw)
+        return _lin(en + (e - en) * cond_scale, sd['to_logits.weight']) + sd['to_logits.bias']
     logits = maskgit_forward(sd, cfg, ids, null_cond=False, **kw)
     if cond_scale == 1:
         return logits
@@ -371,7 +444,7 @@ def sample_step(mg, mg_cfg, cr, cr_cfg, *, step, steps, ids, mask, scores, prime
 
 def sample(cv, cv_cfg, mg, mg_cfg, cr, cr_cfg, *, num_frames, batch_size, context=None, prime_frames=None,
            steps=18, cond_scale=3., starting_temperature=0.9, noise_K=1., anneal='decay',
-           noise_fn=None, trace=None):
+           noise_fn=None, trace=None, trace_logits=False):
     """phenaki_pytorch.py:418-560.  ``noise_fn(kind, step, shape)`` supplies U[0,1) noise
     ('gumbel' (B,n,V) and 'critic' (B,n)); ``trace`` (a list) receives every step's record."""
     prime_ids = None
@@ -405,7 +478,8 @@ def sample(cv, cv_cfg, mg, mg_cfg, cr, cr_cfg, *, num_frames, batch_size, contex
         rec = sample_step(mg, mg_cfg, cr, cr_cfg, step=step, steps=steps, ids=ids, mask=mask, scores=scores,
                           prime_ids=prime_ids, patch_shape=patch_shape, context=context, text_mask=text_mask,
                           cond_scale=cond_scale, starting_temperature=starting_temperature, noise_K=noise_K,
-                          anneal=anneal, gumbel_u=gu, critic_u=cu, mask_id=mask_id)
+                          anneal=anneal, gumbel_u=gu, critic_u=cu, mask_id=mask_id, return_logits=trace_logits)
+        rec['temperature'] = starting_temperature * ((steps - (step + 1)) / steps)
         ids, mask, scores = rec['ids'], rec['mask'], rec['scores']
         if trace is not None:
             trace.append(rec)

@@ -11,10 +11,18 @@ import torch
 from oracle import phenaki_oracle as O
 from oracle import weights
 from oracle.configs import TINY, FULL, oracle_cfgs, state_dicts
-from tests.util import close, ids_equal_with_margin, load_product, noise_fn_cuda
+from tests.util import (argmax_equal_with_margin, close, gumbel_noisy, ids_equal_with_margin, load_product, noise_fn_cuda,
+                        record_parity)
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
+
+# Tolerances.  fp32 mode is held to the north star directly: ids bit-exact (LFQ sign bits and gumbel argmax audited by the
+# oracle's own decision margin), logits / pixels 1e-3 relative.  bf16 mode (the mode bench.py times) is held to THE SAME bar
+# against the oracle run in ITS precision -- oracle.precision('bf16') rounds at the kernels' rounding points -- so a bf16
+# kernel bug that flips ids cannot hide behind an "agreement fraction".
+BF16_TOL = 1e-3
+MODES = [('fp32', 1e-3, 1e-4), ('bf16', BF16_TOL, BF16_TOL)]       # (compute dtype, value tolerance, decision-margin tolerance)
 
 
 def golden(golden_dir, name):
@@ -48,25 +56,27 @@ def test_cvivit_tiny_matches_reference_golden(golden_dir):
     assert torch.equal(img_ids, cv(video[:, :, :1], return_only_codebook_ids=True))
 
 
-@pytest.mark.parametrize('dtype,tol,min_agree', [('fp32', 1e-3, 1.0), ('bf16', 5e-2, 0.85)])
-def test_cvivit_full_config_matches_oracle(dtype, tol, min_agree):
-    """BASELINE configs[1] geometry (dim 512, 256x256, patch 32, tpatch 2, depth 4+4) at B=2."""
+@pytest.mark.parametrize('dtype,tol,mtol', MODES)
+def test_cvivit_full_config_matches_oracle(dtype, tol, mtol):
+    """BASELINE configs[1] geometry (dim 512, 256x256, patch 32, tpatch 2, depth 4+4) at B=2, each compute mode against
+    the oracle in the same precision: ids equal under the LFQ margin audit, projection / pixels within tol."""
     cv_sd, _, _ = state_dicts('full')
     cvc, _, _ = oracle_cfgs(FULL)
     cv, _, _, _ = load_product('full', FULL, dtype=dtype)
     video = weights.synthetic_video(2, 17, 256, 256, seed=0)
-    ids_ref, proj_ref = O.cvivit_tokenize(cv_sd, cvc, video, return_proj=True)
+    with O.precision(dtype):
+        ids_ref, proj_ref = O.cvivit_tokenize(cv_sd, cvc, video, return_proj=True)
+        rec_ref = O.cvivit_decode_ids(cv_sd, cvc, ids_ref.flatten(1))
     ids, proj = cv.tokenize(video.cuda(), return_proj=True)
     assert ids.shape == (2, 9, 8, 8) and ids.dtype == torch.int64
-    close(proj, proj_ref, tol, f'lfq projection {dtype}')
-    if dtype == 'fp32':
-        ids_equal_with_margin(ids, ids_ref, proj_ref)
-    agree = (ids.cpu() == ids_ref).float().mean().item()
-    assert agree >= min_agree, f'{dtype}: only {agree:.3f} of ids agree with the f32 oracle'
-    rec_ref = O.cvivit_decode_ids(cv_sd, cvc, ids_ref.flatten(1))
+    e_proj = close(proj, proj_ref, tol, f'lfq projection {dtype}')
+    flips = ids_equal_with_margin(ids, ids_ref, proj_ref, tol=mtol)
+    assert flips <= 4, f'{dtype}: {flips} audited near-zero sign flips out of {ids.numel() * 16} bits'
     rec = cv.decode_from_codebook_indices(ids_ref.flatten(1).cuda())
     assert rec.shape == (2, 3, 17, 256, 256)
-    close(rec, rec_ref, tol, f'decoded pixels {dtype}')
+    e_rec = close(rec, rec_ref, tol, f'decoded pixels {dtype}')
+    record_parity('cvivit_full_vs_oracle', dict(dtype=dtype, proj_rel_err=e_proj, pixel_rel_err=e_rec, audited_bit_flips=flips,
+                                                ids_equal=bool(torch.equal(ids.cpu(), ids_ref))))
 
 
 def test_cvivit_asserts_match_reference():
@@ -127,9 +137,10 @@ def test_maskgit_and_critic_tiny_match_reference_golden(golden_dir):
     close(mg(ids4, context=ctx, text_mask=tm), g['cond'], 1e-3, '4-d ids')
 
 
-@pytest.mark.parametrize('dtype,tol', [('fp32', 1e-3), ('bf16', 6e-2)])
-def test_maskgit_full_config_matches_oracle(dtype, tol):
-    """BASELINE configs[2] geometry: dim 512, depth 6, vocab 65 536, n = 576, cross-attention on a 12-token context."""
+@pytest.mark.parametrize('dtype,tol,mtol', MODES)
+def test_maskgit_full_config_matches_oracle(dtype, tol, mtol):
+    """BASELINE configs[2] geometry: dim 512, depth 6, vocab 65 536, n = 576, cross-attention on a 12-token context;
+    each compute mode against the oracle in the same precision."""
     _, mg_sd, cr_sd = state_dicts('full')
     _, mgc, crc = oracle_cfgs(FULL)
     _, mg, cr, _ = load_product('full', FULL, dtype=dtype)
@@ -139,17 +150,16 @@ def test_maskgit_full_config_matches_oracle(dtype, tol):
     ctx = weights.synthetic_context(1, 12, 768, seed=1, pad_last=3)
     tm = (ctx != 0).any(-1)
     kw = dict(video_patch_shape=(9, 8, 8), context=ctx, text_mask=tm)
-    ref = O.maskgit_cfg(mg_sd, mgc, ids, cond_scale=5., **kw)
+    with O.precision(dtype):
+        ref = O.maskgit_cfg(mg_sd, mgc, ids, cond_scale=5., **kw)
+        sref = O.critic_cfg(cr_sd, crc, ids, cond_scale=5., **kw)
     kwd = dict(video_patch_shape=(9, 8, 8), context=ctx.cuda(), text_mask=tm.cuda())
     out = mg.forward_with_cond_scale(ids.cuda(), cond_scale=5., **kwd)
     assert out.shape == (1, 576, 65536)
-    close(out, ref, tol, f'cfg logits {dtype}')
-    if dtype == 'fp32':
-        top2 = ref.topk(2, dim=-1).values
-        safe = (top2[..., 0] - top2[..., 1]) > 1e-3 * ref.abs().max()
-        assert torch.equal(out.argmax(-1).cpu()[safe], ref.argmax(-1)[safe])
-    sref = O.critic_cfg(cr_sd, crc, ids, cond_scale=5., **kw)
-    close(cr.forward_with_cond_scale(ids.cuda(), cond_scale=5., **kwd), sref, tol, f'critic scores {dtype}')
+    e_logits = close(out, ref, tol, f'cfg logits {dtype}')
+    flips = argmax_equal_with_margin(out.argmax(-1), ref.argmax(-1), ref, tol=mtol, what=f'cfg argmax {dtype}')
+    e_critic = close(cr.forward_with_cond_scale(ids.cuda(), cond_scale=5., **kwd), sref, tol, f'critic scores {dtype}')
+    record_parity('maskgit_full_vs_oracle', dict(dtype=dtype, logits_rel_err=e_logits, critic_rel_err=e_critic, audited_argmax_flips=flips))
 
 
 # ------------------------------------------------------------------------------------------ Phenaki.sample
@@ -230,11 +240,14 @@ def test_self_token_critic_and_unconditional_paths_run():
     assert vu.shape == (2, 3, 5, 64, 64) and torch.isfinite(vu).all()
 
 
-def test_sample_full_config_two_steps_matches_oracle():
-    """full-size Phenaki.sample (n = 576, vocab 65 536, TokenCritic) teacher-checked over 2 steps against the oracle."""
+@pytest.mark.parametrize('dtype,tol,mtol', MODES)
+def test_sample_full_config_two_steps_matches_oracle(dtype, tol, mtol):
+    """full-size Phenaki.sample (n = 576, vocab 65 536, TokenCritic, CFG 5) over 2 free-running steps against the oracle in the
+    same precision: the masked inputs of every step are identical, the gumbel-argmax ids are identical or differ only where
+    the oracle's own noisy logits tie within the decision margin, and the decoded pixels agree."""
     cv_sd, mg_sd, cr_sd = state_dicts('full')
     cvc, mgc, crc = oracle_cfgs(FULL)
-    _, _, _, ph = load_product('full', FULL, steps=2)
+    _, _, _, ph = load_product('full', FULL, steps=2, dtype=dtype)
     ctx = weights.synthetic_context(1, 12, 768, seed=2)
     ph.encode_texts = lambda texts, output_device=None: ctx.cuda()
 
@@ -242,16 +255,57 @@ def test_sample_full_config_two_steps_matches_oracle():
         return weights.uniform_noise(tuple(shape), 900 + 2 * step + (1 if kind == 'critic' else 0))
 
     trace_ref, trace = [], []
-    vid_ref, ids_ref = O.sample(cv_sd, cvc, mg_sd, mgc, cr_sd, crc, num_frames=17, batch_size=1, context=ctx, steps=2,
-                                cond_scale=5., noise_fn=nf_cpu, trace=trace_ref)
+    with O.precision(dtype):
+        vid_ref, ids_ref = O.sample(cv_sd, cvc, mg_sd, mgc, cr_sd, crc, num_frames=17, batch_size=1, context=ctx, steps=2,
+                                    cond_scale=5., noise_fn=nf_cpu, trace=trace_ref, trace_logits=True)
     vid, ids = ph.sample(texts=['x'], num_frames=17, cond_scale=5., _noise_fn=lambda k, s, sh: nf_cpu(k, s, sh).cuda(),
                          _trace=trace, _return_ids=True)
+    flips = 0
     for s, (a, b) in enumerate(zip(trace_ref, trace)):
-        agree = (a['pred'] == b['pred'].cpu()).float().mean().item()
-        assert agree >= 0.995, f'step {s}: only {agree:.4f} of predicted ids agree'
-        assert torch.equal(a['mask'], b['mask'].cpu()) or s > 0
+        if flips == 0:
+            assert torch.equal(a['masked_ids'], b['masked_ids'].cpu()), f'{dtype} step {s}: masked input ids differ'
+        noisy = gumbel_noisy(a['logits'], a['temperature'], nf_cpu('gumbel', s, a['logits'].shape))
+        flips += argmax_equal_with_margin(b['pred'], a['pred'], noisy, tol=mtol, what=f'{dtype} step {s} pred')
+        if flips:
+            break                      # an audited near-tie changes the next step's input: later steps are not comparable
+    e_pix = None
     if torch.equal(ids_ref, ids.cpu()):
-        close(vid, vid_ref, 1e-3, 'sampled pixels')
+        e_pix = close(vid, vid_ref, tol, f'sampled pixels {dtype}')
+    record_parity('sample_full_2step_vs_oracle', dict(dtype=dtype, audited_argmax_flips=flips, final_ids_equal=bool(torch.equal(ids_ref, ids.cpu())),
+                                                      pixel_rel_err=e_pix))
+
+
+@pytest.mark.parametrize('with_critic', [True, False])
+def test_sample_tiny_bf16_free_running_matches_bf16_oracle(with_critic):
+    """the timed precision mode, free running over all 6 steps of the tiny config (with the TokenCritic, and with the
+    softmax-confidence scores of the critic-less path) against oracle.precision('bf16'): every step's masked ids and
+    predictions equal under the margin audit, pixels within BF16_TOL."""
+    cv_sd, mg_sd, cr_sd = state_dicts('tiny')
+    cvc, mgc, crc = oracle_cfgs(TINY)
+    _, _, _, ph = load_product('tiny', TINY, with_critic=with_critic, dtype='bf16')
+    ctx = weights.synthetic_context(2, 6, TINY['maskgit']['dim_context'], seed=2)
+    ph.encode_texts = lambda texts, output_device=None: ctx.cuda()
+
+    def nf_cpu(kind, step, shape):
+        return weights.uniform_noise(tuple(shape), 500 + 2 * step + (1 if kind == 'critic' else 0))
+
+    trace_ref, trace = [], []
+    with O.precision('bf16'):
+        vid_ref, ids_ref = O.sample(cv_sd, cvc, mg_sd, mgc, cr_sd if with_critic else None, crc, num_frames=5, batch_size=2,
+                                    context=ctx, steps=TINY['steps'], cond_scale=5., noise_fn=nf_cpu, trace=trace_ref, trace_logits=True)
+    vid, ids = ph.sample(texts=['a', 'b'], num_frames=5, cond_scale=5., _noise_fn=noise_fn_cuda(500), _trace=trace, _return_ids=True)
+    assert len(trace) == len(trace_ref) == TINY['steps']
+    flips = 0
+    for s, (a, b) in enumerate(zip(trace_ref, trace)):
+        if flips == 0:
+            assert torch.equal(a['masked_ids'], b['masked_ids'].cpu()), f'step {s}: masked input ids differ'
+        noisy = gumbel_noisy(a['logits'], a['temperature'], nf_cpu('gumbel', s, a['logits'].shape))
+        flips += argmax_equal_with_margin(b['pred'], a['pred'], noisy, tol=BF16_TOL, what=f'bf16 tiny step {s} pred')
+        if flips:
+            break
+    e_pix = close(vid, vid_ref, BF16_TOL, 'bf16 sampled pixels') if torch.equal(ids.cpu(), ids_ref) else None
+    record_parity('sample_tiny_bf16_vs_oracle', dict(with_critic=with_critic, audited_argmax_flips=flips,
+                                                     final_ids_equal=bool(torch.equal(ids.cpu(), ids_ref)), pixel_rel_err=e_pix))
 
 
 # ------------------------------------------------------------------------------------------ full size vs the REAL reference
@@ -292,36 +346,47 @@ def test_maskgit_full_matches_reference_golden(golden_dir):
 
 
 def test_sample_full_free_running_matches_reference_golden(golden_dir):
-    """18-step full-size Phenaki.sample (TokenCritic, CFG 5, n = 576, vocab 65 536) against the REAL reference run with
-    the same injected noise: ids must match step by step (a near-tie flip would make later steps incomparable, so the
-    comparison is strict up to the first differing step and that step must still agree on >= 99.5 % of positions)."""
+    """18-step full-size Phenaki.sample (TokenCritic, CFG 5, n = 576, vocab 65 536) against the REAL reference run with the
+    same injected noise.  Required: all 18 steps' masked inputs and predicted ids bit-identical to the reference -- or, at the
+    FIRST differing step, every differing id is a near tie by the oracle's own noisy logits (margin audit; the oracle is
+    teacher-forced with the reference's masked input of that step).  The matched-step count is recorded."""
     g = golden(golden_dir, 'sample_full.pt')
+    cv_sd, mg_sd, cr_sd = state_dicts('full')
+    cvc, mgc, crc = oracle_cfgs(FULL)
     _, _, _, ph = load_product('full', FULL)
-    ctx = weights.synthetic_context(1, g['ctx_len'], 768, seed=2).cuda()
-    ph.encode_texts = lambda texts, output_device=None: ctx
+    ctx = weights.synthetic_context(1, g['ctx_len'], 768, seed=2)
+    ph.encode_texts = lambda texts, output_device=None: ctx.cuda()
     trace = []
     video = ph.sample(texts=['x'], num_frames=17, cond_scale=5., _noise_fn=noise_fn_cuda(500, 0), _trace=trace)
     assert len(trace) == 18
-    matched = 0
+    matched, flips = 0, 0
     for r, t in zip(g['steps'], trace):
-        if not torch.equal(r['mg_input'], t['masked_ids'].cpu()):
-            break
-        agree = (r['pred'] == t['pred'].cpu()).float().mean().item()
-        assert agree >= 0.995, f"step {r['step']}: predicted-id agreement {agree:.4f}"
-        if agree < 1.0:
-            break
-        matched += 1
-    print(f'full-size sample: {matched}/18 steps bit-identical to the reference')
-    assert matched >= 6
+        assert torch.equal(r['mg_input'], t['masked_ids'].cpu()), f"step {r['step']}: masked input ids differ although every earlier step matched"
+        if torch.equal(r['pred'], t['pred'].cpu()):
+            matched += 1
+            continue
+        # first divergence: audit it against the oracle's noisy logits for the reference's own input of this step
+        step = r['step']
+        logits = O.maskgit_cfg(mg_sd, mgc, r['mg_input'], cond_scale=5., video_patch_shape=(9, 8, 8), context=ctx,
+                               text_mask=(ctx != 0).any(-1))
+        temperature = 0.9 * ((18 - (step + 1)) / 18)
+        noisy = gumbel_noisy(logits, temperature, weights.uniform_noise((1, 576, 65536), 500 + 2 * step))
+        assert torch.equal(noisy.argmax(-1), r['pred']), 'oracle and reference disagree on this step (oracle unpinned?)'
+        flips = argmax_equal_with_margin(t['pred'], r['pred'], noisy, tol=1e-4, what=f'step {step} pred')
+        break
+    record_parity('sample_full_18step_vs_reference', dict(dtype='fp32', matched_steps=matched, of=18, audited_argmax_flips_at_first_divergence=flips))
+    print(f'full-size sample: {matched}/18 steps bit-identical to the reference, {flips} audited near-tie flips at the first divergence')
+    assert matched == 18 or flips > 0
     if matched == 18:
         close(video[:, :, ::4, ::8, ::8], g['videos_sub'][0], 1e-3, 'sampled pixels')
 
 
-@pytest.mark.parametrize('dtype,tol', [('fp32', 2e-4), ('bf16', 3e-2)])
+@pytest.mark.parametrize('dtype,tol', [('fp32', 2e-4), ('bf16', BF16_TOL)])
 def test_forward_objective_tiny_matches_reference_golden(golden_dir, dtype, tol):
     """Phenaki.forward (the training objective, value only) against the REAL reference's losses with the reference's
     three random draws injected: total, generator-only and critic-only; in f32 the gumbel-sampled critic inputs
-    (hence the critic labels) are the reference's own."""
+    (hence the critic labels) are the reference's own.  bf16 mode: the same three values against the oracle run in bf16
+    precision on the same draws (the reference itself has no run with these rounding points)."""
     g = torch.load(os.path.join(golden_dir, 'forward_tiny.pt'), weights_only=False)
     cv, mg, cr, ph = load_product('tiny', TINY, dtype=dtype)
     batch, frames = g['batch'], g['frames']
@@ -339,7 +404,20 @@ def test_forward_objective_tiny_matches_reference_golden(golden_dir, dtype, tol)
     total = ph(video_codebook_ids=ids, text_embeds=ctx, _draws=draws)
     gen = ph(video_codebook_ids=ids, text_embeds=ctx, only_train_generator=True, _draws=draws)
     crit = ph(video_codebook_ids=ids, text_embeds=ctx, only_train_critic=True, _draws=draws)
-    for name, got, ref in (('total', total, g['loss']), ('generator', gen, g['loss_generator']), ('critic', crit, g['loss_critic'])):
+    refs = (g['loss'], g['loss_generator'], g['loss_critic'])
+    if dtype == 'bf16':
+        _, mg_sd, cr_sd = state_dicts('tiny')
+        _, mgc, crc = oracle_cfgs(TINY)
+        okw = dict(patch_shape=tuple(g['ids'].shape[1:]), context=ctx.cpu(), steps=TINY['steps'], mask_id=TINY['maskgit']['num_tokens'],
+                   critic_loss_weight=g['critic_loss_weight'], critic_temperature=g['critic_temperature'], **draws)
+        with O.precision('bf16'):
+            flat = g['ids'].flatten(1)
+            refs = (O.phenaki_forward_loss(mg_sd, mgc, cr_sd, crc, flat, **okw)['loss'],
+                    O.phenaki_forward_loss(mg_sd, mgc, cr_sd, crc, flat, only_train_generator=True, **okw)['loss'],
+                    O.phenaki_forward_loss(mg_sd, mgc, cr_sd, crc, flat, only_train_critic=True, **okw)['loss'])
+        for got_f32, ref_b in zip((g['loss'], g['loss_generator'], g['loss_critic']), refs):      # the bf16 oracle stays near the f32 reference
+            assert abs(float(got_f32) - float(ref_b)) <= 3e-2 * abs(float(got_f32))
+    for name, got, ref in (('total', total, refs[0]), ('generator', gen, refs[1]), ('critic', crit, refs[2])):
         assert abs(float(got) - float(ref)) <= tol * abs(float(ref)), f'{name}: {float(got)} vs reference {float(ref)}'
     if dtype == 'fp32' and same_ids:
         via_video = ph(video, text_embeds=ctx, _draws=draws)   # encodes the video live, as the reference call did
@@ -352,7 +430,7 @@ def test_forward_objective_tiny_matches_reference_golden(golden_dir, dtype, tol)
     assert torch.isfinite(a) and float(a) == float(b2)
 
 
-@pytest.mark.parametrize('dtype,tol', [('fp32', 1e-3), ('bf16', 3e-2)])
+@pytest.mark.parametrize('dtype,tol', [('fp32', 1e-3), ('bf16', BF16_TOL)])
 def test_forward_objective_full_config_matches_oracle(dtype, tol):
     """BASELINE geometry (dim 512, depth 6 + 6, vocab 65 536, n = 576): Phenaki.forward against the CPU oracle with the
     same three draws -- the cross entropy comes from the fused vocab head (the (1,576,65536) logits are never written)."""
@@ -364,8 +442,9 @@ def test_forward_objective_full_config_matches_oracle(dtype, tol):
     ctx = weights.synthetic_context(1, 12, 768, seed=1, pad_last=3)
     draws = dict(rand_step=torch.tensor([7]), perm_noise=weights.uniform_noise((1, 576), 710),
                  gumbel_u=weights.uniform_noise((1, 576, 65536), 711))
-    ref = O.phenaki_forward_loss(mg_sd, mgc, cr_sd, crc, ids, patch_shape=(9, 8, 8), context=ctx, steps=FULL['steps'],
-                                 mask_id=65536, **draws)
+    with O.precision(dtype):
+        ref = O.phenaki_forward_loss(mg_sd, mgc, cr_sd, crc, ids, patch_shape=(9, 8, 8), context=ctx, steps=FULL['steps'],
+                                     mask_id=65536, **draws)
     kw = dict(video_codebook_ids=ids.view(1, 9, 8, 8).cuda(), text_embeds=ctx.cuda(), _draws=draws)
     gen_loss = ph(only_train_generator=True, **kw)
     assert abs(float(gen_loss) - float(ref['ce'])) <= tol * float(ref['ce']), (float(gen_loss), float(ref['ce']))
@@ -373,16 +452,31 @@ def test_forward_objective_full_config_matches_oracle(dtype, tol):
     assert abs(float(total) - float(ref['loss'])) <= tol * float(ref['loss']), (float(total), float(ref['loss']))
 
 
-@pytest.mark.parametrize('dtype,tol', [('fp32', 1e-3), ('bf16', 3e-2)])
+@pytest.mark.parametrize('dtype,tol', [('fp32', 1e-3), ('bf16', 2 * BF16_TOL)])
 def test_cvivit_reconstruction_loss_matches_reference_golden(golden_dir, dtype, tol):
     """CViViT.forward's default return with use_vgg_and_gan=False (cvivit.py:585-627, value only) against the real
     reference: plain MSE, MSE over the frames a (b, f) mask keeps, the (loss, recon) pair, and a 4-D image batch;
-    the GAN / VGG branches still refuse loudly."""
+    the GAN / VGG branches still refuse loudly.  bf16 mode: against the oracle in bf16 precision (same ids required: the loss
+    jumps when a near-zero LFQ sign flips, which the C-ViViT tests audit by margin)."""
     g = golden(golden_dir, 'recon_loss_tiny.pt')
     cv, _, _, _ = load_product('tiny', TINY, dtype=dtype, with_critic=False)
     H = TINY['cvivit']['image_size']
     video = weights.synthetic_video(2, 5, H, H, seed=6).cuda()
     rel = lambda a, b: abs(float(a) - float(b)) / abs(float(b))
+    if dtype == 'bf16':
+        cv_sd, _, _ = state_dicts('tiny')
+        cvc, _, _ = oracle_cfgs(TINY)
+        vc = video.cpu()
+        with O.precision('bf16'):
+            ob = dict(loss=O.cvivit_recon_loss(cv_sd, cvc, vc), loss_masked=O.cvivit_recon_loss(cv_sd, cvc, vc, mask=g['mask']),
+                      loss_image=O.cvivit_recon_loss(cv_sd, cvc, vc[:, :, 0]))
+            ids_b = O.cvivit_tokenize(cv_sd, cvc, vc)
+            ob['recon_sum'] = O.cvivit_decode_ids(cv_sd, cvc, ids_b.flatten(1)).double().sum().item()
+        for k in ('loss', 'loss_masked', 'loss_image'):
+            assert rel(ob[k], g[k]) <= 3e-2, f'bf16 oracle {k} drifted from the f32 reference'
+        if not torch.equal(cv(video, return_only_codebook_ids=True).cpu(), ids_b):
+            pytest.skip('an audited near-zero LFQ sign bit differs: the scalar losses are not comparable')
+        g = {**g, **ob}
     assert rel(cv(video), g['loss']) <= tol
     assert rel(cv(video, mask=g['mask'].cuda()), g['loss_masked']) <= tol
     loss, recon = cv(video, return_recons=True)

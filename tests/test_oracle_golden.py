@@ -187,3 +187,33 @@ def test_recon_loss_matches_reference(golden_dir):
     assert abs(float(O.cvivit_recon_loss(cv, cvc, video)) - float(g['loss'])) < 1e-5
     assert abs(float(O.cvivit_recon_loss(cv, cvc, video, mask=g['mask'])) - float(g['loss_masked'])) < 1e-5
     assert abs(float(O.cvivit_recon_loss(cv, cvc, video[:, :, 0])) - float(g['loss_image'])) < 1e-5
+
+
+def test_bf16_precision_mode_is_the_f32_oracle_plus_roundings():
+    """oracle.precision('bf16') only inserts roundings into the pinned f32 oracle: with the rounding hook disabled it IS the
+    f32 oracle (the tiled flash restatement equals the softmax), with it enabled it stays within bf16 distance of it."""
+    cv, mg, cr = state_dicts('tiny')
+    cvc, mgc, crc = oracle_cfgs(TINY)
+    video = weights.synthetic_video(2, 5, 64, 64, seed=0)
+    ids, proj = O.cvivit_tokenize(cv, cvc, video, return_proj=True)
+    with O.precision('bf16'):
+        assert O.is_bf16()
+        ids_b, proj_b = O.cvivit_tokenize(cv, cvc, video, return_proj=True)
+    assert not O.is_bf16()
+    rel = ((proj - proj_b).abs().max() / proj.abs().max()).item()
+    assert 1e-5 < rel < 3e-2, rel
+    assert (ids == ids_b).float().mean().item() > 0.95
+    sim = torch.randn(2, 3, 70, 100, generator=torch.Generator().manual_seed(0)) * 3
+    sim[..., 40:45] = O.NEG_MAX
+    v = torch.randn(2, 3, 100, 64, generator=torch.Generator().manual_seed(1))
+    ref = torch.einsum('bhij,bhjd->bhid', sim.softmax(-1), v)
+    for tk in (32, 64):
+        close(O._flash_bf16(sim, v, tk), ref, 1e-5)          # fp32 mode: _r is the identity
+    tid = torch.randint(0, 257, (2, 48), generator=torch.Generator().manual_seed(1))
+    ctx = weights.synthetic_context(2, 6, 96, seed=1, pad_last=3)
+    kw = dict(cond_scale=5., video_patch_shape=(3, 4, 4), context=ctx, text_mask=(ctx != 0).any(-1))
+    a = O.maskgit_cfg(mg, mgc, tid, **kw)
+    with O.precision('bf16'):
+        b = O.maskgit_cfg(mg, mgc, tid, **kw)
+    rel = ((a - b).abs().max() / a.abs().max()).item()
+    assert 1e-5 < rel < 3e-2, rel

@@ -38,6 +38,48 @@ def ids_equal_with_margin(ids, ids_ref, proj_ref, tol=1e-4, what='ids'):
     return flips
 
 
+def gumbel_noisy(logits, temperature, u):
+    """the value the reference's gumbel_sample takes the argmax of (phenaki_pytorch.py:78-93), U[0,1) draws injected"""
+    g = -torch.log(-torch.log(u + 1e-10) + 1e-10)
+    return logits / max(temperature, 1e-10) + g
+
+
+def argmax_equal_with_margin(pred, pred_ref, noisy_ref, tol=1e-4, what='pred', rows=None):
+    """gumbel-argmax ids (SURVEY.md 7 'margin audit'): a position where `pred` differs from the oracle's `pred_ref` is a
+    failure unless the oracle's own noisy logits rank the two candidates within tol * max|noisy| of each other (a near tie
+    that f32 summation order alone decides).  rows: optional bool (B, n) of the positions that are compared.
+    Returns the number of audited (tolerated) flips."""
+    pred, pred_ref = pred.cpu(), pred_ref.cpu()
+    diff = pred != pred_ref
+    if rows is not None:
+        diff = diff & rows.cpu().bool()
+    bad = diff.nonzero()
+    if bad.numel() == 0:
+        return 0
+    finite = noisy_ref[torch.isfinite(noisy_ref)]
+    scale = finite.abs().max().item()
+    for b, i in bad.tolist():
+        top = noisy_ref[b, i, pred_ref[b, i]].item()
+        got = noisy_ref[b, i, pred[b, i]].item()
+        assert top - got <= tol * scale, (f'{what}: position ({b},{i}) picked id {int(pred[b, i])} with oracle noisy logit {got:.6f}, '
+                                          f'oracle argmax {int(pred_ref[b, i])} has {top:.6f} (gap {top - got:.3e} > {tol:g} * {scale:.3e})')
+    return int(bad.shape[0])
+
+
+def record_parity(name, payload):
+    """append one parity measurement (matched steps, audited flips, max rel error) to gpurun_out/parity.jsonl so the numbers the
+    tests assert on are also on record (copied to profiles/parity_rNN.jsonl)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        os.makedirs(os.path.join(root, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(root, 'gpurun_out', 'parity.jsonl'), 'a') as f:
+            f.write(json.dumps(dict(test=name, **payload)) + '\n')
+    except OSError:
+        pass
+
+
 def load_product(tag, cfgs, device='cuda', with_critic=True, steps=None, dtype='fp32'):
     """product CViViT / MaskGit / TokenCritic / Phenaki filled with the name-keyed weights of oracle/weights.py."""
     import phenaki_pytorch_amd as P
