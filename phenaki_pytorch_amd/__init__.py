@@ -4,10 +4,10 @@ Drop-in names of lucidrains/phenaki-pytorch's public interface (phenaki_pytorch/
 inference path: same constructor signatures, state_dict keys and .forward/.encode/.decode/.sample surfaces;
 the compute is hand-written HIP in libphenaki_hip.so (build: `python -m phenaki_pytorch_amd.build`).
 """
-from .attention import set_compute_dtype
+from .attention import set_compute_dtype, invalidate_packed
 from .cvivit import CViViT
 from .phenaki import MaskGit, TokenCritic, SelfCritic, Phenaki, make_video
 from .dist import shard_batch, sample_sharded, make_video_sharded
 
-__all__ = ['CViViT', 'MaskGit', 'TokenCritic', 'SelfCritic', 'Phenaki', 'make_video', 'set_compute_dtype',
+__all__ = ['CViViT', 'MaskGit', 'TokenCritic', 'SelfCritic', 'Phenaki', 'make_video', 'set_compute_dtype', 'invalidate_packed',
            'shard_batch', 'sample_sharded', 'make_video_sharded']

@@ -79,8 +79,28 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def stream():
-    return torch.cuda.current_stream().cuda_stream
+def f32p(t, name='parameter', rows_ok=False):
+    """device pointer of an f32 parameter / buffer the kernels read as `const float*`: a module that went through
+    .half() / .bfloat16() / .double(), or holds a strided view, must fail here instead of computing garbage."""
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not (t.is_contiguous() or (rows_ok and t.stride(-1) == 1)):
+        raise RuntimeError(f'{name}: the MI355X kernels read this tensor as contiguous float32, got {t.dtype} '
+                           f'{"contiguous" if t.is_contiguous() else "strided"} (keep the module in float32; the compute '
+                           'precision is chosen with set_compute_dtype, not with .half()/.bfloat16())')
+    return t.data_ptr()
+
+
+def stream(t=None):
+    """the HIP stream of the operand's device.  Kernels are launched on the CURRENT device, so an operand living on another
+    GPU of the process is refused (torch.cuda.set_device / one process per GPU) instead of being launched on the wrong stream."""
+    if t is None:
+        return torch.cuda.current_stream().cuda_stream
+    idx = t.device.index
+    if idx is not None and idx != torch.cuda.current_device():
+        raise RuntimeError(f'operand on cuda:{idx} but the current device is cuda:{torch.cuda.current_device()}: '
+                           'call torch.cuda.set_device(...) first (one process per GPU)')
+    return torch.cuda.current_stream(t.device).cuda_stream
 
 
 def require_device(t, name='tensor'):
@@ -106,8 +126,8 @@ def gemm(dtype, A, W, M, N, K, *, C, bias=None, res=None, act=ACT_NONE, a_rows=N
     lda = A.stride(-2) if lda is None else lda
     ldc = C.stride(-2) if ldc is None else ldc
     ldr = res.stride(-2) if res is not None else 0
-    rc = load().pk_gemm_ex(dtype, a_is_f32, ptr(A), lda, ptr(W), W.stride(0), M, N, K, ptr(bias), ptr(res), ldr,
-                           ptr(C), ldc, out_is_f32, act, ptr(a_rows), A.shape[0] if a_rows is not None else M, variant, stream())
+    rc = load().pk_gemm_ex(dtype, a_is_f32, ptr(A), lda, ptr(W), W.stride(0), M, N, K, f32p(bias, 'bias'), f32p(res, 'residual'), ldr,
+                           ptr(C), ldc, out_is_f32, act, ptr(a_rows), A.shape[0] if a_rows is not None else M, variant, stream(C))
     _check(rc, 'pk_gemm_ex')
     return C
 
@@ -116,23 +136,23 @@ def layernorm(x, gamma, beta, M, D, *, out=None, out2=None, raw=None, eps=1e-5, 
     """out (T) / out2 (f32) <- LN(x); raw (T, same type as out) <- x.  remap / perm: output row maps (see the header)."""
     tt = out if out is not None else raw
     out_kind = 1 if (tt is not None and tt.dtype == torch.bfloat16) else 0
-    rc = load().pk_layernorm(ptr(x), x.stride(-2) if ldx is None else ldx, ptr(gamma), ptr(beta), eps,
+    rc = load().pk_layernorm(f32p(x, 'x', rows_ok=True), x.stride(-2) if ldx is None else ldx, f32p(gamma, 'LayerNorm gamma'), f32p(beta, 'LayerNorm beta'), eps,
                              ptr(out), out.stride(-2) if out is not None else 0, out_kind,
                              ptr(out2), out2.stride(-2) if out2 is not None else 0,
-                             ptr(raw), raw.stride(-2) if raw is not None else 0, M, D, *remap, *perm, stream())
+                             ptr(raw), raw.stride(-2) if raw is not None else 0, M, D, *remap, *perm, stream(x))
     _check(rc, 'pk_layernorm')
 
 
 def patchify_ln(video, f0, nt, pt, ph, pw, weight, bias, out, eps=1e-5):
     B, C, F, H, W = video.shape
-    rc = load().pk_patchify_ln(ptr(video), B, C, F, H, W, f0, nt, pt, ph, pw, ptr(weight), ptr(bias), eps,
-                               ptr(out), out.stride(0), 1 if out.dtype == torch.bfloat16 else 0, stream())
+    rc = load().pk_patchify_ln(f32p(video, 'video'), B, C, F, H, W, f0, nt, pt, ph, pw, f32p(weight, 'LayerNorm weight'), f32p(bias, 'LayerNorm bias'), eps,
+                               ptr(out), out.stride(0), 1 if out.dtype == torch.bfloat16 else 0, stream(video))
     _check(rc, 'pk_patchify_ln')
 
 
 def unpatchify(pix, video, f0, nt, pt, ph, pw):
     B, C, F, H, W = video.shape
-    rc = load().pk_unpatchify(ptr(pix), pix.stride(0), ptr(video), B, C, F, H, W, f0, nt, pt, ph, pw, stream())
+    rc = load().pk_unpatchify(ptr(pix), pix.stride(0), ptr(video), B, C, F, H, W, f0, nt, pt, ph, pw, stream(video))
     _check(rc, 'pk_unpatchify')
 
 
@@ -142,34 +162,34 @@ def sqdiff_sum(a, b, frame_mask=None):
     lib = load()
     partials = torch.empty((1024,), device=a.device, dtype=torch.float64)            # PK_SQDIFF_BLOCKS
     fm = frame_mask.to(torch.uint8).contiguous() if frame_mask is not None else None
-    _check(lib.pk_sqdiff_partials(ptr(a), ptr(b), ptr(fm), B, C, F, H, W, ptr(partials), stream()), 'pk_sqdiff_partials')
+    _check(lib.pk_sqdiff_partials(ptr(a), ptr(b), ptr(fm), B, C, F, H, W, ptr(partials), stream(a)), 'pk_sqdiff_partials')
     return partials.sum()
 
 
 def peg(x, wt, bias, out, B, T, H, W, D, causal):
-    rc = load().pk_peg(ptr(x), ptr(wt), ptr(bias), ptr(out), B, T, H, W, D, 1 if causal else 0, stream())
+    rc = load().pk_peg(f32p(x, 'x', rows_ok=True), f32p(wt, 'PEG weight'), f32p(bias, 'PEG bias'), ptr(out), B, T, H, W, D, 1 if causal else 0, stream(x))
     _check(rc, 'pk_peg')
 
 
 def lfq_encode(x, wp, bp, ids, proj, M, D, cd):
-    rc = load().pk_lfq_encode(ptr(x), x.stride(-2), ptr(wp), ptr(bp), ptr(ids), ptr(proj), M, D, cd, stream())
+    rc = load().pk_lfq_encode(ptr(x), x.stride(-2), f32p(wp, 'LFQ project_in.weight'), f32p(bp, 'LFQ project_in.bias'), ptr(ids), ptr(proj), M, D, cd, stream(x))
     _check(rc, 'pk_lfq_encode')
 
 
 def lfq_decode(ids, wo, bo, out, M, D, cd):
-    rc = load().pk_lfq_decode(ptr(ids), ptr(wo), ptr(bo), ptr(out), M, D, cd, stream())
+    rc = load().pk_lfq_decode(ptr(ids), f32p(wo, 'LFQ project_out.weight'), f32p(bo, 'LFQ project_out.bias'), ptr(out), M, D, cd, stream(out))
     _check(rc, 'pk_lfq_decode')
 
 
 def embed(ids, tok, pos, out, rows, n, D):
-    rc = load().pk_embed(ptr(ids), ptr(tok), ptr(pos), ptr(out), rows, n, D, stream())
+    rc = load().pk_embed(ptr(ids), f32p(tok, 'token_emb.weight'), f32p(pos, 'pos_emb.weight'), ptr(out), rows, n, D, stream(out))
     _check(rc, 'pk_embed')
 
 
 def cpb_input(w0, b0, out, dims, D):
     nd = len(dims)
     d = (1,) * (3 - nd) + tuple(dims)
-    rc = load().pk_cpb_input(ptr(w0), ptr(b0), ptr(out), d[0], d[1], d[2], nd, D, stream())
+    rc = load().pk_cpb_input(ptr(w0), ptr(b0), ptr(out), d[0], d[1], d[2], nd, D, stream(out))
     _check(rc, 'pk_cpb_input')
 
 
@@ -180,14 +200,14 @@ def attn_pads(nq, n_kv, nnull):
 
 
 def attn_prep(dtype, q, kv, null_kv, q_scale, k_scale, scale, Qp, Kp, Vt, S, h, nq, n_kv, nnull):
-    rc = load().pk_attn_prep(dtype, ptr(q), q.stride(-2), ptr(kv), kv.stride(-2) if kv is not None else 0, ptr(null_kv) if nnull else None,
-                             ptr(q_scale), ptr(k_scale), scale, ptr(Qp), ptr(Kp), ptr(Vt), S, h, nq, n_kv, nnull, stream())
+    rc = load().pk_attn_prep(dtype, ptr(q), q.stride(-2), ptr(kv), kv.stride(-2) if kv is not None else 0, f32p(null_kv, 'null_kv') if nnull else None,
+                             f32p(q_scale, 'q_scale'), f32p(k_scale, 'k_scale'), scale, ptr(Qp), ptr(Kp), ptr(Vt), S, h, nq, n_kv, nnull, stream(q))
     _check(rc, 'pk_attn_prep')
 
 
 def qkv_project(xq, xkv, wq, wkv, S, nseq, h, K, q_scale, k_scale, scale, Qp, Kp, Vt, nq_pad, nk_pad):
-    rc = load().pk_qkv_project(ptr(xq), ptr(xkv), xq.stride(-2), ptr(wq), ptr(wkv), wq.stride(0), S, nseq, h, K, ptr(q_scale),
-                                ptr(k_scale), scale, ptr(Qp), ptr(Kp), ptr(Vt), nq_pad, nk_pad, stream())
+    rc = load().pk_qkv_project(ptr(xq), ptr(xkv), xq.stride(-2), ptr(wq), ptr(wkv), wq.stride(0), S, nseq, h, K, f32p(q_scale, 'q_scale'),
+                                f32p(k_scale, 'k_scale'), scale, ptr(Qp), ptr(Kp), ptr(Vt), nq_pad, nk_pad, stream(xq))
     _check(rc, 'pk_qkv_project')
 
 
@@ -196,23 +216,23 @@ def attn_fwd(dtype, Qp, Kp, Vt, O, S, h, nq, n_kv, nnull, *, bias=None, kmask=No
         bh, bld = bias.stride(0), bias.stride(1)
     else:
         bh, bld = 0, 0
-    rc = load().pk_attn_fwd(dtype, ptr(Qp), ptr(Kp), ptr(Vt), ptr(bias), bh, bld, ptr(kmask), ptr(slopes),
+    rc = load().pk_attn_fwd(dtype, ptr(Qp), ptr(Kp), ptr(Vt), ptr(bias), bh, bld, ptr(kmask), f32p(slopes, 'ALiBi slopes'),
                             1 if causal else 0, ptr(O), O.stride(-2), 1 if O.dtype == torch.float32 else 0,
-                            S, h, nq, n_kv, nnull, stream())
+                            S, h, nq, n_kv, nnull, stream(O))
     _check(rc, 'pk_attn_fwd')
 
 
 def attn_small(q, kv, q_scale, k_scale, scale, O, S, h, n, *, bias=None, kmask=None, slopes=None, causal=False):
     bh, bld = (bias.stride(0), bias.stride(1)) if bias is not None else (0, 0)
-    rc = load().pk_attn_small(ptr(q), q.stride(-2), ptr(kv), kv.stride(-2), ptr(q_scale), ptr(k_scale), scale, ptr(bias), bh, bld,
-                              ptr(kmask), ptr(slopes), 1 if causal else 0, ptr(O), O.stride(-2),
-                              1 if O.dtype == torch.bfloat16 else 0, S, h, n, stream())
+    rc = load().pk_attn_small(ptr(q), q.stride(-2), ptr(kv), kv.stride(-2), f32p(q_scale, 'q_scale'), f32p(k_scale, 'k_scale'), scale, ptr(bias), bh, bld,
+                              ptr(kmask), f32p(slopes, 'ALiBi slopes'), 1 if causal else 0, ptr(O), O.stride(-2),
+                              1 if O.dtype == torch.bfloat16 else 0, S, h, n, stream(q))
     _check(rc, 'pk_attn_small')
 
 
 def cfg_mix(x, nb, n_tot, n_prime, rows, nrows, scale, has_null, out, D):
     rc = load().pk_cfg_mix(ptr(x), x.stride(-2), nb, n_tot, n_prime, ptr(rows), nrows, scale, 1 if has_null else 0,
-                           ptr(out), out.stride(-2), 1 if out.dtype == torch.float32 else 0, D, stream())
+                           ptr(out), out.stride(-2), 1 if out.dtype == torch.float32 else 0, D, stream(x))
     _check(rc, 'pk_cfg_mix')
 
 
@@ -221,36 +241,36 @@ def vocab_ntiles(V):
 
 
 def l2norm_rows(x, out, M, D):
-    rc = load().pk_l2norm_rows(ptr(x), x.stride(-2), ptr(out), out.stride(-2), 1 if out.dtype == torch.bfloat16 else 0, M, D, stream())
+    rc = load().pk_l2norm_rows(ptr(x), x.stride(-2), ptr(out), out.stride(-2), 1 if out.dtype == torch.bfloat16 else 0, M, D, stream(x))
     _check(rc, 'pk_l2norm_rows')
 
 
 def vocab_sample(dtype, A, W, bias, M, V, D, temperature, U, rows, seed, need_lse, partials, no_noise=False):
-    rc = load().pk_vocab_sample(dtype, ptr(A), A.stride(-2), ptr(W), W.stride(0), ptr(bias), M, V, D, temperature,
+    rc = load().pk_vocab_sample(dtype, ptr(A), A.stride(-2), ptr(W), W.stride(0), f32p(bias, 'to_logits.bias'), M, V, D, temperature,
                                 ptr(U), ptr(rows), seed & 0xFFFFFFFFFFFFFFFF, (1 if need_lse else 0) | (2 if no_noise else 0),
-                                ptr(partials), stream())
+                                ptr(partials), stream(A))
     _check(rc, 'pk_vocab_sample')
 
 
 def vocab_reduce(partials, M, V, rows, mask, ids, pred, scores, need_lse):
     rc = load().pk_vocab_reduce(ptr(partials), M, V, ptr(rows), ptr(mask), ptr(ids), ptr(pred), ptr(scores),
-                                1 if need_lse else 0, stream())
+                                1 if need_lse else 0, stream(partials))
     _check(rc, 'pk_vocab_reduce')
 
 
 def vocab_ce(dtype, partials, M, V, A, W, bias, D, targets, rows, loss):
     """loss[m] = lse(logits[m]) - logits[m][targets[rows[m]]] from the partials of vocab_sample(..., need_lse=True)."""
-    rc = load().pk_vocab_ce(dtype, ptr(partials), M, V, ptr(A), A.stride(-2), ptr(W), W.stride(0), ptr(bias), D,
-                            ptr(targets), ptr(rows), ptr(loss), stream())
+    rc = load().pk_vocab_ce(dtype, ptr(partials), M, V, ptr(A), A.stride(-2), ptr(W), W.stride(0), f32p(bias, 'to_logits.bias'), D,
+                            ptr(targets), ptr(rows), ptr(loss), stream(A))
     _check(rc, 'pk_vocab_ce')
 
 
 def topk_mask(scores, B, n, k, mask_id, mask, ids, rows_out=None):
-    rc = load().pk_topk_mask(ptr(scores), B, n, k, mask_id, ptr(mask), ptr(ids), ptr(rows_out), stream())
+    rc = load().pk_topk_mask(ptr(scores), B, n, k, mask_id, ptr(mask), ptr(ids), ptr(rows_out), stream(scores))
     _check(rc, 'pk_topk_mask')
 
 
 def critic_head(x, w, b, D, nb, n_tot, n_prime, has_null, scale, u, noise_mult, out):
-    rc = load().pk_critic_head(ptr(x), x.stride(-2), ptr(w), ptr(b), D, nb, n_tot, n_prime, 1 if has_null else 0, scale,
-                               ptr(u), noise_mult, ptr(out), stream())
+    rc = load().pk_critic_head(ptr(x), x.stride(-2), f32p(w, 'critic head weight'), f32p(b, 'critic head bias'), D, nb, n_tot, n_prime, 1 if has_null else 0, scale,
+                               ptr(u), noise_mult, ptr(out), stream(x))
     _check(rc, 'pk_critic_head')

@@ -70,12 +70,47 @@ def _cache(module):
     return c
 
 
+def invalidate_packed(module):
+    """drop every packed / cached device copy derived from `module`'s parameters (packed GEMM weights, PEG taps, position-bias
+    tables, cached biases): they are rebuilt on the next call.  The caches key on (data_ptr, _version, device) of the source
+    parameters, which catches optimizer steps, load_state_dict (also hooked below) and .to(); in-place writes through `.data`
+    (`p.data.copy_`, `p.data.lerp_` -- ema-pytorch, weight surgery) do NOT bump `_version`: call this after them."""
+    for m in module.modules():
+        m.__dict__.pop('_pk_cache', None)
+    return module
+
+
+class PackedModule(nn.Module):
+    """nn.Module whose packed-weight caches (and those of its children) are dropped by load_state_dict and by every _apply
+    (.to / .cuda / .float ...)."""
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        invalidate_packed(self)
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        invalidate_packed(self)
+        return out
+
+
+def refuse_autograd(module, what):
+    """the MI355X build computes loss VALUES only (no backward kernels yet): a caller that expects to
+    `.backward()` through `what` -- grad mode on and trainable parameters -- gets an error here instead of a silent no-op."""
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        raise RuntimeError(f'{what} returns the value of the objective without an autograd graph on the MI355X build (forward '
+                           'kernels only): evaluate it under torch.no_grad(); training needs the reference implementation')
+
+
 def pack_linear_weight(w, dtype):
     """(N, K) f32 -> (N, Kpad) T with K zero-padded to the GEMM k-tile (64 bf16 / 32 f32): the LDS-DMA main loop
     relies on that zero padding to neutralise the K tail of A."""
     q = 64 if dtype == L.BF16 else 32
     n, k = w.shape
     kp = round_up(k, q)
+    if dtype == L.F32 and kp == k and w.dtype == torch.float32 and w.is_contiguous():
+        return w.detach()              # exact-f32 mode, K already a multiple of the k-tile: the LIVE weight, no copy to go stale
     out = torch.zeros((n, kp), device=w.device, dtype=L.tdtype(dtype))
     out[:, :k] = w.detach().to(out.dtype)
     return out
@@ -170,7 +205,7 @@ def FeedForward(dim, mult=4, dropout=0.):
     )
 
 
-class PEG(nn.Module):
+class PEG(PackedModule):
     """attention.py:57-85 : depthwise Conv3d(dim, dim, 3, groups=dim) on the raw (b,t,h,w,d) reinterpretation."""
 
     def __init__(self, dim, causal=False):
@@ -221,7 +256,7 @@ class AlibiPositionalBias(nn.Module):
         return pow2_slopes(c) + pow2_slopes(2 * c)[0::2][:heads - c]
 
 
-class ContinuousPositionBias(nn.Module):
+class ContinuousPositionBias(PackedModule):
     """attention.py:229-275 : MLP over log-spaced relative positions -> (heads, n, n).
     The MLP always runs in exact f32 (the reference forces rel_pos.float()), and the result is cached per
     (weights, dims): the weights are frozen during sampling, the reference recomputes it every forward."""
@@ -289,7 +324,7 @@ def _vt_buffer(numel, dev, td, padded):
     return ws
 
 
-class Attention(nn.Module):
+class Attention(PackedModule):
     """attention.py:89-182."""
 
     def __init__(self, dim, dim_context=None, dim_head=64, heads=8, causal=False, num_null_kv=0,
@@ -417,7 +452,7 @@ class Attention(nn.Module):
         return (out - x2).reshape(x.shape)
 
 
-class Transformer(nn.Module):
+class Transformer(PackedModule):
     """attention.py:279-332 : per layer [PEG?, self Attention, cross Attention?, FeedForward], each + residual; norm_out."""
 
     def __init__(self, dim, *, depth, dim_context=None, causal=False, dim_head=64, heads=8, ff_mult=4, peg=False,

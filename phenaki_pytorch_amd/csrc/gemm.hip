@@ -130,11 +130,15 @@ static int launch_v1(const GemmOperands& p, const GemmEpilogue& e, hipStream_t s
 template <typename T, int TM, int TN, int STAGES, int WM = 2, int WN = 2, int ROWB = 128, int PW = 0>
 static int launch_dma(const GemmOperands& p, const GemmEpilogue& e, int a_nrows, hipStream_t s) {
     using Tile = GemmDma<T, TM, TN, WM, WN, STAGES, ROWB, PW>;
-    static bool attr_set = false;
-    if (!attr_set && Tile::SMEM > 65536) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel<T, TM, TN, WM, WN, STAGES, ROWB, PW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, Tile::SMEM) != hipSuccess) return PK_ELAUNCH;
-        attr_set = true;
+    if (Tile::SMEM > 65536) {                              // opt-in to > 64 KB of LDS: per kernel AND per device of the process
+        static bool attr_set[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PK_ELAUNCH;
+        if (!attr_set[dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel<T, TM, TN, WM, WN, STAGES, ROWB, PW>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, Tile::SMEM) != hipSuccess) return PK_ELAUNCH;
+            attr_set[dev] = true;
+        }
     }
     const int MT = (p.M + Tile::BM - 1) / Tile::BM, NT = (p.N + Tile::BN - 1) / Tile::BN;
     dim3 grid(8 * ((MT + 7) / 8) * NT);                   // see the XCD-aware tile map in the kernel

@@ -9,8 +9,11 @@
 //   ROWB = 128 (k-tile of 64 bf16 / 32 f32): slot ^ (row & 7)
 //   ROWB = 64  (k-tile of 32 bf16; half the LDS per stage -> 5 workgroups of a 128x128 tile per CU):
 //               slot ^ {0,2,3,1}[(row >> 2) & 3]   (conflict-free for the gfx950 ds_read_b128 16-lane groups)
-// Rows past M / N and bytes past the end of a matrix are fetched through the buffer descriptor's bounds check
-// (they read as 0); the K tail of A multiplies the zero padding of W.
+// Rows past M / N are fetched through the buffer descriptor's bounds check (their per-lane offset is the descriptor size:
+// they read as 0).  The K tail (K not a multiple of the k-tile) is cut the same way: in the LAST k-tile every 16-byte piece
+// that starts at or beyond K is pointed out of bounds, so A never reads into its next row (a NaN / Inf there would survive the
+// multiplication with W's zero padding) or past the end of its allocation.  The k-tile advance goes through the scalar
+// offset, which the bounds check does not include -- hence the explicit per-lane redirect instead of relying on it.
 #pragma once
 #include "gemm_core.hpp"
 
@@ -109,14 +112,17 @@ struct GemmDma {
         // index inside its XCD) spreads the concurrent slabs over all channels; the sum over k only changes order.
         const int nt = (p.K + BK - 1) / BK;
         const int rot = (p.krot && nt > 1) ? (int)(((blockIdx.x >> 3) + blockIdx.y) % (unsigned)nt) : 0;
+        const int ktail_bytes = (p.K * SZ) % ROWB;                    // bytes of the last k-tile that exist (0: K is a multiple of BK)
+        const bool slot_in_tail = ktail_bytes == 0 || srcslot * 16 < ktail_bytes;      // K % (16 / SZ) == 0 (host check): whole pieces
         auto issue = [&](int kt, int slot) {
             char* base = smem + slot * STAGE_BYTES;
             int kk = kt + rot;
             if (kk >= nt) kk -= nt;
             const int koff = kk * ROWB;
+            const bool cut = kk == nt - 1 && !slot_in_tail;          // this lane's piece of the last k-tile lies beyond K
 #pragma unroll
             for (int i = 0; i < IA; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(base + (wave * IA + i) * 1024), 16, offA[i], koff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(base + (wave * IA + i) * 1024), 16, cut ? bytesA : offA[i], koff, 0, 0);
 #pragma unroll
             for (int i = 0; i < IW; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(base + BM * ROWB + (wave * IW + i) * 1024), 16, offW[i], koff, 0, 0);

@@ -13,8 +13,8 @@ import torch
 from torch import nn
 
 from . import _lib as L
-from .attention import (ContinuousPositionBias, Transformer, compute_dtype_of, exists, linear_weight,
-                        set_compute_dtype)
+from .attention import (ContinuousPositionBias, PackedModule, Transformer, compute_dtype_of, exists, invalidate_packed,
+                        linear_weight, refuse_autograd, set_compute_dtype)
 from .quantize import LFQ, VectorQuantize
 
 
@@ -33,7 +33,7 @@ class _Rearrange(nn.Identity):
     the layout change is fused into pk_patchify_ln / pk_unpatchify)."""
 
 
-class CViViT(nn.Module):
+class CViViT(PackedModule):
     def __init__(self, *, dim, codebook_size, image_size, patch_size, temporal_patch_size, spatial_depth,
                  temporal_depth, discr_base_dim=16, dim_head=64, heads=8, channels=3, use_vgg_and_gan=True,
                  vgg=None, discr_attn_res_layers=(16,), use_hinge_loss=True, attn_dropout=0., ff_dropout=0.,
@@ -127,8 +127,7 @@ class CViViT(nn.Module):
 
     def copy_for_eval(self):
         device = next(self.parameters()).device
-        for m in self.modules():                      # packed device weights are rebuilt lazily, never copied
-            m.__dict__.pop('_pk_cache', None)
+        invalidate_packed(self)                       # packed device weights are rebuilt lazily, never copied
         vae_copy = copy.deepcopy(self)
         if vae_copy.use_vgg_and_gan:
             vae_copy.discr = None
@@ -139,7 +138,7 @@ class CViViT(nn.Module):
     def load_state_dict(self, state_dict, *args, **kwargs):
         # reference checkpoints may carry the GAN / VGG parts (cvivit.py:35-49, 336-363): not used here
         sd = {k: v for k, v in state_dict.items() if not (k.startswith('vgg.') or k.startswith('discr.'))}
-        return super().load_state_dict(sd, *args, **kwargs)
+        return super().load_state_dict(sd, *args, **kwargs)            # PackedModule: also drops the packed weight caches
 
     def load(self, path):
         path = Path(path)
@@ -277,9 +276,16 @@ class CViViT(nn.Module):
             return ids.view(B, T, h, w), proj.view(B, T * h * w, -1)
         return self.vq.encode_ids(tokens).view(B, T, h, w)
 
-    @torch.no_grad()
     def forward(self, video, mask=None, return_recons=False, return_recons_only=False, return_discr_loss=False,
                 apply_grad_penalty=True, return_only_codebook_ids=False):
+        if not (return_only_codebook_ids or return_recons_only):
+            refuse_autograd(self, 'CViViT.forward (reconstruction loss)')
+        return self._forward(video, mask, return_recons, return_recons_only, return_discr_loss, apply_grad_penalty,
+                             return_only_codebook_ids)
+
+    @torch.no_grad()
+    def _forward(self, video, mask=None, return_recons=False, return_recons_only=False, return_discr_loss=False,
+                 apply_grad_penalty=True, return_only_codebook_ids=False):
         assert video.ndim in {4, 5}
         is_image = video.ndim == 4
         if is_image:

@@ -18,8 +18,8 @@ import torch
 from torch import nn
 
 from . import _lib as L
-from .attention import (ContinuousPositionBias, Transformer, compute_dtype_of, exists, default, linear_weight,
-                        set_compute_dtype)
+from .attention import (ContinuousPositionBias, PackedModule, Transformer, compute_dtype_of, exists, default, linear_weight,
+                        refuse_autograd, set_compute_dtype)
 from .cvivit import CViViT
 from .t5 import t5_encode_text, get_encoded_dim, DEFAULT_T5_NAME
 
@@ -63,7 +63,7 @@ def _u8(mask):
     return None if mask is None else mask.to(torch.uint8).contiguous()
 
 
-class _TokenTrunk(nn.Module):
+class _TokenTrunk(PackedModule):
     """shared plumbing of MaskGit / TokenCritic: ids -> embeddings -> Transformer -> norm_out rows."""
 
     def _embed(self, ids2d):
@@ -240,7 +240,7 @@ class TokenCritic(_TokenTrunk):
         return self._scores(x, vps, context, text_mask, video_mask, 1., False)
 
 
-class SelfCritic(nn.Module):
+class SelfCritic(PackedModule):
     """phenaki_pytorch.py:306-336 : MaskGit embeddings -> Linear(dim, 1)."""
 
     def __init__(self, maskgit: MaskGit):
@@ -284,7 +284,7 @@ class SelfCritic(nn.Module):
         return out
 
 
-class Phenaki(nn.Module):
+class Phenaki(PackedModule):
     def __init__(self, *, maskgit: MaskGit, cvivit: CViViT, critic=None, steps=18, t5_name=DEFAULT_T5_NAME,
                  sample_temperature=0., text_embed_dim=None, cond_drop_prob=0.25, max_text_len=128,
                  self_token_critic=False, critic_loss_weight=1., critic_noise_anneal_schedule='decay',
@@ -323,9 +323,14 @@ class Phenaki(nn.Module):
                             noise_K=noise_K)
         return video.squeeze(2)
 
+    def forward(self, *args, **kwargs):
+        """phenaki_pytorch.py:562-687, value only -- see `objective_value`; refuses to run where a caller could expect gradients."""
+        refuse_autograd(self, 'Phenaki.forward')
+        return self.objective_value(*args, **kwargs)
+
     @torch.no_grad()
-    def forward(self, videos=None, *, texts=None, video_codebook_ids=None, video_frame_mask=None, text_embeds=None,
-                cond_drop_prob=None, only_train_generator=False, only_train_critic=False, _draws=None):
+    def objective_value(self, videos=None, *, texts=None, video_codebook_ids=None, video_frame_mask=None, text_embeds=None,
+                        cond_drop_prob=None, only_train_generator=False, only_train_critic=False, _draws=None):
         """phenaki_pytorch.py:562-687 -- the VALUE of the training objective (masked-token cross entropy + weighted
         token-critic BCE).  Forward only: the result carries no autograd graph (the backward kernels are SURVEY.md 8f
         "next").  The 65 536-way logits are never written: pk_vocab_sample draws the critic's input ids and leaves the
@@ -334,6 +339,7 @@ class Phenaki(nn.Module):
         _draws (tests): dict(rand_step (b,), perm_noise (b,n) U[0,1), gumbel_u (b,n,V) U[0,1)) replaces the three
         random draws of the reference (:620, :626 -> :43-55, :653)."""
         assert not (only_train_generator and only_train_critic)
+        assert not (only_train_critic and not exists(self.critic)), 'only_train_critic needs a critic (Phenaki(critic=...) or self_token_critic=True)'
         assert exists(videos) ^ exists(video_codebook_ids), 'either raw video or video codebook ids must be given'
         assert not (exists(videos) and not exists(self.cvivit)), 'cvivit must be provided if one wants to encode the videos live during training'
         assert (exists(text_embeds) ^ exists(texts)) ^ self.unconditional, \

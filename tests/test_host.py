@@ -15,6 +15,7 @@ from oracle import phenaki_oracle as O
 from oracle.configs import TINY, FULL
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+torch.set_grad_enabled(False)      # inference surface; the loss-value forwards refuse to run where a caller could expect gradients
 
 
 @pytest.fixture(scope='module')
@@ -182,3 +183,55 @@ def test_sharded_sampling_world_size_2_gloo(n_items):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_packed_weight_cache_invalidation_and_pointer_checks():
+    """packed weights must not go stale silently, and parameter pointers are dtype / layout checked."""
+    import phenaki_pytorch_amd as P
+    from phenaki_pytorch_amd import _lib
+    from phenaki_pytorch_amd.attention import _cache, linear_weight, pack_linear_weight
+    mg = P.MaskGit(**TINY['maskgit'])
+    lin = mg.to_logits
+    w1 = linear_weight(lin, _lib.BF16)
+    assert w1.dtype == torch.bfloat16 and linear_weight(lin, _lib.BF16) is w1
+    with torch.no_grad():
+        lin.weight.mul_(2.)                                   # an optimizer-style in-place update bumps _version
+    w2 = linear_weight(lin, _lib.BF16)
+    assert w2 is not w1 and torch.equal(w2[:, :lin.weight.shape[1]].float(), lin.weight.detach().to(torch.bfloat16).float())
+    lin.weight.data.mul_(0.5)                                 # a .data write does not: explicit invalidation is the contract
+    assert linear_weight(lin, _lib.BF16) is w2
+    P.invalidate_packed(mg)
+    w3 = linear_weight(lin, _lib.BF16)
+    assert w3 is not w2 and torch.equal(w3[:, :lin.weight.shape[1]].float(), lin.weight.detach().to(torch.bfloat16).float())
+    mg.load_state_dict(mg.state_dict())                       # load_state_dict drops the caches of the whole tree
+    assert '_pk_cache' not in lin.__dict__
+    linear_weight(lin, _lib.BF16)
+    mg.float()                                                # so does every _apply (.to / .cuda / .float)
+    assert '_pk_cache' not in lin.__dict__
+    # exact-f32 mode with K a multiple of the k-tile hands the kernel the LIVE weight (nothing to go stale)
+    assert pack_linear_weight(lin.weight, _lib.F32).data_ptr() == lin.weight.data_ptr()
+    # parameters reach the kernels as raw pointers: non-f32 or strided ones are refused
+    with pytest.raises(RuntimeError, match='contiguous float32'):
+        _lib.f32p(torch.zeros(4, dtype=torch.float16), 'gamma')
+    with pytest.raises(RuntimeError, match='contiguous float32'):
+        _lib.f32p(torch.zeros(4, 4)[:, 1], 'gamma')
+    assert _lib.f32p(torch.zeros(4, 8)[:, :4], 'x', rows_ok=True) and _lib.f32p(None) is None
+
+
+def test_loss_value_forwards_refuse_autograd():
+    """Phenaki.forward / CViViT.forward return loss VALUES; with grad mode on and trainable parameters they raise
+    instead of returning a tensor whose .backward() would fail later; only_train_critic needs a critic."""
+    import phenaki_pytorch_amd as P
+    cv = P.CViViT(use_vgg_and_gan=False, **TINY['cvivit'])
+    mg = P.MaskGit(**TINY['maskgit'])
+    ph = P.Phenaki(maskgit=mg, cvivit=cv, text_embed_dim=96)
+    with torch.enable_grad():
+        with pytest.raises(RuntimeError, match='without an autograd graph'):
+            cv(torch.randn(1, 3, 5, 64, 64))
+        with pytest.raises(RuntimeError, match='without an autograd graph'):
+            ph(video_codebook_ids=torch.zeros(1, 3, 4, 4, dtype=torch.long), text_embeds=torch.randn(1, 4, 96))
+        with pytest.raises(RuntimeError, match='no CPU fallback'):      # the ids path has no loss: not refused, reaches the device check
+            cv(torch.randn(1, 3, 5, 64, 64), return_only_codebook_ids=True)
+    with torch.no_grad():
+        with pytest.raises(AssertionError, match='needs a critic'):
+            ph(video_codebook_ids=torch.zeros(1, 3, 4, 4, dtype=torch.long), text_embeds=torch.randn(1, 4, 96), only_train_critic=True)
