@@ -86,12 +86,22 @@ int pk_lfq_encode(const float* x, int ldx, const float* wp, const float* bp, lon
                   int M, int D, int cd, void* stream);
 int pk_lfq_decode(const long long* ids, const float* wo, const float* bo, float* out, int M, int D, int cd, void* stream);
 
+/* cvivit.py:472 (the encoder's final norm_out) fused with the LFQ of cvivit.py:570: ids[orow] = LFQ(LayerNorm(x[row]) * gamma
+ * (+ beta)) in one pass over x, cd <= 16; orow = the (a, b, c) -> (a, c, b) row permutation of pk_layernorm (pb = 0: identity).
+ * tokens (f32 [M][ldt], or NULL) receives the normalised rows, proj ([M][cd], or NULL) the pre-sign projections. */
+int pk_layernorm_lfq(const float* x, int ldx, const float* gamma, const float* beta, float eps, const float* wp,
+                     const float* bp, long long* ids, float* tokens, int ldt, float* proj, int M, int D, int cd,
+                     int pb, int pc, void* stream);
+
 /* rows of x scaled to unit l2 norm (F.normalize, eps 1e-12), out in T (out_kind 1) or f32: the query side of the cosine-sim
  * VectorQuantize lookup (cvivit.py:321). */
 int pk_l2norm_rows(const float* x, int ldx, void* out, int ldo, int out_kind, int M, int D, void* stream);
 
-/* phenaki_pytorch.py:194-197, 290-291: out[r] = token_emb[ids[r]] + pos_emb[r % n]. */
-int pk_embed(const long long* ids, const float* tok, const float* pos, float* out, int rows, int n, int D, void* stream);
+/* phenaki_pytorch.py:194-197, 290-291 (+ the prime-token concat of :500): S sequences of n_tot = n_prime + n positions,
+ * out[s*n_tot + i] = token_emb[id] + pos_emb[i] with id = ids_prime[b][i] for i < n_prime (NULL if n_prime == 0), else
+ * ids[b][i - n_prime], b = s % nb -- the cond and null replicas of a classifier-free-guidance batch (S = 2 nb) share ids. */
+int pk_embed(const long long* ids_prime, int n_prime, const long long* ids, int n, int nb, const float* tok,
+             const float* pos, float* out, int S, int D, void* stream);
 
 /* attention.py:257-272 first CPB layer: out[(i,j)][D] = leaky_relu(W0 @ (sign(rel) log(|rel|+1)) + b0, 0.1) over the
  * flattened (d0,d1,d2) grid; nd = 2 uses (d1,d2) with d0 = 1. */
@@ -134,15 +144,16 @@ int pk_cfg_mix(const float* x, int ldx, int nb, int n_tot, int n_prime, const in
 
 /* phenaki_pytorch.py:213 + 88-93 + 506-509 + 547-550, never materialising logits: per row
  * pred = argmax(logits / max(T,1e-10) + gumbel(U)), optional (max, sum exp) for 1 - softmax[pred].
- * U != NULL: PARITY mode, uniform noise read from U[row][V]; U == NULL: counter-hash noise from `seed`.
+ * U != NULL: PARITY mode, uniform noise read from U[row][V]; U == NULL: counter-hash noise from `seed` (+ *seed_dev when
+ * seed_dev != NULL: a device-resident 64-bit word read at run time, so a captured hipGraph replays with fresh noise).
  * need_lse is a flag word: bit 0 = keep the softmax statistics, bit 1 = no noise at all (plain argmax of A @ W^T + bias:
  * the cosine-sim codebook lookup of the VectorQuantize path, cvivit.py:321,568-570).
  * partials: 5 * pk_vocab_ntiles(V) * M 4-byte words of workspace consumed by pk_vocab_reduce, which writes
  * pred[r], ids[r] = where(mask[r], pred, ids[r]) and scores[r] = where(mask[r], 1 - p, -1e4). */
 int pk_vocab_ntiles(int V);
 int pk_vocab_sample(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, int M, int V, int D,
-                    float temperature, const float* U, const int* rows, unsigned long long seed, int need_lse,
-                    void* partials, void* stream);
+                    float temperature, const float* U, const int* rows, unsigned long long seed,
+                    const unsigned long long* seed_dev, int need_lse, void* partials, void* stream);
 int pk_vocab_reduce(const void* partials, int M, int V, const int* rows, const unsigned char* mask, long long* ids,
                     long long* pred, float* scores, int need_lse, void* stream);
 
@@ -154,13 +165,17 @@ int pk_vocab_ce(int dtype, const void* partials, int M, int V, const void* A, in
 
 /* phenaki_pytorch.py:488-491: mask = zeros.scatter(1, scores.topk(k).indices, 1).bool(); ids = where(mask, mask_id, ids).
  * rows_out (B*k int32, or NULL) receives the flat positions b*n + i of the masked tokens: only those rows need the vocab
- * head in this step (pk_cfg_mix / pk_vocab_sample / pk_vocab_reduce take it as `rows`). */
+ * head in this step (pk_cfg_mix / pk_vocab_sample / pk_vocab_reduce take it as `rows`).  scores_next (B*n, or NULL; must
+ * not alias scores) is filled with -1e4: the critic-less confidence scores where(mask, 1 - p, -1e4) of :547-550, whose
+ * masked rows pk_vocab_reduce overwrites afterwards. */
 int pk_topk_mask(const float* scores, int B, int n, int k, long long mask_id, unsigned char* mask, long long* ids,
-                 int* rows_out, void* stream);
+                 int* rows_out, float* scores_next, void* stream);
 
-/* phenaki_pytorch.py:246-263, 523-545: critic head Linear(dim,1) + CFG mix + noise_mult * (u - 0.5), prime dropped. */
+/* phenaki_pytorch.py:246-263, 523-545: critic head Linear(dim,1) + CFG mix + noise_mult * (u - 0.5), prime dropped.
+ * u [nb][n] U[0,1) draws, or NULL: drawn in the kernel from the counter hash of seed (+ *seed_dev, see pk_vocab_sample). */
 int pk_critic_head(const float* x, int ldx, const float* w, const float* b, int D, int nb, int n_tot, int n_prime,
-                   int has_null, float scale, const float* u, float noise_mult, float* out, void* stream);
+                   int has_null, float scale, const float* u, float noise_mult, unsigned long long seed,
+                   const unsigned long long* seed_dev, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -33,7 +33,8 @@ SIGNATURES = {
     'pk_peg': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'pk_lfq_encode': [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P],
     'pk_lfq_decode': [_P, _P, _P, _P, _I, _I, _I, _P],
-    'pk_embed': [_P, _P, _P, _P, _I, _I, _I, _P],
+    'pk_layernorm_lfq': [_P, _I, _P, _P, _F, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
+    'pk_embed': [_P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P],
     'pk_cpb_input': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     'pk_attn_pads': [_I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)],
     'pk_attn_prep': [_I, _P, _I, _P, _I, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -42,11 +43,11 @@ SIGNATURES = {
     'pk_attn_small': [_P, _I, _P, _I, _P, _P, _F, _P, _L, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     'pk_cfg_mix': [_P, _I, _I, _I, _I, _P, _I, _F, _I, _P, _I, _I, _I, _P],
     'pk_vocab_ntiles': [_I],
-    'pk_vocab_sample': [_I, _P, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P, _ULL, _I, _P, _P],
+    'pk_vocab_sample': [_I, _P, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P, _ULL, _P, _I, _P, _P],
     'pk_vocab_reduce': [_P, _I, _I, _P, _P, _P, _P, _P, _I, _P],
     'pk_vocab_ce': [_I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P],
-    'pk_topk_mask': [_P, _I, _I, _I, _LL, _P, _P, _P, _P],
-    'pk_critic_head': [_P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P, _F, _P, _P],
+    'pk_topk_mask': [_P, _I, _I, _I, _LL, _P, _P, _P, _P, _P],
+    'pk_critic_head': [_P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P, _F, _ULL, _P, _P, _P],
 }
 
 _ERR = {-1: 'PK_EINVAL (bad shape/size/flag)', -2: 'PK_EALIGN (pointer/stride alignment)', -3: 'PK_ELAUNCH (HIP launch failed)'}
@@ -181,9 +182,20 @@ def lfq_decode(ids, wo, bo, out, M, D, cd):
     _check(rc, 'pk_lfq_decode')
 
 
-def embed(ids, tok, pos, out, rows, n, D):
-    rc = load().pk_embed(ptr(ids), f32p(tok, 'token_emb.weight'), f32p(pos, 'pos_emb.weight'), ptr(out), rows, n, D, stream(out))
+def embed(ids, tok, pos, out, S, n, D, *, nb=None, ids_prime=None):
+    """out[s*n_tot + i] = tok[id] + pos[i]; ids (nb, n) int64 shared by the S sequences (s % nb), ids_prime (nb, n_prime) optional"""
+    n_prime = ids_prime.shape[-1] if ids_prime is not None else 0
+    rc = load().pk_embed(ptr(ids_prime), n_prime, ptr(ids), n, S if nb is None else nb, f32p(tok, 'token_emb.weight'),
+                         f32p(pos, 'pos_emb.weight'), ptr(out), S, D, stream(out))
     _check(rc, 'pk_embed')
+
+
+def layernorm_lfq(x, gamma, beta, wp, bp, ids, M, D, cd, *, tokens=None, proj=None, eps=1e-5, perm=(0, 0)):
+    """ids[orow] = LFQ(LayerNorm(x[row])): the encoder's final norm_out fused with the quantizer (cd <= 16)"""
+    rc = load().pk_layernorm_lfq(f32p(x, 'x', rows_ok=True), x.stride(-2), f32p(gamma, 'LayerNorm gamma'), f32p(beta, 'LayerNorm beta'), eps,
+                                 f32p(wp, 'LFQ project_in.weight'), f32p(bp, 'LFQ project_in.bias'), ptr(ids), ptr(tokens),
+                                 tokens.stride(-2) if tokens is not None else 0, ptr(proj), M, D, cd, *perm, stream(x))
+    _check(rc, 'pk_layernorm_lfq')
 
 
 def cpb_input(w0, b0, out, dims, D):
@@ -245,9 +257,9 @@ def l2norm_rows(x, out, M, D):
     _check(rc, 'pk_l2norm_rows')
 
 
-def vocab_sample(dtype, A, W, bias, M, V, D, temperature, U, rows, seed, need_lse, partials, no_noise=False):
+def vocab_sample(dtype, A, W, bias, M, V, D, temperature, U, rows, seed, need_lse, partials, no_noise=False, seed_dev=None):
     rc = load().pk_vocab_sample(dtype, ptr(A), A.stride(-2), ptr(W), W.stride(0), f32p(bias, 'to_logits.bias'), M, V, D, temperature,
-                                ptr(U), ptr(rows), seed & 0xFFFFFFFFFFFFFFFF, (1 if need_lse else 0) | (2 if no_noise else 0),
+                                ptr(U), ptr(rows), seed & 0xFFFFFFFFFFFFFFFF, ptr(seed_dev), (1 if need_lse else 0) | (2 if no_noise else 0),
                                 ptr(partials), stream(A))
     _check(rc, 'pk_vocab_sample')
 
@@ -265,12 +277,12 @@ def vocab_ce(dtype, partials, M, V, A, W, bias, D, targets, rows, loss):
     _check(rc, 'pk_vocab_ce')
 
 
-def topk_mask(scores, B, n, k, mask_id, mask, ids, rows_out=None):
-    rc = load().pk_topk_mask(ptr(scores), B, n, k, mask_id, ptr(mask), ptr(ids), ptr(rows_out), stream(scores))
+def topk_mask(scores, B, n, k, mask_id, mask, ids, rows_out=None, scores_next=None):
+    rc = load().pk_topk_mask(ptr(scores), B, n, k, mask_id, ptr(mask), ptr(ids), ptr(rows_out), ptr(scores_next), stream(scores))
     _check(rc, 'pk_topk_mask')
 
 
-def critic_head(x, w, b, D, nb, n_tot, n_prime, has_null, scale, u, noise_mult, out):
+def critic_head(x, w, b, D, nb, n_tot, n_prime, has_null, scale, u, noise_mult, out, seed=0, seed_dev=None):
     rc = load().pk_critic_head(ptr(x), x.stride(-2), f32p(w, 'critic head weight'), f32p(b, 'critic head bias'), D, nb, n_tot, n_prime, 1 if has_null else 0, scale,
-                               ptr(u), noise_mult, ptr(out), stream(x))
+                               ptr(u), noise_mult, seed & 0xFFFFFFFFFFFFFFFF, ptr(seed_dev), ptr(out), stream(x))
     _check(rc, 'pk_critic_head')

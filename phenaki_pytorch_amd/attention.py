@@ -302,28 +302,6 @@ class ContinuousPositionBias(PackedModule):
         return out.reshape(n, n, heads).permute(2, 0, 1).contiguous()
 
 
-_VT_ZERO_WS = {}
-
-
-def _vt_buffer(numel, dev, td, padded):
-    """V^T operand image for pk_qkv_project.  Its pad columns (keys >= n) are multiplied by p = 0 and must stay finite;
-    pk_qkv_project never writes them, so ONE zero-initialised workspace per (device, size, dtype, stream) is handed out again
-    and again (layers run back to back on one stream) instead of a 17 MB fill launch per temporal layer.
-    Never cached while a hipGraph is being captured: capture-time allocations belong to the graph's private pool."""
-    if not padded:
-        return torch.empty((numel,), device=dev, dtype=td)
-    if torch.cuda.is_current_stream_capturing():
-        ws = _VT_ZERO_WS.get((dev, numel, td, torch.cuda.current_stream(dev).cuda_stream))
-        return ws if ws is not None else torch.zeros((numel,), device=dev, dtype=td)
-    key = (dev, numel, td, torch.cuda.current_stream(dev).cuda_stream)
-    ws = _VT_ZERO_WS.get(key)
-    if ws is None:
-        if len(_VT_ZERO_WS) >= 8:
-            _VT_ZERO_WS.clear()
-        ws = _VT_ZERO_WS[key] = torch.zeros((numel,), device=dev, dtype=td)
-    return ws
-
-
 class Attention(PackedModule):
     """attention.py:89-182."""
 
@@ -417,8 +395,8 @@ class Attention(PackedModule):
                               Qp, None, None, nq_pad, nk_pad)
             else:
                 Kp = torch.empty((S * h * nk_pad * 64,), device=dev, dtype=td)
-                # V^T pad columns multiply p = 0 and must be finite
-                Vt = _vt_buffer(S * h * nk_pad * 64, dev, td, padded=nk_pad != n_kv)
+                # V^T pad columns (keys >= n) are never written: the attention kernels mask them in the tail tile
+                Vt = torch.empty((S * h * nk_pad * 64,), device=dev, dtype=td)
                 L.qkv_project(xn, xraw, linear_weight(self.to_q, dtype), linear_weight(self.to_kv, dtype), S, n, h, D,
                               self.q_scale, self.k_scale, float(self.scale), Qp, Kp, Vt, nq_pad, nk_pad)
         elif cached is None:
@@ -470,9 +448,11 @@ class Transformer(PackedModule):
         self.norm_out = LayerNorm(dim)
 
     def run(self, x2d, S, n, dtype, *, video_shape=None, attn_bias=None, context2d=None, n_ctx=None,
-            self_attn_mask=None, cross_attn_context_mask=None, kv_cache=None, out=None, out_t=None, perm=(0, 0)):
+            self_attn_mask=None, cross_attn_context_mask=None, kv_cache=None, out=None, out_t=None, perm=(0, 0),
+            skip_norm_out=False):
         """x2d (S*n, D) f32.  Writes norm_out(x) to `out` (f32) and/or `out_t` (T); returns `out` (allocated if both None).
-        perm = (pb, pc): the output rows are written transposed, (a, b, c) -> (a, c, b)."""
+        perm = (pb, pc): the output rows are written transposed, (a, b, c) -> (a, c, b).
+        skip_norm_out: return the residual stream BEFORE norm_out (the caller fuses that LayerNorm into its next kernel)."""
         x = x2d
         for peg, self_attn, cross_attn, ff in self.layers:
             if exists(peg):
@@ -482,6 +462,8 @@ class Transformer(PackedModule):
                 x = cross_attn.run(x, S, n, dtype, context2d=context2d, n_ctx=n_ctx, kmask=cross_attn_context_mask,
                                    kv_cache=kv_cache)
             x = ff.run(x, dtype)
+        if skip_norm_out:
+            return x
         if out is None and out_t is None:
             out = torch.empty_like(x)
         M, D = x.shape

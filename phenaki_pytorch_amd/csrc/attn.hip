@@ -126,6 +126,25 @@ __device__ __forceinline__ void load_vt(Frag<float>& f, const float* row, int kb
     f.hi = *reinterpret_cast<const f32x4*>(row + kb + 16 + g * 4);
 }
 
+// V^T columns of keys >= nk (tile padding) are multiplied by p = 0 exactly, but 0 * NaN = NaN: the images written by
+// pk_qkv_project leave those columns untouched, so the tail tile's fragment is masked here instead of zero-filling
+// 17 MB of V^T with a separate launch per layer.  Element e of a fragment is key kb + (e >> 2) * 16 + g * 4 + (e & 3).
+__device__ __forceinline__ void mask_vt_tail(Frag<bf16>& f, int kb, int g, int nk) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int key = kb + (w >> 1) * 16 + g * 4 + (w & 1) * 2;
+        const uint32_t m = (key < nk ? 0x0000FFFFu : 0u) | (key + 1 < nk ? 0xFFFF0000u : 0u);
+        f.v[w] &= m;
+    }
+}
+__device__ __forceinline__ void mask_vt_tail(Frag<float>& f, int kb, int g, int nk) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (kb + g * 4 + e >= nk) f.lo[e] = 0.f;
+        if (kb + 16 + g * 4 + e >= nk) f.hi[e] = 0.f;
+    }
+}
+
 template <typename T, int QF>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
@@ -190,6 +209,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         Frag<T> fv[4];
 #pragma unroll
         for (int df = 0; df < 4; ++df) load_vt(fv[df], Vt + (size_t)(df * 16 + lr) * p.nk_pad, kb, g);
+        if (kb + 32 > nk) {                                   // wave-uniform: only the tail tile
+#pragma unroll
+            for (int df = 0; df < 4; ++df) mask_vt_tail(fv[df], kb, g, nk);
+        }
         Frag<T> fkn[2][2];
         f32x4 bzn[QF][2];
         const bool has_next = kb + 32 < p.nk_pad;
@@ -477,6 +500,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
             for (int df = 0; df < 4; ++df) {
                 Frag<bf16> fv;
                 lds_frag_vt(fv, vt, df * 16 + lr, kc, g);
+                if (kb + 64 > nk) {                           // tail tile: keys kb + kc*32 + g*8 + 0..7 beyond nk carry p = 0, make V finite
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const int key = kb + kc * 32 + g * 8 + w * 2;
+                        fv.v[w] &= (key < nk ? 0x0000FFFFu : 0u) | (key + 1 < nk ? 0xFFFF0000u : 0u);
+                    }
+                }
 #pragma unroll
                 for (int qf = 0; qf < QF; ++qf) o[qf][df] = mma(fv, fp[qf], o[qf][df]);
             }

@@ -115,6 +115,22 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // exact erf GELU (torch F.gelu default)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// the same GELU for results that are rounded to bf16 right away (the GEGLU epilogue in bf16 mode): erf by Abramowitz-Stegun
+// 7.1.26 -- |error| <= 1.5e-7 absolute, 3 to 4 decimal digits below a bf16 ulp of the result -- with one v_rcp and one v_exp
+// instead of libm's branchy erff (the epilogue of the FF1 GEMM was 2.1 of 9 us per workgroup, profiles/gemm_timeline_r01.txt)
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float erfz = fmaf(-p * t, __expf(-z * z), 1.0f);          // erf(|x| / sqrt 2)
+    return 0.5f * x * (1.0f + copysignf(erfz, x));
+}
+template <typename T> __device__ __forceinline__ float gelu_for(float x);
+template <> __device__ __forceinline__ float gelu_for<float>(float x) { return gelu_erf(x); }
+template <> __device__ __forceinline__ float gelu_for<bf16>(float x) { return gelu_erf_fast(x); }
 
 // ---- counter-based uniform noise shared by the sampler kernels and their tests -------------
 // u = hash(seed, stream, index) mapped to [0, 1) with 24 bits, the same granularity torch's
@@ -127,6 +143,20 @@ __device__ __host__ __forceinline__ float uniform24(uint32_t seed_lo, uint32_t s
     uint32_t h = mix32(idx_lo ^ seed_lo);
     h = mix32(h + 0x9e3779b9u * (idx_hi + 1u) + seed_hi);
     return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+// four draws for the 4 consecutive elements of group q = flat_index >> 2 (the vocab head's epilogue owns 4 consecutive
+// columns per lane): ONE hash chain per group, three finalisers = 96 bits = 4 x 24 -- half the integer multiplies of
+// uniform24 per element (v_mul_lo_u32 is a quarter-rate instruction and the hash was the largest part of the epilogue)
+__device__ __host__ __forceinline__ void uniform24x4(uint32_t seed_lo, uint32_t seed_hi, uint32_t q_lo, uint32_t q_hi, float (&u)[4]) {
+    uint32_t h = mix32(q_lo ^ seed_lo);
+    h = h + 0x9e3779b9u * (q_hi + 1u) + seed_hi;
+    const uint32_t w0 = mix32(h), w1 = mix32(h + 0x85EBCA77u), w2 = mix32(h + 0x0BD794EEu);
+    const float k = 1.0f / 16777216.0f;
+    u[0] = (float)(w0 >> 8) * k;
+    u[1] = (float)(w1 >> 8) * k;
+    u[2] = (float)(w2 >> 8) * k;
+    u[3] = (float)(((w0 & 0xFFu) << 16) | ((w1 & 0xFFu) << 8) | (w2 & 0xFFu)) * k;
 }
 
 constexpr float NEG_MAX = -3.402823466e+38f;   // -finfo(float32).max, the reference's mask fill value

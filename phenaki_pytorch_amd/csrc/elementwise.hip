@@ -121,36 +121,72 @@ __global__ __launch_bounds__(256) void lfq_encode_kernel(const float* __restrict
     if (lane == 0) ids[row] = id;
 }
 
-// decode: codes = (+1 | -1 per bit, MSB first) @ Wo^T + bo ; wo is [D][cd]
+// decode: codes = (+1 | -1 per bit, MSB first) @ Wo^T + bo ; wo is [D][cd].
+// A rank-cd outer product per row: each thread keeps the cd weights (+ bias) of its 4 output channels in registers for the
+// whole launch and walks the rows (grid-stride), so a row costs one 8-byte id read (broadcast), 4*cd signed adds and ONE
+// 16-byte store per thread -- the 2 KB write per token is the only HBM traffic (the first version re-read wo per
+// element: 74 us for 9.4 MB).  HBM-bound: algorithmic bytes = 4*D + 8 per row.
+template <int CD>
 __global__ __launch_bounds__(256) void lfq_decode_kernel(const long long* __restrict__ ids, const float* __restrict__ wo,
                                                          const float* __restrict__ bo, float* __restrict__ out,
-                                                         int M, int D, int cd) {
+                                                         int M, int D, int row_stride) {
+    const int dv = D >> 2;                                   // 16-byte column groups per row
+    const int lanes = blockDim.x;                            // host: lanes == dv * rpb, rpb rows in flight per block
+    const int cg = threadIdx.x % dv, rl = threadIdx.x / dv;
+    float w[4][CD];
+    f32x4 b4 = *reinterpret_cast<const f32x4*>(bo + cg * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < CD; ++k) w[e][k] = wo[(size_t)(cg * 4 + e) * CD + k];
+    for (int row = blockIdx.x * (lanes / dv) + rl; row < M; row += row_stride) {
+        const unsigned long long id = (unsigned long long)ids[row];
+        f32x4 acc = b4;
+#pragma unroll
+        for (int k = 0; k < CD; ++k) {
+            const bool on = (id >> (CD - 1 - k)) & 1ull;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += on ? w[e][k] : -w[e][k];
+        }
+        *reinterpret_cast<f32x4*>(out + (size_t)row * D + cg * 4) = acc;
+    }
+}
+
+// generic fallback (any D, cd <= 62): one thread per output element
+__global__ __launch_bounds__(256) void lfq_decode_generic_kernel(const long long* __restrict__ ids, const float* __restrict__ wo,
+                                                                 const float* __restrict__ bo, float* __restrict__ out,
+                                                                 int M, int D, int cd) {
     const long total = (long)M * D;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int d = (int)(idx % D);
         const long long id = ids[idx / D];
-        float acc = 0.f;
+        float acc = bo[d];
         for (int k = 0; k < cd; ++k) {
             const float sgn = ((id >> (cd - 1 - k)) & 1) ? 1.f : -1.f;
             acc += sgn * wo[(size_t)d * cd + k];
         }
-        out[idx] = acc + bo[d];
+        out[idx] = acc;
     }
 }
 
 // ---- token + position embedding (reference phenaki_pytorch.py:194-197, :290-291)
-__global__ __launch_bounds__(256) void embed_kernel(const long long* __restrict__ ids, const float* __restrict__ tok,
-                                                    const float* __restrict__ pos, float* __restrict__ out,
-                                                    int n, int D, long total_vec) {
+// Row r = s * n_tot + i of the output is sequence s, position i.  The token id comes from ids_prime[b][i] for i < n_prime
+// (the primed frames' tokens, phenaki_pytorch.py:500) and from ids[b][i - n_prime] otherwise, with b = s % nb: the S = 2*nb
+// sequences of a classifier-free-guidance batch (cond | null) read the SAME nb id rows -- no torch.cat on the host.
+__global__ __launch_bounds__(256) void embed_kernel(const long long* __restrict__ ids_prime, int n_prime, const long long* __restrict__ ids,
+                                                    int n, int nb, const float* __restrict__ tok, const float* __restrict__ pos,
+                                                    float* __restrict__ out, int D, long total_vec) {
     const int dv = D >> 2;
+    const int n_tot = n_prime + n;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total_vec; idx += (long)gridDim.x * 256) {
         const int c = (int)(idx % dv) * 4;
         const long r = idx / dv;
-        const int i = (int)(r % n);
-        const long long id = ids[r];
+        const int i = (int)(r % n_tot);
+        const int b = (int)((r / n_tot) % nb);
+        const long long id = i < n_prime ? ids_prime[(size_t)b * n_prime + i] : ids[(size_t)b * n + (i - n_prime)];
         const f32x4 a = *reinterpret_cast<const f32x4*>(pos + (size_t)i * D + c);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(tok + (size_t)id * D + c);
-        *reinterpret_cast<f32x4*>(out + (size_t)r * D + c) = a + b;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(tok + (size_t)id * D + c);
+        *reinterpret_cast<f32x4*>(out + (size_t)r * D + c) = a + t;
     }
 }
 
@@ -182,6 +218,7 @@ __global__ __launch_bounds__(256) void cpb_input_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void critic_head_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                           const float* __restrict__ bptr, int D, int nb, int n_tot, int n_prime, int has_null,
                                                           float scale, const float* __restrict__ u, float noise_mult,
+                                                          unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
                                                           float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int n = n_tot - n_prime;
@@ -204,6 +241,10 @@ __global__ __launch_bounds__(256) void critic_head_kernel(const float* __restric
         s = sn + (s - sn) * scale;
     }
     if (u) s += noise_mult * (u[r] - 0.5f);
+    else if (noise_mult != 0.f) {                           // FAST mode: the uniform draw of phenaki_pytorch.py:541 from the counter hash
+        const unsigned long long sd = seed + (seed_dev ? *seed_dev : 0ull);
+        s += noise_mult * (uniform24((uint32_t)sd, (uint32_t)(sd >> 32), (uint32_t)r, 0xC817u) - 0.5f);
+    }
     if (lane == 0) out[r] = s;
 }
 
@@ -247,16 +288,29 @@ extern "C" int pk_lfq_encode(const float* x, int ldx, const float* wp, const flo
 
 extern "C" int pk_lfq_decode(const long long* ids, const float* wo, const float* bo, float* out, int M, int D, int cd, void* stream) {
     if (!ids || !wo || !bo || !out || M <= 0 || D <= 0 || cd <= 0 || cd > 62) return PK_EINVAL;
-    hipLaunchKernelGGL(lfq_decode_kernel, dim3(nblocks((long)M * D)), dim3(256), 0, STREAM(stream), ids, wo, bo, out, M, D, cd);
+    hipStream_t s = STREAM(stream);
+    const int dv = D >> 2;
+    const bool fast = (D & 3) == 0 && dv <= 256 && (256 % dv == 0 || dv == 256) && (cd == 8 || cd == 16) &&
+                      (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(bo) & 15) == 0;
+    if (fast) {
+        const int rpb = 256 / dv;                               // rows in flight per 256-thread block
+        int blocks = (M + rpb - 1) / rpb;
+        if (blocks > 1024) blocks = 1024;                       // >= 4 blocks per CU; each thread then walks several rows
+        if (cd == 16) hipLaunchKernelGGL((lfq_decode_kernel<16>), dim3(blocks), dim3(256), 0, s, ids, wo, bo, out, M, D, blocks * rpb);
+        else hipLaunchKernelGGL((lfq_decode_kernel<8>), dim3(blocks), dim3(256), 0, s, ids, wo, bo, out, M, D, blocks * rpb);
+    } else {
+        hipLaunchKernelGGL(lfq_decode_generic_kernel, dim3(nblocks((long)M * D)), dim3(256), 0, s, ids, wo, bo, out, M, D, cd);
+    }
     PK_CHECK_LAUNCH();
     return PK_OK;
 }
 
-extern "C" int pk_embed(const long long* ids, const float* tok, const float* pos, float* out, int rows, int n, int D, void* stream) {
-    if (!ids || !tok || !pos || !out || rows <= 0 || n <= 0 || D <= 0) return PK_EINVAL;
+extern "C" int pk_embed(const long long* ids_prime, int n_prime, const long long* ids, int n, int nb, const float* tok,
+                        const float* pos, float* out, int S, int D, void* stream) {
+    if (!ids || !tok || !pos || !out || S <= 0 || n <= 0 || nb <= 0 || D <= 0 || n_prime < 0 || (n_prime > 0 && !ids_prime)) return PK_EINVAL;
     if (D & 3) return PK_EALIGN;
-    const long total = (long)rows * (D >> 2);
-    hipLaunchKernelGGL(embed_kernel, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), ids, tok, pos, out, n, D, total);
+    const long total = (long)S * (n_prime + n) * (D >> 2);
+    hipLaunchKernelGGL(embed_kernel, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), ids_prime, n_prime, ids, n, nb, tok, pos, out, D, total);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }
@@ -271,12 +325,13 @@ extern "C" int pk_cpb_input(const float* w0, const float* b0, float* out, int d0
 }
 
 extern "C" int pk_critic_head(const float* x, int ldx, const float* w, const float* b, int D, int nb, int n_tot, int n_prime,
-                              int has_null, float scale, const float* u, float noise_mult, float* out, void* stream) {
+                              int has_null, float scale, const float* u, float noise_mult, unsigned long long seed,
+                              const unsigned long long* seed_dev, float* out, void* stream) {
     if (!x || !w || !out || D <= 0 || nb <= 0 || n_tot <= n_prime || n_prime < 0) return PK_EINVAL;
     if ((D & 3) || (ldx & 3)) return PK_EALIGN;
     const int rows = nb * (n_tot - n_prime);
     hipLaunchKernelGGL(critic_head_kernel, dim3((rows + 3) / 4), dim3(256), 0, STREAM(stream), x, ldx, w, b, D, nb, n_tot, n_prime,
-                       has_null, scale, u, noise_mult, out);
+                       has_null, scale, u, noise_mult, seed, seed_dev, out);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

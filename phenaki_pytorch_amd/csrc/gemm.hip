@@ -38,7 +38,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[TM][TN], int M,
             if (e.vec_ok) {
                 if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + n);
                 if (e.act == ACT_GEGLU) {
-                    const float o0 = gelu_erf(v[1]) * v[0], o1 = gelu_erf(v[3]) * v[2];
+                    const float o0 = gelu_for<T>(v[1]) * v[0], o1 = gelu_for<T>(v[3]) * v[2];
                     const size_t o = (size_t)m * e.ldc + (n >> 1);
                     if (e.out_f32) store2(Cf + o, o0, o1); else store2(Ct + o, o0, o1);
                 } else {
@@ -59,7 +59,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[TM][TN], int M,
                     if (e.act == ACT_GEGLU) {
                         if (r & 1) continue;
                         const float gate = (nn + 1 < N) ? v[r + 1] + (e.bias ? e.bias[nn + 1] : 0.f) : 0.f;
-                        x = gelu_erf(gate) * x;
+                        x = gelu_for<T>(gate) * x;
                         const size_t o = (size_t)m * e.ldc + (nn >> 1);
                         if (e.out_f32) Cf[o] = x; else store_elem(Ct + o, x);
                         continue;

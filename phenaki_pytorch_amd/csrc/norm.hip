@@ -83,6 +83,110 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const LnArgs p) {
     }
 }
 
+// Final LayerNorm of the C-ViViT encoder fused with the lookup-free quantizer (cvivit.py:472 norm_out -> :570 LFQ): one wave
+// per row normalises it in registers and takes the cd <= 16 dot products with project_in, so the (M, D) f32 token matrix is
+// neither written nor read back and one launch disappears.  The 16 wave-wide sums are folded with a halving butterfly (the
+// lanes exchange the half of the partials they do not keep: 8 + 4 + 2 + 1 + 1 + 1 = 17 shuffles instead of 16 x 6); lane
+// group k = lane >> 2 ends up with sum k, one ballot collects the sign bits.  ids[orow] = sum_k (proj_k > 0) << (cd-1-k),
+// orow = the (a, b, c) -> (a, c, b) row permutation of pk_layernorm.  tokens (f32, optional) receives LN(x) for callers that
+// still need it; proj (optional) the pre-sign values for the parity margin audit.
+template <int VMAX>
+__global__ __launch_bounds__(256) void ln_lfq_kernel(const LnArgs p, const float* __restrict__ wp, const float* __restrict__ bp,
+                                                      int cd, long long* __restrict__ ids, float* __restrict__ proj) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    int orow = row;
+    if (p.pb > 0) {
+        const int c = row % p.pc, b = (row / p.pc) % p.pb, a = row / (p.pc * p.pb);
+        orow = (a * p.pc + c) * p.pb + b;
+    }
+    const float* xr = p.x + (size_t)row * p.ldx;
+    const int nv = p.D >> 2;
+    f32x4 v[VMAX];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VMAX; ++i) {
+        const int c = lane + i * 64;
+        v[i] = c < nv ? *reinterpret_cast<const f32x4*>(xr + c * 4) : f32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < VMAX; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(s) / (float)p.D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VMAX; ++i)
+        if (lane + i * 64 < nv) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = v[i][r] - mean; q += d * d; }
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)p.D + p.eps);
+    float part[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) part[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < VMAX; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gamma + c * 4);
+            const f32x4 b4 = p.beta ? *reinterpret_cast<const f32x4*>(p.beta + c * 4) : f32x4{0, 0, 0, 0};
+            f32x4 y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = (v[i][r] - mean) * rstd * g4[r] + b4[r];
+            if (p.out2) store4(p.out2 + (size_t)orow * p.ldo2 + c * 4, y);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (k < cd) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + (size_t)k * p.D + c * 4);
+                    part[k] += (y[0] * wv[0] + y[1] * wv[1]) + (y[2] * wv[2] + y[3] * wv[3]);
+                }
+            }
+        }
+    }
+    // halving butterfly: after the step with lane bit `bit`, a lane keeps the partials whose index has that bit equal to its own
+    float h8[8], h4[4], h2[2], h1;
+    {
+        const bool hi = lane & 32;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float keep = hi ? part[i + 8] : part[i], send = hi ? part[i] : part[i + 8];
+            h8[i] = keep + __shfl_xor(send, 32, 64);
+        }
+    }
+    {
+        const bool hi = lane & 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float keep = hi ? h8[i + 4] : h8[i], send = hi ? h8[i] : h8[i + 4];
+            h4[i] = keep + __shfl_xor(send, 16, 64);
+        }
+    }
+    {
+        const bool hi = lane & 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float keep = hi ? h4[i + 2] : h4[i], send = hi ? h4[i] : h4[i + 2];
+            h2[i] = keep + __shfl_xor(send, 8, 64);
+        }
+    }
+    {
+        const bool hi = lane & 4;
+        const float keep = hi ? h2[1] : h2[0], send = hi ? h2[0] : h2[1];
+        h1 = keep + __shfl_xor(send, 4, 64);
+    }
+    h1 += __shfl_xor(h1, 2, 64);
+    h1 += __shfl_xor(h1, 1, 64);
+    const int k = lane >> 2;                                 // bits 5..2 of the lane = bits 3..0 of k
+    const float val = h1 + (k < cd ? bp[k] : 0.f);
+    if (proj && k < cd && (lane & 3) == 0) proj[(size_t)orow * cd + k] = val;
+    const unsigned long long bal = __ballot(val > 0.f);
+    if (lane == 0) {
+        long long id = 0;
+        for (int kk = 0; kk < cd; ++kk) id |= (long long)((bal >> (4 * kk)) & 1ull) << (cd - 1 - kk);
+        ids[orow] = id;
+    }
+}
+
 // one wave per row: out = x / max(||x||_2, 1e-12)
 template <typename TO>
 __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, int ldx, TO* __restrict__ out, int ldo, int M, int D) {
@@ -116,6 +220,24 @@ extern "C" int pk_l2norm_rows(const float* x, int ldx, void* out, int ldo, int o
     return PK_OK;
 }
 
+
+// ids[orow] <- LFQ(LayerNorm(x[row])) (see ln_lfq_kernel); cd <= 16, D <= 2048; tokens / proj optional outputs; pb, pc as in
+// pk_layernorm (orow = the transposed row), pb = 0: orow = row
+extern "C" int pk_layernorm_lfq(const float* x, int ldx, const float* gamma, const float* beta, float eps, const float* wp,
+                                const float* bp, long long* ids, float* tokens, int ldt, float* proj, int M, int D, int cd,
+                                int pb, int pc, void* stream) {
+    if (M <= 0 || D <= 0 || !x || !gamma || !wp || !bp || !ids || cd <= 0 || cd > 16) return PK_EINVAL;
+    if ((D & 3) || (ldx & 3) || (tokens && (ldt & 3))) return PK_EALIGN;
+    if (D > 64 * 4 * 8) return PK_EINVAL;
+    if (pb > 0 && (pc <= 0 || M % (pb * pc))) return PK_EINVAL;
+    LnArgs p{x, ldx, gamma, beta, eps, nullptr, 0, tokens, ldt, nullptr, 0, M, D, 0, 0, 0, pb, pc};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((M + 3) / 4), block(256);
+    if (D <= 64 * 4 * 2) hipLaunchKernelGGL((ln_lfq_kernel<2>), grid, block, 0, s, p, wp, bp, cd, ids, proj);
+    else hipLaunchKernelGGL((ln_lfq_kernel<8>), grid, block, 0, s, p, wp, bp, cd, ids, proj);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
 
 // out / raw (f32 if out_kind == 0 else bf16) and/or out2 (always f32); out, out2 receive LN(x) * gamma + beta, raw
 // receives x itself.  Output rows may be remapped: grp > 0: r -> (r / grp) * gstride + goff + r % grp (cvivit.py:549

@@ -11,7 +11,8 @@
 //                    confidence scores where(mask, 1 - p, -1e4).
 //  pk_topk_mask    : mask = top-k(scores) per row (:488-489) and ids = where(mask, mask_id, ids) (:491).
 // Noise: PARITY mode reads U[0,1) from memory (the tests inject the oracle's draws) and uses logf / true
-// division exactly like the reference expression; FAST mode draws U from the counter hash in common.hpp.
+// division exactly like the reference expression; FAST mode draws U from the counter hash in common.hpp (four draws per
+// hash chain) and compares in the log2 domain (no eps terms: a draw of exactly 0 maps to -inf and never wins).
 #include "gemm_dma.hpp"
 
 namespace pk {
@@ -44,6 +45,7 @@ struct VocabArgs {
     const int* rows;         // optional: output row r is logical row rows[r] (noise / partial indexing)
     float temp;              // max(temperature, 1e-10)
     uint32_t seed_lo, seed_hi;
+    const unsigned long long* seed_dev;   // optional: added to the seed at run time (a captured hipGraph replays with fresh noise)
     int need_lse;
     int no_noise;            // 1: plain argmax of the logits (cosine-sim codebook lookup of the VectorQuantize path)
     int ntiles;
@@ -57,7 +59,7 @@ struct VocabArgs {
 constexpr int VTM = 4, VTN = 2, VWM = 2, VWN = 4;
 template <typename T> using VocabTile = GemmDma<T, VTM, VTN, VWM, VWN, 2>;
 
-template <typename T, bool PARITY>
+template <typename T, bool PARITY, bool LSE>
 __global__ __launch_bounds__(64 * VWM * VWN) void vocab_sample_kernel(const GemmOperands p, const VocabArgs e) {
     using Tile = VocabTile<T>;
     static_assert(Tile::BM == 128 && Tile::BN == 128, "partials are laid out per 128-column tile");
@@ -72,6 +74,14 @@ __global__ __launch_bounds__(64 * VWM * VWN) void vocab_sample_kernel(const Gemm
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / VWN, wn = wave % VWN, g = lane >> 4, lr = lane & 15;
+    uint32_t seed_lo = e.seed_lo, seed_hi = e.seed_hi;
+    if (!PARITY && e.seed_dev) {
+        const unsigned long long sd = (((unsigned long long)e.seed_hi << 32) | e.seed_lo) + *e.seed_dev;
+        seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32);
+    }
+    // FAST mode works in the log2 domain: argmax_v (l_v / T - ln(-ln u_v)) = argmax_v (l_v * log2(e) / T - log2(-log2 u_v))
+    // (the two differ by the constant ln(ln 2) and the factor ln 2), i.e. two bare v_log_f32 and one fma per logit
+    const float inv_t = 1.0f / e.temp, inv_t_log2e = inv_t * 1.44269504088896340736f;
     // LDS scratch (the GEMM stages are dead after run()'s final barrier): [wn][128 rows][5 words]
     float* red = reinterpret_cast<float*>(smem);
     const int V = p.N;
@@ -90,6 +100,11 @@ __global__ __launch_bounds__(64 * VWM * VWN) void vocab_sample_kernel(const Gemm
             f32x4 bv = f32x4{0, 0, 0, 0}, uv = f32x4{0.5f, 0.5f, 0.5f, 0.5f};
             if (n < V) bv = *reinterpret_cast<const f32x4*>(e.bias + n);         // V % 4 == 0 (host check)
             if (PARITY) { if (mok && n < V) uv = *reinterpret_cast<const f32x4*>(e.U + (size_t)lrow * V + n); }
+            float uf[4] = {0.5f, 0.5f, 0.5f, 0.5f};
+            if (!PARITY && !e.no_noise) {
+                const uint64_t gq = ((uint64_t)lrow * (uint64_t)V + (uint64_t)n) >> 2;      // V % 4 == 0: group of 4 columns
+                uniform24x4(seed_lo, seed_hi, (uint32_t)gq, (uint32_t)(gq >> 32), uf);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int nn = n + r;
@@ -99,20 +114,17 @@ __global__ __launch_bounds__(64 * VWM * VWN) void vocab_sample_kernel(const Gemm
                     const float gum = -logf(-logf(uv[r] + 1e-10f) + 1e-10f);
                     noisy = logit / e.temp + gum;
                 } else {
-                    const uint64_t gi = (uint64_t)lrow * (uint64_t)V + (uint64_t)nn;
-                    const float u = uniform24(e.seed_lo, e.seed_hi, (uint32_t)gi, (uint32_t)(gi >> 32));
-                    const float gum = -__logf(-__logf(u + 1e-10f) + 1e-10f);
-                    noisy = logit * (1.0f / e.temp) + gum;
+                    noisy = fmaf(logit, inv_t_log2e, -__log2f(-__log2f(uf[r])));           // u = 0: -inf, never chosen
                 }
                 if (e.no_noise) noisy = logit;
                 const bool ok = nn < V;
-                lg[j * 4 + r] = ok ? logit : -INFINITY;
+                if (LSE) lg[j * 4 + r] = ok ? logit : -INFINITY;
                 if (ok && (noisy > best)) { best = noisy; bidx = nn; blog = logit; }   // ascending nn: first max wins
-                if (ok) lmax = fmaxf(lmax, logit);
+                if (LSE && ok) lmax = fmaxf(lmax, logit);
             }
         }
         float lsum = 0.f;
-        if (e.need_lse) {
+        if (LSE) {
 #pragma unroll
             for (int q = 0; q < 4 * VTN; ++q) lsum += __expf(lg[q] - lmax);         // exp(-inf) = 0 for padding
         }
@@ -122,10 +134,12 @@ __global__ __launch_bounds__(64 * VWM * VWN) void vocab_sample_kernel(const Gemm
             const float ob = __shfl_xor(best, off, 64), ol = __shfl_xor(blog, off, 64);
             const int oi = __shfl_xor(bidx, off, 64);
             if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; blog = ol; }
-            const float om = __shfl_xor(lmax, off, 64), os = __shfl_xor(lsum, off, 64);
-            const float nm = fmaxf(lmax, om);
-            if (e.need_lse) lsum = (lmax == -INFINITY ? 0.f : lsum * __expf(lmax - nm)) + (om == -INFINITY ? 0.f : os * __expf(om - nm));
-            lmax = nm;
+            if (LSE) {
+                const float om = __shfl_xor(lmax, off, 64), os = __shfl_xor(lsum, off, 64);
+                const float nm = fmaxf(lmax, om);
+                lsum = (lmax == -INFINITY ? 0.f : lsum * __expf(lmax - nm)) + (om == -INFINITY ? 0.f : os * __expf(om - nm));
+                lmax = nm;
+            }
         }
         if (g == 0) {
             float* rr = red + ((size_t)wn * 128 + ml) * 5;
@@ -144,12 +158,15 @@ __global__ __launch_bounds__(64 * VWM * VWN) void vocab_sample_kernel(const Gemm
                 const float* b = red + ((size_t)q * 128 + ml) * 5;
                 const int oi = __builtin_bit_cast(int, b[1]);
                 if (b[0] > best || (b[0] == best && oi < bidx)) { best = b[0]; bidx = oi; blog = b[2]; }
-                const float nm = fmaxf(lmax, b[3]);
-                if (e.need_lse) lsum = (lmax == -INFINITY ? 0.f : lsum * __expf(lmax - nm)) + (b[3] == -INFINITY ? 0.f : b[4] * __expf(b[3] - nm));
-                lmax = nm;
+                if (LSE) {
+                    const float nm = fmaxf(lmax, b[3]);
+                    lsum = (lmax == -INFINITY ? 0.f : lsum * __expf(lmax - nm)) + (b[3] == -INFINITY ? 0.f : b[4] * __expf(b[3] - nm));
+                    lmax = nm;
+                }
             }
             const size_t o = (size_t)blockIdx.y * p.M + m;
-            e.p_val[o] = best; e.p_idx[o] = bidx; e.p_logit[o] = blog; e.p_max[o] = lmax; e.p_sum[o] = lsum;
+            e.p_val[o] = best; e.p_idx[o] = bidx; e.p_logit[o] = blog;
+            if (LSE) { e.p_max[o] = lmax; e.p_sum[o] = lsum; }
         }
     }
 }
@@ -237,7 +254,7 @@ __global__ __launch_bounds__(256) void vocab_ce_kernel(const float* __restrict__
 // mask = top-k of scores per row (ties: lower index first), ids = where(mask, mask_id, ids)
 __global__ __launch_bounds__(256) void topk_mask_kernel(const float* __restrict__ scores, int n, int k, long long mask_id,
                                                         unsigned char* __restrict__ mask, long long* __restrict__ ids,
-                                                        int* __restrict__ rows_out) {
+                                                        int* __restrict__ rows_out, float* __restrict__ scores_next) {
     // grid (B, ceil(n / 64)): a workgroup ranks 64 positions of one batch row, 4 lanes per position each scanning a
     // quarter of the row from LDS (B workgroups of 3 x n serial compares each took 47 us at B = 8, n = 576)
     extern __shared__ float sc[];
@@ -256,6 +273,9 @@ __global__ __launch_bounds__(256) void topk_mask_kernel(const float* __restrict_
     rank += __shfl_xor(rank, 1, 64);
     rank += __shfl_xor(rank, 2, 64);
     if (part != 0 || i >= n) return;
+    // critic-less sampling: the next scores are where(mask, 1 - p, -1e4) (phenaki_pytorch.py:547-550); pk_vocab_reduce only
+    // visits the masked rows, so the -1e4 of every other position is laid down here, in the OTHER score buffer
+    if (scores_next) scores_next[(size_t)b * n + i] = -1e4f;
     const bool sel = rank < k;
     mask[(size_t)b * n + i] = sel ? 1 : 0;
     if (sel) ids[(size_t)b * n + i] = mask_id;
@@ -284,7 +304,7 @@ extern "C" int pk_vocab_ntiles(int V) { return (V + 127) / 128; }
 // workspace: 5 arrays of ntiles*M 4-byte words, passed as one buffer `partials` of 5*ntiles*M words
 extern "C" int pk_vocab_sample(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias,
                                int M, int V, int D, float temperature, const float* U, const int* rows,
-                               unsigned long long seed, int need_lse, void* partials, void* stream) {
+                               unsigned long long seed, const unsigned long long* seed_dev, int need_lse, void* partials, void* stream) {
     if (!A || !W || !bias || !partials || M <= 0 || V <= 0 || D <= 0) return PK_EINVAL;
     if (dtype != 0 && dtype != 1) return PK_EINVAL;
     const int eps = dtype == 1 ? 8 : 4;
@@ -297,7 +317,7 @@ extern "C" int pk_vocab_sample(int dtype, const void* A, int lda, const void* W,
     VocabArgs e;
     e.bias = bias; e.U = U; e.rows = rows;
     e.temp = temperature > 1e-10f ? temperature : 1e-10f;
-    e.seed_lo = (uint32_t)seed; e.seed_hi = (uint32_t)(seed >> 32);
+    e.seed_lo = (uint32_t)seed; e.seed_hi = (uint32_t)(seed >> 32); e.seed_dev = seed_dev;
     e.need_lse = need_lse & 1; e.no_noise = (need_lse >> 1) & 1; e.ntiles = ntiles;
     const size_t sz = (size_t)ntiles * M;
     e.p_val = reinterpret_cast<float*>(partials);
@@ -307,15 +327,16 @@ extern "C" int pk_vocab_sample(int dtype, const void* A, int lda, const void* W,
     e.p_sum = reinterpret_cast<float*>(partials) + 4 * sz;
     dim3 grid((M + 127) / 128, ntiles), block(64 * VWM * VWN);
     hipStream_t s = STREAM(stream);
+#define PK_VS(TT, PAR, LS) hipLaunchKernelGGL((vocab_sample_kernel<TT, PAR, LS>), grid, block, VocabTile<TT>::SMEM, s, p, e)
+    const bool lse = e.need_lse != 0;
     if (dtype == 1) {
-        constexpr int SM = VocabTile<bf16>::SMEM;
-        if (U) hipLaunchKernelGGL((vocab_sample_kernel<bf16, true>), grid, block, SM, s, p, e);
-        else hipLaunchKernelGGL((vocab_sample_kernel<bf16, false>), grid, block, SM, s, p, e);
+        if (U) { if (lse) PK_VS(bf16, true, true); else PK_VS(bf16, true, false); }
+        else { if (lse) PK_VS(bf16, false, true); else PK_VS(bf16, false, false); }
     } else {
-        constexpr int SM = VocabTile<float>::SMEM;
-        if (U) hipLaunchKernelGGL((vocab_sample_kernel<float, true>), grid, block, SM, s, p, e);
-        else hipLaunchKernelGGL((vocab_sample_kernel<float, false>), grid, block, SM, s, p, e);
+        if (U) { if (lse) PK_VS(float, true, true); else PK_VS(float, true, false); }
+        else { if (lse) PK_VS(float, false, true); else PK_VS(float, false, false); }
     }
+#undef PK_VS
     PK_CHECK_LAUNCH();
     return PK_OK;
 }
@@ -353,9 +374,9 @@ extern "C" int pk_vocab_ce(int dtype, const void* partials, int M, int V, const 
 }
 
 extern "C" int pk_topk_mask(const float* scores, int B, int n, int k, long long mask_id, unsigned char* mask,
-                            long long* ids, int* rows_out, void* stream) {
-    if (!scores || !mask || !ids || B <= 0 || n <= 0 || k < 0 || n > 12288) return PK_EINVAL;
-    hipLaunchKernelGGL(topk_mask_kernel, dim3(B, (n + 63) / 64), dim3(256), n * sizeof(float), STREAM(stream), scores, n, k, mask_id, mask, ids, rows_out);
+                            long long* ids, int* rows_out, float* scores_next, void* stream) {
+    if (!scores || !mask || !ids || B <= 0 || n <= 0 || k < 0 || n > 12288 || scores_next == scores) return PK_EINVAL;
+    hipLaunchKernelGGL(topk_mask_kernel, dim3(B, (n + 63) / 64), dim3(256), n * sizeof(float), STREAM(stream), scores, n, k, mask_id, mask, ids, rows_out, scores_next);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

@@ -191,16 +191,17 @@ class CViViT(PackedModule):
         return transformer.run(x2d, B * T, h * w, dt, video_shape=(B, T, h, w), attn_bias=bias, out_t=out_t,
                                perm=(T, h * w) if to_temporal else (0, 0))
 
-    def _temporal(self, transformer, xt2d, B, T):
+    def _temporal(self, transformer, xt2d, B, T, skip_norm_out=False):
         """rows '(b h w) t' in, '(b t) (h w)' out (the final norm_out writes transposed, cvivit.py:472,496).
         NOTE: video_shape stays (b, t, h, w) although rows are ((b h w), t): the reference's PEG sees that
         scrambled view (cvivit.py:456,468-470) and so must we."""
         h, w = self.patch_height_width
-        return transformer.run(xt2d, B * h * w, T, compute_dtype_of(self), video_shape=(B, T, h, w), perm=(h * w, T))
+        return transformer.run(xt2d, B * h * w, T, compute_dtype_of(self), video_shape=(B, T, h, w), perm=(h * w, T),
+                               skip_norm_out=skip_norm_out)
 
-    def _encode2d(self, tokens2d, B, T):
+    def _encode2d(self, tokens2d, B, T, skip_norm_out=False):
         x = self._spatial(self.enc_spatial_transformer, tokens2d, B, T, to_temporal=True)
-        return self._temporal(self.enc_temporal_transformer, x, B, T)
+        return self._temporal(self.enc_temporal_transformer, x, B, T, skip_norm_out=skip_norm_out)
 
     def _decode2d(self, tokens2d, B, T):
         """tokens (B*T*h*w, dim) f32 -> video (B, C, 1 + (T-1)*pt, H, W) f32 (cvivit.py:476-516)."""
@@ -268,8 +269,15 @@ class CViViT(PackedModule):
         """ids (B, T', h, w) int64 [and the pre-sign LFQ projection (B, n, cd), used by the parity margin audit]."""
         tokens, T = self._patch_embed(video)
         B = video.shape[0]
-        tokens = self._encode2d(tokens, B, T)
         h, w = self.patch_height_width
+        if self.lookup_free_quantization and self.vq.codebook_dim <= 16:
+            # the encoder's last LayerNorm (rows '(b h w) t' -> '(b t) (h w)') and the quantizer in one launch
+            x = self._encode2d(tokens, B, T, skip_norm_out=True)
+            r = self.vq.encode_ids_from_prenorm(x, self.enc_temporal_transformer.norm_out, perm=(h * w, T), return_proj=return_proj)
+            if return_proj:
+                return r[0].view(B, T, h, w), r[1].view(B, T * h * w, -1)
+            return r.view(B, T, h, w)
+        tokens = self._encode2d(tokens, B, T)
         if return_proj:
             assert self.lookup_free_quantization, 'the pre-sign projection exists for LFQ only'
             ids, proj = self.vq.encode_ids(tokens, return_proj=True)
@@ -306,9 +314,8 @@ class CViViT(PackedModule):
             raise NotImplementedError('the discriminator / VGG / adaptive-weight losses (cvivit.py:604-671) need autograd and are '
                                       'outside the MI355X build; the reconstruction loss (use_vgg_and_gan=False), '
                                       'return_only_codebook_ids=True and return_recons_only=True are supported')
-        tokens, T = self._patch_embed(video)
-        tokens = self._encode2d(tokens, b, T)
-        ids = self.vq.encode_ids(tokens)
+        ids = self.tokenize(video).reshape(-1)
+        T = 1 + (f - 1) // self.temporal_patch_size
         recon = self._decode2d(self.vq.codes_2d(ids), b, T)
         returned_recon = recon.squeeze(2) if is_image else recon
         if return_recons_only:

@@ -35,6 +35,17 @@ class LFQ(nn.Module):
         L.lfq_encode(x2d, self.project_in.weight, self.project_in.bias, ids, proj, M, D, self.codebook_dim)
         return (ids, proj) if return_proj else ids
 
+    def encode_ids_from_prenorm(self, x2d, norm, perm=(0, 0), return_proj=False):
+        """ids of LayerNorm(x2d) with the (gamma, beta) of `norm` (the encoder's norm_out), rows permuted like pk_layernorm's
+        (pb, pc): ONE fused launch, the normalised tokens never reach HBM (cvivit.py:472 + :570).  Needs cd <= 16."""
+        L.require_device(x2d, 'tokens')
+        M, D = x2d.shape
+        ids = torch.empty((M,), device=x2d.device, dtype=torch.int64)
+        proj = torch.empty((M, self.codebook_dim), device=x2d.device, dtype=torch.float32) if return_proj else None
+        L.layernorm_lfq(x2d, norm.gamma, norm.beta, self.project_in.weight, self.project_in.bias, ids, M, D, self.codebook_dim,
+                        proj=proj, perm=perm)
+        return (ids, proj) if return_proj else ids
+
     def codes_2d(self, ids_flat):
         """ids (M,) int64 -> project_out(+-1 codes) (M, dim) f32"""
         L.require_device(ids_flat, 'indices')

@@ -8,7 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import phenaki_oracle as O
-from tests.util import close, uniform24_np
+from tests.util import close, uniform24_np, uniform24x4_np
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
@@ -216,13 +216,60 @@ def test_lfq_encode_decode(L):
     close(out, O.lfq_codes(sd, ids_ref), 1e-5, 'lfq codes')
 
 
+@pytest.mark.parametrize('M,D,cd', [(4608, 512, 16), (5, 128, 8), (333, 96, 10), (100, 512, 12)])
+def test_lfq_decode_shapes(L, M, D, cd):
+    """the register-resident outer-product kernel (cd 8 / 16, D/4 dividing 256) and the generic fallback"""
+    sd = {'vq.project_in.weight': torch.zeros(cd, D), 'vq.project_out.weight': torch.randn(D, cd, generator=g(21)) / 4,
+          'vq.project_out.bias': torch.randn(D, generator=g(22)) * 0.05}
+    ids = torch.randint(0, 2 ** cd, (M,), generator=g(23))
+    out = torch.full((M, D), float('nan'), device='cuda')
+    L.lfq_decode(ids.cuda(), sd['vq.project_out.weight'].cuda(), sd['vq.project_out.bias'].cuda(), out, M, D, cd)
+    close(out, O.lfq_codes(sd, ids), 1e-5, f'lfq codes {M}x{D} cd={cd}')
+
+
+@pytest.mark.parametrize('a,b,c,D,cd', [(2, 16, 3, 128, 8), (2, 64, 9, 512, 16), (1, 5, 7, 1024, 13), (3, 1, 1, 64, 4)])
+def test_layernorm_lfq_fused(L, a, b, c, D, cd):
+    """pk_layernorm_lfq = pk_layernorm (rows (a,b,c) -> (a,c,b)) followed by pk_lfq_encode, in one launch"""
+    M = a * b * c
+    x = torch.randn(M, D, generator=g(30)) * 2 + 0.3
+    gamma, beta = 1 + 0.1 * torch.randn(D, generator=g(31)), torch.zeros(D)
+    wp, bp = torch.randn(cd, D, generator=g(32)) / math.sqrt(D), torch.randn(cd, generator=g(33)) * 0.05
+    y = F.layer_norm(x, (D,), gamma, beta).reshape(a, b, c, D).transpose(1, 2).reshape(M, D)
+    proj_ref = y @ wp.t() + bp
+    ids_ref = O.lfq_ids(proj_ref)
+    ids = torch.full((M,), -1, device='cuda', dtype=torch.int64)
+    proj = torch.empty(M, cd, device='cuda')
+    tok = torch.empty(M, D, device='cuda')
+    L.layernorm_lfq(x.cuda(), gamma.cuda(), beta.cuda(), wp.cuda(), bp.cuda(), ids, M, D, cd, tokens=tok, proj=proj, perm=(b, c))
+    close(tok, y, 1e-5, 'fused LN tokens')
+    close(proj, proj_ref, 1e-5, 'fused lfq proj')
+    safe = (proj_ref.abs() > 1e-4).all(dim=-1)
+    assert safe.float().mean() > 0.9
+    assert torch.equal(ids.cpu()[safe], ids_ref[safe])
+    assert ((ids >= 0) & (ids < 2 ** cd)).all()
+    ids2 = torch.full((M,), -1, device='cuda', dtype=torch.int64)           # no optional outputs, identity row order
+    L.layernorm_lfq(x.cuda(), gamma.cuda(), None, wp.cuda(), bp.cuda(), ids2, M, D, cd)
+    ref2 = O.lfq_ids(F.layer_norm(x, (D,), gamma, None) @ wp.t() + bp)
+    p2 = F.layer_norm(x, (D,), gamma, None) @ wp.t() + bp
+    safe2 = (p2.abs() > 1e-4).all(dim=-1)
+    assert torch.equal(ids2.cpu()[safe2], ref2[safe2])
+
+
 def test_embed(L):
     V, n, D, S = 257, 20, 128, 3
     tok, pos = torch.randn(V, D, generator=g(23)), torch.randn(64, D, generator=g(24))
     ids = torch.randint(0, V, (S, n), generator=g(25))
     out = torch.empty(S * n, D, device='cuda')
-    L.embed(ids.cuda(), tok.cuda(), pos.cuda(), out, S * n, n, D)
+    L.embed(ids.cuda(), tok.cuda(), pos.cuda(), out, S, n, D)
     assert torch.equal(out.cpu(), (tok[ids] + pos[:n]).reshape(S * n, D))
+    # cond | null replicas read the same id rows; primed tokens come first (phenaki_pytorch.py:500)
+    npr = 7
+    prime = torch.randint(0, V, (S, npr), generator=g(26))
+    out2 = torch.empty(2 * S * (npr + n), D, device='cuda')
+    L.embed(ids.cuda(), tok.cuda(), pos.cuda(), out2, 2 * S, n, D, nb=S, ids_prime=prime.cuda())
+    full = torch.cat((prime, ids), dim=1)
+    ref2 = (tok[full] + pos[:npr + n]).reshape(S * (npr + n), D)
+    assert torch.equal(out2.cpu(), torch.cat((ref2, ref2), dim=0))
 
 
 @pytest.mark.parametrize('dims,D,heads', [((3, 4, 4), 64, 2), ((8, 8), 128, 8), ((2, 3, 5), 64, 8)])
@@ -453,9 +500,12 @@ def test_vocab_sample_fast_mode_matches_its_numpy_twin(L):
         preds.append(pred.cpu())
     assert torch.equal(preds[0], preds[1]), 'FAST mode must be deterministic for a fixed seed'
     idx = np.arange(M * V, dtype=np.uint64)
-    U = torch.from_numpy(uniform24_np(seed, idx)).reshape(M, V)
+    U = torch.from_numpy(uniform24x4_np(seed, idx)).reshape(M, V)
     assert 0.45 < U.mean() < 0.55 and U.min() >= 0 and U.max() < 1
-    noisy = (e @ W.t() + b) / 0.7 + (-torch.log(-torch.log(U + 1e-10) + 1e-10))
+    for r in range(4):                                           # the four draws of a group are distinct streams
+        assert 0.45 < U[:, r::4].mean() < 0.55
+    assert abs(np.corrcoef(U[:, 0::4].flatten().numpy(), U[:, 3::4].flatten().numpy())[0, 1]) < 0.02
+    noisy = (e @ W.t() + b) / 0.7 + (-torch.log(-torch.log(U)))          # FAST mode has no eps terms: u = 0 -> -inf
     top2 = noisy.topk(2, dim=-1).values
     safe = (top2[:, 0] - top2[:, 1]) > 1e-3 * noisy.abs().max()
     assert safe.float().mean() > 0.95
@@ -464,6 +514,12 @@ def test_vocab_sample_fast_mode_matches_its_numpy_twin(L):
     pred2 = torch.empty(M, device='cuda', dtype=torch.int64)
     L.vocab_reduce(partials, M, V, None, None, None, pred2, None, False)
     assert (pred2.cpu() != preds[0]).float().mean() > 0.2, 'a different seed must change the draws'
+    # a device-resident seed word is ADDED to the by-value seed (hipGraph replays draw fresh noise): seed - 5 + [5] == seed
+    sd = torch.tensor([5], device='cuda', dtype=torch.int64)
+    L.vocab_sample(L.F32, e.cuda(), W.cuda(), b.cuda(), M, V, D, 0.7, None, None, seed - 5, False, partials, seed_dev=sd)
+    pred3 = torch.empty(M, device='cuda', dtype=torch.int64)
+    L.vocab_reduce(partials, M, V, None, None, None, pred3, None, False)
+    assert torch.equal(pred3.cpu(), preds[0])
 
 
 @pytest.mark.parametrize('B,n,k', [(3, 48, 1), (3, 48, 47), (2, 576, 288), (1, 1024, 50)])
@@ -475,7 +531,9 @@ def test_topk_mask(L, B, n, k):
     mask = torch.zeros(B, n, device='cuda', dtype=torch.uint8)
     ids = ids0.clone().cuda()
     rows = torch.full((B * k,), -1, device='cuda', dtype=torch.int32)
-    L.topk_mask(scores.cuda(), B, n, k, 100, mask, ids, rows)
+    nxt = torch.zeros(B, n, device='cuda')
+    L.topk_mask(scores.cuda(), B, n, k, 100, mask, ids, rows, scores_next=nxt)
+    assert (nxt == -1e4).all()
     assert torch.equal(mask.cpu().bool(), mask_ref)
     assert torch.equal(ids.cpu(), torch.where(mask_ref, 100, ids0))
     flat = (idx + torch.arange(B)[:, None] * n).reshape(-1)            # topk order = descending score = rank order
@@ -497,3 +555,10 @@ def test_cfg_mix_and_critic_head(L):
     outs = torch.empty(nb, n_tot - n_prime, device='cuda')
     L.critic_head(x.cuda(), w.cuda(), b.cuda(), D, nb, n_tot, n_prime, True, 5., u.cuda(), 0.5, outs)
     close(outs, ref_s, 1e-5, 'critic head')
+    # FAST mode: the uniform draw comes from the counter hash (seed by value + device word), stream 0xC817
+    seed = 0x0123456789ABCDEF
+    sd = torch.tensor([1000], device='cuda', dtype=torch.int64)
+    L.critic_head(x.cuda(), w.cuda(), b.cuda(), D, nb, n_tot, n_prime, True, 5., None, 0.5, outs, seed=seed - 1000, seed_dev=sd)
+    r = np.arange(nb * (n_tot - n_prime), dtype=np.uint64) | (np.uint64(0xC817) << np.uint64(32))
+    uh = torch.from_numpy(uniform24_np(seed, r)).reshape(nb, n_tot - n_prime)
+    close(outs, (sn + (sc - sn) * 5.)[:, n_prime:] + 0.5 * (uh - 0.5), 1e-5, 'critic head hash noise')

@@ -121,6 +121,23 @@ def _mix32(h):
     return h
 
 
+def uniform24x4_np(seed, idx):
+    """numpy twin of csrc/common.hpp uniform24x4: the FAST-mode draw for flat element index idx (row * V + col, V % 4 == 0):
+    group q = idx >> 2 runs one hash chain, its three finalisers give 96 bits = 4 x 24."""
+    with np.errstate(over='ignore'):
+        idx = idx.astype(np.uint64)
+        q, r = idx >> np.uint64(2), (idx & np.uint64(3)).astype(np.int64)
+        lo = (q & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        hi = (q >> np.uint64(32)).astype(np.uint32)
+        s_lo, s_hi = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
+        h = _mix32(lo ^ s_lo)
+        h = (h + np.uint32(0x9e3779b9) * (hi + np.uint32(1)) + s_hi).astype(np.uint32)
+        w0, w1, w2 = _mix32(h.copy()), _mix32((h + np.uint32(0x85EBCA77)).astype(np.uint32)), _mix32((h + np.uint32(0x0BD794EE)).astype(np.uint32))
+        last = ((w0 & np.uint32(0xFF)) << np.uint32(16)) | ((w1 & np.uint32(0xFF)) << np.uint32(8)) | (w2 & np.uint32(0xFF))
+        bits = np.select([r == 0, r == 1, r == 2], [w0 >> np.uint32(8), w1 >> np.uint32(8), w2 >> np.uint32(8)], last)
+        return bits.astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+
 def uniform24_np(seed, idx):
     """idx: uint64 array of flat element indices (row * V + col); seed: python int (uint64)."""
     with np.errstate(over='ignore'):
