@@ -3,21 +3,32 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one batch of synthetic input: BASELINE.json configs[1], the C-ViViT
-tokenizer (dim 512, patch 32, temporal patch 2, depth 4+4, LFQ 65 536) encoding a (8, 3, 17, 256, 256) f32 video that
-is already resident in HBM into (8, 9, 8, 8) int64 token ids, bf16 MFMA operands / f32 accumulation.  With N > 1 every
-rank encodes its own 8 videos (batch sharding, weak scaling, no collective on the data path); the timed region is
-bracketed by barrier + synchronize and the reported time is the max over ranks.
+A "step" is one pass of the hot path over one batch of synthetic input: BASELINE.json configs[1], the C-ViViT tokenizer
+(dim 512, patch 32, temporal patch 2, depth 4+4, LFQ 65 536) encoding a (8, 3, 17, 256, 256) f32 video that is already
+resident in HBM into (8, 9, 8, 8) int64 token ids, bf16 MFMA operands / f32 accumulation.  With N > 1 every rank encodes
+its own 8 videos (batch sharding, weak scaling, no collective on the data path).  The timed region is K steps bracketed by
+barrier + synchronize; it is repeated `--groups` times and the MEDIAN group is reported (a 20-step region is 20 ms: one
+scheduling hiccup would move a single region by several per cent), max over ranks.  The steps rotate through `--rotate`
+distinct input batches (3 x 107 MB > the 256 MB Infinity Cache) so the video really comes from HBM.
 
-The same JSON line also carries
-  roofline     : the dominant kernel (the MFMA GEMM) -- algorithmic flops / launch over the live HIP-event duration;
+The same JSON line carries
+  roofline     : the encode leg's dominant kernel -- algorithmic flops per launch over its live HIP-event duration, plus the
+                 HBM traffic per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic_r02.json);
+  kernels      : every kernel of the encode / decode / sampling legs against ITS roofline (HBM GB/s for the patch / VQ /
+                 norm / PEG kernels, MFMA TFLOP/s for the GEMM / attention / vocab-head kernels), from in-run HIP events;
+  decode       : C-ViViT decode ids -> pixels, frames/s;
+  sample       : MaskGIT sampled tokens/s of an 18-step Phenaki.sample (configs[2]; with N > 1 through sample_sharded,
+                 i.e. WITH the one RCCL all-gather of the decoded videos inside the timed region), eager and hipGraph;
+  sample_cfg3  : the same at configs[3]'s per-GPU batch (32 videos over 8 GPUs = 4 per GPU);
+  make_video   : configs[4], 3 scenes (17, 14, 14 frames, prime K = 5), one video per GPU, tokens/s and wall-clock;
+  parity_mode  : the exact-f32 mode (the one held to bit-exact ids / 1e-3 against the reference) timed on the same legs;
   cpu_baseline : the CPU oracle (a port of the reference algorithm, oracle/phenaki_oracle.py) on a bounded sample of
-                 the same workload on this box's host cores;
-  sample       : the second half of the metric, MaskGIT sampled tokens/sec of an 18-step Phenaki.sample (configs[2]).
+                 the same workload on this box's host cores.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -31,7 +42,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
-PEAK_HBM_GBS = 8000.0
+PEAK_F32_TFLOPS = 157.3          # f32-input MFMA = the f32 vector rate
+PEAK_HBM_GBS = 8000.0            # HBM3E spec
 
 
 def parse():
@@ -39,11 +51,16 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--groups', type=int, default=25, help='timed regions of --steps steps; the median is reported')
+    ap.add_argument('--rotate', type=int, default=3, help='distinct input batches the steps rotate through')
     ap.add_argument('--batch', type=int, default=8, help='videos per GPU (configs[1]: 8)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
-    ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a captured hipGraph')
-    ap.add_argument('--no-sample', action='store_true', help='skip the MaskGIT sampling leg')
+    ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying captured hipGraphs')
+    ap.add_argument('--no-sample', action='store_true', help='skip the MaskGIT sampling / make_video / objective legs')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    ap.add_argument('--no-parity-mode', action='store_true', help='skip the exact-f32 timing')
+    ap.add_argument('--no-kernels', action='store_true', help='skip the per-kernel roofline table')
+    ap.add_argument('--encode-only', action='store_true', help='only the headline leg (profiling runs)')
     ap.add_argument('--sample-batch', type=int, default=8)
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     return ap.parse_args()
@@ -78,6 +95,21 @@ def max_over_ranks(x, ws):
     t = torch.tensor([x], device='cuda', dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def timed_groups(fn, steps, groups, ws):
+    """`groups` timed regions of exactly `steps` calls of fn(i), each bracketed by barrier + synchronize, max over ranks per
+    region; returns the list of region times (s)."""
+    out, i = [], 0
+    for _ in range(groups):
+        barrier_sync(ws)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn(i)
+            i += 1
+        barrier_sync(ws)
+        out.append(max_over_ranks(time.perf_counter() - t0, ws))
+    return out
 
 
 # BASELINE.json configs[1..2]: C-ViViT dim 512 / codebook 65 536 / 256x256 / patch 32 / temporal patch 2 / depth 4+4;
@@ -125,153 +157,338 @@ def synthetic_context(batch, length, dim, seed):
     return torch.randn(batch, length, dim, generator=g)
 
 
+def capture(fn):
+    """fn() captured as one hipGraph (after a side-stream warm-up); returns (replay, outputs)"""
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(graph):
+        out = fn()
+    return graph.replay, out
+
+
+# ------------------------------------------------------------------------------------------ per-kernel rooflines
+
 # template order: T, TM, TN, WM, WN, STAGES, ROWB, PW (the names rocprofv3 prints)
 VARIANT_KERNEL = {1: 'gemm_kernel<T,TA,2,2>', 2: 'gemm_kernel<T,TA,4,4>', 3: 'gemm_dma_kernel<T,2,2,2,2,4,128,0>',
                   8: 'gemm_dma_kernel<T,2,2,2,2,2,128,0>', 9: 'gemm_dma_kernel<T,4,4,2,2,2,128,0>',
                   24: 'gemm_dma_kernel<T,4,2,2,4,2,128,0>', 33: 'gemm_dma_kernel<T,2,2,2,2,3,128,2>'}
 
 
-class GemmProfiler:
-    """live HIP-event timing of the pk_gemm launches of one (untimed, eager) pass of the step, on the stream the
-    kernels run on: every launch of the pass is recorded with its live operands, then each one is re-issued REPS times
-    back to back between two HIP events (a per-launch event pair around a ~10 us kernel mostly measures the events).
-    Grouped by the kernel instantiation pk_gemm picked (the names rocprofv3 reports)."""
-    REPS = 20
+def _esz(t):
+    return 0 if t is None else t.element_size()
 
-    def __init__(self):
+
+class KernelProfiler:
+    """live HIP-event timing of every libphenaki_hip launch of one (untimed, eager) pass, on the stream the kernels run on:
+    each launch of the pass is recorded with its live operands, then re-issued REPS times back to back between two HIP
+    events (an event pair around ONE ~10 us kernel mostly measures the events).  Every launch carries its algorithmic work:
+    flops for the MFMA kernels, bytes for the HBM-bound ones (DESIGN.md section 4 lists the per-unit figures)."""
+    REPS = 10
+
+    def __init__(self, leg, f32_mode=False):
+        self.leg, self.f32 = leg, f32_mode
         self.calls = []
+
+    # (label, bound, work) of one wrapper call; work = flops ('mfma') or bytes ('hbm')
+    def _model(self, name, a, kw):
+        lib = self._lib
+        if name == 'gemm':
+            dtype, A, W, M, N, K = a[:6]
+            a_is_f32 = 1 if A.dtype == torch.float32 else 0
+            rows = A.shape[0] if kw.get('a_rows') is not None else M
+            v = kw.get('variant') or lib.load().pk_gemm_auto_variant(dtype, a_is_f32, M, N, K, kw.get('lda') or A.stride(-2), W.stride(0), rows)
+            t = 'pk::bf16' if dtype == lib.BF16 else 'float'
+            label = VARIANT_KERNEL.get(v, f'gemm variant{v}').replace('TA', 'float' if a_is_f32 else t).replace('T', t)
+            return label, 'mfma', 2.0 * M * N * K
+        if name == 'qkv_project':
+            xq, xkv, wq, wkv, S, nseq, h, K = a[:8]
+            return f'qkv_project_kernel[n={nseq}]', 'mfma', 2.0 * S * nseq * K * 64 * h * (3 if xkv is not None else 1)
+        if name == 'attn_fwd':
+            dtype, Qp, Kp, Vt, O, S, h, nq, n_kv, nnull = a[:10]
+            return f'attn_fwd[nq={nq},nk={n_kv + nnull}]', 'mfma', 4.0 * S * h * nq * (n_kv + nnull) * 64
+        if name == 'attn_small':
+            S, h, n = a[6:9]
+            return f'attn_small_kernel[n={n}]', 'valu', 4.0 * S * h * n * n * 64
+        if name == 'vocab_sample':
+            dtype, A, W, bias, M, V, D = a[:7]
+            return 'vocab_sample_kernel', 'mfma', 2.0 * M * V * D
+        if name == 'layernorm':
+            x, gamma, beta, M, D = a[:5]
+            b = 4 * M * D + sum(_esz(kw.get(k)) * M * D for k in ('out', 'out2', 'raw'))
+            return f'ln_rows_kernel[D={D}]', 'hbm', b
+        if name == 'layernorm_lfq':
+            M, D = a[6], a[7]
+            return 'ln_lfq_kernel', 'hbm', 4 * M * D + 8 * M
+        if name == 'patchify_ln':
+            video, f0, nt, pt, ph, pw, weight, bias, out = a[:9]
+            B, C, F, H, W = video.shape
+            rows, P = B * nt * (H // ph) * (W // pw), C * pt * ph * pw
+            return f'patchify_ln_kernel[P={P}]', 'hbm', rows * P * (4 + _esz(out))
+        if name == 'unpatchify':
+            pix, video, f0, nt, pt, ph, pw = a[:7]
+            B, C, F, H, W = video.shape
+            return 'unpatchify_kernel', 'hbm', 8 * B * nt * pt * C * H * W
+        if name == 'peg':
+            B, T, H, W, D = a[4:9]
+            return 'peg_row_kernel', 'hbm', 8 * B * T * H * W * D
+        if name == 'lfq_encode':
+            M, D = a[5], a[6]
+            return 'lfq_encode_kernel', 'hbm', 4 * M * D + 8 * M
+        if name == 'lfq_decode':
+            M, D = a[4], a[5]
+            return 'lfq_decode_kernel', 'hbm', 4 * M * D + 8 * M
+        if name == 'embed':
+            ids, tok, pos, out, S, n, D = a[:7]
+            npr = kw['ids_prime'].shape[-1] if kw.get('ids_prime') is not None else 0
+            return 'embed_kernel', 'hbm', 8 * S * (n + npr) * D
+        if name == 'cfg_mix':
+            x, nb, n_tot, n_prime, rows, nrows, scale, has_null, out, D = a[:10]
+            return 'cfg_mix_kernel', 'hbm', nrows * D * (4 * (2 if has_null else 1) + _esz(out))
+        if name == 'critic_head':
+            x, w, b, D, nb, n_tot, n_prime, has_null = a[:8]
+            return 'critic_head_kernel', 'hbm', 4 * nb * (n_tot - n_prime) * D * (2 if has_null else 1)
+        if name == 'attn_prep':
+            dtype, q, kv = a[:3]
+            return 'attn_prep kernels', 'hbm', q.numel() * 4 + (kv.numel() * 4 if kv is not None else 0)
+        if name in ('vocab_reduce', 'topk_mask', 'l2norm_rows', 'cpb_input', 'vocab_ce', 'sqdiff_sum'):
+            return f'{name} kernel', 'latency', 0
+        return None
 
     def __enter__(self):
         from phenaki_pytorch_amd import _lib
         self._lib = _lib
-        self._orig = _lib.gemm
+        self._orig = {}
         prof = self
+        names = ['gemm', 'qkv_project', 'attn_fwd', 'attn_small', 'vocab_sample', 'layernorm', 'layernorm_lfq', 'patchify_ln',
+                 'unpatchify', 'peg', 'lfq_encode', 'lfq_decode', 'embed', 'cfg_mix', 'critic_head', 'attn_prep', 'vocab_reduce',
+                 'topk_mask', 'l2norm_rows']
 
-        def gemm(dtype, A, W, M, N, K, **kw):
-            prof.calls.append((dtype, A, W, M, N, K, kw))
-            return prof._orig(dtype, A, W, M, N, K, **kw)
-        _lib.gemm = gemm
+        def wrap(name, fn):
+            def inner(*a, **kw):
+                prof.calls.append((name, fn, a, kw))
+                return fn(*a, **kw)
+            return inner
+        for n in names:
+            self._orig[n] = getattr(_lib, n)
+            setattr(_lib, n, wrap(n, self._orig[n]))
         return self
 
     def __exit__(self, *exc):
-        self._lib.gemm = self._orig
+        for n, fn in self._orig.items():
+            setattr(self._lib, n, fn)
         torch.cuda.synchronize()
 
-    def summary(self):
-        lib, by = self._lib, {}
-        for dtype, A, W, M, N, K, kw in self.calls:
-            a_is_f32 = 1 if A.dtype == torch.float32 else 0
-            rows = A.shape[0] if kw.get('a_rows') is not None else M
-            v = lib.load().pk_gemm_auto_variant(dtype, a_is_f32, M, N, K, A.stride(-2), W.stride(0), rows)
-            t = 'pk::bf16' if dtype == lib.BF16 else 'float'
-            name = VARIANT_KERNEL.get(v, f'variant{v}').replace('TA', 'float' if a_is_f32 else t).replace('T', t)
+    def table(self):
+        by = {}
+        for name, fn, a, kw in self.calls:
+            m = self._model(name, a, kw)
+            if m is None:
+                continue
+            label, bound, work = m
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            self._orig(dtype, A, W, M, N, K, **kw)
+            fn(*a, **kw)
             e0.record()
             for _ in range(self.REPS):
-                self._orig(dtype, A, W, M, N, K, **kw)
+                fn(*a, **kw)
             e1.record()
             torch.cuda.synchronize()
-            d = by.setdefault(name, [0, 0.0, 0.0])
+            d = by.setdefault((label, bound), [0, 0.0, 0.0])
             d[0] += 1
-            d[1] += 2.0 * M * N * K
+            d[1] += work
             d[2] += e0.elapsed_time(e1) * 1e-3 / self.REPS
-        return {k: dict(launches=v[0], flops=v[1], seconds=v[2]) for k, v in by.items()}
+        self.calls = []
+        rows = []
+        for (label, bound), (launches, work, secs) in by.items():
+            r = dict(kernel=label, leg=self.leg, launches=launches, avg_us=secs / launches * 1e6, us_total=secs * 1e6, bound=bound)
+            if bound in ('mfma', 'valu'):
+                peak = PEAK_F32_TFLOPS if (self.f32 or bound == 'valu' or 'float' in label) else PEAK_BF16_TFLOPS
+                r.update(achieved=work / secs / 1e12, unit='TFLOP/s', peak=peak, algorithmic_flops_per_launch=work / launches)
+            elif bound == 'hbm':
+                r.update(achieved=work / secs / 1e9, unit='GB/s', peak=PEAK_HBM_GBS, algorithmic_bytes_per_launch=work / launches)
+            if 'achieved' in r:
+                r['frac'] = r['achieved'] / r['peak']
+            rows.append(r)
+        rows.sort(key=lambda r: -r['us_total'])
+        return rows
 
 
-def pmc_traffic(kernel, args):
-    """HBM bytes per launch of the encode leg's dominant kernel.  PMC counters need their own rocprofv3 passes (they cannot
-    be collected from inside this process), so this is the committed measurement of exactly this configuration
-    (profiles/gemm_hbm_pmc_r01.txt: mean of the 8 to_out + 8 FF2 launches of a step), or None for any other."""
-    if kernel == 'gemm_dma_kernel<pk::bf16,2,2,2,2,2,128,0>' and args.dtype == 'bf16' and args.batch == 8:
-        return 35.57e6
-    return None
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this bench's encode leg (counters need their
+    own rocprofv3 runs -- they cannot be collected from inside this process): profiles/pmc_traffic_r02.json, written by
+    tools/pmc_traffic.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 read correction."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic_r02.json')
+    if not os.path.exists(path):
+        return None, None
+    try:
+        tab = json.load(open(path))
+    except (OSError, ValueError):
+        return None, None
+    key = kernel.replace(' ', '')
+    for name, rec in tab.get('kernels', {}).items():
+        if name.replace(' ', '') == key:
+            return rec.get('hbm_bytes_per_launch'), tab.get('source')
+    return None, None
 
 
-def bench_encode(cv, args, ws):
-    B = args.batch
-    video = synthetic_video(B, 17, 256, seed=int(os.environ.get('RANK', 0))).cuda()
+def roofline_of(rows, dtype):
+    """the roofline object of a leg: its dominant MFMA kernel by total time"""
+    cand = [r for r in rows if r['bound'] == 'mfma']
+    if not cand:
+        return None
+    r = cand[0]
+    traffic, src = pmc_traffic(r['kernel'])
+    return {'bound': 'mfma', 'kernel': r['kernel'], 'achieved': r['achieved'], 'peak': r['peak'], 'unit': 'TFLOP/s', 'frac': r['frac'],
+            'traffic': traffic, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': src,
+            'launches_per_step': r['launches'], 'avg_launch_us': r['avg_us'], 'algorithmic_flops_per_launch': r['algorithmic_flops_per_launch']}
+
+
+# ------------------------------------------------------------------------------------------ legs
+
+def bench_encode(cv, args, ws, want_kernels):
+    B, R = args.batch, max(1, args.rotate)
+    rank = int(os.environ.get('RANK', 0))
+    videos = [synthetic_video(B, 17, 256, seed=7 * rank + i).cuda() for i in range(R)]
     # the metric's own entry point (SURVEY.md 8d): CViViT.forward(video, return_only_codebook_ids=True)
-    step = lambda: cv(video, return_only_codebook_ids=True)
-    ids = step()                                   # builds the packed weights / bias caches
+    ids0 = cv(videos[0], return_only_codebook_ids=True)            # builds the packed weights / bias caches
     torch.cuda.synchronize()
+    steps_fn = [(lambda v=v: cv(v, return_only_codebook_ids=True)) for v in videos]
     used_graph = False
     if not args.no_graph:
         try:
-            graph = torch.cuda.CUDAGraph()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step()
-            torch.cuda.current_stream().wait_stream(side)
-            with torch.cuda.graph(graph):
-                ids_g = step()
-            graph.replay()
-            torch.cuda.synchronize()
-            assert torch.equal(ids_g, ids), 'graph replay changed the token ids'
-            step = graph.replay
-            used_graph = True
+            replays = []
+            for i, f in enumerate(steps_fn):
+                rp, out = capture(f)
+                rp()
+                torch.cuda.synchronize()
+                if i == 0:
+                    assert torch.equal(out, ids0), 'graph replay changed the token ids'
+                replays.append(rp)
+            steps_fn, used_graph = replays, True
         except Exception as e:                     # noqa: BLE001  (recorded in the JSON, never silent)
             print(f'[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
             torch.cuda.synchronize()
-            step = lambda: cv(video, return_only_codebook_ids=True)
-    for _ in range(args.warmup):
-        step()
-    barrier_sync(ws)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier_sync(ws)
-    dt = max_over_ranks(time.perf_counter() - t0, ws)
-    # roofline of the dominant kernel: one extra, untimed, eager pass with HIP events around every GEMM launch
-    with GemmProfiler() as prof:
-        cv(video, return_only_codebook_ids=True)
-    return dt, used_graph, prof.summary(), ids
+    step = lambda i: steps_fn[i % R]()
+    for i in range(args.warmup):
+        step(i)
+    times = timed_groups(step, args.steps, args.groups, ws)
+    rows = None
+    if want_kernels:
+        with KernelProfiler('encode', args.dtype == 'fp32') as prof:
+            cv(videos[0], return_only_codebook_ids=True)
+        rows = prof.table()
+    return times, used_graph, rows
 
 
-def bench_sample(ph, args, ws):
-    """configs[2]: 18-step MaskGIT sampling (CFG scale 5, TokenCritic) with frozen random C-ViViT codes and a cached
-    (random) T5 context; tokens/sec = B * 576 / wall time of Phenaki.sample (including the final decode)."""
-    B = args.sample_batch
+def bench_decode(cv, args, ws, want_kernels):
+    """C-ViViT decode leg (cvivit.py:437-516): (B, 576) token ids -> (B, 3, 17, 256, 256) pixels, frames/s"""
+    B, R = args.batch, max(1, args.rotate)
+    g = torch.Generator(device='cpu')
+    g.manual_seed(5)
+    idsets = [torch.randint(0, 65536, (B, 576), generator=g).cuda() for _ in range(R)]
+    cv.decode_from_codebook_indices(idsets[0])
+    torch.cuda.synchronize()
+    fns = [(lambda t=t: cv.decode_from_codebook_indices(t)) for t in idsets]
+    used_graph = False
+    if not args.no_graph:
+        try:
+            fns = [capture(f)[0] for f in fns]
+            used_graph = True
+        except Exception as e:                     # noqa: BLE001
+            print(f'[bench] decode hipGraph capture failed ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
+            fns = [(lambda t=t: cv.decode_from_codebook_indices(t)) for t in idsets]
+    step = lambda i: fns[i % R]()
+    for i in range(args.warmup):
+        step(i)
+    groups = max(5, args.groups // 3)
+    times = timed_groups(step, args.steps, groups, ws)
+    med = statistics.median(times)
+    out = dict(metric='cvivit_decode_frames_per_sec', value=B * 17 * args.steps * ws / med, unit='frames/s', ms_per_step=med / args.steps * 1e3,
+               batch_per_gpu=B, hip_graph=used_graph, groups=groups,
+               roofline_note='13.37 MB f32 pixels written per video is the HBM floor (SURVEY.md 8d); per-kernel fractions in `kernels`')
+    rows = None
+    if want_kernels:
+        with KernelProfiler('decode', args.dtype == 'fp32') as prof:
+            cv.decode_from_codebook_indices(idsets[0])
+        rows = prof.table()
+    return out, rows
+
+
+def _sample_call(ph, B_local, ws, ctx, **kw):
+    """one Phenaki.sample of the whole job: B_local videos per GPU; with ws > 1 through sample_sharded, i.e. including the
+    RCCL all-gather of the decoded videos (the one collective of the design)"""
+    from phenaki_pytorch_amd import sample_sharded
+    if ws == 1:
+        return ph.sample(texts=['x'] * B_local, num_frames=17, cond_scale=5., **kw)
+    return sample_sharded(ph, texts=['x'] * (B_local * ws), num_frames=17, cond_scale=5., **kw)
+
+
+def bench_sample(ph, args, ws, B, name, want_kernels):
+    """configs[2] / [3]: 18-step MaskGIT sampling (CFG scale 5, TokenCritic) with frozen random C-ViViT weights and a cached
+    (random) T5 context; tokens/sec = global batch * 576 / wall time of the sample call (final decode and, with N > 1, the
+    all-gather of the decoded videos included)."""
     ctx = synthetic_context(B, 12, 768, seed=1).cuda()
-    ph.encode_texts = lambda texts, output_device=None: ctx
-    texts = ['x'] * B
+    ph.encode_texts = lambda texts, output_device=None: ctx[:len(texts)]
     torch.manual_seed(0)
-    ph.sample(texts=texts, num_frames=17, cond_scale=5.)          # warm-up (packs weights, position bias)
-    barrier_sync(ws)
-    runs = 2
-    t0 = time.perf_counter()
-    for _ in range(runs):
-        ph.sample(texts=texts, num_frames=17, cond_scale=5.)
-    barrier_sync(ws)
-    dt = max_over_ranks(time.perf_counter() - t0, ws) / runs
-    out = dict(metric='maskgit_sampled_tokens_per_sec', value=B * 576 * ws / dt, unit='tokens/s', seconds_per_sample_call=dt,
-               batch_per_gpu=B, steps=ph.steps, cond_scale=5.0, critic='TokenCritic depth 6 cross-attn', tokens_per_video=576,
-               noise='in-kernel counter hash (FAST mode)')
-    # roofline of this leg's dominant kernel (the MFMA GEMM at M = 2B*576 rows): 2 untimed sampling steps under the profiler
-    steps = ph.steps
-    try:
-        ph.steps = 2
-        with GemmProfiler() as prof:
-            ph.sample(texts=texts, num_frames=17, cond_scale=5.)
-        g = prof.summary()
-    finally:
-        ph.steps = steps
-    if g:
-        name, d = max(g.items(), key=lambda kv: kv[1]['seconds'])
-        ach = d['flops'] / d['seconds'] / 1e12
-        peak = PEAK_BF16_TFLOPS if args.dtype == 'bf16' else 157.3
-        out['roofline'] = {'bound': 'mfma', 'kernel': name, 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                           'traffic': None, 'avg_launch_us': d['seconds'] / d['launches'] * 1e6,
-                           'algorithmic_flops_per_launch': d['flops'] / d['launches'],
-                           'all_gemm_variants': {k: {'launches': v['launches'], 'TFLOP/s': v['flops'] / v['seconds'] / 1e12,
-                                                     'us_total': v['seconds'] * 1e6} for k, v in g.items()}}
-    return out
+    res = {}
+    for mode in (['eager'] if args.no_graph else ['eager', 'graph']):
+        ph.enable_sample_graph(mode == 'graph')
+        try:
+            _sample_call(ph, B, ws, ctx)                       # warm-up (packs weights, position bias; captures the graph)
+            _sample_call(ph, B, ws, ctx)
+            runs = 3
+            ts = timed_groups(lambda i: _sample_call(ph, B, ws, ctx), 1, runs, ws)
+            res[mode] = statistics.median(ts)
+        except Exception as e:                                  # noqa: BLE001
+            print(f'[bench] sample leg in {mode} mode failed ({type(e).__name__}: {e})', file=sys.stderr)
+            torch.cuda.synchronize()
+    ph.enable_sample_graph(False)
+    best = min(res, key=res.get)
+    dt = res[best]
+    out = dict(metric='maskgit_sampled_tokens_per_sec', value=B * 576 * ws / dt, unit='tokens/s', seconds_per_sample_call=dt, launch_mode=best,
+               seconds_by_launch_mode=res, batch_per_gpu=B, global_batch=B * ws, steps=ph.steps, cond_scale=5.0,
+               critic='TokenCritic depth 6 cross-attn', tokens_per_video=576, noise='in-kernel counter hash (FAST mode)',
+               collective='none (1 GPU)' if ws == 1 else f'one all_gather_into_tensor of ({B},3,17,256,256) f32 per rank (RCCL), inside the timed region',
+               workload=name)
+    rows = None
+    if want_kernels:
+        # per-kernel rooflines of this leg: 2 untimed sampling steps under the profiler
+        steps = ph.steps
+        try:
+            ph.steps = 2
+            with KernelProfiler('sample', args.dtype == 'fp32') as prof:
+                ph.sample(texts=['x'] * B, num_frames=17, cond_scale=5.)
+            rows = prof.table()
+        finally:
+            ph.steps = steps
+        out['roofline'] = roofline_of(rows, args.dtype)
+    return out, rows
+
+
+def bench_make_video(ph, args, ws):
+    """configs[4]: make_video, 3 scenes of (17, 14, 14) frames, prime K = 5, 256x256, one video per GPU (batch 8 over 8 GPUs);
+    1 472 sampled tokens per video; tokens/s and wall-clock of the whole call (priming encodes, 3 x 18 steps, 3 decodes, and with
+    N > 1 the single all-gather of the final 45-frame videos)."""
+    from phenaki_pytorch_amd import make_video_sharded
+    ctx = synthetic_context(1, 12, 768, seed=3).cuda()
+    ph.encode_texts = lambda texts, output_device=None: ctx.expand(len(texts), -1, -1).contiguous()
+    texts = [['a', 'b', 'c']] * ws
+    call = lambda: make_video_sharded(ph, texts, (17, 14, 14), 5)
+    video = call()
+    assert tuple(video.shape) == (ws, 3, 45, 256, 256), tuple(video.shape)
+    ts = timed_groups(lambda i: call(), 1, 3, ws)
+    dt = statistics.median(ts)
+    ntok = 576 + 2 * 448
+    return dict(metric='make_video_sampled_tokens_per_sec', value=ws * ntok / dt, unit='tokens/s', wall_clock_s=dt, videos=ws,
+                videos_per_gpu=1, scenes=[17, 14, 14], prime_frames=5, tokens_per_video=ntok, frames_out=45)
 
 
 def bench_objective(ph, args, ws):
     """SURVEY.md 8f row 1, first slice: Phenaki.forward -- the VALUE of the training objective (masked cross entropy without
-    logits + token-critic BCE) on B videos' worth of token ids; videos/sec.  Reported beside the two headline legs."""
+    logits + token-critic BCE) on B videos' worth of token ids; videos/sec.  Reported beside the headline legs."""
     B = args.sample_batch
     ctx = synthetic_context(B, 12, 768, seed=1).cuda()
     g = torch.Generator(device='cpu')
@@ -279,22 +496,38 @@ def bench_objective(ph, args, ws):
     ids = torch.randint(0, 65536, (B, 9, 8, 8), generator=g).cuda()
     torch.manual_seed(0)
     ph(video_codebook_ids=ids, text_embeds=ctx)                 # warm-up
-    barrier_sync(ws)
-    runs = 5
-    t0 = time.perf_counter()
-    for _ in range(runs):
-        loss = ph(video_codebook_ids=ids, text_embeds=ctx)
-    barrier_sync(ws)
-    dt = max_over_ranks(time.perf_counter() - t0, ws) / runs
+    ts = timed_groups(lambda i: ph(video_codebook_ids=ids, text_embeds=ctx), 5, 3, ws)
+    dt = statistics.median(ts) / 5
+    loss = ph(video_codebook_ids=ids, text_embeds=ctx)
     return dict(metric='phenaki_forward_objective_videos_per_sec', value=B * ws / dt, unit='videos/s', ms_per_call=dt * 1e3,
                 batch_per_gpu=B, tokens_per_video=576, loss=float(loss),
                 note='forward value only (no autograd graph): MaskGit trunk + vocab head with fused gumbel sampling and '
                      'cross entropy (logits never written) + TokenCritic trunk + BCE; random-init weights, random ids')
 
 
+def bench_parity_mode(args, ws):
+    """the exact-f32 mode -- the configuration the parity tests hold to bit-exact ids / 1e-3 against the REAL reference --
+    timed on the same workloads (v_mfma_f32_16x16x4_f32: 157.3 TFLOP/s peak, 1/16 of bf16)."""
+    import copy
+    a = copy.copy(args)
+    a.dtype, a.groups, a.no_graph = 'fp32', max(5, args.groups // 5), args.no_graph
+    cv, mg, cr, ph = build_models('fp32', not args.no_sample)
+    times, used_graph, rows = bench_encode(cv, a, ws, True)
+    med = statistics.median(times)
+    out = dict(dtype='f32', metric='cvivit_encode_frames_per_sec', value=a.batch * 17 * a.steps * ws / med, unit='frames/s',
+               ms_per_step=med / a.steps * 1e3, hip_graph=used_graph, roofline=roofline_of(rows, 'fp32'),
+               tolerance='ids bit-exact (margin-audited), logits / pixels 1e-3 vs the reference goldens (tests/test_modules_gpu.py)')
+    if not args.no_sample:
+        s, _ = bench_sample(ph, a, ws, args.sample_batch, 'BASELINE configs[2] in exact f32', True)
+        out['sample'] = {k: s[k] for k in ('metric', 'value', 'unit', 'seconds_per_sample_call', 'launch_mode', 'batch_per_gpu', 'roofline') if k in s}
+    del cv, mg, cr, ph
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(args):
     """the CPU oracle (port of the reference algorithm) on a bounded sample: B = 2 videos per call, repeated for
-    ~cpu_seconds; frames/sec on this box's host cores."""
+    ~cpu_seconds; frames/sec on this box's host cores; then ONE real (short) Phenaki.sample of the port: 4 steps, B = 1."""
     from oracle import phenaki_oracle as O
     from oracle import weights
     from oracle.configs import FULL, oracle_cfgs, state_dicts
@@ -313,19 +546,17 @@ def cpu_baseline(args):
     out = dict(value=n * 2 * 17 / dt, unit='frames/s', cores=torch.get_num_threads(), kind='port',
                sample=f'{n} calls of oracle cvivit_tokenize on (2,3,17,256,256) f32, {dt:.1f} s')
     if not args.no_sample:
-        # sampler: 1 CFG MaskGit step + 1 CFG critic step at B = 1, scaled to the 18-step loop
         ctx = weights.synthetic_context(1, 12, 768, seed=1)
-        ids = torch.full((1, 576), 65536)
+        steps = 4
+        nf = lambda kind, step, shape: weights.uniform_noise(tuple(shape), 100 + 2 * step + (1 if kind == 'critic' else 0))
         with torch.no_grad():
             t0 = time.perf_counter()
-            O.maskgit_cfg(mg_sd, mgc, ids, cond_scale=5., video_patch_shape=(9, 8, 8), context=ctx, text_mask=(ctx != 0).any(-1))
-            t_mg = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            O.critic_cfg(cr_sd, crc, ids, cond_scale=5., video_patch_shape=(9, 8, 8), context=ctx, text_mask=(ctx != 0).any(-1))
-            t_cr = time.perf_counter() - t0
-        est = 18 * t_mg + 17 * t_cr
-        out['sample'] += f'; sampler: 1 CFG MaskGit forward {t_mg:.2f} s + 1 CFG critic forward {t_cr:.2f} s at B=1'
-        out['sample_tokens_per_sec_estimate'] = 576 / est
+            O.sample(cv_sd, cvc, mg_sd, mgc, cr_sd, crc, num_frames=17, batch_size=1, context=ctx, steps=steps, cond_scale=5., noise_fn=nf)
+            ts = time.perf_counter() - t0
+        out['sample'] += f'; sampler: one real oracle.sample, {steps} steps (of 18), B=1, CFG 5, TokenCritic, incl. decode: {ts:.1f} s'
+        # per-step cost is constant (every step runs the full 2 x 576-token trunks): 18 steps ~ 18/4 of the timed loop
+        out['sample_tokens_per_sec'] = 576 / (ts * 18 / steps)
+        out['sample_kind'] = 'port, 4 of 18 steps timed, scaled by 18/4'
     return out
 
 
@@ -337,37 +568,46 @@ def main():
     if rank == 0:
         build()
     barrier_sync(ws)
-    cv, mg, cr, ph = build_models(args.dtype, not args.no_sample)
+    sampler = not (args.no_sample or args.encode_only)
+    cv, mg, cr, ph = build_models(args.dtype, sampler)
+    want_k = not (args.no_kernels or args.encode_only)
 
-    dt, used_graph, gemms, _ = bench_encode(cv, args, ws)
+    times, used_graph, enc_rows = bench_encode(cv, args, ws, want_k or not args.no_kernels)
+    med = statistics.median(times)
     frames = args.batch * 17 * args.steps * ws
     result = {
-        'metric': 'cvivit_encode_frames_per_sec', 'value': frames / dt, 'unit': 'frames/s', 'n_gpus': ws,
-        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+        'metric': 'cvivit_encode_frames_per_sec', 'value': frames / med, 'unit': 'frames/s', 'n_gpus': ws,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': med / args.steps * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype if args.dtype == 'bf16' else 'f32', 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[1]: C-ViViT (dim 512, patch 32, tpatch 2, depth 4+4, LFQ 65536) encode '
                                f'video -> token ids, ({args.batch},3,17,256,256) f32 per GPU resident in HBM',
                    'global_batch': args.batch * ws, 'frames_per_video': 17, 'parallelism': f'batch-shard x{ws}, no data-path collective',
-                   'hip_graph': used_graph},
+                   'hip_graph': used_graph, 'input_rotation': f'{args.rotate} distinct batches ({args.rotate * args.batch * 13.37:.0f} MB) per GPU',
+                   'timing': f'median of {args.groups} regions of {args.steps} steps (min {min(times) / args.steps * 1e3:.4f}, '
+                             f'max {max(times) / args.steps * 1e3:.4f} ms/step), total timed {sum(times):.2f} s'},
     }
-    # roofline: dominant GEMM instantiation by total time
-    if gemms:
-        name, d = max(gemms.items(), key=lambda kv: kv[1]['seconds'])
-        ach = d['flops'] / d['seconds'] / 1e12
-        peak = PEAK_BF16_TFLOPS if args.dtype == 'bf16' else 157.3
-        result['roofline'] = {'bound': 'mfma', 'kernel': name, 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
-                              'traffic': pmc_traffic(name, args), 'traffic_unit': 'HBM bytes per launch',
-                              'traffic_source': 'profiles/gemm_hbm_pmc_r01.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, '
-                                                'gfx950 x2 read correction); null when the run is not that configuration',
-                              'launches_per_step': d['launches'],
-                              'avg_launch_us': d['seconds'] / d['launches'] * 1e6,
-                              'algorithmic_flops_per_launch': d['flops'] / d['launches'],
-                              'all_gemm_variants': {k: {'launches': v['launches'], 'TFLOP/s': v['flops'] / v['seconds'] / 1e12,
-                                                        'us_total': v['seconds'] * 1e6} for k, v in gemms.items()}}
-    if not args.no_sample:
-        result['sample'] = bench_sample(ph, args, ws)
+    kernels = []
+    if enc_rows:
+        result['roofline'] = roofline_of(enc_rows, args.dtype)
+        kernels += enc_rows
+    if not args.encode_only:
+        result['decode'], dec_rows = bench_decode(cv, args, ws, want_k)
+        kernels += dec_rows or []
+    if sampler:
+        result['sample'], s_rows = bench_sample(ph, args, ws, args.sample_batch, 'BASELINE configs[2]', want_k)
+        kernels += s_rows or []
+        s3, _ = bench_sample(ph, args, ws, 4, 'BASELINE configs[3] per-GPU share (32 videos over 8 GPUs = 4 per GPU)', False)
+        result['sample_cfg3'] = s3
+        result['make_video'] = bench_make_video(ph, args, ws)
         result['objective'] = bench_objective(ph, args, ws)
-    if rank == 0 and ws == 1 and not args.no_cpu:
+    if kernels:
+        keep = ('kernel', 'leg', 'launches', 'avg_us', 'bound', 'achieved', 'unit', 'peak', 'frac')
+        result['kernels'] = [{k: (round(r[k], 4) if isinstance(r[k], float) else r[k]) for k in keep if k in r} for r in kernels]
+    del cv, mg, cr, ph
+    torch.cuda.empty_cache()
+    if not (args.no_parity_mode or args.encode_only) and args.dtype == 'bf16':
+        result['parity_mode'] = bench_parity_mode(args, ws)
+    if rank == 0 and ws == 1 and not (args.no_cpu or args.encode_only):
         result['cpu_baseline'] = cpu_baseline(args)
     if rank == 0:
         print(json.dumps(result))

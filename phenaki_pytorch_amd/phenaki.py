@@ -549,10 +549,11 @@ class Phenaki(PackedModule):
     @eval_decorator
     @torch.no_grad()
     def sample(self, *, num_frames, texts=None, prime_frames=None, batch_size=1, cond_scale=3.,
-               starting_temperature=0.9, noise_K=1., _noise_fn=None, _trace=None, _return_ids=False, _compact=None):
+               starting_temperature=0.9, noise_K=1., _noise_fn=None, _trace=None, _return_ids=False, _compact=None, _seed=None):
         """phenaki_pytorch.py:418-560.  `_noise_fn(kind, step, shape)` (tests) injects the U[0,1) draws of the
         reference run ('gumbel' (B,n,V) and 'critic' (B,n), device f32 tensors); without it the noise comes from the
-        in-kernel counter hash seeded from torch's default (CPU) generator."""
+        in-kernel counter hash seeded from torch's default (CPU) generator (`_seed`: the exact 64-bit stream seed instead;
+        the seed a call used is kept in `self._pk_last_seed`)."""
         device = next(self.parameters()).device
         L.require_device(next(self.parameters()), 'Phenaki parameters')
         mg, critic = self.maskgit, self.critic
@@ -595,6 +596,9 @@ class Phenaki(PackedModule):
         if _noise_fn is None and torch.distributed.is_available() and torch.distributed.is_initialized():
             # batch-sharded sampling: every rank draws from its own noise stream even under a common torch seed
             seed_base = (seed_base + 0xD1B54A32D192ED03 * (torch.distributed.get_rank() + 1)) & 0x3FFFFFFFFFFFFFFF
+        if _seed is not None:
+            seed_base = int(_seed) & 0x3FFFFFFFFFFFFFFF
+        self.__dict__['_pk_last_seed'] = seed_base
         compact = (_trace is None) if _compact is None else bool(_compact)    # traces record the prediction at EVERY position
 
         use_graph = self.__dict__.get('_pk_sample_graph', False) and _noise_fn is None and _trace is None
