@@ -184,8 +184,8 @@ def _esz(t):
 
 class KernelProfiler:
     """live HIP-event timing of every libphenaki_hip launch of one (untimed, eager) pass, on the stream the kernels run on:
-    each launch of the pass is recorded with its live operands, then re-issued REPS times back to back between two HIP
-    events (an event pair around ONE ~10 us kernel mostly measures the events).  Every launch carries its algorithmic work:
+    each launch of the pass is recorded with its live operands, then re-issued REPS times back to back (as one captured
+    hipGraph) between two HIP events (an event pair around ONE ~10 us kernel mostly measures the events).  Every launch carries its algorithmic work:
     flops for the MFMA kernels, bytes for the HBM-bound ones (DESIGN.md section 4 lists the per-unit figures)."""
     REPS = 10
 
@@ -289,17 +289,24 @@ class KernelProfiler:
             if m is None:
                 continue
             label, bound, work = m
+            # the REPS re-issues are captured into ONE hipGraph and the replay is timed: issued from Python, launches shorter
+            # than the ~8 us ctypes call would measure the host, not the kernel
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             fn(*a, **kw)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for _ in range(self.REPS):
+                    fn(*a, **kw)
+            graph.replay()
             e0.record()
-            for _ in range(self.REPS):
-                fn(*a, **kw)
+            graph.replay()
             e1.record()
             torch.cuda.synchronize()
             d = by.setdefault((label, bound), [0, 0.0, 0.0])
             d[0] += 1
             d[1] += work
             d[2] += e0.elapsed_time(e1) * 1e-3 / self.REPS
+            del graph
         self.calls = []
         rows = []
         for (label, bound), (launches, work, secs) in by.items():

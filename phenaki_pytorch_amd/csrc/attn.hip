@@ -419,6 +419,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                     // tile t landed for all waves; everyone finished tile t-1
         if (t + 1 < ntiles) issue(kb + 64, (t + 1) & 1);
+        if (kb + 64 > nk) {
+            // tail tile (wave-uniform, at most once per workgroup): the V^T columns of keys >= nk carry p = 0 but may hold anything
+            // (pk_qkv_project never writes them; 0 * NaN = NaN) -> zero them in the LDS image, all 256 threads, one extra barrier.
+            // (Masking the fragments in registers instead cost 13 VGPRs and spilled the main loop.)
+            char* vz = smem + (t & 1) * STAGE + 8192;
+            const int d = threadIdx.x >> 2, k0 = (threadIdx.x & 3) * 16;
+            for (int kk = k0; kk < k0 + 16; ++kk)
+                if (kb + kk >= nk) *reinterpret_cast<u16*>(vz + d * 128 + ((((kk >> 3) ^ (d & 7))) << 4) + (kk & 7) * 2) = 0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         if (!active) continue;
         const char* kt = smem + (t & 1) * STAGE;
         const char* vt = kt + 8192;
@@ -500,13 +511,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
             for (int df = 0; df < 4; ++df) {
                 Frag<bf16> fv;
                 lds_frag_vt(fv, vt, df * 16 + lr, kc, g);
-                if (kb + 64 > nk) {                           // tail tile: keys kb + kc*32 + g*8 + 0..7 beyond nk carry p = 0, make V finite
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const int key = kb + kc * 32 + g * 8 + w * 2;
-                        fv.v[w] &= (key < nk ? 0x0000FFFFu : 0u) | (key + 1 < nk ? 0xFFFF0000u : 0u);
-                    }
-                }
 #pragma unroll
                 for (int qf = 0; qf < QF; ++qf) o[qf][df] = mma(fv, fp[qf], o[qf][df]);
             }

