@@ -123,6 +123,14 @@ int pk_qkv_project(const void* xq, const void* xkv, int ld, const void* wq, cons
                    int h, int K, const float* q_scale, const float* k_scale, float scale, void* Qp, void* Kp, void* Vt,
                    int nq_pad, int nk_pad, void* stream);
 
+/* attention.py:142-182 for SHORT self-attention sequences (n <= 64, no null keys, no key mask; bf16) in ONE launch: the
+ * to_q / to_kv projections, l2norm + scales, and softmax(q k^T + bias (+ ALiBi, causal)) v -- what pk_qkv_project + pk_attn_fwd
+ * compute, without Qp / Kp / Vt ever reaching HBM.  A workgroup owns one head of floor(64 / n) whole sequences.  xq = LayerNorm(x)
+ * rows, xkv = x rows (both bf16 [S*n][ld]); bias [h][n][n] f32 or NULL; slopes [h] with causal; O bf16 [S*n][ldo], heads merged. */
+int pk_qkv_attn(const void* xq, const void* xkv, int ld, const void* wq, const void* wkv, int ldw, int S, int n, int h, int K,
+                const float* q_scale, const float* k_scale, float scale, const float* bias, long bias_hstride, int bias_ld,
+                const float* slopes, int causal, void* O, int ldo, void* stream);
+
 /* attention.py:157-182: softmax(sim + bias (+ key mask, + ALiBi, causal)) @ v, heads merged: O[(s,i)][hh*64 + d].
  * bias[hh][i][j] is over the real (non-null) keys; kmask [S][n_kv] uint8 (1 = keep); slopes [h] with causal. */
 int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void* Vt, const float* bias, long bias_hstride,

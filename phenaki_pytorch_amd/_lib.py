@@ -39,6 +39,7 @@ SIGNATURES = {
     'pk_attn_pads': [_I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)],
     'pk_attn_prep': [_I, _P, _I, _P, _I, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'pk_qkv_project': [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P],
+    'pk_qkv_attn': [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _L, _I, _P, _I, _P, _I, _P],
     'pk_attn_fwd': [_I, _P, _P, _P, _P, _L, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'pk_attn_small': [_P, _I, _P, _I, _P, _P, _F, _P, _L, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     'pk_cfg_mix': [_P, _I, _I, _I, _I, _P, _I, _F, _I, _P, _I, _I, _I, _P],
@@ -221,6 +222,15 @@ def qkv_project(xq, xkv, wq, wkv, S, nseq, h, K, q_scale, k_scale, scale, Qp, Kp
     rc = load().pk_qkv_project(ptr(xq), ptr(xkv), xq.stride(-2), ptr(wq), ptr(wkv), wq.stride(0), S, nseq, h, K, f32p(q_scale, 'q_scale'),
                                 f32p(k_scale, 'k_scale'), scale, ptr(Qp), ptr(Kp), ptr(Vt), nq_pad, nk_pad, stream(xq))
     _check(rc, 'pk_qkv_project')
+
+
+def qkv_attn(xq, xkv, wq, wkv, S, n, h, K, q_scale, k_scale, scale, O, *, bias=None, slopes=None, causal=False):
+    """O (S*n, h*64) bf16 <- softmax(l2norm(xq Wq^T) l2norm(xkv Wk^T)^T * scale + bias) (xkv Wv^T), n <= 64 (one launch)"""
+    bh, bld = (bias.stride(0), bias.stride(1)) if bias is not None else (0, 0)
+    rc = load().pk_qkv_attn(ptr(xq), ptr(xkv), xq.stride(-2), ptr(wq), ptr(wkv), wq.stride(0), S, n, h, K, f32p(q_scale, 'q_scale'),
+                            f32p(k_scale, 'k_scale'), scale, f32p(bias, 'attention bias'), bh, bld, f32p(slopes, 'ALiBi slopes'),
+                            1 if causal else 0, ptr(O), O.stride(-2), stream(xq))
+    _check(rc, 'pk_qkv_attn')
 
 
 def attn_fwd(dtype, Qp, Kp, Vt, O, S, h, nq, n_kv, nnull, *, bias=None, kmask=None, slopes=None, causal=False):

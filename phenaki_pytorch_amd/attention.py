@@ -6,6 +6,7 @@ operands are bf16 (`compute_dtype = 'bf16'`, f32 accumulation) or exact f32 (`'f
 There is no eager fallback: tensors must be on a HIP device.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -302,6 +303,10 @@ class ContinuousPositionBias(PackedModule):
         return out.reshape(n, n, heads).permute(2, 0, 1).contiguous()
 
 
+# PK_QKV_ATTN=0: keep pk_qkv_project + pk_attn_fwd for short sequences too (A/B timing of the fused kernel)
+_SHORT_FUSED = os.environ.get('PK_QKV_ATTN', '1') != '0'
+
+
 class Attention(PackedModule):
     """attention.py:89-182."""
 
@@ -368,6 +373,16 @@ class Attention(PackedModule):
         # bf16: to_q / to_kv run as ONE GEMM launch whose epilogue writes the attention operand images directly
         # (pk_qkv_project); available for self-attention (no null keys) and for cross-attention with cached K / V
         fused = dtype == L.BF16 and not small and ((not is_cross and nnull == 0) or cached is not None)
+
+        if _SHORT_FUSED and fused and not is_cross and n <= 64 and kmask is None and (attn_bias is None or attn_bias.stride(-1) == 1):
+            # short sequences (the C-ViViT spatial n = 64 and temporal n = 9..10 layers): projections + attention in ONE launch,
+            # a workgroup per (whole sequences, head); the operand images never leave LDS
+            o = torch.empty((M, inner), device=dev, dtype=td)
+            L.qkv_attn(xn, xraw, linear_weight(self.to_q, dtype), linear_weight(self.to_kv, dtype), S, n, h, D, self.q_scale,
+                       self.k_scale, float(self.scale), o, bias=attn_bias, slopes=slopes, causal=self.causal)
+            out = torch.empty_like(x2d)
+            L.gemm(dtype, o, linear_weight(self.to_out, dtype), M, D, inner, C=out, res=x2d)
+            return out
 
         q = None
         if not fused:

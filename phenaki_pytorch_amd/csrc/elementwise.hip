@@ -133,12 +133,18 @@ __global__ __launch_bounds__(256) void lfq_decode_kernel(const long long* __rest
     const int dv = D >> 2;                                   // 16-byte column groups per row
     const int lanes = blockDim.x;                            // host: lanes == dv * rpb, rpb rows in flight per block
     const int cg = threadIdx.x % dv, rl = threadIdx.x / dv;
+    // this thread's 4 output channels x CD weights are 4*CD CONTIGUOUS floats of wo ([D][CD] row-major): 16-byte loads
     float w[4][CD];
     f32x4 b4 = *reinterpret_cast<const f32x4*>(bo + cg * 4);
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(wo + (size_t)cg * 4 * CD);
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+        for (int q = 0; q < CD; ++q) {
+            const f32x4 t = src[q];
 #pragma unroll
-        for (int k = 0; k < CD; ++k) w[e][k] = wo[(size_t)(cg * 4 + e) * CD + k];
+            for (int r = 0; r < 4; ++r) w[(q * 4 + r) / CD][(q * 4 + r) % CD] = t[r];
+        }
+    }
     for (int row = blockIdx.x * (lanes / dv) + rl; row < M; row += row_stride) {
         const unsigned long long id = (unsigned long long)ids[row];
         f32x4 acc = b4;
@@ -291,11 +297,12 @@ extern "C" int pk_lfq_decode(const long long* ids, const float* wo, const float*
     hipStream_t s = STREAM(stream);
     const int dv = D >> 2;
     const bool fast = (D & 3) == 0 && dv <= 256 && (256 % dv == 0 || dv == 256) && (cd == 8 || cd == 16) &&
-                      (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(bo) & 15) == 0;
+                      (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(bo) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(wo) & 15) == 0;
     if (fast) {
         const int rpb = 256 / dv;                               // rows in flight per 256-thread block
         int blocks = (M + rpb - 1) / rpb;
-        if (blocks > 1024) blocks = 1024;                       // >= 4 blocks per CU; each thread then walks several rows
+        if (blocks > 512) blocks = 512;                         // 2 blocks per CU: the per-thread weight load is amortised over >= 4 rows at M = 4608
         if (cd == 16) hipLaunchKernelGGL((lfq_decode_kernel<16>), dim3(blocks), dim3(256), 0, s, ids, wo, bo, out, M, D, blocks * rpb);
         else hipLaunchKernelGGL((lfq_decode_kernel<8>), dim3(blocks), dim3(256), 0, s, ids, wo, bo, out, M, D, blocks * rpb);
     } else {

@@ -90,100 +90,131 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const LnArgs p) {
 // group k = lane >> 2 ends up with sum k, one ballot collects the sign bits.  ids[orow] = sum_k (proj_k > 0) << (cd-1-k),
 // orow = the (a, b, c) -> (a, c, b) row permutation of pk_layernorm.  tokens (f32, optional) receives LN(x) for callers that
 // still need it; proj (optional) the pre-sign values for the parity margin audit.
-template <int VMAX>
+template <int VMAX, int R>
 __global__ __launch_bounds__(256) void ln_lfq_kernel(const LnArgs p, const float* __restrict__ wp, const float* __restrict__ bp,
                                                       int cd, long long* __restrict__ ids, float* __restrict__ proj) {
+    // one wave owns R consecutive rows: every project_in vector it loads is applied to R rows (the first version re-read the
+    // 32 KB of project_in per ROW through L1: 10 us for 4608 rows)
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= p.M) return;
-    int orow = row;
-    if (p.pb > 0) {
-        const int c = row % p.pc, b = (row / p.pc) % p.pb, a = row / (p.pc * p.pb);
-        orow = (a * p.pc + c) * p.pb + b;
-    }
-    const float* xr = p.x + (size_t)row * p.ldx;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= p.M) return;
     const int nv = p.D >> 2;
-    f32x4 v[VMAX];
-    float s = 0.f;
+    f32x4 y[R][VMAX];
+    float mean[R], rstd[R];
 #pragma unroll
-    for (int i = 0; i < VMAX; ++i) {
-        const int c = lane + i * 64;
-        v[i] = c < nv ? *reinterpret_cast<const f32x4*>(xr + c * 4) : f32x4{0, 0, 0, 0};
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + r < p.M ? row0 + r : p.M - 1;          // tail rows recompute the last row, their ids are not stored
+        const float* xr = p.x + (size_t)row * p.ldx;
+#pragma unroll
+        for (int i = 0; i < VMAX; ++i) {
+            const int c = lane + i * 64;
+            y[r][i] = c < nv ? *reinterpret_cast<const f32x4*>(xr + c * 4) : f32x4{0, 0, 0, 0};
+        }
     }
 #pragma unroll
-    for (int i = 0; i < VMAX; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-    const float mean = wave_sum(s) / (float)p.D;
-    float q = 0.f;
+    for (int r = 0; r < R; ++r) {
+        float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < VMAX; ++i)
-        if (lane + i * 64 < nv) {
+        for (int i = 0; i < VMAX; ++i) s += (y[r][i][0] + y[r][i][1]) + (y[r][i][2] + y[r][i][3]);
+        mean[r] = wave_sum(s) / (float)p.D;
+        float q = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float d = v[i][r] - mean; q += d * d; }
-        }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)p.D + p.eps);
-    float part[16];
+        for (int i = 0; i < VMAX; ++i)
+            if (lane + i * 64 < nv) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) part[k] = 0.f;
+                for (int e = 0; e < 4; ++e) { const float d = y[r][i][e] - mean[r]; q += d * d; }
+            }
+        rstd[r] = 1.0f / sqrtf(wave_sum(q) / (float)p.D + p.eps);
+    }
 #pragma unroll
     for (int i = 0; i < VMAX; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
             const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gamma + c * 4);
             const f32x4 b4 = p.beta ? *reinterpret_cast<const f32x4*>(p.beta + c * 4) : f32x4{0, 0, 0, 0};
-            f32x4 y;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) y[r] = (v[i][r] - mean) * rstd * g4[r] + b4[r];
-            if (p.out2) store4(p.out2 + (size_t)orow * p.ldo2 + c * 4, y);
+            for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                if (k < cd) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + (size_t)k * p.D + c * 4);
-                    part[k] += (y[0] * wv[0] + y[1] * wv[1]) + (y[2] * wv[2] + y[3] * wv[3]);
-                }
+                for (int e = 0; e < 4; ++e) y[r][i][e] = (y[r][i][e] - mean[r]) * rstd[r] * g4[e] + b4[e];
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) y[r][i] = f32x4{0, 0, 0, 0};
+        }
+    }
+    float part[R][16];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) part[r][k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (k < cd) {
+#pragma unroll
+            for (int i = 0; i < VMAX; ++i) {
+                const int c = lane + i * 64;
+                const f32x4 wv = c < nv ? *reinterpret_cast<const f32x4*>(wp + (size_t)k * p.D + c * 4) : f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    part[r][k] += (y[r][i][0] * wv[0] + y[r][i][1] * wv[1]) + (y[r][i][2] * wv[2] + y[r][i][3] * wv[3]);
             }
         }
     }
-    // halving butterfly: after the step with lane bit `bit`, a lane keeps the partials whose index has that bit equal to its own
-    float h8[8], h4[4], h2[2], h1;
-    {
-        const bool hi = lane & 32;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float keep = hi ? part[i + 8] : part[i], send = hi ? part[i] : part[i + 8];
-            h8[i] = keep + __shfl_xor(send, 32, 64);
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + r;
+        if (row >= p.M) break;                               // wave-uniform
+        int orow = row;
+        if (p.pb > 0) {
+            const int c = row % p.pc, b = (row / p.pc) % p.pb, a = row / (p.pc * p.pb);
+            orow = (a * p.pc + c) * p.pb + b;
         }
-    }
-    {
-        const bool hi = lane & 16;
+        if (p.out2) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float keep = hi ? h8[i + 4] : h8[i], send = hi ? h8[i] : h8[i + 4];
-            h4[i] = keep + __shfl_xor(send, 16, 64);
+            for (int i = 0; i < VMAX; ++i)
+                if (lane + i * 64 < nv) store4(p.out2 + (size_t)orow * p.ldo2 + (lane + i * 64) * 4, y[r][i]);
         }
-    }
-    {
-        const bool hi = lane & 8;
+        // halving butterfly: after the step with lane bit `bit`, a lane keeps the partials whose index has that bit equal to its own
+        float h8[8], h4[4], h2[2], h1;
+        {
+            const bool hi = lane & 32;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float keep = hi ? h4[i + 2] : h4[i], send = hi ? h4[i] : h4[i + 2];
-            h2[i] = keep + __shfl_xor(send, 8, 64);
+            for (int i = 0; i < 8; ++i) {
+                const float keep = hi ? part[r][i + 8] : part[r][i], send = hi ? part[r][i] : part[r][i + 8];
+                h8[i] = keep + __shfl_xor(send, 32, 64);
+            }
         }
-    }
-    {
-        const bool hi = lane & 4;
-        const float keep = hi ? h2[1] : h2[0], send = hi ? h2[0] : h2[1];
-        h1 = keep + __shfl_xor(send, 4, 64);
-    }
-    h1 += __shfl_xor(h1, 2, 64);
-    h1 += __shfl_xor(h1, 1, 64);
-    const int k = lane >> 2;                                 // bits 5..2 of the lane = bits 3..0 of k
-    const float val = h1 + (k < cd ? bp[k] : 0.f);
-    if (proj && k < cd && (lane & 3) == 0) proj[(size_t)orow * cd + k] = val;
-    const unsigned long long bal = __ballot(val > 0.f);
-    if (lane == 0) {
-        long long id = 0;
-        for (int kk = 0; kk < cd; ++kk) id |= (long long)((bal >> (4 * kk)) & 1ull) << (cd - 1 - kk);
-        ids[orow] = id;
+        {
+            const bool hi = lane & 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float keep = hi ? h8[i + 4] : h8[i], send = hi ? h8[i] : h8[i + 4];
+                h4[i] = keep + __shfl_xor(send, 16, 64);
+            }
+        }
+        {
+            const bool hi = lane & 8;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float keep = hi ? h4[i + 2] : h4[i], send = hi ? h4[i] : h4[i + 2];
+                h2[i] = keep + __shfl_xor(send, 8, 64);
+            }
+        }
+        {
+            const bool hi = lane & 4;
+            const float keep = hi ? h2[1] : h2[0], send = hi ? h2[0] : h2[1];
+            h1 = keep + __shfl_xor(send, 4, 64);
+        }
+        h1 += __shfl_xor(h1, 2, 64);
+        h1 += __shfl_xor(h1, 1, 64);
+        const int k = lane >> 2;                                 // bits 5..2 of the lane = bits 3..0 of k
+        const float val = h1 + (k < cd ? bp[k] : 0.f);
+        if (proj && k < cd && (lane & 3) == 0) proj[(size_t)orow * cd + k] = val;
+        const unsigned long long bal = __ballot(val > 0.f);
+        if (lane == 0) {
+            long long id = 0;
+            for (int kk = 0; kk < cd; ++kk) id |= (long long)((bal >> (4 * kk)) & 1ull) << (cd - 1 - kk);
+            ids[orow] = id;
+        }
     }
 }
 
@@ -232,9 +263,9 @@ extern "C" int pk_layernorm_lfq(const float* x, int ldx, const float* gamma, con
     if (pb > 0 && (pc <= 0 || M % (pb * pc))) return PK_EINVAL;
     LnArgs p{x, ldx, gamma, beta, eps, nullptr, 0, tokens, ldt, nullptr, 0, M, D, 0, 0, 0, pb, pc};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    dim3 grid((M + 3) / 4), block(256);
-    if (D <= 64 * 4 * 2) hipLaunchKernelGGL((ln_lfq_kernel<2>), grid, block, 0, s, p, wp, bp, cd, ids, proj);
-    else hipLaunchKernelGGL((ln_lfq_kernel<8>), grid, block, 0, s, p, wp, bp, cd, ids, proj);
+    dim3 block(256);
+    if (D <= 64 * 4 * 2) hipLaunchKernelGGL((ln_lfq_kernel<2, 4>), dim3((M + 15) / 16), block, 0, s, p, wp, bp, cd, ids, proj);
+    else hipLaunchKernelGGL((ln_lfq_kernel<8, 1>), dim3((M + 3) / 4), block, 0, s, p, wp, bp, cd, ids, proj);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

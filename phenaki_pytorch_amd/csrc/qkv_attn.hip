@@ -1,0 +1,238 @@
+// pk_qkv_attn (bf16): a whole short-sequence self-attention block of the C-ViViT transformers (reference attention.py:142-182;
+// the spatial layers n = 64 with the continuous position bias, cvivit.py:460-466, and the causal temporal layers n = 9..10 with
+// ALiBi, cvivit.py:468-472) in ONE launch per layer:
+//   to_q / to_kv projections (MFMA, LDS-DMA ring)  ->  l2norm, q_scale / k_scale, similarity scale  ->  softmax(q k^T + bias) v
+// A workgroup owns one head of R = floor(64 / n) * n consecutive rows = floor(64 / n) WHOLE sequences (n = 64: one sequence, n = 9:
+// seven), so every key a query needs is produced by the same workgroup: q^, k^ and v go to LDS as the bf16 operand images the
+// attention MFMAs read (the same images, rounding points and fragment reads as pk_qkv_project + pk_attn_fwd, which this replaces for
+// n <= 64: Qp / Kp / Vt never reach HBM -- the V^T scatter alone made the n = 9 projection 20 us -- and one launch per layer goes).
+// Sequences sharing a tile are kept apart by a block-diagonal mask (other sequences' keys get weight exp(-inf) = 0 exactly).
+// Three 64 x 64 x K GEMMs run back to back on one 2-stage ring (32 KB) + 16 KB of q^ / k^ staging: 48 KB, 3 workgroups per CU.
+// Roofline: MFMA (2 * R * 192 * K flops per workgroup) -- in practice bound by the L1 -> LDS fill rate like every short-K GEMM here.
+#include "gemm_dma.hpp"
+
+namespace pk {
+
+struct QkvAttnArgs {
+    const void* xq; const void* xkv;        // [M][ld] bf16: LayerNorm(x) rows (queries) and the un-normalised x rows (keys / values)
+    const void* wq; const void* wkv;        // [h*64][ldw], [2*h*64][ldw] bf16, K zero-padded to the k-tile
+    int ld, ldw;
+    int S, n, h, K;                         // S sequences of n <= 64 tokens, M = S * n
+    int spt;                                // sequences per tile = 64 / n
+    const float* q_scale; const float* k_scale; float scale;
+    const float* bias; long bias_hstride; int bias_ld;     // [h][n][n] f32 or null
+    const float* slopes; int causal;        // ALiBi slopes [h] with causal
+    void* O; int ldo;                       // bf16 [(s*n + i)][hh*64 + d]
+    uint32_t recip;                         // ceil(65536 / n): x / n == (x * recip) >> 16 for x < 64
+};
+
+using QaTile = GemmDma<bf16, 1, 4, 4, 1, 2, 128>;          // 64 rows x 64 columns (one head), 4 waves stacked on the rows
+
+// K tile rows permuted / swizzled exactly like pk_attn_fwd's LDS kernel (attn.hip): see attn_kperm / attn_ksw there
+__device__ __forceinline__ int qa_kperm(int f, int i) { return (f >> 1) * 32 + (i >> 2) * 8 + (f & 1) * 4 + (i & 3); }
+__device__ __forceinline__ int qa_ksw(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
+
+__global__ __launch_bounds__(256) void qkv_attn_kernel(const QkvAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [ring 32 KB | Qs 8 KB | Ks 8 KB]; V^T reuses the ring
+    char* Qs = smem + QaTile::SMEM;
+    char* Ks = Qs + 8192;
+    char* Vts = smem;
+    // block -> (row tile, head): the 8 heads of a row tile run on ONE XCD (block b is observed on XCD b % 8; speed only), so the
+    // two A tiles they all read are fetched over the fabric once
+    const int R = a.spt * a.n;
+    const int tiles = (a.S + a.spt - 1) / a.spt;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int tile = (idx / a.h) * 8 + xcd, hh = idx % a.h;
+    if (tile >= tiles) return;
+    const int M = a.S * a.n;
+    const int m0 = tile * R;
+    const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rq = wave * 16 + lr;                                     // this lane's row of the tile (query / key index)
+
+    GemmOperands p;
+    p.a_rows = nullptr;
+    p.lda = a.ld; p.ldw = a.ldw;
+    p.M = M; p.K = a.K;
+    p.plain_map = 0; p.krot = 0;
+
+    // ---- q^ = l2norm(LN(x) Wq^T) * q_scale * scale  -> Qs [row][64] bf16, 16-B slot ^ (row & 7)
+    {
+        f32x4 acc[1][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0, 0, 0, 0};
+        p.A = a.xq; p.W = a.wq; p.N = a.h * 64;
+        (void)QaTile::run(p, M, m0, hh * 64, smem, acc);
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ss += acc[0][j][r] * acc[0][j][r];
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        const float inv = a.scale / fmaxf(sqrtf(ss), 1e-12f);          // F.normalize eps = 1e-12
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.q_scale + j * 16 + g * 4);
+            f32x4 v = acc[0][j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= inv * sc[r];
+            const int slot = (2 * j + (g >> 1)) ^ (rq & 7);
+            *reinterpret_cast<u32x2*>(Qs + rq * 128 + (slot << 4) + (g & 1) * 8) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        }
+    }
+    // ---- k^ = l2norm(x Wk^T) * k_scale -> Ks [key][64] bf16, slot ^ qa_ksw(key)
+    {
+        f32x4 acc[1][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0, 0, 0, 0};
+        p.A = a.xkv; p.W = a.wkv; p.N = 2 * a.h * 64;
+        (void)QaTile::run(p, M, m0, hh * 64, smem, acc);
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ss += acc[0][j][r] * acc[0][j][r];
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.k_scale + j * 16 + g * 4);
+            f32x4 v = acc[0][j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= inv * sc[r];
+            const int slot = (2 * j + (g >> 1)) ^ qa_ksw(rq);
+            *reinterpret_cast<u32x2*>(Ks + rq * 128 + (slot << 4) + (g & 1) * 8) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        }
+    }
+    // ---- v = x Wv^T -> V^T [dim][64 keys] bf16 in the (now dead) ring, slot ^ (dim & 7)
+    {
+        f32x4 acc[1][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0, 0, 0, 0};
+        p.A = a.xkv; p.W = a.wkv; p.N = 2 * a.h * 64;
+        (void)QaTile::run(p, M, m0, (a.h + hh) * 64, smem, acc);         // run() ends with a barrier: every wave is done with the ring
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = j * 16 + g * 4 + r;
+                *reinterpret_cast<u16*>(Vts + d * 128 + ((((rq >> 3) ^ (d & 7))) << 4) + (rq & 7) * 2) = f2bf(acc[0][j][r]);
+            }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- attention of this wave's 16 query rows against the 64 keys of the tile (block-diagonal over the tile's sequences)
+    Frag<bf16> fq[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) fq[c].v = *reinterpret_cast<const u32x4*>(Qs + rq * 128 + (((c * 4 + g) ^ (rq & 7)) << 4));
+    f32x4 st[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) st[f] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int krow = qa_kperm(f, lr);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            Frag<bf16> fk;
+            fk.v = *reinterpret_cast<const u32x4*>(Ks + krow * 128 + (((c * 4 + g) ^ qa_ksw(krow)) << 4));
+            st[f] = mma(fk, fq[c], st[f]);
+        }
+    }
+    const int seq_q = (int)(((uint32_t)rq * a.recip) >> 16), pos_q = rq - seq_q * a.n;
+    const bool qvalid = rq < R && tile * a.spt + seq_q < a.S;
+    const float slope = (a.causal && a.slopes) ? a.slopes[hh] : 0.f;
+    const float* brow = a.bias ? a.bias + (size_t)hh * a.bias_hstride + (size_t)pos_q * a.bias_ld : nullptr;
+    const bool whole = a.n == 64 && !a.causal;                  // one sequence per tile, every key valid: no per-element masks
+    float pr[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int k0 = qa_kperm(f, g * 4);                      // the lane's 4 keys of block f are k0 .. k0 + 3
+        f32x4 bz = f32x4{0, 0, 0, 0};
+        if (whole && brow && (a.bias_ld & 3) == 0) bz = *reinterpret_cast<const f32x4*>(brow + k0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float sv = st[f][r];
+            if (whole) {
+                if (brow) sv += (a.bias_ld & 3) == 0 ? bz[r] : brow[k0 + r];
+            } else {
+                const int kk = k0 + r;
+                const int seq_k = (int)(((uint32_t)kk * a.recip) >> 16), pos_k = kk - seq_k * a.n;
+                if (kk >= R || seq_k != seq_q) sv = -INFINITY;                 // not a key of this query's sequence: weight 0
+                else {
+                    if (brow) sv += brow[pos_k];
+                    if (a.causal) {
+                        const int dj = pos_k - pos_q;
+                        sv -= fabsf((float)dj) * slope;                        // ALiBi, attention.py:198-227 (i == j: no offset)
+                        if (dj > 0) sv = NEG_MAX;                              // causal mask fill, attention.py:172-174
+                    }
+                }
+            }
+            pr[f * 4 + r] = sv;
+            mx = fmaxf(mx, sv);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (!qvalid) mx = 0.f;                                      // rows past the tile's sequences: keep the arithmetic finite, never stored
+    float ls = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { pr[e] = __expf(pr[e] - mx); ls += pr[e]; }
+    ls += __shfl_xor(ls, 16, 64);
+    ls += __shfl_xor(ls, 32, 64);
+    f32x4 o[4];
+#pragma unroll
+    for (int df = 0; df < 4; ++df) o[df] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+        Frag<bf16> fp;
+        fp.v = u32x4{pack_bf2(pr[kc * 8 + 0], pr[kc * 8 + 1]), pack_bf2(pr[kc * 8 + 2], pr[kc * 8 + 3]),
+                     pack_bf2(pr[kc * 8 + 4], pr[kc * 8 + 5]), pack_bf2(pr[kc * 8 + 6], pr[kc * 8 + 7])};
+#pragma unroll
+        for (int df = 0; df < 4; ++df) {
+            const int d = df * 16 + lr;
+            Frag<bf16> fv;
+            fv.v = *reinterpret_cast<const u32x4*>(Vts + d * 128 + (((kc * 4 + g) ^ (d & 7)) << 4));
+            o[df] = mma(fv, fp, o[df]);
+        }
+    }
+    if (!qvalid) return;
+    const float inv = 1.0f / ls;
+    bf16* orow = reinterpret_cast<bf16*>(a.O) + (size_t)(m0 + rq) * a.ldo + hh * 64;
+#pragma unroll
+    for (int df = 0; df < 4; ++df) store4(orow + df * 16 + g * 4, o[df] * inv);
+}
+
+}  // namespace pk
+using namespace pk;
+
+// bf16 only.  xq [S*n][ld] = LayerNorm(x), xkv [S*n][ld] = x (both bf16); wq [h*64][ldw], wkv [2*h*64][ldw] bf16 with K zero-padded
+// to a multiple of 64; bias [h][n][n] f32 (or NULL), slopes [h] with causal; O [S*n][ldo] bf16 receives softmax(q k^T + bias) v
+// with the heads merged (column hh*64 + d).  n <= 64, no null keys, no key mask.
+extern "C" int pk_qkv_attn(const void* xq, const void* xkv, int ld, const void* wq, const void* wkv, int ldw, int S, int n, int h,
+                           int K, const float* q_scale, const float* k_scale, float scale, const float* bias, long bias_hstride,
+                           int bias_ld, const float* slopes, int causal, void* O, int ldo, void* stream) {
+    if (!xq || !xkv || !wq || !wkv || !q_scale || !k_scale || !O || S <= 0 || n <= 0 || n > 64 || h <= 0 || K <= 0) return PK_EINVAL;
+    auto mis = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) != 0; };
+    if ((K & 7) || (ld & 7) || (ldw & 7) || (ldo & 3) || mis(xq) || mis(xkv) || mis(wq) || mis(wkv) || mis(q_scale) || mis(k_scale) ||
+        (reinterpret_cast<uintptr_t>(O) & 7) || (bias && mis(bias))) return PK_EALIGN;
+    if (ldw < (K + 63) / 64 * 64) return PK_EINVAL;             // W zero-padded along K to the 64-wide k-tile
+    const long M = (long)S * n;
+    if ((size_t)M * ld * 2 >= 0xFFFFFFF0ull || (size_t)2 * h * 64 * ldw * 2 >= 0xFFFFFFF0ull) return PK_EINVAL;
+    QkvAttnArgs a;
+    a.xq = xq; a.xkv = xkv; a.wq = wq; a.wkv = wkv; a.ld = ld; a.ldw = ldw;
+    a.S = S; a.n = n; a.h = h; a.K = K; a.spt = 64 / n;
+    a.q_scale = q_scale; a.k_scale = k_scale; a.scale = scale;
+    a.bias = bias; a.bias_hstride = bias_hstride; a.bias_ld = bias_ld;
+    a.slopes = slopes; a.causal = causal;
+    a.O = O; a.ldo = ldo;
+    a.recip = (65536u + (uint32_t)n - 1u) / (uint32_t)n;
+    const int tiles = (S + a.spt - 1) / a.spt;
+    dim3 grid(8 * ((tiles + 7) / 8) * h);
+    hipLaunchKernelGGL(qkv_attn_kernel, grid, dim3(256), QaTile::SMEM + 16384, reinterpret_cast<hipStream_t>(stream), a);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}

@@ -562,3 +562,39 @@ def test_cfg_mix_and_critic_head(L):
     r = np.arange(nb * (n_tot - n_prime), dtype=np.uint64) | (np.uint64(0xC817) << np.uint64(32))
     uh = torch.from_numpy(uniform24_np(seed, r)).reshape(nb, n_tot - n_prime)
     close(outs, (sn + (sc - sn) * 5.)[:, n_prime:] + 0.5 * (uh - 0.5), 1e-5, 'critic head hash noise')
+
+
+@pytest.mark.parametrize('S,n,causal,with_bias,heads', [(18, 64, False, True, 8), (130, 9, True, False, 8), (7, 10, True, False, 2),
+                                                        (5, 64, False, False, 8), (3, 48, False, True, 2), (9, 7, False, True, 4),
+                                                        (1, 1, True, False, 2), (2, 64, True, False, 2)])
+def test_qkv_attn_fused_short_sequences(L, S, n, causal, with_bias, heads):
+    """pk_qkv_attn (projections + attention of whole short sequences in one launch) against the oracle in bf16 precision, and
+    against the two-launch path it replaces (pk_qkv_project + pk_attn_fwd), through the product Attention module."""
+    from phenaki_pytorch_amd import attention as A
+    D = 128
+    torch.manual_seed(100 + n)
+    att = A.Attention(dim=D, heads=heads, causal=causal)
+    with torch.no_grad():
+        att.q_scale.add_(0.1 * torch.randn(64))
+        att.k_scale.add_(0.1 * torch.randn(64))
+        att.norm.gamma.add_(0.1 * torch.randn(D))
+    sd = {'a.' + k: v.detach().clone() for k, v in att.state_dict().items()}
+    att = att.cuda().eval()
+    x = torch.randn(S, n, D, generator=g(7 + n)) * 1.5 + 0.2
+    bias = torch.randn(heads, n, n, generator=g(8 + n)) if with_bias else None
+    with O.precision('bf16'):
+        ref = O.attention(sd, 'a.', x, heads=heads, causal=causal, attn_bias=bias)
+    ref_f32 = O.attention(sd, 'a.', x, heads=heads, causal=causal, attn_bias=bias)
+    xg = x.reshape(S * n, D).cuda()
+    bg = bias.cuda() if with_bias else None
+    assert A._SHORT_FUSED
+    fused = att.run(xg, S, n, L.BF16, attn_bias=bg) - xg
+    A._SHORT_FUSED = False
+    try:
+        split = att.run(xg, S, n, L.BF16, attn_bias=bg) - xg
+    finally:
+        A._SHORT_FUSED = True
+    gap = ((ref - ref_f32).abs().max() / ref_f32.abs().max()).item()
+    close(fused.view(S, n, D), ref, 3e-3, f'fused qkv+attn S={S} n={n} (bf16-vs-f32 gap {gap:.1e})')
+    close(fused, split, 3e-3, 'fused vs pk_qkv_project + pk_attn_fwd')
+    assert torch.isfinite(fused).all()
