@@ -40,10 +40,16 @@ int pk_gemm(int dtype, int a_is_f32, const void* A, int lda, const void* W, int 
 
 /* pk_gemm with an explicit main-loop variant (0 = automatic; 1/2 = register-staged 64x64 / 128x128 tiles, 3..6 = LDS-DMA
  * ring variants, see csrc/gemm.hip) and the number of physical rows behind a gathered A (bounds of the DMA descriptor).
- * The DMA variants need A in T and ldw >= K rounded up to the k-tile (64 bf16 / 32 f32) with zero padding. */
+ * The DMA variants need A in T and ldw >= K rounded up to the k-tile (64 bf16 / 32 f32) with zero padding.
+ * C2 (bf16 [M][ldc2], or NULL): a second copy of an f32 result for the next GEMM's LDS-DMA operand (dtype 1 only).
+ * ln_s / ln_t ([N] f32, or both NULL): the LayerNorm that precedes this nn.Linear in the reference (attention.py:47,142,
+ * cvivit.py:277) folded into it -- A holds the UN-normalised rows x, W holds gamma (.) W, and the epilogue applies
+ *   LN(x) W^T = rstd * (x (gamma.W)^T - mean * ln_s) + ln_t,  ln_s[n] = sum_k gamma[k] W[n][k],  ln_t[n] = sum_k beta[k] W[n][k]
+ * with mean / rstd (biased variance over K, ln_eps inside the sqrt) taken from the A tiles of the main loop; then bias / act / res. */
 int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const void* W, int ldw, int M, int N, int K,
                const float* bias, const float* res, int ldr, void* C, int ldc, int out_is_f32, int act,
-               const int* a_rows, int a_nrows, int variant, void* stream);
+               const int* a_rows, int a_nrows, int variant, void* C2, int ldc2, const float* ln_s, const float* ln_t,
+               float ln_eps, void* stream);
 /* the variant `0 = automatic` resolves to for a shape (host-only helper; used to label kernels in bench.py) */
 int pk_gemm_auto_variant(int dtype, int a_is_f32, int M, int N, int K, int lda, int ldw, int a_nrows);
 
@@ -76,8 +82,8 @@ int pk_sqdiff_partials(const float* a, const float* b, const unsigned char* fmas
 /* attention.py:57-85 + residual of attention.py:323: out = x + bias + depthwise_conv3d_3x3x3(zero-padded x) on the
  * channels-last (B,T,H,W,D) reinterpretation of the token buffer; time pad (2,0) if causal else (1,1).
  * wt is dsconv.weight (D,1,3,3,3) pre-transposed to [27][D].  Not in-place. */
-int pk_peg(const float* x, const float* wt, const float* bias, float* out, int B, int T, int H, int W, int D,
-           int causal, void* stream);
+int pk_peg(const float* x, const float* wt, const float* bias, float* out, void* out_t, int B, int T, int H, int W, int D,
+           int causal, void* stream);       /* out_t: optional bf16 copy of out (the next GEMM's operand) */
 
 /* LFQ (vector-quantize-pytorch, un-vendored; call sites cvivit.py:570 and :439; restated in oracle/lfq.py).
  * encode: proj = x @ Wp^T + bp (f32), ids = sum_k (proj_k > 0) << (cd-1-k); proj (M x cd) optional output.
@@ -101,7 +107,7 @@ int pk_l2norm_rows(const float* x, int ldx, void* out, int ldo, int out_kind, in
  * out[s*n_tot + i] = token_emb[id] + pos_emb[i] with id = ids_prime[b][i] for i < n_prime (NULL if n_prime == 0), else
  * ids[b][i - n_prime], b = s % nb -- the cond and null replicas of a classifier-free-guidance batch (S = 2 nb) share ids. */
 int pk_embed(const long long* ids_prime, int n_prime, const long long* ids, int n, int nb, const float* tok,
-             const float* pos, float* out, int S, int D, void* stream);
+             const float* pos, float* out, void* out_t, int S, int D, void* stream);       /* out_t: optional bf16 copy */
 
 /* attention.py:257-272 first CPB layer: out[(i,j)][D] = leaky_relu(W0 @ (sign(rel) log(|rel|+1)) + b0, 0.1) over the
  * flattened (d0,d1,d2) grid; nd = 2 uses (d1,d2) with d0 = 1. */
@@ -121,7 +127,9 @@ int pk_attn_prep(int dtype, const float* q, int ldq, const float* kv, int ldkv, 
  * pk_attn_prep is not needed.  Self-attention only on the kv side (no null keys); M = S * nseq rows. */
 int pk_qkv_project(const void* xq, const void* xkv, int ld, const void* wq, const void* wkv, int ldw, int S, int nseq,
                    int h, int K, const float* q_scale, const float* k_scale, float scale, void* Qp, void* Kp, void* Vt,
-                   int nq_pad, int nk_pad, void* stream);
+                   int nq_pad, int nk_pad, const float* q_ln_s, void* stream);
+/* q_ln_s ([h*64] f32, or NULL): the attention's LayerNorm folded into to_q -- xq then holds the un-normalised rows (= xkv), wq holds
+ * gamma (.) Wq and q_ln_s its row sums; q = l2norm(x (gamma.Wq)^T - mean(x) q_ln_s) (the l2norm cancels the LayerNorm's rstd). */
 
 /* attention.py:142-182 for SHORT self-attention sequences (n <= 64, no null keys, no key mask; bf16) in ONE launch: the
  * to_q / to_kv projections, l2norm + scales, and softmax(q k^T + bias (+ ALiBi, causal)) v -- what pk_qkv_project + pk_attn_fwd
@@ -129,7 +137,7 @@ int pk_qkv_project(const void* xq, const void* xkv, int ld, const void* wq, cons
  * rows, xkv = x rows (both bf16 [S*n][ld]); bias [h][n][n] f32 or NULL; slopes [h] with causal; O bf16 [S*n][ldo], heads merged. */
 int pk_qkv_attn(const void* xq, const void* xkv, int ld, const void* wq, const void* wkv, int ldw, int S, int n, int h, int K,
                 const float* q_scale, const float* k_scale, float scale, const float* bias, long bias_hstride, int bias_ld,
-                const float* slopes, int causal, void* O, int ldo, void* stream);
+                const float* slopes, int causal, void* O, int ldo, const float* q_ln_s, void* stream);
 
 /* attention.py:157-182: softmax(sim + bias (+ key mask, + ALiBi, causal)) @ v, heads merged: O[(s,i)][hh*64 + d].
  * bias[hh][i][j] is over the real (non-null) keys; kmask [S][n_kv] uint8 (1 = keep); slopes [h] with causal. */

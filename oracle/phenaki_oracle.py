@@ -55,6 +55,29 @@ def _lin(x, w):
     return _r(x) @ _r(w).t()
 
 
+# bf16 mode: the product folds the LayerNorm in front of to_q and of the first feed-forward Linear INTO that GEMM
+# (csrc/gemm.hip, pk_gemm_ex ln_s / ln_t): the MFMA operands are the rounded UN-normalised rows r(x) and the rounded folded
+# weight r(gamma (.) W), the statistics are those of r(x) (taken from the operand tiles), and
+#     LN(x) W^T = rstd * (r(x) r(gamma.W)^T - mean * s) + t,   s = rowsum(r(gamma.W)),  t = W beta   (f32).
+# LN_FOLD mirrors phenaki_pytorch_amd.attention._LN_FOLD (PK_LN_FOLD=0 keeps the separate LayerNorm: rounding point r(LN(x))).
+LN_FOLD = True
+LN_FOLD_FF = False          # the feed-forward LayerNorm stays a separate launch in the product by default (PK_LN_FOLD_FF)
+
+
+def _ln_lin(x, gamma, beta, w, eps=1e-5, ff=False):
+    """LayerNorm(x; gamma, beta) @ w^T -- in bf16 mode with the product's rounding points (see above)"""
+    if not (is_bf16() and LN_FOLD and (LN_FOLD_FF or not ff)):
+        return _lin(F.layer_norm(x, x.shape[-1:], gamma, beta, eps), w)
+    xb = _r(x)
+    mean = xb.mean(dim=-1, keepdim=True)
+    var = (xb * xb).mean(dim=-1, keepdim=True) - mean * mean
+    rstd = 1.0 / torch.sqrt(var.clamp(min=0) + eps)
+    wg = _r(w * gamma[None, :])
+    s = wg.sum(dim=-1)
+    t = w @ beta if beta is not None else torch.zeros(w.shape[0])
+    return rstd * (xb @ wg.t() - mean * s) + t
+
+
 
 # --------------------------------------------------------------------------- blocks
 
@@ -65,8 +88,7 @@ def gamma_layernorm(sd, p, x):
 
 def feedforward(sd, p, x):
     """attention.py:40-53  nn.LayerNorm -> Linear(d, 2*inner, no bias) -> x*gelu(gate) -> Linear(inner, d)."""
-    h = F.layer_norm(x, x.shape[-1:], sd[p + '0.weight'], sd[p + '0.bias'])
-    h = _lin(h, sd[p + '1.weight'])
+    h = _ln_lin(x, sd[p + '0.weight'], sd[p + '0.bias'], sd[p + '1.weight'], ff=True)
     val, gate = h.chunk(2, dim=-1)
     h = F.gelu(gate) * val
     return _lin(h, sd[p + '4.weight'])
@@ -111,8 +133,7 @@ def attention(sd, p, x, *, heads, causal=False, mask=None, context=None, attn_bi
     if context is not None:
         context = gamma_layernorm(sd, p + 'context_norm.', context)
     kv_in = context if context is not None else x
-    xn = gamma_layernorm(sd, p + 'norm.', x)
-    q = _lin(xn, sd[p + 'to_q.weight'])
+    q = _ln_lin(x, sd[p + 'norm.gamma'], sd[p + 'norm.beta'], sd[p + 'to_q.weight'])
     k, v = _lin(kv_in, sd[p + 'to_kv.weight']).chunk(2, dim=-1)
 
     def split(t):

@@ -23,23 +23,23 @@ _ULL = ctypes.c_ulonglong
 # name -> argtypes, kept in the order of include/phenaki_hip.h (tests check every symbol is exported)
 SIGNATURES = {
     'pk_gemm': [_I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P],
-    'pk_gemm_ex': [_I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P],
+    'pk_gemm_ex': [_I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P, _I, _P, _P, _F, _P],
     'pk_gemm_auto_variant': [_I, _I, _I, _I, _I, _I, _I, _I],
     'pk_layernorm': [_P, _I, _P, _P, _F, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'pk_l2norm_rows': [_P, _I, _P, _I, _I, _I, _I, _P],
     'pk_patchify_ln': [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _I, _I, _P],
     'pk_unpatchify': [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'pk_sqdiff_partials': [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
-    'pk_peg': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    'pk_peg': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'pk_lfq_encode': [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P],
     'pk_lfq_decode': [_P, _P, _P, _P, _I, _I, _I, _P],
     'pk_layernorm_lfq': [_P, _I, _P, _P, _F, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
-    'pk_embed': [_P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P],
+    'pk_embed': [_P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _P],
     'pk_cpb_input': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     'pk_attn_pads': [_I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)],
     'pk_attn_prep': [_I, _P, _I, _P, _I, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    'pk_qkv_project': [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P],
-    'pk_qkv_attn': [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _L, _I, _P, _I, _P, _I, _P],
+    'pk_qkv_project': [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _P],
+    'pk_qkv_attn': [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _L, _I, _P, _I, _P, _I, _P, _P],
     'pk_attn_fwd': [_I, _P, _P, _P, _P, _L, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'pk_attn_small': [_P, _I, _P, _I, _P, _P, _F, _P, _L, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     'pk_cfg_mix': [_P, _I, _I, _I, _I, _P, _I, _F, _I, _P, _I, _I, _I, _P],
@@ -120,16 +120,20 @@ def tdtype(dtype):
 
 # ----------------------------------------------------------------------------- wrappers
 
-def gemm(dtype, A, W, M, N, K, *, C, bias=None, res=None, act=ACT_NONE, a_rows=None, lda=None, ldc=None, variant=0):
+def gemm(dtype, A, W, M, N, K, *, C, bias=None, res=None, act=ACT_NONE, a_rows=None, lda=None, ldc=None, variant=0, C2=None, ln=None):
     """C = act(A @ W^T + bias) (+ res).  A: (rows, K) f32 or T; W: (N, Kpad) T; C preallocated.
-    a_rows gathers rows of A (A.shape[0] physical rows bound the DMA descriptor)."""
+    a_rows gathers rows of A (A.shape[0] physical rows bound the DMA descriptor).
+    C2: optional bf16 copy of an f32 C.  ln = (s, t, eps): the LayerNorm in front of this Linear folded in (A = the un-normalised
+    rows, W = gamma (.) W, s / t its (N,) correction vectors)."""
     a_is_f32 = 1 if A.dtype == torch.float32 else 0
     out_is_f32 = 1 if C.dtype == torch.float32 else 0
     lda = A.stride(-2) if lda is None else lda
     ldc = C.stride(-2) if ldc is None else ldc
     ldr = res.stride(-2) if res is not None else 0
     rc = load().pk_gemm_ex(dtype, a_is_f32, ptr(A), lda, ptr(W), W.stride(0), M, N, K, f32p(bias, 'bias'), f32p(res, 'residual'), ldr,
-                           ptr(C), ldc, out_is_f32, act, ptr(a_rows), A.shape[0] if a_rows is not None else M, variant, stream(C))
+                           ptr(C), ldc, out_is_f32, act, ptr(a_rows), A.shape[0] if a_rows is not None else M, variant,
+                           ptr(C2), C2.stride(-2) if C2 is not None else 0, ptr(ln[0]) if ln else None, ptr(ln[1]) if ln else None,
+                           float(ln[2]) if ln else 0., stream(C))
     _check(rc, 'pk_gemm_ex')
     return C
 
@@ -168,8 +172,9 @@ def sqdiff_sum(a, b, frame_mask=None):
     return partials.sum()
 
 
-def peg(x, wt, bias, out, B, T, H, W, D, causal):
-    rc = load().pk_peg(f32p(x, 'x', rows_ok=True), f32p(wt, 'PEG weight'), f32p(bias, 'PEG bias'), ptr(out), B, T, H, W, D, 1 if causal else 0, stream(x))
+def peg(x, wt, bias, out, B, T, H, W, D, causal, out_t=None):
+    rc = load().pk_peg(f32p(x, 'x', rows_ok=True), f32p(wt, 'PEG weight'), f32p(bias, 'PEG bias'), ptr(out), ptr(out_t), B, T, H, W, D,
+                       1 if causal else 0, stream(x))
     _check(rc, 'pk_peg')
 
 
@@ -183,11 +188,11 @@ def lfq_decode(ids, wo, bo, out, M, D, cd):
     _check(rc, 'pk_lfq_decode')
 
 
-def embed(ids, tok, pos, out, S, n, D, *, nb=None, ids_prime=None):
+def embed(ids, tok, pos, out, S, n, D, *, nb=None, ids_prime=None, out_t=None):
     """out[s*n_tot + i] = tok[id] + pos[i]; ids (nb, n) int64 shared by the S sequences (s % nb), ids_prime (nb, n_prime) optional"""
     n_prime = ids_prime.shape[-1] if ids_prime is not None else 0
     rc = load().pk_embed(ptr(ids_prime), n_prime, ptr(ids), n, S if nb is None else nb, f32p(tok, 'token_emb.weight'),
-                         f32p(pos, 'pos_emb.weight'), ptr(out), S, D, stream(out))
+                         f32p(pos, 'pos_emb.weight'), ptr(out), ptr(out_t), S, D, stream(out))
     _check(rc, 'pk_embed')
 
 
@@ -218,18 +223,18 @@ def attn_prep(dtype, q, kv, null_kv, q_scale, k_scale, scale, Qp, Kp, Vt, S, h, 
     _check(rc, 'pk_attn_prep')
 
 
-def qkv_project(xq, xkv, wq, wkv, S, nseq, h, K, q_scale, k_scale, scale, Qp, Kp, Vt, nq_pad, nk_pad):
+def qkv_project(xq, xkv, wq, wkv, S, nseq, h, K, q_scale, k_scale, scale, Qp, Kp, Vt, nq_pad, nk_pad, q_ln_s=None):
     rc = load().pk_qkv_project(ptr(xq), ptr(xkv), xq.stride(-2), ptr(wq), ptr(wkv), wq.stride(0), S, nseq, h, K, f32p(q_scale, 'q_scale'),
-                                f32p(k_scale, 'k_scale'), scale, ptr(Qp), ptr(Kp), ptr(Vt), nq_pad, nk_pad, stream(xq))
+                                f32p(k_scale, 'k_scale'), scale, ptr(Qp), ptr(Kp), ptr(Vt), nq_pad, nk_pad, ptr(q_ln_s), stream(xq))
     _check(rc, 'pk_qkv_project')
 
 
-def qkv_attn(xq, xkv, wq, wkv, S, n, h, K, q_scale, k_scale, scale, O, *, bias=None, slopes=None, causal=False):
+def qkv_attn(xq, xkv, wq, wkv, S, n, h, K, q_scale, k_scale, scale, O, *, bias=None, slopes=None, causal=False, q_ln_s=None):
     """O (S*n, h*64) bf16 <- softmax(l2norm(xq Wq^T) l2norm(xkv Wk^T)^T * scale + bias) (xkv Wv^T), n <= 64 (one launch)"""
     bh, bld = (bias.stride(0), bias.stride(1)) if bias is not None else (0, 0)
     rc = load().pk_qkv_attn(ptr(xq), ptr(xkv), xq.stride(-2), ptr(wq), ptr(wkv), wq.stride(0), S, n, h, K, f32p(q_scale, 'q_scale'),
                             f32p(k_scale, 'k_scale'), scale, f32p(bias, 'attention bias'), bh, bld, f32p(slopes, 'ALiBi slopes'),
-                            1 if causal else 0, ptr(O), O.stride(-2), stream(xq))
+                            1 if causal else 0, ptr(O), O.stride(-2), ptr(q_ln_s), stream(xq))
     _check(rc, 'pk_qkv_attn')
 
 

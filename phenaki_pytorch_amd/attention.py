@@ -121,6 +121,35 @@ def linear_weight(lin, dtype):
     return _cache(lin).get(('w', dtype), [lin.weight], lambda: pack_linear_weight(lin.weight, dtype))
 
 
+# LayerNorm folded into the nn.Linear that consumes it (bf16 mode; PK_LN_FOLD=0 keeps the separate LayerNorm launches for A/B):
+#   LN(x) W^T = rstd * (x (gamma.W)^T - mean * s) + t,   s[n] = sum_k (gamma.W)[n][k],   t[n] = sum_k beta[k] W[n][k]
+# The GEMM reads the bf16 copy of the residual stream that its producer wrote beside the f32 one and takes mean / rstd from its own
+# A tiles (pk_gemm_ex ln_s / ln_t, pk_qkv_project / pk_qkv_attn q_ln_s): the LayerNorm launches and their 14 MB round trips go.
+_LN_FOLD = os.environ.get('PK_LN_FOLD', '1') != '0'
+# the feed-forward LayerNorm stays a separate launch by default: folded, the 128x128 FF1 kernel needs mean AND rstd of every row
+# (64 v_dot2c per wave per k-tile beside its 16 MFMAs) and ran 25 -> 41 us at M = 4608 -- more than the LayerNorm launch it saves
+_LN_FOLD_FF = os.environ.get('PK_LN_FOLD_FF', '0') != '0'
+
+
+def ln_fold_enabled(dtype):
+    return _LN_FOLD and dtype == L.BF16
+
+
+def folded_weight(owner, key, w_f32, gamma, beta, dtype, params):
+    """(packed gamma (.) W in T, s, t, beta_is_zero) for the (N, K) f32 weight `w_f32` (a callable building it), cached on `owner`"""
+    def build():
+        w = w_f32().float()
+        wg = pack_linear_weight(w * gamma.detach().float()[None, :], dtype)
+        s = wg[:, :w.shape[1]].float().sum(dim=1).contiguous()            # from the ROUNDED operand the MFMAs see
+        if beta is None:
+            t, bz = torch.zeros_like(s), True
+        else:
+            t = (w @ beta.detach().float()).contiguous()
+            bz = bool((beta.detach() == 0).all().item())
+        return wg, s, t, bz
+    return _cache(owner).get((key, dtype), params, build)
+
+
 def f32c(t):
     return t.detach().float().contiguous()
 
@@ -175,19 +204,41 @@ class FeedForwardSeq(nn.Sequential):
             return pack_linear_weight(w1p, dtype), pack_linear_weight(w2p, dtype), ip
         return _cache(self).get(('ff', dtype), [lin1.weight, lin2.weight], build)
 
-    def run(self, x2d, dtype):
-        """x2d (M, D) f32 -> ff(x) + x  (M, D) f32"""
+    def _packed_folded(self, dtype):
+        """first GEMM with the block's nn.LayerNorm folded in: (gamma (.) W1 interleaved / padded, s, t, beta_is_zero)"""
+        lin1, lin2, ln = self[1], self[4], self[0]
+
+        def w1():
+            inner = lin2.weight.shape[1]
+            ip = round_up(inner, 8 if dtype == L.BF16 else 4)
+            w = lin1.weight.detach().float()
+            w1p = torch.zeros((2 * ip, w.shape[1]), device=w.device, dtype=torch.float32)
+            w1p[0:2 * inner:2] = w[:inner]
+            w1p[1:2 * inner:2] = w[inner:]
+            return w1p
+        return folded_weight(self, 'ff1_ln', w1, ln.weight, ln.bias, dtype, [lin1.weight, ln.weight, ln.bias])
+
+    def run(self, x2d, dtype, xt=None, want_t=False):
+        """x2d (M, D) f32 -> ff(x) + x  (M, D) f32.  xt: the T copy of x2d (bf16 mode, LayerNorm folded into the first GEMM);
+        want_t: also return the T copy of the result for the next block -> (out, out_t)."""
         M, D = x2d.shape
         w1p, w2p, ip = self._packed(dtype)
         td = L.tdtype(dtype)
         ln = self[0]
-        xn = torch.empty((M, D), device=x2d.device, dtype=td)
-        L.layernorm(x2d, ln.weight, ln.bias, M, D, out=xn, eps=ln.eps)
         hmid = torch.empty((M, ip), device=x2d.device, dtype=td)
-        L.gemm(dtype, xn, w1p, M, 2 * ip, D, C=hmid, act=L.ACT_GEGLU)
+        if ln_fold_enabled(dtype) and _LN_FOLD_FF:
+            w1g, s1, t1, _ = self._packed_folded(dtype)
+            if xt is None:
+                xt = x2d.to(td)
+            L.gemm(dtype, xt, w1g, M, 2 * ip, D, C=hmid, act=L.ACT_GEGLU, ln=(s1, t1, ln.eps))
+        else:
+            xn = torch.empty((M, D), device=x2d.device, dtype=td)
+            L.layernorm(x2d, ln.weight, ln.bias, M, D, out=xn, eps=ln.eps)
+            L.gemm(dtype, xn, w1p, M, 2 * ip, D, C=hmid, act=L.ACT_GEGLU)
         out = torch.empty_like(x2d)
-        L.gemm(dtype, hmid, w2p, M, D, ip, C=out, res=x2d)
-        return out
+        out_t = torch.empty((M, D), device=x2d.device, dtype=td) if (want_t and dtype == L.BF16) else None
+        L.gemm(dtype, hmid, w2p, M, D, ip, C=out, res=x2d, C2=out_t)
+        return (out, out_t) if want_t else out
 
     def forward(self, x):
         L.require_device(x, 'x')
@@ -218,14 +269,15 @@ class PEG(PackedModule):
         w = self.dsconv.weight
         return _cache(self).get('wt', [w], lambda: w.detach().float().reshape(w.shape[0], 27).t().contiguous())
 
-    def run(self, x2d, shape):
-        """x2d (M, D) f32 contiguous, shape (b,t,h,w) with b*t*h*w == M -> peg(x) + x"""
+    def run(self, x2d, shape, want_t=False):
+        """x2d (M, D) f32 contiguous, shape (b,t,h,w) with b*t*h*w == M -> peg(x) + x  [, its bf16 copy]"""
         b, t, h, w = shape
         M, D = x2d.shape
         assert b * t * h * w == M, 'PEG shape does not match the token buffer'
         out = torch.empty_like(x2d)
-        L.peg(x2d, self._packed(), self.dsconv.bias, out, b, t, h, w, D, self.causal)
-        return out
+        out_t = torch.empty((M, D), device=x2d.device, dtype=torch.bfloat16) if want_t else None
+        L.peg(x2d, self._packed(), self.dsconv.bias, out, b, t, h, w, D, self.causal, out_t=out_t)
+        return (out, out_t) if want_t else out
 
     def forward(self, x, shape=None):
         L.require_device(x, 'x')
@@ -349,8 +401,24 @@ class Attention(PackedModule):
         L.gemm(dtype, src, linear_weight(self.to_kv, dtype), Mk, 2 * inner, Dk, C=kv)
         return kv
 
-    def run(self, x2d, S, n, dtype, *, context2d=None, n_ctx=None, attn_bias=None, kmask=None, kv_cache=None):
-        """x2d (S*n, D) f32 -> attention(x) + x.  kmask: (S, n_kv) uint8/bool over the real keys or None."""
+    def _finish(self, o, x2d, dtype, want_t):
+        """to_out projection + residual  [+ the bf16 copy of the result for the next block's folded LayerNorm]"""
+        M, D = x2d.shape
+        out = torch.empty_like(x2d)
+        out_t = torch.empty((M, D), device=x2d.device, dtype=torch.bfloat16) if (want_t and dtype == L.BF16) else None
+        L.gemm(dtype, o, linear_weight(self.to_out, dtype), M, D, o.shape[1], C=out, res=x2d, C2=out_t)
+        return (out, out_t) if want_t else out
+
+    def _folded_q(self, dtype):
+        """to_q with this block's LayerNorm folded in (gamma (.) Wq, s, t); None when the (zero) beta buffer is not zero"""
+        wg, s, t, beta_zero = folded_weight(self.to_q, 'q_ln', lambda: self.to_q.weight.detach(), self.norm.gamma, self.norm.beta, dtype,
+                                            [self.to_q.weight, self.norm.gamma, self.norm.beta])
+        return (wg, s, t) if beta_zero else None
+
+    def run(self, x2d, S, n, dtype, *, context2d=None, n_ctx=None, attn_bias=None, kmask=None, kv_cache=None, xt=None, want_t=False):
+        """x2d (S*n, D) f32 -> attention(x) + x.  kmask: (S, n_kv) uint8/bool over the real keys or None.
+        xt: the bf16 copy of x2d its producer wrote (bf16 mode: the block's LayerNorm is folded into to_q, K / V read the same
+        un-normalised rows); want_t: return (out, bf16 copy of out)."""
         dev = x2d.device
         td = L.tdtype(dtype)
         M, D = x2d.shape
@@ -359,14 +427,50 @@ class Attention(PackedModule):
         nnull = self.num_null_kv
         is_cross = context2d is not None
         n_kv = n_ctx if is_cross else n
+        slopes = self.rel_pos_bias.slopes if self.causal else None
+        cached = kv_cache.get(id(self)) if (kv_cache is not None and is_cross) else None
 
+        fq = self._folded_q(dtype) if ln_fold_enabled(dtype) else None
+        if fq is not None:
+            # ---- bf16, LayerNorm folded: q = l2norm(x (gamma.Wq)^T - mean(x) s)  (the l2norm cancels rstd), K / V from the same x
+            wq, sq, tq = fq
+            if xt is None:
+                xt = x2d.to(td)
+            if not is_cross and nnull == 0 and _SHORT_FUSED and n <= 64 and kmask is None and (attn_bias is None or attn_bias.stride(-1) == 1):
+                # short sequences (C-ViViT spatial n = 64 / temporal n = 9..10): projections + attention in ONE launch
+                o = torch.empty((M, inner), device=dev, dtype=td)
+                L.qkv_attn(xt, xt, wq, linear_weight(self.to_kv, dtype), S, n, h, D, self.q_scale, self.k_scale, float(self.scale), o,
+                           bias=attn_bias, slopes=slopes, causal=self.causal, q_ln_s=sq)
+                return self._finish(o, x2d, dtype, want_t)
+            nq_pad, nk_pad = L.attn_pads(n, n_kv, nnull)
+            Qp = torch.empty((S * h * nq_pad * 64,), device=dev, dtype=td)
+            if not is_cross and nnull == 0:
+                Kp = torch.empty((S * h * nk_pad * 64,), device=dev, dtype=td)
+                Vt = torch.empty((S * h * nk_pad * 64,), device=dev, dtype=td)      # pad columns: masked inside the attention kernels
+                L.qkv_project(xt, xt, wq, linear_weight(self.to_kv, dtype), S, n, h, D, self.q_scale, self.k_scale, float(self.scale),
+                              Qp, Kp, Vt, nq_pad, nk_pad, q_ln_s=sq)
+            elif cached is not None:
+                Kp, Vt = cached                       # step-invariant context: only the query side is projected again
+                L.qkv_project(xt, None, wq, None, S, n, h, D, self.q_scale, None, float(self.scale), Qp, None, None, nq_pad, nk_pad, q_ln_s=sq)
+            else:
+                q = torch.empty((M, inner), device=dev, dtype=torch.float32)
+                L.gemm(dtype, xt, wq, M, inner, D, C=q, ln=(sq, tq, 1e-5))
+                kv = self.project_kv(context2d if is_cross else xt, S, n_kv, dtype, is_cross)
+                Kp = torch.empty((S * h * nk_pad * 64,), device=dev, dtype=td)
+                Vt = torch.empty((S * h * nk_pad * 64,), device=dev, dtype=td)
+                L.attn_prep(dtype, q, kv, self.null_kv, self.q_scale, self.k_scale, float(self.scale), Qp, Kp, Vt, S, h, n, n_kv, nnull)
+                if kv_cache is not None and is_cross:
+                    kv_cache[id(self)] = (Kp, Vt)
+            o = torch.empty((M, inner), device=dev, dtype=td)
+            L.attn_fwd(dtype, Qp, Kp, Vt, o, S, h, n, n_kv, nnull, bias=attn_bias, kmask=kmask, slopes=slopes, causal=self.causal)
+            return self._finish(o, x2d, dtype, want_t)
+
+        # ---- separate LayerNorm launch (exact-f32 mode; bf16 with PK_LN_FOLD=0)
         xn = torch.empty((M, D), device=dev, dtype=td)
         # self-attention K/V come from the UN-normalised x (attention.py:140-144): in bf16 mode the same LN launch
         # also emits x in bf16 so every GEMM operand is T and can be fed by LDS-DMA
         xraw = torch.empty((M, D), device=dev, dtype=td) if (not is_cross and dtype == L.BF16) else None
         L.layernorm(x2d, self.norm.gamma, self.norm.beta, M, D, out=xn, raw=xraw)
-        slopes = self.rel_pos_bias.slopes if self.causal else None
-        cached = kv_cache.get(id(self)) if (kv_cache is not None and is_cross) else None
         # exact-f32 mode, very short sequences: one fused f32 launch; in bf16 mode the fused projection + MFMA attention
         # measured faster for the temporal layers (1.030 vs 1.046 ms per encode step)
         small = not is_cross and nnull == 0 and n <= 16 and dtype == L.F32
@@ -375,14 +479,10 @@ class Attention(PackedModule):
         fused = dtype == L.BF16 and not small and ((not is_cross and nnull == 0) or cached is not None)
 
         if _SHORT_FUSED and fused and not is_cross and n <= 64 and kmask is None and (attn_bias is None or attn_bias.stride(-1) == 1):
-            # short sequences (the C-ViViT spatial n = 64 and temporal n = 9..10 layers): projections + attention in ONE launch,
-            # a workgroup per (whole sequences, head); the operand images never leave LDS
             o = torch.empty((M, inner), device=dev, dtype=td)
             L.qkv_attn(xn, xraw, linear_weight(self.to_q, dtype), linear_weight(self.to_kv, dtype), S, n, h, D, self.q_scale,
                        self.k_scale, float(self.scale), o, bias=attn_bias, slopes=slopes, causal=self.causal)
-            out = torch.empty_like(x2d)
-            L.gemm(dtype, o, linear_weight(self.to_out, dtype), M, D, inner, C=out, res=x2d)
-            return out
+            return self._finish(o, x2d, dtype, want_t)
 
         q = None
         if not fused:
@@ -397,9 +497,7 @@ class Attention(PackedModule):
             o = torch.empty((M, inner), device=dev, dtype=td)
             L.attn_small(q, kv, self.q_scale, self.k_scale, float(self.scale), o, S, h, n, bias=attn_bias, kmask=kmask,
                          slopes=slopes, causal=self.causal)
-            out = torch.empty_like(x2d)
-            L.gemm(dtype, o, linear_weight(self.to_out, dtype), M, D, inner, C=out, res=x2d)
-            return out
+            return self._finish(o, x2d, dtype, want_t)
 
         nq_pad, nk_pad = L.attn_pads(n, n_kv, nnull)
         Qp = torch.empty((S * h * nq_pad * 64,), device=dev, dtype=td)
@@ -425,11 +523,8 @@ class Attention(PackedModule):
             Kp, Vt = cached      # step-invariant context: only the query side is prepared again
             L.attn_prep(dtype, q, None, self.null_kv, self.q_scale, self.k_scale, float(self.scale), Qp, None, None, S, h, n, n_kv, nnull)
         o = torch.empty((M, inner), device=dev, dtype=td)
-        slopes = self.rel_pos_bias.slopes if self.causal else None
         L.attn_fwd(dtype, Qp, Kp, Vt, o, S, h, n, n_kv, nnull, bias=attn_bias, kmask=kmask, slopes=slopes, causal=self.causal)
-        out = torch.empty_like(x2d)
-        L.gemm(dtype, o, linear_weight(self.to_out, dtype), M, D, inner, C=out, res=x2d)
-        return out
+        return self._finish(o, x2d, dtype, want_t)
 
     def forward(self, x, mask=None, context=None, attn_bias=None):
         L.require_device(x, 'x')
@@ -464,12 +559,31 @@ class Transformer(PackedModule):
 
     def run(self, x2d, S, n, dtype, *, video_shape=None, attn_bias=None, context2d=None, n_ctx=None,
             self_attn_mask=None, cross_attn_context_mask=None, kv_cache=None, out=None, out_t=None, perm=(0, 0),
-            skip_norm_out=False):
+            skip_norm_out=False, xt=None):
         """x2d (S*n, D) f32.  Writes norm_out(x) to `out` (f32) and/or `out_t` (T); returns `out` (allocated if both None).
         perm = (pb, pc): the output rows are written transposed, (a, b, c) -> (a, c, b).
+        xt: the bf16 copy of x2d, if the producer already wrote one (bf16 mode; else the first block converts).
         skip_norm_out: return the residual stream BEFORE norm_out (the caller fuses that LayerNorm into its next kernel)."""
         x = x2d
-        for peg, self_attn, cross_attn, ff in self.layers:
+        fold = ln_fold_enabled(dtype)
+        nl = len(self.layers)
+        for li, (peg, self_attn, cross_attn, ff) in enumerate(self.layers):
+            if fold:
+                # bf16: a block whose LayerNorm is folded into its first GEMM reads the bf16 copy (xt) of the residual stream, which the
+                # block BEFORE it writes beside the f32 one (only when somebody will read it)
+                has_cross = exists(cross_attn) and exists(context2d)
+                if exists(peg):
+                    x, xt = peg.run(x, video_shape, want_t=True)
+                r = self_attn.run(x, S, n, dtype, attn_bias=attn_bias, kmask=self_attn_mask, xt=xt, want_t=has_cross or _LN_FOLD_FF)
+                x, xt = r if isinstance(r, tuple) else (r, None)
+                if has_cross:
+                    r = cross_attn.run(x, S, n, dtype, context2d=context2d, n_ctx=n_ctx, kmask=cross_attn_context_mask,
+                                       kv_cache=kv_cache, xt=xt, want_t=_LN_FOLD_FF)
+                    x, xt = r if isinstance(r, tuple) else (r, None)
+                next_reads_xt = li + 1 < nl and not exists(self.layers[li + 1][0])       # next layer starts with attention (no PEG)
+                r = ff.run(x, dtype, xt=xt, want_t=next_reads_xt)
+                x, xt = r if isinstance(r, tuple) else (r, None)
+                continue
             if exists(peg):
                 x = peg.run(x, video_shape)
             x = self_attn.run(x, S, n, dtype, attn_bias=attn_bias, kmask=self_attn_mask)

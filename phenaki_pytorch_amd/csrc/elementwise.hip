@@ -8,7 +8,7 @@ namespace pk {
 // of the token buffer, zero padding, time pad (2,0) if causal else (1,1), bias, + residual (attention.py:323).
 // wt is the conv weight pre-transposed to [27][D] (tap-major) so channel loads are 16-byte vectors.
 __global__ __launch_bounds__(256) void peg_kernel(const float* __restrict__ x, const float* __restrict__ wt,
-                                                  const float* __restrict__ bias, float* __restrict__ out,
+                                                  const float* __restrict__ bias, float* __restrict__ out, bf16* __restrict__ out_t,
                                                   int B, int T, int H, int W, int D, int tfront, long total_vec) {
     const int dv = D >> 2;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total_vec; idx += (long)gridDim.x * 256) {
@@ -38,7 +38,9 @@ __global__ __launch_bounds__(256) void peg_kernel(const float* __restrict__ x, c
                 }
             }
         }
-        *reinterpret_cast<f32x4*>(out + ((((size_t)b * T + t) * H + h) * W + w) * D + c) = acc + center;
+        const size_t o = ((((size_t)b * T + t) * H + h) * W + w) * D + c;
+        *reinterpret_cast<f32x4*>(out + o) = acc + center;
+        if (out_t) store4(out_t + o, acc + center);
     }
 }
 
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(256) void peg_kernel(const float* __restrict__ x, c
 // and reused by its 3 taps, and the 27 weight vectors are loaded once per thread (3x fewer L2 reads than peg_kernel)
 template <int WW>
 __global__ __launch_bounds__(256) void peg_row_kernel(const float* __restrict__ x, const float* __restrict__ wt,
-                                                      const float* __restrict__ bias, float* __restrict__ out,
+                                                      const float* __restrict__ bias, float* __restrict__ out, bf16* __restrict__ out_t,
                                                       int B, int T, int H, int D, int tfront, long total) {
     const int dv = D >> 2;
     // XCD-contiguous order (common.hpp): a stencil row's 9 neighbour rows then sit in the SAME XCD's L2 -- 19.2 -> 13.3 us
@@ -85,9 +87,13 @@ __global__ __launch_bounds__(256) void peg_row_kernel(const float* __restrict__ 
             }
         }
     }
-    float* orow = out + (((size_t)b * T + t) * H + h) * WW * D + c;
+    const size_t o0 = (((size_t)b * T + t) * H + h) * WW * D + c;
 #pragma unroll
-    for (int w = 0; w < WW; ++w) *reinterpret_cast<f32x4*>(orow + (size_t)w * D) = acc[w];
+    for (int w = 0; w < WW; ++w) *reinterpret_cast<f32x4*>(out + o0 + (size_t)w * D) = acc[w];
+    if (out_t) {                                             // bf16 copy: the next GEMM's LDS-DMA operand
+#pragma unroll
+        for (int w = 0; w < WW; ++w) store4(out_t + o0 + (size_t)w * D, acc[w]);
+    }
 }
 
 // ---- LFQ (vector-quantize-pytorch LFQ restated in oracle/lfq.py; call sites cvivit.py:570, :439)
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(256) void lfq_decode_generic_kernel(const long long
 // sequences of a classifier-free-guidance batch (cond | null) read the SAME nb id rows -- no torch.cat on the host.
 __global__ __launch_bounds__(256) void embed_kernel(const long long* __restrict__ ids_prime, int n_prime, const long long* __restrict__ ids,
                                                     int n, int nb, const float* __restrict__ tok, const float* __restrict__ pos,
-                                                    float* __restrict__ out, int D, long total_vec) {
+                                                    float* __restrict__ out, bf16* __restrict__ out_t, int D, long total_vec) {
     const int dv = D >> 2;
     const int n_tot = n_prime + n;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total_vec; idx += (long)gridDim.x * 256) {
@@ -193,6 +199,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const long long* __restrict_
         const f32x4 a = *reinterpret_cast<const f32x4*>(pos + (size_t)i * D + c);
         const f32x4 t = *reinterpret_cast<const f32x4*>(tok + (size_t)id * D + c);
         *reinterpret_cast<f32x4*>(out + (size_t)r * D + c) = a + t;
+        if (out_t) store4(out_t + (size_t)r * D + c, a + t);
     }
 }
 
@@ -260,7 +267,7 @@ using namespace pk;
 static inline int nblocks(long total) { long b = (total + 255) / 256; return (int)(b < 16384 ? (b > 0 ? b : 1) : 16384); }
 #define STREAM(s) reinterpret_cast<hipStream_t>(s)
 
-extern "C" int pk_peg(const float* x, const float* wt, const float* bias, float* out, int B, int T, int H, int W, int D,
+extern "C" int pk_peg(const float* x, const float* wt, const float* bias, float* out, void* out_t, int B, int T, int H, int W, int D,
                       int causal, void* stream) {
     if (!x || !wt || !bias || !out || B <= 0 || T <= 0 || H <= 0 || W <= 0 || D <= 0) return PK_EINVAL;
     if (D & 3) return PK_EALIGN;
@@ -268,10 +275,12 @@ extern "C" int pk_peg(const float* x, const float* wt, const float* bias, float*
     const long total = (long)B * T * H * W * (D >> 2);
     const long rows = (long)B * T * H * (D >> 2);
     const dim3 rgrid(xcd_padded_grid((rows + 255) / 256));
-    if (W == 8) hipLaunchKernelGGL((peg_row_kernel<8>), rgrid, dim3(256), 0, STREAM(stream), x, wt, bias, out, B, T, H, D, causal ? 2 : 1, rows);
-    else if (W == 4) hipLaunchKernelGGL((peg_row_kernel<4>), rgrid, dim3(256), 0, STREAM(stream), x, wt, bias, out, B, T, H, D, causal ? 2 : 1, rows);
-    else if (W == 16) hipLaunchKernelGGL((peg_row_kernel<16>), rgrid, dim3(256), 0, STREAM(stream), x, wt, bias, out, B, T, H, D, causal ? 2 : 1, rows);
-    else hipLaunchKernelGGL(peg_kernel, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), x, wt, bias, out, B, T, H, W, D, causal ? 2 : 1, total);
+    bf16* ot = reinterpret_cast<bf16*>(out_t);
+    if (ot && (reinterpret_cast<uintptr_t>(ot) & 7)) return PK_EALIGN;
+    if (W == 8) hipLaunchKernelGGL((peg_row_kernel<8>), rgrid, dim3(256), 0, STREAM(stream), x, wt, bias, out, ot, B, T, H, D, causal ? 2 : 1, rows);
+    else if (W == 4) hipLaunchKernelGGL((peg_row_kernel<4>), rgrid, dim3(256), 0, STREAM(stream), x, wt, bias, out, ot, B, T, H, D, causal ? 2 : 1, rows);
+    else if (W == 16) hipLaunchKernelGGL((peg_row_kernel<16>), rgrid, dim3(256), 0, STREAM(stream), x, wt, bias, out, ot, B, T, H, D, causal ? 2 : 1, rows);
+    else hipLaunchKernelGGL(peg_kernel, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), x, wt, bias, out, ot, B, T, H, W, D, causal ? 2 : 1, total);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }
@@ -313,11 +322,11 @@ extern "C" int pk_lfq_decode(const long long* ids, const float* wo, const float*
 }
 
 extern "C" int pk_embed(const long long* ids_prime, int n_prime, const long long* ids, int n, int nb, const float* tok,
-                        const float* pos, float* out, int S, int D, void* stream) {
+                        const float* pos, float* out, void* out_t, int S, int D, void* stream) {
     if (!ids || !tok || !pos || !out || S <= 0 || n <= 0 || nb <= 0 || D <= 0 || n_prime < 0 || (n_prime > 0 && !ids_prime)) return PK_EINVAL;
     if (D & 3) return PK_EALIGN;
     const long total = (long)S * (n_prime + n) * (D >> 2);
-    hipLaunchKernelGGL(embed_kernel, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), ids_prime, n_prime, ids, n, nb, tok, pos, out, D, total);
+    hipLaunchKernelGGL(embed_kernel, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), ids_prime, n_prime, ids, n, nb, tok, pos, out, reinterpret_cast<bf16*>(out_t), D, total);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

@@ -18,10 +18,17 @@ struct GemmEpilogue {
     int out_f32;         // 1: C is f32, 0: C is T
     int act;
     int vec_ok;          // N, ldc, ldr multiples of 4 and pointers 16-B aligned -> vector epilogue
+    void* C2;            // optional second copy of an f32 result in T (bf16): the next GEMM's LDS-DMA operand (vector epilogue only)
+    int ldc2;
+    // LayerNorm folded into this GEMM (A holds the UN-normalised rows x, W holds gamma (.) W):
+    //   LN(x) W^T = rstd * (x (gamma.W)^T - mean * s) + t,   s[n] = sum_k gamma[k] W[n][k],  t[n] = sum_k beta[k] W[n][k]
+    // mean / rstd come from the A fragments of the main loop (GemmDma::run_stats); null ln_s: plain GEMM
+    const float* ln_s; const float* ln_t; float ln_eps;
 };
 
-template <typename T, int TM, int TN, int WN = 2>
-__device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[TM][TN], int M, int N, const GemmEpilogue& e, int m0, int n0) {
+template <typename T, int TM, int TN, int WN = 2, bool LNF = false>
+__device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[TM][TN], int M, int N, const GemmEpilogue& e, int m0, int n0,
+                                              const float* rsum = nullptr, const float* rsq = nullptr, int K = 1) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN, g = lane >> 4, lr = lane & 15;
     float* Cf = reinterpret_cast<float*>(e.C);
@@ -30,11 +37,22 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[TM][TN], int M,
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * 16 * TM + i * 16 + lr;
         if (m >= M) continue;
+        float mean = 0.f, rstd = 1.f;
+        if (LNF) {                                          // statistics of row m over its K features (biased variance, eps inside the sqrt)
+            mean = rsum[i] / (float)K;
+            rstd = 1.0f / sqrtf(fmaxf(rsq[i] / (float)K - mean * mean, 0.f) + e.ln_eps);
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * 16 * TN + j * 16 + g * 4;
             if (n >= N) continue;
             f32x4 v = acc[i][j];
+            if (LNF) {                                      // host guarantees the vector path (N % 4 == 0)
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(e.ln_s + n);
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(e.ln_t + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = rstd * (v[r] - mean * s4[r]) + t4[r];
+            }
             if (e.vec_ok) {
                 if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + n);
                 if (e.act == ACT_GEGLU) {
@@ -49,6 +67,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[TM][TN], int M,
                     if (e.res) v += *reinterpret_cast<const f32x4*>(e.res + (size_t)m * e.ldr + n);
                     const size_t o = (size_t)m * e.ldc + n;
                     if (e.out_f32) store4(Cf + o, v); else store4(Ct + o, v);
+                    if (e.C2) store4(reinterpret_cast<bf16*>(e.C2) + (size_t)m * e.ldc2 + n, v);
                 }
             } else {
                 // scalar path (N not a multiple of 4, e.g. heads = 2 or a 1-wide critic head)
@@ -88,7 +107,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmOperands p, const G
     gemm_epilogue<T, TM, TN>(acc, p.M, p.N, e, m0, n0);
 }
 
-template <typename T, int TM, int TN, int WM, int WN, int STAGES, int ROWB, int PW>
+template <typename T, int TM, int TN, int WM, int WN, int STAGES, int ROWB, int PW, bool LNF = false>
 __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_dma_kernel(const GemmOperands p, const GemmEpilogue e, int a_nrows) {
     using Tile = GemmDma<T, TM, TN, WM, WN, STAGES, ROWB, PW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -114,8 +133,14 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_dma_kernel(const Gem
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-    if (!Tile::run(p, a_nrows, m0, n0, smem, acc)) return;      // producer waves hold no accumulators
-    gemm_epilogue<T, TM, TN, WN>(acc, p.M, p.N, e, m0, n0);
+    if constexpr (LNF) {
+        float rsum[TM], rsq[TM];
+        if (!Tile::template run_stats<2>(p, a_nrows, m0, n0, smem, acc, rsum, rsq)) return;
+        gemm_epilogue<T, TM, TN, WN, true>(acc, p.M, p.N, e, m0, n0, rsum, rsq, p.K);
+    } else {
+        if (!Tile::run(p, a_nrows, m0, n0, smem, acc)) return;      // producer waves hold no accumulators
+        gemm_epilogue<T, TM, TN, WN>(acc, p.M, p.N, e, m0, n0);
+    }
 }
 
 template <typename T, typename TA, int TM, int TN>
@@ -127,7 +152,7 @@ static int launch_v1(const GemmOperands& p, const GemmEpilogue& e, hipStream_t s
     return PK_OK;
 }
 
-template <typename T, int TM, int TN, int STAGES, int WM = 2, int WN = 2, int ROWB = 128, int PW = 0>
+template <typename T, int TM, int TN, int STAGES, int WM = 2, int WN = 2, int ROWB = 128, int PW = 0, bool LNF = false>
 static int launch_dma(const GemmOperands& p, const GemmEpilogue& e, int a_nrows, hipStream_t s) {
     using Tile = GemmDma<T, TM, TN, WM, WN, STAGES, ROWB, PW>;
     if (Tile::SMEM > 65536) {                              // opt-in to > 64 KB of LDS: per kernel AND per device of the process
@@ -135,14 +160,14 @@ static int launch_dma(const GemmOperands& p, const GemmEpilogue& e, int a_nrows,
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PK_ELAUNCH;
         if (!attr_set[dev]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel<T, TM, TN, WM, WN, STAGES, ROWB, PW>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel<T, TM, TN, WM, WN, STAGES, ROWB, PW, LNF>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, Tile::SMEM) != hipSuccess) return PK_ELAUNCH;
             attr_set[dev] = true;
         }
     }
     const int MT = (p.M + Tile::BM - 1) / Tile::BM, NT = (p.N + Tile::BN - 1) / Tile::BN;
     dim3 grid(8 * ((MT + 7) / 8) * NT);                   // see the XCD-aware tile map in the kernel
-    hipLaunchKernelGGL((gemm_dma_kernel<T, TM, TN, WM, WN, STAGES, ROWB, PW>), grid, dim3(Tile::THREADS), Tile::SMEM, s, p, e, a_nrows);
+    hipLaunchKernelGGL((gemm_dma_kernel<T, TM, TN, WM, WN, STAGES, ROWB, PW, LNF>), grid, dim3(Tile::THREADS), Tile::SMEM, s, p, e, a_nrows);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }
@@ -187,7 +212,7 @@ extern "C" int pk_gemm_auto_variant(int dtype, int a_is_f32, int M, int N, int K
 extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const void* W, int ldw,
                           int M, int N, int K, const float* bias, const float* res, int ldr,
                           void* C, int ldc, int out_is_f32, int act, const int* a_rows, int a_nrows,
-                          int variant, void* stream) {
+                          int variant, void* C2, int ldc2, const float* ln_s, const float* ln_t, float ln_eps, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !C) return PK_EINVAL;
     if (dtype != 0 && dtype != 1) return PK_EINVAL;
     if (act < 0 || act > 2) return PK_EINVAL;
@@ -202,16 +227,25 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
     if (!a_rows) a_nrows = M;
     // k-rotation (gemm_dma.hpp): measured +12..33 % on the 65536-wide vocab-head shape, -0..13 % on the N <= 2736 shapes
     GemmOperands p{A, W, a_rows, lda, ldw, M, N, K, 0, N >= 8192 ? krot_default() : 0};
-    GemmEpilogue e{bias, res, C, ldr, ldc, out_is_f32, act, 0};
+    GemmEpilogue e{bias, res, C, ldr, ldc, out_is_f32, act, 0, C2, ldc2, ln_s, ln_t, ln_eps};
     bool v = (N % 4 == 0) && (ldc % 4 == 0) && al16(C) && (!bias || al16(bias)) && (!res || (al16(res) && ldr % 4 == 0));
     if (act == ACT_GEGLU) v = v && (ldc % 2 == 0) && ((reinterpret_cast<uintptr_t>(C) & 7) == 0);
     e.vec_ok = v ? 1 : 0;
+    if (C2 && (!v || !out_is_f32 || act == ACT_GEGLU || dtype != 1 || (ldc2 & 3) || (reinterpret_cast<uintptr_t>(C2) & 7))) return PK_EINVAL;
+    if ((ln_s == nullptr) != (ln_t == nullptr)) return PK_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
     const bool dma_ok = dma_possible(dtype, a_is_f32, N, K, lda, ldw, a_nrows);
     if (variant >= 100) { p.plain_map = 1; variant -= 100; }
     if (variant == 0) variant = auto_variant(dtype, a_is_f32, M, N, K, lda, ldw, a_nrows);
     if (variant >= 3 && !dma_ok) return PK_EINVAL;
+    if (ln_s) {
+        // LayerNorm-folded GEMM: LDS-DMA main loop only (the statistics come from its A fragments), vector epilogue, 64x64 / 128x128 tiles
+        if (!dma_ok || !v || !al16(ln_s) || !al16(ln_t) || a_rows) return PK_EINVAL;
+        const bool big = variant == 24 || variant == 2 || variant == 9;
+        if (dtype == 1) return big ? launch_dma<bf16, 4, 2, 2, 2, 4, 128, 0, true>(p, e, a_nrows, s) : launch_dma<bf16, 2, 2, 2, 2, 2, 128, 0, true>(p, e, a_nrows, s);
+        return big ? launch_dma<float, 4, 2, 2, 2, 4, 128, 0, true>(p, e, a_nrows, s) : launch_dma<float, 2, 2, 2, 2, 2, 128, 0, true>(p, e, a_nrows, s);
+    }
     if (dtype == 1) {
         switch (variant) {
             case 1: return a_is_f32 ? launch_v1<bf16, float, 2, 2>(p, e, s) : launch_v1<bf16, bf16, 2, 2>(p, e, s);
@@ -281,7 +315,8 @@ extern "C" int pk_gemm(int dtype, int a_is_f32, const void* A, int lda, const vo
     if (a_rows) {
         const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128);
         return pk_gemm_ex(dtype, a_is_f32, A, lda, W, ldw, M, N, K, bias, res, ldr, C, ldc, out_is_f32, act, a_rows,
-                          0x7fffffff / (lda > 0 ? lda : 1) / 4, blocks128 >= 384 ? 2 : 1, stream);
+                          0x7fffffff / (lda > 0 ? lda : 1) / 4, blocks128 >= 384 ? 2 : 1, nullptr, 0, nullptr, nullptr, 0.f, stream);
     }
-    return pk_gemm_ex(dtype, a_is_f32, A, lda, W, ldw, M, N, K, bias, res, ldr, C, ldc, out_is_f32, act, nullptr, M, 0, stream);
+    return pk_gemm_ex(dtype, a_is_f32, A, lda, W, ldw, M, N, K, bias, res, ldr, C, ldc, out_is_f32, act, nullptr, M, 0,
+                      nullptr, 0, nullptr, nullptr, 0.f, stream);
 }

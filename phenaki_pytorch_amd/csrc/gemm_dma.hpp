@@ -19,6 +19,29 @@
 
 namespace pk {
 
+// ---- row statistics of the A operand, taken from the MFMA fragments as they pass (LayerNorm folded into the GEMM, see
+// gemm.hip): a lane holds 8 k-elements of ONE row per fragment chunk, so sum / sum of squares are a few VALU ops beside the
+// MFMAs (bf16: v_dot2c_f32_bf16 against (1, 1) and against itself) and a 4-lane-group shuffle at the end.
+// v_dot2c_f32_bf16 d, a, b : d += a.lo * b.lo + a.hi * b.hi (f32 accumulate).  Issued through inline asm on the raw 32-bit words:
+// with __builtin_amdgcn_fdot2_f32_bf16 on elements of the u32x4 fragment hipcc (ROCm 7.2) selected the FIRST word four times
+// (every v_dot2c of a fragment read the same VGPR; found by the statistics coming out wrong, confirmed in the ISA).
+__device__ __forceinline__ void dot2acc_bf16(float& d, uint32_t a, uint32_t b) {
+    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(d) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void frag_stats(const Frag<bf16>& f, float& s, float& q, bool want_sq) {
+    const uint32_t w0 = f.v[0], w1 = f.v[1], w2 = f.v[2], w3 = f.v[3];
+    const uint32_t ones = 0x3f803f80u;                       // (1.0, 1.0) in bf16
+    dot2acc_bf16(s, w0, ones); dot2acc_bf16(s, w1, ones); dot2acc_bf16(s, w2, ones); dot2acc_bf16(s, w3, ones);
+    if (want_sq) { dot2acc_bf16(q, w0, w0); dot2acc_bf16(q, w1, w1); dot2acc_bf16(q, w2, w2); dot2acc_bf16(q, w3, w3); }
+}
+__device__ __forceinline__ void frag_stats(const Frag<float>& f, float& s, float& q, bool want_sq) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        s += f.lo[e] + f.hi[e];
+        if (want_sq) q = fmaf(f.lo[e], f.lo[e], fmaf(f.hi[e], f.hi[e], q));
+    }
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 __device__ __forceinline__ int swz64(int rowq) { return (0x78 >> (2 * rowq)) & 3; }        // {0,2,3,1}[rowq], two bits each
@@ -72,6 +95,15 @@ struct GemmDma {
     // acc must be zero-initialised by the caller. a_nrows = number of physical rows behind p.A (for the bounds check).
     // Returns true for the waves that hold accumulators (all of them when PW == 0); producer waves must skip the epilogue.
     static __device__ __forceinline__ bool run(const GemmOperands& p, int a_nrows, int m0, int n0, char* smem, f32x4 (&acc)[TM][TN]) {
+        float dummy[TM];
+        return run_stats<0>(p, a_nrows, m0, n0, smem, acc, dummy, dummy);
+    }
+
+    // STATS = 0: plain; 1: rsum[i] = sum_k A[row][k] of the lane's row (wm*16*TM + i*16 + lr); 2: also rsq[i] = sum_k A[row][k]^2.
+    // Every compute wave gets the statistics of its own rows (waves of one row group compute them redundantly).
+    template <int STATS>
+    static __device__ __forceinline__ bool run_stats(const GemmOperands& p, int a_nrows, int m0, int n0, char* smem, f32x4 (&acc)[TM][TN],
+                                                     float (&rsum)[TM], float (&rsq)[TM]) {
         const int tid = threadIdx.x, lane = tid & 63;
         const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
         const bool loads = PW == 0 || wave_all >= NW;
@@ -128,6 +160,10 @@ struct GemmDma {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(base + BM * ROWB + (wave * IW + i) * 1024), 16, offW[i], koff, 0, 0);
         };
 
+        if (STATS) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) { rsum[i] = 0.f; rsq[i] = 0.f; }
+        }
         const int pre = nt < STAGES - 1 ? nt : STAGES - 1;
         if (loads)
             for (int s = 0; s < pre; ++s) issue(s, s);
@@ -158,6 +194,21 @@ struct GemmDma {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = mma(fw[j], fa[i], acc[i][j]);
+                if (STATS) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) frag_stats(fa[i], rsum[i], rsq[i], STATS > 1);
+                }
+            }
+        }
+        if (STATS) {                                      // fold the 4 lane groups (k = g*8 + 0..7 of every chunk) of each row
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                rsum[i] += __shfl_xor(rsum[i], 16, 64);
+                rsum[i] += __shfl_xor(rsum[i], 32, 64);
+                if (STATS > 1) {
+                    rsq[i] += __shfl_xor(rsq[i], 16, 64);
+                    rsq[i] += __shfl_xor(rsq[i], 32, 64);
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -19,6 +19,7 @@ struct QkvArgs {
     void* Qp; void* Kp; void* Vt;
     int nq_pad, nk_pad;
     int krot;
+    const float* q_ln_s;                    // LayerNorm folded into to_q: xq holds the UN-normalised rows, wq = gamma (.) Wq, q_ln_s[n] = sum_k wq[n][k]
 };
 
 using QkvTile = GemmDma<bf16, 1, 4, 4, 1, 2, 128>;
@@ -50,9 +51,23 @@ __global__ __launch_bounds__(256) void qkv_project_kernel(const QkvArgs a) {
     f32x4 acc[1][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0, 0, 0, 0};
-    (void)QkvTile::run(p, a.M, m0, n0, smem, acc);
-
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, lr = lane & 15;
+    if (is_q && a.q_ln_s) {
+        // q = l2norm(LN(x) Wq^T): LN(x) Wq^T = rstd * (x (gamma.Wq)^T - mean * s) and the l2norm cancels rstd > 0, so only the row
+        // mean (from the A fragments of the main loop) and s are needed
+        float rsum[1], rsq[1];
+        (void)QkvTile::run_stats<1>(p, a.M, m0, n0, smem, acc, rsum, rsq);
+        const float mean = rsum[0] / (float)a.K;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.q_ln_s + n0 + j * 16 + g * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[0][j][r] -= mean * s4[r];
+        }
+    } else {
+        (void)QkvTile::run(p, a.M, m0, n0, smem, acc);
+    }
+
     const int m = m0 + wave * 16 + lr;
     if (m >= a.M) return;
     const int s = m / a.nseq, pos = m % a.nseq;
@@ -93,9 +108,10 @@ __global__ __launch_bounds__(256) void qkv_project_kernel(const QkvArgs a) {
 using namespace pk;
 
 // bf16 only.  xq [M][ld] = LayerNorm(x) rows, xkv [M][ld] = x rows (or NULL: query side only); M = S * nseq.
+// q_ln_s != NULL: the LayerNorm is folded into to_q -- xq holds the un-normalised rows, wq = gamma (.) Wq, q_ln_s its row sums.
 extern "C" int pk_qkv_project(const void* xq, const void* xkv, int ld, const void* wq, const void* wkv, int ldw,
                               int S, int nseq, int h, int K, const float* q_scale, const float* k_scale, float scale,
-                              void* Qp, void* Kp, void* Vt, int nq_pad, int nk_pad, void* stream) {
+                              void* Qp, void* Kp, void* Vt, int nq_pad, int nk_pad, const float* q_ln_s, void* stream) {
     if (!xq || !wq || !q_scale || !Qp || S <= 0 || nseq <= 0 || h <= 0 || K <= 0) return PK_EINVAL;
     if (xkv && (!wkv || !k_scale || !Kp || !Vt)) return PK_EINVAL;
     if (nq_pad < nseq || (xkv && nk_pad < nseq)) return PK_EINVAL;
@@ -105,7 +121,8 @@ extern "C" int pk_qkv_project(const void* xq, const void* xkv, int ld, const voi
     if (ldw < (K + 63) / 64 * 64) return PK_EINVAL;             // W zero-padded along K to the 64-wide k-tile
     const long M = (long)S * nseq;
     if ((size_t)M * ld * 2 >= 0xFFFFFFF0ull) return PK_EINVAL;
-    QkvArgs a{xq, xkv, wq, wkv, ld, ldw, (int)M, K, h, nseq, q_scale, k_scale, scale, Qp, Kp, Vt, nq_pad, nk_pad, 0};
+    if (q_ln_s && mis(q_ln_s)) return PK_EALIGN;
+    QkvArgs a{xq, xkv, wq, wkv, ld, ldw, (int)M, K, h, nseq, q_scale, k_scale, scale, Qp, Kp, Vt, nq_pad, nk_pad, 0, q_ln_s};
     const int MT = (int)((M + 63) / 64), NT = xkv ? 3 * h : h;
     dim3 grid(8 * ((MT + 7) / 8) * NT);
     hipLaunchKernelGGL(qkv_project_kernel, grid, dim3(256), QkvTile::SMEM, reinterpret_cast<hipStream_t>(stream), a);

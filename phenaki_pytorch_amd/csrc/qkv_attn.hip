@@ -24,6 +24,7 @@ struct QkvAttnArgs {
     const float* slopes; int causal;        // ALiBi slopes [h] with causal
     void* O; int ldo;                       // bf16 [(s*n + i)][hh*64 + d]
     uint32_t recip;                         // ceil(65536 / n): x / n == (x * recip) >> 16 for x < 64
+    const float* q_ln_s;                    // LayerNorm folded into to_q (see pk_qkv_project): xq = the un-normalised rows, wq = gamma (.) Wq
 };
 
 using QaTile = GemmDma<bf16, 1, 4, 4, 1, 2, 128>;          // 64 rows x 64 columns (one head), 4 waves stacked on the rows
@@ -62,7 +63,19 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(const QkvAttnArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0, 0, 0, 0};
         p.A = a.xq; p.W = a.wq; p.N = a.h * 64;
-        (void)QaTile::run(p, M, m0, hh * 64, smem, acc);
+        if (a.q_ln_s) {                                                 // l2norm cancels rstd: only the row mean and s are needed
+            float rsum[1], rsq[1];
+            (void)QaTile::run_stats<1>(p, M, m0, hh * 64, smem, acc, rsum, rsq);
+            const float mean = rsum[0] / (float)a.K;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.q_ln_s + hh * 64 + j * 16 + g * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[0][j][r] -= mean * s4[r];
+            }
+        } else {
+            (void)QaTile::run(p, M, m0, hh * 64, smem, acc);
+        }
         float ss = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -211,10 +224,10 @@ using namespace pk;
 
 // bf16 only.  xq [S*n][ld] = LayerNorm(x), xkv [S*n][ld] = x (both bf16); wq [h*64][ldw], wkv [2*h*64][ldw] bf16 with K zero-padded
 // to a multiple of 64; bias [h][n][n] f32 (or NULL), slopes [h] with causal; O [S*n][ldo] bf16 receives softmax(q k^T + bias) v
-// with the heads merged (column hh*64 + d).  n <= 64, no null keys, no key mask.
+// with the heads merged (column hh*64 + d).  n <= 64, no null keys, no key mask.  q_ln_s != NULL: LayerNorm folded into to_q (xq = x).
 extern "C" int pk_qkv_attn(const void* xq, const void* xkv, int ld, const void* wq, const void* wkv, int ldw, int S, int n, int h,
                            int K, const float* q_scale, const float* k_scale, float scale, const float* bias, long bias_hstride,
-                           int bias_ld, const float* slopes, int causal, void* O, int ldo, void* stream) {
+                           int bias_ld, const float* slopes, int causal, void* O, int ldo, const float* q_ln_s, void* stream) {
     if (!xq || !xkv || !wq || !wkv || !q_scale || !k_scale || !O || S <= 0 || n <= 0 || n > 64 || h <= 0 || K <= 0) return PK_EINVAL;
     auto mis = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) != 0; };
     if ((K & 7) || (ld & 7) || (ldw & 7) || (ldo & 3) || mis(xq) || mis(xkv) || mis(wq) || mis(wkv) || mis(q_scale) || mis(k_scale) ||
@@ -230,6 +243,8 @@ extern "C" int pk_qkv_attn(const void* xq, const void* xkv, int ld, const void* 
     a.slopes = slopes; a.causal = causal;
     a.O = O; a.ldo = ldo;
     a.recip = (65536u + (uint32_t)n - 1u) / (uint32_t)n;
+    a.q_ln_s = q_ln_s;
+    if (q_ln_s && mis(q_ln_s)) return PK_EALIGN;
     const int tiles = (S + a.spt - 1) / a.spt;
     dim3 grid(8 * ((tiles + 7) / 8) * h);
     hipLaunchKernelGGL(qkv_attn_kernel, grid, dim3(256), QaTile::SMEM + 16384, reinterpret_cast<hipStream_t>(stream), a);

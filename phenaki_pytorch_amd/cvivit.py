@@ -14,7 +14,7 @@ from torch import nn
 
 from . import _lib as L
 from .attention import (ContinuousPositionBias, PackedModule, Transformer, compute_dtype_of, exists, invalidate_packed,
-                        linear_weight, refuse_autograd, set_compute_dtype)
+                        linear_weight, ln_fold_enabled, refuse_autograd, set_compute_dtype)
 from .quantize import LFQ, VectorQuantize
 
 
@@ -165,6 +165,8 @@ class CViViT(PackedModule):
         T = 1 + nt
         dev = video.device
         tokens = torch.empty((B * T * hw, self.dim), device=dev, dtype=torch.float32)
+        # bf16 copy for the first transformer block (its LayerNorm is folded into its first GEMM, which reads bf16 rows)
+        tokens_t = torch.empty((B * T * hw, self.dim), device=dev, dtype=td) if ln_fold_enabled(dt) else None
 
         def group(seq, f0, ntg, ptg, goff):
             ln1, lin, ln2 = seq[1], seq[2], seq[3]
@@ -174,14 +176,15 @@ class CViViT(PackedModule):
             L.patchify_ln(video, f0, ntg, ptg, ph, pw, ln1.weight, ln1.bias, patches, eps=ln1.eps)
             tmp = torch.empty((rows, self.dim), device=dev, dtype=torch.float32)
             L.gemm(dt, patches, linear_weight(lin, dt), rows, self.dim, P, C=tmp, bias=lin.bias)
-            L.layernorm(tmp, ln2.weight, ln2.bias, rows, self.dim, out2=tokens, eps=ln2.eps, remap=(ntg * hw, T * hw, goff))
+            L.layernorm(tmp, ln2.weight, ln2.bias, rows, self.dim, out=tokens_t, out2=tokens, eps=ln2.eps, remap=(ntg * hw, T * hw, goff))
 
         group(self.to_patch_emb_first_frame, 0, 1, 1, 0)
         if nt > 0:
             group(self.to_patch_emb, 1, nt, pt, hw)
+        self.__dict__['_pk_tokens_t'] = tokens_t          # picked up by tokenize() / forward() for the encoder's first block
         return tokens, T
 
-    def _spatial(self, transformer, x2d, B, T, to_temporal=False, as_t=False):
+    def _spatial(self, transformer, x2d, B, T, to_temporal=False, as_t=False, xt=None):
         """rows '(b t) (h w)'.  to_temporal: the final norm_out writes its rows as '(b h w) t' (cvivit.py:468) so the
         temporal transformer needs no transpose pass; as_t: return the rows in the GEMM operand type."""
         h, w = self.patch_height_width
@@ -189,18 +192,25 @@ class CViViT(PackedModule):
         bias = self.spatial_rel_pos_bias(h, w)
         out_t = torch.empty((x2d.shape[0], x2d.shape[1]), device=x2d.device, dtype=L.tdtype(dt)) if as_t else None
         return transformer.run(x2d, B * T, h * w, dt, video_shape=(B, T, h, w), attn_bias=bias, out_t=out_t,
-                               perm=(T, h * w) if to_temporal else (0, 0))
+                               perm=(T, h * w) if to_temporal else (0, 0), xt=xt)
 
-    def _temporal(self, transformer, xt2d, B, T, skip_norm_out=False):
+    def _temporal(self, transformer, xt2d, B, T, skip_norm_out=False, want_t=False):
         """rows '(b h w) t' in, '(b t) (h w)' out (the final norm_out writes transposed, cvivit.py:472,496).
         NOTE: video_shape stays (b, t, h, w) although rows are ((b h w), t): the reference's PEG sees that
         scrambled view (cvivit.py:456,468-470) and so must we."""
         h, w = self.patch_height_width
-        return transformer.run(xt2d, B * h * w, T, compute_dtype_of(self), video_shape=(B, T, h, w), perm=(h * w, T),
-                               skip_norm_out=skip_norm_out)
+        dt = compute_dtype_of(self)
+        if want_t and ln_fold_enabled(dt):
+            # the final norm_out writes its rows twice: f32 (residual stream of the next transformer) and bf16 (its first GEMM operand)
+            out = torch.empty_like(xt2d)
+            out_t = torch.empty(xt2d.shape, device=xt2d.device, dtype=L.tdtype(dt))
+            transformer.run(xt2d, B * h * w, T, dt, video_shape=(B, T, h, w), perm=(h * w, T), out=out, out_t=out_t)
+            return out, out_t
+        out = transformer.run(xt2d, B * h * w, T, dt, video_shape=(B, T, h, w), perm=(h * w, T), skip_norm_out=skip_norm_out)
+        return (out, None) if want_t else out
 
-    def _encode2d(self, tokens2d, B, T, skip_norm_out=False):
-        x = self._spatial(self.enc_spatial_transformer, tokens2d, B, T, to_temporal=True)
+    def _encode2d(self, tokens2d, B, T, skip_norm_out=False, xt=None):
+        x = self._spatial(self.enc_spatial_transformer, tokens2d, B, T, to_temporal=True, xt=xt)
         return self._temporal(self.enc_temporal_transformer, x, B, T, skip_norm_out=skip_norm_out)
 
     def _decode2d(self, tokens2d, B, T):
@@ -209,8 +219,8 @@ class CViViT(PackedModule):
         hw0 = self.image_num_tokens
         D0 = tokens2d.shape[-1]
         xt = tokens2d.view(B, T, hw0, D0).transpose(1, 2).contiguous().view(B * hw0 * T, D0)    # 'b t h w d -> (b h w) t d'
-        x = self._temporal(self.dec_temporal_transformer, xt, B, T)
-        x = self._spatial(self.dec_spatial_transformer, x, B, T, as_t=True)
+        x, x_t = self._temporal(self.dec_temporal_transformer, xt, B, T, want_t=True)
+        x = self._spatial(self.dec_spatial_transformer, x, B, T, as_t=True, xt=x_t)
         h, w = self.patch_height_width
         hw = h * w
         ph, pw = self.patch_size
@@ -268,16 +278,17 @@ class CViViT(PackedModule):
     def tokenize(self, video, return_proj=False):
         """ids (B, T', h, w) int64 [and the pre-sign LFQ projection (B, n, cd), used by the parity margin audit]."""
         tokens, T = self._patch_embed(video)
+        tokens_t = self.__dict__.pop('_pk_tokens_t', None)
         B = video.shape[0]
         h, w = self.patch_height_width
         if self.lookup_free_quantization and self.vq.codebook_dim <= 16:
             # the encoder's last LayerNorm (rows '(b h w) t' -> '(b t) (h w)') and the quantizer in one launch
-            x = self._encode2d(tokens, B, T, skip_norm_out=True)
+            x = self._encode2d(tokens, B, T, skip_norm_out=True, xt=tokens_t)
             r = self.vq.encode_ids_from_prenorm(x, self.enc_temporal_transformer.norm_out, perm=(h * w, T), return_proj=return_proj)
             if return_proj:
                 return r[0].view(B, T, h, w), r[1].view(B, T * h * w, -1)
             return r.view(B, T, h, w)
-        tokens = self._encode2d(tokens, B, T)
+        tokens = self._encode2d(tokens, B, T, xt=tokens_t)
         if return_proj:
             assert self.lookup_free_quantization, 'the pre-sign projection exists for LFQ only'
             ids, proj = self.vq.encode_ids(tokens, return_proj=True)

@@ -14,6 +14,13 @@ pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
 
+@pytest.fixture(scope='module', autouse=True)
+def _oracle_follows_product_ln_fold():
+    """the bf16 oracle rounds where the product rounds: LayerNorm folded into the consuming GEMM unless PK_LN_FOLD=0"""
+    from phenaki_pytorch_amd import attention
+    O.LN_FOLD, O.LN_FOLD_FF = attention._LN_FOLD, attention._LN_FOLD_FF
+
+
 @pytest.fixture(scope='module')
 def L():
     from phenaki_pytorch_amd import _lib
@@ -598,3 +605,67 @@ def test_qkv_attn_fused_short_sequences(L, S, n, causal, with_bias, heads):
     close(fused.view(S, n, D), ref, 3e-3, f'fused qkv+attn S={S} n={n} (bf16-vs-f32 gap {gap:.1e})')
     close(fused, split, 3e-3, 'fused vs pk_qkv_project + pk_attn_fwd')
     assert torch.isfinite(fused).all()
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('M,N,K,geglu', [(300, 192, 128, False), (1000, 512, 512, False), (700, 2736, 512, True), (129, 64, 1368, False)])
+def test_gemm_layernorm_fold_and_bf16_copy(L, mode, M, N, K, geglu):
+    """pk_gemm_ex with ln_s / ln_t: LN(x) W^T = rstd * (x (gamma.W)^T - mean * s) + t from the A tiles' own statistics, against
+    the same expression in torch (operands rounded as the MFMAs see them) and against the plain LayerNorm + Linear; C2 = the
+    bf16 copy of an f32 result (the next block's operand)."""
+    from torch import nn
+    from phenaki_pytorch_amd import attention as A
+    dt = L.F32 if mode == 'f32' else L.BF16
+    td = L.tdtype(dt)
+    cast = (lambda t: t) if mode == 'f32' else bf
+    x = torch.randn(M, K, generator=g(70)) * 1.3 + 0.4
+    gamma, beta = 1 + 0.2 * torch.randn(K, generator=g(71)), 0.1 * torch.randn(K, generator=g(72))
+    W = torch.randn(N, K, generator=g(73)) / math.sqrt(K)
+    owner = nn.Linear(1, 1)
+    Wd, gd, bd = W.cuda(), gamma.cuda(), beta.cuda()
+    wg, s, t, beta_zero = A.folded_weight(owner, 'k', lambda: Wd, gd, bd, dt, [gd])
+    assert not beta_zero and wg.dtype == td and wg.shape[0] == N
+    xb = cast(x)
+    mean = xb.mean(-1, keepdim=True)
+    rstd = 1 / torch.sqrt((xb * xb).mean(-1, keepdim=True) - mean * mean + 1e-5)
+    wgr = cast(W * gamma)
+    ref = rstd * (xb @ wgr.t() - mean * wgr.sum(-1)) + W @ beta
+    true = F.layer_norm(x, (K,), gamma, beta) @ W.t()
+    close(ref, true, 1e-4 if mode == 'f32' else 3e-2, 'folded expression vs LayerNorm + Linear')
+    if geglu:
+        ref = F.gelu(ref[:, 1::2]) * ref[:, 0::2]
+        C = torch.full((M, N // 2), float('nan'), device='cuda', dtype=td)
+        L.gemm(dt, x.cuda().to(td), wg, M, N, K, C=C, act=L.ACT_GEGLU, ln=(s, t, 1e-5))
+        close(C.float(), cast(ref), 2e-5 if mode == 'f32' else 8e-3, f'ln-folded geglu gemm {mode}')
+        return
+    res = torch.randn(M, N, generator=g(74))
+    C = torch.full((M, N), float('nan'), device='cuda')
+    C2 = torch.full((M, N), float('nan'), device='cuda', dtype=torch.bfloat16) if mode == 'bf16' else None
+    L.gemm(dt, x.cuda().to(td), wg, M, N, K, C=C, res=res.cuda(), ln=(s, t, 1e-5), C2=C2)
+    close(C, ref + res, 3e-5, f'ln-folded gemm {mode} {M}x{N}x{K}')
+    if C2 is not None:
+        assert torch.equal(C2.float(), bf(C.cpu()).cuda()), 'C2 must be the bf16 rounding of C'
+    # plain GEMM with a bf16 copy (the to_out / FF2 producers)
+    if mode == 'bf16':
+        C3 = torch.empty(M, N, device='cuda')
+        C4 = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+        L.gemm(dt, x.cuda().to(td), pack := A.pack_linear_weight(Wd, dt), M, N, K, C=C3, res=res.cuda(), C2=C4)
+        close(C3, xb @ bf(W).t() + res, 3e-5, 'gemm + C2')
+        assert torch.equal(C4.float(), bf(C3.cpu()).cuda())
+
+
+def test_peg_and_embed_bf16_copies(L):
+    B, T, H, W, D = 2, 3, 4, 8, 64
+    x = torch.randn(B * T * H * W, D, generator=g(80))
+    wt, bias = torch.randn(27, D, generator=g(81)) * 0.1, torch.randn(D, generator=g(82)) * 0.1
+    out, out_t = torch.empty_like(x, device='cuda'), torch.empty(x.shape, device='cuda', dtype=torch.bfloat16)
+    L.peg(x.cuda(), wt.cuda(), bias.cuda(), out, B, T, H, W, D, True, out_t=out_t)
+    out2 = torch.empty_like(x, device='cuda')
+    L.peg(x.cuda(), wt.cuda(), bias.cuda(), out2, B, T, H, W, D, True)
+    assert torch.equal(out, out2) and torch.equal(out_t.float(), bf(out.cpu()).cuda())
+    V, n, S = 50, 12, 3
+    tok, pos = torch.randn(V, D, generator=g(83)), torch.randn(32, D, generator=g(84))
+    ids = torch.randint(0, V, (S, n), generator=g(85))
+    e, e_t = torch.empty(S * n, D, device='cuda'), torch.empty(S * n, D, device='cuda', dtype=torch.bfloat16)
+    L.embed(ids.cuda(), tok.cuda(), pos.cuda(), e, S, n, D, out_t=e_t)
+    assert torch.equal(e.cpu(), (tok[ids] + pos[:n]).reshape(S * n, D)) and torch.equal(e_t.float(), bf(e.cpu()).cuda())

@@ -17,6 +17,13 @@ from tests.util import (argmax_equal_with_margin, close, gumbel_noisy, ids_equal
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
+
+@pytest.fixture(scope='module', autouse=True)
+def _oracle_follows_product_ln_fold():
+    """the bf16 oracle rounds where the product rounds: LayerNorm folded into the consuming GEMM unless PK_LN_FOLD=0"""
+    from phenaki_pytorch_amd import attention
+    O.LN_FOLD, O.LN_FOLD_FF = attention._LN_FOLD, attention._LN_FOLD_FF
+
 # Tolerances.  fp32 mode is held to the north star directly: ids bit-exact (LFQ sign bits and gumbel argmax audited by the
 # oracle's own decision margin), logits / pixels 1e-3 relative.
 # bf16 mode (the mode bench.py times) is compared with the oracle run in ITS precision -- oracle.precision('bf16') rounds at the
