@@ -207,6 +207,13 @@ class KernelProfiler:
         if name == 'qkv_project':
             xq, xkv, wq, wkv, S, nseq, h, K = a[:8]
             return f'qkv_project_kernel[n={nseq}]', 'mfma', 2.0 * S * nseq * K * 64 * h * (3 if xkv is not None else 1)
+        if name == 'qkv_attn':
+            xq, xkv, wq, wkv, S, n, h, K = a[:8]
+            return f'qkv_attn_kernel[n={n}]', 'mfma', 2.0 * S * n * K * 192 * h + 4.0 * S * h * n * n * 64
+        if name == 'q_attn_cached':
+            xq, wq, S, n, h, K = a[:6]
+            n_kv, nnull = a[11], a[12]
+            return f'q_attn_cached_kernel[nk={n_kv + nnull}]', 'mfma', 2.0 * S * n * K * 64 * h + 4.0 * S * h * n * (n_kv + nnull) * 64
         if name == 'attn_fwd':
             dtype, Qp, Kp, Vt, O, S, h, nq, n_kv, nnull = a[:10]
             return f'attn_fwd[nq={nq},nk={n_kv + nnull}]', 'mfma', 4.0 * S * h * nq * (n_kv + nnull) * 64
@@ -263,7 +270,7 @@ class KernelProfiler:
         self._lib = _lib
         self._orig = {}
         prof = self
-        names = ['gemm', 'qkv_project', 'attn_fwd', 'attn_small', 'vocab_sample', 'layernorm', 'layernorm_lfq', 'patchify_ln',
+        names = ['gemm', 'qkv_project', 'qkv_attn', 'q_attn_cached', 'attn_fwd', 'attn_small', 'vocab_sample', 'layernorm', 'layernorm_lfq', 'patchify_ln',
                  'unpatchify', 'peg', 'lfq_encode', 'lfq_decode', 'embed', 'cfg_mix', 'critic_head', 'attn_prep', 'vocab_reduce',
                  'topk_mask', 'l2norm_rows']
 

@@ -139,6 +139,13 @@ int pk_qkv_attn(const void* xq, const void* xkv, int ld, const void* wq, const v
                 const float* q_scale, const float* k_scale, float scale, const float* bias, long bias_hstride, int bias_ld,
                 const float* slopes, int causal, void* O, int ldo, const float* q_ln_s, void* stream);
 
+/* Cross-attention against CACHED key / value images (the step-invariant text context, attention.py:142-182 with context) in ONE launch:
+ * to_q (+ the folded LayerNorm, q_ln_s as in pk_qkv_project) + l2norm + softmax(q k^T (+ key mask)) v.  Kp / Vt are the images
+ * pk_attn_prep wrote for nnull + n_kv <= 64 keys (nk_pad from pk_attn_pads); n % 64 == 0; kmask [S][n_kv] uint8 or NULL; O bf16. */
+int pk_q_attn_cached(const void* xq, int ld, const void* wq, int ldw, int S, int n, int h, int K, const float* q_scale, float scale,
+                     const float* q_ln_s, const void* Kp, const void* Vt, int nk_pad, int n_kv, int nnull,
+                     const unsigned char* kmask, void* O, int ldo, void* stream);
+
 /* attention.py:157-182: softmax(sim + bias (+ key mask, + ALiBi, causal)) @ v, heads merged: O[(s,i)][hh*64 + d].
  * bias[hh][i][j] is over the real (non-null) keys; kmask [S][n_kv] uint8 (1 = keep); slopes [h] with causal. */
 int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void* Vt, const float* bias, long bias_hstride,

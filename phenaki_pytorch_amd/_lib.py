@@ -40,6 +40,7 @@ SIGNATURES = {
     'pk_attn_prep': [_I, _P, _I, _P, _I, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'pk_qkv_project': [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _P],
     'pk_qkv_attn': [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _L, _I, _P, _I, _P, _I, _P, _P],
+    'pk_q_attn_cached': [_P, _I, _P, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P],
     'pk_attn_fwd': [_I, _P, _P, _P, _P, _L, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'pk_attn_small': [_P, _I, _P, _I, _P, _P, _F, _P, _L, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     'pk_cfg_mix': [_P, _I, _I, _I, _I, _P, _I, _F, _I, _P, _I, _I, _I, _P],
@@ -236,6 +237,13 @@ def qkv_attn(xq, xkv, wq, wkv, S, n, h, K, q_scale, k_scale, scale, O, *, bias=N
                             f32p(k_scale, 'k_scale'), scale, f32p(bias, 'attention bias'), bh, bld, f32p(slopes, 'ALiBi slopes'),
                             1 if causal else 0, ptr(O), O.stride(-2), ptr(q_ln_s), stream(xq))
     _check(rc, 'pk_qkv_attn')
+
+
+def q_attn_cached(xq, wq, S, n, h, K, q_scale, scale, Kp, Vt, nk_pad, n_kv, nnull, O, *, kmask=None, q_ln_s=None):
+    """O (S*n, h*64) bf16 <- cross-attention of the rows of xq against the cached K^ / V^T images (one launch; n % 64 == 0, <= 64 keys)"""
+    rc = load().pk_q_attn_cached(ptr(xq), xq.stride(-2), ptr(wq), wq.stride(0), S, n, h, K, f32p(q_scale, 'q_scale'), scale, ptr(q_ln_s),
+                                 ptr(Kp), ptr(Vt), nk_pad, n_kv, nnull, ptr(kmask), ptr(O), O.stride(-2), stream(xq))
+    _check(rc, 'pk_q_attn_cached')
 
 
 def attn_fwd(dtype, Qp, Kp, Vt, O, S, h, nq, n_kv, nnull, *, bias=None, kmask=None, slopes=None, causal=False):

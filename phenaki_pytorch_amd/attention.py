@@ -357,6 +357,8 @@ class ContinuousPositionBias(PackedModule):
 
 # PK_QKV_ATTN=0: keep pk_qkv_project + pk_attn_fwd for short sequences too (A/B timing of the fused kernel)
 _SHORT_FUSED = os.environ.get('PK_QKV_ATTN', '1') != '0'
+# PK_CROSS_FUSED=0: cross-attention against the cached context keeps pk_qkv_project + pk_attn_fwd (A/B timing of pk_q_attn_cached)
+_CROSS_FUSED = os.environ.get('PK_CROSS_FUSED', '1') != '0'
 
 
 class Attention(PackedModule):
@@ -451,6 +453,11 @@ class Attention(PackedModule):
                               Qp, Kp, Vt, nq_pad, nk_pad, q_ln_s=sq)
             elif cached is not None:
                 Kp, Vt = cached                       # step-invariant context: only the query side is projected again
+                if _CROSS_FUSED and n % 64 == 0 and nnull + n_kv <= 64:
+                    # few keys (the text context): query projection + attention against the cached images in ONE launch
+                    o = torch.empty((M, inner), device=dev, dtype=td)
+                    L.q_attn_cached(xt, wq, S, n, h, D, self.q_scale, float(self.scale), Kp, Vt, nk_pad, n_kv, nnull, o, kmask=kmask, q_ln_s=sq)
+                    return self._finish(o, x2d, dtype, want_t)
                 L.qkv_project(xt, None, wq, None, S, n, h, D, self.q_scale, None, float(self.scale), Qp, None, None, nq_pad, nk_pad, q_ln_s=sq)
             else:
                 q = torch.empty((M, inner), device=dev, dtype=torch.float32)

@@ -33,6 +33,46 @@ using QaTile = GemmDma<bf16, 1, 4, 4, 1, 2, 128>;          // 64 rows x 64 colum
 __device__ __forceinline__ int qa_kperm(int f, int i) { return (f >> 1) * 32 + (i >> 2) * 8 + (f & 1) * 4 + (i & 3); }
 __device__ __forceinline__ int qa_ksw(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
 
+// q^ rows of one 64-row tile of head hh -> Qs [row][64] bf16 (16-B slot ^ (row & 7)); p.A / p.W / p.N / strides set by the caller
+__device__ __forceinline__ void qa_project_q(const GemmOperands& p, int M, int m0, int hh, int K, const float* q_scale, float scale,
+                                             const float* q_ln_s, char* smem, char* Qs) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
+    const int rq = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 16 + lr;
+    f32x4 acc[1][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0, 0, 0, 0};
+    if (q_ln_s) {                                                   // LayerNorm folded into to_q; the l2norm cancels rstd: row mean and s suffice
+        float rsum[1], rsq[1];
+        (void)QaTile::run_stats<1>(p, M, m0, hh * 64, smem, acc, rsum, rsq);
+        const float mean = rsum[0] / (float)K;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(q_ln_s + hh * 64 + j * 16 + g * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[0][j][r] -= mean * s4[r];
+        }
+    } else {
+        (void)QaTile::run(p, M, m0, hh * 64, smem, acc);
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ss += acc[0][j][r] * acc[0][j][r];
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    const float inv = scale / fmaxf(sqrtf(ss), 1e-12f);              // F.normalize eps = 1e-12
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(q_scale + j * 16 + g * 4);
+        f32x4 v = acc[0][j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= inv * sc[r];
+        const int slot = (2 * j + (g >> 1)) ^ (rq & 7);
+        *reinterpret_cast<u32x2*>(Qs + rq * 128 + (slot << 4) + (g & 1) * 8) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    }
+}
+
 __global__ __launch_bounds__(256) void qkv_attn_kernel(const QkvAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];       // [ring 32 KB | Qs 8 KB | Ks 8 KB]; V^T reuses the ring
     char* Qs = smem + QaTile::SMEM;
@@ -58,42 +98,8 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(const QkvAttnArgs a) {
     p.plain_map = 0; p.krot = 0;
 
     // ---- q^ = l2norm(LN(x) Wq^T) * q_scale * scale  -> Qs [row][64] bf16, 16-B slot ^ (row & 7)
-    {
-        f32x4 acc[1][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0, 0, 0, 0};
-        p.A = a.xq; p.W = a.wq; p.N = a.h * 64;
-        if (a.q_ln_s) {                                                 // l2norm cancels rstd: only the row mean and s are needed
-            float rsum[1], rsq[1];
-            (void)QaTile::run_stats<1>(p, M, m0, hh * 64, smem, acc, rsum, rsq);
-            const float mean = rsum[0] / (float)a.K;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.q_ln_s + hh * 64 + j * 16 + g * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[0][j][r] -= mean * s4[r];
-            }
-        } else {
-            (void)QaTile::run(p, M, m0, hh * 64, smem, acc);
-        }
-        float ss = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ss += acc[0][j][r] * acc[0][j][r];
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
-        const float inv = a.scale / fmaxf(sqrtf(ss), 1e-12f);          // F.normalize eps = 1e-12
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.q_scale + j * 16 + g * 4);
-            f32x4 v = acc[0][j];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= inv * sc[r];
-            const int slot = (2 * j + (g >> 1)) ^ (rq & 7);
-            *reinterpret_cast<u32x2*>(Qs + rq * 128 + (slot << 4) + (g & 1) * 8) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-        }
-    }
+    p.A = a.xq; p.W = a.wq; p.N = a.h * 64;
+    qa_project_q(p, M, m0, hh, a.K, a.q_scale, a.scale, a.q_ln_s, smem, Qs);
     // ---- k^ = l2norm(x Wk^T) * k_scale -> Ks [key][64] bf16, slot ^ qa_ksw(key)
     {
         f32x4 acc[1][4];
@@ -219,6 +225,123 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(const QkvAttnArgs a) {
     for (int df = 0; df < 4; ++df) store4(orow + df * 16 + g * 4, o[df] * inv);
 }
 
+// ---- cross-attention against CACHED keys / values (the step-invariant text context of MaskGit / TokenCritic, attention.py:142-182
+// with context; <= 64 keys incl. the null keys): to_q (+ folded LayerNorm) + l2norm + softmax(q k^T) v in ONE launch.  Replaces
+// pk_qkv_project (query side) + pk_attn_fwd: Qp (9.4 MB at 2 x 8 x 576 rows) is neither written nor read, one launch per layer and
+// step goes.  A workgroup = 64 consecutive rows of one sequence (n % 64 == 0) x one head; K^ / V^T of that (sequence, head) come from
+// the images pk_attn_prep left ([S][h][nk_pad][64], [S][h][64][nk_pad]).
+struct QAttnCachedArgs {
+    const void* xq; const void* wq; int ld, ldw;
+    int S, n, h, K;
+    const float* q_scale; float scale; const float* q_ln_s;
+    const void* Kp; const void* Vt; int nk_pad, nk, nnull;
+    const unsigned char* kmask; int n_kv;     // [S][n_kv] over the real keys (1 = keep) or null
+    void* O; int ldo;
+};
+
+template <bool NK64>
+__global__ __launch_bounds__(256) void q_attn_cached_kernel(const QAttnCachedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // [ring 32 KB | Qs 8 KB | Ks 8 KB]; V^T reuses the ring
+    char* Qs = smem + QaTile::SMEM;
+    char* Ks = Qs + 8192;
+    char* Vts = smem;
+    const int M = a.S * a.n;
+    const int tiles = M / 64;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int tile = (idx / a.h) * 8 + xcd, hh = idx % a.h;
+    if (tile >= tiles) return;
+    const int m0 = tile * 64;
+    const int s = m0 / a.n;
+    const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rq = wave * 16 + lr;
+
+    GemmOperands p;
+    p.a_rows = nullptr;
+    p.lda = a.ld; p.ldw = a.ldw;
+    p.M = M; p.K = a.K;
+    p.plain_map = 0; p.krot = 0;
+    p.A = a.xq; p.W = a.wq; p.N = a.h * 64;
+    qa_project_q(p, M, m0, hh, a.K, a.q_scale, a.scale, a.q_ln_s, smem, Qs);      // its main loop ends with a barrier: the ring is dead
+
+    // K^ [key][64] -> Ks (slot ^ qa_ksw(key)), V^T [dim][keys] -> Vts (64-key rows of 128 B, slot ^ (dim & 7)); keys >= nk_pad: zeros
+    {
+        const size_t sh = (size_t)s * a.h + hh;
+        const int row = threadIdx.x >> 2, part = threadIdx.x & 3;          // 64 rows x 4 parts of 2 slots (32 B)
+        const u32x4 zero = u32x4{0, 0, 0, 0};
+        const bf16* krow = reinterpret_cast<const bf16*>(a.Kp) + (sh * a.nk_pad + row) * 64;
+        const bf16* vrow = reinterpret_cast<const bf16*>(a.Vt) + (sh * 64 + row) * a.nk_pad;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int slot = part * 2 + q;
+            const u32x4 kv = row < a.nk_pad ? *reinterpret_cast<const u32x4*>(krow + slot * 8) : zero;
+            *reinterpret_cast<u32x4*>(Ks + row * 128 + ((slot ^ qa_ksw(row)) << 4)) = kv;
+            const u32x4 vv = slot * 8 < a.nk_pad ? *reinterpret_cast<const u32x4*>(vrow + slot * 8) : zero;     // nk_pad % 32 == 0
+            *reinterpret_cast<u32x4*>(Vts + row * 128 + ((slot ^ (row & 7)) << 4)) = vv;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    constexpr int NF = NK64 ? 4 : 2;                              // 16-key blocks that can hold real keys
+    Frag<bf16> fq[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) fq[c].v = *reinterpret_cast<const u32x4*>(Qs + rq * 128 + (((c * 4 + g) ^ (rq & 7)) << 4));
+    f32x4 st[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        st[f] = f32x4{0, 0, 0, 0};
+        const int krow = qa_kperm(f, lr);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            Frag<bf16> fk;
+            fk.v = *reinterpret_cast<const u32x4*>(Ks + krow * 128 + (((c * 4 + g) ^ qa_ksw(krow)) << 4));
+            st[f] = mma(fk, fq[c], st[f]);
+        }
+    }
+    const unsigned char* km = a.kmask ? a.kmask + (size_t)s * a.n_kv : nullptr;
+    float pr[4 * NF];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kk = qa_kperm(f, g * 4 + r);
+            float sv = st[f][r];
+            if (kk >= a.nk) sv = -INFINITY;                                           // tile padding: weight 0 exactly
+            else if (km && kk >= a.nnull && !km[kk - a.nnull]) sv = NEG_MAX;          // masked_fill(~mask, -finfo.max), attention.py:164-168
+            pr[f * 4 + r] = sv;
+            mx = fmaxf(mx, sv);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float ls = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4 * NF; ++e) { pr[e] = __expf(pr[e] - mx); ls += pr[e]; }
+    ls += __shfl_xor(ls, 16, 64);
+    ls += __shfl_xor(ls, 32, 64);
+    f32x4 o[4];
+#pragma unroll
+    for (int df = 0; df < 4; ++df) o[df] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int kc = 0; kc < NF / 2; ++kc) {
+        Frag<bf16> fp;
+        fp.v = u32x4{pack_bf2(pr[kc * 8 + 0], pr[kc * 8 + 1]), pack_bf2(pr[kc * 8 + 2], pr[kc * 8 + 3]),
+                     pack_bf2(pr[kc * 8 + 4], pr[kc * 8 + 5]), pack_bf2(pr[kc * 8 + 6], pr[kc * 8 + 7])};
+#pragma unroll
+        for (int df = 0; df < 4; ++df) {
+            const int d = df * 16 + lr;
+            Frag<bf16> fv;
+            fv.v = *reinterpret_cast<const u32x4*>(Vts + d * 128 + (((kc * 4 + g) ^ (d & 7)) << 4));
+            o[df] = mma(fv, fp, o[df]);
+        }
+    }
+    const float inv = 1.0f / ls;
+    bf16* orow = reinterpret_cast<bf16*>(a.O) + (size_t)(m0 + rq) * a.ldo + hh * 64;
+#pragma unroll
+    for (int df = 0; df < 4; ++df) store4(orow + df * 16 + g * 4, o[df] * inv);
+}
+
 }  // namespace pk
 using namespace pk;
 
@@ -248,6 +371,31 @@ extern "C" int pk_qkv_attn(const void* xq, const void* xkv, int ld, const void* 
     const int tiles = (S + a.spt - 1) / a.spt;
     dim3 grid(8 * ((tiles + 7) / 8) * h);
     hipLaunchKernelGGL(qkv_attn_kernel, grid, dim3(256), QaTile::SMEM + 16384, reinterpret_cast<hipStream_t>(stream), a);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+// bf16 only.  Cross-attention of S sequences of n tokens (n % 64 == 0) against cached K^ / V^T images of nk = nnull + n_kv <= 64 keys
+// (layouts of pk_attn_prep with nk_pad = pk_attn_pads(...)): O [S*n][ldo] bf16 <- softmax(l2norm(xq Wq^T) K^^T) V, heads merged.
+// kmask [S][n_kv] uint8 over the real keys or NULL; q_ln_s: LayerNorm folded into to_q (xq = the un-normalised rows) or NULL.
+extern "C" int pk_q_attn_cached(const void* xq, int ld, const void* wq, int ldw, int S, int n, int h, int K, const float* q_scale,
+                                float scale, const float* q_ln_s, const void* Kp, const void* Vt, int nk_pad, int n_kv, int nnull,
+                                const unsigned char* kmask, void* O, int ldo, void* stream) {
+    if (!xq || !wq || !q_scale || !Kp || !Vt || !O || S <= 0 || n <= 0 || (n & 63) || h <= 0 || K <= 0 || n_kv <= 0 || nnull < 0) return PK_EINVAL;
+    const int nk = nnull + n_kv;
+    if (nk > 64 || nk_pad < nk || nk_pad > 64 || (nk_pad & 31)) return PK_EINVAL;
+    auto mis = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) != 0; };
+    if ((K & 7) || (ld & 7) || (ldw & 7) || (ldo & 3) || mis(xq) || mis(wq) || mis(q_scale) || mis(Kp) || mis(Vt) ||
+        (reinterpret_cast<uintptr_t>(O) & 7) || (q_ln_s && mis(q_ln_s))) return PK_EALIGN;
+    if (ldw < (K + 63) / 64 * 64) return PK_EINVAL;
+    const long M = (long)S * n;
+    if ((size_t)M * ld * 2 >= 0xFFFFFFF0ull || (size_t)h * 64 * ldw * 2 >= 0xFFFFFFF0ull) return PK_EINVAL;
+    QAttnCachedArgs a{xq, wq, ld, ldw, S, n, h, K, q_scale, scale, q_ln_s, Kp, Vt, nk_pad, nk, nnull, kmask, n_kv, O, ldo};
+    const int tiles = (int)(M / 64);
+    dim3 grid(8 * ((tiles + 7) / 8) * h);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (nk_pad > 32) hipLaunchKernelGGL((q_attn_cached_kernel<true>), grid, dim3(256), QaTile::SMEM + 16384, st, a);
+    else hipLaunchKernelGGL((q_attn_cached_kernel<false>), grid, dim3(256), QaTile::SMEM + 16384, st, a);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

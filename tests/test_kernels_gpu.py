@@ -669,3 +669,38 @@ def test_peg_and_embed_bf16_copies(L):
     e, e_t = torch.empty(S * n, D, device='cuda'), torch.empty(S * n, D, device='cuda', dtype=torch.bfloat16)
     L.embed(ids.cuda(), tok.cuda(), pos.cuda(), e, S, n, D, out_t=e_t)
     assert torch.equal(e.cpu(), (tok[ids] + pos[:n]).reshape(S * n, D)) and torch.equal(e_t.float(), bf(e.cpu()).cuda())
+
+
+@pytest.mark.parametrize('S,n,n_ctx,masked', [(3, 64, 13, True), (2, 192, 40, True), (2, 128, 62, False), (4, 64, 1, False)])
+def test_cross_attention_cached_fused(L, S, n, n_ctx, masked):
+    """pk_q_attn_cached (query projection + attention against the cached context K / V in one launch) through the product
+    Attention module: first call fills the cache (pk_attn_prep path), second call takes the fused kernel; both against the oracle
+    in bf16 precision, incl. the CFG null branch (every text key masked: only the null keys remain)."""
+    from phenaki_pytorch_amd import attention as A
+    D, heads, dc = 128, 2, 96
+    torch.manual_seed(200 + n_ctx)
+    att = A.Attention(dim=D, heads=heads, num_null_kv=2, dim_context=dc)
+    with torch.no_grad():
+        att.q_scale.add_(0.1 * torch.randn(64))
+        att.k_scale.add_(0.1 * torch.randn(64))
+        att.norm.gamma.add_(0.1 * torch.randn(D))
+        att.context_norm.gamma.add_(0.1 * torch.randn(dc))
+    sd = {'a.' + k: v.detach().clone() for k, v in att.state_dict().items()}
+    att = att.cuda().eval()
+    x = torch.randn(S, n, D, generator=g(9 + n)) * 1.5 + 0.2
+    ctx = torch.randn(S, n_ctx, dc, generator=g(10 + n))
+    mask = torch.ones(S, n_ctx, dtype=torch.bool)
+    if masked:
+        mask[1, n_ctx // 2:] = False
+        mask[-1, :] = False
+    with O.precision('bf16'):
+        ref = O.attention(sd, 'a.', x, heads=heads, context=ctx, mask=mask)
+    xg = x.reshape(S * n, D).cuda()
+    cache = {}
+    kw = dict(context2d=ctx.reshape(-1, dc).cuda(), n_ctx=n_ctx, kmask=mask.to(torch.uint8).cuda(), kv_cache=cache)
+    first = att.run(xg, S, n, L.BF16, **kw) - xg
+    assert len(cache) == 1
+    fused = att.run(xg, S, n, L.BF16, **kw) - xg
+    close(first.view(S, n, D), ref, 3e-3, 'cross-attention, cache-filling call')
+    close(fused.view(S, n, D), ref, 3e-3, f'fused cached cross-attention n={n} n_ctx={n_ctx}')
+    close(fused, first, 3e-3, 'fused vs unfused')
