@@ -32,6 +32,7 @@ struct GemmOperands {
     int M, N, K;
     int plain_map;      // 1: row-major tile order (A/B benchmarking only); 0: XCD-aware tile map (DMA kernels)
     int krot;           // 1: workgroup b walks the k-tiles starting at tile (b >> 3) % nt (DMA kernels; see gemm_dma.hpp)
+    int w_gap_from, w_gap_rows;   // DMA kernels: tile rows >= w_gap_from of W read global row n0 + row + w_gap_rows (two row ranges, one tile)
 };
 
 template <typename T, typename TA> struct RawSlot;                    // one thread's 16-B LDS slot, pre-conversion

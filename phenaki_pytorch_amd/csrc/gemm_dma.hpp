@@ -134,7 +134,7 @@ struct GemmDma {
 #pragma unroll
         for (int i = 0; i < IW; ++i) {
             const int row = (wave * IW + i) * RPI + lrow;
-            const int gn = n0 + row;
+            const int gn = n0 + row + ((p.w_gap_from > 0 && row >= p.w_gap_from) ? p.w_gap_rows : 0);
             offW[i] = gn < p.N ? (uint32_t)gn * (uint32_t)p.ldw * SZ + srcslot * 16 : bytesW;
         }
 

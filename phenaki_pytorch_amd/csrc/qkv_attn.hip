@@ -7,7 +7,8 @@
 // attention MFMAs read (the same images, rounding points and fragment reads as pk_qkv_project + pk_attn_fwd, which this replaces for
 // n <= 64: Qp / Kp / Vt never reach HBM -- the V^T scatter alone made the n = 9 projection 20 us -- and one launch per layer goes).
 // Sequences sharing a tile are kept apart by a block-diagonal mask (other sequences' keys get weight exp(-inf) = 0 exactly).
-// Three 64 x 64 x K GEMMs run back to back on one 2-stage ring (32 KB) + 16 KB of q^ / k^ staging: 48 KB, 3 workgroups per CU.
+// Two GEMM passes over the rows (q: 64 x 64 x K; k|v: 64 x 128 x K) on one 2-stage ring whose dead stages also stage q^ / k^ / v^T:
+// 48 KB, 3 workgroups per CU.
 // Roofline: MFMA (2 * R * 192 * K flops per workgroup) -- in practice bound by the L1 -> LDS fill rate like every short-K GEMM here.
 #include "gemm_dma.hpp"
 
@@ -28,6 +29,8 @@ struct QkvAttnArgs {
 };
 
 using QaTile = GemmDma<bf16, 1, 4, 4, 1, 2, 128>;          // 64 rows x 64 columns (one head), 4 waves stacked on the rows
+using QaKvTile = GemmDma<bf16, 1, 8, 4, 1, 2, 128>;        // 64 rows x 128 columns: the head's k | v columns in ONE pass over x
+constexpr int QA_SMEM = QaKvTile::SMEM;                   // 48 KB: the ring of the k|v pass; q^ / k^ / v^T staging aliases it
 
 // K tile rows permuted / swizzled exactly like pk_attn_fwd's LDS kernel (attn.hip): see attn_kperm / attn_ksw there
 __device__ __forceinline__ int qa_kperm(int f, int i) { return (f >> 1) * 32 + (i >> 2) * 8 + (f & 1) * 4 + (i & 3); }
@@ -74,10 +77,12 @@ __device__ __forceinline__ void qa_project_q(const GemmOperands& p, int M, int m
 }
 
 __global__ __launch_bounds__(256) void qkv_attn_kernel(const QkvAttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];       // [ring 32 KB | Qs 8 KB | Ks 8 KB]; V^T reuses the ring
-    char* Qs = smem + QaTile::SMEM;
-    char* Ks = Qs + 8192;
-    char* Vts = smem;
+    // LDS: ONE 48 KB ring.  q pass (32 KB of it) -> q^ staged in the dead ring -> each lane pulls its two q^ fragments into 8 VGPRs ->
+    // k|v pass (48 KB) -> k^ and v^T staged in the dead ring -> attention.  48 KB per workgroup: 3 workgroups per CU.
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;
+    char* Ks = smem;
+    char* Vts = smem + 8192;
     // block -> (row tile, head): the 8 heads of a row tile run on ONE XCD (block b is observed on XCD b % 8; speed only), so the
     // two A tiles they all read are fetched over the fabric once
     const int R = a.spt * a.n;
@@ -96,17 +101,27 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(const QkvAttnArgs a) {
     p.lda = a.ld; p.ldw = a.ldw;
     p.M = M; p.K = a.K;
     p.plain_map = 0; p.krot = 0;
+    p.w_gap_from = 0; p.w_gap_rows = 0;
 
-    // ---- q^ = l2norm(LN(x) Wq^T) * q_scale * scale  -> Qs [row][64] bf16, 16-B slot ^ (row & 7)
+    // ---- q^ = l2norm(LN(x) Wq^T) * q_scale * scale  -> Qs [row][64] bf16 (16-B slot ^ (row & 7)) -> this lane's fragments
     p.A = a.xq; p.W = a.wq; p.N = a.h * 64;
     qa_project_q(p, M, m0, hh, a.K, a.q_scale, a.scale, a.q_ln_s, smem, Qs);
-    // ---- k^ = l2norm(x Wk^T) * k_scale -> Ks [key][64] bf16, slot ^ qa_ksw(key)
-    {
-        f32x4 acc[1][4];
+    Frag<bf16> fq[2];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // a wave reads only rows its own lanes wrote
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0, 0, 0, 0};
+    for (int c = 0; c < 2; ++c) fq[c].v = *reinterpret_cast<const u32x4*>(Qs + rq * 128 + (((c * 4 + g) ^ (rq & 7)) << 4));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                      // every wave holds its q^ : the ring may be refilled
+
+    // ---- k | v = x [Wk ; Wv]^T of head hh in one pass (tile columns 0..63 = k, 64..127 = v: wkv rows hh*64 + c and (h + hh)*64 + c - 64)
+    {
+        f32x4 acc[1][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[0][j] = f32x4{0, 0, 0, 0};
         p.A = a.xkv; p.W = a.wkv; p.N = 2 * a.h * 64;
-        (void)QaTile::run(p, M, m0, hh * 64, smem, acc);
+        p.w_gap_from = 64; p.w_gap_rows = (a.h - 1) * 64;
+        (void)QaKvTile::run(p, M, m0, hh * 64, smem, acc);              // ends with a barrier: the ring is dead
+        // k^ = l2norm(k) * k_scale -> Ks [key][64] bf16, slot ^ qa_ksw(key)
         float ss = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -124,29 +139,19 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(const QkvAttnArgs a) {
             const int slot = (2 * j + (g >> 1)) ^ qa_ksw(rq);
             *reinterpret_cast<u32x2*>(Ks + rq * 128 + (slot << 4) + (g & 1) * 8) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
         }
-    }
-    // ---- v = x Wv^T -> V^T [dim][64 keys] bf16 in the (now dead) ring, slot ^ (dim & 7)
-    {
-        f32x4 acc[1][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0, 0, 0, 0};
-        p.A = a.xkv; p.W = a.wkv; p.N = 2 * a.h * 64;
-        (void)QaTile::run(p, M, m0, (a.h + hh) * 64, smem, acc);         // run() ends with a barrier: every wave is done with the ring
+        // v -> V^T [dim][64 keys] bf16, slot ^ (dim & 7)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int d = j * 16 + g * 4 + r;
-                *reinterpret_cast<u16*>(Vts + d * 128 + ((((rq >> 3) ^ (d & 7))) << 4) + (rq & 7) * 2) = f2bf(acc[0][j][r]);
+                *reinterpret_cast<u16*>(Vts + d * 128 + ((((rq >> 3) ^ (d & 7))) << 4) + (rq & 7) * 2) = f2bf(acc[0][4 + j][r]);
             }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     // ---- attention of this wave's 16 query rows against the 64 keys of the tile (block-diagonal over the tile's sequences)
-    Frag<bf16> fq[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) fq[c].v = *reinterpret_cast<const u32x4*>(Qs + rq * 128 + (((c * 4 + g) ^ (rq & 7)) << 4));
     f32x4 st[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) st[f] = f32x4{0, 0, 0, 0};
@@ -261,6 +266,7 @@ __global__ __launch_bounds__(256) void q_attn_cached_kernel(const QAttnCachedArg
     p.lda = a.ld; p.ldw = a.ldw;
     p.M = M; p.K = a.K;
     p.plain_map = 0; p.krot = 0;
+    p.w_gap_from = 0; p.w_gap_rows = 0;
     p.A = a.xq; p.W = a.wq; p.N = a.h * 64;
     qa_project_q(p, M, m0, hh, a.K, a.q_scale, a.scale, a.q_ln_s, smem, Qs);      // its main loop ends with a barrier: the ring is dead
 
@@ -370,7 +376,7 @@ extern "C" int pk_qkv_attn(const void* xq, const void* xkv, int ld, const void* 
     if (q_ln_s && mis(q_ln_s)) return PK_EALIGN;
     const int tiles = (S + a.spt - 1) / a.spt;
     dim3 grid(8 * ((tiles + 7) / 8) * h);
-    hipLaunchKernelGGL(qkv_attn_kernel, grid, dim3(256), QaTile::SMEM + 16384, reinterpret_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(qkv_attn_kernel, grid, dim3(256), QA_SMEM, reinterpret_cast<hipStream_t>(stream), a);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }
