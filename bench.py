@@ -173,9 +173,9 @@ def capture(fn):
 # ------------------------------------------------------------------------------------------ per-kernel rooflines
 
 # template order: T, TM, TN, WM, WN, STAGES, ROWB, PW (the names rocprofv3 prints)
-VARIANT_KERNEL = {1: 'gemm_kernel<T,TA,2,2>', 2: 'gemm_kernel<T,TA,4,4>', 3: 'gemm_dma_kernel<T,2,2,2,2,4,128,0>',
-                  8: 'gemm_dma_kernel<T,2,2,2,2,2,128,0>', 9: 'gemm_dma_kernel<T,4,4,2,2,2,128,0>',
-                  24: 'gemm_dma_kernel<T,4,2,2,4,2,128,0>', 33: 'gemm_dma_kernel<T,2,2,2,2,3,128,2>'}
+VARIANT_KERNEL = {1: 'gemm_kernel<T,TA,2,2>', 2: 'gemm_kernel<T,TA,4,4>', 3: 'gemm_dma_kernel<T,2,2,2,2,4,128,0,false>',
+                  8: 'gemm_dma_kernel<T,2,2,2,2,2,128,0,false>', 9: 'gemm_dma_kernel<T,4,4,2,2,2,128,0,false>',
+                  24: 'gemm_dma_kernel<T,4,2,2,4,2,128,0,false>', 33: 'gemm_dma_kernel<T,2,2,2,2,3,128,2,false>'}
 
 
 def _esz(t):
@@ -203,6 +203,8 @@ class KernelProfiler:
             v = kw.get('variant') or lib.load().pk_gemm_auto_variant(dtype, a_is_f32, M, N, K, kw.get('lda') or A.stride(-2), W.stride(0), rows)
             t = 'pk::bf16' if dtype == lib.BF16 else 'float'
             label = VARIANT_KERNEL.get(v, f'gemm variant{v}').replace('TA', 'float' if a_is_f32 else t).replace('T', t)
+            if kw.get('ln'):                                  # LayerNorm-folded instantiation: 64x64 or 128x128 by the same size rule
+                label = (VARIANT_KERNEL[24] if v in (24, 2, 9) else VARIANT_KERNEL[8]).replace('T', t).replace('false', 'true')
             return label, 'mfma', 2.0 * M * N * K
         if name == 'qkv_project':
             xq, xkv, wq, wkv, S, nseq, h, K = a[:8]
