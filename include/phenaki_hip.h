@@ -150,7 +150,11 @@ int pk_q_attn_cached(const void* xq, int ld, const void* wq, int ldw, int S, int
  * bias[hh][i][j] is over the real (non-null) keys; kmask [S][n_kv] uint8 (1 = keep); slopes [h] with causal. */
 int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void* Vt, const float* bias, long bias_hstride,
                 int bias_ld, const unsigned char* kmask, const float* slopes, int causal, void* O, int ldo,
-                int out_is_f32, int S, int h, int nq, int n_kv, int nnull, void* stream);
+                int out_is_f32, int S, int h, int nq, int n_kv, int nnull, const float* bias_tab, int tab_len,
+                const int* pos_code, int code_off, void* stream);
+/* bias_tab ([h][tab_len] f32, or NULL; then bias must be NULL): the relative-position form of the continuous position bias
+ * (attention.py:229-275), bias[hh][i][j] = bias_tab[hh][pos_code[i] - pos_code[j] + code_off] with pos_code [n] int32 -- staged
+ * in LDS by the bf16 kernel for nq = n_kv >= 64 (self-attention, no null keys / mask / causal); other shapes: PK_EINVAL. */
 
 /* attention.py:128-182 for short self-attention sequences (n <= 64, no null keys: the C-ViViT spatial / temporal layers)
  * straight from the projection outputs q [S*n][ldq], kv [S*n][ldkv]: one launch instead of pk_attn_prep + pk_attn_fwd;

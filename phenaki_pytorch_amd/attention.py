@@ -309,6 +309,24 @@ class AlibiPositionalBias(nn.Module):
         return pow2_slopes(c) + pow2_slopes(2 * c)[0::2][:heads - c]
 
 
+class BiasSpec:
+    """an attention bias that is a ContinuousPositionBias of a grid: the consumers pick the form they can use"""
+
+    def __init__(self, module, dims):
+        self.module, self.dims = module, dims
+
+    @property
+    def full(self):
+        return self.module(*self.dims)
+
+    def table(self):
+        return self.module.table(*self.dims)
+
+
+def _full_bias(b):
+    return b.full if isinstance(b, BiasSpec) else b
+
+
 class ContinuousPositionBias(PackedModule):
     """attention.py:229-275 : MLP over log-spaced relative positions -> (heads, n, n).
     The MLP always runs in exact f32 (the reference forces rel_pos.float()), and the result is cached per
@@ -331,6 +349,34 @@ class ContinuousPositionBias(PackedModule):
         params = list(self.parameters())
         L.require_device(params[0], 'ContinuousPositionBias parameters')
         return _cache(self).get(('bias', tuple(dimensions)), params, lambda: self._compute(dimensions))
+
+    def spec(self, *dimensions):
+        """lazy handle: .full is forward(*dimensions); .table() its relative-position form for the LDS attention kernel"""
+        return BiasSpec(self, tuple(dimensions))
+
+    def table(self, *dimensions):
+        """(tab (heads, L) f32, pos_code (n,) int32, offset): bias[h][i][j] == tab[h][pos_code[i] - pos_code[j] + offset].
+        The bias depends on (i, j) only through the relative grid position (attention.py:257-272), so the (heads, n, n) matrix --
+        10.6 MB at (9, 8, 8), re-read by every (sequence, head) of every attention launch -- collapses to prod(2 d - 1) = 3 825
+        values per head.  Built ONCE per (weights, dims) by scattering the exact entries of the full matrix (bit-identical values)."""
+        params = list(self.parameters())
+
+        def build():
+            dims = tuple(dimensions)
+            full = self._compute(dims)                                    # (heads, n, n), not kept
+            dev = full.device
+            grids = torch.meshgrid(*[torch.arange(d, device=dev) for d in dims], indexing='ij')
+            strides, acc = [], 1
+            for d in reversed(dims):
+                strides.insert(0, acc)
+                acc *= 2 * d - 1
+            code = sum(g.reshape(-1) * st for g, st in zip(grids, strides))                  # (n,) mixed-radix position code
+            off = sum((d - 1) * st for d, st in zip(dims, strides))
+            idx = (code[:, None] - code[None, :] + off).reshape(-1)
+            tab = torch.zeros((full.shape[0], acc), device=dev, dtype=torch.float32)
+            tab[:, idx] = full.reshape(full.shape[0], -1)
+            return tab.contiguous(), code.to(torch.int32).contiguous(), int(off)
+        return _cache(self).get(('table', tuple(dimensions)), params, build)
 
     def _compute(self, dims):
         dev = self.net[0][0].weight.device
@@ -359,6 +405,8 @@ class ContinuousPositionBias(PackedModule):
 _SHORT_FUSED = os.environ.get('PK_QKV_ATTN', '1') != '0'
 # PK_CROSS_FUSED=0: cross-attention against the cached context keeps pk_qkv_project + pk_attn_fwd (A/B timing of pk_q_attn_cached)
 _CROSS_FUSED = os.environ.get('PK_CROSS_FUSED', '1') != '0'
+# PK_BIAS_TABLE=0: the n >= 64 attention kernel streams the full (heads, n, n) position bias instead of its relative-position table
+_BIAS_TABLE = os.environ.get('PK_BIAS_TABLE', '1') != '0' and os.environ.get('PK_ATTN_LDS', '1') != '0'
 
 
 class Attention(PackedModule):
@@ -431,6 +479,13 @@ class Attention(PackedModule):
         n_kv = n_ctx if is_cross else n
         slopes = self.rel_pos_bias.slopes if self.causal else None
         cached = kv_cache.get(id(self)) if (kv_cache is not None and is_cross) else None
+        # a position bias given as a BiasSpec reaches the bf16 LDS attention kernel (n >= 64 keys and queries, no null keys / mask /
+        # causal) as a 15 KB relative-position table instead of the (heads, n, n) matrix; every other consumer takes the matrix
+        bias_table = None
+        if (isinstance(attn_bias, BiasSpec) and _BIAS_TABLE and dtype == L.BF16 and not is_cross and nnull == 0 and n >= 64 and
+                not (_SHORT_FUSED and n <= 64) and kmask is None and not self.causal):
+            bias_table, attn_bias = attn_bias.table(), None
+        attn_bias = _full_bias(attn_bias)
 
         fq = self._folded_q(dtype) if ln_fold_enabled(dtype) else None
         if fq is not None:
@@ -469,7 +524,8 @@ class Attention(PackedModule):
                 if kv_cache is not None and is_cross:
                     kv_cache[id(self)] = (Kp, Vt)
             o = torch.empty((M, inner), device=dev, dtype=td)
-            L.attn_fwd(dtype, Qp, Kp, Vt, o, S, h, n, n_kv, nnull, bias=attn_bias, kmask=kmask, slopes=slopes, causal=self.causal)
+            L.attn_fwd(dtype, Qp, Kp, Vt, o, S, h, n, n_kv, nnull, bias=attn_bias, kmask=kmask, slopes=slopes, causal=self.causal,
+                       bias_table=bias_table)
             return self._finish(o, x2d, dtype, want_t)
 
         # ---- separate LayerNorm launch (exact-f32 mode; bf16 with PK_LN_FOLD=0)
@@ -530,7 +586,8 @@ class Attention(PackedModule):
             Kp, Vt = cached      # step-invariant context: only the query side is prepared again
             L.attn_prep(dtype, q, None, self.null_kv, self.q_scale, self.k_scale, float(self.scale), Qp, None, None, S, h, n, n_kv, nnull)
         o = torch.empty((M, inner), device=dev, dtype=td)
-        L.attn_fwd(dtype, Qp, Kp, Vt, o, S, h, n, n_kv, nnull, bias=attn_bias, kmask=kmask, slopes=slopes, causal=self.causal)
+        L.attn_fwd(dtype, Qp, Kp, Vt, o, S, h, n, n_kv, nnull, bias=attn_bias, kmask=kmask, slopes=slopes, causal=self.causal,
+                   bias_table=bias_table)
         return self._finish(o, x2d, dtype, want_t)
 
     def forward(self, x, mask=None, context=None, attn_bias=None):

@@ -114,6 +114,11 @@ struct AttnArgs {
     void* O; int ldo; int out_f32;                         // O[(s*nq + i)][hh*64 + d]
     int S, h, nq, n_kv, nnull, nq_pad, nk_pad, causal;
     int bias_vec;                                          // bias rows are 16-byte loadable (nnull == 0, aligned strides)
+    // relative-position bias as a TABLE (LDS-staged kernel only): bias[hh][i][j] = bias_tab[hh][pos_code[i] - pos_code[j] + code_off].
+    // The continuous position bias of the reference (attention.py:229-275) depends on (i, j) only through the relative grid
+    // position: (2T-1)(2H-1)(2W-1) = 3825 distinct values per head at (9, 8, 8) -- 15 KB in LDS instead of a 1.33 MB f32 stream per
+    // (sequence, head) through L2 (170 MB per launch at 16 x 8: the n = 576 kernel ran 37 us with the stream, 9 us without a bias)
+    const float* bias_tab; int tab_len; const int* pos_code; int code_off;
 };
 
 __device__ __forceinline__ void load_vt(Frag<bf16>& f, const bf16* row, int kb, int g) {
@@ -342,10 +347,16 @@ __device__ __forceinline__ void lds_frag_vt(Frag<bf16>& f, const char* tile, int
 // instead of every wave pulling fragment-shaped pieces (16 rows x 64 B per instruction) through the texture path.
 typedef __attribute__((address_space(3))) void* attn_lds_ptr;
 
-template <int QF, bool PF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (PF ? 4 : 5) : 3))) void attn_fwd_lds_kernel(const AttnArgs p, uint32_t kv_bytes) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];          // 2 stages x (K 8 KB | V^T 8 KB)
+// STAGES: depth of the K / V^T ring.  With 2 stages a workgroup has ONE tile in flight while it computes the other and every
+// iteration waits out most of an LDS-DMA round trip (~1.1 us vs ~0.4 us of work per tile); deeper rings (only without the vector
+// bias stream: a counted vmcnt must see nothing but the DMA pieces) keep STAGES - 1 tiles in flight behind a counted s_waitcnt.
+template <int QF, bool PF, bool TAB = false, int STAGES = 2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (PF ? 4 : ((TAB || STAGES > 2) ? 3 : 5)) : 3))) void attn_fwd_lds_kernel(const AttnArgs p, uint32_t kv_bytes) {
+    static_assert(STAGES == 2 || !PF, "the deep ring counts vmcnt: no other vector loads may be in flight in the loop");
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // STAGES x (K 8 KB | V^T 8 KB) [| bias table | position codes]
     constexpr int STAGE = 16384;
+    float* tab = reinterpret_cast<float*>(smem + STAGES * STAGE);         // TAB: this head's bias table, then the position codes of all keys
+    int* codes = reinterpret_cast<int*>(smem + STAGES * STAGE + ((p.tab_len * 4 + 15) & ~15));
     const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int qblocks = (p.nq_pad + 64 * QF - 1) / (64 * QF);
@@ -400,6 +411,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
     int qrow[QF];
 #pragma unroll
     for (int qf = 0; qf < QF; ++qf) { const int qi = q0 + qf * 16 + lr; qrow[qf] = qi < p.nq ? qi : p.nq - 1; }
+    int cq[QF];                                                            // TAB: position code of the lane's query row(s) + offset
+    if (TAB) {
+        const float* src = p.bias_tab + (size_t)hh * p.tab_len;
+        for (int i = threadIdx.x; i < p.tab_len; i += 256) tab[i] = src[i];
+        for (int i = threadIdx.x; i < p.n_kv; i += 256) codes[i] = p.pos_code[i];
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) cq[qf] = p.pos_code[qrow[qf]] + p.code_off;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // visible to every wave after the first barrier of the loop
+    }
 
     const int ntiles = (p.nk_pad + 63) / 64;
     // additive-bias vectors (16 B per lane per 4 keys, straight from global) are requested ONE TILE AHEAD: used right
@@ -413,17 +433,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
     };
     f32x4 bz[QF][4];
     if (PF && active && vb_all && 64 <= nk) load_bz(bz, 0);
-    issue(0, 0);
+    if (STAGES > 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // table / code / q loads retired: from here only DMA pieces count
+#pragma unroll
+    for (int s0 = 0; s0 < STAGES - 1; ++s0)
+        if (s0 < ntiles) issue(s0 * 64, s0);
     for (int t = 0; t < ntiles; ++t) {
         const int kb = t * 64;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (STAGES == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else {
+            // tiles issued so far: min(ntiles, t + STAGES - 1); all but tile t may stay in flight (4 DMA pieces per wave per tile)
+            const int ahead = (t + STAGES - 1 < ntiles ? t + STAGES - 1 : ntiles) - (t + 1);
+            if (ahead >= 2 && STAGES > 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();                     // tile t landed for all waves; everyone finished tile t-1
-        if (t + 1 < ntiles) issue(kb + 64, (t + 1) & 1);
+        if (t + STAGES - 1 < ntiles) issue(kb + (STAGES - 1) * 64, (t + STAGES - 1) % STAGES);
         if (kb + 64 > nk) {
             // tail tile (wave-uniform, at most once per workgroup): the V^T columns of keys >= nk carry p = 0 but may hold anything
             // (pk_qkv_project never writes them; 0 * NaN = NaN) -> zero them in the LDS image, all 256 threads, one extra barrier.
             // (Masking the fragments in registers instead cost 13 VGPRs and spilled the main loop.)
-            char* vz = smem + (t & 1) * STAGE + 8192;
+            char* vz = smem + (t % STAGES) * STAGE + 8192;
             const int d = threadIdx.x >> 2, k0 = (threadIdx.x & 3) * 16;
             for (int kk = k0; kk < k0 + 16; ++kk)
                 if (kb + kk >= nk) *reinterpret_cast<u16*>(vz + d * 128 + ((((kk >> 3) ^ (d & 7))) << 4) + (kk & 7) * 2) = 0;
@@ -431,7 +461,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
             __builtin_amdgcn_s_barrier();
         }
         if (!active) continue;
-        const char* kt = smem + (t & 1) * STAGE;
+        const char* kt = smem + (t % STAGES) * STAGE;
         const char* vt = kt + 8192;
         const bool simple = (kb + 64 <= nk) && !km && !p.causal;
         const bool vbias = vb_all && simple;
@@ -463,17 +493,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
 #pragma unroll
                 for (int f = 0; f < 4; ++f) st[qf][f] += bz[qf][f];
             }
+            if (TAB && simple) {
+                // whole tile of real keys: the lane's 4 keys of block f are consecutive -> their position codes are ONE 16-byte LDS read
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const u32x4 ck = *reinterpret_cast<const u32x4*>(codes + kb + attn_kperm(f, g * 4));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[qf][f][r] += tab[cq[qf] - (int)ck[r]];
+                }
+            }
 #pragma unroll
             for (int f = 0; f < 4; ++f)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float sv = st[qf][f][r];
-                    if (!plain) {
+                    if (!(plain || (TAB && simple))) {
                         const int key = kb + attn_kperm(f, g * 4 + r);
                         const int j = key - p.nnull;
                         if (key >= nk) sv = -INFINITY;
                         else {
-                            if (bias && j >= 0 && qi < p.nq) sv += bias[(size_t)qi * p.bias_ld + j];
+                            if (TAB) { if (j >= 0 && qi < p.nq) sv += tab[cq[qf] - codes[j]]; }
+                            else if (bias && j >= 0 && qi < p.nq) sv += bias[(size_t)qi * p.bias_ld + j];
                             bool masked = km && j >= 0 && !km[j];
                             if (p.causal && j >= 0) {
                                 const int dj = j - (qi + coff);
@@ -698,12 +738,15 @@ extern "C" int pk_attn_prep(int dtype, const float* q, int ldq, const float* kv,
 extern "C" int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void* Vt,
                            const float* bias, long bias_hstride, int bias_ld, const unsigned char* kmask,
                            const float* slopes, int causal, void* O, int ldo, int out_is_f32,
-                           int S, int h, int nq, int n_kv, int nnull, void* stream) {
+                           int S, int h, int nq, int n_kv, int nnull, const float* bias_tab, int tab_len, const int* pos_code,
+                           int code_off, void* stream) {
     if (!Qp || !Kp || !Vt || !O || S <= 0 || h <= 0) return PK_EINVAL;
+    if (bias_tab && (bias || !pos_code || tab_len <= 0 || nnull != 0 || nq != n_kv || causal || kmask)) return PK_EINVAL;
     if (ldo & 3) return PK_EALIGN;
     int nq_pad, nk_pad;
     if (int rc = pk_attn_pads(nq, n_kv, nnull, &nq_pad, &nk_pad)) return rc;
-    AttnArgs a{Qp, Kp, Vt, bias, bias_hstride, bias_ld, kmask, slopes, O, ldo, out_is_f32, S, h, nq, n_kv, nnull, nq_pad, nk_pad, causal, 0};
+    AttnArgs a{Qp, Kp, Vt, bias, bias_hstride, bias_ld, kmask, slopes, O, ldo, out_is_f32, S, h, nq, n_kv, nnull, nq_pad, nk_pad, causal, 0,
+               bias_tab, tab_len, pos_code, code_off};
     a.bias_vec = (bias && nnull == 0 && (bias_ld & 3) == 0 && (bias_hstride & 3) == 0 &&
                   (reinterpret_cast<uintptr_t>(bias) & 15) == 0) ? 1 : 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -727,6 +770,33 @@ extern "C" int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void
         const int qblocks = (nq_pad + 64 * qf - 1) / (64 * qf);
         const uint32_t kv_bytes = (uint32_t)((size_t)S * h * nk_pad * 128);
         dim3 g2((unsigned)(S * h * qblocks));
+        // deep ring: only where no vector bias stream shares the vmcnt counter (no bias, or the relative-position table)
+        static const int stages_env = [] { const char* e = getenv("PK_ATTN_STAGES"); return e ? atoi(e) : 0; }();   // tuning knob
+        const int ntl = (nk_pad + 63) / 64;
+        const bool no_stream = bias_tab || !(bias && a.bias_vec && !kmask && !causal);
+        int stages = stages_env ? stages_env : 2;      // measured at n = 576, S*h = 128 (tools/attn_bias_bench.py): 2 stages 32.7 us, 3: 35.1, 4: 43.3 -- the loop is not DMA-latency bound
+        if (!no_stream || ntl < 3 || stages < 2 || stages > 4) stages = 2;
+        const size_t lds = (size_t)stages * 16384 + (bias_tab ? (((size_t)tab_len * 4 + 15) & ~(size_t)15) + (((size_t)n_kv * 4 + 15) & ~(size_t)15) : 0);
+        if (lds > 65536) return PK_EINVAL;
+#define PK_ATTN_DEEP(QFV, TABV, STV) hipLaunchKernelGGL((attn_fwd_lds_kernel<QFV, false, TABV, STV>), g2, block, lds, s, a, kv_bytes)
+        if (stages > 2) {
+            if (qf == 2) {
+                if (bias_tab) { if (stages == 3) PK_ATTN_DEEP(2, true, 3); else PK_ATTN_DEEP(2, true, 4); }
+                else { if (stages == 3) PK_ATTN_DEEP(2, false, 3); else PK_ATTN_DEEP(2, false, 4); }
+            } else {
+                if (bias_tab) { if (stages == 3) PK_ATTN_DEEP(1, true, 3); else PK_ATTN_DEEP(1, true, 4); }
+                else { if (stages == 3) PK_ATTN_DEEP(1, false, 3); else PK_ATTN_DEEP(1, false, 4); }
+            }
+            PK_CHECK_LAUNCH();
+            return PK_OK;
+        }
+#undef PK_ATTN_DEEP
+        if (bias_tab) {
+            if (qf == 2) hipLaunchKernelGGL((attn_fwd_lds_kernel<2, false, true>), g2, block, lds, s, a, kv_bytes);
+            else hipLaunchKernelGGL((attn_fwd_lds_kernel<1, false, true>), g2, block, lds, s, a, kv_bytes);
+            PK_CHECK_LAUNCH();
+            return PK_OK;
+        }
         if (qf == 2) {
             if (pf) hipLaunchKernelGGL((attn_fwd_lds_kernel<2, true>), g2, block, 32768, s, a, kv_bytes);
             else hipLaunchKernelGGL((attn_fwd_lds_kernel<2, false>), g2, block, 32768, s, a, kv_bytes);
@@ -737,6 +807,7 @@ extern "C" int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void
         PK_CHECK_LAUNCH();
         return PK_OK;
     }
+    if (bias_tab) return PK_EINVAL;                       // the table form exists in the LDS-staged kernel only
     if (dtype == 1) {
         if (QF == 4) hipLaunchKernelGGL((attn_fwd_kernel<bf16, 4>), grid, block, 0, s, a);
         else if (QF == 2) hipLaunchKernelGGL((attn_fwd_kernel<bf16, 2>), grid, block, 0, s, a);

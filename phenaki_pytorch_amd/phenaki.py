@@ -154,7 +154,7 @@ class MaskGit(_TokenTrunk):
         if exists(text_mask) and null_rows and text_mask.dtype != torch.uint8:
             text_mask = text_mask.clone()
             text_mask[S - null_rows:] = False
-        bias = self.continuous_pos_bias(*video_patch_shape)
+        bias = self.continuous_pos_bias.spec(*video_patch_shape)       # matrix or relative-position table, as each attention launch can use
         return self._trunk(x, video_patch_shape, context=context, text_mask=text_mask, video_mask=video_mask,
                            attn_bias=bias, use_cross=not self.unconditional, kv_cache=kv_cache, replicas=replicas,
                            ids_prime=ids_prime)

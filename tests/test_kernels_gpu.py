@@ -704,3 +704,29 @@ def test_cross_attention_cached_fused(L, S, n, n_ctx, masked):
     close(first.view(S, n, D), ref, 3e-3, 'cross-attention, cache-filling call')
     close(fused.view(S, n, D), ref, 3e-3, f'fused cached cross-attention n={n} n_ctx={n_ctx}')
     close(fused, first, 3e-3, 'fused vs unfused')
+
+
+@pytest.mark.parametrize('dims,S,heads', [((9, 8, 8), 2, 8), ((3, 8, 8), 3, 2), ((10, 8, 8), 1, 8), ((4, 5, 4), 2, 2)])
+def test_attention_relative_position_bias_table(L, dims, S, heads):
+    """the continuous position bias as a relative-position TABLE in LDS (pk_attn_fwd bias_tab) against the full (heads, n, n)
+    matrix streamed from memory: the table holds the matrix' own entries, so the attention outputs must be identical."""
+    from phenaki_pytorch_amd.attention import ContinuousPositionBias
+    n = dims[0] * dims[1] * dims[2]
+    torch.manual_seed(7)
+    cpb = ContinuousPositionBias(dim=64, heads=heads, num_dims=3).cuda()
+    full = cpb(*dims)
+    tab, codes, off = cpb.table(*dims)
+    assert tuple(full.shape) == (heads, n, n) and tab.shape[0] == heads and codes.dtype == torch.int32
+    idx = (codes.long()[:, None] - codes.long()[None, :] + off)
+    assert idx.min() >= 0 and idx.max() < tab.shape[1]
+    assert torch.equal(tab[:, idx], full), 'the table must reproduce every entry of the bias matrix bit for bit'
+    nq_pad, nk_pad = L.attn_pads(n, n, 0)
+    Qp = (torch.randn(S * heads * nq_pad * 64, generator=g(91)) * 0.35).cuda().to(torch.bfloat16)
+    Kp = (torch.randn(S * heads * nk_pad * 64, generator=g(92)) * 0.35).cuda().to(torch.bfloat16)
+    Vt = torch.randn(S * heads * nk_pad * 64, generator=g(93)).cuda().to(torch.bfloat16)
+    o_full = torch.empty(S * n, heads * 64, device='cuda', dtype=torch.bfloat16)
+    o_tab = torch.full_like(o_full, float('nan'))
+    L.attn_fwd(L.BF16, Qp, Kp, Vt, o_full, S, heads, n, n, 0, bias=full)
+    L.attn_fwd(L.BF16, Qp, Kp, Vt, o_tab, S, heads, n, n, 0, bias_table=(tab, codes, off))
+    assert torch.isfinite(o_tab.float()).all()
+    close(o_tab.float(), o_full.float(), 1e-6 if n % 64 == 0 else 4e-3, f'table vs matrix bias {dims}')
