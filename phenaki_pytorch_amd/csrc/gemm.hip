@@ -207,8 +207,8 @@ extern "C" int pk_gemm_auto_variant(int dtype, int a_is_f32, int M, int N, int K
     return auto_variant(dtype, a_is_f32, M, N, K, lda, ldw, a_nrows);
 }
 
-// variant: 0 = automatic; 1/2 = register-staged 64x64 / 128x128; 3/4 = DMA ring 64x64 / 128x128 (4 stages);
-//          5 = DMA 64x64 8 stages; 6 = DMA 128x128 3 stages     (explicit variants exist for tools/gemm_bench.py)
+// variant: 0 = automatic; 1/2 = register-staged 64x64 / 128x128; 8 = DMA 64x64 2 stages; 9 / 24 = DMA 128x128 (4 / 8 waves);
+//          33 = DMA 64x64 with 2 producer waves, 3 stages (bf16); 3 = DMA 64x64 4 stages (f32)   (explicit: tools/gemm_bench.py)
 extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const void* W, int ldw,
                           int M, int N, int K, const float* bias, const float* res, int ldr,
                           void* C, int ldc, int out_is_f32, int act, const int* a_rows, int a_nrows,
@@ -246,61 +246,23 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
         if (dtype == 1) return big ? launch_dma<bf16, 4, 2, 2, 2, 4, 128, 0, true>(p, e, a_nrows, s) : launch_dma<bf16, 2, 2, 2, 2, 2, 128, 0, true>(p, e, a_nrows, s);
         return big ? launch_dma<float, 4, 2, 2, 2, 4, 128, 0, true>(p, e, a_nrows, s) : launch_dma<float, 2, 2, 2, 2, 2, 128, 0, true>(p, e, a_nrows, s);
     }
+    // the main-loop variants that survived round 1's sweep (profiles/gemm_variants*_r01.txt; the 35 losers -- deeper rings, k-tile 32,
+    // 128x256 / 256x256 tiles, other wave layouts, other producer / consumer splits -- were deleted in round 2)
     if (dtype == 1) {
         switch (variant) {
-            case 1: return a_is_f32 ? launch_v1<bf16, float, 2, 2>(p, e, s) : launch_v1<bf16, bf16, 2, 2>(p, e, s);
-            case 2: return a_is_f32 ? launch_v1<bf16, float, 4, 4>(p, e, s) : launch_v1<bf16, bf16, 4, 4>(p, e, s);
-            case 3: return launch_dma<bf16, 2, 2, 4>(p, e, a_nrows, s);
-            case 4: return launch_dma<bf16, 4, 4, 4>(p, e, a_nrows, s);
-            case 5: return launch_dma<bf16, 2, 2, 8>(p, e, a_nrows, s);
-            case 6: return launch_dma<bf16, 4, 4, 3>(p, e, a_nrows, s);
-            case 7: return launch_dma<bf16, 2, 2, 3>(p, e, a_nrows, s);
-            case 8: return launch_dma<bf16, 2, 2, 2>(p, e, a_nrows, s);
-            case 9: return launch_dma<bf16, 4, 4, 2>(p, e, a_nrows, s);
-            case 10: return launch_dma<bf16, 4, 2, 3>(p, e, a_nrows, s);
-            case 11: return launch_dma<bf16, 2, 4, 3>(p, e, a_nrows, s);
-            case 12: return launch_dma<bf16, 4, 2, 4>(p, e, a_nrows, s);
-            case 13: return launch_dma<bf16, 4, 2, 3, 2, 4>(p, e, a_nrows, s);     // 128x128, 8 waves (2x4), wave tile 64x32
-            case 14: return launch_dma<bf16, 2, 4, 3, 4, 2>(p, e, a_nrows, s);     // 128x128, 8 waves (4x2), wave tile 32x64
-            case 15: return launch_dma<bf16, 4, 2, 4, 2, 4>(p, e, a_nrows, s);     // 128x128, 8 waves, 4 stages
-            case 16: return launch_dma<bf16, 4, 4, 2, 2, 4>(p, e, a_nrows, s);     // 128x256, 8 waves (2x4), 2 stages (96 KB)
-            case 17: return launch_dma<bf16, 4, 4, 3, 2, 4>(p, e, a_nrows, s);     // 128x256, 8 waves, 3 stages (144 KB)
-            case 18: return launch_dma<bf16, 4, 4, 2, 2, 2, 64>(p, e, a_nrows, s);  // 128x128, k-tile 32, 2 stages (32 KB: 5 WG/CU)
-            case 19: return launch_dma<bf16, 4, 4, 3, 2, 2, 64>(p, e, a_nrows, s);  // 128x128, k-tile 32, 3 stages (48 KB: 3 WG/CU)
-            case 20: return launch_dma<bf16, 4, 4, 4, 2, 2, 64>(p, e, a_nrows, s);  // 128x128, k-tile 32, 4 stages (64 KB: 2 WG/CU)
-            case 21: return launch_dma<bf16, 2, 2, 2, 2, 2, 64>(p, e, a_nrows, s);  // 64x64,   k-tile 32, 2 stages (16 KB)
-            case 22: return launch_dma<bf16, 4, 2, 2, 2, 2, 64>(p, e, a_nrows, s);  // 128x64,  k-tile 32, 2 stages (24 KB: 6 WG/CU)
-            case 23: return launch_dma<bf16, 4, 4, 2, 2, 4, 64>(p, e, a_nrows, s);  // 128x256, 8 waves, k-tile 32, 2 stages (48 KB)
-            case 24: return launch_dma<bf16, 4, 2, 2, 2, 4>(p, e, a_nrows, s);      // 128x128, 8 waves (2x4), 2 stages (64 KB: 16 waves/CU)
-            case 25: return launch_dma<bf16, 4, 2, 2, 2, 4, 64>(p, e, a_nrows, s);  // 128x128, 8 waves, k-tile 32, 2 stages (32 KB: 32 waves/CU)
-            case 26: return launch_dma<bf16, 2, 2, 2, 4, 4>(p, e, a_nrows, s);      // 128x128, 16 waves (4x4), 2 stages (64 KB: 32 waves/CU)
-            case 27: return launch_dma<bf16, 2, 4, 2, 4, 2>(p, e, a_nrows, s);      // 128x128, 8 waves (4x2), 2 stages (64 KB)
-            case 28: return launch_dma<bf16, 4, 4, 2, 4, 2>(p, e, a_nrows, s);      // 256x128, 8 waves (4x2), 2 stages (96 KB)
-            case 29: return launch_dma<bf16, 4, 4, 2, 4, 4, 64>(p, e, a_nrows, s);  // 256x256, 16 waves, k-tile 32, 2 stages (64 KB: 2 WG/CU)
-            case 30: return launch_dma<bf16, 4, 4, 3, 4, 4, 64>(p, e, a_nrows, s);  // 256x256, 16 waves, k-tile 32, 3 stages (96 KB)
-            // producer / consumer role split (PW producer waves feed the ring, the others only compute)
-            case 31: return launch_dma<bf16, 4, 4, 3, 2, 2, 128, 4>(p, e, a_nrows, s);  // 128x128, 4 consumers + 4 producers, 3 stages (96 KB)
-            case 32: return launch_dma<bf16, 4, 2, 3, 2, 4, 128, 4>(p, e, a_nrows, s);  // 128x128, 8 consumers + 4 producers, 3 stages
-            case 33: return launch_dma<bf16, 2, 2, 3, 2, 2, 128, 2>(p, e, a_nrows, s);  // 64x64, 4 consumers + 2 producers, 3 stages (48 KB)
-            case 34: return launch_dma<bf16, 2, 2, 3, 2, 2, 128, 1>(p, e, a_nrows, s);  // 64x64, 4 consumers + 1 producer, 3 stages
-            case 35: return launch_dma<bf16, 2, 2, 4, 2, 2, 128, 4>(p, e, a_nrows, s);  // 64x64, 4 + 4, 4 stages (64 KB)
-            case 36: return launch_dma<bf16, 4, 4, 4, 2, 2, 128, 4>(p, e, a_nrows, s);  // 128x128, 4 + 4, 4 stages (128 KB)
-            case 37: return launch_dma<bf16, 4, 4, 3, 2, 4, 128, 4>(p, e, a_nrows, s);  // 128x256, 8 consumers + 4 producers, 3 stages (144 KB)
-            case 38: return launch_dma<bf16, 4, 4, 2, 2, 2, 128, 4>(p, e, a_nrows, s);  // 128x128, 4 + 4, 2 stages (64 KB: 2 WG/CU)
-            case 39: return launch_dma<bf16, 2, 2, 2, 2, 2, 128, 2>(p, e, a_nrows, s);  // 64x64, 4 + 2, 2 stages (32 KB: 5 WG/CU)
-            case 40: return launch_dma<bf16, 4, 2, 2>(p, e, a_nrows, s);                 // 128x64, 4 waves, 2 stages (48 KB: 3 WG/CU)
-            case 41: return launch_dma<bf16, 2, 4, 2>(p, e, a_nrows, s);                 // 64x128, 4 waves, 2 stages (48 KB: 3 WG/CU)
+            case 1: return a_is_f32 ? launch_v1<bf16, float, 2, 2>(p, e, s) : launch_v1<bf16, bf16, 2, 2>(p, e, s);      // register-staged 64x64
+            case 2: return a_is_f32 ? launch_v1<bf16, float, 4, 4>(p, e, s) : launch_v1<bf16, bf16, 4, 4>(p, e, s);      // register-staged 128x128
+            case 8: return launch_dma<bf16, 2, 2, 2>(p, e, a_nrows, s);                 // 64x64, 2 stages (5 WG/CU)
+            case 9: return launch_dma<bf16, 4, 4, 2>(p, e, a_nrows, s);                 // 128x128, 4 waves, 2 stages
+            case 24: return launch_dma<bf16, 4, 2, 2, 2, 4>(p, e, a_nrows, s);          // 128x128, 8 waves (2x4), 2 stages (64 KB: 16 waves/CU)
+            case 33: return launch_dma<bf16, 2, 2, 3, 2, 2, 128, 2>(p, e, a_nrows, s);  // 64x64, 4 consumers + 2 producers, 3 stages (long K)
             default: return PK_EINVAL;
         }
     }
     switch (variant) {
         case 1: return launch_v1<float, float, 2, 2>(p, e, s);
         case 2: return launch_v1<float, float, 4, 4>(p, e, s);
-        case 3: return launch_dma<float, 2, 2, 4>(p, e, a_nrows, s);
-        case 4: return launch_dma<float, 4, 4, 4>(p, e, a_nrows, s);
-        case 5: return launch_dma<float, 2, 2, 8>(p, e, a_nrows, s);
-        case 6: return launch_dma<float, 4, 4, 3>(p, e, a_nrows, s);
-        case 7: return launch_dma<float, 2, 2, 3>(p, e, a_nrows, s);
+        case 3: return launch_dma<float, 2, 2, 4>(p, e, a_nrows, s);                    // 64x64, 4 stages (long K)
         case 8: return launch_dma<float, 2, 2, 2>(p, e, a_nrows, s);
         case 9: return launch_dma<float, 4, 4, 2>(p, e, a_nrows, s);
         case 24: return launch_dma<float, 4, 2, 2, 2, 4>(p, e, a_nrows, s);

@@ -7,8 +7,6 @@
 // An LDS-DMA writes wave-uniform base + lane*16, so the 16-B-slot XOR swizzle that makes ds_read_b128 conflict-free
 // is applied on the per-lane SOURCE address; the read side XORs the same way.
 //   ROWB = 128 (k-tile of 64 bf16 / 32 f32): slot ^ (row & 7)
-//   ROWB = 64  (k-tile of 32 bf16; half the LDS per stage -> 5 workgroups of a 128x128 tile per CU):
-//               slot ^ {0,2,3,1}[(row >> 2) & 3]   (conflict-free for the gfx950 ds_read_b128 16-lane groups)
 // Rows past M / N are fetched through the buffer descriptor's bounds check (their per-lane offset is the descriptor size:
 // they read as 0).  The K tail (K not a multiple of the k-tile) is cut the same way: in the LAST k-tile every 16-byte piece
 // that starts at or beyond K is pointed out of bounds, so A never reads into its next row (a NaN / Inf there would survive the
@@ -44,13 +42,6 @@ __device__ __forceinline__ void frag_stats(const Frag<float>& f, float& s, float
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-__device__ __forceinline__ int swz64(int rowq) { return (0x78 >> (2 * rowq)) & 3; }        // {0,2,3,1}[rowq], two bits each
-
-__device__ __forceinline__ void lds_frag64(Frag<bf16>& f, const char* tile, int row, int g) {
-    const int slot = g ^ swz64((row >> 2) & 3);
-    f.v = *reinterpret_cast<const u32x4*>(tile + row * 64 + (slot << 4));
-}
-
 // TM x TN MFMA tiles per wave, WM x WN compute waves per workgroup, ROWB bytes of k per LDS row.
 // PW = 0: every wave both feeds the ring and computes (64 * WM * WN threads).
 // PW > 0: role split -- PW extra PRODUCER waves (wave ids >= WM*WN) issue all the LDS-DMA pieces and wait for them, the
@@ -59,7 +50,7 @@ __device__ __forceinline__ void lds_frag64(Frag<bf16>& f, const char* tile, int 
 //         the consumer's MFMAs on the same SIMD (MI355X: separate waves issue independently).
 template <typename T, int TM, int TN, int WM, int WN, int STAGES, int ROWB = 128, int PW = 0>
 struct GemmDma {
-    static_assert(ROWB == 128 || (ROWB == 64 && sizeof(T) == 2), "64-byte k-tiles are built for bf16 only");
+    static_assert(ROWB == 128, "k-tile = 128 bytes per row (the 64-byte k-tile variants lost the round-1 sweep and were removed)");
     static constexpr int NW = WM * WN;
     static constexpr int BM = 16 * TM * WM, BN = 16 * TN * WN;
     static constexpr int RPI = 1024 / ROWB;                             // rows per DMA wave-instruction
@@ -121,7 +112,7 @@ struct GemmDma {
         // per-lane source offsets (bytes) at k = 0; the k-tile advance goes through the scalar offset.
         // lane -> (row within the instruction's RPI rows, 16-byte slot); the slot is swizzled on the SOURCE side
         const int lrow = lane / SLOTS, lslot = lane % SLOTS;
-        const int srcslot = ROWB == 128 ? (lslot ^ (lrow & 7)) : (lslot ^ swz64((lrow >> 2) & 3));
+        const int srcslot = lslot ^ (lrow & 7);
         uint32_t offA[IA], offW[IW];
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
@@ -179,17 +170,10 @@ struct GemmDma {
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 Frag<T> fa[TM], fw[TN];
-                if constexpr (ROWB == 128) {
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) lds_frag(fa[i], a, wm * 16 * TM + i * 16 + lr, c, g);
+                for (int i = 0; i < TM; ++i) lds_frag(fa[i], a, wm * 16 * TM + i * 16 + lr, c, g);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) lds_frag(fw[j], w, wn * 16 * TN + j * 16 + lr, c, g);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) lds_frag64(fa[i], a, wm * 16 * TM + i * 16 + lr, g);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) lds_frag64(fw[j], w, wn * 16 * TN + j * 16 + lr, g);
-                }
+                for (int j = 0; j < TN; ++j) lds_frag(fw[j], w, wn * 16 * TN + j * 16 + lr, c, g);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll

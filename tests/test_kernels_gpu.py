@@ -87,13 +87,13 @@ def test_gemm_geglu_leaky_gather_and_T_output(L, mode):
     close(C3, h[idx.long()], 2e-5, 'gather')
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9] + [('bf16only', v) for v in range(10, 42)])
+@pytest.mark.parametrize('variant', [0, 1, 2, 8, 9, 24, ('f32only', 3), ('bf16only', 33)])
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])
 @pytest.mark.parametrize('M,N,K', [(300, 200, 96), (1000, 520, 1368), (4608, 512, 512), (129, 2736, 512)])
 def test_gemm_main_loop_variants(L, variant, mode, M, N, K):
     if isinstance(variant, tuple):
-        if mode != 'bf16':
-            pytest.skip('tuning variants are instantiated for bf16 only')
+        if (variant[0] == 'bf16only') != (mode == 'bf16'):
+            pytest.skip('this main loop is instantiated for the other operand type only')
         variant = variant[1]
     """register-staged and LDS-DMA main loops (tile / ring-depth variants) agree with torch, incl. M/N/K tails, a row
     gather, and the K tail handled by W's zero padding."""
