@@ -45,11 +45,18 @@ int pk_gemm(int dtype, int a_is_f32, const void* A, int lda, const void* W, int 
  * ln_s / ln_t ([N] f32, or both NULL): the LayerNorm that precedes this nn.Linear in the reference (attention.py:47,142,
  * cvivit.py:277) folded into it -- A holds the UN-normalised rows x, W holds gamma (.) W, and the epilogue applies
  *   LN(x) W^T = rstd * (x (gamma.W)^T - mean * ln_s) + ln_t,  ln_s[n] = sum_k gamma[k] W[n][k],  ln_t[n] = sum_k beta[k] W[n][k]
- * with mean / rstd (biased variance over K, ln_eps inside the sqrt) taken from the A tiles of the main loop; then bias / act / res. */
+ * with mean / rstd (biased variance over K, ln_eps inside the sqrt) taken from the A tiles of the main loop; then bias / act / res.
+ * row_off [M] / col_off [N] (int32 element offsets, or both NULL): scattered f32 output, element (m, n) -> C[row_off[m] + col_off[n]]
+ * with col_off[n + r] = col_off[n] + r inside every aligned group of 4 columns -- the un-patchify 'b t h w (c pt p1 p2) -> b c (t pt)
+ * (h p1) (w p2)' of cvivit.py:326-334 is such a map, so to_pixels writes the video in place (no res / C2 / GEGLU with it).
+ * stats_out [M][ceil(N/32)][2] f32 (or NULL): every 32-column chunk of every output row also leaves (sum, sum of squares) of its values
+ * -- as stored in C2 when given, else in C -- for the LayerNorm-folded GEMM that reads those rows next; that GEMM passes the buffer as
+ * ln_stats [M][ceil(K/32)][2] beside ln_s / ln_t and takes mean / rstd from it instead of from its own main loop (LDS-DMA variants
+ * 8 / 24 / 33 / f32 3 only; partials are added in index order, so results do not depend on scheduling). */
 int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const void* W, int ldw, int M, int N, int K,
                const float* bias, const float* res, int ldr, void* C, int ldc, int out_is_f32, int act,
                const int* a_rows, int a_nrows, int variant, void* C2, int ldc2, const float* ln_s, const float* ln_t,
-               float ln_eps, void* stream);
+               float ln_eps, const int* row_off, const int* col_off, float* stats_out, const float* ln_stats, void* stream);
 /* the variant `0 = automatic` resolves to for a shape (host-only helper; used to label kernels in bench.py) */
 int pk_gemm_auto_variant(int dtype, int a_is_f32, int M, int N, int K, int lda, int ldw, int a_nrows);
 

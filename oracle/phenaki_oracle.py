@@ -61,12 +61,25 @@ def _lin(x, w):
 #     LN(x) W^T = rstd * (r(x) r(gamma.W)^T - mean * s) + t,   s = rowsum(r(gamma.W)),  t = W beta   (f32).
 # LN_FOLD mirrors phenaki_pytorch_amd.attention._LN_FOLD (PK_LN_FOLD=0 keeps the separate LayerNorm: rounding point r(LN(x))).
 LN_FOLD = True
-LN_FOLD_FF = False          # the feed-forward LayerNorm stays a separate launch in the product by default (PK_LN_FOLD_FF)
+LN_FOLD_FF = False          # the feed-forward LayerNorm is folded into FF1 ...
+LN_FOLD_FF_MAX_ROWS = 0     # ... for inputs of at most this many rows (0: no limit); the tests copy both from the product's settings
+_ROWS_SCALE = [1]           # the product runs the cond | null halves of a CFG step as ONE batch: its row count is twice this oracle's
+
+
+class _cfg_batch:
+    """inside: every row count the fold rule sees is doubled (the product's 2B-sequence CFG batch)"""
+    def __enter__(self):
+        _ROWS_SCALE.append(2)
+
+    def __exit__(self, *a):
+        _ROWS_SCALE.pop()
 
 
 def _ln_lin(x, gamma, beta, w, eps=1e-5, ff=False):
     """LayerNorm(x; gamma, beta) @ w^T -- in bf16 mode with the product's rounding points (see above)"""
-    if not (is_bf16() and LN_FOLD and (LN_FOLD_FF or not ff)):
+    rows = _ROWS_SCALE[-1] * (x.numel() // x.shape[-1])
+    ff_folded = LN_FOLD_FF and (LN_FOLD_FF_MAX_ROWS <= 0 or rows <= LN_FOLD_FF_MAX_ROWS)
+    if not (is_bf16() and LN_FOLD and (ff_folded or not ff)):
         return _lin(F.layer_norm(x, x.shape[-1:], gamma, beta, eps), w)
     xb = _r(x)
     mean = xb.mean(dim=-1, keepdim=True)
@@ -370,8 +383,9 @@ def maskgit_cfg(sd, cfg, ids, *, cond_scale, **kw):
         # the product mixes the 512-d trunk outputs (CFG is linear in the logits and to_logits is linear), rounds the mix to
         # bf16 and runs ONE vocab-head GEMM (csrc/sampler.hip pk_cfg_mix)
         kw = {k: v for k, v in kw.items() if k != 'return_embeds'}
-        e = maskgit_forward(sd, cfg, ids, null_cond=False, return_embeds=True, **kw)
-        en = maskgit_forward(sd, cfg, ids, null_cond=True, return_embeds=True, **kw)
+        with _cfg_batch():
+            e = maskgit_forward(sd, cfg, ids, null_cond=False, return_embeds=True, **kw)
+            en = maskgit_forward(sd, cfg, ids, null_cond=True, return_embeds=True, **kw)
         return _lin(en + (e - en) * cond_scale, sd['to_logits.weight']) + sd['to_logits.bias']
     logits = maskgit_forward(sd, cfg, ids, null_cond=False, **kw)
     if cond_scale == 1:
@@ -397,10 +411,11 @@ def critic_forward(sd, cfg, ids, *, video_patch_shape, context=None, text_mask=N
 
 def critic_cfg(sd, cfg, ids, *, cond_scale, **kw):
     """phenaki_pytorch.py:251-263"""
-    s = critic_forward(sd, cfg, ids, null_cond=False, **kw)
     if cond_scale == 1:
-        return s
-    n = critic_forward(sd, cfg, ids, null_cond=True, **kw)
+        return critic_forward(sd, cfg, ids, null_cond=False, **kw)
+    with _cfg_batch():
+        s = critic_forward(sd, cfg, ids, null_cond=False, **kw)
+        n = critic_forward(sd, cfg, ids, null_cond=True, **kw)
     return n + (s - n) * cond_scale
 
 

@@ -128,7 +128,16 @@ def linear_weight(lin, dtype):
 _LN_FOLD = os.environ.get('PK_LN_FOLD', '1') != '0'
 # the feed-forward LayerNorm stays a separate launch by default: folded, the 128x128 FF1 kernel needs mean AND rstd of every row
 # (64 v_dot2c per wave per k-tile beside its 16 MFMAs) and ran 25 -> 41 us at M = 4608 -- more than the LayerNorm launch it saves
-_LN_FOLD_FF = os.environ.get('PK_LN_FOLD_FF', '0') != '0'
+# feed-forward LayerNorm: 0 = ln_rows launch in front of FF1; 1 = folded into FF1 with in-loop statistics (measured slower: FF1 25 -> 41 us);
+# 2 = folded, statistics handed over by the to_out GEMM that wrote the rows (pk_gemm_ex stats_out -> ln_stats): no ln_rows launch.
+# Measured (same-box A/B, 2 rounds): mode 2 vs 0  encode -5 %, decode -3 %, cfg sampling (M = 4608 rows) -3 %, but B = 8 sampling
+# (M = 9216 rows: FF1 +3.6 us for the fold epilogue, ln_rows 6.3 us) +1 %  ->  the hand-over is used up to PK_LN_FOLD_FF_MAX_ROWS rows.
+_LN_FOLD_FF = int(os.environ.get('PK_LN_FOLD_FF', '2'))
+_LN_FOLD_FF_MAX_ROWS = int(os.environ.get('PK_LN_FOLD_FF_MAX_ROWS', '6144'))
+
+
+def ff_fold_mode(rows):
+    return _LN_FOLD_FF if (_LN_FOLD_FF_MAX_ROWS <= 0 or rows <= _LN_FOLD_FF_MAX_ROWS) else 0
 
 
 def ln_fold_enabled(dtype):
@@ -218,19 +227,20 @@ class FeedForwardSeq(nn.Sequential):
             return w1p
         return folded_weight(self, 'ff1_ln', w1, ln.weight, ln.bias, dtype, [lin1.weight, ln.weight, ln.bias])
 
-    def run(self, x2d, dtype, xt=None, want_t=False):
+    def run(self, x2d, dtype, xt=None, want_t=False, stats=None):
         """x2d (M, D) f32 -> ff(x) + x  (M, D) f32.  xt: the T copy of x2d (bf16 mode, LayerNorm folded into the first GEMM);
+        stats: the (M, D/32, 2) row statistics of xt its producer left (else the GEMM takes them from its own main loop);
         want_t: also return the T copy of the result for the next block -> (out, out_t)."""
         M, D = x2d.shape
         w1p, w2p, ip = self._packed(dtype)
         td = L.tdtype(dtype)
         ln = self[0]
         hmid = torch.empty((M, ip), device=x2d.device, dtype=td)
-        if ln_fold_enabled(dtype) and _LN_FOLD_FF:
+        if ln_fold_enabled(dtype) and ff_fold_mode(M):
             w1g, s1, t1, _ = self._packed_folded(dtype)
             if xt is None:
                 xt = x2d.to(td)
-            L.gemm(dtype, xt, w1g, M, 2 * ip, D, C=hmid, act=L.ACT_GEGLU, ln=(s1, t1, ln.eps))
+            L.gemm(dtype, xt, w1g, M, 2 * ip, D, C=hmid, act=L.ACT_GEGLU, ln=(s1, t1, ln.eps), ln_stats=stats)
         else:
             xn = torch.empty((M, D), device=x2d.device, dtype=td)
             L.layernorm(x2d, ln.weight, ln.bias, M, D, out=xn, eps=ln.eps)
@@ -452,11 +462,17 @@ class Attention(PackedModule):
         return kv
 
     def _finish(self, o, x2d, dtype, want_t):
-        """to_out projection + residual  [+ the bf16 copy of the result for the next block's folded LayerNorm]"""
+        """to_out projection + residual  [+ the bf16 copy of the result for the next block's folded LayerNorm; want_t == 'stats': and
+        the row statistics of that copy for a folded feed-forward LayerNorm -> (out, out_t, stats)]"""
         M, D = x2d.shape
         out = torch.empty_like(x2d)
         out_t = torch.empty((M, D), device=x2d.device, dtype=torch.bfloat16) if (want_t and dtype == L.BF16) else None
-        L.gemm(dtype, o, linear_weight(self.to_out, dtype), M, D, o.shape[1], C=out, res=x2d, C2=out_t)
+        stats = None
+        if want_t == 'stats' and out_t is not None and D % 4 == 0:
+            stats = torch.empty((M, (D + 31) // 32, 2), device=x2d.device, dtype=torch.float32)
+        L.gemm(dtype, o, linear_weight(self.to_out, dtype), M, D, o.shape[1], C=out, res=x2d, C2=out_t, stats_out=stats)
+        if want_t == 'stats':
+            return out, out_t, stats
         return (out, out_t) if want_t else out
 
     def _folded_q(self, dtype):
@@ -604,6 +620,13 @@ class Attention(PackedModule):
         return (out - x2).reshape(x.shape)
 
 
+def _unpack(r):
+    """out | (out, out_t) | (out, out_t, stats) -> (out, out_t, stats)"""
+    if not isinstance(r, tuple):
+        return r, None, None
+    return r if len(r) == 3 else (r[0], r[1], None)
+
+
 class Transformer(PackedModule):
     """attention.py:279-332 : per layer [PEG?, self Attention, cross Attention?, FeedForward], each + residual; norm_out."""
 
@@ -638,15 +661,14 @@ class Transformer(PackedModule):
                 has_cross = exists(cross_attn) and exists(context2d)
                 if exists(peg):
                     x, xt = peg.run(x, video_shape, want_t=True)
-                r = self_attn.run(x, S, n, dtype, attn_bias=attn_bias, kmask=self_attn_mask, xt=xt, want_t=has_cross or _LN_FOLD_FF)
-                x, xt = r if isinstance(r, tuple) else (r, None)
+                ff_wants = {0: False, 1: True, 2: 'stats'}[ff_fold_mode(x.shape[0])]      # what the block in front of the FF leaves for it
+                x, xt, stats = _unpack(self_attn.run(x, S, n, dtype, attn_bias=attn_bias, kmask=self_attn_mask, xt=xt,
+                                                     want_t=True if has_cross else ff_wants))
                 if has_cross:
-                    r = cross_attn.run(x, S, n, dtype, context2d=context2d, n_ctx=n_ctx, kmask=cross_attn_context_mask,
-                                       kv_cache=kv_cache, xt=xt, want_t=_LN_FOLD_FF)
-                    x, xt = r if isinstance(r, tuple) else (r, None)
+                    x, xt, stats = _unpack(cross_attn.run(x, S, n, dtype, context2d=context2d, n_ctx=n_ctx, kmask=cross_attn_context_mask,
+                                                          kv_cache=kv_cache, xt=xt, want_t=ff_wants))
                 next_reads_xt = li + 1 < nl and not exists(self.layers[li + 1][0])       # next layer starts with attention (no PEG)
-                r = ff.run(x, dtype, xt=xt, want_t=next_reads_xt)
-                x, xt = r if isinstance(r, tuple) else (r, None)
+                x, xt, _ = _unpack(ff.run(x, dtype, xt=xt, want_t=next_reads_xt, stats=stats))
                 continue
             if exists(peg):
                 x = peg.run(x, video_shape)

@@ -24,11 +24,22 @@ struct GemmEpilogue {
     //   LN(x) W^T = rstd * (x (gamma.W)^T - mean * s) + t,   s[n] = sum_k gamma[k] W[n][k],  t[n] = sum_k beta[k] W[n][k]
     // mean / rstd come from the A fragments of the main loop (GemmDma::run_stats); null ln_s: plain GEMM
     const float* ln_s; const float* ln_t; float ln_eps;
+    // scattered f32 output (vector epilogue): element (m, n) goes to C[row_off[m] + col_off[n]] instead of C[m*ldc + n]; the 4 columns a
+    // lane owns must stay contiguous (col_off[n + r] = col_off[n] + r for n % 4 == 0).  The un-patchify of cvivit.py:326-334 is exactly
+    // such a separable map, so to_pixels writes the (B, C, F, H, W) video directly and the 100 MB pixel matrix never exists.
+    const int* row_off; const int* col_off;
+    // row statistics handed from the GEMM that PRODUCES a residual-stream row to the LayerNorm-folded GEMM that consumes it, so neither an
+    // ln_rows launch nor in-loop statistics are needed: every wave writes (sum, sum of squares) of its 32 columns of row m -- of the values
+    // as the consumer will read them (the T-rounded C2 copy when there is one) -- to stats_out[m][chunk][2], chunk = column / 32; the
+    // consumer (ln_s set, ln_stats set) adds the ceil(K / 32) partials of a row in index order: deterministic, no atomics.
+    float* stats_out; const float* ln_stats; int stats_np;
 };
 
-template <typename T, int TM, int TN, int WN = 2, bool LNF = false>
-__device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[TM][TN], int M, int N, const GemmEpilogue& e, int m0, int n0,
-                                              const float* rsum = nullptr, const float* rsq = nullptr, int K = 1) {
+constexpr int STATS_CHUNK = 32;      // columns per partial: the 16 * TN columns one wave owns in every TN = 2 kernel
+
+// scalar epilogue (N not a multiple of 4, e.g. heads = 2 or a 1-wide critic head): no LayerNorm fold, C2, scatter or stats_out (host refuses)
+template <typename T, int TM, int TN, int WN>
+__device__ __forceinline__ void gemm_epilogue_scalar(const f32x4 (&acc)[TM][TN], int M, int N, const GemmEpilogue& e, int m0, int n0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN, g = lane >> 4, lr = lane & 15;
     float* Cf = reinterpret_cast<float*>(e.C);
@@ -37,57 +48,134 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[TM][TN], int M,
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * 16 * TM + i * 16 + lr;
         if (m >= M) continue;
-        float mean = 0.f, rstd = 1.f;
-        if (LNF) {                                          // statistics of row m over its K features (biased variance, eps inside the sqrt)
-            mean = rsum[i] / (float)K;
-            rstd = 1.0f / sqrtf(fmaxf(rsq[i] / (float)K - mean * mean, 0.f) + e.ln_eps);
-        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * 16 * TN + j * 16 + g * 4;
-            if (n >= N) continue;
-            f32x4 v = acc[i][j];
-            if (LNF) {                                      // host guarantees the vector path (N % 4 == 0)
-                const f32x4 s4 = *reinterpret_cast<const f32x4*>(e.ln_s + n);
-                const f32x4 t4 = *reinterpret_cast<const f32x4*>(e.ln_t + n);
+            const f32x4 v = acc[i][j];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = rstd * (v[r] - mean * s4[r]) + t4[r];
+            for (int r = 0; r < 4; ++r) {
+                const int nn = n + r;
+                if (nn >= N) break;
+                float x = v[r] + (e.bias ? e.bias[nn] : 0.f);
+                if (e.act == ACT_GEGLU) {
+                    if (r & 1) continue;
+                    const float gate = (nn + 1 < N) ? v[r + 1] + (e.bias ? e.bias[nn + 1] : 0.f) : 0.f;
+                    x = gelu_for<T>(gate) * x;
+                    const size_t o = (size_t)m * e.ldc + (nn >> 1);
+                    if (e.out_f32) Cf[o] = x; else store_elem(Ct + o, x);
+                    continue;
+                }
+                if (e.act == ACT_LEAKY) x = x > 0.f ? x : 0.1f * x;
+                if (e.res) x += e.res[(size_t)m * e.ldr + nn];
+                const size_t o = (size_t)m * e.ldc + nn;
+                if (e.out_f32) Cf[o] = x; else store_elem(Ct + o, x);
             }
-            if (e.vec_ok) {
-                if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + n);
+        }
+    }
+}
+
+// LNF: LayerNorm fold with the row statistics rsum / rsq (of the main loop, or of the producer: load_row_stats).
+// Every load of the epilogue (bias / s / t vectors, the residual tile, the scatter maps) is issued up front with clamped, unconditional
+// addresses and consumed afterwards: written as one load -> use -> store chain per 16x16 block the compiler waits for each load in turn
+// (stores may alias the next load), i.e. TM*TN dependent L2 round trips at the tail of a kernel whose tiles all finish together.
+// rows blocks (of 16 rows) per load round of the epilogue: IB * TN residual vectors in flight per lane
+template <int TM> constexpr int epi_rows_per_round() { return TM > 2 ? 2 : TM; }
+
+template <typename T, int TM, int TN, int WN = 2, bool LNF = false>
+__device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[TM][TN], int M, int N, const GemmEpilogue& e, int m0, int n0,
+                                              const float* rsum = nullptr, const float* rsq = nullptr, int K = 1) {
+    if (!e.vec_ok) {
+        if (!LNF) gemm_epilogue_scalar<T, TM, TN, WN>(acc, M, N, e, m0, n0);
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN, g = lane >> 4, lr = lane & 15;
+    float* __restrict__ Cf = reinterpret_cast<float*>(e.C);
+    T* __restrict__ Ct = reinterpret_cast<T*>(e.C);
+    const int mb = m0 + wm * 16 * TM + lr, nb = n0 + wn * 16 * TN + g * 4;      // + i*16, + j*16
+    // N % 4 == 0 and N >= 4 here, so N - 4 is a valid clamped column; values loaded through a clamped index are never stored
+    f32x4 b4[TN], s4[TN], t4[TN];
+    int coff[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nj = min(nb + j * 16, N - 4);
+        b4[j] = e.bias ? *reinterpret_cast<const f32x4*>(e.bias + nj) : f32x4{0, 0, 0, 0};
+        if (LNF) {
+            s4[j] = *reinterpret_cast<const f32x4*>(e.ln_s + nj);
+            t4[j] = *reinterpret_cast<const f32x4*>(e.ln_t + nj);
+        }
+        coff[j] = e.row_off ? e.col_off[nj] : nj;
+    }
+    constexpr int IB = epi_rows_per_round<TM>();
+#pragma unroll
+    for (int i0 = 0; i0 < TM; i0 += IB) {
+        // ---- phase 1: loads
+        f32x4 r4[IB][TN];
+        int roff[IB];
+#pragma unroll
+        for (int ii = 0; ii < IB; ++ii) {
+            const int mi = min(mb + (i0 + ii) * 16, M - 1);
+            roff[ii] = e.row_off ? e.row_off[mi] : 0;
+            if (!LNF && e.res && e.act != ACT_GEGLU) {      // (a folded GEMM with a residual -- no such call on the hot path -- loads it in phase 2)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) r4[ii][j] = *reinterpret_cast<const f32x4*>(e.res + (size_t)mi * e.ldr + min(nb + j * 16, N - 4));
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) r4[ii][j] = f32x4{0, 0, 0, 0};
+            }
+        }
+        // ---- phase 2: math and stores
+#pragma unroll
+        for (int ii = 0; ii < IB; ++ii) {
+            const int i = i0 + ii, m = mb + i * 16;
+            float mean = 0.f, rstd = 1.f;
+            if (LNF) {                                      // statistics of row m over its K features (biased variance, eps inside the sqrt)
+                const float inv_k = 1.0f / (float)K;        // (uniform: one scalar division)
+                mean = rsum[i] * inv_k;
+                rstd = __builtin_amdgcn_rsqf(fmaxf(rsq[i] * inv_k - mean * mean, 0.f) + e.ln_eps);      // v_rsq_f32: 1 ulp
+            }
+            float ps = 0.f, pq = 0.f;                       // stats_out partial of this lane's 4 * TN columns of row m
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = nb + j * 16;
+                const bool live = m < M && n < N;
+                f32x4 v = acc[i][j];
+                if (LNF) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = rstd * (v[r] - mean * s4[j][r]) + t4[j][r];
+                }
+                v += b4[j];
                 if (e.act == ACT_GEGLU) {
                     const float o0 = gelu_for<T>(v[1]) * v[0], o1 = gelu_for<T>(v[3]) * v[2];
                     const size_t o = (size_t)m * e.ldc + (n >> 1);
-                    if (e.out_f32) store2(Cf + o, o0, o1); else store2(Ct + o, o0, o1);
-                } else {
-                    if (e.act == ACT_LEAKY) {
+                    if (live) { if (e.out_f32) store2(Cf + o, o0, o1); else store2(Ct + o, o0, o1); }
+                    continue;
+                }
+                if (e.act == ACT_LEAKY) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.1f * v[r];
-                    }
-                    if (e.res) v += *reinterpret_cast<const f32x4*>(e.res + (size_t)m * e.ldr + n);
-                    const size_t o = (size_t)m * e.ldc + n;
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.1f * v[r];
+                }
+                if (!LNF) v += r4[ii][j];
+                else if (e.res && live) v += *reinterpret_cast<const f32x4*>(e.res + (size_t)m * e.ldr + n);
+                if (live) {
+                    const size_t o = e.row_off ? (size_t)((long)roff[ii] + (long)coff[j]) : (size_t)m * e.ldc + n;
                     if (e.out_f32) store4(Cf + o, v); else store4(Ct + o, v);
                     if (e.C2) store4(reinterpret_cast<bf16*>(e.C2) + (size_t)m * e.ldc2 + n, v);
-                }
-            } else {
-                // scalar path (N not a multiple of 4, e.g. heads = 2 or a 1-wide critic head)
-                for (int r = 0; r < 4; ++r) {
-                    const int nn = n + r;
-                    if (nn >= N) break;
-                    float x = v[r] + (e.bias ? e.bias[nn] : 0.f);
-                    if (e.act == ACT_GEGLU) {
-                        if (r & 1) continue;
-                        const float gate = (nn + 1 < N) ? v[r + 1] + (e.bias ? e.bias[nn + 1] : 0.f) : 0.f;
-                        x = gelu_for<T>(gate) * x;
-                        const size_t o = (size_t)m * e.ldc + (nn >> 1);
-                        if (e.out_f32) Cf[o] = x; else store_elem(Ct + o, x);
-                        continue;
+                    if (TN == 2 && e.stats_out) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float x = (sizeof(T) == 2 && (e.C2 || !e.out_f32)) ? bf2f(f2bf(v[r])) : v[r];
+                            ps += x; pq += x * x;
+                        }
                     }
-                    if (e.act == ACT_LEAKY) x = x > 0.f ? x : 0.1f * x;
-                    if (e.res) x += e.res[(size_t)m * e.ldr + nn];
-                    const size_t o = (size_t)m * e.ldc + nn;
-                    if (e.out_f32) Cf[o] = x; else store_elem(Ct + o, x);
                 }
+            }
+            if (TN == 2 && e.stats_out) {                   // uniform branch; the 4 lane groups g hold the 4 column quarters of the chunk
+                ps += __shfl_xor(ps, 16); pq += __shfl_xor(pq, 16);
+                ps += __shfl_xor(ps, 32); pq += __shfl_xor(pq, 32);
+                const int chunk = (n0 + wn * 16 * TN) / STATS_CHUNK;
+                if (g == 0 && m < M && chunk < e.stats_np)
+                    reinterpret_cast<float2*>(e.stats_out)[(size_t)m * e.stats_np + chunk] = float2{ps, pq};
             }
         }
     }
@@ -107,8 +195,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmOperands p, const G
     gemm_epilogue<T, TM, TN>(acc, p.M, p.N, e, m0, n0);
 }
 
-template <typename T, int TM, int TN, int WM, int WN, int STAGES, int ROWB, int PW, bool LNF = false>
-__global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_dma_kernel(const GemmOperands p, const GemmEpilogue e, int a_nrows) {
+// waves per SIMD the LDS footprint allows (160 KB per CU, 4 SIMDs): the register allocator is held to that occupancy, so the batched
+// loads of the epilogue cannot push the 64x64 kernel from 5 to 4 workgroups per CU
+template <typename Tile>
+constexpr int lds_waves_per_simd() {
+    const int wgs = 163840 / Tile::SMEM, w = wgs * (Tile::THREADS / 64) / 4;
+    return w < 1 ? 1 : (w > 8 ? 8 : w);
+}
+
+template <typename T, int TM, int TN, int WM, int WN, int STAGES, int ROWB, int PW, int LNF = 0>
+__global__ __launch_bounds__(64 * (WM * WN + PW))
+__attribute__((amdgpu_waves_per_eu(lds_waves_per_simd<GemmDma<T, TM, TN, WM, WN, STAGES, ROWB, PW>>(), 8)))
+void gemm_dma_kernel(const GemmOperands p, const GemmEpilogue e, int a_nrows) {
     using Tile = GemmDma<T, TM, TN, WM, WN, STAGES, ROWB, PW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware tile map.  Workgroup b is observed to run on XCD b % 8 (speed only, never correctness); each XCD has a
@@ -128,18 +226,50 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void gemm_dma_kernel(const Gem
         m0 = (mstart + ml) * Tile::BM;
         n0 = (idx / cmax) * Tile::BN;
     }
+    PK_TL_KERNEL(0);
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-    if constexpr (LNF) {
+    if constexpr (LNF == 1) {
         float rsum[TM], rsq[TM];
         if (!Tile::template run_stats<2>(p, a_nrows, m0, n0, smem, acc, rsum, rsq)) return;
         gemm_epilogue<T, TM, TN, WN, true>(acc, p.M, p.N, e, m0, n0, rsum, rsq, p.K);
+    } else if constexpr (LNF == 2) {
+        // statistics of the tile's BM rows from the partials their producer left in e.ln_stats: 4 threads per row, each with a quarter of
+        // the row's partials.  The loads are issued here and ride under the main loop (whose first vmcnt(0) covers them); sums, the
+        // 4-lane fold and the hand-over through LDS happen after it.  (Waiting for them up front cost 12 us per launch: ~1.5 tiles per
+        // CU slot, each starting with dependent L2 round trips; 16 dependent loads per lane in the epilogue cost 45 us.)
+        static_assert(Tile::THREADS == 4 * Tile::BM, "4 threads per tile row");
+        const int srow = threadIdx.x >> 2, sq4 = threadIdx.x & 3;
+        const int per = (e.stats_np + 3) >> 2, c0 = sq4 * per, c1 = min(c0 + per, e.stats_np);
+        const float2* st = reinterpret_cast<const float2*>(e.ln_stats) + (size_t)min(m0 + srow, p.M - 1) * e.stats_np;
+        float su = 0.f, sq = 0.f;
+        for (int c = c0 + 4; c < c1; ++c) { const float2 pr = st[c]; su += pr.x; sq += pr.y; }      // K > 512 only
+        float2 pre[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pre[u] = c0 + u < c1 ? st[c0 + u] : float2{0.f, 0.f};
+        if (!Tile::run(p, a_nrows, m0, n0, smem, acc)) return;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { su += pre[u].x; sq += pre[u].y; }
+        su += __shfl_xor(su, 1); sq += __shfl_xor(sq, 1);
+        su += __shfl_xor(su, 2); sq += __shfl_xor(sq, 2);
+        __syncthreads();                                  // the last k-tile's fragments have been read: the ring can be reused
+        float2* ls = reinterpret_cast<float2*>(smem);
+        if (sq4 == 0) ls[srow] = float2{su, sq};
+        __syncthreads();
+        float rsum[TM], rsq[TM];
+        const int lane = threadIdx.x & 63, wm = (threadIdx.x >> 6) / WN;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { const float2 pr = ls[wm * 16 * TM + i * 16 + (lane & 15)]; rsum[i] = pr.x; rsq[i] = pr.y; }
+        gemm_epilogue<T, TM, TN, WN, true>(acc, p.M, p.N, e, m0, n0, rsum, rsq, p.K);
     } else {
         if (!Tile::run(p, a_nrows, m0, n0, smem, acc)) return;      // producer waves hold no accumulators
+        PK_TL_KERNEL(1);
         gemm_epilogue<T, TM, TN, WN>(acc, p.M, p.N, e, m0, n0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PK_TL_KERNEL(2);
     }
 }
 
@@ -152,7 +282,7 @@ static int launch_v1(const GemmOperands& p, const GemmEpilogue& e, hipStream_t s
     return PK_OK;
 }
 
-template <typename T, int TM, int TN, int STAGES, int WM = 2, int WN = 2, int ROWB = 128, int PW = 0, bool LNF = false>
+template <typename T, int TM, int TN, int STAGES, int WM = 2, int WN = 2, int ROWB = 128, int PW = 0, int LNF = 0>
 static int launch_dma(const GemmOperands& p, const GemmEpilogue& e, int a_nrows, hipStream_t s) {
     using Tile = GemmDma<T, TM, TN, WM, WN, STAGES, ROWB, PW>;
     if (Tile::SMEM > 65536) {                              // opt-in to > 64 KB of LDS: per kernel AND per device of the process
@@ -212,7 +342,8 @@ extern "C" int pk_gemm_auto_variant(int dtype, int a_is_f32, int M, int N, int K
 extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const void* W, int ldw,
                           int M, int N, int K, const float* bias, const float* res, int ldr,
                           void* C, int ldc, int out_is_f32, int act, const int* a_rows, int a_nrows,
-                          int variant, void* C2, int ldc2, const float* ln_s, const float* ln_t, float ln_eps, void* stream) {
+                          int variant, void* C2, int ldc2, const float* ln_s, const float* ln_t, float ln_eps,
+                          const int* row_off, const int* col_off, float* stats_out, const float* ln_stats, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !C) return PK_EINVAL;
     if (dtype != 0 && dtype != 1) return PK_EINVAL;
     if (act < 0 || act > 2) return PK_EINVAL;
@@ -227,12 +358,17 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
     if (!a_rows) a_nrows = M;
     // k-rotation (gemm_dma.hpp): measured +12..33 % on the 65536-wide vocab-head shape, -0..13 % on the N <= 2736 shapes
     GemmOperands p{A, W, a_rows, lda, ldw, M, N, K, 0, N >= 8192 ? krot_default() : 0};
-    GemmEpilogue e{bias, res, C, ldr, ldc, out_is_f32, act, 0, C2, ldc2, ln_s, ln_t, ln_eps};
+    GemmEpilogue e{bias, res, C, ldr, ldc, out_is_f32, act, 0, C2, ldc2, ln_s, ln_t, ln_eps, row_off, col_off, stats_out, ln_stats,
+                   ((ln_stats ? K : N) + STATS_CHUNK - 1) / STATS_CHUNK};
     bool v = (N % 4 == 0) && (ldc % 4 == 0) && al16(C) && (!bias || al16(bias)) && (!res || (al16(res) && ldr % 4 == 0));
     if (act == ACT_GEGLU) v = v && (ldc % 2 == 0) && ((reinterpret_cast<uintptr_t>(C) & 7) == 0);
     e.vec_ok = v ? 1 : 0;
     if (C2 && (!v || !out_is_f32 || act == ACT_GEGLU || dtype != 1 || (ldc2 & 3) || (reinterpret_cast<uintptr_t>(C2) & 7))) return PK_EINVAL;
     if ((ln_s == nullptr) != (ln_t == nullptr)) return PK_EINVAL;
+    if ((row_off == nullptr) != (col_off == nullptr)) return PK_EINVAL;
+    if (row_off && (!v || !out_is_f32 || act == ACT_GEGLU || res || C2)) return PK_EINVAL;
+    if (ln_stats && (!ln_s || stats_out || (reinterpret_cast<uintptr_t>(ln_stats) & 7))) return PK_EINVAL;
+    if (stats_out && (!v || act == ACT_GEGLU || row_off || (reinterpret_cast<uintptr_t>(stats_out) & 7))) return PK_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
     const bool dma_ok = dma_possible(dtype, a_is_f32, N, K, lda, ldw, a_nrows);
@@ -243,9 +379,15 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
         // LayerNorm-folded GEMM: LDS-DMA main loop only (the statistics come from its A fragments), vector epilogue, 64x64 / 128x128 tiles
         if (!dma_ok || !v || !al16(ln_s) || !al16(ln_t) || a_rows) return PK_EINVAL;
         const bool big = variant == 24 || variant == 2 || variant == 9;
-        if (dtype == 1) return big ? launch_dma<bf16, 4, 2, 2, 2, 4, 128, 0, true>(p, e, a_nrows, s) : launch_dma<bf16, 2, 2, 2, 2, 2, 128, 0, true>(p, e, a_nrows, s);
-        return big ? launch_dma<float, 4, 2, 2, 2, 4, 128, 0, true>(p, e, a_nrows, s) : launch_dma<float, 2, 2, 2, 2, 2, 128, 0, true>(p, e, a_nrows, s);
+        if (ln_stats) {
+            if (dtype == 1) return big ? launch_dma<bf16, 4, 2, 2, 2, 4, 128, 0, 2>(p, e, a_nrows, s) : launch_dma<bf16, 2, 2, 2, 2, 2, 128, 0, 2>(p, e, a_nrows, s);
+            return big ? launch_dma<float, 4, 2, 2, 2, 4, 128, 0, 2>(p, e, a_nrows, s) : launch_dma<float, 2, 2, 2, 2, 2, 128, 0, 2>(p, e, a_nrows, s);
+        }
+        if (dtype == 1) return big ? launch_dma<bf16, 4, 2, 2, 2, 4, 128, 0, 1>(p, e, a_nrows, s) : launch_dma<bf16, 2, 2, 2, 2, 2, 128, 0, 1>(p, e, a_nrows, s);
+        return big ? launch_dma<float, 4, 2, 2, 2, 4, 128, 0, 1>(p, e, a_nrows, s) : launch_dma<float, 2, 2, 2, 2, 2, 128, 0, 1>(p, e, a_nrows, s);
     }
+    // stats_out is written by the TN = 2 LDS-DMA kernels only (one 32-column chunk per wave)
+    if (stats_out && !(dma_ok && (variant == 8 || variant == 24 || variant == 33 || (variant == 3 && dtype == 0)))) return PK_EINVAL;
     // the main-loop variants that survived round 1's sweep (profiles/gemm_variants*_r01.txt; the 35 losers -- deeper rings, k-tile 32,
     // 128x256 / 256x256 tiles, other wave layouts, other producer / consumer splits -- were deleted in round 2)
     if (dtype == 1) {
@@ -270,6 +412,17 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
     }
 }
 
+#ifdef PK_TIMELINE
+extern "C" int pk_debug_timeline(unsigned long long* out, int n) {
+    if (hipDeviceSynchronize() != hipSuccess) return PK_ELAUNCH;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pk_tl), sizeof(unsigned long long) * n) == hipSuccess ? PK_OK : PK_ELAUNCH;
+}
+extern "C" int pk_debug_timeline_clear() {
+    static unsigned long long z[8 * 5 * 40] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(pk_tl), z, sizeof(z)) == hipSuccess ? PK_OK : PK_ELAUNCH;
+}
+#endif
+
 extern "C" int pk_gemm(int dtype, int a_is_f32, const void* A, int lda, const void* W, int ldw,
                        int M, int N, int K, const float* bias, const float* res, int ldr,
                        void* C, int ldc, int out_is_f32, int act, const int* a_rows, void* stream) {
@@ -277,8 +430,8 @@ extern "C" int pk_gemm(int dtype, int a_is_f32, const void* A, int lda, const vo
     if (a_rows) {
         const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128);
         return pk_gemm_ex(dtype, a_is_f32, A, lda, W, ldw, M, N, K, bias, res, ldr, C, ldc, out_is_f32, act, a_rows,
-                          0x7fffffff / (lda > 0 ? lda : 1) / 4, blocks128 >= 384 ? 2 : 1, nullptr, 0, nullptr, nullptr, 0.f, stream);
+                          0x7fffffff / (lda > 0 ? lda : 1) / 4, blocks128 >= 384 ? 2 : 1, nullptr, 0, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, stream);
     }
     return pk_gemm_ex(dtype, a_is_f32, A, lda, W, ldw, M, N, K, bias, res, ldr, C, ldc, out_is_f32, act, nullptr, M, 0,
-                      nullptr, 0, nullptr, nullptr, 0.f, stream);
+                      nullptr, 0, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, stream);
 }

@@ -40,6 +40,21 @@ __device__ __forceinline__ void frag_stats(const Frag<float>& f, float& s, float
     }
 }
 
+#ifdef PK_TIMELINE
+// instrumented build only (tools/build_alt.sh tl -DPK_TIMELINE; tools/gemm_timeline.py): s_memtime stamps of wave 0 of a few workgroups
+__device__ unsigned long long pk_tl[8 * 5 * 40];
+#define PK_TL(slot) do { if (tl_on && kt < 38) pk_tl[(tl_wg * 40 + kt) * 5 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ __forceinline__ int pk_tl_wg() {
+    return blockIdx.x == 0 ? 0 : blockIdx.x == 8 ? 1 : blockIdx.x == 1 ? 2 : blockIdx.x == gridDim.x / 2 ? 3 :
+           blockIdx.x == gridDim.x - 8 ? 4 : blockIdx.x == 256 ? 5 : blockIdx.x == 512 ? 6 : blockIdx.x == 1024 ? 7 : -1;
+}
+// row 39 of a workgroup's table: [0] kernel entry, [1] main loop done, [2] epilogue done
+#define PK_TL_KERNEL(slot) do { const int w_ = pk_tl_wg(); if (w_ >= 0 && threadIdx.x == 0) pk_tl[(w_ * 40 + 39) * 5 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PK_TL_KERNEL(slot) do {} while (0)
+#define PK_TL(slot) do {} while (0)
+#endif
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // TM x TN MFMA tiles per wave, WM x WN compute waves per workgroup, ROWB bytes of k per LDS row.
@@ -159,11 +174,19 @@ struct GemmDma {
         if (loads)
             for (int s = 0; s < pre; ++s) issue(s, s);
         if (PW > 0 && computes) __builtin_amdgcn_s_setprio(1);      // consumers win issue arbitration against their SIMD's producer
+#ifdef PK_TIMELINE
+        const int tl_wg = pk_tl_wg();
+        const bool tl_on = tl_wg >= 0 && tid == 0;
+#endif
         for (int kt = 0; kt < nt; ++kt) {
             const int issued = (kt + STAGES - 1 < nt) ? kt + STAGES - 1 : nt;      // tiles issued so far
+            PK_TL(0);
             if (loads) wait_outstanding(issued - (kt + 1));
+            PK_TL(1);
             __builtin_amdgcn_s_barrier();                 // tile kt landed for every wave; everyone is done with tile kt-1
+            PK_TL(2);
             if (loads && kt + STAGES - 1 < nt) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+            PK_TL(3);
             if (!computes) continue;
             const char* a = smem + (kt % STAGES) * STAGE_BYTES;
             const char* w = a + BM * ROWB;
@@ -183,6 +206,7 @@ struct GemmDma {
                     for (int i = 0; i < TM; ++i) frag_stats(fa[i], rsum[i], rsq[i], STATS > 1);
                 }
             }
+            PK_TL(4);
         }
         if (STATS) {                                      // fold the 4 lane groups (k = g*8 + 0..7 of every chunk) of each row
 #pragma unroll

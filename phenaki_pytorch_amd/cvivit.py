@@ -213,6 +213,29 @@ class CViViT(PackedModule):
         x = self._spatial(self.enc_spatial_transformer, tokens2d, B, T, to_temporal=True, xt=xt)
         return self._temporal(self.enc_temporal_transformer, x, B, T, skip_norm_out=skip_norm_out)
 
+    def _unpatch_maps(self, B, T, f0, ntg, ptg, row0, dev):
+        """(token rows of the frame group, video offset of every row, video offset of every pixel column), cached per geometry."""
+        cache = self.__dict__.setdefault('_pk_unpatch_maps', {})
+        key = (B, T, f0, ntg, ptg, row0, str(dev))
+        if key not in cache:
+            h, w = self.patch_height_width
+            ph, pw = self.patch_size
+            C, hw = self.channels, h * w
+            F = 1 + (T - 1) * self.temporal_patch_size
+            H, W = self.image_size
+            if B * C * F * H * W >= 2 ** 31:
+                raise ValueError('video too large for 32-bit scatter offsets')
+            if pw % 4 or W % 4:
+                raise ValueError('patch width and image width must be multiples of 4 (16-byte pixel stores)')
+            ar = lambda n: torch.arange(n, dtype=torch.int64)
+            b, tt, hh, ww = torch.meshgrid(ar(B), ar(ntg), ar(h), ar(w), indexing='ij')
+            idx = (b * (T * hw) + row0 + tt * hw + hh * w + ww).reshape(-1)
+            row_off = (((b * C * F + f0 + tt * ptg) * H + hh * ph) * W + ww * pw).reshape(-1)
+            c, d, y, x = torch.meshgrid(ar(C), ar(ptg), ar(ph), ar(pw), indexing='ij')
+            col_off = (((c * F + d) * H + y) * W + x).reshape(-1)
+            cache[key] = tuple(t.to(device=dev, dtype=torch.int32).contiguous() for t in (idx, row_off, col_off))
+        return cache[key]
+
     def _decode2d(self, tokens2d, B, T):
         """tokens (B*T*h*w, dim) f32 -> video (B, C, 1 + (T-1)*pt, H, W) f32 (cvivit.py:476-516)."""
         dt = compute_dtype_of(self)
@@ -230,20 +253,15 @@ class CViViT(PackedModule):
         F = 1 + (T - 1) * pt
         H, W = self.image_size
         video = torch.empty((B, C, F, H, W), device=dev, dtype=torch.float32)
-        base = torch.arange(B, device=dev, dtype=torch.int32)[:, None] * (T * hw)
-
-        def group(seq, f0, ntg, ptg, row0):
+        for seq, f0, ntg, ptg, row0 in ((self.to_pixels_first_frame, 0, 1, 1, 0), (self.to_pixels, 1, T - 1, pt, hw)):
+            if ntg <= 0:
+                continue
             lin = seq[0]
-            P = C * ptg * ph * pw
-            rows = B * ntg * hw
-            idx = (base + torch.arange(row0, row0 + ntg * hw, device=dev, dtype=torch.int32)[None, :]).reshape(-1).contiguous()
-            pix = torch.empty((rows, P), device=dev, dtype=torch.float32)
-            L.gemm(dt, x, linear_weight(lin, dt), rows, P, self.dim, C=pix, bias=lin.bias, a_rows=idx)
-            L.unpatchify(pix, video, f0, ntg, ptg, ph, pw)
-
-        group(self.to_pixels_first_frame, 0, 1, 1, 0)
-        if T > 1:
-            group(self.to_pixels, 1, T - 1, pt, hw)
+            idx, row_off, col_off = self._unpatch_maps(B, T, f0, ntg, ptg, row0, dev)
+            # 'b t h w (c pt p1 p2) -> b c (t pt) (h p1) (w p2)' is separable in (row, column), so the GEMM epilogue writes the video
+            # in place (round 1 materialised the (rows, P) pixel matrix -- 100 MB at the bench shape -- and re-read it in pk_unpatchify)
+            L.gemm(dt, x, linear_weight(lin, dt), idx.numel(), col_off.numel(), self.dim, C=video, bias=lin.bias, a_rows=idx,
+                   scatter=(row_off, col_off))
         return video
 
     # ---------------------------------------------------------------- public surface (cvivit.py:437-583)

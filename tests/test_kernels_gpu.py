@@ -18,7 +18,7 @@ torch.set_grad_enabled(False)
 def _oracle_follows_product_ln_fold():
     """the bf16 oracle rounds where the product rounds: LayerNorm folded into the consuming GEMM unless PK_LN_FOLD=0"""
     from phenaki_pytorch_amd import attention
-    O.LN_FOLD, O.LN_FOLD_FF = attention._LN_FOLD, attention._LN_FOLD_FF
+    O.LN_FOLD, O.LN_FOLD_FF, O.LN_FOLD_FF_MAX_ROWS = attention._LN_FOLD, bool(attention._LN_FOLD_FF), attention._LN_FOLD_FF_MAX_ROWS
 
 
 @pytest.fixture(scope='module')
@@ -652,6 +652,87 @@ def test_gemm_layernorm_fold_and_bf16_copy(L, mode, M, N, K, geglu):
         L.gemm(dt, x.cuda().to(td), pack := A.pack_linear_weight(Wd, dt), M, N, K, C=C3, res=res.cuda(), C2=C4)
         close(C3, xb @ bf(W).t() + res, 3e-5, 'gemm + C2')
         assert torch.equal(C4.float(), bf(C3.cpu()).cuda())
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('M,N,K,D,variant', [(200, 304, 64, 96, 0), (4608, 1368 * 2, 512, 512, 0), (700, 96, 2048, 72, 0), (9216, 64, 128, 512, 24)])
+def test_gemm_row_stats_handoff(L, mode, M, N, K, D, variant):
+    """stats_out -> ln_stats: the producer (x = o Wo^T + res, D columns) leaves per-32-column (sum, sum of squares) of the rows as its
+    consumer reads them; the LayerNorm-folded consumer (N columns over K = D) must match the same GEMM with in-loop statistics."""
+    from torch import nn
+    from phenaki_pytorch_amd import attention as A
+    dt = L.F32 if mode == 'f32' else L.BF16
+    td = L.tdtype(dt)
+    cast = (lambda t: t) if mode == 'f32' else bf
+    o = torch.randn(M, K, generator=g(90))
+    Wo = torch.randn(D, K, generator=g(91)) / math.sqrt(K)
+    res = torch.randn(M, D, generator=g(92)) * 2 + 0.3
+    x = torch.full((M, D), float('nan'), device='cuda')
+    xt = torch.full((M, D), float('nan'), device='cuda', dtype=torch.bfloat16) if mode == 'bf16' else None
+    npart = (D + 31) // 32
+    stats = torch.full((M, npart, 2), float('nan'), device='cuda')
+    L.gemm(dt, o.cuda().to(td), A.pack_linear_weight(Wo.cuda(), dt), M, D, K, C=x, res=res.cuda(), C2=xt, stats_out=stats, variant=variant)
+    close(x, cast(o) @ cast(Wo).t() + res, 3e-5, 'producer')
+    seen = (xt.float() if xt is not None else x).cpu().double()
+    pad = torch.zeros(M, npart * 32, dtype=torch.float64)
+    pad[:, :D] = seen
+    pad = pad.view(M, npart, 32)
+    close(stats[..., 0], pad.sum(-1).float(), 1e-5, 'stats: sums')
+    close(stats[..., 1], (pad * pad).sum(-1).float(), 1e-5, 'stats: sums of squares')
+    # consumer
+    gamma, beta = 1 + 0.2 * torch.randn(D, generator=g(93)), 0.1 * torch.randn(D, generator=g(94))
+    W = torch.randn(N, D, generator=g(95)) / math.sqrt(D)
+    Wd, gd, bd = W.cuda(), gamma.cuda(), beta.cuda()
+    wg, s, t, _ = A.folded_weight(nn.Linear(1, 1), 'k', lambda: Wd, gd, bd, dt, [gd])
+    a = xt if xt is not None else x
+    for act in (L.ACT_NONE, L.ACT_GEGLU):
+        shape = (M, N // 2) if act == L.ACT_GEGLU else (M, N)
+        c1 = torch.full(shape, float('nan'), device='cuda', dtype=td)
+        c2 = torch.full(shape, float('nan'), device='cuda', dtype=td)
+        L.gemm(dt, a, wg, M, N, D, C=c1, act=act, ln=(s, t, 1e-5))
+        L.gemm(dt, a, wg, M, N, D, C=c2, act=act, ln=(s, t, 1e-5), ln_stats=stats)
+        close(c2.float(), c1.float(), 1e-5 if mode == 'f32' else 8e-3, f'handed-over vs in-loop statistics, act {act}')
+        xs = seen.float()
+        mean = xs.mean(-1, keepdim=True)
+        rstd = 1 / torch.sqrt((xs * xs).mean(-1, keepdim=True) - mean * mean + 1e-5)
+        wgr = cast(W * gamma)
+        ref = rstd * (xs @ wgr.t() - mean * wgr.sum(-1)) + W @ beta
+        if act == L.ACT_GEGLU:
+            ref = F.gelu(ref[:, 1::2]) * ref[:, 0::2]
+        close(c2.float(), cast(ref), 3e-5 if mode == 'f32' else 8e-3, f'ln_stats gemm {mode} act {act}')
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('B,T,pt,hw,p,variant', [(2, 3, 2, 4, 8, 0), (1, 2, 2, 8, 4, 0), (3, 1, 1, 2, 8, 1), (2, 3, 2, 4, 8, 24)])
+def test_gemm_scatter_epilogue_unpatchify(L, mode, B, T, pt, hw, p, variant):
+    """pk_gemm_ex row_off / col_off: the gathered to_pixels GEMM writes 'b t h w (c pt p1 p2) -> b c (t pt) (h p1) (w p2)' in place
+    (cvivit.py:326-334, 505-516); checked against the (rows, P) product rearranged by torch, untouched frames stay NaN."""
+    from phenaki_pytorch_amd.cvivit import CViViT
+    dt = L.F32 if mode == 'f32' else L.BF16
+    td = L.tdtype(dt)
+    cast = (lambda t: t) if mode == 'f32' else bf
+    C, D = 3, 64
+    net = CViViT(dim=D, codebook_size=16, image_size=hw * p, patch_size=p, temporal_patch_size=pt, spatial_depth=1, temporal_depth=1,
+                 dim_head=64, heads=1, channels=C)
+    Fr = 1 + (T - 1) * pt
+    x = torch.randn(B * T * hw * hw, D, generator=g(80))
+    video = torch.full((B, C, Fr, hw * p, hw * p), float('nan'), device='cuda')
+    for f0, ntg, ptg, row0 in ((0, 1, 1, 0), (1, T - 1, pt, hw * hw)):
+        if ntg <= 0:
+            continue
+        P = C * ptg * p * p
+        W = torch.randn(P, D, generator=g(81 + ptg)) / math.sqrt(D)
+        bias = torch.randn(P, generator=g(83))
+        idx, row_off, col_off = net._unpatch_maps(B, T, f0, ntg, ptg, row0, torch.device('cuda'))
+        L.gemm(dt, x.cuda().to(td), W.cuda().to(td), idx.numel(), P, D, C=video, bias=bias.cuda(), a_rows=idx,
+               scatter=(row_off, col_off), variant=variant)
+        rows = x.view(B, T, hw * hw, D)[:, (0 if f0 == 0 else 1):(1 if f0 == 0 else T)].reshape(-1, D)
+        pix = cast(rows) @ cast(W).t() + bias
+        ref = pix.view(B, ntg, hw, hw, C, ptg, p, p).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(B, C, ntg * ptg, hw * p, hw * p)
+        close(video[:, :, f0:f0 + ntg * ptg], ref, 3e-5, f'scatter gemm {mode} frames {f0}+{ntg * ptg}')
+        if f0 == 0 and T > 1:
+            assert torch.isnan(video[:, :, 1:]).all(), 'first-frame group must not touch the other frames'
+    assert not torch.isnan(video).any()
 
 
 def test_peg_and_embed_bf16_copies(L):

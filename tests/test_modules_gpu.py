@@ -22,7 +22,7 @@ torch.set_grad_enabled(False)
 def _oracle_follows_product_ln_fold():
     """the bf16 oracle rounds where the product rounds: LayerNorm folded into the consuming GEMM unless PK_LN_FOLD=0"""
     from phenaki_pytorch_amd import attention
-    O.LN_FOLD, O.LN_FOLD_FF = attention._LN_FOLD, attention._LN_FOLD_FF
+    O.LN_FOLD, O.LN_FOLD_FF, O.LN_FOLD_FF_MAX_ROWS = attention._LN_FOLD, bool(attention._LN_FOLD_FF), attention._LN_FOLD_FF_MAX_ROWS
 
 # Tolerances.  fp32 mode is held to the north star directly: ids bit-exact (LFQ sign bits and gumbel argmax audited by the
 # oracle's own decision margin), logits / pixels 1e-3 relative.
