@@ -158,8 +158,15 @@ int pk_q_attn_cached(const void* xq, int ld, const void* wq, int ldw, int S, int
 int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void* Vt, const float* bias, long bias_hstride,
                 int bias_ld, const unsigned char* kmask, const float* slopes, int causal, void* O, int ldo,
                 int out_is_f32, int S, int h, int nq, int n_kv, int nnull, const float* bias_tab, int tab_len,
-                const int* pos_code, int code_off, void* stream);
-/* bias_tab ([h][tab_len] f32, or NULL; then bias must be NULL): the relative-position form of the continuous position bias
+                const int* pos_code, int code_off, int tab_run4, float score_bound, void* stream);
+/* score_bound: an upper bound of sim + bias over every (head, query, key), or NaN.  q^ and k^ are unit vectors times q_scale / k_scale,
+ * so |sim| <= scale * max_d |q_scale_d k_scale_d| and the caller knows the maximum of its bias: with a finite bound (and no key
+ * mask, not causal, bf16, >= 64 queries and keys) the softmax numerators are p = 2^(s log2(e) - ceil(bound log2(e))) -- no running
+ * maximum, no cross-lane max, no accumulator rescale per key tile (the same softmax: it is shift-invariant; an integer shift of
+ * the exponent keeps every mantissa, hence the bf16 rounding of p, independent of the tiling).  NaN: running-max flash loop.
+ * tab_run4: 1 when pos_code[4k + r] == pos_code[4k] + r for every k (last grid dimension a multiple of 4): the kernel then fetches the
+ * 4 table entries of 4 consecutive keys with two 8-byte LDS reads.
+ * bias_tab ([h][tab_len] f32, or NULL; then bias must be NULL): the relative-position form of the continuous position bias
  * (attention.py:229-275), bias[hh][i][j] = bias_tab[hh][pos_code[i] - pos_code[j] + code_off] with pos_code [n] int32 -- staged
  * in LDS by the bf16 kernel for nq = n_kv >= 64 (self-attention, no null keys / mask / causal); other shapes: PK_EINVAL. */
 

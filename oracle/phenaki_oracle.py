@@ -63,6 +63,7 @@ def _lin(x, w):
 LN_FOLD = True
 LN_FOLD_FF = False          # the feed-forward LayerNorm is folded into FF1 ...
 LN_FOLD_FF_MAX_ROWS = 0     # ... for inputs of at most this many rows (0: no limit); the tests copy both from the product's settings
+ATTN_FIXED_OFFSET = True    # long self-attention (n > 64, no masks): p = 2^(s log2e - integer) instead of the running-max flash loop
 _ROWS_SCALE = [1]           # the product runs the cond | null halves of a CFG step as ONE batch: its row count is twice this oracle's
 
 
@@ -176,7 +177,14 @@ def attention(sd, p, x, *, heads, causal=False, mask=None, context=None, attn_bi
         sim = sim + alibi_bias(heads, i, j)
         cm = torch.ones((i, j), dtype=torch.bool).triu(j - i + 1)
         sim = sim.masked_fill(cm, NEG_MAX)
-    if is_bf16():
+    if is_bf16() and ATTN_FIXED_OFFSET and context is None and nnull == 0 and mask is None and not causal and i > 64:
+        # the product's fixed-offset softmax (pk_attn_fwd score_bound): an INTEGER exponent shift, so the mantissa of every p -- and
+        # its bf16 rounding -- does not depend on which integer is used; numerator and row sum both use the ROUNDED p (the row sum is
+        # one more MFMA block against a V^T block of ones)
+        s2 = sim * 1.4426950408889634
+        pt = _r(torch.exp2(s2 - torch.ceil(s2.max())))
+        out = torch.einsum('bhij,bhjd->bhid', pt, v) / pt.sum(dim=-1, keepdim=True)
+    elif is_bf16():
         out = _flash_bf16(sim, v, 64 if (i >= 64 and j >= 64) else 32)
     else:
         attn = sim.softmax(dim=-1)

@@ -41,7 +41,7 @@ SIGNATURES = {
     'pk_qkv_project': [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _P],
     'pk_qkv_attn': [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _L, _I, _P, _I, _P, _I, _P, _P],
     'pk_q_attn_cached': [_P, _I, _P, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P],
-    'pk_attn_fwd': [_I, _P, _P, _P, _P, _L, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P],
+    'pk_attn_fwd': [_I, _P, _P, _P, _P, _L, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _F, _P],
     'pk_attn_small': [_P, _I, _P, _I, _P, _P, _F, _P, _L, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     'pk_cfg_mix': [_P, _I, _I, _I, _I, _P, _I, _F, _I, _P, _I, _I, _I, _P],
     'pk_vocab_ntiles': [_I],
@@ -250,16 +250,20 @@ def q_attn_cached(xq, wq, S, n, h, K, q_scale, scale, Kp, Vt, nk_pad, n_kv, nnul
     _check(rc, 'pk_q_attn_cached')
 
 
-def attn_fwd(dtype, Qp, Kp, Vt, O, S, h, nq, n_kv, nnull, *, bias=None, kmask=None, slopes=None, causal=False, bias_table=None):
-    """bias: full (h, nq, n_kv) f32 tensor, or bias_table = (tab (h, L) f32, pos_code (n,) int32, offset): the relative-position form"""
-    tab, codes, off = bias_table if bias_table is not None else (None, None, 0)
+def attn_fwd(dtype, Qp, Kp, Vt, O, S, h, nq, n_kv, nnull, *, bias=None, kmask=None, slopes=None, causal=False, bias_table=None,
+             score_bound=None):
+    """bias: full (h, nq, n_kv) f32 tensor, or bias_table = (tab (h, L) f32, pos_code (n,) int32, offset, ...): the relative-position
+    form.  score_bound: upper bound of sim + bias (python float) -> fixed-offset softmax; None: running-max flash loop."""
+    tab, codes, off = bias_table[:3] if bias_table is not None else (None, None, 0)
+    run4 = 1 if (bias_table is not None and len(bias_table) > 5 and bias_table[5]) else 0
     if bias is not None:
         bh, bld = bias.stride(0), bias.stride(1)
     else:
         bh, bld = 0, 0
     rc = load().pk_attn_fwd(dtype, ptr(Qp), ptr(Kp), ptr(Vt), ptr(bias), bh, bld, ptr(kmask), f32p(slopes, 'ALiBi slopes'),
                             1 if causal else 0, ptr(O), O.stride(-2), 1 if O.dtype == torch.float32 else 0,
-                            S, h, nq, n_kv, nnull, f32p(tab, 'bias table'), tab.shape[1] if tab is not None else 0, ptr(codes), off, stream(O))
+                            S, h, nq, n_kv, nnull, f32p(tab, 'bias table'), tab.shape[1] if tab is not None else 0, ptr(codes), off, run4,
+                            float('nan') if score_bound is None else float(score_bound), stream(O))
     _check(rc, 'pk_attn_fwd')
 
 

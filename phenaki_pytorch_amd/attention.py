@@ -365,7 +365,7 @@ class ContinuousPositionBias(PackedModule):
         return BiasSpec(self, tuple(dimensions))
 
     def table(self, *dimensions):
-        """(tab (heads, L) f32, pos_code (n,) int32, offset): bias[h][i][j] == tab[h][pos_code[i] - pos_code[j] + offset].
+        """(tab (heads, L) f32, pos_code (n,) int32, offset, min, max, run4): bias[h][i][j] == tab[h][pos_code[i] - pos_code[j] + offset].
         The bias depends on (i, j) only through the relative grid position (attention.py:257-272), so the (heads, n, n) matrix --
         10.6 MB at (9, 8, 8), re-read by every (sequence, head) of every attention launch -- collapses to prod(2 d - 1) = 3 825
         values per head.  Built ONCE per (weights, dims) by scattering the exact entries of the full matrix (bit-identical values)."""
@@ -385,7 +385,8 @@ class ContinuousPositionBias(PackedModule):
             idx = (code[:, None] - code[None, :] + off).reshape(-1)
             tab = torch.zeros((full.shape[0], acc), device=dev, dtype=torch.float32)
             tab[:, idx] = full.reshape(full.shape[0], -1)
-            return tab.contiguous(), code.to(torch.int32).contiguous(), int(off)
+            lo, hi = (float(v) for v in torch.stack((full.min(), full.max())).tolist())     # one host sync per (weights, dims)
+            return tab.contiguous(), code.to(torch.int32).contiguous(), int(off), lo, hi, dims[-1] % 4 == 0
         return _cache(self).get(('table', tuple(dimensions)), params, build)
 
     def _compute(self, dims):
@@ -417,6 +418,8 @@ _SHORT_FUSED = os.environ.get('PK_QKV_ATTN', '1') != '0'
 _CROSS_FUSED = os.environ.get('PK_CROSS_FUSED', '1') != '0'
 # PK_BIAS_TABLE=0: the n >= 64 attention kernel streams the full (heads, n, n) position bias instead of its relative-position table
 _BIAS_TABLE = os.environ.get('PK_BIAS_TABLE', '1') != '0' and os.environ.get('PK_ATTN_LDS', '1') != '0'
+# PK_ATTN_FIXED=0: the n > 64 attention kernel keeps a running maximum (flash) instead of the fixed-offset softmax (pk_attn_fwd score_bound)
+_ATTN_FIXED = os.environ.get('PK_ATTN_FIXED', '1') != '0'
 
 
 class Attention(PackedModule):
@@ -502,6 +505,17 @@ class Attention(PackedModule):
                 not (_SHORT_FUSED and n <= 64) and kmask is None and not self.causal):
             bias_table, attn_bias = attn_bias.table(), None
         attn_bias = _full_bias(attn_bias)
+        # fixed-offset softmax for the long self-attention (pk_attn_fwd score_bound): q^ / k^ are unit vectors times q_scale / k_scale,
+        # so |sim| <= scale * max|q_scale . k_scale| (+ 1/64 for the bf16 rounding of the operand images); the table knows its extremes
+        score_bound = None
+        if (_ATTN_FIXED and dtype == L.BF16 and not is_cross and nnull == 0 and n > 64 and kmask is None and not self.causal and
+                (attn_bias is None)):
+            c = _cache(self).get(('qk_bound',), [self.q_scale, self.k_scale],
+                                 lambda: float((self.q_scale.detach().float() * self.k_scale.detach().float()).abs().max()))
+            qk = float(self.scale) * c * (1 + 1 / 64)
+            lo, hi = (bias_table[3], bias_table[4]) if bias_table is not None else (0., 0.)
+            if math.isfinite(qk + hi - lo) and (2 * qk + hi - lo) * 1.4427 < 64:       # else: exponent range too wide for one offset
+                score_bound = qk + hi
 
         fq = self._folded_q(dtype) if ln_fold_enabled(dtype) else None
         if fq is not None:
@@ -541,7 +555,7 @@ class Attention(PackedModule):
                     kv_cache[id(self)] = (Kp, Vt)
             o = torch.empty((M, inner), device=dev, dtype=td)
             L.attn_fwd(dtype, Qp, Kp, Vt, o, S, h, n, n_kv, nnull, bias=attn_bias, kmask=kmask, slopes=slopes, causal=self.causal,
-                       bias_table=bias_table)
+                       bias_table=bias_table, score_bound=score_bound)
             return self._finish(o, x2d, dtype, want_t)
 
         # ---- separate LayerNorm launch (exact-f32 mode; bf16 with PK_LN_FOLD=0)
@@ -603,7 +617,7 @@ class Attention(PackedModule):
             L.attn_prep(dtype, q, None, self.null_kv, self.q_scale, self.k_scale, float(self.scale), Qp, None, None, S, h, n, n_kv, nnull)
         o = torch.empty((M, inner), device=dev, dtype=td)
         L.attn_fwd(dtype, Qp, Kp, Vt, o, S, h, n, n_kv, nnull, bias=attn_bias, kmask=kmask, slopes=slopes, causal=self.causal,
-                   bias_table=bias_table)
+                   bias_table=bias_table, score_bound=score_bound)
         return self._finish(o, x2d, dtype, want_t)
 
     def forward(self, x, mask=None, context=None, attn_bias=None):

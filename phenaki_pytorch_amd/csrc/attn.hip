@@ -119,7 +119,17 @@ struct AttnArgs {
     // position: (2T-1)(2H-1)(2W-1) = 3825 distinct values per head at (9, 8, 8) -- 15 KB in LDS instead of a 1.33 MB f32 stream per
     // (sequence, head) through L2 (170 MB per launch at 16 x 8: the n = 576 kernel ran 37 us with the stream, 9 us without a bias)
     const float* bias_tab; int tab_len; const int* pos_code; int code_off;
+    int tab_run4;                                          // pos_code[4k + r] == pos_code[4k] + r (last grid dimension a multiple of 4)
+    // fixed-offset softmax (LDS-staged kernel, no key mask / causal): the caller knows an upper bound of sim + bias (|sim| <= scale *
+    // max|q_scale . k_scale| because q^ and k^ are unit vectors; the bias table has a known maximum), so p = 2^(s*log2e - off2) with
+    // the INTEGER off2 = ceil(bound * log2e) can never overflow and no running maximum, no cross-lane max, no accumulator rescale is
+    // needed: ~40 % of the VALU work of a key tile.  An integer shift of the exponent leaves every mantissa -- hence the bf16
+    // rounding of p -- independent of the tiling.  off2 < 0: running-max softmax.
+    float off2;
 };
+
+constexpr float ATTN_LOG2E = 1.4426950408889634f;
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));      // 8-byte LDS read at dword alignment (ds_read2_b32)
 
 __device__ __forceinline__ void load_vt(Frag<bf16>& f, const bf16* row, int kb, int g) {
     const u32x2 a = *reinterpret_cast<const u32x2*>(row + kb + g * 4);
@@ -347,12 +357,12 @@ __device__ __forceinline__ void lds_frag_vt(Frag<bf16>& f, const char* tile, int
 // instead of every wave pulling fragment-shaped pieces (16 rows x 64 B per instruction) through the texture path.
 typedef __attribute__((address_space(3))) void* attn_lds_ptr;
 
-// STAGES: depth of the K / V^T ring.  With 2 stages a workgroup has ONE tile in flight while it computes the other and every
-// iteration waits out most of an LDS-DMA round trip (~1.1 us vs ~0.4 us of work per tile); deeper rings (only without the vector
-// bias stream: a counted vmcnt must see nothing but the DMA pieces) keep STAGES - 1 tiles in flight behind a counted s_waitcnt.
-template <int QF, bool PF, bool TAB = false, int STAGES = 2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (PF ? 4 : ((TAB || STAGES > 2) ? 3 : 5)) : 3))) void attn_fwd_lds_kernel(const AttnArgs p, uint32_t kv_bytes) {
-    static_assert(STAGES == 2 || !PF, "the deep ring counts vmcnt: no other vector loads may be in flight in the loop");
+// The K / V^T ring has 2 stages: 3- and 4-stage rings behind a counted vmcnt were measured slower (35.1 / 43.3 vs 32.7 us at
+// n = 576, profiles/attn_variants_r02.txt -- the loop is bound by its VALU stream, not by DMA latency) and were removed.
+// FIX: fixed-offset softmax (AttnArgs::off2), host-selected when there is no key mask and no causal mask.
+template <int QF, bool PF, bool TAB = false, bool FIX = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (PF ? 4 : (TAB ? 3 : 5)) : ((FIX && !TAB) ? 4 : 3)))) void attn_fwd_lds_kernel(const AttnArgs p, uint32_t kv_bytes) {
+    constexpr int STAGES = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];          // STAGES x (K 8 KB | V^T 8 KB) [| bias table | position codes]
     constexpr int STAGE = 16384;
     float* tab = reinterpret_cast<float*>(smem + STAGES * STAGE);         // TAB: this head's bias table, then the position codes of all keys
@@ -396,16 +406,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
         for (int c = 0; c < 2; ++c) frag_load(fq[qf][c], Qp + (size_t)(qf * 16 + lr) * DH + c * 32 + g * 8);
 
     float m[QF], l[QF];
-    f32x4 o[QF][4];
+    f32x4 o[QF][4], lsum[QF];
 #pragma unroll
     for (int qf = 0; qf < QF; ++qf) {
-        m[qf] = -INFINITY; l[qf] = 0.f;
+        m[qf] = -INFINITY; l[qf] = 0.f; lsum[qf] = f32x4{0, 0, 0, 0};
 #pragma unroll
         for (int df = 0; df < 4; ++df) o[qf][df] = f32x4{0, 0, 0, 0};
     }
     const float slope = (p.causal && p.slopes) ? p.slopes[hh] : 0.f;
-    const float* bias = p.bias ? p.bias + (size_t)hh * p.bias_hstride : nullptr;
-    const unsigned char* km = p.kmask ? p.kmask + (size_t)s * p.n_kv : nullptr;
+    const float* bias = (p.bias && !FIX) ? p.bias + (size_t)hh * p.bias_hstride : nullptr;
+    const unsigned char* km = (p.kmask && !FIX) ? p.kmask + (size_t)s * p.n_kv : nullptr;
     const int coff = p.n_kv - p.nq;
     const bool vb_all = bias && p.bias_vec && !km && !p.causal;
     int qrow[QF];
@@ -414,7 +424,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
     int cq[QF];                                                            // TAB: position code of the lane's query row(s) + offset
     if (TAB) {
         const float* src = p.bias_tab + (size_t)hh * p.tab_len;
-        for (int i = threadIdx.x; i < p.tab_len; i += 256) tab[i] = src[i];
+        for (int i = threadIdx.x; i < p.tab_len; i += 256) tab[i] = FIX ? fmaf(src[i], ATTN_LOG2E, -p.off2) : src[i];
         for (int i = threadIdx.x; i < p.n_kv; i += 256) codes[i] = p.pos_code[i];
 #pragma unroll
         for (int qf = 0; qf < QF; ++qf) cq[qf] = p.pos_code[qrow[qf]] + p.code_off;
@@ -433,20 +443,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
     };
     f32x4 bz[QF][4];
     if (PF && active && vb_all && 64 <= nk) load_bz(bz, 0);
-    if (STAGES > 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // table / code / q loads retired: from here only DMA pieces count
 #pragma unroll
     for (int s0 = 0; s0 < STAGES - 1; ++s0)
         if (s0 < ntiles) issue(s0 * 64, s0);
     for (int t = 0; t < ntiles; ++t) {
         const int kb = t * 64;
-        if (STAGES == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else {
-            // tiles issued so far: min(ntiles, t + STAGES - 1); all but tile t may stay in flight (4 DMA pieces per wave per tile)
-            const int ahead = (t + STAGES - 1 < ntiles ? t + STAGES - 1 : ntiles) - (t + 1);
-            if (ahead >= 2 && STAGES > 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                     // tile t landed for all waves; everyone finished tile t-1
         if (t + STAGES - 1 < ntiles) issue(kb + (STAGES - 1) * 64, (t + STAGES - 1) % STAGES);
         if (kb + 64 > nk) {
@@ -492,6 +494,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
             if (vbias) {
 #pragma unroll
                 for (int f = 0; f < 4; ++f) st[qf][f] += bz[qf][f];
+            }
+            if (FIX) {
+                // p = 2^(s * log2e + bias * log2e - off2): the table already holds bias * log2e - off2 (host: no other bias form here)
+                const float noff = -p.off2;
+                if (TAB && simple && p.tab_run4) {
+                    // the lane's 4 keys of block f are consecutive AND so are their position codes: their table entries are 4
+                    // consecutive floats (descending in r) -> one code read + two dword-aligned 8-byte LDS reads instead of 4 gathers
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        const float* tp = tab + (cq[qf] - codes[kb + attn_kperm(f, g * 4)] - 3);
+                        const f32x2u lo = *reinterpret_cast<const f32x2u*>(tp), hi = *reinterpret_cast<const f32x2u*>(tp + 2);
+                        pr[qf][f * 4 + 0] = __builtin_amdgcn_exp2f(fmaf(st[qf][f][0], ATTN_LOG2E, hi[1]));
+                        pr[qf][f * 4 + 1] = __builtin_amdgcn_exp2f(fmaf(st[qf][f][1], ATTN_LOG2E, hi[0]));
+                        pr[qf][f * 4 + 2] = __builtin_amdgcn_exp2f(fmaf(st[qf][f][2], ATTN_LOG2E, lo[1]));
+                        pr[qf][f * 4 + 3] = __builtin_amdgcn_exp2f(fmaf(st[qf][f][3], ATTN_LOG2E, lo[0]));
+                    }
+                } else if (TAB && simple) {
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        const u32x4 ck = *reinterpret_cast<const u32x4*>(codes + kb + attn_kperm(f, g * 4));
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            pr[qf][f * 4 + r] = __builtin_amdgcn_exp2f(fmaf(st[qf][f][r], ATTN_LOG2E, tab[cq[qf] - (int)ck[r]]));
+                    }
+                } else {
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float add = noff;
+                            if (!simple) {
+                                const int key = kb + attn_kperm(f, g * 4 + r);
+                                const int j = key - p.nnull;
+                                if (key >= nk) add = -INFINITY;
+                                else if (TAB && j >= 0 && qi < p.nq) add = tab[cq[qf] - codes[j]];
+                            }
+                            pr[qf][f * 4 + r] = __builtin_amdgcn_exp2f(fmaf(st[qf][f][r], ATTN_LOG2E, add));
+                        }
+                }
+                continue;
             }
             if (TAB && simple) {
                 // whole tile of real keys: the lane's 4 keys of block f are consecutive -> their position codes are ONE 16-byte LDS read
@@ -554,6 +596,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
 #pragma unroll
                 for (int qf = 0; qf < QF; ++qf) o[qf][df] = mma(fv, fp[qf], o[qf][df]);
             }
+            if (FIX) {
+                // row sums on the matrix core: a V^T block of ones gives l = sum_j bf16(p_j) in every lane of the query row -- the SAME
+                // rounded weights the numerator uses (a dominant key contributes exactly p / p), no VALU adds, no cross-lane fold
+                Frag<bf16> ones;
+                ones.v = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+#pragma unroll
+                for (int qf = 0; qf < QF; ++qf) lsum[qf] = mma(ones, fp[qf], lsum[qf]);
+            }
         }
         if (vbias_next) {
 #pragma unroll
@@ -567,9 +617,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
     bf16* Ot = reinterpret_cast<bf16*>(p.O);
 #pragma unroll
     for (int qf = 0; qf < QF; ++qf) {
-        float lt = l[qf];
-        lt += __shfl_xor(lt, 16, 64);
-        lt += __shfl_xor(lt, 32, 64);
+        float lt;
+        if (FIX) lt = lsum[qf][0];
+        else {
+            lt = l[qf];
+            lt += __shfl_xor(lt, 16, 64);
+            lt += __shfl_xor(lt, 32, 64);
+        }
         const float inv = 1.0f / lt;
         const int qi = q0 + qf * 16 + lr;
         if (qi < p.nq) {
@@ -739,14 +793,14 @@ extern "C" int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void
                            const float* bias, long bias_hstride, int bias_ld, const unsigned char* kmask,
                            const float* slopes, int causal, void* O, int ldo, int out_is_f32,
                            int S, int h, int nq, int n_kv, int nnull, const float* bias_tab, int tab_len, const int* pos_code,
-                           int code_off, void* stream) {
+                           int code_off, int tab_run4, float score_bound, void* stream) {
     if (!Qp || !Kp || !Vt || !O || S <= 0 || h <= 0) return PK_EINVAL;
     if (bias_tab && (bias || !pos_code || tab_len <= 0 || nnull != 0 || nq != n_kv || causal || kmask)) return PK_EINVAL;
     if (ldo & 3) return PK_EALIGN;
     int nq_pad, nk_pad;
     if (int rc = pk_attn_pads(nq, n_kv, nnull, &nq_pad, &nk_pad)) return rc;
     AttnArgs a{Qp, Kp, Vt, bias, bias_hstride, bias_ld, kmask, slopes, O, ldo, out_is_f32, S, h, nq, n_kv, nnull, nq_pad, nk_pad, causal, 0,
-               bias_tab, tab_len, pos_code, code_off};
+               bias_tab, tab_len, pos_code, code_off, tab_run4, -1.f};
     a.bias_vec = (bias && nnull == 0 && (bias_ld & 3) == 0 && (bias_hstride & 3) == 0 &&
                   (reinterpret_cast<uintptr_t>(bias) & 15) == 0) ? 1 : 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -763,34 +817,29 @@ extern "C" int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void
         // measured on maskgit self-attention (S*h = 128, n = 576, bias): 16 query rows per wave + bias prefetch 41.2 us,
         // 32 rows per wave 44.5 us (its prefetch spills: 77 us); with a single key tile (n = 64) there is nothing to
         // prefetch and the leaner kernel (5 waves/SIMD) wins, 8.1 vs 11.3 us
-        static const int lds_qf = [] { const char* e = getenv("PK_ATTN_LDS_QF"); return e ? atoi(e) : 1; }();   // tuning knobs
+        static const int lds_qf = [] { const char* e = getenv("PK_ATTN_LDS_QF"); return e ? atoi(e) : 0; }();   // tuning knobs (0: automatic)
         static const int pf_env = [] { const char* e = getenv("PK_ATTN_PF"); return e ? atoi(e) : -1; }();
-        const int qf = lds_qf == 2 && nq >= 128 ? 2 : 1;
+        // fixed-offset softmax (below): 32 query rows per wave fit the register budget and 576 / 128 query blocks per (sequence, head)
+        // fit ONE round of workgroups: 28.3 vs 35.8 us (table), 23.9 vs 29.9 us (no bias); the running-max kernels stay at 16 rows
+        const bool fix = score_bound == score_bound && fabsf(score_bound) < 1e4f && !kmask && !causal && !bias;
+        const int qf = ((lds_qf == 2 || (fix && lds_qf != 1)) && nq >= 128) ? 2 : 1;
         const bool pf = pf_env >= 0 ? pf_env != 0 : (qf == 1 && nk_pad >= 192);
         const int qblocks = (nq_pad + 64 * qf - 1) / (64 * qf);
         const uint32_t kv_bytes = (uint32_t)((size_t)S * h * nk_pad * 128);
         dim3 g2((unsigned)(S * h * qblocks));
-        // deep ring: only where no vector bias stream shares the vmcnt counter (no bias, or the relative-position table)
-        static const int stages_env = [] { const char* e = getenv("PK_ATTN_STAGES"); return e ? atoi(e) : 0; }();   // tuning knob
-        const int ntl = (nk_pad + 63) / 64;
-        const bool no_stream = bias_tab || !(bias && a.bias_vec && !kmask && !causal);
-        int stages = stages_env ? stages_env : 2;      // measured at n = 576, S*h = 128 (tools/attn_bias_bench.py): 2 stages 32.7 us, 3: 35.1, 4: 43.3 -- the loop is not DMA-latency bound
-        if (!no_stream || ntl < 3 || stages < 2 || stages > 4) stages = 2;
-        const size_t lds = (size_t)stages * 16384 + (bias_tab ? (((size_t)tab_len * 4 + 15) & ~(size_t)15) + (((size_t)n_kv * 4 + 15) & ~(size_t)15) : 0);
+        const size_t lds = (size_t)2 * 16384 + (bias_tab ? (((size_t)tab_len * 4 + 15) & ~(size_t)15) + (((size_t)n_kv * 4 + 15) & ~(size_t)15) : 0);
         if (lds > 65536) return PK_EINVAL;
-#define PK_ATTN_DEEP(QFV, TABV, STV) hipLaunchKernelGGL((attn_fwd_lds_kernel<QFV, false, TABV, STV>), g2, block, lds, s, a, kv_bytes)
-        if (stages > 2) {
+        // fixed-offset softmax: a finite bound of sim + bias from the caller, no masks (a fully masked row needs the running maximum)
+        if (fix) {
+            a.off2 = ceilf(score_bound * ATTN_LOG2E);
             if (qf == 2) {
-                if (bias_tab) { if (stages == 3) PK_ATTN_DEEP(2, true, 3); else PK_ATTN_DEEP(2, true, 4); }
-                else { if (stages == 3) PK_ATTN_DEEP(2, false, 3); else PK_ATTN_DEEP(2, false, 4); }
-            } else {
-                if (bias_tab) { if (stages == 3) PK_ATTN_DEEP(1, true, 3); else PK_ATTN_DEEP(1, true, 4); }
-                else { if (stages == 3) PK_ATTN_DEEP(1, false, 3); else PK_ATTN_DEEP(1, false, 4); }
-            }
+                if (bias_tab) hipLaunchKernelGGL((attn_fwd_lds_kernel<2, false, true, true>), g2, block, lds, s, a, kv_bytes);
+                else hipLaunchKernelGGL((attn_fwd_lds_kernel<2, false, false, true>), g2, block, lds, s, a, kv_bytes);
+            } else if (bias_tab) hipLaunchKernelGGL((attn_fwd_lds_kernel<1, false, true, true>), g2, block, lds, s, a, kv_bytes);
+            else hipLaunchKernelGGL((attn_fwd_lds_kernel<1, false, false, true>), g2, block, lds, s, a, kv_bytes);
             PK_CHECK_LAUNCH();
             return PK_OK;
         }
-#undef PK_ATTN_DEEP
         if (bias_tab) {
             if (qf == 2) hipLaunchKernelGGL((attn_fwd_lds_kernel<2, false, true>), g2, block, lds, s, a, kv_bytes);
             else hipLaunchKernelGGL((attn_fwd_lds_kernel<1, false, true>), g2, block, lds, s, a, kv_bytes);

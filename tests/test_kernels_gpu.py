@@ -19,6 +19,7 @@ def _oracle_follows_product_ln_fold():
     """the bf16 oracle rounds where the product rounds: LayerNorm folded into the consuming GEMM unless PK_LN_FOLD=0"""
     from phenaki_pytorch_amd import attention
     O.LN_FOLD, O.LN_FOLD_FF, O.LN_FOLD_FF_MAX_ROWS = attention._LN_FOLD, bool(attention._LN_FOLD_FF), attention._LN_FOLD_FF_MAX_ROWS
+    O.ATTN_FIXED_OFFSET = attention._ATTN_FIXED
 
 
 @pytest.fixture(scope='module')
@@ -787,7 +788,7 @@ def test_cross_attention_cached_fused(L, S, n, n_ctx, masked):
     close(fused, first, 3e-3, 'fused vs unfused')
 
 
-@pytest.mark.parametrize('dims,S,heads', [((9, 8, 8), 2, 8), ((3, 8, 8), 3, 2), ((10, 8, 8), 1, 8), ((4, 5, 4), 2, 2)])
+@pytest.mark.parametrize('dims,S,heads', [((9, 8, 8), 2, 8), ((3, 8, 8), 3, 2), ((10, 8, 8), 1, 8), ((4, 5, 4), 2, 2), ((5, 5, 5), 1, 2), ((2, 9, 12), 2, 1)])
 def test_attention_relative_position_bias_table(L, dims, S, heads):
     """the continuous position bias as a relative-position TABLE in LDS (pk_attn_fwd bias_tab) against the full (heads, n, n)
     matrix streamed from memory: the table holds the matrix' own entries, so the attention outputs must be identical."""
@@ -796,7 +797,9 @@ def test_attention_relative_position_bias_table(L, dims, S, heads):
     torch.manual_seed(7)
     cpb = ContinuousPositionBias(dim=64, heads=heads, num_dims=3).cuda()
     full = cpb(*dims)
-    tab, codes, off = cpb.table(*dims)
+    tab, codes, off, lo, hi, run4 = cpb.table(*dims)
+    assert run4 == (dims[-1] % 4 == 0)
+    assert lo == full.min().item() and hi == full.max().item()
     assert tuple(full.shape) == (heads, n, n) and tab.shape[0] == heads and codes.dtype == torch.int32
     idx = (codes.long()[:, None] - codes.long()[None, :] + off)
     assert idx.min() >= 0 and idx.max() < tab.shape[1]
@@ -811,3 +814,25 @@ def test_attention_relative_position_bias_table(L, dims, S, heads):
     L.attn_fwd(L.BF16, Qp, Kp, Vt, o_tab, S, heads, n, n, 0, bias_table=(tab, codes, off))
     assert torch.isfinite(o_tab.float()).all()
     close(o_tab.float(), o_full.float(), 1e-6 if n % 64 == 0 else 4e-3, f'table vs matrix bias {dims}')
+    # fixed-offset softmax (score_bound) against the running-max loop and against an f64 softmax of the same operand images
+    Q = Qp.view(S * heads, nq_pad, 64)[:, :n].double().cpu()
+    K = Kp.view(S * heads, nk_pad, 64)[:, :n].double().cpu()
+    V = Vt.view(S * heads, 64, nk_pad)[:, :, :n].double().cpu()
+    bias_d = full.double().cpu().repeat(S, 1, 1)
+    for what, kw, extra in (('table', dict(bias_table=(tab, codes, off)), bias_d), ('table, 4-key runs', dict(bias_table=cpb.table(*dims)), bias_d),
+                            ('no bias', {}, 0.)):
+        sim = Q @ K.transpose(1, 2) + extra
+        ref = (sim.softmax(-1) @ V.transpose(1, 2)).view(S, heads, n, 64).permute(0, 2, 1, 3).reshape(S * n, heads * 64)
+        bound = float(sim.max()) + 0.3
+        o_fix = torch.full_like(o_full, float('nan'))
+        o_run = torch.full_like(o_full, float('nan'))
+        L.attn_fwd(L.BF16, Qp, Kp, Vt, o_run, S, heads, n, n, 0, **kw)
+        L.attn_fwd(L.BF16, Qp, Kp, Vt, o_fix, S, heads, n, n, 0, score_bound=bound, **kw)
+        e_run = close(o_run.float(), ref, 1.2e-2, f'running-max attention vs f64 softmax ({what})')
+        e_fix = close(o_fix.float(), ref, 1.2e-2, f'fixed-offset attention vs f64 softmax ({what})')
+        close(o_fix.float(), o_run.float(), 1.2e-2, f'fixed-offset vs running-max ({what})')
+        assert e_fix <= 1.5 * e_run + 1e-3, f'{what}: the fixed offset must not cost accuracy ({e_fix:.2e} vs {e_run:.2e})'
+        # a generous bound (12 above the true maximum) only shifts exponents
+        o_far = torch.full_like(o_full, float('nan'))
+        L.attn_fwd(L.BF16, Qp, Kp, Vt, o_far, S, heads, n, n, 0, score_bound=bound + 12, **kw)
+        close(o_far.float(), ref, 1.2e-2, f'fixed-offset attention, loose bound ({what})')

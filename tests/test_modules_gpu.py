@@ -23,6 +23,7 @@ def _oracle_follows_product_ln_fold():
     """the bf16 oracle rounds where the product rounds: LayerNorm folded into the consuming GEMM unless PK_LN_FOLD=0"""
     from phenaki_pytorch_amd import attention
     O.LN_FOLD, O.LN_FOLD_FF, O.LN_FOLD_FF_MAX_ROWS = attention._LN_FOLD, bool(attention._LN_FOLD_FF), attention._LN_FOLD_FF_MAX_ROWS
+    O.ATTN_FIXED_OFFSET = attention._ATTN_FIXED
 
 # Tolerances.  fp32 mode is held to the north star directly: ids bit-exact (LFQ sign bits and gumbel argmax audited by the
 # oracle's own decision margin), logits / pixels 1e-3 relative.
@@ -254,9 +255,17 @@ def test_bf16_blocks_match_bf16_oracle():
     S, n = 2, 576
     x = torch.randn(S, n, D, generator=gen) * 1.5 + 0.1
     bias = O.continuous_position_bias(mg_sd, 'continuous_pos_bias.', (9, 8, 8))
-    ob, of = both(lambda: O.attention(mg_sd, 'transformer.layers.0.1.', x, heads=8, attn_bias=bias))
     xg = x.reshape(S * n, D).cuda()
-    check('maskgit self-attn n=576 bias', mg.transformer.layers[0][1].run(xg, S, n, L.BF16, attn_bias=mg.continuous_pos_bias(9, 8, 8)) - xg, ob, of)
+    from phenaki_pytorch_amd import attention as A
+    # as MaskGit passes it (a BiasSpec: relative-position table + fixed-offset softmax), and as a plain (heads, n, n) tensor (running-max
+    # flash loop): each against the oracle restating THAT softmax
+    for how, fixed, bias_arg in (('table', A._ATTN_FIXED, mg.continuous_pos_bias.spec(9, 8, 8)), ('matrix', False, mg.continuous_pos_bias(9, 8, 8))):
+        O.ATTN_FIXED_OFFSET = fixed
+        try:
+            ob, of = both(lambda: O.attention(mg_sd, 'transformer.layers.0.1.', x, heads=8, attn_bias=bias))
+        finally:
+            O.ATTN_FIXED_OFFSET = A._ATTN_FIXED
+        check(f'maskgit self-attn n=576 bias ({how})', mg.transformer.layers[0][1].run(xg, S, n, L.BF16, attn_bias=bias_arg) - xg, ob, of)
     ctx = weights.synthetic_context(2, 12, 768, seed=1, pad_last=3)
     tm = (ctx != 0).any(-1)
     ob, of = both(lambda: O.attention(mg_sd, 'transformer.layers.0.2.', x, heads=8, context=ctx, mask=tm))

@@ -29,3 +29,7 @@ def bench(name, fn, reps=20):
 bench('no bias', lambda: L.attn_fwd(L.BF16, Qp, Kp, Vt, o, S, h, n, n, 0))
 bench('full f32 bias', lambda: L.attn_fwd(L.BF16, Qp, Kp, Vt, o, S, h, n, n, 0, bias=full))
 bench('relative-position table', lambda: L.attn_fwd(L.BF16, Qp, Kp, Vt, o, S, h, n, n, 0, bias_table=tab))
+bound = 0.35 * 0.35 * 64 * 3 + tab[4]      # comfortably above any q.k of these operands
+bench('no bias, fixed offset', lambda: L.attn_fwd(L.BF16, Qp, Kp, Vt, o, S, h, n, n, 0, score_bound=bound))
+bench('full f32 bias, fixed offset', lambda: L.attn_fwd(L.BF16, Qp, Kp, Vt, o, S, h, n, n, 0, bias=full, score_bound=bound))
+bench('table, fixed offset', lambda: L.attn_fwd(L.BF16, Qp, Kp, Vt, o, S, h, n, n, 0, bias_table=tab, score_bound=bound))
