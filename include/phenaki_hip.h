@@ -52,11 +52,15 @@ int pk_gemm(int dtype, int a_is_f32, const void* A, int lda, const void* W, int 
  * stats_out [M][ceil(N/32)][2] f32 (or NULL): every 32-column chunk of every output row also leaves (sum, sum of squares) of its values
  * -- as stored in C2 when given, else in C -- for the LayerNorm-folded GEMM that reads those rows next; that GEMM passes the buffer as
  * ln_stats [M][ceil(K/32)][2] beside ln_s / ln_t and takes mean / rstd from it instead of from its own main loop (LDS-DMA variants
- * 8 / 24 / 33 / f32 3 only; partials are added in index order, so results do not depend on scheduling). */
+ * 8 / 24 / 33 / f32 3 only; partials are added in index order, so results do not depend on scheduling).
+ * dup_rows (0, or >= M): every output row m of C (and C2) is also written at row m + dup_rows -- the to_out GEMM of the first
+ * self-attention block of a classifier-free-guidance batch writes the cond and the null copy of the residual stream at once
+ * (phenaki_pytorch.py:149-161: both forwards see the same ids; they differ from the first cross-attention on). */
 int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const void* W, int ldw, int M, int N, int K,
                const float* bias, const float* res, int ldr, void* C, int ldc, int out_is_f32, int act,
                const int* a_rows, int a_nrows, int variant, void* C2, int ldc2, const float* ln_s, const float* ln_t,
-               float ln_eps, const int* row_off, const int* col_off, float* stats_out, const float* ln_stats, void* stream);
+               float ln_eps, const int* row_off, const int* col_off, float* stats_out, const float* ln_stats, int dup_rows,
+               void* stream);
 /* the variant `0 = automatic` resolves to for a shape (host-only helper; used to label kernels in bench.py) */
 int pk_gemm_auto_variant(int dtype, int a_is_f32, int M, int N, int K, int lda, int ldw, int a_nrows);
 

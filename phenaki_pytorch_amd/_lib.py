@@ -23,7 +23,7 @@ _ULL = ctypes.c_ulonglong
 # name -> argtypes, kept in the order of include/phenaki_hip.h (tests check every symbol is exported)
 SIGNATURES = {
     'pk_gemm': [_I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P],
-    'pk_gemm_ex': [_I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P, _I, _P, _P, _F, _P, _P, _P, _P, _P],
+    'pk_gemm_ex': [_I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P, _I, _P, _P, _F, _P, _P, _P, _P, _I, _P],
     'pk_gemm_auto_variant': [_I, _I, _I, _I, _I, _I, _I, _I],
     'pk_layernorm': [_P, _I, _P, _P, _F, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'pk_l2norm_rows': [_P, _I, _P, _I, _I, _I, _I, _P],
@@ -122,13 +122,14 @@ def tdtype(dtype):
 # ----------------------------------------------------------------------------- wrappers
 
 def gemm(dtype, A, W, M, N, K, *, C, bias=None, res=None, act=ACT_NONE, a_rows=None, lda=None, ldc=None, variant=0, C2=None, ln=None,
-         scatter=None, stats_out=None, ln_stats=None):
+         scatter=None, stats_out=None, ln_stats=None, dup_rows=0):
     """C = act(A @ W^T + bias) (+ res).  A: (rows, K) f32 or T; W: (N, Kpad) T; C preallocated.
     a_rows gathers rows of A (A.shape[0] physical rows bound the DMA descriptor).
     C2: optional bf16 copy of an f32 C.  ln = (s, t, eps): the LayerNorm in front of this Linear folded in (A = the un-normalised
     rows, W = gamma (.) W, s / t its (N,) correction vectors).  scatter = (row_off (M,) int32, col_off (N,) int32): element (m, n) is
     written to C.view(-1)[row_off[m] + col_off[n]] (f32 C of any shape; the un-patchify map).  stats_out (M, ceil(N/32), 2) f32: per-chunk
-    (sum, sum of squares) of every output row for the LayerNorm-folded GEMM that consumes it, which passes the same buffer as ln_stats."""
+    (sum, sum of squares) of every output row for the LayerNorm-folded GEMM that consumes it, which passes the same buffer as ln_stats.
+    dup_rows: every output row m of C / C2 is also written at row m + dup_rows."""
     a_is_f32 = 1 if A.dtype == torch.float32 else 0
     out_is_f32 = 1 if C.dtype == torch.float32 else 0
     lda = A.stride(-2) if lda is None else lda
@@ -138,7 +139,7 @@ def gemm(dtype, A, W, M, N, K, *, C, bias=None, res=None, act=ACT_NONE, a_rows=N
                            ptr(C), ldc, out_is_f32, act, ptr(a_rows), A.shape[0] if a_rows is not None else M, variant,
                            ptr(C2), C2.stride(-2) if C2 is not None else 0, ptr(ln[0]) if ln else None, ptr(ln[1]) if ln else None,
                            float(ln[2]) if ln else 0., ptr(scatter[0]) if scatter else None, ptr(scatter[1]) if scatter else None,
-                           ptr(stats_out) if stats_out is not None else None, ptr(ln_stats) if ln_stats is not None else None, stream(C))
+                           ptr(stats_out) if stats_out is not None else None, ptr(ln_stats) if ln_stats is not None else None, int(dup_rows), stream(C))
     _check(rc, 'pk_gemm_ex')
     return C
 

@@ -418,6 +418,8 @@ _SHORT_FUSED = os.environ.get('PK_QKV_ATTN', '1') != '0'
 _CROSS_FUSED = os.environ.get('PK_CROSS_FUSED', '1') != '0'
 # PK_BIAS_TABLE=0: the n >= 64 attention kernel streams the full (heads, n, n) position bias instead of its relative-position table
 _BIAS_TABLE = os.environ.get('PK_BIAS_TABLE', '1') != '0' and os.environ.get('PK_ATTN_LDS', '1') != '0'
+# PK_CFG_SHARED_PREFIX=0: the cond | null halves of a CFG batch run layer 0's PEG + self-attention separately (they are identical there)
+_CFG_SHARED_PREFIX = os.environ.get('PK_CFG_SHARED_PREFIX', '1') != '0'
 # PK_ATTN_FIXED=0: the n > 64 attention kernel keeps a running maximum (flash) instead of the fixed-offset softmax (pk_attn_fwd score_bound)
 _ATTN_FIXED = os.environ.get('PK_ATTN_FIXED', '1') != '0'
 
@@ -464,16 +466,18 @@ class Attention(PackedModule):
         L.gemm(dtype, src, linear_weight(self.to_kv, dtype), Mk, 2 * inner, Dk, C=kv)
         return kv
 
-    def _finish(self, o, x2d, dtype, want_t):
+    def _finish(self, o, x2d, dtype, want_t, dup=1):
         """to_out projection + residual  [+ the bf16 copy of the result for the next block's folded LayerNorm; want_t == 'stats': and
-        the row statistics of that copy for a folded feed-forward LayerNorm -> (out, out_t, stats)]"""
+        the row statistics of that copy for a folded feed-forward LayerNorm -> (out, out_t, stats)].  dup = 2: the result (and its bf16
+        copy) is written twice, rows [0, M) and [M, 2M) -- the cond | null copies of a CFG batch that was identical up to here."""
         M, D = x2d.shape
-        out = torch.empty_like(x2d)
-        out_t = torch.empty((M, D), device=x2d.device, dtype=torch.bfloat16) if (want_t and dtype == L.BF16) else None
+        out = torch.empty((dup * M, D), device=x2d.device, dtype=torch.float32)
+        out_t = torch.empty((dup * M, D), device=x2d.device, dtype=torch.bfloat16) if (want_t and dtype == L.BF16) else None
         stats = None
-        if want_t == 'stats' and out_t is not None and D % 4 == 0:
+        if want_t == 'stats' and out_t is not None and D % 4 == 0 and dup == 1:
             stats = torch.empty((M, (D + 31) // 32, 2), device=x2d.device, dtype=torch.float32)
-        L.gemm(dtype, o, linear_weight(self.to_out, dtype), M, D, o.shape[1], C=out, res=x2d, C2=out_t, stats_out=stats)
+        L.gemm(dtype, o, linear_weight(self.to_out, dtype), M, D, o.shape[1], C=out, res=x2d, C2=out_t, stats_out=stats,
+               dup_rows=M if dup == 2 else 0)
         if want_t == 'stats':
             return out, out_t, stats
         return (out, out_t) if want_t else out
@@ -484,10 +488,10 @@ class Attention(PackedModule):
                                             [self.to_q.weight, self.norm.gamma, self.norm.beta])
         return (wg, s, t) if beta_zero else None
 
-    def run(self, x2d, S, n, dtype, *, context2d=None, n_ctx=None, attn_bias=None, kmask=None, kv_cache=None, xt=None, want_t=False):
+    def run(self, x2d, S, n, dtype, *, context2d=None, n_ctx=None, attn_bias=None, kmask=None, kv_cache=None, xt=None, want_t=False, dup=1):
         """x2d (S*n, D) f32 -> attention(x) + x.  kmask: (S, n_kv) uint8/bool over the real keys or None.
         xt: the bf16 copy of x2d its producer wrote (bf16 mode: the block's LayerNorm is folded into to_q, K / V read the same
-        un-normalised rows); want_t: return (out, bf16 copy of out)."""
+        un-normalised rows); want_t: return (out, bf16 copy of out).  dup = 2: the outputs hold the result twice (see _finish)."""
         dev = x2d.device
         td = L.tdtype(dtype)
         M, D = x2d.shape
@@ -528,7 +532,7 @@ class Attention(PackedModule):
                 o = torch.empty((M, inner), device=dev, dtype=td)
                 L.qkv_attn(xt, xt, wq, linear_weight(self.to_kv, dtype), S, n, h, D, self.q_scale, self.k_scale, float(self.scale), o,
                            bias=attn_bias, slopes=slopes, causal=self.causal, q_ln_s=sq)
-                return self._finish(o, x2d, dtype, want_t)
+                return self._finish(o, x2d, dtype, want_t, dup)
             nq_pad, nk_pad = L.attn_pads(n, n_kv, nnull)
             Qp = torch.empty((S * h * nq_pad * 64,), device=dev, dtype=td)
             if not is_cross and nnull == 0:
@@ -542,7 +546,7 @@ class Attention(PackedModule):
                     # few keys (the text context): query projection + attention against the cached images in ONE launch
                     o = torch.empty((M, inner), device=dev, dtype=td)
                     L.q_attn_cached(xt, wq, S, n, h, D, self.q_scale, float(self.scale), Kp, Vt, nk_pad, n_kv, nnull, o, kmask=kmask, q_ln_s=sq)
-                    return self._finish(o, x2d, dtype, want_t)
+                    return self._finish(o, x2d, dtype, want_t, dup)
                 L.qkv_project(xt, None, wq, None, S, n, h, D, self.q_scale, None, float(self.scale), Qp, None, None, nq_pad, nk_pad, q_ln_s=sq)
             else:
                 q = torch.empty((M, inner), device=dev, dtype=torch.float32)
@@ -556,7 +560,7 @@ class Attention(PackedModule):
             o = torch.empty((M, inner), device=dev, dtype=td)
             L.attn_fwd(dtype, Qp, Kp, Vt, o, S, h, n, n_kv, nnull, bias=attn_bias, kmask=kmask, slopes=slopes, causal=self.causal,
                        bias_table=bias_table, score_bound=score_bound)
-            return self._finish(o, x2d, dtype, want_t)
+            return self._finish(o, x2d, dtype, want_t, dup)
 
         # ---- separate LayerNorm launch (exact-f32 mode; bf16 with PK_LN_FOLD=0)
         xn = torch.empty((M, D), device=dev, dtype=td)
@@ -575,7 +579,7 @@ class Attention(PackedModule):
             o = torch.empty((M, inner), device=dev, dtype=td)
             L.qkv_attn(xn, xraw, linear_weight(self.to_q, dtype), linear_weight(self.to_kv, dtype), S, n, h, D, self.q_scale,
                        self.k_scale, float(self.scale), o, bias=attn_bias, slopes=slopes, causal=self.causal)
-            return self._finish(o, x2d, dtype, want_t)
+            return self._finish(o, x2d, dtype, want_t, dup)
 
         q = None
         if not fused:
@@ -590,7 +594,7 @@ class Attention(PackedModule):
             o = torch.empty((M, inner), device=dev, dtype=td)
             L.attn_small(q, kv, self.q_scale, self.k_scale, float(self.scale), o, S, h, n, bias=attn_bias, kmask=kmask,
                          slopes=slopes, causal=self.causal)
-            return self._finish(o, x2d, dtype, want_t)
+            return self._finish(o, x2d, dtype, want_t, dup)
 
         nq_pad, nk_pad = L.attn_pads(n, n_kv, nnull)
         Qp = torch.empty((S * h * nq_pad * 64,), device=dev, dtype=td)
@@ -618,7 +622,7 @@ class Attention(PackedModule):
         o = torch.empty((M, inner), device=dev, dtype=td)
         L.attn_fwd(dtype, Qp, Kp, Vt, o, S, h, n, n_kv, nnull, bias=attn_bias, kmask=kmask, slopes=slopes, causal=self.causal,
                    bias_table=bias_table, score_bound=score_bound)
-        return self._finish(o, x2d, dtype, want_t)
+        return self._finish(o, x2d, dtype, want_t, dup)
 
     def forward(self, x, mask=None, context=None, attn_bias=None):
         L.require_device(x, 'x')
@@ -642,6 +646,14 @@ def _unpack(r):
 
 
 class Transformer(PackedModule):
+    def shares_cfg_prefix(self, dtype, context2d, self_attn_mask):
+        """True when run(..., replicas=2) may be used: bf16 with folded LayerNorms (the path that threads the bf16 copy), layer 0 has a
+        cross-attention that will run, and no per-sequence self-attention mask (the two copies must be identical up to there)."""
+        if not (_CFG_SHARED_PREFIX and ln_fold_enabled(dtype) and len(self.layers) > 0):
+            return False
+        cross = self.layers[0][2]
+        return exists(cross) and exists(context2d) and self_attn_mask is None
+
     """attention.py:279-332 : per layer [PEG?, self Attention, cross Attention?, FeedForward], each + residual; norm_out."""
 
     def __init__(self, dim, *, depth, dim_context=None, causal=False, dim_head=64, heads=8, ff_mult=4, peg=False,
@@ -660,24 +672,29 @@ class Transformer(PackedModule):
 
     def run(self, x2d, S, n, dtype, *, video_shape=None, attn_bias=None, context2d=None, n_ctx=None,
             self_attn_mask=None, cross_attn_context_mask=None, kv_cache=None, out=None, out_t=None, perm=(0, 0),
-            skip_norm_out=False, xt=None):
+            skip_norm_out=False, xt=None, replicas=1):
         """x2d (S*n, D) f32.  Writes norm_out(x) to `out` (f32) and/or `out_t` (T); returns `out` (allocated if both None).
         perm = (pb, pc): the output rows are written transposed, (a, b, c) -> (a, c, b).
         xt: the bf16 copy of x2d, if the producer already wrote one (bf16 mode; else the first block converts).
-        skip_norm_out: return the residual stream BEFORE norm_out (the caller fuses that LayerNorm into its next kernel)."""
+        skip_norm_out: return the residual stream BEFORE norm_out (the caller fuses that LayerNorm into its next kernel).
+        replicas = 2 (see shares_cfg_prefix): the S sequences are the cond | null copies of S / 2 sequences, identical until the first
+        cross-attention; x2d holds the S / 2 distinct ones, layer 0's PEG + self-attention run once and write both copies."""
         x = x2d
         fold = ln_fold_enabled(dtype)
         nl = len(self.layers)
+        assert replicas == 1 or self.shares_cfg_prefix(dtype, context2d, self_attn_mask), 'replicas: see shares_cfg_prefix'
+        S_cur = S // replicas
         for li, (peg, self_attn, cross_attn, ff) in enumerate(self.layers):
             if fold:
                 # bf16: a block whose LayerNorm is folded into its first GEMM reads the bf16 copy (xt) of the residual stream, which the
                 # block BEFORE it writes beside the f32 one (only when somebody will read it)
                 has_cross = exists(cross_attn) and exists(context2d)
                 if exists(peg):
-                    x, xt = peg.run(x, video_shape, want_t=True)
-                ff_wants = {0: False, 1: True, 2: 'stats'}[ff_fold_mode(x.shape[0])]      # what the block in front of the FF leaves for it
-                x, xt, stats = _unpack(self_attn.run(x, S, n, dtype, attn_bias=attn_bias, kmask=self_attn_mask, xt=xt,
-                                                     want_t=True if has_cross else ff_wants))
+                    x, xt = peg.run(x, video_shape if S_cur == S else (video_shape[0] * S_cur // S, *video_shape[1:]), want_t=True)
+                ff_wants = {0: False, 1: True, 2: 'stats'}[ff_fold_mode(S * n)]           # what the block in front of the FF leaves for it
+                x, xt, stats = _unpack(self_attn.run(x, S_cur, n, dtype, attn_bias=attn_bias, kmask=self_attn_mask, xt=xt,
+                                                     want_t=True if has_cross else ff_wants, dup=S // S_cur))
+                S_cur = S
                 if has_cross:
                     x, xt, stats = _unpack(cross_attn.run(x, S, n, dtype, context2d=context2d, n_ctx=n_ctx, kmask=cross_attn_context_mask,
                                                           kv_cache=kv_cache, xt=xt, want_t=ff_wants))

@@ -33,6 +33,10 @@ struct GemmEpilogue {
     // as the consumer will read them (the T-rounded C2 copy when there is one) -- to stats_out[m][chunk][2], chunk = column / 32; the
     // consumer (ln_s set, ln_stats set) adds the ceil(K / 32) partials of a row in index order: deterministic, no atomics.
     float* stats_out; const float* ln_stats; int stats_np;
+    // dup_rows > 0: every output row m is ALSO written at row m + dup_rows (C and C2).  The cond | null halves of a classifier-free-
+    // guidance batch are identical until the first cross-attention, so the first self-attention block runs on half the sequences and
+    // its to_out GEMM writes both copies of the residual stream.
+    int dup_rows;
 };
 
 constexpr int STATS_CHUNK = 32;      // columns per partial: the 16 * TN columns one wave owns in every TN = 2 kernel
@@ -161,6 +165,11 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[TM][TN], int M,
                     const size_t o = e.row_off ? (size_t)((long)roff[ii] + (long)coff[j]) : (size_t)m * e.ldc + n;
                     if (e.out_f32) store4(Cf + o, v); else store4(Ct + o, v);
                     if (e.C2) store4(reinterpret_cast<bf16*>(e.C2) + (size_t)m * e.ldc2 + n, v);
+                    if (e.dup_rows) {
+                        const size_t od = o + (size_t)e.dup_rows * e.ldc;
+                        if (e.out_f32) store4(Cf + od, v); else store4(Ct + od, v);
+                        if (e.C2) store4(reinterpret_cast<bf16*>(e.C2) + (size_t)(m + e.dup_rows) * e.ldc2 + n, v);
+                    }
                     if (TN == 2 && e.stats_out) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -343,7 +352,7 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
                           int M, int N, int K, const float* bias, const float* res, int ldr,
                           void* C, int ldc, int out_is_f32, int act, const int* a_rows, int a_nrows,
                           int variant, void* C2, int ldc2, const float* ln_s, const float* ln_t, float ln_eps,
-                          const int* row_off, const int* col_off, float* stats_out, const float* ln_stats, void* stream) {
+                          const int* row_off, const int* col_off, float* stats_out, const float* ln_stats, int dup_rows, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !C) return PK_EINVAL;
     if (dtype != 0 && dtype != 1) return PK_EINVAL;
     if (act < 0 || act > 2) return PK_EINVAL;
@@ -359,7 +368,7 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
     // k-rotation (gemm_dma.hpp): measured +12..33 % on the 65536-wide vocab-head shape, -0..13 % on the N <= 2736 shapes
     GemmOperands p{A, W, a_rows, lda, ldw, M, N, K, 0, N >= 8192 ? krot_default() : 0};
     GemmEpilogue e{bias, res, C, ldr, ldc, out_is_f32, act, 0, C2, ldc2, ln_s, ln_t, ln_eps, row_off, col_off, stats_out, ln_stats,
-                   ((ln_stats ? K : N) + STATS_CHUNK - 1) / STATS_CHUNK};
+                   ((ln_stats ? K : N) + STATS_CHUNK - 1) / STATS_CHUNK, dup_rows};
     bool v = (N % 4 == 0) && (ldc % 4 == 0) && al16(C) && (!bias || al16(bias)) && (!res || (al16(res) && ldr % 4 == 0));
     if (act == ACT_GEGLU) v = v && (ldc % 2 == 0) && ((reinterpret_cast<uintptr_t>(C) & 7) == 0);
     e.vec_ok = v ? 1 : 0;
@@ -369,6 +378,7 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
     if (row_off && (!v || !out_is_f32 || act == ACT_GEGLU || res || C2)) return PK_EINVAL;
     if (ln_stats && (!ln_s || stats_out || (reinterpret_cast<uintptr_t>(ln_stats) & 7))) return PK_EINVAL;
     if (stats_out && (!v || act == ACT_GEGLU || row_off || (reinterpret_cast<uintptr_t>(stats_out) & 7))) return PK_EINVAL;
+    if (dup_rows < 0 || (dup_rows && (!v || act == ACT_GEGLU || row_off || stats_out || dup_rows < M))) return PK_EINVAL;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
     const bool dma_ok = dma_possible(dtype, a_is_f32, N, K, lda, ldw, a_nrows);
@@ -430,8 +440,8 @@ extern "C" int pk_gemm(int dtype, int a_is_f32, const void* A, int lda, const vo
     if (a_rows) {
         const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128);
         return pk_gemm_ex(dtype, a_is_f32, A, lda, W, ldw, M, N, K, bias, res, ldr, C, ldc, out_is_f32, act, a_rows,
-                          0x7fffffff / (lda > 0 ? lda : 1) / 4, blocks128 >= 384 ? 2 : 1, nullptr, 0, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, stream);
+                          0x7fffffff / (lda > 0 ? lda : 1) / 4, blocks128 >= 384 ? 2 : 1, nullptr, 0, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, 0, stream);
     }
     return pk_gemm_ex(dtype, a_is_f32, A, lda, W, ldw, M, N, K, bias, res, ldr, C, ldc, out_is_f32, act, nullptr, M, 0,
-                      nullptr, 0, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, stream);
+                      nullptr, 0, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, 0, stream);
 }

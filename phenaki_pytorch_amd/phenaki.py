@@ -100,17 +100,21 @@ class _TokenTrunk(PackedModule):
         nb, n = ids2d.shape
         S = replicas * nb
         n_tot = n + (ids_prime.shape[-1] if ids_prime is not None else 0)
-        x = self._embed(ids2d, replicas, ids_prime)
         ctx2, n_ctx = None, None
         if use_cross and exists(context):
             n_ctx = context.shape[1]
             ctx2 = context.reshape(S * n_ctx, context.shape[-1])
             if ctx2.dtype != torch.float32 or not ctx2.is_contiguous():
                 ctx2 = ctx2.float().contiguous()
-        return self.transformer.run(x, S, n_tot, compute_dtype_of(self), video_shape=(S, *video_patch_shape),
+        dt = compute_dtype_of(self)
+        # the cond | null copies of a CFG batch see the same ids: until the first cross-attention they are the same rows, so layer 0's
+        # PEG + self-attention run on nb sequences and write both copies (Transformer.run replicas)
+        shared = replicas == 2 and self.transformer.shares_cfg_prefix(dt, ctx2, video_mask)
+        x = self._embed(ids2d, 1 if shared else replicas, ids_prime)
+        return self.transformer.run(x, S, n_tot, dt, video_shape=(S, *video_patch_shape),
                                     attn_bias=attn_bias, context2d=ctx2, n_ctx=n_ctx, self_attn_mask=_u8(video_mask),
                                     cross_attn_context_mask=_u8(text_mask) if ctx2 is not None else None,
-                                    kv_cache=kv_cache)
+                                    kv_cache=kv_cache, replicas=2 if shared else 1)
 
     def set_compute_dtype(self, name):
         return set_compute_dtype(self, name)

@@ -202,6 +202,44 @@ def test_maskgit_full_config_matches_oracle(dtype, tol, mtol):
     record_parity('maskgit_full_vs_oracle', dict(dtype=dtype, logits_rel_err=e_logits, critic_rel_err=e_critic, audited_argmax_flips=flips, **extra))
 
 
+def L_BF16():
+    from phenaki_pytorch_amd import _lib as L
+    return L.BF16
+
+
+@pytest.mark.parametrize('size', ['tiny', 'full'])
+def test_cfg_shared_prefix_equals_separate_replicas(size):
+    """the cond | null copies of a CFG batch are the same rows until the first cross-attention: running layer 0's PEG + self-attention
+    once and writing both copies (Transformer.run replicas = 2, pk_gemm_ex dup_rows) must give what two separate copies give."""
+    from phenaki_pytorch_amd import attention as A
+    cfg = TINY if size == 'tiny' else FULL
+    _, mg, cr, _ = load_product(size, cfg, dtype='bf16')
+    vps = (3, 4, 4) if size == 'tiny' else (9, 8, 8)
+    gen = torch.Generator().manual_seed(5)
+    B = 2
+    dctx = mg.transformer.layers[0][2].to_kv.weight.shape[1]
+    ctx = torch.randn(B, 5, dctx, generator=gen).cuda()
+    tm = torch.ones(B, 5, dtype=torch.bool).cuda()
+    rep = lambda t: torch.cat((t, t), dim=0)
+    for net in (mg, cr):
+        if not (hasattr(net, 'embeds') and net.transformer.layers[0][2] is not None):
+            continue
+        V = net.token_emb.weight.shape[0]
+        nn_ = vps[0] * vps[1] * vps[2]
+        ids = torch.randint(0, V, (B, nn_), generator=gen).cuda()
+        outs = []
+        for shared in (True, False):
+            A._CFG_SHARED_PREFIX = shared
+            try:
+                assert net.transformer.shares_cfg_prefix(L_BF16(), ctx.reshape(-1, dctx), None) == shared
+                e = net.embeds(ids, replicas=2, video_patch_shape=vps, context=rep(ctx), text_mask=torch.cat((tm, torch.zeros_like(tm)), 0))
+            finally:
+                A._CFG_SHARED_PREFIX = True
+            outs.append(e.float().cpu())
+        assert outs[0].shape == outs[1].shape and outs[0].shape[0] == 2 * B * nn_
+        close(outs[0], outs[1], 1e-6, f'{type(net).__name__}: shared CFG prefix vs separate replicas')
+
+
 def test_bf16_blocks_match_bf16_oracle():
     """every block type of the path at BASELINE geometry with its real (name-keyed) weights, fed the SAME input as
     oracle.precision('bf16'): one block's output agrees to BF16_BLOCK_MAX (max-norm) / BF16_BLOCK_RMS -- an order of magnitude
