@@ -819,10 +819,13 @@ extern "C" int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void
         // prefetch and the leaner kernel (5 waves/SIMD) wins, 8.1 vs 11.3 us
         static const int lds_qf = [] { const char* e = getenv("PK_ATTN_LDS_QF"); return e ? atoi(e) : 0; }();   // tuning knobs (0: automatic)
         static const int pf_env = [] { const char* e = getenv("PK_ATTN_PF"); return e ? atoi(e) : -1; }();
-        // fixed-offset softmax (below): 32 query rows per wave fit the register budget and 576 / 128 query blocks per (sequence, head)
-        // fit ONE round of workgroups: 28.3 vs 35.8 us (table), 23.9 vs 29.9 us (no bias); the running-max kernels stay at 16 rows
+        // fixed-offset softmax (below): 32 query rows per wave fit its register budget, and once 16-row waves would need more than one
+        // round of workgroups (3 per CU with the bias table in LDS) the 128-row workgroups win: S*h = 128, n = 576: 26.6 vs 35.8 us
+        // (table), 23.4 vs 29.9 (no bias); S*h = 96: 21.6 vs 30.1; at S*h <= 64 one round either way and 16 rows win (18.8 vs 20.5 us)
         const bool fix = score_bound == score_bound && fabsf(score_bound) < 1e4f && !kmask && !causal && !bias;
-        const int qf = ((lds_qf == 2 || (fix && lds_qf != 1)) && nq >= 128) ? 2 : 1;
+        static const int n_cu = [] { int dev = 0, cus = 256; if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); return cus > 0 ? cus : 256; }();
+        const long wgs16 = (long)S * h * ((nq_pad + 63) / 64);
+        const int qf = ((lds_qf == 2 || (fix && lds_qf != 1 && wgs16 > 3L * n_cu)) && nq >= 128) ? 2 : 1;
         const bool pf = pf_env >= 0 ? pf_env != 0 : (qf == 1 && nk_pad >= 192);
         const int qblocks = (nq_pad + 64 * qf - 1) / (64 * qf);
         const uint32_t kv_bytes = (uint32_t)((size_t)S * h * nk_pad * 128);

@@ -336,6 +336,9 @@ static int auto_variant(int dtype, int a_is_f32, int M, int N, int K, int lda, i
     // 128x128 once there are >= 256 of them (one per CU): measured in the sampling loop (M = 9216: to_out 288 tiles) +2.5 %
     // tokens/s over a 512 threshold; at 144 tiles (M = 4608, N = 512) the 64x64 kernel wins by 9 % (same-box A/B)
     static const long t128 = getenv("PK_GEMM_T128") ? atol(getenv("PK_GEMM_T128")) : 256;      // tuning knob
+    // 256..383 tiles of 128x128 with a short K (the sampling loop's to_out, M = 9216, N = K = 512: 288 tiles = 1.1 per CU): 128x64
+    // tiles give every CU 2+ workgroups -- 14.9 vs 17.0 us with the residual epilogue (8-wave 128x64 / 64x128 layouts: 16.5 us)
+    if (dtype == 1 && blocks128 >= t128 && blocks128 < 384 && K <= 1024) return 27;
     if (blocks128 >= t128) return 24;                                       // 128x128, 8 waves, 2 stages (16 waves/CU)
     if (K >= 2048) return dtype == 1 ? 33 : 3;      // long K (patch embed): 64x64, 3-stage ring fed by 2 producer waves (bf16) / 4 stages
     return 8;                                                               // 64x64, 2 stages (5 WG/CU)
@@ -347,7 +350,7 @@ extern "C" int pk_gemm_auto_variant(int dtype, int a_is_f32, int M, int N, int K
 }
 
 // variant: 0 = automatic; 1/2 = register-staged 64x64 / 128x128; 8 = DMA 64x64 2 stages; 9 / 24 = DMA 128x128 (4 / 8 waves);
-//          33 = DMA 64x64 with 2 producer waves, 3 stages (bf16); 3 = DMA 64x64 4 stages (f32)   (explicit: tools/gemm_bench.py)
+//          27 = DMA 128x64 4 waves (bf16); 33 = DMA 64x64 with 2 producer waves, 3 stages (bf16); 3 = DMA 64x64 4 stages (f32)   (explicit: tools/gemm_bench.py)
 extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const void* W, int ldw,
                           int M, int N, int K, const float* bias, const float* res, int ldr,
                           void* C, int ldc, int out_is_f32, int act, const int* a_rows, int a_nrows,
@@ -397,7 +400,7 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
         return big ? launch_dma<float, 4, 2, 2, 2, 4, 128, 0, 1>(p, e, a_nrows, s) : launch_dma<float, 2, 2, 2, 2, 2, 128, 0, 1>(p, e, a_nrows, s);
     }
     // stats_out is written by the TN = 2 LDS-DMA kernels only (one 32-column chunk per wave)
-    if (stats_out && !(dma_ok && (variant == 8 || variant == 24 || variant == 33 || (variant == 3 && dtype == 0)))) return PK_EINVAL;
+    if (stats_out && !(dma_ok && (variant == 8 || variant == 24 || variant == 27 || variant == 33 || (variant == 3 && dtype == 0)))) return PK_EINVAL;
     // the main-loop variants that survived round 1's sweep (profiles/gemm_variants*_r01.txt; the 35 losers -- deeper rings, k-tile 32,
     // 128x256 / 256x256 tiles, other wave layouts, other producer / consumer splits -- were deleted in round 2)
     if (dtype == 1) {
@@ -408,6 +411,7 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
             case 9: return launch_dma<bf16, 4, 4, 2>(p, e, a_nrows, s);                 // 128x128, 4 waves, 2 stages
             case 24: return launch_dma<bf16, 4, 2, 2, 2, 4>(p, e, a_nrows, s);          // 128x128, 8 waves (2x4), 2 stages (64 KB: 16 waves/CU)
             case 33: return launch_dma<bf16, 2, 2, 3, 2, 2, 128, 2>(p, e, a_nrows, s);  // 64x64, 4 consumers + 2 producers, 3 stages (long K)
+            case 27: return launch_dma<bf16, 4, 2, 2, 2, 2>(p, e, a_nrows, s);          // 128x64, 4 waves (wave tile 64x32), 2 stages (48 KB: 3 WG/CU)
             default: return PK_EINVAL;
         }
     }

@@ -4,9 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from phenaki_pytorch_amd import _lib as L
 from phenaki_pytorch_amd.attention import ContinuousPositionBias
 torch.manual_seed(0)
-S, h, n = 16, 8, 576
+S, h, n = int(os.environ.get('S', 16)), 8, int(os.environ.get('N', 576))
 cpb = ContinuousPositionBias(dim=64, heads=h, num_dims=3).cuda()
-full = cpb(9, 8, 8); tab = cpb.table(9, 8, 8)
+T = n // 64
+full = cpb(T, 8, 8); tab = cpb.table(T, 8, 8)
 Qp = (torch.randn(S * h * n * 64) * 0.35).cuda().to(torch.bfloat16)
 Kp = (torch.randn(S * h * n * 64) * 0.35).cuda().to(torch.bfloat16)
 Vt = torch.randn(S * h * n * 64).cuda().to(torch.bfloat16)

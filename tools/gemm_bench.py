@@ -24,7 +24,7 @@ SHAPES = [  # (M, N, K, note)
     (9216, 512, 1368, 'maskgit FF2'),
     (4608, 65536, 512, 'vocab head as plain GEMM'),
 ]
-VARIANTS = {8: 'd64s2', 9: 'd128s2', 24: 'd128w8s2', 33: 'pc64 4+2 s3'}
+VARIANTS = {8: 'd64s2', 9: 'd128s2', 24: 'd128w8s2', 27: 'd128x64w4', 33: 'pc64 4+2 s3'}
 
 
 def main():
