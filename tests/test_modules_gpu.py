@@ -371,8 +371,32 @@ def test_sample_fast_mode_is_seeded_and_shapes_match_readme():
     img = ph.sample_images(texts=['a', 'b'], cond_scale=5.)
     assert img.shape == (2, 3, 64, 64)
     from phenaki_pytorch_amd import make_video
+    torch.manual_seed(11)
     whole, scenes = make_video(ph, texts=['a', 'b', 'c'], num_frames=(5, 4, 4), prime_lengths=3)
     assert whole.shape == (1, 3, 13, 64, 64) and len(scenes) == 3
+    # make_video's own chaining (phenaki_pytorch.py:691-714: one text per scene, the last K frames of a scene prime the next, the last
+    # scene primes nothing) against the hand-written loop the primed reference golden validates scene by scene
+    torch.manual_seed(11)
+    prime, manual = None, []
+    for text, nf, k in zip(['a', 'b', 'c'], (5, 4, 4), (3, 3, 0)):
+        v = ph.sample(texts=text, prime_frames=prime, num_frames=nf)
+        manual.append(v)
+        prime = v[:, :, -k:]            # (k = 0 takes the whole scene, exactly as the reference's slice does; it is never used)
+    for a, b in zip(scenes, manual):
+        assert torch.equal(a, b)
+    assert torch.equal(whole, torch.cat(manual, dim=2))
+    # per-scene prime lengths and the hipGraph launch mode give the same videos
+    torch.manual_seed(12)
+    w1, _ = make_video(ph, texts=['a', 'b', 'c'], num_frames=(5, 4, 4), prime_lengths=(3, 1))
+    ph.enable_sample_graph(True)
+    try:
+        torch.manual_seed(12)
+        w2, _ = make_video(ph, texts=['a', 'b', 'c'], num_frames=(5, 4, 4), prime_lengths=(3, 1))
+        torch.manual_seed(12)
+        w3, _ = make_video(ph, texts=['a', 'b', 'c'], num_frames=(5, 4, 4), prime_lengths=(3, 1))
+    finally:
+        ph.enable_sample_graph(False)
+    assert torch.equal(w1, w2) and torch.equal(w2, w3), 'make_video: captured-graph launches must reproduce the eager videos'
 
 
 def test_self_token_critic_and_unconditional_paths_run():
