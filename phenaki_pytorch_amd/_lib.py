@@ -100,10 +100,17 @@ def stream(t=None):
     if t is None:
         return torch.cuda.current_stream().cuda_stream
     idx = t.device.index
-    if idx is not None and idx != torch.cuda.current_device():
-        raise RuntimeError(f'operand on cuda:{idx} but the current device is cuda:{torch.cuda.current_device()}: '
+    cur = _current_device()
+    if idx is not None and idx != cur:
+        raise RuntimeError(f'operand on cuda:{idx} but the current device is cuda:{cur}: '
                            'call torch.cuda.set_device(...) first (one process per GPU)')
-    return torch.cuda.current_stream(t.device).cuda_stream
+    # the raw handle straight from the C binding: torch.cuda.current_stream() builds a Stream object per call (5.7 us -- more than
+    # a third of the host cost of a launch when the sampling loop is launch-bound at small batches)
+    return _raw_stream(cur)
+
+
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None) or (lambda i: torch.cuda.current_stream(i).cuda_stream)
+_current_device = getattr(torch._C, '_cuda_getDevice', None) or torch.cuda.current_device
 
 
 def require_device(t, name='tensor'):
