@@ -129,6 +129,15 @@ struct AttnArgs {
 };
 
 constexpr float ATTN_LOG2E = 1.4426950408889634f;
+#ifdef PK_TIMELINE
+// instrumented build only (tools/build_alt.sh with PK_ALT_SRC=attn; tools/attn_timeline.py): s_memtime stamps of wave 0 of a few workgroups
+__device__ unsigned long long pk_attn_tl[8 * 6 * 16];
+#define PK_ATL(slot) do { if (tl_on && t < 14) pk_attn_tl[(tl_wg * 16 + t) * 6 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PK_ATL_K(slot) do { if (tl_on) pk_attn_tl[(tl_wg * 16 + 15) * 6 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PK_ATL(slot) do {} while (0)
+#define PK_ATL_K(slot) do {} while (0)
+#endif
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));      // 8-byte LDS read at dword alignment (ds_read2_b32)
 
 __device__ __forceinline__ void load_vt(Frag<bf16>& f, const bf16* row, int kb, int g) {
@@ -363,6 +372,12 @@ typedef __attribute__((address_space(3))) void* attn_lds_ptr;
 template <int QF, bool PF, bool TAB = false, bool FIX = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (PF ? 4 : (TAB ? 3 : 5)) : ((FIX && !TAB) ? 4 : 3)))) void attn_fwd_lds_kernel(const AttnArgs p, uint32_t kv_bytes) {
     constexpr int STAGES = 2;
+#ifdef PK_TIMELINE
+    const int tl_wg = blockIdx.x == 0 ? 0 : blockIdx.x == 8 ? 1 : blockIdx.x == 1 ? 2 : blockIdx.x == gridDim.x / 2 ? 3 :
+                      blockIdx.x == gridDim.x - 8 ? 4 : blockIdx.x == 256 ? 5 : blockIdx.x == 300 ? 6 : blockIdx.x == 511 ? 7 : -1;
+    const bool tl_on = tl_wg >= 0 && threadIdx.x == 0;
+    PK_ATL_K(0);
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];          // STAGES x (K 8 KB | V^T 8 KB) [| bias table | position codes]
     constexpr int STAGE = 16384;
     float* tab = reinterpret_cast<float*>(smem + STAGES * STAGE);         // TAB: this head's bias table, then the position codes of all keys
@@ -423,11 +438,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
     for (int qf = 0; qf < QF; ++qf) { const int qi = q0 + qf * 16 + lr; qrow[qf] = qi < p.nq ? qi : p.nq - 1; }
     int cq[QF];                                                            // TAB: position code of the lane's query row(s) + offset
     if (TAB) {
+        // staging loads are issued in batches of 8 independent requests per thread: written as one load -> store per iteration the
+        // 15 trips of the 3825-entry table were 15 dependent L2 / HBM round trips -- 11.4 k of the kernel's 46 k cycles (s_memtime
+        // timeline, tools/attn_timeline.py) before the first key tile
         const float* src = p.bias_tab + (size_t)hh * p.tab_len;
-        for (int i = threadIdx.x; i < p.tab_len; i += 256) tab[i] = FIX ? fmaf(src[i], ATTN_LOG2E, -p.off2) : src[i];
-        for (int i = threadIdx.x; i < p.n_kv; i += 256) codes[i] = p.pos_code[i];
 #pragma unroll
         for (int qf = 0; qf < QF; ++qf) cq[qf] = p.pos_code[qrow[qf]] + p.code_off;
+        for (int i0 = threadIdx.x; i0 < p.tab_len; i0 += 8 * 256) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256; v[u] = i < p.tab_len ? src[i] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256; if (i < p.tab_len) tab[i] = FIX ? fmaf(v[u], ATTN_LOG2E, -p.off2) : v[u]; }
+        }
+        for (int i0 = threadIdx.x; i0 < p.n_kv; i0 += 4 * 256) {
+            int v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * 256; v[u] = i < p.n_kv ? p.pos_code[i] : 0; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * 256; if (i < p.n_kv) codes[i] = v[u]; }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // visible to every wave after the first barrier of the loop
     }
 
@@ -448,9 +478,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
         if (s0 < ntiles) issue(s0 * 64, s0);
     for (int t = 0; t < ntiles; ++t) {
         const int kb = t * 64;
+        PK_ATL(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PK_ATL(1);
         __builtin_amdgcn_s_barrier();                     // tile t landed for all waves; everyone finished tile t-1
+        PK_ATL(2);
         if (t + STAGES - 1 < ntiles) issue(kb + (STAGES - 1) * 64, (t + STAGES - 1) % STAGES);
+        PK_ATL(3);
         if (kb + 64 > nk) {
             // tail tile (wave-uniform, at most once per workgroup): the V^T columns of keys >= nk carry p = 0 but may hold anything
             // (pk_qkv_project never writes them; 0 * NaN = NaN) -> zero them in the LDS image, all 256 threads, one extra barrier.
@@ -487,6 +521,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
                 for (int qf = 0; qf < QF; ++qf) st[qf][f] = mma(fk, fq[qf][c], st[qf][f]);
             }
         float pr[QF][16];
+        PK_ATL(4);
 #pragma unroll
         for (int qf = 0; qf < QF; ++qf) {
             const int qi = q0 + qf * 16 + lr;
@@ -611,7 +646,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
 #pragma unroll
                 for (int f = 0; f < 4; ++f) bz[qf][f] = bzn[qf][f];
         }
+        PK_ATL(5);
     }
+    PK_ATL_K(1);
     if (!active) return;
     float* Of = reinterpret_cast<float*>(p.O);
     bf16* Ot = reinterpret_cast<bf16*>(p.O);
@@ -789,6 +826,14 @@ extern "C" int pk_attn_prep(int dtype, const float* q, int ldq, const float* kv,
     return PK_OK;
 }
 
+#ifdef PK_TIMELINE
+extern "C" int pk_debug_attn_timeline(unsigned long long* out, int n, int clear) {
+    if (hipDeviceSynchronize() != hipSuccess) return PK_ELAUNCH;
+    if (clear) { static unsigned long long z[8 * 6 * 16] = {}; return hipMemcpyToSymbol(HIP_SYMBOL(pk_attn_tl), z, sizeof(z)) == hipSuccess ? PK_OK : PK_ELAUNCH; }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pk_attn_tl), sizeof(unsigned long long) * n) == hipSuccess ? PK_OK : PK_ELAUNCH;
+}
+#endif
+
 extern "C" int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void* Vt,
                            const float* bias, long bias_hstride, int bias_ld, const unsigned char* kmask,
                            const float* slopes, int causal, void* O, int ldo, int out_is_f32,
@@ -823,7 +868,7 @@ extern "C" int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void
         // round of workgroups (3 per CU with the bias table in LDS) the 128-row workgroups win: S*h = 128, n = 576: 26.6 vs 35.8 us
         // (table), 23.4 vs 29.9 (no bias); S*h = 96: 21.6 vs 30.1; at S*h <= 64 one round either way and 16 rows win (18.8 vs 20.5 us)
         const bool fix = score_bound == score_bound && fabsf(score_bound) < 1e4f && !kmask && !causal && !bias;
-        static const int n_cu = [] { int dev = 0, cus = 256; if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); return cus > 0 ? cus : 256; }();
+        static const int n_cu = [] { int dev = 0, cus = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256; return cus > 0 ? cus : 256; }();
         const long wgs16 = (long)S * h * ((nq_pad + 63) / 64);
         const int qf = ((lds_qf == 2 || (fix && lds_qf != 1 && wgs16 > 3L * n_cu)) && nq >= 128) ? 2 : 1;
         const bool pf = pf_env >= 0 ? pf_env != 0 : (qf == 1 && nk_pad >= 192);
