@@ -85,20 +85,34 @@ __global__ __launch_bounds__(64 * VWM * VWN) void vocab_sample_kernel(const Gemm
     // LDS scratch (the GEMM stages are dead after run()'s final barrier): [wn][128 rows][5 words]
     float* red = reinterpret_cast<float*>(smem);
     const int V = p.N;
+    // the bias vectors of the lane's columns and the logical row numbers are loaded ONCE, ahead of the row-block loop (inside it each
+    // was a dependent L2 round trip per 16x16 block)
+    f32x4 bvj[VTN];
+#pragma unroll
+    for (int j = 0; j < VTN; ++j) {
+        const int n = n0 + wn * 16 * VTN + j * 16 + g * 4;
+        bvj[j] = n < V ? *reinterpret_cast<const f32x4*>(e.bias + n) : f32x4{0, 0, 0, 0};         // V % 4 == 0 (host check)
+    }
+    long lrows[VTM];
+#pragma unroll
+    for (int i = 0; i < VTM; ++i) {
+        const int m = m0 + wm * 16 * VTM + i * 16 + lr;
+        lrows[i] = m < p.M ? (e.rows ? e.rows[m] : m) : 0;
+    }
 #pragma unroll
     for (int i = 0; i < VTM; ++i) {
         const int ml = wm * 16 * VTM + i * 16 + lr;
         const int m = m0 + ml;
         const bool mok = m < p.M;
-        const long lrow = mok ? (e.rows ? e.rows[m] : m) : 0;
+        const long lrow = lrows[i];
         float best = -INFINITY, blog = 0.f, lmax = -INFINITY;
         int bidx = 0x7fffffff;
         float lg[4 * VTN];
 #pragma unroll
         for (int j = 0; j < VTN; ++j) {
             const int n = n0 + wn * 16 * VTN + j * 16 + g * 4;
-            f32x4 bv = f32x4{0, 0, 0, 0}, uv = f32x4{0.5f, 0.5f, 0.5f, 0.5f};
-            if (n < V) bv = *reinterpret_cast<const f32x4*>(e.bias + n);         // V % 4 == 0 (host check)
+            const f32x4 bv = bvj[j];
+            f32x4 uv = f32x4{0.5f, 0.5f, 0.5f, 0.5f};
             if (PARITY) { if (mok && n < V) uv = *reinterpret_cast<const f32x4*>(e.U + (size_t)lrow * V + n); }
             float uf[4] = {0.5f, 0.5f, 0.5f, 0.5f};
             if (!PARITY && !e.no_noise) {
