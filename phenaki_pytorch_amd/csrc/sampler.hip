@@ -200,16 +200,27 @@ __global__ __launch_bounds__(256) void vocab_reduce_kernel(const float* __restri
     float best = -INFINITY, blog = 0.f, lmax = -INFINITY, lsum = 0.f;
     int bidx = 0x7fffffff;
     if (m < M) {
-        for (int t = tg; t < ntiles; t += 8) {
-            const size_t o = (size_t)t * M + m;
-            const float v = p_val[o];
-            const int ix = p_idx[o];
-            if (v > best || (v == best && ix < bidx)) { best = v; bidx = ix; blog = p_logit[o]; }
-            if (need_lse) {
-                const float om = p_max[o], os = p_sum[o];
-                const float nm = fmaxf(lmax, om);
-                lsum = (lmax == -INFINITY ? 0.f : lsum * __expf(lmax - nm)) + (om == -INFINITY ? 0.f : os * __expf(om - nm));
-                lmax = nm;
+        // 8 tiles' partials are requested together and folded in tile order: one load -> compare chain per tile was 64 dependent
+        // round trips per thread (the kernel ran at 1.3 TB/s on 28 MB)
+        for (int t0 = tg; t0 < ntiles; t0 += 64) {
+            float v[8], lg[8], om[8], os[8];
+            int ix[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u * 8;
+                const size_t o = (size_t)(t < ntiles ? t : tg) * M + m;
+                v[u] = p_val[o]; ix[u] = p_idx[o]; lg[u] = p_logit[o];
+                if (need_lse) { om[u] = p_max[o]; os[u] = p_sum[o]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (t0 + u * 8 >= ntiles) break;
+                if (v[u] > best || (v[u] == best && ix[u] < bidx)) { best = v[u]; bidx = ix[u]; blog = lg[u]; }
+                if (need_lse) {
+                    const float nm = fmaxf(lmax, om[u]);
+                    lsum = (lmax == -INFINITY ? 0.f : lsum * __expf(lmax - nm)) + (om[u] == -INFINITY ? 0.f : os[u] * __expf(om[u] - nm));
+                    lmax = nm;
+                }
             }
         }
     }
