@@ -63,7 +63,8 @@ def _lin(x, w):
 LN_FOLD = True
 LN_FOLD_FF = False          # the feed-forward LayerNorm is folded into FF1 ...
 LN_FOLD_FF_MAX_ROWS = 0     # ... for inputs of at most this many rows (0: no limit); the tests copy both from the product's settings
-ATTN_FIXED_OFFSET = True    # long self-attention (n > 64, no masks): p = 2^(s log2e - integer) instead of the running-max flash loop
+ATTN_FIXED_OFFSET = True    # long self-attention (n > 64, no masks): p = 2^(s log2e - integer) instead of the running-max flash loop ...
+ATTN_FIXED_OFFSET_BIAS = True   # ... also when it carries a position bias (the product needs its relative-position table for that)
 _ROWS_SCALE = [1]           # the product runs the cond | null halves of a CFG step as ONE batch: its row count is twice this oracle's
 
 
@@ -177,7 +178,8 @@ def attention(sd, p, x, *, heads, causal=False, mask=None, context=None, attn_bi
         sim = sim + alibi_bias(heads, i, j)
         cm = torch.ones((i, j), dtype=torch.bool).triu(j - i + 1)
         sim = sim.masked_fill(cm, NEG_MAX)
-    if is_bf16() and ATTN_FIXED_OFFSET and context is None and nnull == 0 and mask is None and not causal and i > 64:
+    fixed = ATTN_FIXED_OFFSET and (attn_bias is None or ATTN_FIXED_OFFSET_BIAS)
+    if is_bf16() and fixed and context is None and nnull == 0 and mask is None and not causal and i > 64:
         # the product's fixed-offset softmax (pk_attn_fwd score_bound): an INTEGER exponent shift, so the mantissa of every p -- and
         # its bf16 rounding -- does not depend on which integer is used; numerator and row sum both use the ROUNDED p (the row sum is
         # one more MFMA block against a V^T block of ones)

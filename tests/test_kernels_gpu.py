@@ -20,6 +20,7 @@ def _oracle_follows_product_ln_fold():
     from phenaki_pytorch_amd import attention
     O.LN_FOLD, O.LN_FOLD_FF, O.LN_FOLD_FF_MAX_ROWS = attention._LN_FOLD, bool(attention._LN_FOLD_FF), attention._LN_FOLD_FF_MAX_ROWS
     O.ATTN_FIXED_OFFSET = attention._ATTN_FIXED
+    O.ATTN_FIXED_OFFSET_BIAS = attention._ATTN_FIXED and attention._BIAS_TABLE
 
 
 @pytest.fixture(scope='module')

@@ -24,6 +24,7 @@ def _oracle_follows_product_ln_fold():
     from phenaki_pytorch_amd import attention
     O.LN_FOLD, O.LN_FOLD_FF, O.LN_FOLD_FF_MAX_ROWS = attention._LN_FOLD, bool(attention._LN_FOLD_FF), attention._LN_FOLD_FF_MAX_ROWS
     O.ATTN_FIXED_OFFSET = attention._ATTN_FIXED
+    O.ATTN_FIXED_OFFSET_BIAS = attention._ATTN_FIXED and attention._BIAS_TABLE
 
 # Tolerances.  fp32 mode is held to the north star directly: ids bit-exact (LFQ sign bits and gumbel argmax audited by the
 # oracle's own decision margin), logits / pixels 1e-3 relative.
@@ -231,7 +232,7 @@ def test_cfg_shared_prefix_equals_separate_replicas(size):
         for shared in (True, False):
             A._CFG_SHARED_PREFIX = shared
             try:
-                assert net.transformer.shares_cfg_prefix(L_BF16(), ctx.reshape(-1, dctx), None) == shared
+                assert net.transformer.shares_cfg_prefix(L_BF16(), ctx.reshape(-1, dctx), None) == (shared and A.ln_fold_enabled(L_BF16()))
                 e = net.embeds(ids, replicas=2, video_patch_shape=vps, context=rep(ctx), text_mask=torch.cat((tm, torch.zeros_like(tm)), 0))
             finally:
                 A._CFG_SHARED_PREFIX = True
@@ -297,12 +298,13 @@ def test_bf16_blocks_match_bf16_oracle():
     from phenaki_pytorch_amd import attention as A
     # as MaskGit passes it (a BiasSpec: relative-position table + fixed-offset softmax), and as a plain (heads, n, n) tensor (running-max
     # flash loop): each against the oracle restating THAT softmax
-    for how, fixed, bias_arg in (('table', A._ATTN_FIXED, mg.continuous_pos_bias.spec(9, 8, 8)), ('matrix', False, mg.continuous_pos_bias(9, 8, 8))):
-        O.ATTN_FIXED_OFFSET = fixed
+    for how, fixed, bias_arg in (('table', A._ATTN_FIXED and A._BIAS_TABLE, mg.continuous_pos_bias.spec(9, 8, 8)),
+                                 ('matrix', False, mg.continuous_pos_bias(9, 8, 8))):
+        O.ATTN_FIXED_OFFSET_BIAS = fixed
         try:
             ob, of = both(lambda: O.attention(mg_sd, 'transformer.layers.0.1.', x, heads=8, attn_bias=bias))
         finally:
-            O.ATTN_FIXED_OFFSET = A._ATTN_FIXED
+            O.ATTN_FIXED_OFFSET_BIAS = A._ATTN_FIXED and A._BIAS_TABLE
         check(f'maskgit self-attn n=576 bias ({how})', mg.transformer.layers[0][1].run(xg, S, n, L.BF16, attn_bias=bias_arg) - xg, ob, of)
     ctx = weights.synthetic_context(2, 12, 768, seed=1, pad_last=3)
     tm = (ctx != 0).any(-1)
