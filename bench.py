@@ -70,11 +70,17 @@ def init_dist(n):
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     ws = int(os.environ.get('WORLD_SIZE', 1))
+    one_device = bool(os.environ.get('PK_BENCH_ONE_DEVICE'))   # dry run of the N > 1 code path on a 1-GPU box: every rank on cuda:0,
+    if one_device:                                              # gloo instead of RCCL (which refuses two ranks on one device)
+        local = 0
     if ws > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', rank=rank, world_size=ws, device_id=torch.device('cuda', local))
+        if one_device:
+            dist.init_process_group('gloo', rank=rank, world_size=ws)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=ws, device_id=torch.device('cuda', local))
     else:
         torch.cuda.set_device(0)
     assert ws == n or ws == 1, f'--gpus {n} but WORLD_SIZE={ws}'
