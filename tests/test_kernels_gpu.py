@@ -705,6 +705,34 @@ def test_gemm_row_stats_handoff(L, mode, M, N, K, D, variant):
 
 
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('M,N,K,variant', [(200, 96, 64, 0), (4608, 512, 512, 0), (9216, 512, 512, 27), (333, 128, 192, 24)])
+def test_gemm_dup_rows(L, mode, M, N, K, variant):
+    """pk_gemm_ex dup_rows: every output row of C (and of its bf16 copy C2) is written a second time dup_rows rows further down -- the
+    cond | null copies of a CFG batch from ONE to_out GEMM; rows outside both copies stay untouched."""
+    from phenaki_pytorch_amd import attention as A
+    if mode == 'f32' and variant in (27,):
+        pytest.skip('bf16-only tile')
+    dt = L.F32 if mode == 'f32' else L.BF16
+    td = L.tdtype(dt)
+    cast = (lambda t: t) if mode == 'f32' else bf
+    x = torch.randn(M, K, generator=g(120))
+    W = torch.randn(N, K, generator=g(121)) / math.sqrt(K)
+    res = torch.randn(M, N, generator=g(122))
+    gap = 5                                                     # the second copy need not be adjacent
+    C = torch.full((2 * M + gap, N), float('nan'), device='cuda')
+    C2 = torch.full((2 * M + gap, N), float('nan'), device='cuda', dtype=torch.bfloat16) if mode == 'bf16' else None
+    L.gemm(dt, x.cuda().to(td), A.pack_linear_weight(W.cuda(), dt), M, N, K, C=C, res=res.cuda(), C2=C2, dup_rows=M + gap, variant=variant)
+    ref = cast(x) @ cast(W).t() + res
+    close(C[:M], ref, 3e-5, 'first copy')
+    assert torch.equal(C[M + gap:], C[:M]), 'the second copy must be bit-identical'
+    assert torch.isnan(C[M:M + gap]).all()
+    if C2 is not None:
+        assert torch.equal(C2[:M].float(), bf(C[:M].cpu()).cuda()) and torch.equal(C2[M + gap:], C2[:M]) and torch.isnan(C2[M:M + gap].float()).all()
+    with pytest.raises(RuntimeError):                            # a second copy that would overlap the first is refused
+        L.gemm(dt, x.cuda().to(td), A.pack_linear_weight(W.cuda(), dt), M, N, K, C=C, res=res.cuda(), dup_rows=M - 1, variant=variant)
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
 @pytest.mark.parametrize('B,T,pt,hw,p,variant', [(2, 3, 2, 4, 8, 0), (1, 2, 2, 8, 4, 0), (3, 1, 1, 2, 8, 1), (2, 3, 2, 4, 8, 24)])
 def test_gemm_scatter_epilogue_unpatchify(L, mode, B, T, pt, hw, p, variant):
     """pk_gemm_ex row_off / col_off: the gathered to_pixels GEMM writes 'b t h w (c pt p1 p2) -> b c (t pt) (h p1) (w p2)' in place
