@@ -22,22 +22,27 @@ struct QkvArgs {
     const float* q_ln_s;                    // LayerNorm folded into to_q: xq holds the UN-normalised rows, wq = gamma (.) Wq, q_ln_s[n] = sum_k wq[n][k]
 };
 
-using QkvTile = GemmDma<bf16, 1, 4, 4, 1, 2, 128>;
+// TM = 1: 64-row tiles (wave tile 16 x 64); TM = 2: 128-row tiles (wave tile 32 x 64) -- the kernel is bound by the L1 -> LDS fill path
+// (3456 tiles x 128 KB = 442 MB per launch at 2 x 8 x 576 rows) and a 128-row tile moves 24 KB per k-tile for the work of two 64-row
+// tiles (2 x 16 KB): a quarter less fill traffic, still 48 KB of LDS = 3 workgroups per CU
+template <int TM> using QkvTileT = GemmDma<bf16, TM, 4, 4, 1, 2, 128>;
 
+template <int TM>
 __global__ __launch_bounds__(256) void qkv_project_kernel(const QkvArgs a) {
+    using QkvTile = QkvTileT<TM>;
+    constexpr int BM = 64 * TM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware tile map (see gemm.hip): XCD x owns a contiguous chunk of row tiles and walks all column tiles for it
-    const int MT = (a.M + 63) / 64, cmax = (MT + 7) / 8;
+    const int MT = (a.M + BM - 1) / BM, cmax = (MT + 7) / 8;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int mstart = xcd * MT / 8, mcount = (xcd + 1) * MT / 8 - mstart;
     const int ml = idx % cmax;
     if (ml >= mcount) return;
-    const int m0 = (mstart + ml) * 64;
+    const int m0 = (mstart + ml) * BM;
     const int nt = idx / cmax;                                  // 0..3h-1
     const bool is_q = nt < a.h;
     const int kind = is_q ? 0 : (nt < 2 * a.h ? 1 : 2);         // 0 q, 1 k, 2 v
     const int hh = nt - kind * a.h;
-
     GemmOperands p;
     p.A = is_q ? a.xq : a.xkv;
     p.W = is_q ? a.wq : a.wkv;
@@ -49,59 +54,70 @@ __global__ __launch_bounds__(256) void qkv_project_kernel(const QkvArgs a) {
     p.w_gap_from = 0; p.w_gap_rows = 0;
     const int n0 = is_q ? hh * 64 : (kind == 1 ? hh * 64 : (a.h + hh) * 64);
 
-    f32x4 acc[1][4];
+    f32x4 acc[TM][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0, 0, 0, 0};
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, lr = lane & 15;
     if (is_q && a.q_ln_s) {
         // q = l2norm(LN(x) Wq^T): LN(x) Wq^T = rstd * (x (gamma.Wq)^T - mean * s) and the l2norm cancels rstd > 0, so only the row
         // mean (from the A fragments of the main loop) and s are needed
-        float rsum[1], rsq[1];
-        (void)QkvTile::run_stats<1>(p, a.M, m0, n0, smem, acc, rsum, rsq);
-        const float mean = rsum[0] / (float)a.K;
+        float rsum[TM], rsq[TM];
+        (void)QkvTile::template run_stats<1>(p, a.M, m0, n0, smem, acc, rsum, rsq);
+        f32x4 s4[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.q_ln_s + n0 + j * 16 + g * 4);
+        for (int j = 0; j < 4; ++j) s4[j] = *reinterpret_cast<const f32x4*>(a.q_ln_s + n0 + j * 16 + g * 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[0][j][r] -= mean * s4[r];
+        for (int i = 0; i < TM; ++i) {
+            const float mean = rsum[i] / (float)a.K;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] -= mean * s4[j][r];
         }
     } else {
         (void)QkvTile::run(p, a.M, m0, n0, smem, acc);
     }
 
-    const int m = m0 + wave * 16 + lr;
-    if (m >= a.M) return;
-    const int s = m / a.nseq, pos = m % a.nseq;
-    const size_t sh = (size_t)s * a.h + hh;
-    if (kind == 2) {
-        // V^T: element (key = pos, d) -> Vt[sh][d][pos]
-        bf16* vt = reinterpret_cast<bf16*>(a.Vt) + sh * 64 * a.nk_pad + pos;
+    const float* sc = kind == 0 ? a.q_scale : a.k_scale;
+    f32x4 scv[4];                                               // all loads before the first store (in-order vmcnt)
+    if (kind != 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) scv[j] = *reinterpret_cast<const f32x4*>(sc + j * 16 + g * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wave * 16 * TM + i * 16 + lr;
+        if (m >= a.M) continue;
+        const int s = m / a.nseq, pos = m % a.nseq;
+        const size_t sh = (size_t)s * a.h + hh;
+        if (kind == 2) {
+            // V^T: element (key = pos, d) -> Vt[sh][d][pos]
+            bf16* vt = reinterpret_cast<bf16*>(a.Vt) + sh * 64 * a.nk_pad + pos;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) store_elem(vt + (size_t)(j * 16 + g * 4 + r) * a.nk_pad, acc[i][j][r]);
+            continue;
+        }
+        float ss = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) store_elem(vt + (size_t)(j * 16 + g * 4 + r) * a.nk_pad, acc[0][j][r]);
-        return;
-    }
-    float ss = 0.f;
+            for (int r = 0; r < 4; ++r) ss += acc[i][j][r] * acc[i][j][r];
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        const float inv = (kind == 0 ? a.scale : 1.0f) / fmaxf(sqrtf(ss), 1e-12f);        // F.normalize eps = 1e-12
+        bf16* dst = kind == 0 ? reinterpret_cast<bf16*>(a.Qp) + (sh * a.nq_pad + pos) * 64
+                              : reinterpret_cast<bf16*>(a.Kp) + (sh * a.nk_pad + pos) * 64;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v = acc[i][j];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ss += acc[0][j][r] * acc[0][j][r];
-    ss += __shfl_xor(ss, 16, 64);
-    ss += __shfl_xor(ss, 32, 64);
-    const float inv = (kind == 0 ? a.scale : 1.0f) / fmaxf(sqrtf(ss), 1e-12f);        // F.normalize eps = 1e-12
-    const float* sc = kind == 0 ? a.q_scale : a.k_scale;
-    bf16* dst = kind == 0 ? reinterpret_cast<bf16*>(a.Qp) + (sh * a.nq_pad + pos) * 64
-                          : reinterpret_cast<bf16*>(a.Kp) + (sh * a.nk_pad + pos) * 64;
-    f32x4 scv[4];                                               // all loads before the first store (in-order vmcnt)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) scv[j] = *reinterpret_cast<const f32x4*>(sc + j * 16 + g * 4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        f32x4 v = acc[0][j];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= inv * scv[j][r];
-        store4(dst + j * 16 + g * 4, v);
+            for (int r = 0; r < 4; ++r) v[r] *= inv * scv[j][r];
+            store4(dst + j * 16 + g * 4, v);
+        }
     }
 }
 
@@ -124,9 +140,19 @@ extern "C" int pk_qkv_project(const void* xq, const void* xkv, int ld, const voi
     if ((size_t)M * ld * 2 >= 0xFFFFFFF0ull) return PK_EINVAL;
     if (q_ln_s && mis(q_ln_s)) return PK_EALIGN;
     QkvArgs a{xq, xkv, wq, wkv, ld, ldw, (int)M, K, h, nseq, q_scale, k_scale, scale, Qp, Kp, Vt, nq_pad, nk_pad, 0, q_ln_s};
-    const int MT = (int)((M + 63) / 64), NT = xkv ? 3 * h : h;
-    dim3 grid(8 * ((MT + 7) / 8) * NT);
-    hipLaunchKernelGGL(qkv_project_kernel, grid, dim3(256), QkvTile::SMEM, reinterpret_cast<hipStream_t>(stream), a);
+    const int NT = xkv ? 3 * h : h;
+    // 128-row tiles once there are >= 4 of them per CU (tuning knob PK_QKV_TM: 1 / 2).  tools/qkv_bench.py, n = 576, 8 heads, K = 512:
+    // S = 16 (1728 tiles of 128 rows) 29.4 vs 35.2 us; S = 8 (864) 18.4 vs 17.7 us; S = 4: 11.5 vs 11.2 us
+    static const int tm_env = [] { const char* e = getenv("PK_QKV_TM"); return e ? atoi(e) : 0; }();
+    const long tiles128 = ((M + 127) / 128) * NT;
+    const bool big = tm_env ? tm_env == 2 : tiles128 >= 4 * 256;
+    if (big) {
+        const int MT = (int)((M + 127) / 128);
+        hipLaunchKernelGGL(qkv_project_kernel<2>, dim3(8 * ((MT + 7) / 8) * NT), dim3(256), QkvTileT<2>::SMEM, reinterpret_cast<hipStream_t>(stream), a);
+    } else {
+        const int MT = (int)((M + 63) / 64);
+        hipLaunchKernelGGL(qkv_project_kernel<1>, dim3(8 * ((MT + 7) / 8) * NT), dim3(256), QkvTileT<1>::SMEM, reinterpret_cast<hipStream_t>(stream), a);
+    }
     PK_CHECK_LAUNCH();
     return PK_OK;
 }
