@@ -3,7 +3,7 @@
 set -u
 export TMPDIR=/tmp
 out=gpurun_out/pmc_gemm_$1_$2_$3_$4_${5:-plain}
-rm -rf $out; mkdir -p $out
+rm -rf $out ${out}_b; mkdir -p $out ${out}_b
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS \
   --output-format csv -d $out -o p -- python tools/one_gemm.py $1 $2 $3 $4 10 ${5:-} > $out/log.txt 2>&1
 python tools/pmc_sq.py $out

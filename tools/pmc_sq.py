@@ -9,7 +9,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for path in glob.glob(os.path.join(sys.argv[1], '**', '*counter_collection.csv'), recursive=True):
     with open(path, newline='') as f:
         for row in csv.DictReader(f):
-            a = agg[row['Kernel_Name'][:80]][row['Counter_Name']]
+            a = agg[row["Kernel_Name"][:110]][row['Counter_Name']]
             a[0] += 1
             a[1] += float(row['Counter_Value'])
 for k, cs in agg.items():
