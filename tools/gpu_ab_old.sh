@@ -1,5 +1,8 @@
 #!/bin/bash
-# same-box A/B of the whole bench: the tree of an older commit (unpacked + built under tools/_bin/old) against the working tree
+# same-box A/B of the whole bench: the tree of an older commit (unpacked + built under tools/_bin/old) against the working tree.
+# Prepare HERE (the GPU box has no .git), then run this script through gpurun:
+#   rm -rf tools/_bin/old && mkdir -p tools/_bin/old && git archive <commit> | tar -x -C tools/_bin/old && \
+#     rm -rf tools/_bin/old/tests/golden tools/_bin/old/profiles && (cd tools/_bin/old && python -m phenaki_pytorch_amd.build)
 set -u
 export TMPDIR=/tmp
 mkdir -p gpurun_out
