@@ -61,9 +61,39 @@ def parse():
     ap.add_argument('--no-parity-mode', action='store_true', help='skip the exact-f32 timing')
     ap.add_argument('--no-kernels', action='store_true', help='skip the per-kernel roofline table')
     ap.add_argument('--encode-only', action='store_true', help='only the headline leg (profiling runs)')
+    ap.add_argument('--legs', default='decode,encode_b32,sample,sample_cfg3,sample_b32,make_video,objective',
+                    help='comma list of the legs reported beside the headline encode leg')
     ap.add_argument('--sample-batch', type=int, default=8)
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def spawn_ranks_if_needed(args):
+    """`python bench.py --gpus N` (N > 1, no launcher): start the N ranks ourselves -- one process per GPU under
+    torch.distributed.run, RCCL over xGMI -- by replacing this process, so the single JSON line still comes from rank 0 on stdout.
+    Under a launcher (WORLD_SIZE set) this is a no-op.  Fewer than N visible devices is an error, never a silent 1-rank run."""
+    if args.gpus <= 1 or 'WORLD_SIZE' in os.environ:
+        return
+    one_device = bool(os.environ.get('PK_BENCH_ONE_DEVICE'))
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and not one_device:
+        raise SystemExit(f'bench.py --gpus {args.gpus}: only {ndev} HIP device(s) visible (PK_BENCH_ONE_DEVICE=1 dry-runs the '
+                         'multi-rank path on one device over gloo)')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execvpe(cmd[0], cmd, env)
 
 
 def init_dist(n):
@@ -83,7 +113,9 @@ def init_dist(n):
             dist.init_process_group('nccl', rank=rank, world_size=ws, device_id=torch.device('cuda', local))
     else:
         torch.cuda.set_device(0)
-    assert ws == n or ws == 1, f'--gpus {n} but WORLD_SIZE={ws}'
+    if ws != n:
+        raise SystemExit(f'bench.py --gpus {n} but {ws} rank(s) are running (WORLD_SIZE={os.environ.get("WORLD_SIZE")}): refusing to report a '
+                         f'{ws}-rank number as an {n}-GPU one')
     return rank, local, ws
 
 
@@ -366,13 +398,13 @@ def roofline_of(rows, dtype, with_traffic=True):
     r = cand[0]
     traffic, src = pmc_traffic(r['kernel']) if with_traffic else (None, None)
     return {'bound': 'mfma', 'kernel': r['kernel'], 'achieved': r['achieved'], 'peak': r['peak'], 'unit': 'TFLOP/s', 'frac': r['frac'],
-            'traffic': traffic, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': src,
+            'traffic': traffic, 'traffic_unit': 'fabric bytes per launch (L2 memory-side requests: Infinity-Cache hits are counted)', 'traffic_source': src,
             'launches_per_step': r['launches'], 'avg_launch_us': r['avg_us'], 'algorithmic_flops_per_launch': r['algorithmic_flops_per_launch']}
 
 
 # ------------------------------------------------------------------------------------------ legs
 
-def bench_encode(cv, args, ws, want_kernels):
+def bench_encode(cv, args, ws, want_kernels, leg='encode'):
     B, R = args.batch, max(1, args.rotate)
     rank = int(os.environ.get('RANK', 0))
     videos = [synthetic_video(B, 17, 256, seed=7 * rank + i).cuda() for i in range(R)]
@@ -401,10 +433,27 @@ def bench_encode(cv, args, ws, want_kernels):
     times = timed_groups(step, args.steps, args.groups, ws)
     rows = None
     if want_kernels:
-        with KernelProfiler('encode', args.dtype == 'fp32') as prof:
+        with KernelProfiler(leg, args.dtype == 'fp32') as prof:
             cv(videos[0], return_only_codebook_ids=True)
         rows = prof.table()
     return times, used_graph, rows
+
+
+def bench_encode_big(cv, args, ws, B, want_kernels):
+    """the encode leg at B videos per GPU (default 32): same entry point, hipGraph, 2 rotating inputs (2 x 428 MB > Infinity Cache)"""
+    import copy
+    a = copy.copy(args)
+    a.batch, a.rotate, a.groups, a.steps = B, 2, max(5, args.groups // 3), max(5, args.steps // 2)
+    times, used_graph, rows = bench_encode(cv, a, ws, want_kernels, leg=f'encode_b{B}')
+    med = statistics.median(times)
+    out = dict(metric='cvivit_encode_frames_per_sec', value=B * 17 * a.steps * ws / med, unit='frames/s', ms_per_step=med / a.steps * 1e3,
+               batch_per_gpu=B, token_rows_per_step=B * 576, hip_graph=used_graph, groups=a.groups, steps=a.steps,
+               note='not the BASELINE batch: shows what the same kernels reach when every CU has several tiles')
+    if rows:
+        out['roofline'] = roofline_of(rows, args.dtype, with_traffic=False)
+        flops = sum(r.get('algorithmic_flops_per_launch', 0) * r['launches'] for r in rows if r['bound'] == 'mfma')
+        out['step_tflops'] = flops / (med / a.steps) / 1e12
+    return out, rows
 
 
 def bench_decode(cv, args, ws, want_kernels):
@@ -450,7 +499,38 @@ def _sample_call(ph, B_local, ws, ctx, **kw):
     return sample_sharded(ph, texts=['x'] * (B_local * ws), num_frames=17, cond_scale=5., **kw)
 
 
-def bench_sample(ph, args, ws, B, name, want_kernels):
+def collective_info(ws, B):
+    """what moved the gathered videos, and how long that one collective takes on its own: the all_gather_into_tensor of sample_sharded
+    on a (B, 3, 17, 256, 256) f32 shard per rank, 5 timed repetitions between HIP events on the current stream (max over ranks)"""
+    if ws == 1:
+        return dict(collective='none (1 GPU)')
+    import torch.distributed as dist
+    from phenaki_pytorch_amd.dist import all_gather_batch
+    backend = dist.get_backend()
+    lib = 'RCCL' if backend == 'nccl' else backend
+    ver = None
+    if backend == 'nccl':
+        try:
+            ver = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:                                       # noqa: BLE001
+            ver = None
+    shard = torch.randn(B, 3, 17, 256, 256, device='cuda')
+    all_gather_batch(shard, B * ws)
+    barrier_sync(ws)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        all_gather_batch(shard, B * ws)
+    e1.record()
+    torch.cuda.synchronize()
+    us = max_over_ranks(e0.elapsed_time(e1) * 1e3 / 5, ws)
+    nbytes = shard.numel() * 4
+    return dict(collective=f'one all_gather_into_tensor of ({B},3,17,256,256) f32 per rank ({lib}), inside the timed region',
+                backend=backend, nccl_version=ver, all_gather_us=us, shard_bytes=nbytes,
+                all_gather_algbw_GBs=nbytes * (ws - 1) / (us * 1e-6) / 1e9)
+
+
+def bench_sample(ph, args, ws, B, name, want_kernels, leg='sample', runs=3):
     """configs[2] / [3]: 18-step MaskGIT sampling (CFG scale 5, TokenCritic) with frozen random C-ViViT weights and a cached
     (random) T5 context; tokens/sec = global batch * 576 / wall time of the sample call (final decode and, with N > 1, the
     all-gather of the decoded videos included)."""
@@ -463,7 +543,6 @@ def bench_sample(ph, args, ws, B, name, want_kernels):
         try:
             _sample_call(ph, B, ws, ctx)                       # warm-up (packs weights, position bias; captures the graph)
             _sample_call(ph, B, ws, ctx)
-            runs = 3
             ts = timed_groups(lambda i: _sample_call(ph, B, ws, ctx), 1, runs, ws)
             res[mode] = statistics.median(ts)
         except Exception as e:                                  # noqa: BLE001
@@ -475,15 +554,14 @@ def bench_sample(ph, args, ws, B, name, want_kernels):
     out = dict(metric='maskgit_sampled_tokens_per_sec', value=B * 576 * ws / dt, unit='tokens/s', seconds_per_sample_call=dt, launch_mode=best,
                seconds_by_launch_mode=res, batch_per_gpu=B, global_batch=B * ws, steps=ph.steps, cond_scale=5.0,
                critic='TokenCritic depth 6 cross-attn', tokens_per_video=576, noise='in-kernel counter hash (FAST mode)',
-               collective='none (1 GPU)' if ws == 1 else f'one all_gather_into_tensor of ({B},3,17,256,256) f32 per rank (RCCL), inside the timed region',
-               workload=name)
+               workload=name, **collective_info(ws, B))
     rows = None
     if want_kernels:
         # per-kernel rooflines of this leg: 2 untimed sampling steps under the profiler
         steps = ph.steps
         try:
             ph.steps = 2
-            with KernelProfiler('sample', args.dtype == 'fp32') as prof:
+            with KernelProfiler(leg, args.dtype == 'fp32') as prof:
                 ph.sample(texts=['x'] * B, num_frames=17, cond_scale=5.)
             rows = prof.table()
         finally:
@@ -599,6 +677,7 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    spawn_ranks_if_needed(args)
     torch.set_grad_enabled(False)
     from __graft_entry__ import build
     rank, local, ws = init_dist(args.gpus)
@@ -627,15 +706,28 @@ def main():
     if enc_rows:
         result['roofline'] = roofline_of(enc_rows, args.dtype)
         kernels += enc_rows
-    if not args.encode_only:
+    legs = set() if args.encode_only else set(x for x in args.legs.split(',') if x)
+    if 'decode' in legs:
         result['decode'], dec_rows = bench_decode(cv, args, ws, want_k)
         kernels += dec_rows or []
-    if sampler:
+    if 'encode_b32' in legs:
+        # the same leg with the GPU full (32 videos = 18 432 token rows per GPU): separates "the kernels' ceiling" from "B = 8 is one
+        # partial wave of tiles" -- the headline stays the BASELINE batch of 8
+        result['encode_b32'], b32_rows = bench_encode_big(cv, args, ws, 32, want_k)
+        kernels += b32_rows or []
+    if sampler and 'sample' in legs:
         result['sample'], s_rows = bench_sample(ph, args, ws, args.sample_batch, 'BASELINE configs[2]', want_k)
         kernels += s_rows or []
+    if sampler and 'sample_cfg3' in legs:
         s3, _ = bench_sample(ph, args, ws, 4, 'BASELINE configs[3] per-GPU share (32 videos over 8 GPUs = 4 per GPU)', False)
         result['sample_cfg3'] = s3
+    if sampler and 'sample_b32' in legs:
+        result['sample_b32'], sb_rows = bench_sample(ph, args, ws, 32, 'configs[2] with 32 videos per GPU (GPU full: 36 864 trunk rows per step)', want_k,
+                                                      leg='sample_b32', runs=2)
+        kernels += sb_rows or []
+    if sampler and 'make_video' in legs:
         result['make_video'] = bench_make_video(ph, args, ws)
+    if sampler and 'objective' in legs:
         result['objective'] = bench_objective(ph, args, ws)
     if kernels:
         keep = ('kernel', 'leg', 'launches', 'avg_us', 'bound', 'achieved', 'unit', 'peak', 'frac')

@@ -78,7 +78,14 @@ def invalidate_packed(module):
     (`p.data.copy_`, `p.data.lerp_` -- ema-pytorch, weight surgery) do NOT bump `_version`: call this after them."""
     for m in module.modules():
         m.__dict__.pop('_pk_cache', None)
+        # captured sampling hipGraphs (Phenaki.enable_sample_graph) hold raw pointers into the packed copies dropped above
+        m.__dict__.pop('_pk_sample_graphs', None)
     return module
+
+
+def param_fingerprint(module):
+    """(data_ptr, _version) of every parameter and buffer: what a captured hipGraph of `module`'s kernels silently depends on"""
+    return tuple((t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers()))
 
 
 class PackedModule(nn.Module):
@@ -96,12 +103,32 @@ class PackedModule(nn.Module):
         return out
 
 
-def refuse_autograd(module, what):
-    """the MI355X build computes loss VALUES only (no backward kernels yet): a caller that expects to
-    `.backward()` through `what` -- grad mode on and trainable parameters -- gets an error here instead of a silent no-op."""
-    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
-        raise RuntimeError(f'{what} returns the value of the objective without an autograd graph on the MI355X build (forward '
-                           'kernels only): evaluate it under torch.no_grad(); training needs the reference implementation')
+class _NoBackward(torch.autograd.Function):
+    """identity on a loss VALUE whose backward raises: the MI355X build has forward kernels only"""
+
+    @staticmethod
+    def forward(ctx, value, anchor, what):
+        ctx.what = what
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, grad):
+        raise RuntimeError(f'{ctx.what} returned the VALUE of the objective: the MI355X build has no backward kernels yet (forward '
+                           'kernels only, SURVEY.md 8f) -- train with the reference implementation, evaluate with this one')
+
+
+def value_without_graph(module, what, value):
+    """`value` as the caller of the reference signature expects it: under no_grad / frozen parameters the plain tensor; with grad
+    mode on and trainable parameters a tensor that requires grad and whose .backward() raises a clear error (instead of either
+    refusing the forward call, which broke `loss = phenaki(...)`, or silently returning a leaf that trains nothing)."""
+    if not torch.is_grad_enabled():
+        return value
+    anchor = next((p for p in module.parameters() if p.requires_grad), None)
+    if anchor is None:
+        return value
+    if isinstance(value, tuple):
+        return (_NoBackward.apply(value[0], anchor, what),) + tuple(value[1:])
+    return _NoBackward.apply(value, anchor, what)
 
 
 def pack_linear_weight(w, dtype):
@@ -167,6 +194,8 @@ def f32c(t):
 
 class LayerNorm(nn.Module):
     """attention.py:29-36 : learned gamma, zero `beta` buffer (persistent -> in the state_dict)."""
+
+    eps = 1e-5                      # F.layer_norm default, which attention.py:36 uses
 
     def __init__(self, dim):
         super().__init__()
@@ -550,7 +579,7 @@ class Attention(PackedModule):
                 L.qkv_project(xt, None, wq, None, S, n, h, D, self.q_scale, None, float(self.scale), Qp, None, None, nq_pad, nk_pad, q_ln_s=sq)
             else:
                 q = torch.empty((M, inner), device=dev, dtype=torch.float32)
-                L.gemm(dtype, xt, wq, M, inner, D, C=q, ln=(sq, tq, 1e-5))
+                L.gemm(dtype, xt, wq, M, inner, D, C=q, ln=(sq, tq, self.norm.eps))
                 kv = self.project_kv(context2d if is_cross else xt, S, n_kv, dtype, is_cross)
                 Kp = torch.empty((S * h * nk_pad * 64,), device=dev, dtype=td)
                 Vt = torch.empty((S * h * nk_pad * 64,), device=dev, dtype=td)
@@ -646,6 +675,8 @@ def _unpack(r):
 
 
 class Transformer(PackedModule):
+    """attention.py:279-332 : per layer [PEG?, self Attention, cross Attention?, FeedForward], each + residual; norm_out."""
+
     def shares_cfg_prefix(self, dtype, context2d, self_attn_mask):
         """True when run(..., replicas=2) may be used: bf16 with folded LayerNorms (the path that threads the bf16 copy), layer 0 has a
         cross-attention that will run, and no per-sequence self-attention mask (the two copies must be identical up to there)."""
@@ -653,8 +684,6 @@ class Transformer(PackedModule):
             return False
         cross = self.layers[0][2]
         return exists(cross) and exists(context2d) and self_attn_mask is None
-
-    """attention.py:279-332 : per layer [PEG?, self Attention, cross Attention?, FeedForward], each + residual; norm_out."""
 
     def __init__(self, dim, *, depth, dim_context=None, causal=False, dim_head=64, heads=8, ff_mult=4, peg=False,
                  peg_causal=False, attn_num_null_kv=2, has_cross_attn=False, attn_dropout=0., ff_dropout=0.):

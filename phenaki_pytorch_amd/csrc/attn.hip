@@ -559,13 +559,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float add = noff;
+                            bool pad = false;
                             if (!simple) {
                                 const int key = kb + attn_kperm(f, g * 4 + r);
                                 const int j = key - p.nnull;
-                                if (key >= nk) add = -INFINITY;
-                                else if (TAB && j >= 0 && qi < p.nq) add = tab[cq[qf] - codes[j]];
+                                pad = key >= nk;
+                                if (!pad && TAB && j >= 0 && qi < p.nq) add = tab[cq[qf] - codes[j]];
                             }
-                            pr[qf][f * 4 + r] = __builtin_amdgcn_exp2f(fmaf(st[qf][f][r], ATTN_LOG2E, add));
+                            // tile padding is masked by SELECTING 0, never through arithmetic: the K^ rows of keys >= nk are not
+                            // written by pk_qkv_project (torch.empty), so their scores may be NaN / Inf and fma(NaN, c, -inf) = NaN
+                            const float e2 = __builtin_amdgcn_exp2f(fmaf(st[qf][f][r], ATTN_LOG2E, add));
+                            pr[qf][f * 4 + r] = pad ? 0.f : e2;
                         }
                 }
                 continue;

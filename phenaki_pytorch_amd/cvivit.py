@@ -14,7 +14,7 @@ from torch import nn
 
 from . import _lib as L
 from .attention import (ContinuousPositionBias, PackedModule, Transformer, compute_dtype_of, exists, invalidate_packed,
-                        linear_weight, ln_fold_enabled, refuse_autograd, set_compute_dtype)
+                        linear_weight, ln_fold_enabled, value_without_graph, set_compute_dtype)
 from .quantize import LFQ, VectorQuantize
 
 
@@ -223,10 +223,13 @@ class CViViT(PackedModule):
             C, hw = self.channels, h * w
             F = 1 + (T - 1) * self.temporal_patch_size
             H, W = self.image_size
-            if B * C * F * H * W >= 2 ** 31:
-                raise ValueError('video too large for 32-bit scatter offsets')
             if pw % 4 or W % 4:
-                raise ValueError('patch width and image width must be multiples of 4 (16-byte pixel stores)')
+                # no kernel of this build moves pixels in other than 16-byte pieces (pk_patchify_ln / pk_unpatchify refuse too)
+                raise ValueError('patch width and image width must be multiples of 4 (16-byte pixel accesses)')
+            if B * C * F * H * W >= 2 ** 31:
+                # beyond 32-bit scatter offsets: _decode2d takes the (rows, P) pixel matrix + pk_unpatchify path (64-bit addressing)
+                cache[key] = None
+                return None
             ar = lambda n: torch.arange(n, dtype=torch.int64)
             b, tt, hh, ww = torch.meshgrid(ar(B), ar(ntg), ar(h), ar(w), indexing='ij')
             idx = (b * (T * hw) + row0 + tt * hw + hh * w + ww).reshape(-1)
@@ -257,7 +260,16 @@ class CViViT(PackedModule):
             if ntg <= 0:
                 continue
             lin = seq[0]
-            idx, row_off, col_off = self._unpatch_maps(B, T, f0, ntg, ptg, row0, dev)
+            maps = self._unpatch_maps(B, T, f0, ntg, ptg, row0, dev)
+            if maps is None:
+                # geometry outside the scatter epilogue's constraints: (rows, P) pixel matrix, then the un-patchify pass
+                rows, P = B * ntg * hw, C * ptg * ph * pw
+                xg = x.view(B, T, hw, self.dim)[:, (row0 // hw):(row0 // hw) + ntg].reshape(rows, self.dim)
+                pix = torch.empty((rows, P), device=dev, dtype=torch.float32)
+                L.gemm(dt, xg, linear_weight(lin, dt), rows, P, self.dim, C=pix, bias=lin.bias)
+                L.unpatchify(pix, video, f0, ntg, ptg, ph, pw)
+                continue
+            idx, row_off, col_off = maps
             # 'b t h w (c pt p1 p2) -> b c (t pt) (h p1) (w p2)' is separable in (row, column), so the GEMM epilogue writes the video
             # in place (round 1 materialised the (rows, P) pixel matrix -- 100 MB at the bench shape -- and re-read it in pk_unpatchify)
             L.gemm(dt, x, linear_weight(lin, dt), idx.numel(), col_off.numel(), self.dim, C=video, bias=lin.bias, a_rows=idx,
@@ -315,10 +327,11 @@ class CViViT(PackedModule):
 
     def forward(self, video, mask=None, return_recons=False, return_recons_only=False, return_discr_loss=False,
                 apply_grad_penalty=True, return_only_codebook_ids=False):
-        if not (return_only_codebook_ids or return_recons_only):
-            refuse_autograd(self, 'CViViT.forward (reconstruction loss)')
-        return self._forward(video, mask, return_recons, return_recons_only, return_discr_loss, apply_grad_penalty,
-                             return_only_codebook_ids)
+        out = self._forward(video, mask, return_recons, return_recons_only, return_discr_loss, apply_grad_penalty,
+                            return_only_codebook_ids)
+        if return_only_codebook_ids or return_recons_only:
+            return out
+        return value_without_graph(self, 'CViViT.forward (reconstruction loss)', out)
 
     @torch.no_grad()
     def _forward(self, video, mask=None, return_recons=False, return_recons_only=False, return_discr_loss=False,

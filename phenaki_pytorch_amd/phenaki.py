@@ -19,7 +19,7 @@ from torch import nn
 
 from . import _lib as L
 from .attention import (ContinuousPositionBias, PackedModule, Transformer, compute_dtype_of, exists, default, linear_weight,
-                        refuse_autograd, set_compute_dtype)
+                        param_fingerprint, value_without_graph, set_compute_dtype)
 from .cvivit import CViViT
 from .t5 import t5_encode_text, get_encoded_dim, DEFAULT_T5_NAME
 
@@ -356,9 +356,10 @@ class Phenaki(PackedModule):
         return video.squeeze(2)
 
     def forward(self, *args, **kwargs):
-        """phenaki_pytorch.py:562-687, value only -- see `objective_value`; refuses to run where a caller could expect gradients."""
-        refuse_autograd(self, 'Phenaki.forward')
-        return self.objective_value(*args, **kwargs)
+        """phenaki_pytorch.py:562-687, value only -- see `objective_value`.  Where a caller could expect gradients (grad mode on,
+        trainable parameters) the returned loss is attached to a node whose backward raises: `loss = phenaki(...)` keeps working as
+        in the reference, `loss.backward()` fails loudly instead of silently training nothing."""
+        return value_without_graph(self, 'Phenaki.forward', self.objective_value(*args, **kwargs))
 
     @torch.no_grad()
     def objective_value(self, videos=None, *, texts=None, video_codebook_ids=None, video_frame_mask=None, text_embeds=None,
@@ -611,6 +612,12 @@ class Phenaki(PackedModule):
                self.critic_noise_anneal_schedule)
         graphs = self.__dict__.setdefault('_pk_sample_graphs', {}) if use_graph else None
         entry = graphs.get(key) if use_graph else None
+        # a captured graph holds raw pointers to the live parameters AND to the packed copies derived from them: any change of a
+        # parameter (optimizer step, EMA update through the autograd-visible path, load_state_dict, .to()) re-captures
+        fp = param_fingerprint(self) if use_graph else None
+        if entry is not None and entry['fingerprint'] != fp:
+            graphs.pop(key)
+            entry = None
         if entry is not None:
             st = entry['st']
             if has_ctx or c_has_ctx:
@@ -649,7 +656,7 @@ class Phenaki(PackedModule):
         # first call for this configuration: one eager pass (packs weights, fills the bias caches), then capture
         st['seed_dev'] = torch.zeros((1,), device=device, dtype=torch.int64)
         st['seed_dev'].fill_(seed_base)
-        entry = dict(st=st, text_embeds=text_embeds, tm=text_mask)
+        entry = dict(st=st, text_embeds=text_embeds, tm=text_mask, fingerprint=fp)
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):

@@ -1,6 +1,8 @@
-"""The batch-sharded sampler on the REAL product path under an initialised process group: two ranks spawned
-on the one visible GPU, each running the real Phenaki.sample on its shard and the one all-gather of the decoded videos.
-Needs a real MI355X (-m gpu).  The 8-GPU scaling run is the driver's; this pins correctness of the path it times."""
+"""The batch-sharded sampler on the REAL product path under an initialised process group: two ranks, each running
+the real Phenaki.sample on its shard and the one all-gather of the decoded videos -- one rank per device when two devices are
+visible (then the `nccl` variant is RCCL over xGMI and is NOT skipped), both ranks on the one GPU otherwise (RCCL refuses two ranks
+on one device: the gloo variant covers the same path).  Needs a real MI355X (-m gpu).  The 8-GPU scaling run is the driver's;
+this pins correctness of the path it times."""
 import os
 import socket
 
@@ -26,13 +28,17 @@ def _rank_main(rank, ws, port, backend, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
     torch.set_grad_enabled(False)
-    torch.cuda.set_device(0)                                   # both ranks share the one GPU of the test box
-    dist.init_process_group(backend, rank=rank, world_size=ws)
+    dev = rank % max(1, torch.cuda.device_count())              # one rank per device when there are two; else both share the one GPU
+    torch.cuda.set_device(dev)
+    if backend == 'nccl':
+        dist.init_process_group(backend, rank=rank, world_size=ws, device_id=torch.device('cuda', dev))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=ws)
     from oracle import weights
     from oracle.configs import TINY
     from tests.util import load_product
     import phenaki_pytorch_amd as P
-    _, _, _, ph = load_product('tiny', TINY, device='cuda:0')
+    _, _, _, ph = load_product('tiny', TINY, device=f'cuda:{dev}')
     ctx_row = weights.synthetic_context(1, 6, TINY['maskgit']['dim_context'], seed=2).cuda()
     ph.encode_texts = lambda texts, output_device=None: ctx_row.expand(len(texts), -1, -1).contiguous()   # IDENTICAL prompts
     texts = ['p'] * 5                                           # 5 items over 2 ranks: shards of 3 and 2 (ragged tail padded + trimmed)
@@ -65,11 +71,13 @@ def test_sample_sharded_two_ranks_real_path(tmp_path, backend):
     """(i) gathered order, (ii) per-rank noise streams differ under a common torch seed, (iii) each shard equals the
     single-process result for its seed (eager and hipGraph)."""
     ws, port = 2, _free_port()
+    two_devices = torch.cuda.device_count() >= 2
     try:
         mp.spawn(_rank_main, args=(ws, port, backend, str(tmp_path)), nprocs=ws, join=True)
     except Exception as e:                                       # noqa: BLE001
-        if backend == 'nccl' and any(k in str(e) for k in ('Duplicate GPU', 'duplicate', 'invalid usage', 'unhandled system error', 'NCCL', 'RCCL')):
-            pytest.skip(f'RCCL refuses two ranks on one device ({str(e)[:120]}...): covered by the gloo variant on the same path')
+        # only on a ONE-device box may the RCCL variant be skipped (RCCL refuses two ranks on one device); with two devices it must run
+        if backend == 'nccl' and not two_devices and any(k in str(e) for k in ('Duplicate GPU', 'duplicate', 'invalid usage', 'unhandled system error', 'NCCL', 'RCCL')):
+            pytest.skip(f'one visible device and RCCL refuses two ranks on it ({str(e)[:120]}...): covered by the gloo variant on the same path')
         raise
     r0, r1 = (torch.load(os.path.join(str(tmp_path), f'rank{r}.pt'), weights_only=False) for r in range(2))
     assert torch.equal(r0['full'], r1['full']), 'ranks disagree on the gathered batch'
@@ -77,3 +85,34 @@ def test_sample_sharded_two_ranks_real_path(tmp_path, backend):
     assert r0['seed'] != r1['seed'], 'ranks share a noise stream'
     # identical prompts and torch seed: identical noise streams would make rank 1's first two videos equal rank 0's
     assert not torch.equal(r0['ids'][:2], r1['ids'][:2]), 'per-rank noise streams must differ'
+
+
+def test_bench_gpus2_launches_two_ranks_by_itself(tmp_path):
+    """`python bench.py --gpus 2` with no launcher must start 2 ranks itself and report n_gpus = 2 with the collective
+    that moved the videos (RCCL when two devices are visible; on a one-device box the PK_BENCH_ONE_DEVICE dry run over gloo)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    two = torch.cuda.device_count() >= 2
+    if not two:
+        env['PK_BENCH_ONE_DEVICE'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--groups', '2', '--batch', '2',
+                        '--sample-batch', '1', '--no-cpu', '--no-parity-mode', '--no-kernels', '--no-graph', '--legs', 'sample'],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4
+    s = d['sample']
+    assert s['global_batch'] == 2 and s['all_gather_us'] > 0
+    assert s['backend'] == ('nccl' if two else 'gloo')
+    if two:
+        assert s['nccl_version'] and 'RCCL' in s['collective']
+    # and without enough devices / the dry-run switch it fails loudly instead of running one rank
+    if not two:
+        env.pop('PK_BENCH_ONE_DEVICE')
+        r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--encode-only'], env=env, capture_output=True, text=True, timeout=300)
+        assert r2.returncode != 0 and 'HIP device(s) visible' in (r2.stderr + r2.stdout)

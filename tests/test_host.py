@@ -218,20 +218,30 @@ def test_packed_weight_cache_invalidation_and_pointer_checks():
     assert _lib.f32p(torch.zeros(4, 8)[:, :4], 'x', rows_ok=True) and _lib.f32p(None) is None
 
 
-def test_loss_value_forwards_refuse_autograd():
-    """Phenaki.forward / CViViT.forward return loss VALUES; with grad mode on and trainable parameters they raise
-    instead of returning a tensor whose .backward() would fail later; only_train_critic needs a critic."""
+def test_loss_value_forwards_carry_a_raising_backward():
+    """ADVICE r1 + r2: Phenaki.forward / CViViT.forward return loss VALUES.  `loss = model(...)` works with the reference signature in
+    the default state (grad mode on, trainable parameters); what fails -- loudly -- is `.backward()` on it.  only_train_critic needs a critic."""
     import phenaki_pytorch_amd as P
+    from phenaki_pytorch_amd.attention import value_without_graph
     cv = P.CViViT(use_vgg_and_gan=False, **TINY['cvivit'])
     mg = P.MaskGit(**TINY['maskgit'])
     ph = P.Phenaki(maskgit=mg, cvivit=cv, text_embed_dim=96)
+    val = torch.tensor(1.25)
     with torch.enable_grad():
-        with pytest.raises(RuntimeError, match='without an autograd graph'):
+        out = value_without_graph(mg, 'Phenaki.forward', val)
+        assert out.requires_grad and float(out.detach()) == 1.25
+        with pytest.raises(RuntimeError, match='no backward kernels'):
+            out.backward()
+        tup = value_without_graph(mg, 'CViViT.forward', (val, torch.zeros(2)))          # (loss, recon): only the loss carries the node
+        assert tup[0].requires_grad and not tup[1].requires_grad
+        for p_ in mg.parameters():
+            p_.requires_grad_(False)
+        assert value_without_graph(mg, 'x', val) is val                                 # frozen module: plain value
+        with pytest.raises(RuntimeError, match='no CPU fallback'):      # the forwards are not refused up front any more: they reach the device check
             cv(torch.randn(1, 3, 5, 64, 64))
-        with pytest.raises(RuntimeError, match='without an autograd graph'):
-            ph(video_codebook_ids=torch.zeros(1, 3, 4, 4, dtype=torch.long), text_embeds=torch.randn(1, 4, 96))
-        with pytest.raises(RuntimeError, match='no CPU fallback'):      # the ids path has no loss: not refused, reaches the device check
+        with pytest.raises(RuntimeError, match='no CPU fallback'):
             cv(torch.randn(1, 3, 5, 64, 64), return_only_codebook_ids=True)
     with torch.no_grad():
+        assert value_without_graph(ph, 'x', val) is val
         with pytest.raises(AssertionError, match='needs a critic'):
             ph(video_codebook_ids=torch.zeros(1, 3, 4, 4, dtype=torch.long), text_embeds=torch.randn(1, 4, 96), only_train_critic=True)

@@ -865,3 +865,37 @@ def test_attention_relative_position_bias_table(L, dims, S, heads):
         o_far = torch.full_like(o_full, float('nan'))
         L.attn_fwd(L.BF16, Qp, Kp, Vt, o_far, S, heads, n, n, 0, score_bound=bound + 12, **kw)
         close(o_far.float(), ref, 1.2e-2, f'fixed-offset attention, loose bound ({what})')
+
+
+@pytest.mark.parametrize('dims,heads', [((4, 9, 9), 2), ((3, 5, 7), 8), ((2, 6, 6), 1)])
+def test_attention_fixed_offset_ignores_poisoned_pad_rows(L, dims, heads):
+    """with n > 64 and n % 32 != 0 the K^ / V^T images have pad rows pk_qkv_project never writes (torch.empty:
+    recycled memory, often NaN / Inf).  The fixed-offset softmax masked them through arithmetic (fma(NaN, c, -inf) = NaN) and a
+    whole launch went NaN; padding must be masked by selection.  Pads are poisoned here with NaN, +Inf and -Inf."""
+    from phenaki_pytorch_amd.attention import ContinuousPositionBias
+    n = dims[0] * dims[1] * dims[2]
+    assert n > 64 and n % 32 != 0
+    S = 2
+    torch.manual_seed(11)
+    cpb = ContinuousPositionBias(dim=64, heads=heads, num_dims=3).cuda()
+    nq_pad, nk_pad = L.attn_pads(n, n, 0)
+    Qp = (torch.randn(S * heads, nq_pad, 64, generator=g(191)) * 0.35).cuda().to(torch.bfloat16)
+    Kp = (torch.randn(S * heads, nk_pad, 64, generator=g(192)) * 0.35).cuda().to(torch.bfloat16)
+    Vt = torch.randn(S * heads, 64, nk_pad, generator=g(193)).cuda().to(torch.bfloat16)
+    Q = Qp[:, :n].double().cpu()
+    K = Kp[:, :n].double().cpu()
+    V = Vt[:, :, :n].double().cpu()
+    for tag, kw, extra in (('no bias', {}, 0.), ('table', dict(bias_table=cpb.table(*dims)), cpb(*dims).double().cpu().repeat(S, 1, 1))):
+        sim = Q @ K.transpose(1, 2) + extra
+        ref = (sim.softmax(-1) @ V.transpose(1, 2)).view(S, heads, n, 64).permute(0, 2, 1, 3).reshape(S * n, heads * 64)
+        bound = float(sim.max()) + 0.3
+        for poison in (float('nan'), float('inf'), float('-inf')):
+            Kq, Vq = Kp.clone(), Vt.clone()
+            Kq[:, n:] = poison
+            Vq[:, :, n:] = poison
+            Qq = Qp.clone()
+            Qq[:, n:] = poison                                   # pad QUERY rows: computed, never stored
+            for sb in (bound, None):                             # fixed-offset and running-max loops
+                o = torch.full((S * n, heads * 64), float('nan'), device='cuda', dtype=torch.bfloat16)
+                L.attn_fwd(L.BF16, Qq.reshape(-1), Kq.reshape(-1), Vq.reshape(-1), o, S, heads, n, n, 0, score_bound=sb, **kw)
+                close(o.float(), ref, 1.2e-2, f'{tag}, pads = {poison}, {"fixed offset" if sb else "running max"}')

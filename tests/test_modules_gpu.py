@@ -679,3 +679,65 @@ def test_cvivit_reconstruction_loss_matches_reference_golden(golden_dir, dtype, 
     assert abs(float(L.sqdiff_sum(a, b)) - float(ref_all)) <= 1e-6 * float(ref_all)
     assert abs(float(L.sqdiff_sum(a, b, m)) - float(ref_m)) <= 1e-6 * float(ref_m)
 
+
+
+def test_sample_graph_is_recaptured_when_weights_change():
+    """a captured sampling hipGraph holds raw pointers to the parameters and to the packed bf16 copies derived
+    from them.  An optimizer-style in-place update (bumps _version), load_state_dict and invalidate_packed must all lead to a
+    re-capture -- the replay has to equal an eager run with the NEW weights, not replay stale or freed ones."""
+    import phenaki_pytorch_amd as P
+    _, mg, _, ph = load_product('tiny', TINY, dtype='bf16')
+    ctx = weights.synthetic_context(2, 6, TINY['maskgit']['dim_context'], seed=2).cuda()
+    ph.encode_texts = lambda texts, output_device=None: ctx[:len(texts)]
+    kw = dict(texts=['a', 'b'], num_frames=5, cond_scale=5., _return_ids=True, _seed=1234)
+
+    def both():
+        ph.enable_sample_graph(False)
+        ve, ie = ph.sample(**kw)
+        ph.enable_sample_graph(True)
+        vg, ig = ph.sample(**kw)
+        vg2, ig2 = ph.sample(**kw)                      # second call: a pure replay
+        assert torch.equal(ie, ig) and torch.equal(ve, vg), 'graph launch differs from eager'
+        assert torch.equal(ig, ig2) and torch.equal(vg, vg2), 'graph replay differs from its capture run'
+        return ie
+
+    try:
+        ids0 = both()
+        with torch.no_grad():                           # optimizer-style update: same storage, new _version
+            mg.to_logits.weight.mul_(-1.0)
+            mg.token_emb.weight.add_(0.05)
+        ids1 = both()
+        assert not torch.equal(ids0, ids1), 'the weight change must be visible in the sampled ids'
+        sd = {k: v.clone() for k, v in mg.state_dict().items()}
+        sd['to_logits.bias'] = sd['to_logits.bias'] + 3.0 * torch.randn_like(sd['to_logits.bias'])
+        mg.load_state_dict(sd)                          # in-place copies bump _version: caught by the parameter fingerprint
+        ids2 = both()
+        assert not torch.equal(ids1, ids2)
+        mg.to_logits.weight.data.mul_(-1.0)             # a .data write is invisible to _version: explicit invalidation is the contract
+        P.invalidate_packed(ph)
+        assert '_pk_sample_graphs' not in ph.__dict__
+        ids3 = both()
+        assert not torch.equal(ids2, ids3)
+    finally:
+        ph.enable_sample_graph(False)
+
+
+def test_forward_returns_value_and_backward_raises():
+    """`loss = phenaki(...)` / `loss = cvivit(video)` work in the default state (grad mode on, trainable parameters),
+    as with the reference; `.backward()` on the value raises instead of silently training nothing."""
+    cv, _, _, ph = load_product('tiny', TINY)
+    H = TINY['cvivit']['image_size']
+    video = weights.synthetic_video(1, 5, H, H, seed=6).cuda()
+    ctx = weights.synthetic_context(1, 6, TINY['maskgit']['dim_context'], seed=2).cuda()
+    with torch.no_grad():
+        ref_cv = cv(video)
+    with torch.enable_grad():
+        loss_cv = cv(video)
+        assert loss_cv.requires_grad and float(loss_cv.detach()) == float(ref_cv)
+        with pytest.raises(RuntimeError, match='no backward kernels'):
+            loss_cv.backward()
+        torch.manual_seed(3)
+        loss = ph(videos=video, text_embeds=ctx)
+        assert loss.requires_grad and torch.isfinite(loss.detach())
+        with pytest.raises(RuntimeError, match='no backward kernels'):
+            loss.backward()
