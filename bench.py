@@ -21,7 +21,9 @@ The same JSON line carries
                  i.e. WITH the one RCCL all-gather of the decoded videos inside the timed region), eager and hipGraph;
   sample_cfg3  : the same at configs[3]'s per-GPU batch (32 videos over 8 GPUs = 4 per GPU);
   make_video   : configs[4], 3 scenes (17, 14, 14 frames, prime K = 5), one video per GPU, tokens/s and wall-clock;
-  parity_mode  : the exact-f32 mode (the one held to bit-exact ids / 1e-3 against the reference) timed on the same legs;
+  parity_mode  : the split-bf16 ("bf16x3") mode -- held by the tests to bit-exact ids / 1e-3 against the reference, like exact f32 --
+                 timed on the same legs; parity_mode_f32: the exact-f32 mode beside it;
+  encode_b32 / sample_b32 : the same legs with 32 videos per GPU (what the kernels reach when the GPU is full);
   cpu_baseline : the CPU oracle (a port of the reference algorithm, oracle/phenaki_oracle.py) on a bounded sample of
                  the same workload on this box's host cores.
 """
@@ -54,7 +56,7 @@ def parse():
     ap.add_argument('--groups', type=int, default=25, help='timed regions of --steps steps; the median is reported')
     ap.add_argument('--rotate', type=int, default=3, help='distinct input batches the steps rotate through')
     ap.add_argument('--batch', type=int, default=8, help='videos per GPU (configs[1]: 8)')
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'bf16x3'])
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying captured hipGraphs')
     ap.add_argument('--no-sample', action='store_true', help='skip the MaskGIT sampling / make_video / objective legs')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
@@ -229,8 +231,10 @@ class KernelProfiler:
     flops for the MFMA kernels, bytes for the HBM-bound ones (DESIGN.md section 4 lists the per-unit figures)."""
     REPS = 10
 
-    def __init__(self, leg, f32_mode=False):
-        self.leg, self.f32 = leg, f32_mode
+    def __init__(self, leg, mode='bf16'):
+        # mode: the compute dtype of the models under the profiler ('bf16' | 'fp32' | 'bf16x3'; True / False = legacy f32 flag)
+        mode = {True: 'fp32', False: 'bf16'}.get(mode, mode)
+        self.leg, self.mode, self.f32 = leg, mode, mode == 'fp32'
         self.calls = []
 
     # (label, bound, work) of one wrapper call; work = flops ('mfma') or bytes ('hbm')
@@ -241,7 +245,7 @@ class KernelProfiler:
             a_is_f32 = 1 if A.dtype == torch.float32 else 0
             rows = A.shape[0] if kw.get('a_rows') is not None else M
             v = kw.get('variant') or lib.load().pk_gemm_auto_variant(dtype, a_is_f32, M, N, K, kw.get('lda') or A.stride(-2), W.stride(0), rows)
-            t = 'pk::bf16' if dtype == lib.BF16 else 'float'
+            t = {lib.BF16: 'pk::bf16', lib.BF16X3: 'pk::bf16x3'}.get(dtype, 'float')
             label = VARIANT_KERNEL.get(v, f'gemm variant{v}').replace('TA', 'float' if a_is_f32 else t).replace('T', t)
             if kw.get('ln'):                                  # LayerNorm-folded instantiation: 64x64 or 128x128 by the same size rule
                 label = (VARIANT_KERNEL[24] if v in (24, 2, 9) else VARIANT_KERNEL[8]).replace('T', t)[:-2] + ('2>' if kw.get('ln_stats') is not None else '1>')
@@ -361,7 +365,9 @@ class KernelProfiler:
         for (label, bound), (launches, work, secs) in by.items():
             r = dict(kernel=label, leg=self.leg, launches=launches, avg_us=secs / launches * 1e6, us_total=secs * 1e6, bound=bound)
             if bound in ('mfma', 'valu'):
-                peak = PEAK_F32_TFLOPS if (self.f32 or bound == 'valu' or 'float' in label) else PEAK_BF16_TFLOPS
+                # split-bf16 spends 3 bf16 MFMAs per algorithmic product: its roofline is a third of the bf16 peak
+                split = self.mode == 'bf16x3' and 'float' not in label and bound != 'valu'
+                peak = PEAK_BF16_TFLOPS / 3 if split else (PEAK_F32_TFLOPS if (self.f32 or bound == 'valu' or 'float' in label) else PEAK_BF16_TFLOPS)
                 r.update(achieved=work / secs / 1e12, unit='TFLOP/s', peak=peak, algorithmic_flops_per_launch=work / launches)
             elif bound == 'hbm':
                 r.update(achieved=work / secs / 1e9, unit='GB/s', peak=PEAK_HBM_GBS, algorithmic_bytes_per_launch=work / launches)
@@ -433,7 +439,7 @@ def bench_encode(cv, args, ws, want_kernels, leg='encode'):
     times = timed_groups(step, args.steps, args.groups, ws)
     rows = None
     if want_kernels:
-        with KernelProfiler(leg, args.dtype == 'fp32') as prof:
+        with KernelProfiler(leg, args.dtype) as prof:
             cv(videos[0], return_only_codebook_ids=True)
         rows = prof.table()
     return times, used_graph, rows
@@ -484,7 +490,7 @@ def bench_decode(cv, args, ws, want_kernels):
                roofline_note='13.37 MB f32 pixels written per video is the HBM floor (SURVEY.md 8d); per-kernel fractions in `kernels`')
     rows = None
     if want_kernels:
-        with KernelProfiler('decode', args.dtype == 'fp32') as prof:
+        with KernelProfiler('decode', args.dtype) as prof:
             cv.decode_from_codebook_indices(idsets[0])
         rows = prof.table()
     return out, rows
@@ -561,7 +567,7 @@ def bench_sample(ph, args, ws, B, name, want_kernels, leg='sample', runs=3):
         steps = ph.steps
         try:
             ph.steps = 2
-            with KernelProfiler(leg, args.dtype == 'fp32') as prof:
+            with KernelProfiler(leg, args.dtype) as prof:
                 ph.sample(texts=['x'] * B, num_frames=17, cond_scale=5.)
             rows = prof.table()
         finally:
@@ -620,20 +626,22 @@ def bench_objective(ph, args, ws):
                      'cross entropy (logits never written) + TokenCritic trunk + BCE; random-init weights, random ids')
 
 
-def bench_parity_mode(args, ws):
-    """the exact-f32 mode -- the configuration the parity tests hold to bit-exact ids / 1e-3 against the REAL reference --
-    timed on the same workloads (v_mfma_f32_16x16x4_f32: 157.3 TFLOP/s peak, 1/16 of bf16)."""
+def bench_parity_mode(args, ws, mode='bf16x3'):
+    """a PARITY-GRADE mode -- a configuration the parity tests hold to bit-exact ids (margin-audited) / 1e-3 against the REAL
+    reference -- timed on the same workloads:
+      'bf16x3' split-bf16: every product as three bf16 MFMAs on (hi, lo) operand planes, f32 activations (roofline 2.5 PF / 3);
+      'fp32'   exact f32 (v_mfma_f32_16x16x4_f32: 157.3 TFLOP/s peak, 1/16 of bf16)."""
     import copy
     a = copy.copy(args)
-    a.dtype, a.groups, a.no_graph = 'fp32', max(5, args.groups // 5), args.no_graph
-    cv, mg, cr, ph = build_models('fp32', not args.no_sample)
+    a.dtype, a.groups, a.no_graph = mode, max(5, args.groups // 5), args.no_graph
+    cv, mg, cr, ph = build_models(mode, not args.no_sample)
     times, used_graph, rows = bench_encode(cv, a, ws, True)
     med = statistics.median(times)
-    out = dict(dtype='f32', metric='cvivit_encode_frames_per_sec', value=a.batch * 17 * a.steps * ws / med, unit='frames/s',
-               ms_per_step=med / a.steps * 1e3, hip_graph=used_graph, roofline=roofline_of(rows, 'fp32', with_traffic=False),
+    out = dict(dtype={'fp32': 'f32'}.get(mode, mode), metric='cvivit_encode_frames_per_sec', value=a.batch * 17 * a.steps * ws / med, unit='frames/s',
+               ms_per_step=med / a.steps * 1e3, hip_graph=used_graph, roofline=roofline_of(rows, mode, with_traffic=False),
                tolerance='ids bit-exact (margin-audited), logits / pixels 1e-3 vs the reference goldens (tests/test_modules_gpu.py)')
     if not args.no_sample:
-        s, _ = bench_sample(ph, a, ws, args.sample_batch, 'BASELINE configs[2] in exact f32', True)
+        s, _ = bench_sample(ph, a, ws, args.sample_batch, f'BASELINE configs[2] in {mode}', True)
         out['sample'] = {k: s[k] for k in ('metric', 'value', 'unit', 'seconds_per_sample_call', 'launch_mode', 'batch_per_gpu', 'roofline') if k in s}
     del cv, mg, cr, ph
     torch.cuda.empty_cache()
@@ -735,7 +743,13 @@ def main():
     del cv, mg, cr, ph
     torch.cuda.empty_cache()
     if not (args.no_parity_mode or args.encode_only) and args.dtype == 'bf16':
-        result['parity_mode'] = bench_parity_mode(args, ws)
+        result['parity_mode'] = bench_parity_mode(args, ws, 'bf16x3')
+        result['parity_mode_f32'] = bench_parity_mode(args, ws, 'fp32')
+        for k in ('value',):
+            f32v, x3v = result['parity_mode_f32'][k], result['parity_mode'][k]
+            result['parity_mode']['speedup_vs_exact_f32'] = dict(encode=x3v / f32v)
+        if 'sample' in result['parity_mode'] and 'sample' in result['parity_mode_f32']:
+            result['parity_mode']['speedup_vs_exact_f32']['sample'] = result['parity_mode']['sample']['value'] / result['parity_mode_f32']['sample']['value']
     if rank == 0 and ws == 1 and not (args.no_cpu or args.encode_only):
         result['cpu_baseline'] = cpu_baseline(args)
     if rank == 0:

@@ -12,6 +12,13 @@
  *       PK_EINVAL (-1) bad shape/size/flag, PK_EALIGN (-2) pointer/stride alignment, PK_ELAUNCH (-3) HIP launch error;
  *   - `dtype`: 0 = exact f32 (f32 MFMA, bit-for-bit an fmaf chain), 1 = bf16 MFMA inputs with f32 accumulation.
  *     "T" below means float for dtype 0 and bf16 (uint16 storage, round-to-nearest-even) for dtype 1;
+ *     2 = split-bf16 ("bf16x3", pk_gemm[_ex] / pk_attn_prep / pk_attn_fwd / pk_vocab_sample / pk_vocab_ce): every product is
+ *     accumulated as hi.hi + hi.lo + lo.hi on the bf16 matrix cores with x = hi + lo, hi = bf16(x), lo = bf16(x - hi)
+ *     (~1e-5 per product; held to the f32 tolerances).  Activations stay f32 (T = float, a_is_f32 / out_is_f32 = 1);
+ *     W [N][ldw] is the PRE-SPLIT image of the zero-padded f32 weight: per row and per block of 32 k-elements 128 bytes =
+ *     [hi x 32 | lo x 32] bf16 (ldw counted in 4-byte units, a multiple of 32; _lib.split_planes); the attention operand
+ *     images Qp / Kp / Vt use the same blocked (hi | lo) format per row (same sizes as dtype 0, 128-byte aligned bases).
+ *     LDS-DMA main loops only; no LayerNorm fold / C2 / row statistics (those are dtype 1 features);
  *   - activations in HBM are f32 unless a parameter says T; rows are row-major with an explicit leading
  *     dimension (ld*, in elements);
  *   - dim_head is fixed at 64 in the attention kernels.
@@ -98,10 +105,14 @@ int pk_peg(const float* x, const float* wt, const float* bias, float* out, void*
 
 /* LFQ (vector-quantize-pytorch, un-vendored; call sites cvivit.py:570 and :439; restated in oracle/lfq.py).
  * encode: proj = x @ Wp^T + bp (f32), ids = sum_k (proj_k > 0) << (cd-1-k); proj (M x cd) optional output.
- * decode: out = (bit ? +1 : -1) @ Wo^T + bo,  Wo is [D][cd]. */
+ * decode: out = (bit ? +1 : -1) @ Wo^T + bo,  Wo is [D][cd].  ids_prime (or NULL): row (b, i) of the M = nb * (n_prime + n) rows takes
+ *   its id from ids_prime[b][i] for i < n_prime and ids[b][i - n_prime] otherwise (phenaki_pytorch.py:535-536: the primed tokens are
+ *   prepended before decoding -- no concatenated copy); pb, pc > 0: row (a, b, c) is written at (a, c, b), the '(b h w) t' order
+ *   the decoder's temporal transformer reads (cvivit.py:482), pb = pc = 0: identity. */
 int pk_lfq_encode(const float* x, int ldx, const float* wp, const float* bp, long long* ids, float* proj,
                   int M, int D, int cd, void* stream);
-int pk_lfq_decode(const long long* ids, const float* wo, const float* bo, float* out, int M, int D, int cd, void* stream);
+int pk_lfq_decode(const long long* ids, const float* wo, const float* bo, float* out, int M, int D, int cd,
+                  const long long* ids_prime, int n_prime, int n, int pb, int pc, void* stream);
 
 /* cvivit.py:472 (the encoder's final norm_out) fused with the LFQ of cvivit.py:570: ids[orow] = LFQ(LayerNorm(x[row]) * gamma
  * (+ beta)) in one pass over x, cd <= 16; orow = the (a, b, c) -> (a, c, b) row permutation of pk_layernorm (pb = 0: identity).

@@ -250,6 +250,79 @@ def recon_loss_golden(R, cfgs, tag):
     print(f'recon_loss_{tag}: {float(loss):.6f} masked {float(loss_masked):.6f} image {float(loss_img):.6f}')
 
 
+def selfcritic_golden(R, cfgs, tag):
+    """Phenaki(self_token_critic=True) of the real reference (phenaki_pytorch.py:306-336, 374-375): the SelfCritic scores (plain and
+    with classifier-free guidance) on fixed ids, and a full free-running sample whose score step is the self critic."""
+    cv, mg, _, _ = build_reference(R, cfgs, with_phenaki=False, with_critic=False)
+    ph = R.Phenaki(maskgit=mg, cvivit=cv, self_token_critic=True, steps=cfgs['steps'], text_embed_dim=cfgs['maskgit']['dim_context'])
+    ph.eval()
+    weights.fill_module(ph.critic.to_pred, salt=4)
+    pt = cfgs['cvivit']['temporal_patch_size']
+    hw = cfgs['cvivit']['image_size'] // cfgs['cvivit']['patch_size']
+    batch, frames, ctx_len = 2, 5, 7
+    patch_shape = (1 + (frames - 1) // pt, hw, hw)
+    n = patch_shape[0] * hw * hw
+    V = cfgs['maskgit']['num_tokens']
+    g = torch.Generator().manual_seed(79)
+    ids = torch.randint(0, V + 1, (batch, n), generator=g)
+    ids[:, ::4] = V
+    ctx = weights.synthetic_context(batch, ctx_len, cfgs['maskgit']['dim_context'], seed=1, pad_last=3)
+    text_mask = (ctx != 0).any(-1)
+    kw = dict(video_patch_shape=patch_shape, context=ctx, text_mask=text_mask)
+    with torch.no_grad():
+        sc_cfg = ph.critic.forward_with_cond_scale(ids, cond_scale=5., **kw)
+        sc_cond = ph.critic(ids, cond_drop_prob=0., **kw)
+    sctx = weights.synthetic_context(batch, 6, cfgs['maskgit']['dim_context'], seed=2)
+    ph.encode_texts = lambda texts, output_device=None: sctx
+    rec = Recorder(R, ph, noise_seed_base=500)
+    rec.keep_logits = False
+    rec.install()
+    try:
+        with torch.no_grad():
+            video = ph.sample(texts=['x'] * batch, num_frames=frames, cond_scale=5.)
+    finally:
+        rec.uninstall()
+    out = dict(ids=ids, patch_shape=patch_shape, ctx_len=ctx_len, critic_cfg=sc_cfg, critic_cond=sc_cond,
+               steps=rec.steps, video=video, batch=batch, frames=frames, sample_ctx_len=6)
+    torch.save(out, os.path.join(OUT, f'selfcritic_{tag}.pt'))
+    print(f'selfcritic_{tag}: scores {tuple(sc_cfg.shape)}, {len(rec.steps)} sampling steps')
+
+
+def unconditional_golden(R, cfgs, tag):
+    """an unconditional MaskGit (phenaki_pytorch.py:125-147: no cross-attention) with a TokenCritic without cross-attention: logits,
+    critic scores and a full free-running sample (no texts) of the real reference."""
+    cv = R.CViViT(use_vgg_and_gan=False, **cfgs['cvivit'])
+    mg = R.MaskGit(**{**cfgs['maskgit'], 'unconditional': True})
+    cr = R.TokenCritic(**{**cfgs['critic'], 'has_cross_attn': False})
+    weights.fill_module(cv, salt=1); weights.fill_module(mg, salt=2); weights.fill_module(cr, salt=3)
+    cv.eval(); mg.eval(); cr.eval()
+    ph = R.Phenaki(maskgit=mg, cvivit=cv, critic=cr, steps=cfgs['steps'], text_embed_dim=cfgs['maskgit']['dim_context'])
+    ph.eval()
+    pt = cfgs['cvivit']['temporal_patch_size']
+    hw = cfgs['cvivit']['image_size'] // cfgs['cvivit']['patch_size']
+    batch, frames = 2, 5
+    patch_shape = (1 + (frames - 1) // pt, hw, hw)
+    n = patch_shape[0] * hw * hw
+    V = cfgs['maskgit']['num_tokens']
+    g = torch.Generator().manual_seed(80)
+    ids = torch.randint(0, V + 1, (batch, n), generator=g)
+    ids[:, 1::3] = V
+    with torch.no_grad():
+        logits = mg(ids, video_patch_shape=patch_shape)
+        scores = cr(ids, video_patch_shape=patch_shape)
+    rec = Recorder(R, ph, noise_seed_base=500)
+    rec.keep_logits = False
+    rec.install()
+    try:
+        with torch.no_grad():
+            video = ph.sample(num_frames=frames, batch_size=batch)
+    finally:
+        rec.uninstall()
+    out = dict(ids=ids, patch_shape=patch_shape, logits=logits, critic=scores, steps=rec.steps, video=video, batch=batch, frames=frames)
+    torch.save(out, os.path.join(OUT, f'unconditional_{tag}.pt'))
+    print(f'unconditional_{tag}: logits {tuple(logits.shape)}, {len(rec.steps)} sampling steps')
+
+
 def keys_golden(R):
     """state_dict contract: every key, shape and dtype of the reference modules."""
     import json
@@ -280,6 +353,9 @@ def main():
     if 'tiny' in which or 'forward' in which:
         forward_golden(R, TINY, batch=3, frames=5, ctx_len=6, tag='tiny')
         recon_loss_golden(R, TINY, tag='tiny')
+    if 'tiny' in which or 'critics' in which:
+        selfcritic_golden(R, TINY, tag='tiny')
+        unconditional_golden(R, TINY, tag='tiny')
     if 'full' in which:
         cvivit_golden(R, FULL, batch=2, frames=17, tag='full', subsample=True)
         maskgit_golden(R, FULL, batch=1, frames=17, ctx_len=12, tag='full', col_stride=512)

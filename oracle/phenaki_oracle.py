@@ -30,8 +30,10 @@ _PRECISION = ['fp32']
 
 class precision:
     def __init__(self, mode):
-        assert mode in ('fp32', 'bf16')
-        self.mode = mode
+        # 'bf16x3' (the product's split-bf16 mode: three bf16 MFMAs per product, ~1e-5 per product) has no rounding points of its
+        # own to mirror: it is held to the f32 arithmetic of the reference at the f32 tolerances
+        assert mode in ('fp32', 'bf16', 'bf16x3')
+        self.mode = 'fp32' if mode == 'bf16x3' else mode
 
     def __enter__(self):
         _PRECISION.append(self.mode)
@@ -406,7 +408,14 @@ def maskgit_cfg(sd, cfg, ids, *, cond_scale, **kw):
 
 def critic_forward(sd, cfg, ids, *, video_patch_shape, context=None, text_mask=None,
                    video_mask=None, null_cond=False):
-    """phenaki_pytorch.py:265-302 (no CPB bias, no grad shrink; head Linear(dim,1))."""
+    """phenaki_pytorch.py:265-302 (no CPB bias, no grad shrink; head Linear(dim,1)).
+    cfg['self_critic'] = (maskgit state_dict, maskgit cfg): the SelfCritic of phenaki_pytorch.py:306-336 instead -- the MaskGit
+    embeddings (return_embeds=True, :334) through `to_pred` = sd['to_pred.0.weight'/'bias']."""
+    if cfg.get('self_critic') is not None:
+        mg_sd, mg_cfg = cfg['self_critic']
+        e = maskgit_forward(mg_sd, mg_cfg, ids, video_patch_shape=video_patch_shape, context=context, text_mask=text_mask,
+                            video_mask=video_mask, null_cond=null_cond, return_embeds=True)
+        return (e @ sd['to_pred.0.weight'].t() + sd['to_pred.0.bias']).squeeze(-1)
     b, n = ids.shape
     if text_mask is None:
         text_mask = torch.ones((b, n), dtype=torch.bool)

@@ -32,7 +32,7 @@ SIGNATURES = {
     'pk_sqdiff_partials': [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     'pk_peg': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'pk_lfq_encode': [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P],
-    'pk_lfq_decode': [_P, _P, _P, _P, _I, _I, _I, _P],
+    'pk_lfq_decode': [_P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _P],
     'pk_layernorm_lfq': [_P, _I, _P, _P, _F, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     'pk_embed': [_P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _P],
     'pk_cpb_input': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -118,12 +118,27 @@ def require_device(t, name='tensor'):
         raise RuntimeError(f'{name} is on {t.device}: the MI355X build runs on HIP devices only (no CPU fallback)')
 
 
-F32, BF16 = 0, 1
+# compute dtypes of the C ABI: exact f32 MFMA | bf16 operands | split-bf16 ("bf16x3": every GEMM / attention product as
+# hi.hi + hi.lo + lo.hi on the bf16 matrix cores, operands x = bf16(x) + bf16(x - bf16(x)); activations stay f32 in memory)
+F32, BF16, BF16X3 = 0, 1, 2
 ACT_NONE, ACT_GEGLU, ACT_LEAKY = 0, 1, 2
 
 
 def tdtype(dtype):
+    """torch dtype of the activations a GEMM of this compute dtype reads / writes as `T`"""
     return torch.bfloat16 if dtype == BF16 else torch.float32
+
+
+def split_planes(w32):
+    """(N, K) f32, K % 32 == 0 -> the pre-split image the bf16x3 kernels read as W (csrc/common.hpp): per row and per block of 32
+    k-elements 64 bf16 = [hi x 32 | lo x 32], hi = bf16(w), lo = bf16(w - hi); returned as an (N, K) float32-TYPED tensor of raw bits
+    (same bytes per row as f32, so strides / the LDS-DMA ring are those of the f32 layout)."""
+    n, k = w32.shape
+    assert k % 32 == 0 and w32.dtype == torch.float32
+    hi = w32.to(torch.bfloat16)
+    lo = (w32 - hi.float()).to(torch.bfloat16)
+    img = torch.cat((hi.view(n, k // 32, 32), lo.view(n, k // 32, 32)), dim=-1).contiguous()       # (n, k/32, 64) bf16
+    return img.view(n, 2 * k).view(torch.float32)
 
 
 # ----------------------------------------------------------------------------- wrappers
@@ -196,8 +211,13 @@ def lfq_encode(x, wp, bp, ids, proj, M, D, cd):
     _check(rc, 'pk_lfq_encode')
 
 
-def lfq_decode(ids, wo, bo, out, M, D, cd):
-    rc = load().pk_lfq_decode(ptr(ids), f32p(wo, 'LFQ project_out.weight'), f32p(bo, 'LFQ project_out.bias'), ptr(out), M, D, cd, stream(out))
+def lfq_decode(ids, wo, bo, out, M, D, cd, *, ids_prime=None, perm=(0, 0)):
+    """out[orow] = project_out(+-1 bits of id[row]); ids_prime (nb, n_prime) int64: the primed tokens in front of every sequence of
+    ids (nb, n) (M = nb * (n_prime + n)); perm = (pb, pc): rows (a, b, c) are written at (a, c, b)"""
+    n_prime = ids_prime.shape[-1] if ids_prime is not None else 0
+    n = ids.shape[-1] if ids_prime is not None else 0
+    rc = load().pk_lfq_decode(ptr(ids), f32p(wo, 'LFQ project_out.weight'), f32p(bo, 'LFQ project_out.bias'), ptr(out), M, D, cd,
+                              ptr(ids_prime), n_prime, n, perm[0], perm[1], stream(out))
     _check(rc, 'pk_lfq_decode')
 
 

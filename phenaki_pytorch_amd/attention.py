@@ -13,7 +13,7 @@ from torch import nn
 
 from . import _lib as L
 
-_DTYPES = {'fp32': L.F32, 'float32': L.F32, 'f32': L.F32, 'bf16': L.BF16, 'bfloat16': L.BF16}
+_DTYPES = {'fp32': L.F32, 'float32': L.F32, 'f32': L.F32, 'bf16': L.BF16, 'bfloat16': L.BF16, 'bf16x3': L.BF16X3}
 
 
 def exists(v):
@@ -31,7 +31,9 @@ def resolve_dtype(name):
 
 
 def set_compute_dtype(module, name):
-    """'fp32' (exact f32 MFMA; the reference's default precision) or 'bf16' (bf16 MFMA operands, f32 accumulation)."""
+    """'fp32' (exact f32 MFMA; the reference's default precision), 'bf16' (bf16 MFMA operands, f32 accumulation) or 'bf16x3'
+    (split-bf16: f32 activations, every matrix product as three bf16 MFMAs on (hi, lo) operand planes -- ~1e-5 per product,
+    held to the same tolerances as 'fp32' at a fraction of its cost)."""
     resolve_dtype(name)
     for m in module.modules():
         m._pk_compute_dtype = name
@@ -141,6 +143,8 @@ def pack_linear_weight(w, dtype):
         return w.detach()              # exact-f32 mode, K already a multiple of the k-tile: the LIVE weight, no copy to go stale
     out = torch.zeros((n, kp), device=w.device, dtype=L.tdtype(dtype))
     out[:, :k] = w.detach().to(out.dtype)
+    if dtype == L.BF16X3:
+        return L.split_planes(out)     # (hi | lo) bf16 planes per 32-element block, typed float32 (raw bits)
     return out
 
 
@@ -599,7 +603,7 @@ class Attention(PackedModule):
         L.layernorm(x2d, self.norm.gamma, self.norm.beta, M, D, out=xn, raw=xraw)
         # exact-f32 mode, very short sequences: one fused f32 launch; in bf16 mode the fused projection + MFMA attention
         # measured faster for the temporal layers (1.030 vs 1.046 ms per encode step)
-        small = not is_cross and nnull == 0 and n <= 16 and dtype == L.F32
+        small = not is_cross and nnull == 0 and n <= 16 and dtype != L.BF16
         # bf16: to_q / to_kv run as ONE GEMM launch whose epilogue writes the attention operand images directly
         # (pk_qkv_project); available for self-attention (no null keys) and for cross-attention with cached K / V
         fused = dtype == L.BF16 and not small and ((not is_cross and nnull == 0) or cached is not None)

@@ -150,6 +150,16 @@ __device__ __forceinline__ void load_vt(Frag<float>& f, const float* row, int kb
     f.hi = *reinterpret_cast<const f32x4*>(row + kb + 16 + g * 4);
 }
 
+// pre-split image (common.hpp bf16x3p): keys kb + g*4 .. +3 and kb + 16 + g*4 .. +3 of one V^T row, from both planes of the block
+__device__ __forceinline__ void load_vt(Frag<bf16x3p>& f, const bf16x3p* row, int kb, int g) {
+    int o;
+    const char* blk = split_block(row + kb, o);               // kb % 32 == 0 and rows start on a block: o == 0
+    const u32x2 a = *reinterpret_cast<const u32x2*>(blk + o + g * 8), b = *reinterpret_cast<const u32x2*>(blk + o + 32 + g * 8);
+    const u32x2 c = *reinterpret_cast<const u32x2*>(blk + 64 + o + g * 8), d = *reinterpret_cast<const u32x2*>(blk + 64 + o + 32 + g * 8);
+    f.hi = u32x4{a[0], a[1], b[0], b[1]};
+    f.lo = u32x4{c[0], c[1], d[0], d[1]};
+}
+
 // V^T columns of keys >= nk (tile padding) are multiplied by p = 0 exactly, but 0 * NaN = NaN: the images written by
 // pk_qkv_project leave those columns untouched, so the tail tile's fragment is masked here instead of zero-filling
 // 17 MB of V^T with a separate launch per layer.  Element e of a fragment is key kb + (e >> 2) * 16 + g * 4 + (e & 3).
@@ -159,6 +169,14 @@ __device__ __forceinline__ void mask_vt_tail(Frag<bf16>& f, int kb, int g, int n
         const int key = kb + (w >> 1) * 16 + g * 4 + (w & 1) * 2;
         const uint32_t m = (key < nk ? 0x0000FFFFu : 0u) | (key + 1 < nk ? 0xFFFF0000u : 0u);
         f.v[w] &= m;
+    }
+}
+__device__ __forceinline__ void mask_vt_tail(Frag<bf16x3p>& f, int kb, int g, int nk) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int key = kb + (w >> 1) * 16 + g * 4 + (w & 1) * 2;
+        const uint32_t m = (key < nk ? 0x0000FFFFu : 0u) | (key + 1 < nk ? 0xFFFF0000u : 0u);
+        f.hi[w] &= m; f.lo[w] &= m;
     }
 }
 __device__ __forceinline__ void mask_vt_tail(Frag<float>& f, int kb, int g, int nk) {
@@ -825,6 +843,12 @@ extern "C" int pk_attn_prep(int dtype, const float* q, int ldq, const float* kv,
     } else if (dtype == 0) {
         hipLaunchKernelGGL((prep_q_kernel<float>), dim3((unsigned)((qrows + 15) / 16)), dim3(256), 0, s, p);
         if (kv) hipLaunchKernelGGL((prep_kv_kernel<float>), dim3((unsigned)(S * h * tiles)), dim3(256), 0, s, p);
+    } else if (dtype == 2) {
+        // split-bf16: the images are pre-split (hi | lo) bf16 planes in 128-byte blocks of 32 elements (common.hpp bf16x3p); same sizes
+        // as the f32 images; rows are 64 / nk_pad (% 32 == 0) elements, the bases must sit on a 128-byte boundary
+        if ((reinterpret_cast<uintptr_t>(Qp) & 127) || (kv && ((reinterpret_cast<uintptr_t>(Kp) | reinterpret_cast<uintptr_t>(Vt)) & 127))) return PK_EALIGN;
+        hipLaunchKernelGGL((prep_q_kernel<bf16x3p>), dim3((unsigned)((qrows + 15) / 16)), dim3(256), 0, s, p);
+        if (kv) hipLaunchKernelGGL((prep_kv_kernel<bf16x3p>), dim3((unsigned)(S * h * tiles)), dim3(256), 0, s, p);
     } else return PK_EINVAL;
     PK_CHECK_LAUNCH();
     return PK_OK;
@@ -916,6 +940,10 @@ extern "C" int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void
     } else if (dtype == 0) {
         if (QF == 2) hipLaunchKernelGGL((attn_fwd_kernel<float, 2>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((attn_fwd_kernel<float, 1>), grid, block, 0, s, a);
+    } else if (dtype == 2) {
+        if (!out_is_f32 || ((reinterpret_cast<uintptr_t>(Qp) | reinterpret_cast<uintptr_t>(Kp) | reinterpret_cast<uintptr_t>(Vt)) & 127)) return PK_EINVAL;
+        if (QF == 2) hipLaunchKernelGGL((attn_fwd_kernel<bf16x3p, 2>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<bf16x3p, 1>), grid, block, 0, s, a);
     } else return PK_EINVAL;
     PK_CHECK_LAUNCH();
     return PK_OK;

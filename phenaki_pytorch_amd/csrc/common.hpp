@@ -25,6 +25,21 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 struct bf16 { u16 v; };   // storage-only bf16 (round-to-nearest-even from f32, like torch)
 
+// ---- split-bf16 ("bf16x3") operand types: f32-grade products on the bf16 matrix cores -----------------------------------
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (both round-to-nearest-even): |x - (hi + lo)| <= 2^-18 |x|.  A product of two such
+// operands is accumulated as hi.hi + hi.lo + lo.hi (three v_mfma_f32_16x16x32_bf16 into the same f32 accumulator; the dropped lo.lo
+// term is <= 2^-18 of the product), i.e. ~1e-5 per-product relative error against 2^-9 for plain bf16 operands -- enough to hold the
+// reference's f32 results to the north-star tolerances (1e-3, bit-exact ids) at 3/16 of the f32-MFMA cost.
+//   bf16x3  : an f32 value in memory (every load / store / epilogue treats it as float).  As a GEMM operand type it means: A rows are
+//             f32 in HBM and LDS and are split in registers after the ds_read; W is PRE-SPLIT by the host packer into 128-byte blocks
+//             of 32 k-elements, [hi x 32 | lo x 32] bf16 -- the same bytes per row as f32, so the LDS-DMA ring is unchanged.
+//   bf16x3p : an element of such a pre-split image IN MEMORY (the attention operand images Q^ / K^ / V^T written by pk_attn_prep):
+//             element e of a row lives in block e / 32 as hi at byte (e % 32) * 2 and lo at byte 64 + (e % 32) * 2.  sizeof = 4 and
+//             rows are multiples of 32 elements from a 128-byte aligned base, so ordinary `T* + element index` pointer arithmetic
+//             still lands in the right block: the accessors below recover (block, position) from the address itself.
+struct bf16x3 { float v; };
+struct bf16x3p { uint32_t v; };
+
 // f32 -> bf16 through the native __bf16 type: hipcc lowers it to v_cvt_pk_bf16_f32 on gfx950 (hardware
 // round-to-nearest-even, one instruction per PAIR instead of ~5 VALU per element for a manual RNE)
 typedef __bf16 bf16x2_native __attribute__((ext_vector_type(2)));
@@ -43,6 +58,8 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
 template <typename T> struct Frag;
 template <> struct Frag<bf16> { u32x4 v; };                 // 8 bf16
 template <> struct Frag<float> { f32x4 lo, hi; };           // 8 f32 (k = g*8 + 0..3 | 4..7)
+template <> struct Frag<bf16x3> { u32x4 hi, lo; };          // 8 values as two bf16 planes: value = hi + lo
+template <> struct Frag<bf16x3p> { u32x4 hi, lo; };
 
 // acc += A_chunk (rows i) x B_chunk (cols j) over the chunk's 32 logical k
 __device__ __forceinline__ f32x4 mma(const Frag<bf16>& a, const Frag<bf16>& b, f32x4 c) {
@@ -57,6 +74,29 @@ __device__ __forceinline__ f32x4 mma(const Frag<float>& a, const Frag<float>& b,
     return c;
 }
 
+// split-bf16: 3 MFMAs per fragment pair, small cross terms first
+template <typename TS>
+__device__ __forceinline__ f32x4 mma_split(const Frag<TS>& a, const Frag<TS>& b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a.hi), __builtin_bit_cast(bf16x8_t, b.lo), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a.lo), __builtin_bit_cast(bf16x8_t, b.hi), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a.hi), __builtin_bit_cast(bf16x8_t, b.hi), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma(const Frag<bf16x3>& a, const Frag<bf16x3>& b, f32x4 c) { return mma_split(a, b, c); }
+__device__ __forceinline__ f32x4 mma(const Frag<bf16x3p>& a, const Frag<bf16x3p>& b, f32x4 c) { return mma_split(a, b, c); }
+
+// 8 f32 values -> (hi, lo) bf16 planes: 4 v_cvt_pk (hi, RNE) + 8 shift/and (hi back to f32) + 8 v_sub (exact: Sterbenz-like, the
+// difference of an f32 and its own 8-bit-mantissa rounding fits in 16 bits) + 4 v_cvt_pk (lo) = 24 VALU per fragment
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t h = pack_bf2(x[2 * i], x[2 * i + 1]);
+        hi[i] = h;
+        const float h0 = __builtin_bit_cast(float, h << 16), h1 = __builtin_bit_cast(float, h & 0xFFFF0000u);
+        lo[i] = pack_bf2(x[2 * i] - h0, x[2 * i + 1] - h1);
+    }
+}
+
 // 8 contiguous elements at p (16-byte aligned for bf16, 32-byte span for f32) -> fragment chunk
 __device__ __forceinline__ void frag_load(Frag<bf16>& f, const bf16* p) {
     f.v = *reinterpret_cast<const u32x4*>(p);
@@ -65,6 +105,20 @@ __device__ __forceinline__ void frag_load(Frag<float>& f, const float* p) {
     f.lo = *reinterpret_cast<const f32x4*>(p);
     f.hi = *reinterpret_cast<const f32x4*>(p + 4);
 }
+// pre-split image: p addresses element e of a row (e % 8 == 0); the 8 values are hi at block + (e % 32) * 2, lo 64 bytes further
+__device__ __forceinline__ const char* split_block(const void* p, int& pos2) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    pos2 = (int)(a & 127) >> 1;                                  // (e % 32) * 2
+    return reinterpret_cast<const char*>(a & ~(uintptr_t)127);
+}
+__device__ __forceinline__ void frag_load(Frag<bf16x3p>& f, const bf16x3p* p) {
+    int o;
+    const char* blk = split_block(p, o);
+    f.hi = *reinterpret_cast<const u32x4*>(blk + o);
+    f.lo = *reinterpret_cast<const u32x4*>(blk + 64 + o);
+}
+__device__ __forceinline__ void frag_zero(Frag<bf16x3p>& f) { f.hi = u32x4{0, 0, 0, 0}; f.lo = f.hi; }
+__device__ __forceinline__ void frag_zero(Frag<bf16x3>& f) { f.hi = u32x4{0, 0, 0, 0}; f.lo = f.hi; }
 __device__ __forceinline__ void frag_zero(Frag<bf16>& f) { f.v = u32x4{0, 0, 0, 0}; }
 __device__ __forceinline__ void frag_zero(Frag<float>& f) { f.lo = f32x4{0, 0, 0, 0}; f.hi = f.lo; }
 
@@ -77,12 +131,34 @@ __device__ __forceinline__ void frag_from_f32(Frag<float>& f, const float (&x)[8
     f.hi = f32x4{x[4], x[5], x[6], x[7]};
 }
 
+__device__ __forceinline__ void frag_from_f32(Frag<bf16x3p>& f, const float (&x)[8]) {
+    split8(f32x4{x[0], x[1], x[2], x[3]}, f32x4{x[4], x[5], x[6], x[7]}, f.hi, f.lo);
+}
+__device__ __forceinline__ void frag_from_f32(Frag<bf16x3>& f, const float (&x)[8]) {
+    split8(f32x4{x[0], x[1], x[2], x[3]}, f32x4{x[4], x[5], x[6], x[7]}, f.hi, f.lo);
+}
+
 // scalar store/convert helpers
 __device__ __forceinline__ void store_elem(float* p, float v) { *p = v; }
 __device__ __forceinline__ void store_elem(bf16* p, float v) { p->v = f2bf(v); }
 __device__ __forceinline__ float load_elem(const float* p) { return *p; }
 __device__ __forceinline__ float load_elem(const bf16* p) { return bf2f(p->v); }
 
+__device__ __forceinline__ void store_elem(bf16x3* p, float v) { p->v = v; }
+__device__ __forceinline__ float load_elem(const bf16x3* p) { return p->v; }
+__device__ __forceinline__ void store4(bf16x3* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void store2(bf16x3* p, float a, float b) { *reinterpret_cast<f32x2*>(p) = f32x2{a, b}; }
+// 4 consecutive elements (e % 4 == 0) of a pre-split image: 8 bytes into each plane of the block the address falls into
+__device__ __forceinline__ void store4(bf16x3p* p, f32x4 v) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    char* blk = reinterpret_cast<char*>(a & ~(uintptr_t)127);
+    const int o = (int)(a & 127) >> 1;
+    const uint32_t h0 = pack_bf2(v[0], v[1]), h1 = pack_bf2(v[2], v[3]);
+    const float r0 = v[0] - __builtin_bit_cast(float, h0 << 16), r1 = v[1] - __builtin_bit_cast(float, h0 & 0xFFFF0000u);
+    const float r2 = v[2] - __builtin_bit_cast(float, h1 << 16), r3 = v[3] - __builtin_bit_cast(float, h1 & 0xFFFF0000u);
+    *reinterpret_cast<u32x2*>(blk + o) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(blk + 64 + o) = u32x2{pack_bf2(r0, r1), pack_bf2(r2, r3)};
+}
 __device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ void store4(bf16* p, f32x4 v) {
     *reinterpret_cast<u32x2*>(p) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
@@ -131,6 +207,7 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 template <typename T> __device__ __forceinline__ float gelu_for(float x);
 template <> __device__ __forceinline__ float gelu_for<float>(float x) { return gelu_erf(x); }
 template <> __device__ __forceinline__ float gelu_for<bf16>(float x) { return gelu_erf_fast(x); }
+template <> __device__ __forceinline__ float gelu_for<bf16x3>(float x) { return gelu_erf(x); }
 
 // ---- counter-based uniform noise shared by the sampler kernels and their tests -------------
 // u = hash(seed, stream, index) mapped to [0, 1) with 24 bits, the same granularity torch's

@@ -132,10 +132,26 @@ __global__ __launch_bounds__(256) void lfq_encode_kernel(const float* __restrict
 // whole launch and walks the rows (grid-stride), so a row costs one 8-byte id read (broadcast), 4*cd signed adds and ONE
 // 16-byte store per thread -- the 2 KB write per token is the only HBM traffic (the first version re-read wo per
 // element: 74 us for 9.4 MB).  HBM-bound: algorithmic bytes = 4*D + 8 per row.
+// token id of flat row `row` over (b, i), i < n_prime + n: from ids_prime[b][i] for the primed positions, ids[b][i - n_prime] otherwise
+// (no torch.cat of the two id arrays on the host); ids_prime == NULL: ids[row]
+__device__ __forceinline__ long long lfq_row_id(const long long* __restrict__ ids_prime, int n_prime, const long long* __restrict__ ids, int n, int row) {
+    if (!ids_prime) return ids[row];
+    const int n_tot = n_prime + n, b = row / n_tot, i = row - b * n_tot;
+    return i < n_prime ? ids_prime[(size_t)b * n_prime + i] : ids[(size_t)b * n + (i - n_prime)];
+}
+// output row of input row r = (a, b, c) with extents (*, pb, pc): (a, c, b) -- the decoder's temporal transformer wants its rows as
+// '(b h w) t' (cvivit.py:482), so the transposed order is written directly instead of through a transpose().contiguous() pass
+__device__ __forceinline__ int lfq_out_row(int r, int pb, int pc) {
+    if (pb <= 0) return r;
+    const int c = r % pc, ab = r / pc, b = ab % pb, a = ab / pb;
+    return (a * pc + c) * pb + b;
+}
+
 template <int CD>
-__global__ __launch_bounds__(256) void lfq_decode_kernel(const long long* __restrict__ ids, const float* __restrict__ wo,
+__global__ __launch_bounds__(256) void lfq_decode_kernel(const long long* __restrict__ ids_prime, int n_prime, const long long* __restrict__ ids, int n,
+                                                         const float* __restrict__ wo,
                                                          const float* __restrict__ bo, float* __restrict__ out,
-                                                         int M, int D, int row_stride) {
+                                                         int M, int D, int row_stride, int pb, int pc) {
     const int dv = D >> 2;                                   // 16-byte column groups per row
     const int lanes = blockDim.x;                            // host: lanes == dv * rpb, rpb rows in flight per block
     const int cg = threadIdx.x % dv, rl = threadIdx.x / dv;
@@ -152,7 +168,7 @@ __global__ __launch_bounds__(256) void lfq_decode_kernel(const long long* __rest
         }
     }
     for (int row = blockIdx.x * (lanes / dv) + rl; row < M; row += row_stride) {
-        const unsigned long long id = (unsigned long long)ids[row];
+        const unsigned long long id = (unsigned long long)lfq_row_id(ids_prime, n_prime, ids, n, row);
         f32x4 acc = b4;
 #pragma unroll
         for (int k = 0; k < CD; ++k) {
@@ -160,24 +176,26 @@ __global__ __launch_bounds__(256) void lfq_decode_kernel(const long long* __rest
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] += on ? w[e][k] : -w[e][k];
         }
-        *reinterpret_cast<f32x4*>(out + (size_t)row * D + cg * 4) = acc;
+        *reinterpret_cast<f32x4*>(out + (size_t)lfq_out_row(row, pb, pc) * D + cg * 4) = acc;
     }
 }
 
 // generic fallback (any D, cd <= 62): one thread per output element
-__global__ __launch_bounds__(256) void lfq_decode_generic_kernel(const long long* __restrict__ ids, const float* __restrict__ wo,
+__global__ __launch_bounds__(256) void lfq_decode_generic_kernel(const long long* __restrict__ ids_prime, int n_prime, const long long* __restrict__ ids, int n,
+                                                                 const float* __restrict__ wo,
                                                                  const float* __restrict__ bo, float* __restrict__ out,
-                                                                 int M, int D, int cd) {
+                                                                 int M, int D, int cd, int pb, int pc) {
     const long total = (long)M * D;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int d = (int)(idx % D);
-        const long long id = ids[idx / D];
+        const int row = (int)(idx / D);
+        const long long id = lfq_row_id(ids_prime, n_prime, ids, n, row);
         float acc = bo[d];
         for (int k = 0; k < cd; ++k) {
             const float sgn = ((id >> (cd - 1 - k)) & 1) ? 1.f : -1.f;
             acc += sgn * wo[(size_t)d * cd + k];
         }
-        out[idx] = acc;
+        out[(size_t)lfq_out_row(row, pb, pc) * D + d] = acc;
     }
 }
 
@@ -301,8 +319,12 @@ extern "C" int pk_lfq_encode(const float* x, int ldx, const float* wp, const flo
     return PK_OK;
 }
 
-extern "C" int pk_lfq_decode(const long long* ids, const float* wo, const float* bo, float* out, int M, int D, int cd, void* stream) {
+extern "C" int pk_lfq_decode(const long long* ids, const float* wo, const float* bo, float* out, int M, int D, int cd,
+                             const long long* ids_prime, int n_prime, int n, int pb, int pc, void* stream) {
     if (!ids || !wo || !bo || !out || M <= 0 || D <= 0 || cd <= 0 || cd > 62) return PK_EINVAL;
+    if (ids_prime && (n_prime <= 0 || n <= 0 || M % (n_prime + n))) return PK_EINVAL;
+    if (!ids_prime) { n_prime = 0; n = 0; }
+    if ((pb > 0) != (pc > 0) || (pb > 0 && M % (pb * pc))) return PK_EINVAL;
     hipStream_t s = STREAM(stream);
     const int dv = D >> 2;
     const bool fast = (D & 3) == 0 && dv <= 256 && (256 % dv == 0 || dv == 256) && (cd == 8 || cd == 16) &&
@@ -312,10 +334,10 @@ extern "C" int pk_lfq_decode(const long long* ids, const float* wo, const float*
         const int rpb = 256 / dv;                               // rows in flight per 256-thread block
         int blocks = (M + rpb - 1) / rpb;
         if (blocks > 512) blocks = 512;                         // 2 blocks per CU: the per-thread weight load is amortised over >= 4 rows at M = 4608
-        if (cd == 16) hipLaunchKernelGGL((lfq_decode_kernel<16>), dim3(blocks), dim3(256), 0, s, ids, wo, bo, out, M, D, blocks * rpb);
-        else hipLaunchKernelGGL((lfq_decode_kernel<8>), dim3(blocks), dim3(256), 0, s, ids, wo, bo, out, M, D, blocks * rpb);
+        if (cd == 16) hipLaunchKernelGGL((lfq_decode_kernel<16>), dim3(blocks), dim3(256), 0, s, ids_prime, n_prime, ids, n, wo, bo, out, M, D, blocks * rpb, pb, pc);
+        else hipLaunchKernelGGL((lfq_decode_kernel<8>), dim3(blocks), dim3(256), 0, s, ids_prime, n_prime, ids, n, wo, bo, out, M, D, blocks * rpb, pb, pc);
     } else {
-        hipLaunchKernelGGL(lfq_decode_generic_kernel, dim3(nblocks((long)M * D)), dim3(256), 0, s, ids, wo, bo, out, M, D, cd);
+        hipLaunchKernelGGL(lfq_decode_generic_kernel, dim3(nblocks((long)M * D)), dim3(256), 0, s, ids_prime, n_prime, ids, n, wo, bo, out, M, D, cd, pb, pc);
     }
     PK_CHECK_LAUNCH();
     return PK_OK;

@@ -338,8 +338,10 @@ static int auto_variant(int dtype, int a_is_f32, int M, int N, int K, int lda, i
     static const long t128 = getenv("PK_GEMM_T128") ? atol(getenv("PK_GEMM_T128")) : 256;      // tuning knob
     // 256..383 tiles of 128x128 with a short K (the sampling loop's to_out, M = 9216, N = K = 512: 288 tiles = 1.1 per CU): 128x64
     // tiles give every CU 2+ workgroups -- 14.9 vs 17.0 us with the residual epilogue (8-wave 128x64 / 64x128 layouts: 16.5 us)
-    if (dtype == 1 && blocks128 >= t128 && blocks128 < 384 && K <= 1024) return 27;
-    if (blocks128 >= t128) return 24;                                       // 128x128, 8 waves, 2 stages (16 waves/CU)
+    if (dtype != 0 && blocks128 >= t128 && blocks128 < 384 && K <= 1024) return 27;
+    // split-bf16: 128x128 with 4 waves (64x64 wave tiles: every in-register A split feeds 4 column fragments): 98 vs 107 us at
+    // 9216 x 2736 x 512, 185 vs 208 us at 18432 rows (tools/gemm_bench.py --mode bf16x3)
+    if (blocks128 >= t128) return dtype == 2 ? 9 : 24;                      // 128x128, 8 waves, 2 stages (16 waves/CU)
     if (K >= 2048) return dtype == 1 ? 33 : 3;      // long K (patch embed): 64x64, 3-stage ring fed by 2 producer waves (bf16) / 4 stages
     return 8;                                                               // 64x64, 2 stages (5 WG/CU)
 }
@@ -357,14 +359,15 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
                           int variant, void* C2, int ldc2, const float* ln_s, const float* ln_t, float ln_eps,
                           const int* row_off, const int* col_off, float* stats_out, const float* ln_stats, int dup_rows, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !C) return PK_EINVAL;
-    if (dtype != 0 && dtype != 1) return PK_EINVAL;
+    if (dtype != 0 && dtype != 1 && dtype != 2) return PK_EINVAL;
     if (act < 0 || act > 2) return PK_EINVAL;
-    const int eps_w = dtype == 1 ? 8 : 4;                        // elements per 16 B of W
+    const int eps_w = dtype == 1 ? 8 : 4;                        // elements per 16 B of W (split-bf16: W is counted in 4-byte units, like f32)
     const int eps_a = (dtype == 1 && !a_is_f32) ? 8 : 4;         // alignment quantum of A rows
     if (K % eps_w || ldw % eps_w || lda % eps_a) return PK_EALIGN;
     if (dtype == 1 && a_is_f32 && (K % 8)) return PK_EALIGN;
     if (!al16(A) || !al16(W)) return PK_EALIGN;
-    if (dtype == 0 && !a_is_f32) return PK_EINVAL;               // exact-f32 mode keeps everything f32
+    if (dtype != 1 && !a_is_f32) return PK_EINVAL;               // exact-f32 and split-bf16 modes keep every activation f32
+    if (dtype == 2 && (ln_s || ln_stats || stats_out || C2)) return PK_EINVAL;      // LayerNorm fold / bf16 copies are bf16-mode features
     if (act == ACT_GEGLU && (N & 1)) return PK_EINVAL;
     if (a_rows && a_nrows <= 0) return PK_EINVAL;
     if (!a_rows) a_nrows = M;
@@ -412,6 +415,19 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
             case 24: return launch_dma<bf16, 4, 2, 2, 2, 4>(p, e, a_nrows, s);          // 128x128, 8 waves (2x4), 2 stages (64 KB: 16 waves/CU)
             case 33: return launch_dma<bf16, 2, 2, 3, 2, 2, 128, 2>(p, e, a_nrows, s);  // 64x64, 4 consumers + 2 producers, 3 stages (long K)
             case 27: return launch_dma<bf16, 4, 2, 2, 2, 2>(p, e, a_nrows, s);          // 128x64, 4 waves (wave tile 64x32), 2 stages (48 KB: 3 WG/CU)
+            default: return PK_EINVAL;
+        }
+    }
+    if (dtype == 2) {
+        // split-bf16 ("bf16x3", common.hpp): f32 A rows split in registers, host-packed (hi | lo) W planes, 3 bf16 MFMAs per fragment
+        // pair; LDS-DMA main loops only (the register-staged fallbacks do not exist for it)
+        if (!dma_ok) return PK_EINVAL;
+        switch (variant) {
+            case 3: return launch_dma<bf16x3, 2, 2, 4>(p, e, a_nrows, s);                // 64x64, 4 stages (long K)
+            case 8: return launch_dma<bf16x3, 2, 2, 2>(p, e, a_nrows, s);
+            case 9: return launch_dma<bf16x3, 4, 4, 2>(p, e, a_nrows, s);
+            case 24: return launch_dma<bf16x3, 4, 2, 2, 2, 4>(p, e, a_nrows, s);
+            case 27: return launch_dma<bf16x3, 4, 2, 2, 2, 2>(p, e, a_nrows, s);
             default: return PK_EINVAL;
         }
     }

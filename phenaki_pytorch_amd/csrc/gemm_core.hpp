@@ -63,6 +63,23 @@ __device__ __forceinline__ void lds_frag(Frag<float>& f, const char* tile, int r
     f.hi = *reinterpret_cast<const f32x4*>(tile + row * 128 + (s1 << 4));
 }
 
+// A-tile / W-tile fragment reads: the same image for bf16 and f32; for the split-bf16 operand type (common.hpp) the A tile holds
+// f32 rows (32 k per 128-byte row), split into (hi, lo) planes in registers, and the W tile holds the host-packed planes
+// [hi x 32 | lo x 32]: k = g*8 .. g*8+7 of a row is slot g (hi) and slot 4 + g (lo).  Both use the slot ^ (row & 7) swizzle.
+template <typename T> __device__ __forceinline__ void lds_frag_a(Frag<T>& f, const char* tile, int row, int chunk, int g) { lds_frag(f, tile, row, chunk, g); }
+template <typename T> __device__ __forceinline__ void lds_frag_w(Frag<T>& f, const char* tile, int row, int chunk, int g) { lds_frag(f, tile, row, chunk, g); }
+template <> __device__ __forceinline__ void lds_frag_a<bf16x3>(Frag<bf16x3>& f, const char* tile, int row, int /*chunk*/, int g) {
+    const int s0 = (2 * g) ^ (row & 7), s1 = (2 * g + 1) ^ (row & 7);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(tile + row * 128 + (s0 << 4));
+    const f32x4 b = *reinterpret_cast<const f32x4*>(tile + row * 128 + (s1 << 4));
+    split8(a, b, f.hi, f.lo);
+}
+template <> __device__ __forceinline__ void lds_frag_w<bf16x3>(Frag<bf16x3>& f, const char* tile, int row, int /*chunk*/, int g) {
+    const int s0 = g ^ (row & 7), s1 = (4 + g) ^ (row & 7);
+    f.hi = *reinterpret_cast<const u32x4*>(tile + row * 128 + (s0 << 4));
+    f.lo = *reinterpret_cast<const u32x4*>(tile + row * 128 + (s1 << 4));
+}
+
 template <typename T, typename TA, int TM, int TN>
 struct GemmTile {
     static constexpr int BM = 32 * TM, BN = 32 * TN;

@@ -55,6 +55,15 @@ __device__ __forceinline__ int pk_tl_wg() {
 #define PK_TL(slot) do {} while (0)
 #endif
 
+__device__ __forceinline__ void frag_stats(const Frag<bf16x3>& f, float& s, float& q, bool want_sq) {      // (no LayerNorm fold in split mode: unused)
+    const uint32_t ones = 0x3f803f80u;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        dot2acc_bf16(s, f.hi[w], ones); dot2acc_bf16(s, f.lo[w], ones);
+        if (want_sq) { dot2acc_bf16(q, f.hi[w], f.hi[w]); dot2acc_bf16(q, f.hi[w], f.lo[w]); dot2acc_bf16(q, f.hi[w], f.lo[w]); }
+    }
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // TM x TN MFMA tiles per wave, WM x WN compute waves per workgroup, ROWB bytes of k per LDS row.
@@ -194,9 +203,9 @@ struct GemmDma {
             for (int c = 0; c < CH; ++c) {
                 Frag<T> fa[TM], fw[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) lds_frag(fa[i], a, wm * 16 * TM + i * 16 + lr, c, g);
+                for (int i = 0; i < TM; ++i) lds_frag_a<T>(fa[i], a, wm * 16 * TM + i * 16 + lr, c, g);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) lds_frag(fw[j], w, wn * 16 * TN + j * 16 + lr, c, g);
+                for (int j = 0; j < TN; ++j) lds_frag_w<T>(fw[j], w, wn * 16 * TN + j * 16 + lr, c, g);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll

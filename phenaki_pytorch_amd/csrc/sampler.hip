@@ -56,12 +56,16 @@ struct VocabArgs {
 // vocab-head tile: 128 rows x 128 vocabulary columns, 8 waves as 2 (rows) x 4 (cols), wave tile 64 x 32, LDS-DMA ring of 2
 // (64 KB -> 2 workgroups = 16 waves per CU): the best main loop for N = 65 536 in tools/gemm_bench.py that exists for
 // both operand types
-constexpr int VTM = 4, VTN = 2, VWM = 2, VWN = 4;
-template <typename T> using VocabTile = GemmDma<T, VTM, VTN, VWM, VWN, 2>;
+// (split-bf16: 4 waves as 2 x 2 with 64 x 64 wave tiles -- each A fragment's in-register split is shared by 4 instead of 2 column
+// fragments; tools/gemm_bench.py: 1138 vs 1328 us on the 4608 x 65536 x 512 head)
+template <typename T> struct VocabGeom { static constexpr int TM = 4, TN = 2, WM = 2, WN = 4; };
+template <> struct VocabGeom<bf16x3> { static constexpr int TM = 4, TN = 4, WM = 2, WN = 2; };
+template <typename T> using VocabTile = GemmDma<T, VocabGeom<T>::TM, VocabGeom<T>::TN, VocabGeom<T>::WM, VocabGeom<T>::WN, 2>;
 
 template <typename T, bool PARITY, bool LSE>
-__global__ __launch_bounds__(64 * VWM * VWN) void vocab_sample_kernel(const GemmOperands p, const VocabArgs e) {
+__global__ __launch_bounds__(64 * VocabGeom<T>::WM * VocabGeom<T>::WN) void vocab_sample_kernel(const GemmOperands p, const VocabArgs e) {
     using Tile = VocabTile<T>;
+    constexpr int VTM = VocabGeom<T>::TM, VTN = VocabGeom<T>::TN, VWN = VocabGeom<T>::WN;
     static_assert(Tile::BM == 128 && Tile::BN == 128, "partials are laid out per 128-column tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int m0 = blockIdx.x * Tile::BM, n0 = blockIdx.y * Tile::BN;
@@ -249,6 +253,13 @@ __global__ __launch_bounds__(256) void vocab_reduce_kernel(const float* __restri
 // cross entropy of the vocab head WITHOUT the logits (the masked-token objective, phenaki_pytorch.py:640-643): one wave per
 // row folds the (max, sum exp) partials pk_vocab_sample left per 128-column tile into lse, and takes the target logit as
 // the dot product of the row with ONE row of W (+ bias): loss[m] = lse - logit[target]
+// element c of a weight row as the main loop sees it (split-bf16: hi + lo of the host-packed planes, block c / 32)
+template <typename T> __device__ __forceinline__ float w_elem(const T* wrow, int c) { return load_elem(wrow + c); }
+template <> __device__ __forceinline__ float w_elem<bf16x3>(const bf16x3* wrow, int c) {
+    const u16* blk = reinterpret_cast<const u16*>(wrow + (c & ~31));
+    return bf2f(blk[c & 31]) + bf2f(blk[32 + (c & 31)]);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void vocab_ce_kernel(const float* __restrict__ p_max, const float* __restrict__ p_sum, int ntiles, int M,
                                                        const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(256) void vocab_ce_kernel(const float* __restrict__
     const T* a = A + (size_t)m * lda;
     const T* w = W + (size_t)tgt * ldw;
     float dot = 0.f;
-    for (int c = lane; c < D; c += 64) dot += load_elem(a + c) * load_elem(w + c);
+    for (int c = lane; c < D; c += 64) dot += load_elem(a + c) * w_elem<T>(w, c);
     dot = wave_sum(dot);
     if (lane == 0) loss[m] = (gmax + logf(gsum)) - (dot + bias[tgt]);
 }
@@ -331,7 +342,7 @@ extern "C" int pk_vocab_sample(int dtype, const void* A, int lda, const void* W,
                                int M, int V, int D, float temperature, const float* U, const int* rows,
                                unsigned long long seed, const unsigned long long* seed_dev, int need_lse, void* partials, void* stream) {
     if (!A || !W || !bias || !partials || M <= 0 || V <= 0 || D <= 0) return PK_EINVAL;
-    if (dtype != 0 && dtype != 1) return PK_EINVAL;
+    if (dtype != 0 && dtype != 1 && dtype != 2) return PK_EINVAL;
     const int eps = dtype == 1 ? 8 : 4;
     if ((V & 3) || (D % eps) || (lda % eps) || (ldw % eps) || !al16(A) || !al16(W) || !al16(bias) || (U && !al16(U))) return PK_EALIGN;
     const int ntiles = pk_vocab_ntiles(V);
@@ -350,13 +361,16 @@ extern "C" int pk_vocab_sample(int dtype, const void* A, int lda, const void* W,
     e.p_logit = reinterpret_cast<float*>(partials) + 2 * sz;
     e.p_max = reinterpret_cast<float*>(partials) + 3 * sz;
     e.p_sum = reinterpret_cast<float*>(partials) + 4 * sz;
-    dim3 grid((M + 127) / 128, ntiles), block(64 * VWM * VWN);
+    dim3 grid((M + 127) / 128, ntiles);
     hipStream_t s = STREAM(stream);
-#define PK_VS(TT, PAR, LS) hipLaunchKernelGGL((vocab_sample_kernel<TT, PAR, LS>), grid, block, VocabTile<TT>::SMEM, s, p, e)
+#define PK_VS(TT, PAR, LS) hipLaunchKernelGGL((vocab_sample_kernel<TT, PAR, LS>), grid, dim3(VocabTile<TT>::THREADS), VocabTile<TT>::SMEM, s, p, e)
     const bool lse = e.need_lse != 0;
     if (dtype == 1) {
         if (U) { if (lse) PK_VS(bf16, true, true); else PK_VS(bf16, true, false); }
         else { if (lse) PK_VS(bf16, false, true); else PK_VS(bf16, false, false); }
+    } else if (dtype == 2) {                              // split-bf16: f32 rows of A, host-packed (hi | lo) planes of W (common.hpp)
+        if (U) { if (lse) PK_VS(bf16x3, true, true); else PK_VS(bf16x3, true, false); }
+        else { if (lse) PK_VS(bf16x3, false, true); else PK_VS(bf16x3, false, false); }
     } else {
         if (U) { if (lse) PK_VS(float, true, true); else PK_VS(float, true, false); }
         else { if (lse) PK_VS(float, false, true); else PK_VS(float, false, false); }
@@ -385,11 +399,17 @@ extern "C" int pk_vocab_reduce(const void* partials, int M, int V, const int* ro
 extern "C" int pk_vocab_ce(int dtype, const void* partials, int M, int V, const void* A, int lda, const void* W, int ldw,
                            const float* bias, int D, const long long* targets, const int* rows, float* loss, void* stream) {
     if (!partials || !A || !W || !bias || !targets || !loss || M <= 0 || V <= 0 || D <= 0) return PK_EINVAL;
-    if (dtype != 0 && dtype != 1) return PK_EINVAL;
+    if (dtype != 0 && dtype != 1 && dtype != 2) return PK_EINVAL;
     const int ntiles = pk_vocab_ntiles(V);
     const size_t sz = (size_t)ntiles * M;
     const float* f = reinterpret_cast<const float*>(partials);
     const dim3 grid((M + 3) / 4);
+    if (dtype == 2) {
+        hipLaunchKernelGGL((vocab_ce_kernel<bf16x3>), grid, dim3(256), 0, STREAM(stream), f + 3 * sz, f + 4 * sz, ntiles, M,
+                           reinterpret_cast<const bf16x3*>(A), lda, reinterpret_cast<const bf16x3*>(W), ldw, bias, D, targets, rows, loss);
+        PK_CHECK_LAUNCH();
+        return PK_OK;
+    }
     if (dtype == 1) hipLaunchKernelGGL((vocab_ce_kernel<bf16>), grid, dim3(256), 0, STREAM(stream), f + 3 * sz, f + 4 * sz, ntiles, M,
                                        reinterpret_cast<const bf16*>(A), lda, reinterpret_cast<const bf16*>(W), ldw, bias, D, targets, rows, loss);
     else hipLaunchKernelGGL((vocab_ce_kernel<float>), grid, dim3(256), 0, STREAM(stream), f + 3 * sz, f + 4 * sz, ntiles, M,

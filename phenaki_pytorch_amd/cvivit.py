@@ -239,12 +239,16 @@ class CViViT(PackedModule):
             cache[key] = tuple(t.to(device=dev, dtype=torch.int32).contiguous() for t in (idx, row_off, col_off))
         return cache[key]
 
-    def _decode2d(self, tokens2d, B, T):
-        """tokens (B*T*h*w, dim) f32 -> video (B, C, 1 + (T-1)*pt, H, W) f32 (cvivit.py:476-516)."""
+    def _decode2d(self, tokens2d, B, T, temporal_rows=False):
+        """tokens (B*T*h*w, dim) f32 -> video (B, C, 1 + (T-1)*pt, H, W) f32 (cvivit.py:476-516).
+        temporal_rows: the rows already are in the '(b h w) t' order of the temporal transformer (pk_lfq_decode wrote them so)."""
         dt = compute_dtype_of(self)
         hw0 = self.image_num_tokens
         D0 = tokens2d.shape[-1]
-        xt = tokens2d.view(B, T, hw0, D0).transpose(1, 2).contiguous().view(B * hw0 * T, D0)    # 'b t h w d -> (b h w) t d'
+        if temporal_rows:
+            xt = tokens2d
+        else:
+            xt = tokens2d.view(B, T, hw0, D0).transpose(1, 2).contiguous().view(B * hw0 * T, D0)    # 'b t h w d -> (b h w) t d'
         x, x_t = self._temporal(self.dec_temporal_transformer, xt, B, T, want_t=True)
         x = self._spatial(self.dec_spatial_transformer, x, B, T, as_t=True, xt=x_t)
         h, w = self.patch_height_width
@@ -278,15 +282,21 @@ class CViViT(PackedModule):
 
     # ---------------------------------------------------------------- public surface (cvivit.py:437-583)
 
-    def decode_from_codebook_indices(self, indices):
+    def decode_from_codebook_indices(self, indices, _prime_indices=None):
+        """cvivit.py:437-447.  _prime_indices (B, n_prime) int64: tokens in front of every sequence of `indices` (the sampler's primed
+        frames, phenaki_pytorch.py:535-536) without a concatenated copy."""
         L.require_device(indices, 'indices')
         B = indices.shape[0]
         hw = self.image_num_tokens
         flat = indices.reshape(B, -1)
-        assert flat.shape[1] % hw == 0
-        T = flat.shape[1] // hw
-        codes = self.vq.codes_2d(flat.reshape(-1).long())
-        return self._decode2d(codes, B, T)
+        if flat.dtype != torch.int64:
+            flat = flat.long()
+        n_tot = flat.shape[1] + (_prime_indices.shape[1] if _prime_indices is not None else 0)
+        assert n_tot % hw == 0
+        T = n_tot // hw
+        # the quantizer writes the code rows directly in the temporal transformer's '(b h w) t' order: no transpose pass
+        codes = self.vq.codes_2d(flat, ids_prime=_prime_indices, perm=(T, hw))
+        return self._decode2d(codes, B, T, temporal_rows=True)
 
     def encode(self, tokens):
         L.require_device(tokens, 'tokens')
@@ -358,7 +368,7 @@ class CViViT(PackedModule):
                                       'return_only_codebook_ids=True and return_recons_only=True are supported')
         ids = self.tokenize(video).reshape(-1)
         T = 1 + (f - 1) // self.temporal_patch_size
-        recon = self._decode2d(self.vq.codes_2d(ids), b, T)
+        recon = self._decode2d(self.vq.codes_2d(ids, perm=(T, self.image_num_tokens)), b, T, temporal_rows=True)
         returned_recon = recon.squeeze(2) if is_image else recon
         if return_recons_only:
             return returned_recon

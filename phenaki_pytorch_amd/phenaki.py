@@ -454,12 +454,15 @@ class Phenaki(PackedModule):
 
     # ------------------------------------------------------------------------------------------ sampling (phenaki_pytorch.py:418-560)
 
-    def enable_sample_graph(self, on=True):
+    def enable_sample_graph(self, on=True, static_output=False):
         """replay the whole 18-step sampling loop + final decode as ONE captured hipGraph per (batch, frames, prime, context
         length, guidance, temperature) configuration: ~3 000 kernel launches become one graph launch.  Noise stays fresh per
         call (the kernels add a device-resident seed word to their captured seeds).  Eager launches remain the default and the
-        only mode for the parity hooks (_noise_fn / _trace)."""
+        only mode for the parity hooks (_noise_fn / _trace).
+        static_output=True: `sample` returns the graph's OWN output buffer (overwritten by the next call with the same configuration)
+        instead of a clone of it -- saves a 13.4 MB-per-video copy per call for callers that consume the video before sampling again."""
         self.__dict__['_pk_sample_graph'] = bool(on)
+        self.__dict__['_pk_sample_graph_static'] = bool(on and static_output)
         if not on:
             self.__dict__.pop('_pk_sample_graphs', None)
         return self
@@ -493,6 +496,11 @@ class Phenaki(PackedModule):
                 if st['compact']:
                     rows, M = rows_buf, B * ks[step]
                 L.topk_mask(cur, B, n, ks[step], self.mask_id, mask, ids, rows, scores_next=nxt if need_lse else None)
+
+            if st.get('force_fn') is not None:
+                # parity hook (eager only): the caller overwrites this step's masked ids / mask in place -- teacher forcing from a
+                # reference run's recorded inputs (tests: all 18 steps audited even after a near-tie changed a free-running input)
+                st['force_fn'](step, ids, mask)
 
             rec = None
             if trace is not None:
@@ -533,8 +541,7 @@ class Phenaki(PackedModule):
             if rec is not None:
                 trace.append(rec)
 
-        full = ids if st['prime_ids'] is None else torch.cat((st['prime_ids'], ids), dim=-1)
-        video = self.cvivit.decode_from_codebook_indices(full)
+        video = self.cvivit.decode_from_codebook_indices(ids, _prime_indices=st['prime_ids'])
         if st['prime_ids'] is not None:
             video = video[:, :, st['prime_num_frames']:]
         return video
@@ -554,11 +561,13 @@ class Phenaki(PackedModule):
     @eval_decorator
     @torch.no_grad()
     def sample(self, *, num_frames, texts=None, prime_frames=None, batch_size=1, cond_scale=3.,
-               starting_temperature=0.9, noise_K=1., _noise_fn=None, _trace=None, _return_ids=False, _compact=None, _seed=None):
+               starting_temperature=0.9, noise_K=1., _noise_fn=None, _trace=None, _return_ids=False, _compact=None, _seed=None,
+               _force_fn=None):
         """phenaki_pytorch.py:418-560.  `_noise_fn(kind, step, shape)` (tests) injects the U[0,1) draws of the
         reference run ('gumbel' (B,n,V) and 'critic' (B,n), device f32 tensors); without it the noise comes from the
         in-kernel counter hash seeded from torch's default (CPU) generator (`_seed`: the exact 64-bit stream seed instead;
-        the seed a call used is kept in `self._pk_last_seed`)."""
+        the seed a call used is kept in `self._pk_last_seed`).  `_force_fn(step, ids, mask)` (tests) may overwrite a step's masked
+        input ids (B, n) int64 and mask (B, n) uint8 in place before the trunk runs (teacher forcing; eager, no row compaction)."""
         device = next(self.parameters()).device
         L.require_device(next(self.parameters()), 'Phenaki parameters')
         mg, critic = self.maskgit, self.critic
@@ -605,8 +614,10 @@ class Phenaki(PackedModule):
             seed_base = int(_seed) & 0x3FFFFFFFFFFFFFFF
         self.__dict__['_pk_last_seed'] = seed_base
         compact = (_trace is None) if _compact is None else bool(_compact)    # traces record the prediction at EVERY position
+        if _force_fn is not None:
+            compact = False                                                    # the forced mask need not be the top-k one
 
-        use_graph = self.__dict__.get('_pk_sample_graph', False) and _noise_fn is None and _trace is None
+        use_graph = self.__dict__.get('_pk_sample_graph', False) and _noise_fn is None and _trace is None and _force_fn is None
         key = (B, n, prime_token_length, prime_num_frames, tuple(patch_shape), None if text_embeds is None else tuple(text_embeds.shape),
                float(cond_scale), float(starting_temperature), float(noise_K), compact, dt, str(device), self.steps,
                self.critic_noise_anneal_schedule)
@@ -636,7 +647,7 @@ class Phenaki(PackedModule):
             st['mask'].fill_(1)
             st['seed_dev'].fill_(seed_base)
             entry['graph'].replay()
-            video = entry['video'].clone()
+            video = entry['video'] if self.__dict__.get('_pk_sample_graph_static') else entry['video'].clone()
             return (video, st['ids'].clone()) if _return_ids else video
 
         if use_graph and exists(text_embeds):
@@ -644,7 +655,7 @@ class Phenaki(PackedModule):
         st = self._sample_state(B, n, prime_token_length, device, dt)
         st.update(patch_shape=patch_shape, prime_ids=prime_token_ids, prime_num_frames=prime_num_frames, ks=mask_schedule(n, self.steps),
                   cond_scale=cond_scale, starting_temperature=starting_temperature, noise_K=noise_K, compact=compact,
-                  noise_fn=_noise_fn, trace=_trace, seed_base=seed_base, seed_dev=None, with_null=with_null, c_null=c_null,
+                  noise_fn=_noise_fn, trace=_trace, force_fn=_force_fn, seed_base=seed_base, seed_dev=None, with_null=with_null, c_null=c_null,
                   ctx_r=rep(text_embeds).contiguous() if has_ctx else None, tm_r=_cfg_masks(text_mask, B, with_null) if has_ctx else None,
                   c_ctx_r=crep(text_embeds).contiguous() if c_has_ctx else None, c_tm_r=_cfg_masks(text_mask, B, c_null) if c_has_ctx else None)
         st['ids'].fill_(self.mask_id)
@@ -670,7 +681,7 @@ class Phenaki(PackedModule):
         entry['graph'] = graph
         graphs[key] = entry
         graph.replay()
-        video = entry['video'].clone()
+        video = entry['video'] if self.__dict__.get('_pk_sample_graph_static') else entry['video'].clone()
         return (video, st['ids'].clone()) if _return_ids else video
 
 

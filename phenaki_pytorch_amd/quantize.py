@@ -46,12 +46,14 @@ class LFQ(nn.Module):
                         proj=proj, perm=perm)
         return (ids, proj) if return_proj else ids
 
-    def codes_2d(self, ids_flat):
-        """ids (M,) int64 -> project_out(+-1 codes) (M, dim) f32"""
+    def codes_2d(self, ids_flat, *, ids_prime=None, perm=(0, 0)):
+        """ids (M,) int64 -> project_out(+-1 codes) (M, dim) f32.  ids_prime (nb, n_prime): primed tokens in front of every sequence of
+        `ids_flat` given as (nb, n); perm = (pb, pc): output rows (a, b, c) -> (a, c, b) (see pk_lfq_decode)"""
         L.require_device(ids_flat, 'indices')
-        M = ids_flat.numel()
+        M = ids_flat.numel() + (ids_prime.numel() if ids_prime is not None else 0)
         out = torch.empty((M, self.dim), device=ids_flat.device, dtype=torch.float32)
-        L.lfq_decode(ids_flat.contiguous(), self.project_out.weight, self.project_out.bias, out, M, self.dim, self.codebook_dim)
+        ids = ids_flat if ids_flat.is_contiguous() else ids_flat.contiguous()
+        L.lfq_decode(ids, self.project_out.weight, self.project_out.bias, out, M, self.dim, self.codebook_dim, ids_prime=ids_prime, perm=perm)
         return out
 
     def indices_to_codes(self, indices, project_out=True):
@@ -117,8 +119,14 @@ class VectorQuantize(nn.Module):
         L.vocab_reduce(partials, M, V, None, None, None, ids, None, False)
         return ids
 
-    def codes_2d(self, ids_flat):
-        return self.codebook.index_select(0, ids_flat.reshape(-1).long())
+    def codes_2d(self, ids_flat, *, ids_prime=None, perm=(0, 0)):
+        if ids_prime is not None:
+            ids_flat = torch.cat((ids_prime, ids_flat), dim=-1)
+        codes = self.codebook.index_select(0, ids_flat.reshape(-1).long())
+        if perm[0]:
+            pb, pc = perm
+            codes = codes.view(-1, pb, pc, codes.shape[-1]).transpose(1, 2).reshape(-1, codes.shape[-1])
+        return codes
 
     def forward(self, x, mask=None, **_unused):
         b, n, d = x.shape

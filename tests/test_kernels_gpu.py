@@ -236,6 +236,26 @@ def test_lfq_decode_shapes(L, M, D, cd):
     close(out, O.lfq_codes(sd, ids), 1e-5, f'lfq codes {M}x{D} cd={cd}')
 
 
+@pytest.mark.parametrize('nb,n_prime,n,pb,pc,D,cd', [(3, 8, 16, 6, 4, 512, 16), (2, 0, 12, 3, 4, 128, 8), (2, 5, 10, 0, 0, 96, 10), (1, 64, 512, 9, 64, 512, 16)])
+def test_lfq_decode_prime_ids_and_transposed_rows(L, nb, n_prime, n, pb, pc, D, cd):
+    """pk_lfq_decode reading the primed tokens from a second id array (no torch.cat, phenaki_pytorch.py:535-536) and writing its rows
+    in the temporal transformer's '(b h w) t' order (cvivit.py:482: no transpose().contiguous() pass) -- bit-identical to the
+    concatenate / decode / transpose sequence it replaces."""
+    sd = {'vq.project_in.weight': torch.zeros(cd, D), 'vq.project_out.weight': torch.randn(D, cd, generator=g(24)) / 4,
+          'vq.project_out.bias': torch.randn(D, generator=g(25)) * 0.05}
+    wo, bo = sd['vq.project_out.weight'].cuda(), sd['vq.project_out.bias'].cuda()
+    ids = torch.randint(0, 2 ** cd, (nb, n), generator=g(26)).cuda()
+    prime = torch.randint(0, 2 ** cd, (nb, n_prime), generator=g(27)).cuda() if n_prime else None
+    full = torch.cat((prime, ids), dim=-1) if n_prime else ids
+    M = full.numel()
+    plain = torch.empty(M, D, device='cuda')
+    L.lfq_decode(full.reshape(-1).contiguous(), wo, bo, plain, M, D, cd)
+    ref = plain if not pb else plain.view(-1, pb, pc, D).transpose(1, 2).reshape(M, D)
+    out = torch.full((M, D), float('nan'), device='cuda')
+    L.lfq_decode(ids, wo, bo, out, M, D, cd, ids_prime=prime, perm=(pb, pc))
+    assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize('a,b,c,D,cd', [(2, 16, 3, 128, 8), (2, 64, 9, 512, 16), (1, 5, 7, 1024, 13), (3, 1, 1, 64, 4)])
 def test_layernorm_lfq_fused(L, a, b, c, D, cd):
     """pk_layernorm_lfq = pk_layernorm (rows (a,b,c) -> (a,c,b)) followed by pk_lfq_encode, in one launch"""
@@ -306,7 +326,7 @@ def _attn_module(dim, heads, causal, nnull, dim_context=None, seed=30):
     return m
 
 
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16x3', 'bf16'])
 @pytest.mark.parametrize('case', ['spatial_bias', 'causal_alibi', 'cross_null_mask', 'self_mask_long'])
 def test_attention_block(L, dtype, case):
     from phenaki_pytorch_amd.attention import set_compute_dtype
@@ -340,7 +360,7 @@ def test_attention_block(L, dtype, case):
     m = set_compute_dtype(m.cuda(), dtype)
     out = m(x.cuda(), context=ctx.cuda() if ctx is not None else None, mask=kw['mask'].cuda() if 'mask' in kw else None,
             attn_bias=kw['attn_bias'].cuda() if 'attn_bias' in kw else None)
-    close(out, ref, 1e-4 if dtype == 'fp32' else 3e-2, f'attention {case} {dtype}')
+    close(out, ref, {'fp32': 1e-4, 'bf16x3': 2e-4}.get(dtype, 3e-2), f'attention {case} {dtype}')
 
 
 @pytest.mark.parametrize('S,n,causal,has_bias', [(5, 64, False, True), (23, 9, True, False), (3, 10, True, False), (2, 17, False, True)])
@@ -409,7 +429,7 @@ def test_qkv_project_writes_the_attention_operand_images(L, S, n, h, D):
     assert torch.equal(Q2[:nq_el].view(S, h, nq_pad, 64)[:, :, :n], q4)
 
 
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16x3', 'bf16'])
 def test_transformer_with_peg_cross_and_ff(L, dtype):
     from phenaki_pytorch_amd.attention import Transformer, set_compute_dtype
     from oracle import weights
@@ -427,21 +447,21 @@ def test_transformer_with_peg_cross_and_ff(L, dtype):
                         context=ctx, cross_attn_context_mask=cmask)
     m = set_compute_dtype(m.cuda(), dtype)
     out = m(x.cuda(), video_shape=(S, *vs), context=ctx.cuda(), cross_attn_context_mask=cmask.cuda())
-    close(out, ref, 1e-4 if dtype == 'fp32' else 3e-2, f'transformer {dtype}')
+    close(out, ref, {'fp32': 1e-4, 'bf16x3': 2e-4}.get(dtype, 3e-2), f'transformer {dtype}')
 
 
 # ------------------------------------------------------------------------------------------ sampler kernels
 
-@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('mode', ['f32', 'bf16x3', 'bf16'])
 @pytest.mark.parametrize('M,V,D', [(150, 256, 128), (300, 4096, 512)])
 def test_vocab_sample_parity_mode(L, mode, M, V, D):
     e = torch.randn(M, D, generator=g(40))
     W = torch.randn(V, D, generator=g(41)) / math.sqrt(D) * 3
     b = torch.randn(V, generator=g(42)) * 0.1
     U = torch.rand(M, V, generator=g(43))
-    dt = L.F32 if mode == 'f32' else L.BF16
+    dt = {'f32': L.F32, 'bf16': L.BF16, 'bf16x3': L.BF16X3}[mode]
     td = L.tdtype(dt)
-    cast = (lambda t: t) if mode == 'f32' else bf
+    cast = bf if mode == 'bf16' else (lambda t: t)
     logits = cast(e) @ cast(W).t() + b
     T = 0.45
     noisy = logits / T + (-torch.log(-torch.log(U + 1e-10) + 1e-10))
@@ -450,7 +470,8 @@ def test_vocab_sample_parity_mode(L, mode, M, V, D):
     mask = (torch.rand(M, generator=g(44)) > 0.4)
     ids0 = torch.randint(0, V, (M,), generator=g(45))
     partials = torch.empty(5 * L.vocab_ntiles(V) * M, device='cuda')
-    L.vocab_sample(dt, e.cuda().to(td), W.cuda().to(td), b.cuda(), M, V, D, T, U.cuda(), None, 0, True, partials)
+    Wd = L.split_planes(W.cuda()) if mode == 'bf16x3' else W.cuda().to(td)
+    L.vocab_sample(dt, e.cuda().to(td), Wd, b.cuda(), M, V, D, T, U.cuda(), None, 0, True, partials)
     ids = ids0.clone().cuda()
     pred = torch.empty(M, device='cuda', dtype=torch.int64)
     scores = torch.empty(M, device='cuda')
@@ -466,7 +487,7 @@ def test_vocab_sample_parity_mode(L, mode, M, V, D):
     close(scores.cpu()[same], exp_scores[same], 1e-4, 'confidence scores')
 
 
-@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('mode', ['f32', 'bf16x3', 'bf16'])
 @pytest.mark.parametrize('M,V,D,with_rows', [(130, 512, 128, False), (77, 1000, 96, True), (300, 65536, 512, True)])
 def test_vocab_ce_matches_cross_entropy(L, mode, M, V, D, with_rows):
     """pk_vocab_sample(need_lse) + pk_vocab_ce == F.cross_entropy(reduction='none') of the never-written logits, with and
@@ -474,9 +495,9 @@ def test_vocab_ce_matches_cross_entropy(L, mode, M, V, D, with_rows):
     e = torch.randn(M, D, generator=g(50))
     W = torch.randn(V, D, generator=g(51)) / math.sqrt(D) * 3
     b = torch.randn(V, generator=g(52)) * 0.1
-    dt = L.F32 if mode == 'f32' else L.BF16
+    dt = {'f32': L.F32, 'bf16': L.BF16, 'bf16x3': L.BF16X3}[mode]
     td = L.tdtype(dt)
-    cast = (lambda t: t) if mode == 'f32' else bf
+    cast = bf if mode == 'bf16' else (lambda t: t)
     logits = cast(e) @ cast(W).t() + b
     total = 2 * M + 5
     rows = torch.randperm(total, generator=g(53))[:M].int() if with_rows else None
@@ -488,10 +509,12 @@ def test_vocab_ce_matches_cross_entropy(L, mode, M, V, D, with_rows):
     Wp[:, :D] = W
     partials = torch.empty(5 * L.vocab_ntiles(V) * M, device='cuda')
     A, Wd = e.cuda().to(td), Wp.cuda().to(td)
+    if mode == 'bf16x3':
+        Wd = L.split_planes(Wd)
     L.vocab_sample(dt, A, Wd, b.cuda(), M, V, D, 1.0, None, rows.cuda() if with_rows else None, 7, True, partials)
     loss = torch.full((M,), float('nan'), device='cuda')
     L.vocab_ce(dt, partials, M, V, A, Wd, b.cuda(), D, targets_full.cuda(), rows.cuda() if with_rows else None, loss)
-    close(loss, ref, 2e-5 if mode == 'f32' else 2e-3, f'vocab_ce {mode} V={V}')
+    close(loss, ref, {'f32': 2e-5, 'bf16x3': 4e-5}.get(mode, 2e-3), f'vocab_ce {mode} V={V}')
 
 
 def test_vocab_sample_fast_mode_matches_its_numpy_twin(L):
@@ -899,3 +922,91 @@ def test_attention_fixed_offset_ignores_poisoned_pad_rows(L, dims, heads):
                 o = torch.full((S * n, heads * 64), float('nan'), device='cuda', dtype=torch.bfloat16)
                 L.attn_fwd(L.BF16, Qq.reshape(-1), Kq.reshape(-1), Vq.reshape(-1), o, S, heads, n, n, 0, score_bound=sb, **kw)
                 close(o.float(), ref, 1.2e-2, f'{tag}, pads = {poison}, {"fixed offset" if sb else "running max"}')
+
+
+@pytest.mark.parametrize('variant', [0, 3, 8, 9, 24, 27])
+@pytest.mark.parametrize('M,N,K', [(300, 200, 96), (1000, 520, 1368), (4608, 512, 512), (129, 2736, 512), (512, 512, 6144), (77, 4, 64)])
+def test_gemm_split_bf16(L, variant, M, N, K):
+    """the split-bf16 ("bf16x3") main loops: f32 A rows split into (hi, lo) bf16 planes in registers, host-packed W planes, three bf16
+    MFMAs per fragment pair.  Against an f64 product: per-product error ~2^-17, i.e. two orders below plain bf16 operands (whose error on
+    the same data is measured beside it) and inside the f32 GEMM test's tolerance band; M / N / K tails, row gather, bias + residual,
+    GEGLU and LeakyReLU epilogues, every tile variant."""
+    A = torch.randn(M + 7, K, generator=g(160))
+    W = torch.randn(N, K, generator=g(161)) / math.sqrt(K)
+    bias = torch.randn(N, generator=g(162))
+    res = torch.randn(M, N, generator=g(163))
+    idx = torch.randperm(M + 7, generator=g(164))[:M].int()
+    Kp = (K + 31) // 32 * 32
+    Wp = torch.zeros(N, Kp)
+    Wp[:, :K] = W
+    Wd = L.split_planes(Wp.cuda())
+    assert Wd.dtype == torch.float32 and tuple(Wd.shape) == (N, Kp)
+    ref64 = A.double()[idx.long()] @ W.double().t()
+    ref = (ref64 + bias.double() + res.double()).float()
+    C = torch.full((M, N), float('nan'), device='cuda')
+    L.gemm(L.BF16X3, A.cuda(), Wd, M, N, K, C=C, bias=bias.cuda(), res=res.cuda(), a_rows=idx.cuda(), variant=variant)
+    e_split = close(C, ref, 4e-5, f'split gemm variant {variant} {M}x{N}x{K}')
+    e_bf16 = ((bf(A)[idx.long()] @ bf(W).t() + bias + res) - ref).abs().max().item() / ref.abs().max().item()
+    assert e_split < e_bf16 / 30, f'split-bf16 error {e_split:.2e} is not two orders below plain bf16 ({e_bf16:.2e})'
+    C2 = torch.full((M, N), float('nan'), device='cuda')
+    L.gemm(L.BF16X3, A.cuda(), Wd, M, N, K, C=C2, variant=variant)
+    close(C2, (A.double()[:M] @ W.double().t()).float(), 4e-5, f'split gemm variant {variant} plain')
+    if N % 2 == 0 and N >= 8:
+        h = A.double()[:M] @ W.double().t()
+        C3 = torch.full((M, N // 2), float('nan'), device='cuda')
+        L.gemm(L.BF16X3, A.cuda(), Wd, M, N, K, C=C3, act=L.ACT_GEGLU, variant=variant)
+        close(C3, (F.gelu(h[:, 1::2]) * h[:, 0::2]).float(), 4e-5, f'split gemm variant {variant} geglu')
+        C4 = torch.full((M, N), float('nan'), device='cuda')
+        L.gemm(L.BF16X3, A.cuda(), Wd, M, N, K, C=C4, bias=bias.cuda(), act=L.ACT_LEAKY, variant=variant)
+        close(C4, F.leaky_relu(h + bias.double(), 0.1).float(), 4e-5, f'split gemm variant {variant} leaky')
+    # bf16-mode features do not exist for it, and A must be f32
+    with pytest.raises(RuntimeError, match='PK_EINVAL'):
+        L.gemm(L.BF16X3, A.cuda().to(torch.bfloat16), Wd, M, N, K, C=C2, variant=variant)
+
+
+@pytest.mark.parametrize('S,h,n,nkv,nnull,causal', [(3, 2, 64, 64, 0, False), (2, 8, 200, 200, 0, False), (2, 2, 37, 13, 2, False), (5, 2, 9, 9, 0, True), (1, 8, 576, 576, 0, False)])
+def test_attention_split_bf16_images(L, S, h, n, nkv, nnull, causal):
+    """pk_attn_prep / pk_attn_fwd in split-bf16 mode: the operand images are pre-split (hi | lo) planes in 128-byte blocks; the result must
+    sit at f32 level against an f64 softmax attention of the same q / k / v (and against the exact-f32 kernels)."""
+    dim = h * 64
+    q = torch.randn(S * n, dim, generator=g(170))
+    kv = torch.randn(S * nkv, 2 * dim, generator=g(171))
+    null_kv = torch.randn(h, 2 * max(nnull, 1), 64, generator=g(172))
+    qs, ks = torch.rand(64, generator=g(173)) + 0.5, torch.rand(64, generator=g(174)) + 0.5
+    bias = torch.randn(h, n, nkv, generator=g(175)) if not causal else None
+    km = (torch.rand(S, nkv, generator=g(176)) > 0.25) if nnull else None
+    slopes = (torch.rand(h, generator=g(177)) * 0.5).reshape(h, 1, 1) if causal else None
+    outs = {}
+    for name, dt in (('f32', L.F32), ('split', L.BF16X3)):
+        nq_pad, nk_pad = L.attn_pads(n, nkv, nnull)
+        Qp = torch.full((S * h * nq_pad * 64,), float('nan'), device='cuda')
+        Kp = torch.full((S * h * nk_pad * 64,), float('nan'), device='cuda')
+        Vt = torch.full((S * h * nk_pad * 64,), float('nan'), device='cuda')
+        L.attn_prep(dt, q.cuda(), kv.cuda(), null_kv.cuda(), qs.cuda(), ks.cuda(), 8.0, Qp, Kp, Vt, S, h, n, nkv, nnull)
+        O_ = torch.full((S * n, dim), float('nan'), device='cuda')
+        L.attn_fwd(dt, Qp, Kp, Vt, O_, S, h, n, nkv, nnull, bias=bias.cuda() if bias is not None else None,
+                   kmask=km.to(torch.uint8).cuda() if km is not None else None, slopes=slopes.cuda() if slopes is not None else None, causal=causal)
+        outs[name] = O_.cpu()
+    # f64 reference
+    qd = F.normalize(q.double().view(S, n, h, 64).permute(0, 2, 1, 3), dim=-1) * qs.double() * 8.0
+    kd = kv.double()[:, :dim].view(S, nkv, h, 64).permute(0, 2, 1, 3)
+    vd = kv.double()[:, dim:].view(S, nkv, h, 64).permute(0, 2, 1, 3)
+    if nnull:
+        nk_, nv_ = null_kv.double()[:, 0::2][:, :nnull], null_kv.double()[:, 1::2][:, :nnull]
+        kd = torch.cat((nk_[None].expand(S, -1, -1, -1), kd), dim=2)
+        vd = torch.cat((nv_[None].expand(S, -1, -1, -1), vd), dim=2)
+    kd = F.normalize(kd, dim=-1) * ks.double()
+    sim = qd @ kd.transpose(-1, -2)
+    if bias is not None:
+        sim[..., nnull:] += bias.double()
+    if km is not None:
+        full = torch.cat((torch.ones(S, nnull, dtype=torch.bool), km), dim=1)
+        sim = sim.masked_fill(~full[:, None, None, :], -torch.finfo(torch.float32).max)
+    if causal:
+        i, j = torch.arange(n)[:, None], torch.arange(nkv)[None, :]
+        sim = sim - (j - i).abs().double() * slopes.double().view(1, h, 1, 1)
+        sim = sim.masked_fill((j > i)[None, None], -torch.finfo(torch.float32).max)
+    ref = (sim.softmax(-1) @ vd).permute(0, 2, 1, 3).reshape(S * n, dim).float()
+    e32 = close(outs['f32'], ref, 2e-5, 'exact-f32 attention vs f64')
+    e3 = close(outs['split'], ref, 1e-4, 'split-bf16 attention vs f64')
+    print(f'attention n={n}: f32 err {e32:.2e}, split-bf16 err {e3:.2e}')

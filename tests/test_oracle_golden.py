@@ -217,3 +217,60 @@ def test_bf16_precision_mode_is_the_f32_oracle_plus_roundings():
         b = O.maskgit_cfg(mg, mgc, tid, **kw)
     rel = ((a - b).abs().max() / a.abs().max()).item()
     assert 1e-5 < rel < 3e-2, rel
+
+
+def _selfcritic_parts():
+    """(maskgit sd, maskgit cfg, to_pred sd, oracle critic cfg) of the self-critic golden: MaskGit weights as everywhere (salt 2), the
+    to_pred head filled by name with salt 4 (oracle/make_golden.py selfcritic_golden)"""
+    _, mg, _ = state_dicts('tiny')
+    _, mgc, _ = oracle_cfgs(TINY)
+    D = TINY['maskgit']['dim']
+    head = {'to_pred.0.weight': weights.fill_value('0.weight', torch.empty(1, D), 4), 'to_pred.0.bias': weights.fill_value('0.bias', torch.empty(1), 4)}
+    return mg, mgc, head, dict(self_critic=(mg, mgc))
+
+
+def test_selfcritic_matches_reference(golden_dir):
+    """SelfCritic (phenaki_pytorch.py:306-336) scores and a free-running sample scored by it, against the real reference"""
+    g = load(golden_dir, 'selfcritic_tiny.pt')
+    cv, _, _ = state_dicts('tiny')
+    cvc, _, _ = oracle_cfgs(TINY)
+    mg, mgc, head, crc = _selfcritic_parts()
+    ids = g['ids']
+    ctx = weights.synthetic_context(ids.shape[0], g['ctx_len'], TINY['maskgit']['dim_context'], seed=1, pad_last=3)
+    kw = dict(video_patch_shape=g['patch_shape'], context=ctx, text_mask=(ctx != 0).any(-1))
+    close(O.critic_cfg(head, crc, ids, cond_scale=5., **kw), g['critic_cfg'])
+    close(O.critic_forward(head, crc, ids, **kw), g['critic_cond'])
+    sctx = weights.synthetic_context(g['batch'], g['sample_ctx_len'], TINY['maskgit']['dim_context'], seed=2)
+    trace = []
+    video, _ = O.sample(cv, cvc, mg, mgc, head, crc, num_frames=g['frames'], batch_size=g['batch'], context=sctx, steps=TINY['steps'],
+                        cond_scale=5., noise_fn=_noise_fn(500, 0), trace=trace)
+    assert len(trace) == len(g['steps'])
+    for r, t in zip(g['steps'], trace):
+        assert torch.equal(r['mg_input'], t['masked_ids']) and torch.equal(r['pred'], t['pred'])
+    close(video, g['video'])
+
+
+def _unconditional_parts():
+    """state_dicts of the unconditional golden: MaskGit(unconditional=True) and TokenCritic(has_cross_attn=False) -- the keys of the
+    conditional modules minus the cross-attention blocks (transformer.layers.*.2.*), same name-keyed fill"""
+    _, mg, cr = state_dicts('tiny')
+    drop = lambda sd: {k: v for k, v in sd.items() if not (k.startswith('transformer.layers.') and k.split('.')[3] == '2')}
+    _, mgc, crc = oracle_cfgs(TINY)
+    return drop(mg), {**mgc, 'unconditional': True}, drop(cr), {**crc, 'has_cross_attn': False}
+
+
+def test_unconditional_matches_reference(golden_dir):
+    """unconditional MaskGit (phenaki_pytorch.py:125-147) + a TokenCritic without cross-attention, logits / scores / free-running sample"""
+    g = load(golden_dir, 'unconditional_tiny.pt')
+    cv, _, _ = state_dicts('tiny')
+    cvc, _, _ = oracle_cfgs(TINY)
+    mg, mgc, cr, crc = _unconditional_parts()
+    close(O.maskgit_forward(mg, mgc, g['ids'], video_patch_shape=g['patch_shape']), g['logits'])
+    close(O.critic_forward(cr, crc, g['ids'], video_patch_shape=g['patch_shape']), g['critic'])
+    trace = []
+    video, _ = O.sample(cv, cvc, mg, mgc, cr, crc, num_frames=g['frames'], batch_size=g['batch'], steps=TINY['steps'],
+                        noise_fn=_noise_fn(500, 0), trace=trace)
+    assert len(trace) == len(g['steps'])
+    for r, t in zip(g['steps'], trace):
+        assert torch.equal(r['mg_input'], t['masked_ids']) and torch.equal(r['pred'], t['pred'])
+    close(video, g['video'])
