@@ -281,6 +281,11 @@ class KernelProfiler:
             B, C, F, H, W = video.shape
             rows, P = B * nt * (H // ph) * (W // pw), C * pt * ph * pw
             return f'patchify_ln_kernel[P={P}]', 'hbm', rows * P * (4 + _esz(out))
+        if name == 'patch_embed':
+            video, ph, pw, N, groups = a[:5]
+            B, C, F, H, W = video.shape
+            fl = sum(2.0 * (B * nt * (H // ph) * (W // pw)) * N * (C * pt * ph * pw) for (_, _, _, _, f0, nt, pt) in groups)
+            return 'patch_embed_kernel', 'mfma', fl
         if name == 'unpatchify':
             pix, video, f0, nt, pt, ph, pw = a[:7]
             B, C, F, H, W = video.shape
@@ -316,7 +321,7 @@ class KernelProfiler:
         self._lib = _lib
         self._orig = {}
         prof = self
-        names = ['gemm', 'qkv_project', 'qkv_attn', 'q_attn_cached', 'attn_fwd', 'attn_small', 'vocab_sample', 'layernorm', 'layernorm_lfq', 'patchify_ln',
+        names = ['gemm', 'patch_embed', 'qkv_project', 'qkv_attn', 'q_attn_cached', 'attn_fwd', 'attn_small', 'vocab_sample', 'layernorm', 'layernorm_lfq', 'patchify_ln',
                  'unpatchify', 'peg', 'lfq_encode', 'lfq_decode', 'embed', 'cfg_mix', 'critic_head', 'attn_prep', 'vocab_reduce',
                  'topk_mask', 'l2norm_rows']
 

@@ -86,6 +86,19 @@ int pk_layernorm(const float* x, int ldx, const float* gamma, const float* beta,
 int pk_patchify_ln(const float* video, int B, int C, int F, int H, int W, int f0, int nt, int pt, int ph, int pw,
                    const float* weight, const float* bias, float eps, void* out, int ldo, int out_kind, void* stream);
 
+/* cvivit.py:273-285 up to the Linear, bf16 operands, ONE launch for both frame groups (SURVEY.md 2a "K1"): the patch rows are
+ * gathered from the (B,C,F,H,W) f32 video inside the GEMM's A-tile producer (no patch matrix in HBM) and nn.LayerNorm(P) is folded in:
+ *   out_g[(b,tt,hh,ww)][n] = rstd * (sum_k bf16(x_k - c) * W_g[n][k] - mean' * s_g[n]) + t_g[n]
+ * with c a per-patch centre (below), mean' / rstd the f32 statistics of x - c over the P = C*pt*ph*pw patch features (biased variance,
+ * eps inside the sqrt), W_g [N][ldw_g] bf16 = gamma (.) W zero-padded along K to 64, s_g[n] = sum_k W_g[n][k], t_g[n] = sum_k beta[k]
+ * W[n][k] + bias[n].  Group g covers frames [f0_g, f0_g + nt_g*pt_g) with pt_g frames per patch (ngroups = 1: group 0 only; pass the
+ * long-K group first).  pw a power of two in 8..128, P % 192 == 0, video < 4 GiB;
+ * c = the mean of the patch's first 32 features.  The caller applies the nn.LayerNorm(dim) that follows. */
+int pk_patch_embed(const float* video, int B, int C, int F, int H, int W, int ph, int pw, int N, float eps, int ngroups,
+                   const void* W0, int ldw0, const float* s0, const float* t0, float* out0, int f00, int nt0, int pt0,
+                   const void* W1, int ldw1, const float* s1, const float* t1, float* out1, int f01, int nt1, int pt1,
+                   int ldo, void* stream);
+
 /* cvivit.py:326-334: Rearrange 'b t h w (c pt p1 p2) -> b c (t pt) (h p1) (w p2)' into frames [f0, f0 + nt*pt). */
 int pk_unpatchify(const float* pix, int ldp, float* video, int B, int C, int F, int H, int W, int f0, int nt,
                   int pt, int ph, int pw, void* stream);

@@ -67,6 +67,7 @@ LN_FOLD_FF = False          # the feed-forward LayerNorm is folded into FF1 ...
 LN_FOLD_FF_MAX_ROWS = 0     # ... for inputs of at most this many rows (0: no limit); the tests copy both from the product's settings
 ATTN_FIXED_OFFSET = True    # long self-attention (n > 64, no masks): p = 2^(s log2e - integer) instead of the running-max flash loop ...
 ATTN_FIXED_OFFSET_BIAS = True   # ... also when it carries a position bias (the product needs its relative-position table for that)
+PATCH_FUSED = True          # bf16 patch embedding: LayerNorm(P) folded into the Linear with a centred operand (csrc/patch_embed.hip)
 _ROWS_SCALE = [1]           # the product runs the cond | null halves of a CFG step as ONE batch: its row count is twice this oracle's
 
 
@@ -256,8 +257,19 @@ def cvivit_patch_embed(sd, cfg, video):
     def emb(frames, tp, p):
         t = frames.shape[2] // tp
         pat = frames.reshape(b, c, t, tp, h, ph, w, pw).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(b, t, h, w, -1)
-        pat = F.layer_norm(pat, pat.shape[-1:], sd[p + '1.weight'], sd[p + '1.bias'])
-        pat = _lin(pat, sd[p + '2.weight']) + sd[p + '2.bias']
+        if is_bf16() and PATCH_FUSED:
+            # pk_patch_embed: operand = bf16(x - c), c = the mean of the patch's first 32 features; f32 statistics of the UNROUNDED x - c;
+            # LN(x) W^T + b = rstd * (r(x - c) r(gamma.W)^T - mean' * s) + t,  s = rowsum(r(gamma.W)),  t = W beta + b
+            wl, gamma, beta = sd[p + '2.weight'], sd[p + '1.weight'], sd[p + '1.bias']
+            xc = pat - pat[..., :32].mean(dim=-1, keepdim=True)
+            mean = xc.mean(dim=-1, keepdim=True)
+            var = (xc * xc).mean(dim=-1, keepdim=True) - mean * mean
+            rstd = 1.0 / torch.sqrt(var.clamp(min=0) + 1e-5)
+            wg = _r(wl * gamma[None, :])
+            pat = rstd * (_r(xc) @ wg.t() - mean * wg.sum(dim=-1)) + (wl @ beta + sd[p + '2.bias'])
+        else:
+            pat = F.layer_norm(pat, pat.shape[-1:], sd[p + '1.weight'], sd[p + '1.bias'])
+            pat = _lin(pat, sd[p + '2.weight']) + sd[p + '2.bias']
         return F.layer_norm(pat, pat.shape[-1:], sd[p + '3.weight'], sd[p + '3.bias'])
 
     first = emb(video[:, :, :1], 1, 'to_patch_emb_first_frame.')

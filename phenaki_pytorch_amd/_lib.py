@@ -28,6 +28,9 @@ SIGNATURES = {
     'pk_layernorm': [_P, _I, _P, _P, _F, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'pk_l2norm_rows': [_P, _I, _P, _I, _I, _I, _I, _P],
     'pk_patchify_ln': [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _I, _I, _P],
+    'pk_patch_embed': [_P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I,
+                       _P, _I, _P, _P, _P, _I, _I, _I,
+                       _P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     'pk_unpatchify': [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'pk_sqdiff_partials': [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     'pk_peg': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -182,6 +185,20 @@ def patchify_ln(video, f0, nt, pt, ph, pw, weight, bias, out, eps=1e-5):
     rc = load().pk_patchify_ln(f32p(video, 'video'), B, C, F, H, W, f0, nt, pt, ph, pw, f32p(weight, 'LayerNorm weight'), f32p(bias, 'LayerNorm bias'), eps,
                                ptr(out), out.stride(0), 1 if out.dtype == torch.bfloat16 else 0, stream(video))
     _check(rc, 'pk_patchify_ln')
+
+
+def patch_embed(video, ph, pw, N, groups, eps=1e-5):
+    """groups: 1 or 2 tuples (Wg (N, Kpad) bf16 = gamma (.) W, s (N,), t (N,), out (rows, N) f32, f0, nt, pt), long-K group first.
+    out_g = LayerNorm_P(patches of frames [f0, f0 + nt*pt)) @ W^T + b, the patch rows gathered from the video inside the kernel."""
+    B, C, F, H, W = video.shape
+    flat = []
+    for (Wg, s, t, out, f0, nt, pt) in groups:
+        flat += [ptr(Wg), Wg.stride(0), f32p(s, 'folded s'), f32p(t, 'folded t'), ptr(out), f0, nt, pt]
+    if len(groups) == 1:
+        flat += [None, 0, None, None, None, 0, 0, 0]
+    ldo = groups[0][3].stride(0)
+    rc = load().pk_patch_embed(f32p(video, 'video'), B, C, F, H, W, ph, pw, N, eps, len(groups), *flat, ldo, stream(video))
+    _check(rc, 'pk_patch_embed')
 
 
 def unpatchify(pix, video, f0, nt, pt, ph, pw):

@@ -13,8 +13,13 @@ import torch
 from torch import nn
 
 from . import _lib as L
-from .attention import (ContinuousPositionBias, PackedModule, Transformer, compute_dtype_of, exists, invalidate_packed,
+import os
+
+from .attention import (ContinuousPositionBias, PackedModule, Transformer, compute_dtype_of, exists, folded_weight, invalidate_packed,
                         linear_weight, ln_fold_enabled, value_without_graph, set_compute_dtype)
+
+# PK_PATCH_FUSED=0: the bf16 patch embedding keeps pk_patchify_ln + pk_gemm (A/B timing of the fused pk_patch_embed)
+_PATCH_FUSED = os.environ.get('PK_PATCH_FUSED', '1') != '0' 
 from .quantize import LFQ, VectorQuantize
 
 
@@ -26,6 +31,14 @@ def pair(val):
 
 def divisible_by(numer, denom):
     return (numer % denom) == 0
+
+
+def _pe_bias(lin, t):
+    """t + the Linear's bias (cached with the folded weight's lifetime: rebuilt when either parameter changes)"""
+    from .attention import _cache
+    if lin.bias is None:
+        return t
+    return _cache(lin).get(('pe_t',), [lin.weight, lin.bias, t], lambda: (t + lin.bias.detach().float()).contiguous())
 
 
 class _Rearrange(nn.Identity):
@@ -167,6 +180,28 @@ class CViViT(PackedModule):
         tokens = torch.empty((B * T * hw, self.dim), device=dev, dtype=torch.float32)
         # bf16 copy for the first transformer block (its LayerNorm is folded into its first GEMM, which reads bf16 rows)
         tokens_t = torch.empty((B * T * hw, self.dim), device=dev, dtype=td) if ln_fold_enabled(dt) else None
+
+        groups = [(self.to_patch_emb, 1, nt, pt, hw)] if nt > 0 else []
+        groups.append((self.to_patch_emb_first_frame, 0, 1, 1, 0))                     # long-K group first
+        fused = (_PATCH_FUSED and dt == L.BF16 and pw in (8, 16, 32, 64, 128) and all((C * ptg * ph * pw) % 192 == 0 for _, _, _, ptg, _ in groups)
+                 and (pw >= 32 or ph % (32 // pw) == 0) and self.dim % 4 == 0 and video.numel() * 4 < 0xFFFFFFF0 and
+                 all(seq[1].eps == groups[0][0][1].eps for seq, *_ in groups))
+        if fused:
+            # ONE launch: patch gather + LayerNorm(P) + Linear for both frame groups (pk_patch_embed), then the LayerNorm(dim) per group
+            spec, tmps = [], []
+            for seq, f0, ntg, ptg, goff in groups:
+                ln1, lin = seq[1], seq[2]
+                wg, s_, t_, _ = folded_weight(lin, 'pe_ln', lambda lin=lin: lin.weight.detach(), ln1.weight, ln1.bias, dt, [lin.weight, ln1.weight, ln1.bias])
+                tb = _pe_bias(lin, t_)
+                tmp = torch.empty((B * ntg * hw, self.dim), device=dev, dtype=torch.float32)
+                spec.append((wg, s_, tb, tmp, f0, ntg, ptg))
+                tmps.append(tmp)
+            L.patch_embed(video, ph, pw, self.dim, spec, eps=groups[0][0][1].eps)
+            for (seq, f0, ntg, ptg, goff), tmp in zip(groups, tmps):
+                ln2 = seq[3]
+                L.layernorm(tmp, ln2.weight, ln2.bias, tmp.shape[0], self.dim, out=tokens_t, out2=tokens, eps=ln2.eps, remap=(ntg * hw, T * hw, goff))
+            self.__dict__['_pk_tokens_t'] = tokens_t
+            return tokens, T
 
         def group(seq, f0, ntg, ptg, goff):
             ln1, lin, ln2 = seq[1], seq[2], seq[3]

@@ -21,6 +21,8 @@ def _oracle_follows_product_ln_fold():
     O.LN_FOLD, O.LN_FOLD_FF, O.LN_FOLD_FF_MAX_ROWS = attention._LN_FOLD, bool(attention._LN_FOLD_FF), attention._LN_FOLD_FF_MAX_ROWS
     O.ATTN_FIXED_OFFSET = attention._ATTN_FIXED
     O.ATTN_FIXED_OFFSET_BIAS = attention._ATTN_FIXED and attention._BIAS_TABLE
+    from phenaki_pytorch_amd import cvivit as _cv
+    O.PATCH_FUSED = _cv._PATCH_FUSED
 
 
 @pytest.fixture(scope='module')
@@ -1010,3 +1012,53 @@ def test_attention_split_bf16_images(L, S, h, n, nkv, nnull, causal):
     e32 = close(outs['f32'], ref, 2e-5, 'exact-f32 attention vs f64')
     e3 = close(outs['split'], ref, 1e-4, 'split-bf16 attention vs f64')
     print(f'attention n={n}: f32 err {e32:.2e}, split-bf16 err {e3:.2e}')
+
+
+@pytest.mark.parametrize('B,C,Fr,H,W,pt,ph,pw,N', [(2, 3, 5, 64, 64, 2, 32, 32, 128), (1, 3, 3, 256, 256, 2, 32, 32, 512), (2, 3, 5, 64, 64, 2, 16, 16, 128),
+                                                   (3, 3, 1, 64, 128, 2, 32, 64, 64), (2, 3, 3, 32, 32, 2, 16, 8, 72), (5, 3, 5, 96, 96, 2, 32, 32, 132)])
+def test_patch_embed_fused(L, B, C, Fr, H, W, pt, ph, pw, N):
+    """pk_patch_embed (K1): patch gather + LayerNorm(P) + Linear in one launch for both frame groups, against the reference op sequence
+    (Rearrange -> LayerNorm(P) -> Linear, cvivit.py:273-285) in f64 -- including a video with a large DC offset and little contrast, where
+    rounding the un-centred pixels to bf16 would lose the signal: the kernel centres every patch on its first element before rounding."""
+    nh, nw = H // ph, W // pw
+    nt = (Fr - 1) // pt
+    for offset, contrast in ((0.0, 1.0), (40.0, 0.05)):
+        video = torch.randn(B, C, Fr, H, W, generator=g(300)) * contrast + offset
+        groups, refs, outs = [], [], []
+        for f0, ntg, ptg, seed in ((1, nt, pt, 1), (0, 1, 1, 2)):
+            if ntg <= 0:
+                continue
+            P = C * ptg * ph * pw
+            gamma = 1 + 0.1 * torch.randn(P, generator=g(301 + seed))
+            beta = 0.1 * torch.randn(P, generator=g(303 + seed))
+            Wl = torch.randn(N, P, generator=g(305 + seed)) / math.sqrt(P)
+            bl = 0.1 * torch.randn(N, generator=g(307 + seed))
+            fr = video[:, :, f0:f0 + ntg * ptg]
+            pat = fr.reshape(B, C, ntg, ptg, nh, ph, nw, pw).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B * ntg * nh * nw, P).double()
+            ref = F.layer_norm(pat, (P,), gamma.double(), beta.double()) @ Wl.double().t() + bl.double()
+            Kp = (P + 63) // 64 * 64
+            wg = torch.zeros(N, Kp)
+            wg[:, :P] = Wl * gamma[None, :]
+            wg = wg.to(torch.bfloat16)
+            s = wg.float().sum(dim=1)
+            t = Wl @ beta + bl
+            out = torch.full((B * ntg * nh * nw, N), float('nan'), device='cuda')
+            groups.append((wg.cuda(), s.cuda(), t.cuda(), out, f0, ntg, ptg))
+            refs.append(ref.float())
+            outs.append(out)
+        L.patch_embed(video.cuda(), ph, pw, N, groups)
+        for gi, (out, ref) in enumerate(zip(outs, refs)):
+            close(out, ref, 1.2e-2, f'patch embed group {gi} offset {offset}')           # bf16 operands: ~2^-9 per product over P terms
+            rms = ((out.cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+            assert rms < 4e-3, f'group {gi} offset {offset}: rms error {rms:.2e}'
+    # a single group (single-frame input) and argument checks
+    video = torch.randn(B, C, 1, H, W, generator=g(310))
+    P = C * ph * pw
+    if P % 192 == 0:
+        wg = (torch.randn(N, P, generator=g(311)) / math.sqrt(P)).to(torch.bfloat16)
+        out = torch.full((B * nh * nw, N), float('nan'), device='cuda')
+        L.patch_embed(video.cuda(), ph, pw, N, [(wg.cuda(), wg.float().sum(1).cuda(), torch.zeros(N).cuda(), out, 0, 1, 1)])
+        pat = video.reshape(B, C, 1, 1, nh, ph, nw, pw).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B * nh * nw, P).double()
+        close(out, (F.layer_norm(pat, (P,)) @ wg.double().t()).float(), 1.2e-2, 'single group')
+        with pytest.raises(RuntimeError, match='PK_EINVAL'):
+            L.patch_embed(video.cuda(), ph, pw, N, [(wg.cuda(), wg.float().sum(1).cuda(), torch.zeros(N).cuda(), out, 0, 2, 1)])      # frames beyond F

@@ -25,6 +25,8 @@ def _oracle_follows_product_ln_fold():
     O.LN_FOLD, O.LN_FOLD_FF, O.LN_FOLD_FF_MAX_ROWS = attention._LN_FOLD, bool(attention._LN_FOLD_FF), attention._LN_FOLD_FF_MAX_ROWS
     O.ATTN_FIXED_OFFSET = attention._ATTN_FIXED
     O.ATTN_FIXED_OFFSET_BIAS = attention._ATTN_FIXED and attention._BIAS_TABLE
+    from phenaki_pytorch_amd import cvivit as _cv
+    O.PATCH_FUSED = _cv._PATCH_FUSED
 
 # Tolerances.  fp32 mode is held to the north star directly: ids bit-exact (LFQ sign bits and gumbel argmax audited by the
 # oracle's own decision margin), logits / pixels 1e-3 relative.
