@@ -221,19 +221,19 @@ void gemm_dma_kernel(const GemmOperands p, const GemmEpilogue e, int a_nrows) {
     // XCD-aware tile map.  Workgroup b is observed to run on XCD b % 8 (speed only, never correctness); each XCD has a
     // private 4 MiB L2.  XCD x owns a contiguous chunk of m-tiles and walks ALL n-tiles for it (m fastest), so its
     // slice of A stays L2-resident while W streams through once per XCD, instead of every XCD thrashing on all of A.
-    const int MT = (p.M + Tile::BM - 1) / Tile::BM, cmax = (MT + 7) / 8;
+    const int MT = (p.M + Tile::BM - 1) / Tile::BM, cmax = (MT + 7) / 8, NTn = (p.N + Tile::BN - 1) / Tile::BN;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int mstart = xcd * MT / 8, mcount = (xcd + 1) * MT / 8 - mstart;
-    const int ml = idx % cmax;
     int m0, n0;
     if (p.plain_map) {                                    // A/B reference order: m fastest over the whole grid
-        if ((int)blockIdx.x >= MT * ((p.N + Tile::BN - 1) / Tile::BN)) return;
+        if ((int)blockIdx.x >= MT * NTn) return;
         m0 = (blockIdx.x % MT) * Tile::BM;
         n0 = (blockIdx.x / MT) * Tile::BN;
     } else {
-        if (ml >= mcount) return;                         // whole workgroup exits before any barrier
+        int ml, ntile;
+        if (!xcd_panel_tile(idx, cmax, mcount, NTn, p.panel, ml, ntile)) return;      // whole workgroup exits before any barrier
         m0 = (mstart + ml) * Tile::BM;
-        n0 = (idx / cmax) * Tile::BN;
+        n0 = ntile * Tile::BN;
     }
     PK_TL_KERNEL(0);
     f32x4 acc[TM][TN];
@@ -306,7 +306,10 @@ static int launch_dma(const GemmOperands& p, const GemmEpilogue& e, int a_nrows,
     }
     const int MT = (p.M + Tile::BM - 1) / Tile::BM, NT = (p.N + Tile::BN - 1) / Tile::BN;
     dim3 grid(8 * ((MT + 7) / 8) * NT);                   // see the XCD-aware tile map in the kernel
-    hipLaunchKernelGGL((gemm_dma_kernel<T, TM, TN, WM, WN, STAGES, ROWB, PW, LNF>), grid, dim3(Tile::THREADS), Tile::SMEM, s, p, e, a_nrows);
+    GemmOperands pp = p;
+    static const int panel_env = [] { const char* e_ = getenv("PK_GEMM_PANEL"); return e_ ? atoi(e_) : -1; }();      // tuning knob: 0 = off, n = m-tiles per panel
+    pp.panel = panel_env >= 0 ? panel_env : xcd_panel_rows(Tile::BM, p.K, (int)sizeof(T));
+    hipLaunchKernelGGL((gemm_dma_kernel<T, TM, TN, WM, WN, STAGES, ROWB, PW, LNF>), grid, dim3(Tile::THREADS), Tile::SMEM, s, pp, e, a_nrows);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

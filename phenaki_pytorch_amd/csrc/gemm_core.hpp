@@ -33,7 +33,35 @@ struct GemmOperands {
     int plain_map;      // 1: row-major tile order (A/B benchmarking only); 0: XCD-aware tile map (DMA kernels)
     int krot;           // 1: workgroup b walks the k-tiles starting at tile (b >> 3) % nt (DMA kernels; see gemm_dma.hpp)
     int w_gap_from, w_gap_rows;   // DMA kernels: tile rows >= w_gap_from of W read global row n0 + row + w_gap_rows (two row ranges, one tile)
+    int panel;          // DMA kernels, XCD-aware map: m-tiles per L2 panel (0: the XCD's whole chunk is one panel), see xcd_panel_tile
 };
+
+// XCD-aware tile order of the LDS-DMA GEMMs.  Workgroup b is observed to run on XCD b % 8 (speed only, never correctness); each XCD
+// has a private 4 MiB L2.  XCD x owns a contiguous chunk of `mcount` m-tiles (cmax = the largest chunk) and walks the n-tiles for it,
+// m fastest.  For large M the chunk's slice of A no longer fits the L2 (M = 36 864, K = 512 bf16: 4.7 MB per XCD -- the 128-row GEMMs
+// fell from 612 to 471 TFLOP/s between M = 18 432 and 36 864, profiles/gemm_yardstick_r03.txt), so the chunk is cut into PANELS of
+// `panel` m-tiles (~1 MB of A): a panel walks all n-tiles before the next panel starts, A stays L2-resident, W streams once per panel.
+// idx = position of the workgroup inside its XCD (blockIdx.x >> 3), NT = number of n-tiles.  Returns false: no tile (chunk tail).
+__device__ __forceinline__ bool xcd_panel_tile(int idx, int cmax, int mcount, int NT, int panel, int& ml, int& ntile) {
+    if (panel <= 0 || panel >= cmax) { ml = idx % cmax; ntile = idx / cmax; }
+    else {
+        const int full = cmax / panel;
+        int pi = idx / (panel * NT);
+        if (pi > full) pi = full;
+        const int base = pi * panel;
+        const int pl = pi < full ? panel : cmax - base;         // rows of this (possibly partial, last) panel
+        const int r = idx - pi * panel * NT;
+        ml = base + r % pl;
+        ntile = r / pl;
+    }
+    return ml < mcount;
+}
+// host: m-tiles per panel for a BM-row tile of an A with K elements of `esz` bytes per row (about 1 MB of A per panel, at least 4 tiles)
+static inline int xcd_panel_rows(int BM, int K, int esz) {
+    const long tile_bytes = (long)BM * K * esz;
+    long pnl = (1 << 20) / (tile_bytes > 0 ? tile_bytes : 1);
+    return (int)(pnl < 4 ? 4 : pnl);
+}
 
 template <typename T, typename TA> struct RawSlot;                    // one thread's 16-B LDS slot, pre-conversion
 template <typename T> struct RawSlot<T, T> { u32x4 v; };

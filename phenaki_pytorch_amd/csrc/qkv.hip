@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void qkv_project_kernel(const QkvArgs a) {
     p.M = a.M; p.N = is_q ? a.h * 64 : 2 * a.h * 64; p.K = a.K;
     p.plain_map = 0;
     p.krot = a.krot;
-    p.w_gap_from = 0; p.w_gap_rows = 0;
+    p.w_gap_from = 0; p.w_gap_rows = 0; p.panel = 0;
     const int n0 = is_q ? hh * 64 : (kind == 1 ? hh * 64 : (a.h + hh) * 64);
 
     f32x4 acc[TM][4];

@@ -49,6 +49,7 @@ struct VocabArgs {
     int need_lse;
     int no_noise;            // 1: plain argmax of the logits (cosine-sim codebook lookup of the VectorQuantize path)
     int ntiles;
+    int plain_order;         // 1: (row tile fastest, vocabulary tile) dispatch order of round 2 (A/B knob PK_VOCAB_PANEL=0)
     // partials, SoA [ntiles][M]
     float* p_val; int* p_idx; float* p_logit; float* p_max; float* p_sum;
 };
@@ -68,7 +69,37 @@ __global__ __launch_bounds__(64 * VocabGeom<T>::WM * VocabGeom<T>::WN) void voca
     constexpr int VTM = VocabGeom<T>::TM, VTN = VocabGeom<T>::TN, VWN = VocabGeom<T>::WN;
     static_assert(Tile::BM == 128 && Tile::BN == 128, "partials are laid out per 128-column tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int m0 = blockIdx.x * Tile::BM, n0 = blockIdx.y * Tile::BN;
+    // ---- XCD-aware, L2-panelled tile order.  Workgroup b is observed to run on XCD b % 8 (speed only).  XCD x owns a contiguous
+    // eighth of the vocabulary tiles (its slice of W: 8.4 MB at V = 65 536) and walks it in W-panels of 16 tiles (2 MB) x A-panels of
+    // 8 row tiles (1 MB), rows fastest: both panels stay in the XCD's 4 MB L2 while their 128 tiles run.  The former (row tile, vocab
+    // tile) grid in dispatch order spread every vocabulary tile's row tiles over all 8 XCDs: each L2 then cycled through the WHOLE of A
+    // (4.7 MB at 4608 rows) once per vocabulary tile and fetched every W tile 8 times.
+    const int MT = (p.M + Tile::BM - 1) / Tile::BM;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int cn = (e.ntiles + 7) / 8;
+    const int nstart = xcd * e.ntiles / 8, ncount = (xcd + 1) * e.ntiles / 8 - nstart;
+    int mtile, ntile;
+    if (e.plain_order) {
+        mtile = (int)(blockIdx.x % (unsigned)MT); ntile = (int)(blockIdx.x / (unsigned)MT);
+        if (ntile >= e.ntiles) return;
+    } else {
+        constexpr int PN = 16, PM = 8;
+        const int full_wp = cn / PN;
+        int wp = idx / (PN * MT);
+        if (wp > full_wp) wp = full_wp;
+        const int basen = wp * PN, pnl = wp < full_wp ? PN : cn - basen;
+        const int r = idx - wp * PN * MT;
+        const int full_ap = MT / PM;
+        int ap = r / (pnl * PM);
+        if (ap > full_ap) ap = full_ap;
+        const int basem = ap * PM, pml = ap < full_ap ? PM : MT - basem;
+        const int r2 = r - ap * pnl * PM;
+        mtile = basem + r2 % pml;
+        ntile = basen + r2 / pml;
+        if (ntile >= ncount) return;                       // whole workgroup exits before any barrier
+        ntile += nstart;
+    }
+    const int m0 = mtile * Tile::BM, n0 = ntile * Tile::BN;
     f32x4 acc[VTM][VTN];
 #pragma unroll
     for (int i = 0; i < VTM; ++i)
@@ -182,7 +213,7 @@ __global__ __launch_bounds__(64 * VocabGeom<T>::WM * VocabGeom<T>::WN) void voca
                     lmax = nm;
                 }
             }
-            const size_t o = (size_t)blockIdx.y * p.M + m;
+            const size_t o = (size_t)ntile * p.M + m;
             e.p_val[o] = best; e.p_idx[o] = bidx; e.p_logit[o] = blog;
             if (LSE) { e.p_max[o] = lmax; e.p_sum[o] = lsum; }
         }
@@ -355,13 +386,15 @@ extern "C" int pk_vocab_sample(int dtype, const void* A, int lda, const void* W,
     e.temp = temperature > 1e-10f ? temperature : 1e-10f;
     e.seed_lo = (uint32_t)seed; e.seed_hi = (uint32_t)(seed >> 32); e.seed_dev = seed_dev;
     e.need_lse = need_lse & 1; e.no_noise = (need_lse >> 1) & 1; e.ntiles = ntiles;
+    static const int panel_env = [] { const char* v = getenv("PK_VOCAB_PANEL"); return v ? atoi(v) : 1; }();
+    e.plain_order = panel_env == 0;
     const size_t sz = (size_t)ntiles * M;
     e.p_val = reinterpret_cast<float*>(partials);
     e.p_idx = reinterpret_cast<int*>(partials) + sz;
     e.p_logit = reinterpret_cast<float*>(partials) + 2 * sz;
     e.p_max = reinterpret_cast<float*>(partials) + 3 * sz;
     e.p_sum = reinterpret_cast<float*>(partials) + 4 * sz;
-    dim3 grid((M + 127) / 128, ntiles);
+    dim3 grid(8 * ((ntiles + 7) / 8) * ((M + 127) / 128));        // 1-D: see the tile order in the kernel
     hipStream_t s = STREAM(stream);
 #define PK_VS(TT, PAR, LS) hipLaunchKernelGGL((vocab_sample_kernel<TT, PAR, LS>), grid, dim3(VocabTile<TT>::THREADS), VocabTile<TT>::SMEM, s, p, e)
     const bool lse = e.need_lse != 0;
