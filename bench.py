@@ -13,7 +13,7 @@ distinct input batches (3 x 107 MB > the 256 MB Infinity Cache) so the video rea
 
 The same JSON line carries
   roofline     : the encode leg's dominant kernel -- algorithmic flops per launch over its live HIP-event duration, plus the
-                 HBM traffic per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic_r02.json);
+                 fabric traffic per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic_rNN.json);
   kernels      : every kernel of the encode / decode / sampling legs against ITS roofline (HBM GB/s for the patch / VQ /
                  norm / PEG kernels, MFMA TFLOP/s for the GEMM / attention / vocab-head kernels), from in-run HIP events;
   decode       : C-ViViT decode ids -> pixels, frames/s;
@@ -385,10 +385,10 @@ class KernelProfiler:
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this bench's encode leg (counters need their
-    own rocprofv3 runs -- they cannot be collected from inside this process): profiles/pmc_traffic_r02.json, written by
+    own rocprofv3 runs -- they cannot be collected from inside this process): profiles/pmc_traffic_rNN.json (latest round), written by
     tools/pmc_traffic.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 read correction."""
-    path = os.path.join(ROOT, 'profiles', 'pmc_traffic_r02.json')
-    if not os.path.exists(path):
+    path = next((q for q in (os.path.join(ROOT, 'profiles', f'pmc_traffic_r{r:02d}.json') for r in (3, 2)) if os.path.exists(q)), None)
+    if path is None:
         return None, None
     try:
         tab = json.load(open(path))

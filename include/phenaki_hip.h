@@ -230,7 +230,17 @@ int pk_vocab_reduce(const void* partials, int M, int V, const int* rows, const u
  * need_lse bit 0 set, loss[m] = logsumexp_v(logits[m][:]) - logits[m][targets[r]] with r = rows ? rows[m] : m, where the
  * target logit is the dot product of row m of A with row targets[r] of W (+ bias) -- same A / W / bias as that call. */
 int pk_vocab_ce(int dtype, const void* partials, int M, int V, const void* A, int lda, const void* W, int ldw,
-                const float* bias, int D, const long long* targets, const int* rows, float* loss, void* stream);
+                const float* bias, int D, const long long* targets, const int* rows, float* loss, float* lse_out, void* stream);
+/* lse_out ([M] f32 or NULL): logsumexp of every row, kept for the backward pass below.
+ *
+ * Backward of that cross entropy (first training kernel; phenaki_pytorch.py:640-643 under autograd), one slab of
+ * Vs vocabulary columns [v0, v0 + Vs) at a time: logits [M][ldl] f32 holds the slab's recomputed logits (pk_gemm of the same A / W rows
+ * / bias); g[m][v] = (exp(logit - lse[m]) - [v0 + v == targets[r]]) * scale (r = rows ? rows[m] : m; scale = upstream gradient / number
+ * of rows) is written to g [M][ldg] and, transposed with zeroed pad columns, to gT [Vs][ldgt] (ldgt >= M: the K-padded A operand of the
+ * dW GEMM), both f32 or bf16 (out_bf16); db [Vs] (or NULL) receives the column sums of g.  The caller then runs dE += g W_slab and
+ * dW_slab = gT E through pk_gemm: the (M, V) logits / probabilities never exist. */
+int pk_ce_grad_slab(int out_bf16, const float* logits, int ldl, const float* lse, const long long* targets, const int* rows,
+                    int M, int Vs, int v0, float scale, void* g, int ldg, void* gT, int ldgt, float* db, void* stream);
 
 /* phenaki_pytorch.py:488-491: mask = zeros.scatter(1, scores.topk(k).indices, 1).bool(); ids = where(mask, mask_id, ids).
  * rows_out (B*k int32, or NULL) receives the flat positions b*n + i of the masked tokens: only those rows need the vocab

@@ -323,6 +323,59 @@ def unconditional_golden(R, cfgs, tag):
     print(f'unconditional_{tag}: logits {tuple(logits.shape)}, {len(rec.steps)} sampling steps')
 
 
+def ce_grad_golden(R, cfgs, tag):
+    """gradients of the masked-token cross entropy (phenaki_pytorch.py:640-643) of the REAL reference under autograd, at the vocabulary
+    head: the to_logits input rows of the masked positions, their targets, d loss / d rows, d loss / d to_logits.weight, .bias.
+    `Phenaki.forward(only_train_generator=True)` with the same patched draws as forward_golden; hooks only, nothing is modified."""
+    cv, mg, cr, ph = build_reference(R, cfgs, with_phenaki=True, with_critic=True)
+    m = R.module
+    batch, frames, ctx_len = 3, 5, 6
+    H = cfgs['cvivit']['image_size']
+    steps = cfgs['steps']
+    pt = cfgs['cvivit']['temporal_patch_size']
+    hw = H // cfgs['cvivit']['patch_size']
+    n = (1 + (frames - 1) // pt) * hw * hw
+    g = torch.Generator().manual_seed(81)
+    ids = torch.randint(0, cfgs['maskgit']['num_tokens'], (batch, 1 + (frames - 1) // pt, hw, hw), generator=g)
+    ctx = weights.synthetic_context(batch, ctx_len, cfgs['maskgit']['dim_context'], seed=3, pad_last=2)
+    rand_step = (torch.arange(batch) * 2 + 1) % steps
+    perm_noise = weights.uniform_noise((batch, n), 700)
+    rec = {}
+    orig = (torch.randint, torch.rand, m.get_mask_subset_with_prob)
+
+    def randint(low, high, size, **kw):
+        return rand_step.clone()
+
+    def rand(size, **kw):
+        return perm_noise.clone()
+
+    def mask_subset(mask, prob):
+        out = orig[2](mask, prob)
+        rec['mask'] = out.clone()
+        return out
+
+    def fwd_hook(mod, inp, out):
+        rec['x'] = inp[0].detach().clone()
+        inp[0].register_hook(lambda gr: rec.__setitem__('dx', gr.detach().clone()))
+
+    h = mg.to_logits.register_forward_hook(fwd_hook)
+    torch.randint, torch.rand, m.get_mask_subset_with_prob = randint, rand, mask_subset
+    try:
+        for p_ in ph.parameters():
+            p_.grad = None
+        loss = ph(video_codebook_ids=ids, text_embeds=ctx, only_train_generator=True)
+        loss.backward()
+    finally:
+        torch.randint, torch.rand, m.get_mask_subset_with_prob = orig
+        h.remove()
+    mask = rec['mask']
+    out = dict(loss=loss.detach().clone(), rows=rec['x'][mask].clone(), targets=ids.flatten(1)[mask].clone(), d_rows=rec['dx'][mask].clone(),
+               d_rows_unmasked_absmax=rec['dx'][~mask].abs().max().item(), d_weight=mg.to_logits.weight.grad.detach().clone(),
+               d_bias=mg.to_logits.bias.grad.detach().clone(), num_rows=int(mask.sum()))
+    torch.save(out, os.path.join(OUT, f'ce_grad_{tag}.pt'))
+    print(f"ce_grad_{tag}: loss {float(loss):.6f}, {out['num_rows']} masked rows, |dx| outside the mask {out['d_rows_unmasked_absmax']:.1e}")
+
+
 def keys_golden(R):
     """state_dict contract: every key, shape and dtype of the reference modules."""
     import json
@@ -353,6 +406,8 @@ def main():
     if 'tiny' in which or 'forward' in which:
         forward_golden(R, TINY, batch=3, frames=5, ctx_len=6, tag='tiny')
         recon_loss_golden(R, TINY, tag='tiny')
+    if 'tiny' in which or 'grads' in which:
+        ce_grad_golden(R, TINY, tag='tiny')
     if 'tiny' in which or 'critics' in which:
         selfcritic_golden(R, TINY, tag='tiny')
         unconditional_golden(R, TINY, tag='tiny')

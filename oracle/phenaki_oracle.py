@@ -602,3 +602,18 @@ def phenaki_forward_loss(mg, mg_cfg, cr, cr_cfg, ids, *, patch_shape, context, s
     out.update(pred=pred, critic_logits=crit, critic_loss=critic_loss)
     out['loss'] = critic_loss if only_train_critic else ce + critic_loss * critic_loss_weight
     return out
+
+
+def vocab_ce_grads(rows, weight, bias, targets):
+    """closed-form backward of the masked-token cross entropy (phenaki_pytorch.py:640-643: F.cross_entropy(logits[mask], ids[mask]), mean
+    over the R masked rows) at the vocabulary head: with p = softmax(rows W^T + b), g = (p - onehot(targets)) / R,
+        d rows = g W,   d W = g^T rows,   d b = colsum(g);   also returns the loss.  f64 internally, f32 results."""
+    x, w = rows.double(), weight.double()
+    logits = x @ w.t() + bias.double()
+    lse = torch.logsumexp(logits, dim=-1)
+    R = rows.shape[0]
+    loss = (lse - logits.gather(1, targets[:, None]).squeeze(1)).mean()
+    g = torch.exp(logits - lse[:, None])
+    g[torch.arange(R), targets] -= 1.0
+    g /= R
+    return dict(loss=loss.float(), d_rows=(g @ w).float(), d_weight=(g.t() @ x).float(), d_bias=g.sum(dim=0).float())

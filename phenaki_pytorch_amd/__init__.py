@@ -8,6 +8,7 @@ from .attention import set_compute_dtype, invalidate_packed
 from .cvivit import CViViT
 from .phenaki import MaskGit, TokenCritic, SelfCritic, Phenaki, make_video
 from .dist import shard_batch, sample_sharded, make_video_sharded
+from .train import vocab_cross_entropy
 
 __all__ = ['CViViT', 'MaskGit', 'TokenCritic', 'SelfCritic', 'Phenaki', 'make_video', 'set_compute_dtype', 'invalidate_packed',
-           'shard_batch', 'sample_sharded', 'make_video_sharded']
+           'shard_batch', 'sample_sharded', 'make_video_sharded', 'vocab_cross_entropy']

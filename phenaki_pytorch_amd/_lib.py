@@ -50,7 +50,8 @@ SIGNATURES = {
     'pk_vocab_ntiles': [_I],
     'pk_vocab_sample': [_I, _P, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P, _ULL, _P, _I, _P, _P],
     'pk_vocab_reduce': [_P, _I, _I, _P, _P, _P, _P, _P, _I, _P],
-    'pk_vocab_ce': [_I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P],
+    'pk_vocab_ce': [_I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P],
+    'pk_ce_grad_slab': [_I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _P, _I, _P, _I, _P, _P],
     'pk_topk_mask': [_P, _I, _I, _I, _LL, _P, _P, _P, _P, _P],
     'pk_critic_head': [_P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P, _F, _ULL, _P, _P, _P],
 }
@@ -348,11 +349,18 @@ def vocab_reduce(partials, M, V, rows, mask, ids, pred, scores, need_lse):
     _check(rc, 'pk_vocab_reduce')
 
 
-def vocab_ce(dtype, partials, M, V, A, W, bias, D, targets, rows, loss):
-    """loss[m] = lse(logits[m]) - logits[m][targets[rows[m]]] from the partials of vocab_sample(..., need_lse=True)."""
+def vocab_ce(dtype, partials, M, V, A, W, bias, D, targets, rows, loss, lse=None):
+    """loss[m] = lse(logits[m]) - logits[m][targets[rows[m]]] from the partials of vocab_sample(..., need_lse=True); lse (M,) f32 optional"""
     rc = load().pk_vocab_ce(dtype, ptr(partials), M, V, ptr(A), A.stride(-2), ptr(W), W.stride(0), f32p(bias, 'to_logits.bias'), D,
-                            ptr(targets), ptr(rows), ptr(loss), stream(A))
+                            ptr(targets), ptr(rows), ptr(loss), ptr(lse), stream(A))
     _check(rc, 'pk_vocab_ce')
+
+
+def ce_grad_slab(logits, lse, targets, rows, M, Vs, v0, scale, g, gT, db=None):
+    """g / gT <- (softmax - onehot) * scale of one slab of vocabulary columns (see the header); logits (M, >= Vs) f32"""
+    rc = load().pk_ce_grad_slab(1 if g.dtype == torch.bfloat16 else 0, ptr(logits), logits.stride(0), ptr(lse), ptr(targets), ptr(rows), M, Vs, v0,
+                                float(scale), ptr(g), g.stride(0), ptr(gT), gT.stride(0), ptr(db), stream(logits))
+    _check(rc, 'pk_ce_grad_slab')
 
 
 def topk_mask(scores, B, n, k, mask_id, mask, ids, rows_out=None, scores_next=None):

@@ -295,7 +295,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void vocab_ce_kernel(const float* __restrict__ p_max, const float* __restrict__ p_sum, int ntiles, int M,
                                                        const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
                                                        const float* __restrict__ bias, int D, const long long* __restrict__ targets,
-                                                       const int* __restrict__ rows, float* __restrict__ loss) {
+                                                       const int* __restrict__ rows, float* __restrict__ loss, float* __restrict__ lse_out) {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
@@ -315,7 +315,55 @@ __global__ __launch_bounds__(256) void vocab_ce_kernel(const float* __restrict__
     float dot = 0.f;
     for (int c = lane; c < D; c += 64) dot += load_elem(a + c) * w_elem<T>(w, c);
     dot = wave_sum(dot);
-    if (lane == 0) loss[m] = (gmax + logf(gsum)) - (dot + bias[tgt]);
+    if (lane == 0) {
+        const float lse = gmax + logf(gsum);
+        loss[m] = lse - (dot + bias[tgt]);
+        if (lse_out) lse_out[m] = lse;
+    }
+}
+
+// ---- backward of that cross entropy, one SLAB of vocabulary columns at a time (the first training kernel, SURVEY.md 8f row 1;
+// reference phenaki_pytorch.py:640-643 under autograd): with loss = mean_m (lse_m - logit[m][t_m]) over the M rows,
+//     g[m][v] = d loss / d logit[m][v] = (exp(logit[m][v] - lse_m) - [v == t_m]) * scale,      scale = upstream gradient / M,
+// and dE = g W, dW = g^T E, db = colsum(g).  The (M, V) logits / g matrices never exist: the host loops over slabs of Vs columns,
+// recomputes the slab's logits with pk_gemm, turns them into g IN PLACE here -- also written transposed, the A operand of the dW GEMM --
+// and feeds both to pk_gemm (dE accumulates through the residual input).  Tile: 32 x 32 through LDS (coalesced both ways).
+// TO = float (exact-f32 / split-bf16 GEMMs read f32 A operands) or bf16.
+template <typename TO>
+__global__ __launch_bounds__(256) void ce_grad_slab_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ lse,
+                                                           const long long* __restrict__ targets, const int* __restrict__ rows, int M, int Vs,
+                                                           int v0, float scale, TO* __restrict__ g, int ldg, TO* __restrict__ gT, int ldgt) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8 threads, 4 rows each
+    const int mb = blockIdx.y * 32, vb = blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ml = ty + i * 8, m = mb + ml, v = vb + tx;
+        float x = 0.f;
+        if (m < M && v < Vs) {
+            const long long t = targets[rows ? rows[m] : m];
+            x = (__expf(logits[(size_t)m * ldl + v] - lse[m]) - (t == (long long)(v0 + v) ? 1.f : 0.f)) * scale;
+            store_elem(g + (size_t)m * ldg + v, x);
+        }
+        tile[ml][tx] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int vl = ty + i * 8, v = vb + vl, m = mb + tx;
+        if (v < Vs && m < ldgt) store_elem(gT + (size_t)v * ldgt + m, m < M ? tile[tx][vl] : 0.f);      // pad columns [M, ldgt) are zeroed
+    }
+}
+
+// out[r] = sum_c x[r][c] (one wave per row; fixed order: deterministic) -- db of a slab = row sums of g^T
+template <typename TI>
+__global__ __launch_bounds__(256) void rowsum_kernel(const TI* __restrict__ x, int ldx, int R, int C, float* __restrict__ out) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= R) return;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += load_elem(x + (size_t)r * ldx + c);
+    s = wave_sum(s);
+    if (lane == 0) out[r] = s;
 }
 
 // mask = top-k of scores per row (ties: lower index first), ids = where(mask, mask_id, ids)
@@ -429,8 +477,26 @@ extern "C" int pk_vocab_reduce(const void* partials, int M, int V, const int* ro
 // loss[m] = logsumexp_v(logits[m][v]) - logits[m][targets[r]], r = rows ? rows[m] : m, from the partials of a pk_vocab_sample
 // call made with need_lse bit 0 set on the SAME A / W / bias (phenaki_pytorch.py:640-643 F.cross_entropy, reduction left to
 // the caller).  targets must be < V.
+extern "C" int pk_ce_grad_slab(int out_bf16, const float* logits, int ldl, const float* lse, const long long* targets, const int* rows,
+                               int M, int Vs, int v0, float scale, void* g, int ldg, void* gT, int ldgt, float* db, void* stream) {
+    if (!logits || !lse || !targets || !g || !gT || M <= 0 || Vs <= 0 || v0 < 0 || ldl < Vs || ldg < Vs || ldgt < M) return PK_EINVAL;
+    dim3 grid((Vs + 31) / 32, (ldgt + 31) / 32);
+    hipStream_t s = STREAM(stream);
+    if (out_bf16) {
+        hipLaunchKernelGGL((ce_grad_slab_kernel<bf16>), grid, dim3(256), 0, s, logits, ldl, lse, targets, rows, M, Vs, v0, scale,
+                           reinterpret_cast<bf16*>(g), ldg, reinterpret_cast<bf16*>(gT), ldgt);
+        if (db) hipLaunchKernelGGL((rowsum_kernel<bf16>), dim3((Vs + 3) / 4), dim3(256), 0, s, reinterpret_cast<const bf16*>(gT), ldgt, Vs, M, db);
+    } else {
+        hipLaunchKernelGGL((ce_grad_slab_kernel<float>), grid, dim3(256), 0, s, logits, ldl, lse, targets, rows, M, Vs, v0, scale,
+                           reinterpret_cast<float*>(g), ldg, reinterpret_cast<float*>(gT), ldgt);
+        if (db) hipLaunchKernelGGL((rowsum_kernel<float>), dim3((Vs + 3) / 4), dim3(256), 0, s, reinterpret_cast<const float*>(gT), ldgt, Vs, M, db);
+    }
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
 extern "C" int pk_vocab_ce(int dtype, const void* partials, int M, int V, const void* A, int lda, const void* W, int ldw,
-                           const float* bias, int D, const long long* targets, const int* rows, float* loss, void* stream) {
+                           const float* bias, int D, const long long* targets, const int* rows, float* loss, float* lse_out, void* stream) {
     if (!partials || !A || !W || !bias || !targets || !loss || M <= 0 || V <= 0 || D <= 0) return PK_EINVAL;
     if (dtype != 0 && dtype != 1 && dtype != 2) return PK_EINVAL;
     const int ntiles = pk_vocab_ntiles(V);
@@ -439,14 +505,14 @@ extern "C" int pk_vocab_ce(int dtype, const void* partials, int M, int V, const 
     const dim3 grid((M + 3) / 4);
     if (dtype == 2) {
         hipLaunchKernelGGL((vocab_ce_kernel<bf16x3>), grid, dim3(256), 0, STREAM(stream), f + 3 * sz, f + 4 * sz, ntiles, M,
-                           reinterpret_cast<const bf16x3*>(A), lda, reinterpret_cast<const bf16x3*>(W), ldw, bias, D, targets, rows, loss);
+                           reinterpret_cast<const bf16x3*>(A), lda, reinterpret_cast<const bf16x3*>(W), ldw, bias, D, targets, rows, loss, lse_out);
         PK_CHECK_LAUNCH();
         return PK_OK;
     }
     if (dtype == 1) hipLaunchKernelGGL((vocab_ce_kernel<bf16>), grid, dim3(256), 0, STREAM(stream), f + 3 * sz, f + 4 * sz, ntiles, M,
-                                       reinterpret_cast<const bf16*>(A), lda, reinterpret_cast<const bf16*>(W), ldw, bias, D, targets, rows, loss);
+                                       reinterpret_cast<const bf16*>(A), lda, reinterpret_cast<const bf16*>(W), ldw, bias, D, targets, rows, loss, lse_out);
     else hipLaunchKernelGGL((vocab_ce_kernel<float>), grid, dim3(256), 0, STREAM(stream), f + 3 * sz, f + 4 * sz, ntiles, M,
-                            reinterpret_cast<const float*>(A), lda, reinterpret_cast<const float*>(W), ldw, bias, D, targets, rows, loss);
+                            reinterpret_cast<const float*>(A), lda, reinterpret_cast<const float*>(W), ldw, bias, D, targets, rows, loss, lse_out);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

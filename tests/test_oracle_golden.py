@@ -274,3 +274,16 @@ def test_unconditional_matches_reference(golden_dir):
     for r, t in zip(g['steps'], trace):
         assert torch.equal(r['mg_input'], t['masked_ids']) and torch.equal(r['pred'], t['pred'])
     close(video, g['video'])
+
+
+def test_vocab_ce_grads_match_reference_autograd(golden_dir):
+    """the oracle's closed-form cross-entropy backward at the vocabulary head against the REAL reference's autograd
+    (Phenaki.forward(only_train_generator=True).backward(), hooks at maskgit.to_logits; oracle/make_golden.py ce_grad_golden)"""
+    g = load(golden_dir, 'ce_grad_tiny.pt')
+    _, mg, _ = state_dicts('tiny')
+    assert g['d_rows_unmasked_absmax'] == 0.0 and g['rows'].shape[0] == g['num_rows']
+    r = O.vocab_ce_grads(g['rows'], mg['to_logits.weight'], mg['to_logits.bias'], g['targets'])
+    assert abs(float(r['loss']) - float(g['loss'])) <= 1e-5 * abs(float(g['loss']))
+    close(r['d_rows'], g['d_rows'], 1e-4)
+    close(r['d_weight'], g['d_weight'], 1e-4)
+    close(r['d_bias'], g['d_bias'], 1e-4)

@@ -4,7 +4,7 @@
     # on the GPU box, two SEPARATE passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; no trace domains besides --kernel-trace):
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o p -- python bench.py --encode-only --no-graph --groups 1 --steps 3
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o p -- python bench.py --encode-only --no-graph --groups 1 --steps 3
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/pmc_traffic_r02.json
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/pmc_traffic_rNN.json
 
 Counter values are KiB per dispatch.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-byte requests at
 64 B -> doubled for the wide coalesced streams these kernels issue; WRITE_SIZE is taken as is (r01 calibration: it matched the
@@ -47,7 +47,8 @@ def main():
         nw, kw = write.get(name, [0, 0.0])
         rd = 2.0 * 1024.0 * kf / nf if nf else 0.0
         wr = 1024.0 * kw / nw if nw else 0.0
-        kernels[name] = dict(dispatches=max(nf, nw), fetch_bytes_per_launch_x2=rd, write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr)
+        kernels[name] = dict(dispatches=max(nf, nw), fetch_bytes_per_launch_x2=rd, write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr,
+                             note='fabric-side requests of the L2 (TCC_EA0): Infinity-Cache hits are included')
     src = ('separate rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --encode-only --no-graph`, mean per '
            'dispatch, FETCH_SIZE doubled (gfx950: 128-B requests tallied at 64 B), tools/pmc_traffic.py')
     json.dump(dict(source=src, kernels=kernels), open(out, 'w'), indent=1)
