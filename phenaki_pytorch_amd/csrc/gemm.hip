@@ -418,6 +418,8 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
             case 24: return launch_dma<bf16, 4, 2, 2, 2, 4>(p, e, a_nrows, s);          // 128x128, 8 waves (2x4), 2 stages (64 KB: 16 waves/CU)
             case 33: return launch_dma<bf16, 2, 2, 3, 2, 2, 128, 2>(p, e, a_nrows, s);  // 64x64, 4 consumers + 2 producers, 3 stages (long K)
             case 27: return launch_dma<bf16, 4, 2, 2, 2, 2>(p, e, a_nrows, s);          // 128x64, 4 waves (wave tile 64x32), 2 stages (48 KB: 3 WG/CU)
+            // (256x256 / 256x128 / 128x256 8-wave instantiations were measured again in round 3 against the torch.mm yardstick and removed:
+            //  profiles/gemm_bigtile_r03.txt -- 552 vs 653 TFLOP/s on the vocabulary-head shape, 1081 vs 1011 at 8192^3)
             default: return PK_EINVAL;
         }
     }
