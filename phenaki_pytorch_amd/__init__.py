@@ -7,8 +7,8 @@ the compute is hand-written HIP in libphenaki_hip.so (build: `python -m phenaki_
 from .attention import set_compute_dtype, invalidate_packed
 from .cvivit import CViViT
 from .phenaki import MaskGit, TokenCritic, SelfCritic, Phenaki, make_video
-from .dist import shard_batch, sample_sharded, make_video_sharded
+from .dist import shard_batch, sample_sharded, make_video_sharded, all_reduce_gradients
 from .train import vocab_cross_entropy
 
 __all__ = ['CViViT', 'MaskGit', 'TokenCritic', 'SelfCritic', 'Phenaki', 'make_video', 'set_compute_dtype', 'invalidate_packed',
-           'shard_batch', 'sample_sharded', 'make_video_sharded', 'vocab_cross_entropy']
+           'shard_batch', 'sample_sharded', 'make_video_sharded', 'vocab_cross_entropy', 'all_reduce_gradients']

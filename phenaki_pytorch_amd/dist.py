@@ -89,3 +89,48 @@ def make_video_sharded(phenaki, texts_per_item, num_frames, prime_lengths, make_
         prime = video[:, :, -pl[s]:]
     local = torch.cat(scenes, dim=2)
     return all_gather_batch(local, n_items) if gather else local
+
+
+# ---------------------------------------------------------------------------------------------- training: gradient exchange
+# The reference trains data-parallel through HF accelerate -> torch DDP (cvivit_trainer.py:241-249, phenaki_trainer.py:378-386:
+# `accelerator.backward(loss)` all-reduces the gradients before `clip_grad_norm_` / `opt.step()`).  The MI355X build has no autograd
+# hooks to hang DDP on (its first backward kernel, train.vocab_cross_entropy, is called explicitly), so the exchange is an explicit
+# step: average the .grad of the given parameters over the ranks in BUCKETS.  xGMI is point-to-point (7 links x ~153 GB/s per GPU):
+# a ring all-reduce is bound by one link, ~2 (R-1)/R x bytes / 153 GB/s, so buckets are sized for link efficiency (64 MB default:
+# ~0.8 ms each at 8 ranks, far above RCCL's per-call latency) and kept few -- the 134 MB of the vocabulary head's weight gradient is
+# 3 buckets.  Each bucket is one flat contiguous buffer (one collective per bucket, not per tensor), reduced in f32.
+
+def bucket_plan(numels, bucket_elems):
+    """greedy, order-preserving: lists of tensor indices whose sizes sum to <= bucket_elems (a larger tensor gets its own bucket)"""
+    plan, cur, fill = [], [], 0
+    for i, n in enumerate(numels):
+        if cur and fill + n > bucket_elems:
+            plan.append(cur)
+            cur, fill = [], 0
+        cur.append(i)
+        fill += n
+    if cur:
+        plan.append(cur)
+    return plan
+
+
+def all_reduce_gradients(params, bucket_mb=64.0, average=True, group=None):
+    """in place: p.grad <- mean (or sum) over the ranks of p.grad, for every parameter in `params` that has a gradient.  Identical
+    parameter order on every rank is the caller's contract (as with DDP).  Returns the number of collectives issued."""
+    rank, ws = world()
+    grads = [p.grad for p in params if p.grad is not None]
+    if ws == 1 or not grads:
+        return 0
+    bucket_elems = max(1, int(bucket_mb * (1 << 20) / 4))
+    plan = bucket_plan([g.numel() for g in grads], bucket_elems)
+    for idxs in plan:
+        flat = torch.cat([grads[i].reshape(-1).float() for i in idxs])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            flat /= ws
+        off = 0
+        for i in idxs:
+            n = grads[i].numel()
+            grads[i].copy_(flat[off:off + n].view_as(grads[i]))
+            off += n
+    return len(plan)

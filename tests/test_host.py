@@ -185,6 +185,47 @@ def test_sharded_sampling_world_size_2_gloo(n_items):
     assert sorted(res) == [(0, True), (1, True)]
 
 
+def _grad_worker(rank, ws, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=ws)
+    sys.path.insert(0, ROOT)
+    from phenaki_pytorch_amd.dist import all_reduce_gradients
+    g = torch.Generator().manual_seed(7)
+    shapes = [(300, 17), (5,), (1000, 33), (2, 3, 4), (70000,)]
+    base = [torch.randn(s, generator=g) for s in shapes]
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes] + [torch.nn.Parameter(torch.zeros(3))]     # the last one has no gradient
+    for p_, b in zip(params, base):
+        p_.grad = b * (rank + 1)                                   # rank r holds (r + 1) * base
+    ncoll = all_reduce_gradients(params, bucket_mb=0.15)            # 39 321 floats per bucket: the tensors fall into several buckets
+    mean_factor = sum(r + 1 for r in range(ws)) / ws
+    ok = all(torch.allclose(p_.grad, b * mean_factor, rtol=1e-6, atol=1e-7) for p_, b in zip(params, base)) and params[-1].grad is None
+    for p_, b in zip(params, base):
+        p_.grad = b * (rank + 1)
+    all_reduce_gradients(params, bucket_mb=64., average=False)      # one bucket, plain sum
+    ok = ok and all(torch.allclose(p_.grad, b * sum(r + 1 for r in range(ws)), rtol=1e-6, atol=1e-7) for p_, b in zip(params, base))
+    q.put((rank, bool(ok), ncoll))
+    dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_world_size_2_gloo():
+    """the data-parallel gradient exchange of the trainers (cvivit_trainer.py:241-249, phenaki_trainer.py:378-386) as
+    an explicit bucketed all-reduce: means / sums over 2 ranks, order-preserving buckets, parameters without a gradient skipped."""
+    from phenaki_pytorch_amd.dist import bucket_plan
+    assert bucket_plan([5, 5, 5, 20, 3], 10) == [[0, 1], [2], [3], [4]]
+    assert bucket_plan([], 10) == [] and bucket_plan([3], 10) == [[0]]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 37
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r[:2] for r in res) == [(0, True), (1, True)]
+    assert res[0][2] == res[1][2] == 2                              # the same bucket plan on both ranks: [4 small tensors] [the 70 000-element one]
+
+
 def test_packed_weight_cache_invalidation_and_pointer_checks():
     """packed weights must not go stale silently, and parameter pointers are dtype / layout checked."""
     import phenaki_pytorch_amd as P
