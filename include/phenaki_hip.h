@@ -127,6 +127,16 @@ int pk_lfq_encode(const float* x, int ldx, const float* wp, const float* bp, lon
 int pk_lfq_decode(const long long* ids, const float* wo, const float* bo, float* out, int M, int D, int cd,
                   const long long* ids_prime, int n_prime, int n, int pb, int pc, void* stream);
 
+/* Text-encoder support (reference t5.py:64-103 calls HuggingFace T5EncoderModel; the T5 v1.1 encoder layers are built
+ * from pk_gemm, pk_attn_prep with q_scale = k_scale = NULL (plain dot-product attention: no l2norm, q * scale), pk_attn_fwd and these two):
+ * pk_rmsnorm: T5LayerNorm, y = x * rsqrt(mean(x^2) + eps) * w (f32 statistics, no mean subtraction, no bias); rows with rowmask[row] == 0
+ *   (or NULL: none) are written as zeros (the masked_fill of t5.py:97-100); out is T (out_kind 1) or f32.
+ * pk_gated_gelu_tanh: out[m][f] = gelu_new(h[m][f]) * h[m][F + f] for h (M, >= 2F) f32 -- T5DenseGatedActDense's activation on the output
+ *   of one GEMM against [wi_0 ; wi_1]. */
+int pk_rmsnorm(const float* x, int ldx, const float* w, float eps, const unsigned char* rowmask, void* out, int ldo, int out_kind,
+               int M, int D, void* stream);
+int pk_gated_gelu_tanh(const float* h, int ldh, void* out, int ldo, int out_kind, int M, int F, void* stream);
+
 /* cvivit.py:472 (the encoder's final norm_out) fused with the LFQ of cvivit.py:570: ids[orow] = LFQ(LayerNorm(x[row]) * gamma
  * (+ beta)) in one pass over x, cd <= 16; orow = the (a, b, c) -> (a, c, b) row permutation of pk_layernorm (pb = 0: identity).
  * tokens (f32 [M][ldt], or NULL) receives the normalised rows, proj ([M][cd], or NULL) the pre-sign projections. */

@@ -376,6 +376,23 @@ def ce_grad_golden(R, cfgs, tag):
     print(f"ce_grad_{tag}: loss {float(loss):.6f}, {out['num_rows']} masked rows, |dx| outside the mask {out['d_rows_unmasked_absmax']:.1e}")
 
 
+def t5_golden(tag, cfg, B, L, sub):
+    """the REAL HuggingFace T5EncoderModel (what the reference's t5.py:64-103 runs) on name-keyed random weights: last_hidden_state with the
+    pads zero-filled as in t5.py:97-100.  No checkpoint exists offline; the architecture and arithmetic are what is pinned."""
+    from transformers import T5Config, T5EncoderModel
+    from oracle import t5_oracle as T
+    hf = T5EncoderModel(T5Config(**cfg)).eval()
+    weights.fill_module(hf, salt=5)
+    ids, mask = T.t5_inputs(cfg, B, L)
+    with torch.no_grad():
+        out = hf(input_ids=ids, attention_mask=mask.long()).last_hidden_state
+    out = out.masked_fill(~mask[..., None], 0.)
+    keys = {k: list(v.shape) for k, v in hf.state_dict().items()}
+    torch.save(dict(ids=ids, mask=mask, out=out[:, :, ::sub].clone(), sub=sub, keys=keys, out_absmax=out.abs().max().item()),
+               os.path.join(OUT, f't5_{tag}.pt'))
+    print(f't5_{tag}: out {tuple(out.shape)} absmax {out.abs().max().item():.3f}')
+
+
 def keys_golden(R):
     """state_dict contract: every key, shape and dtype of the reference modules."""
     import json
@@ -406,6 +423,10 @@ def main():
     if 'tiny' in which or 'forward' in which:
         forward_golden(R, TINY, batch=3, frames=5, ctx_len=6, tag='tiny')
         recon_loss_golden(R, TINY, tag='tiny')
+    if 'tiny' in which or 't5' in which:
+        from oracle import t5_oracle as T
+        t5_golden('tiny', T.T5_TINY, B=3, L=21, sub=1)
+        t5_golden('base', T.T5_BASE, B=2, L=40, sub=8)
     if 'tiny' in which or 'grads' in which:
         ce_grad_golden(R, TINY, tag='tiny')
     if 'tiny' in which or 'critics' in which:

@@ -26,6 +26,8 @@ SIGNATURES = {
     'pk_gemm_ex': [_I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _I, _I, _P, _I, _P, _P, _F, _P, _P, _P, _P, _I, _P],
     'pk_gemm_auto_variant': [_I, _I, _I, _I, _I, _I, _I, _I],
     'pk_layernorm': [_P, _I, _P, _P, _F, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'pk_rmsnorm': [_P, _I, _P, _F, _P, _P, _I, _I, _I, _I, _P],
+    'pk_gated_gelu_tanh': [_P, _I, _P, _I, _I, _I, _I, _P],
     'pk_l2norm_rows': [_P, _I, _P, _I, _I, _I, _I, _P],
     'pk_patchify_ln': [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P, _I, _I, _P],
     'pk_patch_embed': [_P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I,
@@ -269,9 +271,21 @@ def attn_pads(nq, n_kv, nnull):
 
 
 def attn_prep(dtype, q, kv, null_kv, q_scale, k_scale, scale, Qp, Kp, Vt, S, h, nq, n_kv, nnull):
+    """q_scale = k_scale = None: plain dot-product attention operands (no l2norm; q * scale) -- the T5 text encoder"""
     rc = load().pk_attn_prep(dtype, ptr(q), q.stride(-2), ptr(kv), kv.stride(-2) if kv is not None else 0, f32p(null_kv, 'null_kv') if nnull else None,
                              f32p(q_scale, 'q_scale'), f32p(k_scale, 'k_scale'), scale, ptr(Qp), ptr(Kp), ptr(Vt), S, h, nq, n_kv, nnull, stream(q))
     _check(rc, 'pk_attn_prep')
+
+
+def rmsnorm(x, w, M, D, out, eps=1e-6, rowmask=None):
+    rc = load().pk_rmsnorm(f32p(x, 'x', rows_ok=True), x.stride(-2), f32p(w, 'T5LayerNorm weight'), eps, ptr(rowmask), ptr(out), out.stride(-2),
+                           1 if out.dtype == torch.bfloat16 else 0, M, D, stream(x))
+    _check(rc, 'pk_rmsnorm')
+
+
+def gated_gelu_tanh(h, out, M, F):
+    rc = load().pk_gated_gelu_tanh(ptr(h), h.stride(-2), ptr(out), out.stride(-2), 1 if out.dtype == torch.bfloat16 else 0, M, F, stream(h))
+    _check(rc, 'pk_gated_gelu_tanh')
 
 
 def qkv_project(xq, xkv, wq, wkv, S, nseq, h, K, q_scale, k_scale, scale, Qp, Kp, Vt, nq_pad, nk_pad, q_ln_s=None):

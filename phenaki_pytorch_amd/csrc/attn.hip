@@ -52,11 +52,16 @@ __global__ __launch_bounds__(256) void prep_q_kernel(const PrepArgs p) {
     f32x4 v = f32x4{0, 0, 0, 0};
     if (i < p.nq) {
         const f32x4 x = *reinterpret_cast<const f32x4*>(p.q + ((size_t)s * p.nq + i) * p.ldq + hh * DH + l16 * 4);
-        const float ss = group16_sum((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]));
-        const float inv = p.scale / fmaxf(sqrtf(ss), 1e-12f);               // F.normalize eps = 1e-12
-        const f32x4 qs = *reinterpret_cast<const f32x4*>(p.q_scale + l16 * 4);
+        if (p.q_scale) {
+            const float ss = group16_sum((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]));
+            const float inv = p.scale / fmaxf(sqrtf(ss), 1e-12f);               // F.normalize eps = 1e-12
+            const f32x4 qs = *reinterpret_cast<const f32x4*>(p.q_scale + l16 * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = x[e] * inv * qs[e];
+            for (int e = 0; e < 4; ++e) v[e] = x[e] * inv * qs[e];
+        } else {                                                                // plain dot-product attention (T5): q * scale, no l2norm
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = x[e] * p.scale;
+        }
     }
     store4(reinterpret_cast<T*>(p.Qp) + (size_t)r * DH + l16 * 4, v);
 }
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(256) void prep_kv_kernel(const PrepArgs p) {
     T* Kp = reinterpret_cast<T*>(p.Kp) + (size_t)sh * p.nk_pad * DH;
     T* Vt = reinterpret_cast<T*>(p.Vt) + (size_t)sh * DH * p.nk_pad;
     const int kend = (p.nk_pad - kt * 64) < 64 ? (p.nk_pad - kt * 64) : 64;   // keys of this tile that exist in the padded image
-    const f32x4 ks = *reinterpret_cast<const f32x4*>(p.k_scale + l16 * 4);
+    const f32x4 ks = p.k_scale ? *reinterpret_cast<const f32x4*>(p.k_scale + l16 * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
     for (int jj = threadIdx.x >> 4; jj < kend; jj += 16) {
         const int key = kt * 64 + jj;
         f32x4 kx = f32x4{0, 0, 0, 0}, vx = kx;
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(256) void prep_kv_kernel(const PrepArgs p) {
             vx = *reinterpret_cast<const f32x4*>(row + p.h * DH + hh * DH + l16 * 4);
         }
         const float ss = group16_sum((kx[0] * kx[0] + kx[1] * kx[1]) + (kx[2] * kx[2] + kx[3] * kx[3]));
-        const float inv = key < nk ? 1.0f / fmaxf(sqrtf(ss), 1e-12f) : 0.f;
+        const float inv = key < nk ? (p.k_scale ? 1.0f / fmaxf(sqrtf(ss), 1e-12f) : 1.0f) : 0.f;      // k_scale == NULL: plain keys (T5)
         f32x4 kn;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { kn[e] = kx[e] * inv * ks[e]; vt[jj][l16 * 4 + e] = vx[e]; }
@@ -826,13 +831,14 @@ extern "C" int pk_attn_pads(int nq, int n_kv, int nnull, int* nq_pad, int* nk_pa
 extern "C" int pk_attn_prep(int dtype, const float* q, int ldq, const float* kv, int ldkv, const float* null_kv,
                             const float* q_scale, const float* k_scale, float scale,
                             void* Qp, void* Kp, void* Vt, int S, int h, int nq, int n_kv, int nnull, void* stream) {
-    if (!q || !q_scale || !Qp || S <= 0 || h <= 0) return PK_EINVAL;
-    if (kv && (!k_scale || !Kp || !Vt)) return PK_EINVAL;      // kv == NULL: query side only (cached K/V)
+    if (!q || !Qp || S <= 0 || h <= 0) return PK_EINVAL;
+    if (kv && (!Kp || !Vt)) return PK_EINVAL;                  // kv == NULL: query side only (cached K/V)
+    if (kv && ((q_scale == nullptr) != (k_scale == nullptr))) return PK_EINVAL;      // both NULL: plain dot-product attention (no l2norm)
     if (kv && nnull > 0 && !null_kv) return PK_EINVAL;
     int nq_pad, nk_pad;
     if (int rc = pk_attn_pads(nq, n_kv, nnull, &nq_pad, &nk_pad)) return rc;
     auto mis = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) != 0; };
-    if ((ldq & 3) || mis(q) || mis(q_scale) || (kv && ((ldkv & 3) || mis(kv) || mis(k_scale) || (nnull > 0 && mis(null_kv))))) return PK_EALIGN;
+    if ((ldq & 3) || mis(q) || (q_scale && mis(q_scale)) || (kv && ((ldkv & 3) || mis(kv) || (k_scale && mis(k_scale)) || (nnull > 0 && mis(null_kv))))) return PK_EALIGN;
     PrepArgs p{q, ldq, kv, ldkv, null_kv, q_scale, k_scale, Qp, Kp, Vt, S, h, nq, n_kv, nnull, nq_pad, nk_pad, scale};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long qrows = (long)S * h * nq_pad;

@@ -279,6 +279,28 @@ __global__ __launch_bounds__(256) void critic_head_kernel(const float* __restric
     if (lane == 0) out[r] = s;
 }
 
+// gated-GELU of T5 v1.1's feed-forward (HuggingFace modeling_t5.py T5DenseGatedActDense: wo(gelu_new(wi_0 x) * wi_1 x)) on the output
+// of ONE GEMM against the row-concatenated [wi_0 ; wi_1]: h (M, 2F) f32 -> out (M, F) T, out = gelu_new(h[:, :F]) * h[:, F:].
+// gelu_new = 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) (transformers activations.py NewGELUActivation).  Not on the video hot
+// path (the text encoder runs once per prompt): kept out of the GEMM epilogue on purpose.
+template <typename TO>
+__global__ __launch_bounds__(256) void gated_gelu_tanh_kernel(const float* __restrict__ h, int ldh, TO* __restrict__ out, int ldo, int M, int Fd) {
+    const int fv = Fd >> 2;
+    const long total = (long)M * fv;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % fv) * 4;
+        const long m = idx / fv;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(h + m * ldh + c), b = *reinterpret_cast<const f32x4*>(h + m * ldh + Fd + c);
+        f32x4 y;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = a[r];
+            y[r] = 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x))) * b[r];
+        }
+        store4(out + m * ldo + c, y);
+    }
+}
+
 }  // namespace pk
 using namespace pk;
 
@@ -370,6 +392,16 @@ extern "C" int pk_critic_head(const float* x, int ldx, const float* w, const flo
     const int rows = nb * (n_tot - n_prime);
     hipLaunchKernelGGL(critic_head_kernel, dim3((rows + 3) / 4), dim3(256), 0, STREAM(stream), x, ldx, w, b, D, nb, n_tot, n_prime,
                        has_null, scale, u, noise_mult, seed, seed_dev, out);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+extern "C" int pk_gated_gelu_tanh(const float* h, int ldh, void* out, int ldo, int out_kind, int M, int F, void* stream) {
+    if (!h || !out || M <= 0 || F <= 0 || ldh < 2 * F || ldo < F) return PK_EINVAL;
+    if ((F & 3) || (ldh & 3) || (ldo & 3) || (reinterpret_cast<uintptr_t>(h) & 15) || (reinterpret_cast<uintptr_t>(out) & 7)) return PK_EALIGN;
+    const long total = (long)M * (F >> 2);
+    if (out_kind == 0) hipLaunchKernelGGL((gated_gelu_tanh_kernel<float>), dim3(nblocks(total)), dim3(256), 0, STREAM(stream), h, ldh, (float*)out, ldo, M, F);
+    else hipLaunchKernelGGL((gated_gelu_tanh_kernel<bf16>), dim3(nblocks(total)), dim3(256), 0, STREAM(stream), h, ldh, (bf16*)out, ldo, M, F);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

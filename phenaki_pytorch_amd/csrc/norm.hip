@@ -237,8 +237,46 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
     }
 }
 
+// T5LayerNorm (HuggingFace transformers modeling_t5.py T5LayerNorm, the text encoder the reference calls in t5.py:64-103): no mean
+// subtraction, no bias -- y = x * rsqrt(mean(x^2) + eps) * w, statistics in f32.  rowmask (or null): rows with rowmask[row] == 0 are
+// written as zeros (t5.py:97-100 masked_fill of the padded positions, fused into the encoder's final norm).  One wave per row.
+template <typename TO>
+__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, float eps,
+                                                           const unsigned char* __restrict__ rowmask, TO* __restrict__ out, int ldo, int M, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * ldx;
+    const bool keep = !rowmask || rowmask[row] != 0;
+    float q = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c), g = *reinterpret_cast<const f32x4*>(w + c);
+        f32x4 y;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = keep ? v[r] * rstd * g[r] : 0.f;
+        store4(out + (size_t)row * ldo + c, y);
+    }
+}
+
 }  // namespace pk
 using namespace pk;
+
+extern "C" int pk_rmsnorm(const float* x, int ldx, const float* w, float eps, const unsigned char* rowmask, void* out, int ldo,
+                          int out_kind, int M, int D, void* stream) {
+    if (!x || !w || !out || M <= 0 || D <= 0) return PK_EINVAL;
+    if ((D & 3) || (ldx & 3) || (ldo & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(w) & 15)) return PK_EALIGN;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((M + 3) / 4), block(256);
+    if (out_kind == 0) hipLaunchKernelGGL((rmsnorm_rows_kernel<float>), grid, block, 0, s, x, ldx, w, eps, rowmask, (float*)out, ldo, M, D);
+    else hipLaunchKernelGGL((rmsnorm_rows_kernel<bf16>), grid, block, 0, s, x, ldx, w, eps, rowmask, (bf16*)out, ldo, M, D);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
 
 extern "C" int pk_l2norm_rows(const float* x, int ldx, void* out, int ldo, int out_kind, int M, int D, void* stream) {
     if (!x || !out || M <= 0 || D <= 0) return PK_EINVAL;

@@ -971,3 +971,38 @@ def test_vocab_cross_entropy_backward_matches_reference_autograd(golden_dir, dty
     f1 = close(E2.grad, 2.5 * ref['d_rows'], tol, f'd rows (65536) {dtype}')
     f2 = close(W2.grad, 2.5 * ref['d_weight'], tol, f'd weight (65536) {dtype}')
     record_parity('vocab_ce_backward', dict(dtype=dtype, tiny_vs_reference=dict(d_rows=e1, d_weight=e2, d_bias=e3), full_vocab_vs_oracle=dict(d_rows=f1, d_weight=f2)))
+
+
+@pytest.mark.parametrize('dtype,tol', [('fp32', 1e-3), ('bf16x3', 1e-3), ('bf16', None)])
+@pytest.mark.parametrize('tag', ['tiny', 'base'])
+def test_t5_encoder_matches_huggingface_golden(golden_dir, tag, dtype, tol):
+    """the T5 v1.1 encoder stack on the MI355X kernels (pk_rmsnorm, pk_gemm, plain pk_attn_prep + pk_attn_fwd with the
+    bucketed relative-position bias and the key mask, pk_gated_gelu_tanh) against the REAL HuggingFace T5EncoderModel -- what the reference's
+    t5.py:64-103 runs -- on name-keyed random weights; HF state_dict keys load unchanged; pads come out zero-filled (t5.py:97-100)."""
+    import phenaki_pytorch_amd as P
+    from phenaki_pytorch_amd.t5 import T5Encoder
+    from oracle import t5_oracle as T
+    g = golden(golden_dir, f't5_{tag}.pt')
+    cfg = T.T5_TINY if tag == 'tiny' else T.T5_BASE
+    enc = T5Encoder(**cfg)
+    assert {k: list(v.shape) for k, v in enc.state_dict().items()} == g['keys']
+    enc.load_state_dict(T.t5_state_dict(cfg))
+    enc = P.set_compute_dtype(enc.cuda().eval(), dtype)
+    out = enc(g['ids'].cuda(), g['mask'].cuda())
+    assert out.shape == (*g['ids'].shape, cfg['d_model']) and (out[~g['mask'].cuda()] == 0).all()
+    if tol is None:
+        # bf16 operands: T5's UNSCALED dot-product attention on random weights (no checkpoint offline) turns 2^-9 operand rounding into
+        # O(1) score changes for a few sharp rows, so the bound is on the rms error (and a loose max), not the 1e-3 of the f32-grade modes
+        # (measured: rms 2.8e-2 at the tiny geometry, 1.2e-1 at the base geometry with 12 heads x 768 random features -- fp32 3.6e-5 and
+        # bf16x3 3.1e-4 on the same weights show the kernels are right; trained T5 weights are far better conditioned)
+        e = rms_rel(out[:, :, ::g['sub']], g['out'])
+        assert e <= (4e-2 if tag == 'tiny' else 2e-1), f't5 {tag} bf16: rms error {e:.3e}'
+        assert torch.isfinite(out).all()
+    else:
+        e = close(out[:, :, ::g['sub']], g['out'], tol, f't5 {tag} {dtype}')
+    record_parity('t5_encoder_vs_huggingface', dict(tag=tag, dtype=dtype, rel_err=e))
+    # without a mask every position is real; unmasked rows of a ragged batch equal the same sequences encoded alone
+    if tag == 'tiny' and dtype == 'fp32':
+        n1 = int(g['mask'][1].sum())
+        solo = enc(g['ids'][1:2, :n1].cuda())
+        close(solo[0], out[1, :n1], 1e-4, 'ragged row vs the same sequence alone')

@@ -287,3 +287,19 @@ def test_vocab_ce_grads_match_reference_autograd(golden_dir):
     close(r['d_rows'], g['d_rows'], 1e-4)
     close(r['d_weight'], g['d_weight'], 1e-4)
     close(r['d_bias'], g['d_bias'], 1e-4)
+
+
+@pytest.mark.parametrize('tag', ['tiny', 'base'])
+def test_t5_encoder_oracle_matches_huggingface(golden_dir, tag):
+    """oracle/t5_oracle.py (restated from transformers' modeling_t5.py) against the REAL HuggingFace T5EncoderModel -- the module the
+    reference's t5.py:64-103 runs -- on name-keyed random weights (oracle/make_golden.py t5_golden); key set identical to HF's"""
+    from oracle import t5_oracle as T
+    g = load(golden_dir, f't5_{tag}.pt')
+    cfg = T.T5_TINY if tag == 'tiny' else T.T5_BASE
+    sd = T.t5_state_dict(cfg)
+    assert {k: list(v.shape) for k, v in sd.items()} == g['keys']
+    ids, mask = T.t5_inputs(cfg, *g['ids'].shape)
+    assert torch.equal(ids, g['ids']) and torch.equal(mask, g['mask'])
+    out = T.t5_encode(sd, cfg, ids, mask)
+    close(out[:, :, ::g['sub']], g['out'], 5e-5)
+    assert (out[~mask] == 0).all()
