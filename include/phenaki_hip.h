@@ -266,6 +266,58 @@ int pk_critic_head(const float* x, int ldx, const float* w, const float* b, int 
                    int has_null, float scale, const float* u, float noise_mult, unsigned long long seed,
                    const unsigned long long* seed_dev, float* out, void* stream);
 
+/* ---- training step, SURVEY.md 8f row 1: backward of the MaskGit / TokenCritic trunk (phenaki_pytorch.py:562-687 under autograd; host side
+ * phenaki_pytorch_amd/train.py).  Activations and gradients are f32; the matrix products are pk_gemm calls on operands laid down by pk_pack.
+ *
+ * pk_pack: f32 matrix -> GEMM operand image.  out[r][k] = (transpose ? src[k][r] : src[r][k]) for r < R, k < K, zero for K <= k < Kp; out has ldo
+ *   elements per row; kind 0 f32, 1 bf16, 2 the split-bf16 image (128-byte aligned, ldo % 32 == 0).  dX = dY W takes W^T, dW = dY^T X takes
+ *   dY^T as A and X^T as the "W" operand (the contraction index of pk_gemm is the contiguous one). */
+int pk_pack(const float* src, long long lds, const int* rows, int R, int K, int transpose, void* out, long long ldo, int Kp, int kind, void* stream);
+/* rows (or NULL) gathers SOURCE rows: out[r][k] = src[rows[k]][r] (transpose) / src[rows[r]][k].   pk_scatter_rows: dst[rows[m]] = src[m], m < M */
+int pk_scatter_rows(const float* src, long long lds, const int* rows, float* dst, long long ldd, int M, int D, void* stream);
+/* out[c] (accumulate ? += : =) scale * sum_r src[r][c], two deterministic stages; work: pk_colsum_parts(M) * N floats */
+int pk_colsum_parts(int M);
+int pk_colsum(const float* src, long long ld, int M, int N, float scale, float* out, int accumulate, float* work, void* stream);
+/* LayerNorm backward (attention.py:29-36, :47): dx = [add +] rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma; pg / pb (pb may be NULL):
+ * (pk_ln_bwd_parts(M), D) per-block partials of dgamma = sum dy xhat / dbeta = sum dy, finished by pk_colsum */
+int pk_ln_bwd_parts(int M);
+int pk_layernorm_bwd(const float* x, long long ldx, const float* gamma, const float* dy, long long lddy, const float* add, long long ldadd,
+                     float* dx, long long lddx, float* pg, float* pb, float eps, int M, int D, void* stream);
+/* GEGLU on stored pre-activations h (M, >= goff + F): out = h[:, :F] * gelu(h[:, goff : goff + F]) (attention.py:40-43), and its backward */
+int pk_geglu(const float* h, long long ldh, int goff, float* out, long long ldo, int M, int F, void* stream);
+int pk_geglu_bwd(const float* h, long long ldh, int goff, const float* dout, long long ldd, float* dh, long long lddh, int M, int F, void* stream);
+/* dz = dy * (y > 0 ? 1 : slope): LeakyReLU backward from the activation's output (position-bias MLP, attention.py:243-247) */
+int pk_leaky_bwd(const float* y, long long ldy, const float* dy, long long lddy, float* dz, long long lddz, int M, int N, float slope, void* stream);
+/* PEG backward (attention.py:57-85 + residual :323): dx = dy + transposed stencil of dy; part (NULL: skip): (pk_peg_wgrad_parts(rows), 27, D)
+ * partial tap gradients sum dy[pos] x[pos + tap], finished by pk_colsum over 27 D columns (the conv bias gradient is pk_colsum of dy) */
+int pk_peg_wgrad_parts(long long rows);
+int pk_peg_bwd(const float* dy, const float* x, const float* wt, float* dx, float* part, int B, int T, int H, int W, int D, int causal, void* stream);
+/* token + position embedding backward (phenaki_pytorch.py:194-199, alpha = gradient_shrink_alpha): dpos (n, D) overwritten, dtok (zeroed by
+ * the caller) += by f32 atomics */
+int pk_embed_bwd(const float* dy, const long long* ids, float alpha, float* dtok, float* dpos, int S, int n, int D, void* stream);
+/* position bias (attention.py:257-275): out[h][i][j] = tab[code[i] - code[j] + off][h] and its adjoint (dtab zeroed by the caller, f32 atomics) */
+int pk_bias_gather(const float* tab, int ldt, const int* code, int off, float* out, int heads, int n, void* stream);
+int pk_bias_scatter(const float* dbias, const int* code, int off, float* dtab, int ldt, int heads, int n, void* stream);
+/* out[e] = sum_s src[s * stride + e], e < E (E % 4 == 0) */
+int pk_sum_batch(const float* src, long long stride, int S, float* out, long long E, void* stream);
+/* critic head + BCE-with-logits forward and backward in one pass (phenaki_pytorch.py:246-249, :673-676): logits / loss_rows (M) optional;
+ * labels NULL: logits only; de = dz w with dz = (sigmoid(z) - y) scale; pw (pk_ln_bwd_parts(M), D) / pb (pk_ln_bwd_parts(M)) partials of dw / db */
+int pk_bce_head(const float* e, long long lde, const float* w, const float* b, const float* labels, float scale, float* logits, float* loss_rows,
+                float* de, long long ldde, float* pw, float* pb, int M, int D, void* stream);
+/* attention backward (attention.py:132-182).  pk_attn_train_prep: the f32 operands q^ = l2norm(q) q_scale scale -> Qh (S heads, n, 64),
+ * k^ = l2norm([null_k ; k]) k_scale -> Kh, [null_v ; v] -> Vh (S heads, nnull + n_kv, 64) from the projection outputs q (S n, ldq), kv (S n_kv, ldkv).
+ * pk_attn_bwd: dQh / dKh / dVh from those, the forward output O (f32 or bf16) and dO; bias (heads, n, n_kv) / kmask (S, n_kv) cover the real keys;
+ * dS (S heads, n, n_kv; optional) = the score gradient for the position-bias gradient (pk_sum_batch over S); lse / Drow: (S heads n) scratch.
+ * pk_attn_train_prep_bwd: back through l2norm / scales / null keys: dq, dkv, partials pq / pk (1024, 64) of dq_scale / dk_scale, dnull (heads, 2 nnull, 64). */
+int pk_attn_train_prep(const float* q, long long ldq, const float* kv, long long ldkv, const float* null_kv, const float* q_scale, const float* k_scale,
+                       float scale, float* Qh, float* Kh, float* Vh, int S, int heads, int n, int n_kv, int nnull, void* stream);
+int pk_attn_train_prep_bwd(const float* q, long long ldq, const float* kv, long long ldkv, const float* null_kv, const float* q_scale, const float* k_scale,
+                           float scale, const float* dQh, const float* dKh, const float* dVh, float* dq, long long lddq, float* dkv, long long lddkv,
+                           float* pq, float* pk, float* dnull, int S, int heads, int n, int n_kv, int nnull, void* stream);
+int pk_attn_bwd(const float* Qh, const float* Kh, const float* Vh, const void* O, long long ldo, int o_bf16, const float* dO, long long lddo,
+                const float* bias, const unsigned char* kmask, float* dQh, float* dKh, float* dVh, float* dS, float* lse, float* Drow,
+                int S, int heads, int n, int n_kv, int nnull, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

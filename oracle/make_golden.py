@@ -232,6 +232,63 @@ def forward_golden(R, cfgs, batch, frames, ctx_len, tag):
     print(f'forward_{tag}: loss {float(total):.6f} = generator {float(gen):.6f} + w * critic {float(crit):.6f}')
 
 
+def forward_grads_golden(R, cfgs, batch, frames, ctx_len, tag):
+    """the REAL reference's training step -- Phenaki.forward (phenaki_pytorch.py:562-687) + loss.backward() -- with the
+    three random draws of forward_golden: the gradient of every MaskGit and TokenCritic parameter (total objective), plus the
+    generator-only / critic-only variants' losses.  Token ids come from the reference C-ViViT (frozen, no grad, as in :580-584)."""
+    cv, mg, cr, ph = build_reference(R, cfgs, with_phenaki=True, with_critic=True)
+    m = R.module
+    H = cfgs['cvivit']['image_size']
+    video = weights.synthetic_video(batch, frames, H, H, seed=5)
+    ctx = weights.synthetic_context(batch, ctx_len, cfgs['maskgit']['dim_context'], seed=3, pad_last=2)
+    steps = cfgs['steps']
+    rand_step = (torch.arange(batch) * 2 + 1) % steps
+    orig = (torch.randint, torch.rand, m.gumbel_noise)
+    pt = cfgs['cvivit']['temporal_patch_size']
+    hw = H // cfgs['cvivit']['patch_size']
+    n = (1 + (frames - 1) // pt) * hw * hw
+    perm_noise = weights.uniform_noise((batch, n), 700)
+    gumbel_u = weights.uniform_noise((batch, n, cfgs['maskgit']['num_tokens']), 701)
+
+    def randint(low, high, size, **kw):
+        return rand_step.clone()
+
+    def rand(size, **kw):
+        return perm_noise.clone()
+
+    def gumbel_noise(t):
+        return -m.log(-m.log(gumbel_u))
+
+    with torch.no_grad():
+        ids = cv(video, return_only_codebook_ids=True)
+    out = dict(ids=ids, rand_step=rand_step, batch=batch, frames=frames, ctx_len=ctx_len)
+    torch.randint, torch.rand, m.gumbel_noise = randint, rand, gumbel_noise
+    try:
+        for name, kw in (('total', {}), ('generator', dict(only_train_generator=True)), ('critic', dict(only_train_critic=True))):
+            for mod in (mg, cr):
+                mod.train()
+                mod.zero_grad(set_to_none=True)
+            for prm in list(mg.parameters()) + list(cr.parameters()):
+                prm.requires_grad_(True)
+            loss = ph(video_codebook_ids=ids, text_embeds=ctx, **kw)
+            loss.backward()
+            out[f'loss_{name}'] = loss.detach().clone()
+            grads = {f'maskgit.{k}': v.grad.detach().clone() for k, v in mg.named_parameters() if v.grad is not None}
+            grads.update({f'critic.{k}': v.grad.detach().clone() for k, v in cr.named_parameters() if v.grad is not None})
+            if name == 'total':
+                out['grads_total'] = grads
+            else:
+                # the variants train one of the two networks: which parameters received a gradient, and one probe value each
+                out[f'grad_keys_{name}'] = sorted(grads)
+                probe = 'maskgit.to_logits.weight' if name == 'generator' else 'critic.to_logits.0.weight'
+                out[f'grad_probe_{name}'] = (probe, grads[probe])
+    finally:
+        torch.randint, torch.rand, m.gumbel_noise = orig
+    torch.save(out, os.path.join(OUT, f'forward_grads_{tag}.pt'))
+    print(f'forward_grads_{tag}: losses {float(out["loss_total"]):.6f} / {float(out["loss_generator"]):.6f} / {float(out["loss_critic"]):.6f}; '
+          f'{len(out["grads_total"])} gradients ({len(out["grad_keys_generator"])} generator-only, {len(out["grad_keys_critic"])} critic-only)')
+
+
 def recon_loss_golden(R, cfgs, tag):
     """CViViT.forward's default return with use_vgg_and_gan=False: the reconstruction MSE (cvivit.py:585-627), plain, with a
     frame mask, with return_recons, and for a 4-D image batch."""
@@ -429,6 +486,8 @@ def main():
         t5_golden('base', T.T5_BASE, B=2, L=40, sub=8)
     if 'tiny' in which or 'grads' in which:
         ce_grad_golden(R, TINY, tag='tiny')
+    if 'tiny' in which or 'grads' in which or 'fwdgrads' in which:
+        forward_grads_golden(R, TINY, batch=3, frames=5, ctx_len=6, tag='tiny')
     if 'tiny' in which or 'critics' in which:
         selfcritic_golden(R, TINY, tag='tiny')
         unconditional_golden(R, TINY, tag='tiny')

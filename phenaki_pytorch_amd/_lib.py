@@ -56,6 +56,25 @@ SIGNATURES = {
     'pk_ce_grad_slab': [_I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _P, _I, _P, _I, _P, _P],
     'pk_topk_mask': [_P, _I, _I, _I, _LL, _P, _P, _P, _P, _P],
     'pk_critic_head': [_P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P, _F, _ULL, _P, _P, _P],
+    'pk_pack': [_P, _LL, _P, _I, _I, _I, _P, _LL, _I, _I, _P],
+    'pk_scatter_rows': [_P, _LL, _P, _P, _LL, _I, _I, _P],
+    'pk_colsum_parts': [_I],
+    'pk_colsum': [_P, _LL, _I, _I, _F, _P, _I, _P, _P],
+    'pk_ln_bwd_parts': [_I],
+    'pk_layernorm_bwd': [_P, _LL, _P, _P, _LL, _P, _LL, _P, _LL, _P, _P, _F, _I, _I, _P],
+    'pk_geglu': [_P, _LL, _I, _P, _LL, _I, _I, _P],
+    'pk_geglu_bwd': [_P, _LL, _I, _P, _LL, _P, _LL, _I, _I, _P],
+    'pk_leaky_bwd': [_P, _LL, _P, _LL, _P, _LL, _I, _I, _F, _P],
+    'pk_peg_wgrad_parts': [_LL],
+    'pk_peg_bwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    'pk_embed_bwd': [_P, _P, _F, _P, _P, _I, _I, _I, _P],
+    'pk_bias_gather': [_P, _I, _P, _I, _P, _I, _I, _P],
+    'pk_bias_scatter': [_P, _P, _I, _P, _I, _I, _I, _P],
+    'pk_sum_batch': [_P, _LL, _I, _P, _LL, _P],
+    'pk_bce_head': [_P, _LL, _P, _P, _P, _F, _P, _P, _P, _LL, _P, _P, _I, _I, _P],
+    'pk_attn_train_prep': [_P, _LL, _P, _LL, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'pk_attn_train_prep_bwd': [_P, _LL, _P, _LL, _P, _P, _P, _F, _P, _P, _P, _P, _LL, _P, _LL, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'pk_attn_bwd': [_P, _P, _P, _P, _LL, _I, _P, _LL, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
 }
 
 _ERR = {-1: 'PK_EINVAL (bad shape/size/flag)', -2: 'PK_EALIGN (pointer/stride alignment)', -3: 'PK_ELAUNCH (HIP launch failed)'}
@@ -386,3 +405,143 @@ def critic_head(x, w, b, D, nb, n_tot, n_prime, has_null, scale, u, noise_mult, 
     rc = load().pk_critic_head(ptr(x), x.stride(-2), f32p(w, 'critic head weight'), f32p(b, 'critic head bias'), D, nb, n_tot, n_prime, 1 if has_null else 0, scale,
                                ptr(u), noise_mult, seed & 0xFFFFFFFFFFFFFFFF, ptr(seed_dev), ptr(out), stream(x))
     _check(rc, 'pk_critic_head')
+
+
+# ----------------------------------------------------------------------------- training-step kernels (csrc/train.hip, attn_train.hip)
+
+def kind_of(dtype):
+    """pk_pack's `kind` of the W-side operand image of compute dtype `dtype`"""
+    return {F32: 0, BF16: 1, BF16X3: 2}[dtype]
+
+
+def pack(src, R, K, transpose, out, Kp, kind, rows=None):
+    """out[r][k] = src[k][r] (transpose) / src[r][k] for r < R, k < K; zero for K <= k < Kp.  rows: int32 gather of SOURCE rows."""
+    rc = load().pk_pack(ptr(src), src.stride(-2), ptr(rows), R, K, 1 if transpose else 0, ptr(out), out.stride(-2), Kp, kind, stream(src))
+    _check(rc, 'pk_pack')
+    return out
+
+
+def scatter_rows(src, rows, dst, M, D):
+    rc = load().pk_scatter_rows(ptr(src), src.stride(-2), ptr(rows), ptr(dst), dst.stride(-2), M, D, stream(src))
+    _check(rc, 'pk_scatter_rows')
+
+
+def colsum(src, M, N, out, *, scale=1.0, accumulate=False, ld=None):
+    """out[c] (+)= scale * sum_r src[r][c] (deterministic two-stage reduction)"""
+    P = load().pk_colsum_parts(M)
+    work = torch.empty((P * N,), device=src.device, dtype=torch.float32)
+    rc = load().pk_colsum(ptr(src), src.stride(-2) if ld is None else ld, M, N, float(scale), ptr(out), 1 if accumulate else 0, ptr(work), stream(src))
+    _check(rc, 'pk_colsum')
+    return out
+
+
+def layernorm_bwd(x, gamma, dy, dx, M, D, *, add=None, want_beta=False, eps=1e-5):
+    """dx = [add +] LN backward; returns (dgamma, dbeta | None)"""
+    P = load().pk_ln_bwd_parts(M)
+    pg = torch.empty((P, D), device=x.device, dtype=torch.float32)
+    pb = torch.empty((P, D), device=x.device, dtype=torch.float32) if want_beta else None
+    rc = load().pk_layernorm_bwd(ptr(x), x.stride(-2), f32p(gamma, 'LayerNorm gamma'), ptr(dy), dy.stride(-2), ptr(add), add.stride(-2) if add is not None else 0,
+                                 ptr(dx), dx.stride(-2), ptr(pg), ptr(pb), eps, M, D, stream(x))
+    _check(rc, 'pk_layernorm_bwd')
+    dg = colsum(pg, P, D, torch.empty((D,), device=x.device, dtype=torch.float32))
+    db = colsum(pb, P, D, torch.empty((D,), device=x.device, dtype=torch.float32)) if want_beta else None
+    return dg, db
+
+
+def geglu(h, goff, out, M, F):
+    rc = load().pk_geglu(ptr(h), h.stride(-2), goff, ptr(out), out.stride(-2), M, F, stream(h))
+    _check(rc, 'pk_geglu')
+
+
+def geglu_bwd(h, goff, dout, dh, M, F):
+    rc = load().pk_geglu_bwd(ptr(h), h.stride(-2), goff, ptr(dout), dout.stride(-2), ptr(dh), dh.stride(-2), M, F, stream(h))
+    _check(rc, 'pk_geglu_bwd')
+
+
+def leaky_bwd(y, dy, dz, M, N, slope=0.1):
+    rc = load().pk_leaky_bwd(ptr(y), y.stride(-2), ptr(dy), dy.stride(-2), ptr(dz), dz.stride(-2), M, N, slope, stream(y))
+    _check(rc, 'pk_leaky_bwd')
+
+
+def peg_bwd(dy, x, wt, dx, B, T, H, W, D, causal, want_wgrad=True):
+    """dx = dy + transposed stencil; returns the (27, D) tap gradient (or None)"""
+    rows = B * T * H * W
+    part = None
+    if want_wgrad:
+        P = load().pk_peg_wgrad_parts(rows)
+        part = torch.empty((P, 27 * D), device=dy.device, dtype=torch.float32)
+    rc = load().pk_peg_bwd(ptr(dy), ptr(x), f32p(wt, 'PEG taps'), ptr(dx), ptr(part), B, T, H, W, D, 1 if causal else 0, stream(dy))
+    _check(rc, 'pk_peg_bwd')
+    if part is None:
+        return None
+    return colsum(part, part.shape[0], 27 * D, torch.empty((27 * D,), device=dy.device, dtype=torch.float32)).view(27, D)
+
+
+def embed_bwd(dy, ids, alpha, dtok, dpos, S, n, D):
+    rc = load().pk_embed_bwd(ptr(dy), ptr(ids), float(alpha), ptr(dtok), ptr(dpos), S, n, D, stream(dy))
+    _check(rc, 'pk_embed_bwd')
+
+
+def bias_gather(tab, code, off, out, heads, n):
+    rc = load().pk_bias_gather(ptr(tab), tab.stride(0), ptr(code), off, ptr(out), heads, n, stream(tab))
+    _check(rc, 'pk_bias_gather')
+
+
+def bias_scatter(dbias, code, off, dtab, heads, n):
+    rc = load().pk_bias_scatter(ptr(dbias), ptr(code), off, ptr(dtab), dtab.stride(0), heads, n, stream(dbias))
+    _check(rc, 'pk_bias_scatter')
+
+
+def sum_batch(src, S, out, E):
+    rc = load().pk_sum_batch(ptr(src), src.stride(0), S, ptr(out), E, stream(src))
+    _check(rc, 'pk_sum_batch')
+
+
+def bce_head(e, w, b, labels, M, D, *, scale=0.0, logits=None, loss_rows=None, de=None):
+    """returns (dw (D,), db (1,)) when de is given, else None"""
+    pw = pb = None
+    P = load().pk_ln_bwd_parts(M)
+    if de is not None:
+        pw = torch.empty((P, D), device=e.device, dtype=torch.float32)
+        pb = torch.empty((P, 1), device=e.device, dtype=torch.float32)
+    rc = load().pk_bce_head(ptr(e), e.stride(-2), f32p(w, 'critic head weight'), f32p(b, 'critic head bias'), ptr(labels), float(scale), ptr(logits), ptr(loss_rows),
+                            ptr(de), de.stride(-2) if de is not None else 0, ptr(pw), ptr(pb), M, D, stream(e))
+    _check(rc, 'pk_bce_head')
+    if de is None:
+        return None
+    dw = colsum(pw, P, D, torch.empty((D,), device=e.device, dtype=torch.float32))
+    db = colsum(pb, P, 1, torch.empty((1,), device=e.device, dtype=torch.float32))
+    return dw, db
+
+
+ATTN_PREP_BWD_PARTS = 1024
+
+
+def attn_train_prep(q, kv, null_kv, q_scale, k_scale, scale, Qh, Kh, Vh, S, h, n, n_kv, nnull):
+    rc = load().pk_attn_train_prep(ptr(q), q.stride(-2), ptr(kv), kv.stride(-2), f32p(null_kv, 'null_kv') if nnull else None, f32p(q_scale, 'q_scale'),
+                                   f32p(k_scale, 'k_scale'), scale, ptr(Qh), ptr(Kh), ptr(Vh), S, h, n, n_kv, nnull, stream(q))
+    _check(rc, 'pk_attn_train_prep')
+
+
+def attn_train_prep_bwd(q, kv, null_kv, q_scale, k_scale, scale, dQh, dKh, dVh, dq, dkv, S, h, n, n_kv, nnull):
+    """-> (dq_scale (64,), dk_scale (64,), dnull_kv | None); dq / dkv are overwritten"""
+    dev = q.device
+    pq = torch.empty((ATTN_PREP_BWD_PARTS, 64), device=dev, dtype=torch.float32)
+    pk = torch.empty((ATTN_PREP_BWD_PARTS, 64), device=dev, dtype=torch.float32)
+    dnull = torch.empty((h, 2 * nnull, 64), device=dev, dtype=torch.float32) if nnull else None
+    rc = load().pk_attn_train_prep_bwd(ptr(q), q.stride(-2), ptr(kv), kv.stride(-2), f32p(null_kv, 'null_kv') if nnull else None, f32p(q_scale, 'q_scale'),
+                                       f32p(k_scale, 'k_scale'), scale, ptr(dQh), ptr(dKh), ptr(dVh), ptr(dq), dq.stride(-2), ptr(dkv), dkv.stride(-2),
+                                       ptr(pq), ptr(pk), ptr(dnull), S, h, n, n_kv, nnull, stream(q))
+    _check(rc, 'pk_attn_train_prep_bwd')
+    dqs = colsum(pq, ATTN_PREP_BWD_PARTS, 64, torch.empty((64,), device=dev, dtype=torch.float32))
+    dks = colsum(pk, ATTN_PREP_BWD_PARTS, 64, torch.empty((64,), device=dev, dtype=torch.float32))
+    return dqs, dks, dnull
+
+
+def attn_bwd(Qh, Kh, Vh, O, dO, dQh, dKh, dVh, S, h, n, n_kv, nnull, *, bias=None, kmask=None, dS=None):
+    dev = Qh.device
+    lse = torch.empty((S * h * n,), device=dev, dtype=torch.float32)
+    drow = torch.empty((S * h * n,), device=dev, dtype=torch.float32)
+    rc = load().pk_attn_bwd(ptr(Qh), ptr(Kh), ptr(Vh), ptr(O), O.stride(-2), 1 if O.dtype == torch.bfloat16 else 0, ptr(dO), dO.stride(-2), ptr(bias), ptr(kmask),
+                            ptr(dQh), ptr(dKh), ptr(dVh), ptr(dS), ptr(lse), ptr(drow), S, h, n, n_kv, nnull, stream(Qh))
+    _check(rc, 'pk_attn_bwd')

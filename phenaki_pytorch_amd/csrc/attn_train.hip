@@ -1,0 +1,381 @@
+// Attention backward for the training step (reference attention.py:132-182 under autograd).
+//   q^ = l2norm(q) * q_scale * scale,  k^ = l2norm([null_k ; k]) * k_scale,  v_all = [null_v ; v]
+//   S = q^ k^T + bias (+ key mask),  P = softmax(S),  O = P v_all
+// The forward pass of a training step runs the inference kernels (pk_attn_prep / pk_attn_fwd); what is saved is q, kv (the projection
+// outputs), O and dO.  Backward recomputes the f32 operands (pk_attn_train_prep), then
+//   pk_attn_bwd :  kernel Q (one workgroup per 64 query rows of a head): lse by an online pass over the keys, D = rowsum(dO * O),
+//                  dS = P * (dO V^T - D), dQ^ = dS K^   [+ dS written out for the position-bias gradient]
+//                  kernel KV (one workgroup per 64 keys of a head): dV = P^T dO, dK^ = dS^T Q^ over all query tiles
+//   pk_attn_train_prep_bwd : l2norm / scale / null-key backward -> dq, dkv, dq_scale, dk_scale, dnull_kv
+// All tile products are 64 x 64 x 64 on v_mfma_f32_16x16x4_f32 from f32 LDS tiles (rows padded to 68 floats: the A-side fragment read
+// (row = lane & 15, k = lane >> 4) touches 64 distinct banks).  No pipelining: 13 GFLOP per MaskGit layer at B = 8, a few hundred
+// microseconds; the GEMMs of the backward pass dominate the step.  Every result is owned by exactly one workgroup (no atomics).
+#include "common.hpp"
+
+namespace pk {
+
+#define STREAM(s) reinterpret_cast<hipStream_t>(s)
+constexpr int TLD = 68;                        // LDS tile row stride (floats)
+constexpr int TSZ = 64 * TLD;                  // one 64 x 64 tile
+
+// ---- f32 operand images of one attention call: Qh [S*h][n][64], Kh / Vh [S*h][nkt][64], nkt = nnull + n_kv --------------------------
+__global__ __launch_bounds__(256) void attn_train_prep_kernel(const float* __restrict__ q, long ldq, const float* __restrict__ kv, long ldkv,
+                                                              const float* __restrict__ null_kv, const float* __restrict__ q_scale,
+                                                              const float* __restrict__ k_scale, float scale, float* __restrict__ Qh,
+                                                              float* __restrict__ Kh, float* __restrict__ Vh, int S, int heads, int n, int n_kv,
+                                                              int nnull, long tasks) {
+    const int lane = threadIdx.x & 63;
+    const int nkt = nnull + n_kv, inner = heads * 64;
+    const long nq = (long)S * heads * n;
+    for (long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6); t < tasks; t += (long)gridDim.x * 4) {
+        if (t < nq) {
+            const int i = (int)(t % n), h = (int)((t / n) % heads), s = (int)(t / ((long)n * heads));
+            const float x = q[((long)s * n + i) * ldq + h * 64 + lane];
+            const float inv = 1.0f / fmaxf(sqrtf(wave_sum(x * x)), 1e-12f);
+            Qh[t * 64 + lane] = x * inv * q_scale[lane] * scale;
+        } else {
+            const long u = t - nq;
+            const int j = (int)(u % nkt), h = (int)((u / nkt) % heads), s = (int)(u / ((long)nkt * heads));
+            float k, v;
+            if (j < nnull) {
+                k = null_kv[((long)h * 2 * nnull + 2 * j) * 64 + lane];
+                v = null_kv[((long)h * 2 * nnull + 2 * j + 1) * 64 + lane];
+            } else {
+                const float* row = kv + ((long)s * n_kv + (j - nnull)) * ldkv + h * 64 + lane;
+                k = row[0];
+                v = row[inner];
+            }
+            const float inv = 1.0f / fmaxf(sqrtf(wave_sum(k * k)), 1e-12f);
+            Kh[u * 64 + lane] = k * inv * k_scale[lane];
+            Vh[u * 64 + lane] = v;
+        }
+    }
+}
+
+// backward of the above.  dq (M, ldq'), dkv (Mk, ldkv') are overwritten for the real rows; pq / pk: (gridDim.x, 64) partials of dq_scale / dk_scale
+__global__ __launch_bounds__(256) void attn_train_prep_bwd_kernel(const float* __restrict__ q, long ldq, const float* __restrict__ kv, long ldkv,
+                                                                  const float* __restrict__ null_kv, const float* __restrict__ q_scale,
+                                                                  const float* __restrict__ k_scale, float scale, const float* __restrict__ dQh,
+                                                                  const float* __restrict__ dKh, const float* __restrict__ dVh, float* __restrict__ dq,
+                                                                  long lddq, float* __restrict__ dkv, long lddkv, float* __restrict__ pq,
+                                                                  float* __restrict__ pk_, int S, int heads, int n, int n_kv, int nnull, long tasks) {
+    __shared__ float red[2][4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nkt = nnull + n_kv, inner = heads * 64;
+    const long nq = (long)S * heads * n;
+    const float qs = q_scale[lane], ks = k_scale[lane];
+    float aq = 0.f, ak = 0.f;
+    for (long t = (long)blockIdx.x * 4 + wv; t < tasks; t += (long)gridDim.x * 4) {
+        if (t < nq) {
+            const int i = (int)(t % n), h = (int)((t / n) % heads), s = (int)(t / ((long)n * heads));
+            const float x = q[((long)s * n + i) * ldq + h * 64 + lane];
+            const float inv = 1.0f / fmaxf(sqrtf(wave_sum(x * x)), 1e-12f);
+            const float xn = x * inv, g = dQh[t * 64 + lane];
+            aq += g * xn * scale;
+            const float dn = g * qs * scale;
+            const float dot = wave_sum(dn * xn);
+            dq[((long)s * n + i) * lddq + h * 64 + lane] = (dn - xn * dot) * inv;
+        } else {
+            const long u = t - nq;
+            const int j = (int)(u % nkt), h = (int)((u / nkt) % heads), s = (int)(u / ((long)nkt * heads));
+            const float k = j < nnull ? null_kv[((long)h * 2 * nnull + 2 * j) * 64 + lane]
+                                      : kv[((long)s * n_kv + (j - nnull)) * ldkv + h * 64 + lane];
+            const float inv = 1.0f / fmaxf(sqrtf(wave_sum(k * k)), 1e-12f);
+            const float kn = k * inv, g = dKh[u * 64 + lane];
+            ak += g * kn;
+            if (j >= nnull) {
+                const float dn = g * ks;
+                const float dot = wave_sum(dn * kn);
+                float* row = dkv + ((long)s * n_kv + (j - nnull)) * lddkv + h * 64 + lane;
+                row[0] = (dn - kn * dot) * inv;
+                row[inner] = dVh[u * 64 + lane];
+            }
+        }
+    }
+    red[0][wv][lane] = aq;
+    red[1][wv][lane] = ak;
+    __syncthreads();
+    if (wv < 2) {
+        float* dst = wv == 0 ? pq : pk_;
+        dst[(long)blockIdx.x * 64 + lane] = (red[wv][0][lane] + red[wv][1][lane]) + (red[wv][2][lane] + red[wv][3][lane]);
+    }
+}
+// dnull_kv[h][2 j + {0, 1}][d] = sum over the sequences of the null key's l2norm backward / of dV at the null slot (one wave per (h, j))
+__global__ __launch_bounds__(64) void null_kv_bwd_kernel(const float* __restrict__ null_kv, const float* __restrict__ k_scale, const float* __restrict__ dKh,
+                                                         const float* __restrict__ dVh, float* __restrict__ dnull, int S, int heads, int nkt, int nnull) {
+    const int lane = threadIdx.x, j = blockIdx.x % nnull, h = blockIdx.x / nnull;
+    const float k = null_kv[((long)h * 2 * nnull + 2 * j) * 64 + lane];
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(k * k)), 1e-12f);
+    const float kn = k * inv, ks = k_scale[lane];
+    float gk = 0.f, gv = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const long u = ((long)s * heads + h) * nkt + j;
+        gk += dKh[u * 64 + lane];
+        gv += dVh[u * 64 + lane];
+    }
+    const float dn = gk * ks;                                   // the l2norm backward is linear in the incoming gradient: sum first
+    const float dot = wave_sum(dn * kn);
+    dnull[((long)h * 2 * nnull + 2 * j) * 64 + lane] = (dn - kn * dot) * inv;
+    dnull[((long)h * 2 * nnull + 2 * j + 1) * 64 + lane] = gv;
+}
+
+// ---- 64 x 64 x 64 tile product on the f32 matrix cores -------------------------------------------------------------------------------
+// acc[nb] (rows m0 + (lane >> 4) * 4 + i, column nb * 16 + (lane & 15)) += sum_k A(m, k) B(n, k),  A(m, k) = As[m * sam + k * sak],
+// B(n, k) = Bs[n * sbn + k * sbk]
+__device__ __forceinline__ void mma64(const float* As, int sam, int sak, const float* Bs, int sbn, int sbk, f32x4 (&acc)[4], int m0, int lane) {
+    const int r = lane & 15, kq = lane >> 4;
+    const float* ap = As + (m0 + r) * sam + kq * sak;
+    const float* bp = Bs + r * sbn + kq * sbk;
+#pragma unroll 4
+    for (int k0 = 0; k0 < 64; k0 += 4) {
+        const float a = ap[k0 * sak];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[nb * 16 * sbn + k0 * sbk], acc[nb], 0, 0, 0);
+    }
+}
+
+struct AttnBwdArgs {
+    const float* Qh; const float* Kh; const float* Vh;       // [S*h][n][64], [S*h][nkt][64]
+    const void* O; long ldo_; int o_bf16;                    // forward output (M, >= heads * 64), f32 or bf16
+    const float* dO; long lddo;                              // (M, >= heads * 64) f32
+    const float* bias;                                       // [heads][n][nkt - nnull] or null (columns = real keys)
+    const unsigned char* kmask;                              // [S][nkt - nnull] or null
+    float* dQh; float* dKh; float* dVh;
+    float* dS;                                               // [S*h][n][nkt - nnull] or null (real-key columns only)
+    float* lse; float* Drow;                                 // [S*h][n] scratch written by kernel Q, read by kernel KV
+    int S, heads, n, nkt, nnull;
+};
+
+// rows [r0, r0 + 64) x 64 floats of a [rows_total][64] matrix -> LDS tile (zero rows beyond rows_total)
+__device__ __forceinline__ void load_tile(float* dst, const float* src, int r0, int rows_total) {
+    for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+        const int r = e >> 4, c = (e & 15) * 4;
+        f32x4 v = f32x4{0, 0, 0, 0};
+        if (r0 + r < rows_total) v = *reinterpret_cast<const f32x4*>(src + (long)(r0 + r) * 64 + c);
+        *reinterpret_cast<f32x4*>(dst + r * TLD + c) = v;
+    }
+}
+// the (s, h) slice of a (M, ld) row-major activation: rows s * n + i, columns h * 64 ..
+__device__ __forceinline__ void load_tile_rows(float* dst, const float* src, long ld, int r0, int rows_total) {
+    for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+        const int r = e >> 4, c = (e & 15) * 4;
+        f32x4 v = f32x4{0, 0, 0, 0};
+        if (r0 + r < rows_total) v = *reinterpret_cast<const f32x4*>(src + (long)(r0 + r) * ld + c);
+        *reinterpret_cast<f32x4*>(dst + r * TLD + c) = v;
+    }
+}
+
+// score of (query row gi, key j) from the raw product, or "excluded"
+__device__ __forceinline__ bool score(const AttnBwdArgs& p, int s, int h, int gi, int j, float raw, float& out) {
+    if (j >= p.nkt || gi >= p.n) return false;
+    const int jr = j - p.nnull;                                // real-key column
+    float v = raw;
+    if (p.bias && jr >= 0) v += p.bias[((long)h * p.n + gi) * (p.nkt - p.nnull) + jr];
+    if (p.kmask && jr >= 0 && !p.kmask[(long)s * (p.nkt - p.nnull) + jr]) v = NEG_MAX;
+    out = v;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Qs = sm; float* dOs = sm + TSZ; float* Ks = sm + 2 * TSZ; float* Vs = sm + 3 * TSZ; float* Ps = sm + 4 * TSZ;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
+    const int nqt = (p.n + 63) / 64;
+    const int qt = blockIdx.x % nqt, sh = blockIdx.x / nqt, h = sh % p.heads, s = sh / p.heads;
+    const int i0 = qt * 64, m0 = wv * 16;
+    const int nreal = p.nkt - p.nnull;
+    load_tile(Qs, p.Qh + (long)sh * p.n * 64, i0, p.n);
+    load_tile_rows(dOs, p.dO + (long)s * p.n * p.lddo + h * 64, p.lddo, i0, p.n);
+    // D = rowsum(dO * O) for this wave's 16 rows
+    float Dl[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+        const int gi = i0 + m0 + rr;
+        float v = 0.f;
+        if (gi < p.n) {
+            const long orow = ((long)s * p.n + gi);
+            const float o = p.o_bf16 ? bf2f(reinterpret_cast<const u16*>(p.O)[orow * p.ldo_ + h * 64 + lane])
+                                     : reinterpret_cast<const float*>(p.O)[orow * p.ldo_ + h * 64 + lane];
+            v = o * p.dO[orow * p.lddo + h * 64 + lane];
+        }
+        v = wave_sum(v);
+        if ((rr >> 2) == kq) Dl[rr & 3] = v;
+        if (lane == 0 && gi < p.n) p.Drow[(long)sh * p.n + gi] = v;
+    }
+    __syncthreads();
+    // ---- pass 1: log-sum-exp of every row (online, per lane over its 4 rows x 16 columns per tile; lanes of a row merged at the end)
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, l[4] = {0.f, 0.f, 0.f, 0.f};
+    const int nkt_tiles = (p.nkt + 63) / 64;
+    for (int kt = 0; kt < nkt_tiles; ++kt) {
+        load_tile(Ks, p.Kh + (long)sh * p.nkt * 64, kt * 64, p.nkt);
+        __syncthreads();
+        f32x4 acc[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+        mma64(Qs, TLD, 1, Ks, TLD, 1, acc, m0, lane);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float sc;
+                if (!score(p, s, h, i0 + m0 + kq * 4 + i, kt * 64 + nb * 16 + r, acc[nb][i], sc)) continue;
+                const float mn = fmaxf(mx[i], sc);
+                l[i] = l[i] * __expf(mx[i] - mn) + __expf(sc - mn);
+                mx[i] = mn;
+            }
+        __syncthreads();
+    }
+    float lse[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const float m2 = __shfl_xor(mx[i], off, 64), l2 = __shfl_xor(l[i], off, 64);
+            const float mn = fmaxf(mx[i], m2);
+            const float a = mx[i] == -INFINITY ? 0.f : l[i] * __expf(mx[i] - mn), b = m2 == -INFINITY ? 0.f : l2 * __expf(m2 - mn);
+            l[i] = a + b;
+            mx[i] = mn;
+        }
+        lse[i] = mx[i] + __logf(l[i]);
+        const int gi = i0 + m0 + kq * 4 + i;
+        if (r == 0 && gi < p.n) p.lse[(long)sh * p.n + gi] = lse[i];
+    }
+    // ---- pass 2: dS and dQ^
+    f32x4 accQ[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    for (int kt = 0; kt < nkt_tiles; ++kt) {
+        load_tile(Ks, p.Kh + (long)sh * p.nkt * 64, kt * 64, p.nkt);
+        load_tile(Vs, p.Vh + (long)sh * p.nkt * 64, kt * 64, p.nkt);
+        __syncthreads();
+        f32x4 accS[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+        f32x4 accP[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+        mma64(Qs, TLD, 1, Ks, TLD, 1, accS, m0, lane);
+        mma64(dOs, TLD, 1, Vs, TLD, 1, accP, m0, lane);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gi = i0 + m0 + kq * 4 + i, j = kt * 64 + nb * 16 + r;
+                float sc, ds = 0.f;
+                if (score(p, s, h, gi, j, accS[nb][i], sc)) ds = __expf(sc - lse[i]) * (accP[nb][i] - Dl[i]);
+                Ps[(m0 + kq * 4 + i) * TLD + nb * 16 + r] = ds;
+                if (p.dS && gi < p.n && j >= p.nnull && j < p.nkt) p.dS[((long)sh * p.n + gi) * nreal + (j - p.nnull)] = ds;
+            }
+        // this wave's 16 rows of Ps are its own: no workgroup barrier needed before reading them back
+        mma64(Ps, TLD, 1, Ks, 1, TLD, accQ, m0, lane);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gi = i0 + m0 + kq * 4 + i;
+            if (gi < p.n) p.dQh[((long)sh * p.n + gi) * 64 + nb * 16 + r] = accQ[nb][i];
+        }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Qs = sm; float* dOs = sm + TSZ; float* Ks = sm + 2 * TSZ; float* Vs = sm + 3 * TSZ; float* Ps = sm + 4 * TSZ; float* Ss = sm + 5 * TSZ;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
+    const int nkt_tiles = (p.nkt + 63) / 64;
+    const int kt = blockIdx.x % nkt_tiles, sh = blockIdx.x / nkt_tiles, h = sh % p.heads, s = sh / p.heads;
+    const int j0 = kt * 64, m0 = wv * 16;
+    load_tile(Ks, p.Kh + (long)sh * p.nkt * 64, j0, p.nkt);
+    load_tile(Vs, p.Vh + (long)sh * p.nkt * 64, j0, p.nkt);
+    f32x4 accK[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    f32x4 accV[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    const int nqt = (p.n + 63) / 64;
+    for (int qt = 0; qt < nqt; ++qt) {
+        const int i0 = qt * 64;
+        __syncthreads();                                          // the previous iteration's readers of Qs / dOs / Ps / Ss are done
+        load_tile(Qs, p.Qh + (long)sh * p.n * 64, i0, p.n);
+        load_tile_rows(dOs, p.dO + (long)s * p.n * p.lddo + h * 64, p.lddo, i0, p.n);
+        __syncthreads();
+        f32x4 accS[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+        f32x4 accP[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+        mma64(Qs, TLD, 1, Ks, TLD, 1, accS, m0, lane);
+        mma64(dOs, TLD, 1, Vs, TLD, 1, accP, m0, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gi = i0 + m0 + kq * 4 + i;
+            const float lse = gi < p.n ? p.lse[(long)sh * p.n + gi] : 0.f, Dr = gi < p.n ? p.Drow[(long)sh * p.n + gi] : 0.f;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                float sc, pr = 0.f;
+                if (score(p, s, h, gi, j0 + nb * 16 + r, accS[nb][i], sc)) pr = __expf(sc - lse);
+                Ps[(m0 + kq * 4 + i) * TLD + nb * 16 + r] = pr;
+                Ss[(m0 + kq * 4 + i) * TLD + nb * 16 + r] = pr * (accP[nb][i] - Dr);
+            }
+        }
+        __syncthreads();
+        // rows of the results = this wave's 16 keys; contraction over the 64 query rows of the tile (transposed reads of Ps / Ss)
+        mma64(Ps, 1, TLD, dOs, 1, TLD, accV, m0, lane);
+        mma64(Ss, 1, TLD, Qs, 1, TLD, accK, m0, lane);
+    }
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gj = j0 + m0 + kq * 4 + i;
+            if (gj < p.nkt) {
+                p.dKh[((long)sh * p.nkt + gj) * 64 + nb * 16 + r] = accK[nb][i];
+                p.dVh[((long)sh * p.nkt + gj) * 64 + nb * 16 + r] = accV[nb][i];
+            }
+        }
+}
+
+}  // namespace pk
+
+using namespace pk;
+
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int pk_attn_train_prep(const float* q, long ldq, const float* kv, long ldkv, const float* null_kv, const float* q_scale, const float* k_scale,
+                                  float scale, float* Qh, float* Kh, float* Vh, int S, int heads, int n, int n_kv, int nnull, void* stream) {
+    if (!q || !kv || !q_scale || !k_scale || !Qh || !Kh || !Vh || S <= 0 || heads <= 0 || n <= 0 || n_kv <= 0 || nnull < 0 || (nnull > 0 && !null_kv)) return PK_EINVAL;
+    const long tasks = (long)S * heads * (n + nnull + n_kv);
+    long blocks = (tasks + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(attn_train_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, STREAM(stream), q, ldq, kv, ldkv, null_kv, q_scale, k_scale, scale, Qh, Kh, Vh,
+                       S, heads, n, n_kv, nnull, tasks);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+// pq / pk: (PK_ATTN_PREP_BWD_PARTS = 1024, 64) partials of dq_scale / dk_scale (finish with pk_colsum); dnull (heads, 2 nnull, 64) or null
+extern "C" int pk_attn_train_prep_bwd(const float* q, long ldq, const float* kv, long ldkv, const float* null_kv, const float* q_scale, const float* k_scale,
+                                      float scale, const float* dQh, const float* dKh, const float* dVh, float* dq, long lddq, float* dkv, long lddkv,
+                                      float* pq, float* pk_, float* dnull, int S, int heads, int n, int n_kv, int nnull, void* stream) {
+    if (!q || !kv || !q_scale || !k_scale || !dQh || !dKh || !dVh || !dq || !dkv || !pq || !pk_ || S <= 0 || heads <= 0 || n <= 0 || n_kv <= 0 || nnull < 0 ||
+        (nnull > 0 && (!null_kv || !dnull))) return PK_EINVAL;
+    const long tasks = (long)S * heads * (n + nnull + n_kv);
+    hipStream_t s = STREAM(stream);
+    hipLaunchKernelGGL(attn_train_prep_bwd_kernel, dim3(1024), dim3(256), 0, s, q, ldq, kv, ldkv, null_kv, q_scale, k_scale, scale, dQh, dKh, dVh,
+                       dq, lddq, dkv, lddkv, pq, pk_, S, heads, n, n_kv, nnull, tasks);
+    if (nnull > 0)
+        hipLaunchKernelGGL(null_kv_bwd_kernel, dim3(heads * nnull), dim3(64), 0, s, null_kv, k_scale, dKh, dVh, dnull, S, heads, nnull + n_kv, nnull);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+// O: the forward output (M = S n rows, ldo elements per row; o_bf16 = 1: bf16), dO its gradient (f32).  bias (heads, n, n_kv) / kmask (S, n_kv)
+// cover the REAL keys (the nnull leading null keys carry no bias and are never masked, attention.py:151-158).  dS (S heads, n, n_kv) optional.
+// lse / Drow: (S heads n) f32 scratch
+extern "C" int pk_attn_bwd(const float* Qh, const float* Kh, const float* Vh, const void* O, long ldo, int o_bf16, const float* dO, long lddo,
+                           const float* bias, const unsigned char* kmask, float* dQh, float* dKh, float* dVh, float* dS, float* lse, float* Drow,
+                           int S, int heads, int n, int n_kv, int nnull, void* stream) {
+    if (!Qh || !Kh || !Vh || !O || !dO || !dQh || !dKh || !dVh || !lse || !Drow || S <= 0 || heads <= 0 || n <= 0 || n_kv <= 0 || nnull < 0) return PK_EINVAL;
+    if (!al16(Qh) || !al16(Kh) || !al16(Vh) || !al16(dO) || (lddo & 3)) return PK_EALIGN;
+    AttnBwdArgs p{Qh, Kh, Vh, O, ldo, o_bf16, dO, lddo, bias, kmask, dQh, dKh, dVh, dS, lse, Drow, S, heads, n, nnull + n_kv, nnull};
+    hipStream_t s = STREAM(stream);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * TSZ * 4) != hipSuccess) return PK_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * TSZ * 4) != hipSuccess) return PK_ELAUNCH;
+        attr_done = true;
+    }
+    const int nqt = (n + 63) / 64, nktt = (p.nkt + 63) / 64;
+    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3((unsigned)((long)S * heads * nqt)), dim3(256), 5 * TSZ * 4, s, p);
+    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3((unsigned)((long)S * heads * nktt)), dim3(256), 6 * TSZ * 4, s, p);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}

@@ -1,0 +1,521 @@
+// Backward kernels of the MaskGit / TokenCritic trunk (the training step of phenaki_pytorch.py:562-687 under autograd;
+// what each one differentiates is cited at the kernel).  Everything here except the operand packer is HBM / latency bound elementwise or
+// row-reduction work; the matrix products of the backward pass are pk_gemm calls on operands laid down by pk_pack (host: train.py).
+// Activations and gradients are f32 in HBM; reductions over rows are two-stage (per-block partials + pk_colsum) so that every gradient
+// is bit-reproducible run to run -- the two exceptions (token-embedding and position-bias scatter) say so.
+#include "common.hpp"
+
+namespace pk {
+
+#define STREAM(s) reinterpret_cast<hipStream_t>(s)
+static inline int nblocks(long total) { long b = (total + 255) / 256; return (int)(b < 65535 ? (b > 0 ? b : 1) : 65535); }
+
+// ---- pk_pack: f32 matrix -> GEMM operand image, optionally transposed, K zero-padded to the k-tile -------------------------------
+// out[r][k] = (TR ? src[k][r] : src[r][k]) for k < K, 0 for K <= k < Kp; rows (optional) gathers SOURCE rows (src[rows[k]][r] / src[rows[r]][k]).   The dW product of a Linear, dW = dY^T X, takes BOTH its operands
+// through this kernel (A = dY^T, "W" = X^T: the contraction index of pk_gemm is the contiguous one), dX = dY W takes W^T.
+template <typename TO, bool TR>
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src, long lds_, const int* __restrict__ rows, int R, int K, int Kp,
+                                                   TO* __restrict__ out, long ldo) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, k0 = blockIdx.x * 64, t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (TR) {
+            const int kk = (t >> 4) + 16 * i, rr = (t & 15) * 4;
+            const int k = k0 + kk, r = r0 + rr;
+            const long sk = (k < K) ? (rows ? rows[k] : k) : 0;          // source row (optionally gathered)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tile[rr + j][kk] = (k < K && r + j < R) ? src[sk * lds_ + r + j] : 0.f;
+        } else {
+            const int rr = (t >> 4) + 16 * i, kk = (t & 15) * 4;
+            const int k = k0 + kk, r = r0 + rr;
+            const long sr = (r < R) ? (rows ? rows[r] : r) : 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tile[rr][kk + j] = (r < R && k + j < K) ? src[sr * lds_ + k + j] : 0.f;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rr = (t >> 4) + 16 * i, kk = (t & 15) * 4;
+        const int r = r0 + rr, k = k0 + kk;
+        if (r < R && k < Kp) store4(out + (long)r * ldo + k, f32x4{tile[rr][kk], tile[rr][kk + 1], tile[rr][kk + 2], tile[rr][kk + 3]});
+    }
+}
+
+// ---- pk_colsum: out[c] (+)= scale * sum_r src[r][c], two deterministic stages -------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ src, long ld, int M, int N, float* __restrict__ part, int rpb) {
+    __shared__ float red[4][64];
+    const int t = threadIdx.x, c = blockIdx.x * 64 + (t & 63), rl = t >> 6;
+    const int rb = blockIdx.y * rpb, re = min(M, rb + rpb);
+    float a = 0.f;
+    if (c < N)
+        for (int r = rb + rl; r < re; r += 4) a += src[(long)r * ld + c];
+    red[rl][t & 63] = a;
+    __syncthreads();
+    if (rl == 0 && c < N) part[(long)blockIdx.y * N + c] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int P, int N, float scale, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += part[(long)p * N + c];
+    out[c] = accumulate ? out[c] + scale * s : scale * s;
+}
+
+// ---- LayerNorm backward (attention.py:29-36 gamma-only LayerNorm and nn.LayerNorm of the feed-forward, attention.py:47) ------------
+// y = xhat * gamma + beta, xhat = (x - mean) * rstd:   g = dy * gamma,  dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ add],
+// dgamma = sum_rows dy * xhat, dbeta = sum_rows dy  (per-block partials; pk_colsum finishes them).  One wave per row, statistics recomputed.
+template <int VMAX>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                     const float* __restrict__ dy, long lddy, const float* __restrict__ add, long ldadd,
+                                                     float* __restrict__ dx, long lddx, float* __restrict__ pg, float* __restrict__ pb,
+                                                     float eps, int M, int D, int rpb) {
+    __shared__ f32x4 red[4][VMAX * 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nv = D >> 2;
+    f32x4 ag[VMAX], ab[VMAX], gm[VMAX];
+#pragma unroll
+    for (int i = 0; i < VMAX; ++i) {
+        ag[i] = f32x4{0, 0, 0, 0};
+        ab[i] = ag[i];
+        const int c = lane + i * 64;
+        gm[i] = c < nv ? *reinterpret_cast<const f32x4*>(gamma + c * 4) : ag[i];
+    }
+    const int rb = blockIdx.x * rpb, re = min(M, rb + rpb);
+    for (int row = rb + wv; row < re; row += 4) {
+        const float* xr = x + (long)row * ldx;
+        const float* dr = dy + (long)row * lddy;
+        f32x4 v[VMAX], g[VMAX];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VMAX; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+                v[i] = *reinterpret_cast<const f32x4*>(xr + c * 4);
+                g[i] = *reinterpret_cast<const f32x4*>(dr + c * 4);
+                s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            }
+        }
+        const float mean = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VMAX; ++i)
+            if (lane + i * 64 < nv) {
+                v[i] -= mean;
+                q += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VMAX; ++i)
+            if (lane + i * 64 < nv) {
+                v[i] *= rstd;                                        // xhat
+                ab[i] += g[i];
+                ag[i] += g[i] * v[i];
+                g[i] *= gm[i];
+                c1 += (g[i][0] + g[i][1]) + (g[i][2] + g[i][3]);
+                c2 += (g[i][0] * v[i][0] + g[i][1] * v[i][1]) + (g[i][2] * v[i][2] + g[i][3] * v[i][3]);
+            }
+        c1 = wave_sum(c1) / (float)D;
+        c2 = wave_sum(c2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < VMAX; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+                f32x4 o = (g[i] - c1 - v[i] * c2) * rstd;
+                if (add) o += *reinterpret_cast<const f32x4*>(add + (long)row * ldadd + c * 4);
+                *reinterpret_cast<f32x4*>(dx + (long)row * lddx + c * 4) = o;
+            }
+        }
+    }
+    // cross-wave fold of the column sums, then one partial row per block
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && !pb) break;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < VMAX; ++i) red[wv][lane + i * 64] = pass == 0 ? ag[i] : ab[i];
+        __syncthreads();
+        float* dst = pass == 0 ? pg : pb;
+        for (int c = threadIdx.x; c < nv; c += 256) {
+            const f32x4 s4 = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+            *reinterpret_cast<f32x4*>(dst + (long)blockIdx.x * D + c * 4) = s4;
+        }
+    }
+}
+
+// ---- GEGLU (attention.py:40-43: x, gate = chunk(2); gelu(gate) * x) forward on stored pre-activations, and its backward ---------------
+__device__ __forceinline__ float gelu_grad(float g) {
+    return 0.5f * (1.0f + erff(g * 0.70710678118654752440f)) + g * 0.3989422804014327f * __expf(-0.5f * g * g);
+}
+__global__ __launch_bounds__(256) void geglu_kernel(const float* __restrict__ h, long ldh, int goff, float* __restrict__ out, long ldo, int M, int F4, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % F4) * 4;
+        const long r = idx / F4;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(h + r * ldh + c), gv = *reinterpret_cast<const f32x4*>(h + r * ldh + goff + c);
+        *reinterpret_cast<f32x4*>(out + r * ldo + c) = f32x4{xv[0] * gelu_erf(gv[0]), xv[1] * gelu_erf(gv[1]), xv[2] * gelu_erf(gv[2]), xv[3] * gelu_erf(gv[3])};
+    }
+}
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const float* __restrict__ h, long ldh, int goff, const float* __restrict__ dout, long ldd,
+                                                        float* __restrict__ dh, long lddh, int M, int F4, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % F4) * 4;
+        const long r = idx / F4;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(h + r * ldh + c), gv = *reinterpret_cast<const f32x4*>(h + r * ldh + goff + c);
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dout + r * ldd + c);
+        f32x4 dxv, dgv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dxv[j] = dv[j] * gelu_erf(gv[j]);
+            dgv[j] = dv[j] * xv[j] * gelu_grad(gv[j]);
+        }
+        *reinterpret_cast<f32x4*>(dh + r * lddh + c) = dxv;
+        *reinterpret_cast<f32x4*>(dh + r * lddh + goff + c) = dgv;
+    }
+}
+
+// ---- LeakyReLU backward from the activation's OUTPUT (the position-bias MLP, attention.py:243-247: sign(y) == sign(pre-activation)) ---
+__global__ __launch_bounds__(256) void leaky_bwd_kernel(const float* __restrict__ y, long ldy, const float* __restrict__ dy, long lddy,
+                                                        float* __restrict__ dz, long lddz, int N, float slope, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % N);
+        const long r = idx / N;
+        dz[r * lddz + c] = dy[r * lddy + c] * (y[r * ldy + c] > 0.f ? 1.0f : slope);
+    }
+}
+
+// ---- PEG backward (attention.py:57-85 + the residual of :323: y = x + dsconv(pad(x)) + b) ------------------------------------------------
+// dx = dy + sum_taps w[tap] * dy[shifted the other way];  tfront = 2 causal / 1 centred frame padding, as in pk_peg
+__global__ __launch_bounds__(256) void peg_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ wt, float* __restrict__ dx,
+                                                      int B, int T, int H, int W, int D, int tfront, long total) {
+    const int dv = D >> 2;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % dv) * 4;
+        long p = idx / dv;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H); p /= H;
+        const int t = (int)(p % T); const int b = (int)(p / T);
+        f32x4 acc = *reinterpret_cast<const f32x4*>(dy + ((((long)b * T + t) * H + h) * W + w) * D + c);
+        for (int dt = 0; dt < 3; ++dt) {
+            const int ts = t - (dt - tfront);                       // the output position whose tap dt read input frame t
+            if (ts < 0 || ts >= T) continue;
+            for (int dh = 0; dh < 3; ++dh) {
+                const int hs = h - (dh - 1);
+                if (hs < 0 || hs >= H) continue;
+                for (int dw = 0; dw < 3; ++dw) {
+                    const int ws = w - (dw - 1);
+                    if (ws < 0 || ws >= W) continue;
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(dy + ((((long)b * T + ts) * H + hs) * W + ws) * D + c);
+                    const f32x4 k = *reinterpret_cast<const f32x4*>(wt + (long)((dt * 3 + dh) * 3 + dw) * D + c);
+                    acc += g * k;
+                }
+            }
+        }
+        *reinterpret_cast<f32x4*>(dx + idx * 4) = acc;
+    }
+}
+// dW[tap][d] = sum_pos dy[pos][d] * x[pos + tap offset][d] as per-block partials part[block][27][D]
+__global__ __launch_bounds__(256) void peg_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
+                                                        int B, int T, int H, int W, int D, int tfront, long rows, int rpb) {
+    __shared__ f32x4 red[256];
+    const int dv = D >> 2, nl = 256 / dv;
+    const int cq = threadIdx.x % dv, rl = threadIdx.x / dv, c = cq * 4;
+    f32x4 acc[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] = f32x4{0, 0, 0, 0};
+    const long rb = (long)blockIdx.x * rpb, re = rb + rpb < rows ? rb + rpb : rows;
+    if (rl < nl)
+        for (long pos = rb + rl; pos < re; pos += nl) {
+            long p = pos;
+            const int w = (int)(p % W); p /= W;
+            const int h = (int)(p % H); p /= H;
+            const int t = (int)(p % T); const int b = (int)(p / T);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(dy + pos * D + c);
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) {
+                const int ts = t + dt - tfront;
+#pragma unroll
+                for (int dh = 0; dh < 3; ++dh) {
+                    const int hs = h + dh - 1;
+#pragma unroll
+                    for (int dw = 0; dw < 3; ++dw) {
+                        const int ws = w + dw - 1;
+                        if (ts >= 0 && ts < T && hs >= 0 && hs < H && ws >= 0 && ws < W)
+                            acc[(dt * 3 + dh) * 3 + dw] += g * *reinterpret_cast<const f32x4*>(x + ((((long)b * T + ts) * H + hs) * W + ws) * D + c);
+                    }
+                }
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        __syncthreads();
+        red[threadIdx.x] = acc[k];
+        __syncthreads();
+        if (rl == 0) {
+            f32x4 s = red[cq];
+            for (int l = 1; l < nl; ++l) s += red[l * dv + cq];
+            *reinterpret_cast<f32x4*>(part + ((long)blockIdx.x * 27 + k) * D + c) = s;
+        }
+    }
+}
+
+// ---- token + position embedding backward (phenaki_pytorch.py:194-199: x = tok[ids] + pos[arange]; x = x * alpha + x.detach() * (1 - alpha))
+// dpos[p] = alpha * sum_s dy[s, p] (deterministic);  dtok[id] += alpha * dy[row] by f32 atomics: the mask id collects thousands of rows, so
+// the summation ORDER (not the set of terms) of this one gradient varies run to run
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dy, const long long* __restrict__ ids, float alpha,
+                                                        float* __restrict__ dtok, float* __restrict__ dpos, int S, int n, int D, long total) {
+    const int dv = D >> 2;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % dv) * 4;
+        const int p = (int)(idx / dv);
+        f32x4 a = f32x4{0, 0, 0, 0};
+        for (int s = 0; s < S; ++s) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(dy + ((long)s * n + p) * D + c) * alpha;
+            a += g;
+            float* dst = dtok + ids[(long)s * n + p] * D + c;
+            atomicAdd(dst, g[0]); atomicAdd(dst + 1, g[1]); atomicAdd(dst + 2, g[2]); atomicAdd(dst + 3, g[3]);
+        }
+        *reinterpret_cast<f32x4*>(dpos + (long)p * D + c) = a;
+    }
+}
+
+// ---- continuous position bias: gather of the relative-position table into (heads, n, n) and its adjoint (attention.py:257-275) ---------
+// bias[h][i][j] = tab[code[i] - code[j] + off][h]  (tab rows = relative positions, the MLP's output layout)
+__global__ __launch_bounds__(256) void bias_gather_kernel(const float* __restrict__ tab, int ldt, const int* __restrict__ code, int off, float* __restrict__ out,
+                                                          int heads, int n, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int j = (int)(idx % n);
+        const int i = (int)((idx / n) % n);
+        const int h = (int)(idx / ((long)n * n));
+        out[idx] = tab[(long)(code[i] - code[j] + off) * ldt + h];
+    }
+}
+__global__ __launch_bounds__(256) void bias_scatter_kernel(const float* __restrict__ dbias, const int* __restrict__ code, int off, float* __restrict__ dtab, int ldt,
+                                                           int heads, int n, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int j = (int)(idx % n);
+        const int i = (int)((idx / n) % n);
+        const int h = (int)(idx / ((long)n * n));
+        atomicAdd(dtab + (long)(code[i] - code[j] + off) * ldt + h, dbias[idx]);
+    }
+}
+
+// ---- dst[rows[m]] = src[m] (rows of the masked positions back into the full (b n, D) gradient; dst zeroed by the caller) ----------------------
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ src, long lds_, const int* __restrict__ rows, float* __restrict__ dst, long ldd,
+                                                           int D4, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % D4) * 4;
+        const long m = idx / D4;
+        *reinterpret_cast<f32x4*>(dst + (long)rows[m] * ldd + c) = *reinterpret_cast<const f32x4*>(src + m * lds_ + c);
+    }
+}
+
+// ---- out[e] = sum_s src[s][e] (the position bias is shared by every sequence of the batch: dbias = sum_s dS_s) -----------------------------
+__global__ __launch_bounds__(256) void sum_batch_kernel(const float* __restrict__ src, long stride, int S, float* __restrict__ out, long E4) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < E4; idx += (long)gridDim.x * 256) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(src + idx * 4);
+        for (int s = 1; s < S; ++s) a += *reinterpret_cast<const f32x4*>(src + (long)s * stride + idx * 4);
+        *reinterpret_cast<f32x4*>(out + idx * 4) = a;
+    }
+}
+
+// ---- critic head + BCE-with-logits, forward and backward in one pass (phenaki_pytorch.py:246-249 / :306-336 to_pred, :673-676) --------------
+// logit = e . w + b;  loss_row = max(z, 0) - z y + log(1 + exp(-|z|));  dz = (sigmoid(z) - y) * scale;  de = dz * w;  dw / db as block partials
+__global__ __launch_bounds__(256) void bce_head_kernel(const float* __restrict__ e, long lde, const float* __restrict__ w, const float* __restrict__ b,
+                                                       const float* __restrict__ labels, float scale, float* __restrict__ logits, float* __restrict__ loss_rows,
+                                                       float* __restrict__ de, long ldde, float* __restrict__ pw, float* __restrict__ pb, int M, int D, int rpb) {
+    __shared__ f32x4 red[4][256];
+    __shared__ float redb[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nv = D >> 2;
+    f32x4 aw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aw[i] = f32x4{0, 0, 0, 0};
+    float abias = 0.f;
+    const int rb = blockIdx.x * rpb, re = min(M, rb + rpb);
+    for (int row = rb + wv; row < re; row += 4) {
+        f32x4 v[4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + i * 64;
+            if (c < nv) {
+                v[i] = *reinterpret_cast<const f32x4*>(e + (long)row * lde + c * 4);
+                const f32x4 wv4 = *reinterpret_cast<const f32x4*>(w + c * 4);
+                s += (v[i][0] * wv4[0] + v[i][1] * wv4[1]) + (v[i][2] * wv4[2] + v[i][3] * wv4[3]);
+            }
+        }
+        const float z = wave_sum(s) + (b ? b[0] : 0.f);
+        const float y = labels ? labels[row] : 0.f;
+        const float dz = labels ? (1.0f / (1.0f + __expf(-z)) - y) * scale : 0.f;
+        if (lane == 0) {
+            if (logits) logits[row] = z;
+            if (loss_rows) loss_rows[row] = fmaxf(z, 0.f) - z * y + log1pf(__expf(-fabsf(z)));
+        }
+        abias += dz;
+        if (de) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = lane + i * 64;
+                if (c < nv) {
+                    aw[i] += v[i] * dz;
+                    *reinterpret_cast<f32x4*>(de + (long)row * ldde + c * 4) = *reinterpret_cast<const f32x4*>(w + c * 4) * dz;
+                }
+            }
+        }
+    }
+    if (!pw) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wv][lane + i * 64] = aw[i];
+    if (lane == 0) redb[wv] = abias;
+    __syncthreads();
+    for (int c = threadIdx.x; c < nv; c += 256)
+        *reinterpret_cast<f32x4*>(pw + (long)blockIdx.x * D + c * 4) = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    if (threadIdx.x == 0) pb[blockIdx.x] = (redb[0] + redb[1]) + (redb[2] + redb[3]);
+}
+
+}  // namespace pk
+
+using namespace pk;
+
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// kind: 0 f32, 1 bf16, 2 split-bf16 image (bf16x3p).  out has R rows of ldo elements; columns [0, K) are filled from src, [K, Kp) zeroed
+extern "C" int pk_pack(const float* src, long lds_, const int* rows, int R, int K, int transpose, void* out, long ldo, int Kp, int kind, void* stream) {
+    if (!src || !out || R <= 0 || K <= 0 || Kp < K || ldo < Kp || kind < 0 || kind > 2) return PK_EINVAL;
+    if ((Kp & 3) || (ldo & 3) || (reinterpret_cast<uintptr_t>(out) & (kind == 2 ? 127 : 15)) || (kind == 2 && ((ldo & 31) || (Kp & 31)))) return PK_EALIGN;
+    const dim3 grid((Kp + 63) / 64, (R + 63) / 64);
+    hipStream_t s = STREAM(stream);
+#define PK_PACK(TO, TR) hipLaunchKernelGGL((pack_kernel<TO, TR>), grid, dim3(256), 0, s, src, lds_, rows, R, K, Kp, reinterpret_cast<TO*>(out), ldo)
+    if (kind == 0) { if (transpose) PK_PACK(float, true); else PK_PACK(float, false); }
+    else if (kind == 1) { if (transpose) PK_PACK(bf16, true); else PK_PACK(bf16, false); }
+    else { if (transpose) PK_PACK(bf16x3p, true); else PK_PACK(bf16x3p, false); }
+#undef PK_PACK
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+// out[c] (+)= scale * sum_r src[r][c];  work: >= P * N floats, P = pk_colsum_parts(M)
+extern "C" int pk_colsum_parts(int M) { int p = (M + 63) / 64; return p < 1 ? 1 : (p > 256 ? 256 : p); }
+extern "C" int pk_colsum(const float* src, long ld, int M, int N, float scale, float* out, int accumulate, float* work, void* stream) {
+    if (!src || !out || !work || M <= 0 || N <= 0) return PK_EINVAL;
+    const int P = pk_colsum_parts(M), rpb = (M + P - 1) / P;
+    hipStream_t s = STREAM(stream);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, P), dim3(256), 0, s, src, ld, M, N, work, rpb);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, work, P, N, scale, out, accumulate);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+// dx = [add +] LayerNorm backward; pg / pb (pb may be null: the gamma-only LayerNorm's beta is a buffer): (pk_ln_bwd_parts(M), D) partials
+extern "C" int pk_ln_bwd_parts(int M) { int p = (M + 31) / 32; return p < 1 ? 1 : (p > 512 ? 512 : p); }
+extern "C" int pk_layernorm_bwd(const float* x, long ldx, const float* gamma, const float* dy, long lddy, const float* add, long ldadd,
+                                float* dx, long lddx, float* pg, float* pb, float eps, int M, int D, void* stream) {
+    if (!x || !gamma || !dy || !dx || !pg || M <= 0 || D <= 0 || D > 1024) return PK_EINVAL;
+    if ((D & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3) || (ldadd & 3) || !al16(x) || !al16(dy) || !al16(dx) || !al16(gamma) || (add && !al16(add)) || !al16(pg) || (pb && !al16(pb))) return PK_EALIGN;
+    const int P = pk_ln_bwd_parts(M), rpb = (M + P - 1) / P;
+    hipStream_t s = STREAM(stream);
+    if (D <= 512) hipLaunchKernelGGL((ln_bwd_kernel<2>), dim3(P), dim3(256), 0, s, x, ldx, gamma, dy, lddy, add, ldadd, dx, lddx, pg, pb, eps, M, D, rpb);
+    else hipLaunchKernelGGL((ln_bwd_kernel<4>), dim3(P), dim3(256), 0, s, x, ldx, gamma, dy, lddy, add, ldadd, dx, lddx, pg, pb, eps, M, D, rpb);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+// h (M, >= goff + F) f32: value columns [0, F), gate columns [goff, goff + F);  F % 4 == 0
+extern "C" int pk_geglu(const float* h, long ldh, int goff, float* out, long ldo, int M, int F, void* stream) {
+    if (!h || !out || M <= 0 || F <= 0 || goff < F) return PK_EINVAL;
+    if ((F & 3) || (goff & 3) || (ldh & 3) || (ldo & 3) || !al16(h) || !al16(out)) return PK_EALIGN;
+    const long total = (long)M * (F >> 2);
+    hipLaunchKernelGGL(geglu_kernel, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), h, ldh, goff, out, ldo, M, F >> 2, total);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+extern "C" int pk_geglu_bwd(const float* h, long ldh, int goff, const float* dout, long ldd, float* dh, long lddh, int M, int F, void* stream) {
+    if (!h || !dout || !dh || M <= 0 || F <= 0 || goff < F) return PK_EINVAL;
+    if ((F & 3) || (goff & 3) || (ldh & 3) || (ldd & 3) || (lddh & 3) || !al16(h) || !al16(dout) || !al16(dh)) return PK_EALIGN;
+    const long total = (long)M * (F >> 2);
+    hipLaunchKernelGGL(geglu_bwd_kernel, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), h, ldh, goff, dout, ldd, dh, lddh, M, F >> 2, total);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+extern "C" int pk_leaky_bwd(const float* y, long ldy, const float* dy, long lddy, float* dz, long lddz, int M, int N, float slope, void* stream) {
+    if (!y || !dy || !dz || M <= 0 || N <= 0) return PK_EINVAL;
+    const long total = (long)M * N;
+    hipLaunchKernelGGL(leaky_bwd_kernel, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), y, ldy, dy, lddy, dz, lddz, N, slope, total);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+// dx = dy + transposed stencil of dy;  part: (pk_peg_wgrad_parts(rows), 27, D) partial tap gradients (finish with pk_colsum over 27 * D columns)
+extern "C" int pk_peg_wgrad_parts(long rows) { long p = (rows + 127) / 128; return (int)(p < 1 ? 1 : (p > 512 ? 512 : p)); }
+extern "C" int pk_peg_bwd(const float* dy, const float* x, const float* wt, float* dx, float* part, int B, int T, int H, int W, int D, int causal, void* stream) {
+    if (!dy || !wt || !dx || B <= 0 || T <= 0 || H <= 0 || W <= 0 || D <= 0 || (part && !x)) return PK_EINVAL;
+    const int dv = D >> 2;
+    if ((D & 3) || !al16(dy) || !al16(wt) || !al16(dx) || (x && !al16(x)) || (part && !al16(part))) return PK_EALIGN;
+    if (part && (dv > 256 || 256 % dv)) return PK_EINVAL;
+    hipStream_t s = STREAM(stream);
+    const long rows = (long)B * T * H * W, total = rows * dv;
+    hipLaunchKernelGGL(peg_bwd_kernel, dim3(nblocks(total)), dim3(256), 0, s, dy, wt, dx, B, T, H, W, D, causal ? 2 : 1, total);
+    if (part) {
+        const int P = pk_peg_wgrad_parts(rows);
+        const int rpb = (int)((rows + P - 1) / P);
+        hipLaunchKernelGGL(peg_wgrad_kernel, dim3(P), dim3(256), 0, s, dy, x, part, B, T, H, W, D, causal ? 2 : 1, rows, rpb);
+    }
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+// dtok must be zeroed by the caller (rows the batch does not touch stay zero); dpos (n, D) is overwritten
+extern "C" int pk_embed_bwd(const float* dy, const long long* ids, float alpha, float* dtok, float* dpos, int S, int n, int D, void* stream) {
+    if (!dy || !ids || !dtok || !dpos || S <= 0 || n <= 0 || D <= 0) return PK_EINVAL;
+    if ((D & 3) || !al16(dy) || !al16(dpos)) return PK_EALIGN;
+    const long total = (long)n * (D >> 2);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), dy, ids, alpha, dtok, dpos, S, n, D, total);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+extern "C" int pk_bias_gather(const float* tab, int ldt, const int* code, int off, float* out, int heads, int n, void* stream) {
+    if (!tab || !code || !out || heads <= 0 || n <= 0 || ldt < heads) return PK_EINVAL;
+    const long total = (long)heads * n * n;
+    hipLaunchKernelGGL(bias_gather_kernel, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), tab, ldt, code, off, out, heads, n, total);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+// dtab must be zeroed by the caller; f32 atomics (up to n collisions per entry: summation order varies run to run)
+extern "C" int pk_bias_scatter(const float* dbias, const int* code, int off, float* dtab, int ldt, int heads, int n, void* stream) {
+    if (!dbias || !code || !dtab || heads <= 0 || n <= 0 || ldt < heads) return PK_EINVAL;
+    const long total = (long)heads * n * n;
+    hipLaunchKernelGGL(bias_scatter_kernel, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), dbias, code, off, dtab, ldt, heads, n, total);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+extern "C" int pk_scatter_rows(const float* src, long lds_, const int* rows, float* dst, long ldd, int M, int D, void* stream) {
+    if (!src || !rows || !dst || M <= 0 || D <= 0) return PK_EINVAL;
+    if ((D & 3) || (lds_ & 3) || (ldd & 3) || !al16(src) || !al16(dst)) return PK_EALIGN;
+    const long total = (long)M * (D >> 2);
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), src, lds_, rows, dst, ldd, D >> 2, total);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+extern "C" int pk_sum_batch(const float* src, long stride, int S, float* out, long E, void* stream) {
+    if (!src || !out || S <= 0 || E <= 0) return PK_EINVAL;
+    if ((E & 3) || (stride & 3) || !al16(src) || !al16(out)) return PK_EALIGN;
+    hipLaunchKernelGGL(sum_batch_kernel, dim3(nblocks(E >> 2)), dim3(256), 0, STREAM(stream), src, stride, S, out, E >> 2);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+// labels null: logits only (inference-style forward).  pw (pk_ln_bwd_parts(M), D) / pb (pk_ln_bwd_parts(M),) partials of dw / db
+extern "C" int pk_bce_head(const float* e, long lde, const float* w, const float* b, const float* labels, float scale, float* logits, float* loss_rows,
+                           float* de, long ldde, float* pw, float* pb, int M, int D, void* stream) {
+    if (!e || !w || M <= 0 || D <= 0 || D > 1024 || (de && !labels) || (pw && (!pb || !de))) return PK_EINVAL;
+    if ((D & 3) || (lde & 3) || (ldde & 3) || !al16(e) || !al16(w) || (de && !al16(de)) || (pw && !al16(pw))) return PK_EALIGN;
+    const int P = pk_ln_bwd_parts(M), rpb = (M + P - 1) / P;
+    hipLaunchKernelGGL(bce_head_kernel, dim3(P), dim3(256), 0, STREAM(stream), e, lde, w, b, labels, scale, logits, loss_rows, de, ldde, pw, pb, M, D, rpb);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}

@@ -356,10 +356,14 @@ class Phenaki(PackedModule):
         return video.squeeze(2)
 
     def forward(self, *args, **kwargs):
-        """phenaki_pytorch.py:562-687, value only -- see `objective_value`.  Where a caller could expect gradients (grad mode on,
-        trainable parameters) the returned loss is attached to a node whose backward raises: `loss = phenaki(...)` keeps working as
-        in the reference, `loss.backward()` fails loudly instead of silently training nothing."""
-        return value_without_graph(self, 'Phenaki.forward', self.objective_value(*args, **kwargs))
+        """phenaki_pytorch.py:562-687.  With grad mode on and trainable MaskGit / critic parameters this is the training step: the loss
+        carries an autograd graph whose nodes are the MI355X forward / backward kernels (train.py::phenaki_loss), `loss.backward()` fills
+        the .grad of the MaskGit and critic parameters (the C-ViViT and the text encoder are frozen here as in the reference, :580-598).
+        Otherwise (no_grad / eval without trainable parameters): the value only, through the fused inference kernels."""
+        if torch.is_grad_enabled() and any(p.requires_grad for m in (self.maskgit, self.critic) if exists(m) for p in m.parameters()):
+            from .train import phenaki_loss
+            return phenaki_loss(self, *args, **kwargs)
+        return self.objective_value(*args, **kwargs)
 
     @torch.no_grad()
     def objective_value(self, videos=None, *, texts=None, video_codebook_ids=None, video_frame_mask=None, text_embeds=None,

@@ -1,22 +1,45 @@
-"""First training kernel of the MI355X build: the masked-token cross entropy of the MaskGit vocabulary head,
-forward AND backward, without ever writing the (rows, 65 536) logits -- reference `F.cross_entropy(logits[mask], ids[mask])` under
-autograd, /root/reference/phenaki_pytorch/phenaki_pytorch.py:640-643 (caller phenaki_trainer.py:351-388).
+"""The training step on the MI355X kernels: `Phenaki.forward` with gradients -- reference
+/root/reference/phenaki_pytorch/phenaki_pytorch.py:562-687 under autograd (caller phenaki_trainer.py:351-388).
 
-    loss = vocab_cross_entropy(embeds, weight, bias, targets)      # embeds (M, D) = the trunk output rows of the masked positions
-    loss.backward()                                                # fills embeds.grad, weight.grad, bias.grad
+    loss = phenaki(videos, texts=...)          # grad mode on, trainable parameters -> phenaki_loss() below
+    loss.backward()                            # MaskGit (CE of the masked tokens) and critic (BCE) parameters get .grad
 
-forward : pk_vocab_sample (no noise, statistics only) + pk_vocab_ce -> per-row lse and loss; nothing of size M x V is stored.
-backward: dlogit = (softmax - onehot) / M.  The vocabulary is walked in slabs of `slab` columns: pk_gemm recomputes the slab's
-          logits, pk_ce_grad_slab turns them into g (and g^T) in place, and two more pk_gemm calls accumulate dE += g W_slab and write
-          dW_slab = g^T E; db_slab = column sums of g.  8 M V D flops in total (recompute + two gradient products); the transient
-          slab buffers (3 x M x slab) stay in the Infinity Cache.
-The rest of Phenaki.forward (trunk backward, critic BCE) has no backward kernels yet: `Phenaki.forward` still returns a value whose
-`.backward()` raises.  Compute dtype: 'fp32' | 'bf16x3' (1e-3-grade gradients) | 'bf16'.
+Every block of the trunk is ONE torch.autograd.Function whose forward and backward are calls into the C ABI (no ATen arithmetic):
+
+    _Embed          token + position embedding (+ gradient_shrink_alpha)       pk_embed            / pk_embed_bwd
+    _PEGBlock       x + dsconv(x)                                              pk_peg              / pk_peg_bwd (+ pk_colsum)
+    _AttnBlock      x + to_out(attention(norm(x) [, context]))                 pk_layernorm, pk_gemm, pk_attn_prep, pk_attn_fwd
+                                                                               / pk_attn_train_prep, pk_attn_bwd, pk_attn_train_prep_bwd,
+                                                                                 pk_pack + pk_gemm (dX, dW), pk_layernorm_bwd
+    _FFBlock        x + W2 geglu(W1 LayerNorm(x))                              pk_layernorm, pk_gemm, pk_geglu / pk_geglu_bwd, ...
+    _LayerNormFn    norm_out                                                   pk_layernorm        / pk_layernorm_bwd
+    _PositionBias   ContinuousPositionBias as (heads, n, n)                    relative-position-table MLP + pk_bias_gather / pk_bias_scatter
+    _VocabCrossEntropy   to_logits + cross entropy on the masked rows          pk_vocab_sample, pk_vocab_ce / pk_ce_grad_slab + pk_gemm
+    _BCEHead        critic to_logits / to_pred + BCE-with-logits               pk_bce_head
+
+Activations and gradients are f32 in HBM (288 GB: every block keeps what its backward needs instead of recomputing it); the GEMMs run in the
+module's compute dtype ('fp32' | 'bf16x3' | 'bf16').  Matrix products of the backward pass: dX = dY W through pk_gemm on pk_pack(W^T),
+dW = dY^T X through pk_gemm on pk_pack(dY^T) and pk_pack(X^T) (contraction over the rows, zero-padded to the k-tile).
+Limits (asserted): dropout 0 (the reference default), non-causal trunk attention (MaskGit / TokenCritic), no C-ViViT training.
 """
+import math
+
 import torch
 
 from . import _lib as L
-from .attention import pack_linear_weight, resolve_dtype, round_up
+from .attention import (Attention, FeedForwardSeq, LayerNorm, PEG, compute_dtype_of, exists, pack_linear_weight, resolve_dtype, round_up)
+
+
+def _q(dtype):
+    return 64 if dtype == L.BF16 else 32
+
+
+def _f32(shape, dev):
+    return torch.empty(shape, device=dev, dtype=torch.float32)
+
+
+def _zeros(shape, dev):
+    return torch.zeros(shape, device=dev, dtype=torch.float32)
 
 
 def _operand(x, dtype):
@@ -24,16 +47,378 @@ def _operand(x, dtype):
     return pack_linear_weight(x, dtype)
 
 
-class _VocabCrossEntropy(torch.autograd.Function):
+def pack_operand(src, dtype, *, transpose=False, side='w', rows=None, nrows=None):
+    """f32 matrix -> operand image of a pk_gemm call in compute dtype `dtype`, contraction index zero-padded to the k-tile.
+    side 'w': the weight-side image (f32 | bf16 | split-bf16 planes); side 'a': the activation side (bf16 in bf16 mode, else f32).
+    transpose: the image holds src^T.  rows (int32): gather of source rows (nrows = how many)."""
+    R0 = src.shape[0] if rows is None else nrows
+    C0 = src.shape[1]
+    R, K = (C0, R0) if transpose else (R0, C0)
+    Kp = round_up(K, _q(dtype))
+    kind = L.kind_of(dtype) if side == 'w' else (1 if dtype == L.BF16 else 0)
+    out = torch.empty((R, Kp), device=src.device, dtype=torch.bfloat16 if kind == 1 else torch.float32)
+    return L.pack(src, R, K, transpose, out, Kp, kind, rows=rows)
+
+
+def linear_fwd(dtype, x, W, *, bias=None, res=None, act=L.ACT_NONE):
+    """x (M, K) f32 @ W (N, K)^T [+ bias] [+ res] -> (M, N) f32"""
+    M, K = x.shape
+    N = W.shape[0]
+    y = _f32((M, N), x.device)
+    L.gemm(dtype, x, pack_operand(W, dtype), M, N, K, C=y, bias=bias, res=res, act=act)
+    return y
+
+
+def linear_bwd(dtype, x, W, dy, *, need_dx=True, add=None, need_dw=True, dw_out=None):
+    """gradients of y = x W^T: dx = dy W [+ add] (M, K), dW = dy^T x (N, K).  dw_out: preallocated (N, K) destination (may be a row slice)."""
+    M, K = x.shape
+    N = W.shape[0]
+    dx = dW = None
+    if need_dx:
+        dx = _f32((M, K), x.device)
+        L.gemm(dtype, dy, pack_operand(W, dtype, transpose=True), M, K, N, C=dx, res=add)
+    if need_dw:
+        Mp = round_up(M, _q(dtype))
+        dyT = pack_operand(dy, dtype, transpose=True, side='a')          # (N, Mp)
+        xT = pack_operand(x, dtype, transpose=True)                      # (K, Mp)
+        dW = dw_out if dw_out is not None else _f32((N, K), x.device)
+        L.gemm(dtype, dyT, xT, N, K, Mp, C=dW)
+    return dx, dW
+
+
+# ------------------------------------------------------------------------------------------------------------ blocks
+
+class _LayerNormFn(torch.autograd.Function):
+    """gamma-only LayerNorm (attention.py:29-36; beta is a zero buffer)"""
+
     @staticmethod
-    def forward(ctx, embeds, weight, bias, targets, dtype, slab):
+    def forward(ctx, x, gamma, beta, eps):
+        M, D = x.shape
+        y = _f32((M, D), x.device)
+        L.layernorm(x, gamma, beta, M, D, out2=y, eps=eps)
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma = ctx.saved_tensors
+        M, D = x.shape
+        dx = _f32((M, D), x.device)
+        dg, _ = L.layernorm_bwd(x, gamma.detach(), dy.contiguous(), dx, M, D, eps=ctx.eps)
+        return dx, dg, None, None
+
+
+class _FFBlock(torch.autograd.Function):
+    """x + Linear(inner, dim)(GEGLU(Linear(dim, 2 inner)(nn.LayerNorm(x))))   (attention.py:45-52 + the residual of :330)"""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w1, w2, dtype, eps):
+        M, D = x.shape
+        F = w2.shape[1]
+        Fp = round_up(F, 8)
+        dev = x.device
+        xn = _f32((M, D), dev)
+        L.layernorm(x, ln_w, ln_b, M, D, out2=xn, eps=eps)
+        # value rows [0, F) and gate rows [Fp, Fp + F) of the K-padded 2 Fp-row weight image; the pad rows stay zero -> h pad columns are 0
+        q = _q(dtype)
+        Kp = round_up(D, q)
+        kind = L.kind_of(dtype)
+        w1p = torch.zeros((2 * Fp, Kp), device=dev, dtype=torch.bfloat16 if kind == 1 else torch.float32)
+        L.pack(w1[:F], F, D, False, w1p[:F], Kp, kind)
+        L.pack(w1[F:], F, D, False, w1p[Fp:Fp + F], Kp, kind)
+        h = _f32((M, 2 * Fp), dev)
+        L.gemm(dtype, xn, w1p, M, 2 * Fp, D, C=h)
+        a = _f32((M, Fp), dev)
+        L.geglu(h, Fp, a, M, Fp)
+        y = _f32((M, D), dev)
+        L.gemm(dtype, a, pack_operand(w2, dtype), M, D, Fp, C=y, res=x)
+        ctx.save_for_backward(x, ln_w, w1, w2, xn, h, a)
+        ctx.dtype, ctx.eps, ctx.Fp = dtype, eps, Fp
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, ln_w, w1, w2, xn, h, a = ctx.saved_tensors
+        dtype, Fp = ctx.dtype, ctx.Fp
+        M, D = x.shape
+        F = w2.shape[1]
+        dev = x.device
+        dy = dy.contiguous()
+        q = _q(dtype)
+        Mp = round_up(M, q)
+        # ---- second Linear: da = dy W2 (pad columns: zero rows of the W2^T image), dW2 = dy^T a
+        w2t = torch.zeros((Fp, round_up(D, q)), device=dev, dtype=torch.bfloat16 if L.kind_of(dtype) == 1 else torch.float32)
+        L.pack(w2, F, D, True, w2t, round_up(D, q), L.kind_of(dtype))
+        da = _f32((M, Fp), dev)
+        L.gemm(dtype, dy, w2t, M, Fp, D, C=da)
+        dyT = pack_operand(dy, dtype, transpose=True, side='a')           # (D, Mp)
+        aT = pack_operand(a, dtype, transpose=True)                       # (Fp, Mp)
+        dW2 = _f32((D, F), dev)
+        L.gemm(dtype, dyT, aT, D, F, Mp, C=dW2)
+        # ---- GEGLU
+        dh = _f32((M, 2 * Fp), dev)
+        L.geglu_bwd(h, Fp, da, dh, M, Fp)
+        # ---- first Linear: dxn = dh W1 (the padded layout, transposed), dW1 = dh^T xn in two row groups (value | gate)
+        kind = L.kind_of(dtype)
+        Kp2 = round_up(2 * Fp, q)
+        w1t = torch.empty((D, Kp2), device=dev, dtype=torch.bfloat16 if kind == 1 else torch.float32)
+        # out[d][k] = w1pad[k][d] with w1pad = the (2 Fp, D) row layout of the forward pass (value rows [0, F), gate rows [Fp, Fp + F), pad rows 0)
+        st = _zeros((2 * Fp, D), dev)
+        L.pack(w1[:F], F, D, False, st[:F], D, 0)
+        L.pack(w1[F:], F, D, False, st[Fp:Fp + F], D, 0)
+        L.pack(st, D, 2 * Fp, True, w1t, Kp2, kind)
+        dxn = _f32((M, D), dev)
+        L.gemm(dtype, dh, w1t, M, D, 2 * Fp, C=dxn)
+        dhT = pack_operand(dh, dtype, transpose=True, side='a')           # (2 Fp, Mp)
+        xnT = pack_operand(xn, dtype, transpose=True)                     # (D, Mp)
+        dW1 = _f32((2 * F, D), dev)
+        L.gemm(dtype, dhT[:F], xnT, F, D, Mp, C=dW1[:F])
+        L.gemm(dtype, dhT[Fp:Fp + F], xnT, F, D, Mp, C=dW1[F:])
+        # ---- LayerNorm + residual
+        dx = _f32((M, D), dev)
+        dg, db = L.layernorm_bwd(x, ln_w.detach(), dxn, dx, M, D, add=dy, want_beta=True, eps=ctx.eps)
+        return dx, dg, db, dW1, dW2, None, None
+
+
+class _PEGBlock(torch.autograd.Function):
+    """x + dsconv(pad(x)) + b   (attention.py:57-85, :323)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, shape, causal):
+        b, t, h, w = shape
+        M, D = x.shape
+        taps = weight.detach().reshape(D, 27).t().contiguous()            # (27, D): the layout pk_peg reads (27 x 512 floats)
+        y = _f32((M, D), x.device)
+        L.peg(x, taps, bias.detach(), y, b, t, h, w, D, causal)
+        ctx.save_for_backward(x, taps)
+        ctx.shape, ctx.causal, ctx.wshape = shape, causal, weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, taps = ctx.saved_tensors
+        b, t, h, w = ctx.shape
+        M, D = x.shape
+        dy = dy.contiguous()
+        dx = _f32((M, D), x.device)
+        dtaps = L.peg_bwd(dy, x, taps, dx, b, t, h, w, D, ctx.causal)
+        dbias = L.colsum(dy, M, D, _f32((D,), x.device))
+        return dx, dtaps.t().contiguous().reshape(ctx.wshape), dbias, None, None
+
+
+class _AttnBlock(torch.autograd.Function):
+    """x + to_out(softmax(q^ k^T + bias) v)   (attention.py:89-182 + the residuals of :325-328); self-attention reads K / V from the
+    UN-normalised x (:140-144), cross-attention from context_norm(context)."""
+
+    @staticmethod
+    def forward(ctx, x, context, gamma, beta, cgamma, cbeta, wq, wkv, null_kv, q_scale, k_scale, wo, bias, kmask, meta):
+        dtype, S, n, n_ctx, heads, scale, eps = meta
+        dev = x.device
+        M, D = x.shape
+        inner = wq.shape[0]
+        nnull = null_kv.shape[1] // 2
+        is_cross = context is not None
+        n_kv = n_ctx if is_cross else n
+        xn = _f32((M, D), dev)
+        L.layernorm(x, gamma, beta, M, D, out2=xn, eps=eps)
+        if is_cross:
+            Mk, Dk = context.shape
+            if cgamma is not None:
+                src = _f32((Mk, Dk), dev)
+                L.layernorm(context, cgamma, cbeta, Mk, Dk, out2=src, eps=eps)
+            else:
+                src = context
+        else:
+            src = x
+        q = linear_fwd(dtype, xn, wq)
+        kv = linear_fwd(dtype, src, wkv)
+        td = L.tdtype(dtype)
+        nq_pad, nk_pad = L.attn_pads(n, n_kv, nnull)
+        Qp = torch.empty((S * heads * nq_pad * 64,), device=dev, dtype=td)
+        Kp = torch.empty((S * heads * nk_pad * 64,), device=dev, dtype=td)
+        Vt = torch.empty((S * heads * nk_pad * 64,), device=dev, dtype=td)
+        L.attn_prep(dtype, q, kv, null_kv.detach(), q_scale.detach(), k_scale.detach(), float(scale), Qp, Kp, Vt, S, heads, n, n_kv, nnull)
+        o = _f32((M, inner), dev)
+        L.attn_fwd(dtype, Qp, Kp, Vt, o, S, heads, n, n_kv, nnull, bias=bias, kmask=kmask)
+        y = _f32((M, D), dev)
+        L.gemm(dtype, o, pack_operand(wo, dtype), M, D, inner, C=y, res=x)
+        ctx.save_for_backward(x, context, gamma, cgamma, wq, wkv, null_kv, q_scale, k_scale, wo, bias, kmask, xn, src, q, kv, o)
+        ctx.meta = meta
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, context, gamma, cgamma, wq, wkv, null_kv, q_scale, k_scale, wo, bias, kmask, xn, src, q, kv, o = ctx.saved_tensors
+        dtype, S, n, n_ctx, heads, scale, eps = ctx.meta
+        dev = x.device
+        M, D = x.shape
+        inner = wq.shape[0]
+        nnull = null_kv.shape[1] // 2
+        is_cross = context is not None
+        n_kv = n_ctx if is_cross else n
+        nkt = nnull + n_kv
+        dy = dy.contiguous()
+        # ---- to_out
+        do, dWo = linear_bwd(dtype, o, wo, dy)
+        # ---- attention core
+        Qh, Kh, Vh = _f32((S * heads * n, 64), dev), _f32((S * heads * nkt, 64), dev), _f32((S * heads * nkt, 64), dev)
+        L.attn_train_prep(q, kv, null_kv.detach(), q_scale.detach(), k_scale.detach(), float(scale), Qh, Kh, Vh, S, heads, n, n_kv, nnull)
+        dQh, dKh, dVh = torch.empty_like(Qh), torch.empty_like(Kh), torch.empty_like(Vh)
+        want_dbias = bias is not None and ctx.needs_input_grad[12]
+        dS = _f32((S, heads * n * n_kv), dev) if want_dbias else None
+        L.attn_bwd(Qh, Kh, Vh, o, do, dQh, dKh, dVh, S, heads, n, n_kv, nnull, bias=bias, kmask=kmask, dS=dS)
+        dbias = None
+        if want_dbias:
+            dbias = _f32(tuple(bias.shape), dev)
+            L.sum_batch(dS, S, dbias, heads * n * n_kv)
+        dq, dkv = _f32((M, inner), dev), _f32(tuple(kv.shape), dev)
+        dqs, dks, dnull = L.attn_train_prep_bwd(q, kv, null_kv.detach(), q_scale.detach(), k_scale.detach(), float(scale), dQh, dKh, dVh, dq, dkv,
+                                                S, heads, n, n_kv, nnull)
+        if dnull is None:
+            dnull = torch.zeros_like(null_kv)
+        # ---- projections, LayerNorms, residual
+        dxn, dWq = linear_bwd(dtype, xn, wq, dq)
+        dx = _f32((M, D), dev)
+        dcg = dctx = None
+        if is_cross:
+            need_ctx = ctx.needs_input_grad[1]
+            dsrc, dWkv = linear_bwd(dtype, src, wkv, dkv, need_dx=(cgamma is not None) or need_ctx)
+            if cgamma is not None:
+                dctx = _f32(tuple(context.shape), dev)
+                dcg, _ = L.layernorm_bwd(context, cgamma.detach(), dsrc, dctx, context.shape[0], context.shape[1], eps=eps)
+            else:
+                dctx = dsrc
+            dg, _ = L.layernorm_bwd(x, gamma.detach(), dxn, dx, M, D, add=dy, eps=eps)
+        else:
+            t, dWkv = linear_bwd(dtype, x, wkv, dkv, add=dy)               # dy + dkv Wkv: K / V read the un-normalised x
+            dg, _ = L.layernorm_bwd(x, gamma.detach(), dxn, dx, M, D, add=t, eps=eps)
+        return dx, dctx, dg, None, dcg, None, dWq, dWkv, dnull, dqs, dks, dWo, dbias, None, None
+
+
+class _Embed(torch.autograd.Function):
+    """tok[ids] + pos[arange(n)], gradient scaled by alpha (phenaki_pytorch.py:194-199; TokenCritic: alpha = 1)"""
+
+    @staticmethod
+    def forward(ctx, tok, pos, ids, alpha):
+        b, n = ids.shape
+        D = tok.shape[1]
+        x = _f32((b * n, D), tok.device)
+        L.embed(ids, tok.detach(), pos.detach(), x, b, n, D)
+        ctx.save_for_backward(ids)
+        ctx.alpha, ctx.shapes = alpha, (tuple(tok.shape), tuple(pos.shape))
+        return x
+
+    @staticmethod
+    def backward(ctx, dy):
+        ids, = ctx.saved_tensors
+        b, n = ids.shape
+        (V1, D), (P, _) = ctx.shapes
+        dy = dy.contiguous()
+        dtok, dpos = _zeros((V1, D), dy.device), _zeros((P, D), dy.device)
+        L.embed_bwd(dy, ids, ctx.alpha, dtok, dpos, b, n, D)
+        return dtok, dpos, None, None
+
+
+def _rel_table(dims, device):
+    """relative-position table of a grid (attention.py:257-268): features (Lt, 8) f32 = sign(d) log(|d| + 1) per axis (zero-padded to 8
+    columns), the mixed-radix position code (n,) int32 and its offset: bias[h][i][j] = mlp(features)[code[i] - code[j] + off][h]"""
+    strides, acc = [], 1
+    for d in reversed(dims):
+        strides.insert(0, acc)
+        acc *= 2 * d - 1
+    grids = torch.meshgrid(*[torch.arange(d) for d in dims], indexing='ij')
+    code = sum(g.reshape(-1) * st for g, st in zip(grids, strides))
+    off = sum((d - 1) * st for d, st in zip(dims, strides))
+    l = torch.arange(acc)
+    feats = torch.zeros((acc, 8))
+    for a, (d, st) in enumerate(zip(dims, strides)):
+        delta = (l // st) % (2 * d - 1) - (d - 1)
+        feats[:, a] = torch.sign(delta) * torch.log(delta.abs().float() + 1)
+    return feats.to(device), code.to(torch.int32).to(device), int(off)
+
+
+class _PositionBias(torch.autograd.Function):
+    """ContinuousPositionBias (attention.py:229-275) evaluated on the prod(2 d - 1) distinct relative positions instead of all n^2 pairs
+    (same function of the same inputs), gathered to (heads, n, n); exact f32 like the reference (rel_pos.float()).  The first Linear's
+    num_dims input columns are zero-padded to the 8 feature columns, the last Linear's `heads` outputs to a multiple of 4 (zero rows)."""
+
+    @staticmethod
+    def _padded(w, b, li, nl, dev):
+        """(weight, bias) of layer li as the GEMM sees them"""
+        N, K = w.shape
+        Np = round_up(N, 4) if li == nl - 1 else N
+        Kp = 8 if li == 0 else K
+        if (Np, Kp) == (N, K):
+            return w.detach(), b.detach()
+        wp, bp = _zeros((Np, Kp), dev), _zeros((1, Np), dev)
+        L.pack(w.detach(), N, K, False, wp, Kp, 0)
+        L.pack(b.detach().view(1, N), 1, N, False, bp, Np, 0)
+        return wp, bp.view(Np)
+
+    @staticmethod
+    def forward(ctx, feats, code, off, n, *params):
+        dev = feats.device
+        ws, bs = params[0::2], params[1::2]
+        nl = len(ws)
+        acts = [feats]
+        hcur = feats
+        for li, (w, b) in enumerate(zip(ws, bs)):
+            wp, bp = _PositionBias._padded(w, b, li, nl, dev)
+            hcur = linear_fwd(L.F32, hcur, wp, bias=bp, act=L.ACT_NONE if li == nl - 1 else L.ACT_LEAKY)
+            acts.append(hcur)
+        heads = ws[-1].shape[0]
+        out = _f32((heads, n, n), dev)
+        L.bias_gather(hcur, code, off, out, heads, n)
+        ctx.save_for_backward(code, *params, *acts)
+        ctx.off, ctx.n, ctx.nl = off, n, nl
+        return out
+
+    @staticmethod
+    def backward(ctx, dbias):
+        nl = ctx.nl
+        code = ctx.saved_tensors[0]
+        params = ctx.saved_tensors[1:1 + 2 * nl]
+        acts = ctx.saved_tensors[1 + 2 * nl:]
+        ws, bs = params[0::2], params[1::2]
+        dev = code.device
+        heads = ws[-1].shape[0]
+        g = _zeros(tuple(acts[-1].shape), dev)                          # (Lt, heads padded to 4): the pad columns stay zero
+        L.bias_scatter(dbias.contiguous(), code, ctx.off, g, heads, ctx.n)
+        grads = [None] * (2 * nl)
+        for li in range(nl - 1, -1, -1):
+            w, xin, yout = ws[li], acts[li], acts[li + 1]
+            N, K = w.shape
+            if li != nl - 1:                                            # LeakyReLU(0.1) behind every layer but the last
+                dz = _f32(tuple(yout.shape), dev)
+                L.leaky_bwd(yout, g, dz, yout.shape[0], yout.shape[1], 0.1)
+                g = dz
+            grads[2 * li + 1] = L.colsum(g, g.shape[0], g.shape[1], _f32((g.shape[1],), dev))[:N]
+            wp, _ = _PositionBias._padded(w, bs[li], li, nl, dev)
+            g_in, dwp = linear_bwd(L.F32, xin, wp, g, need_dx=li > 0)
+            grads[2 * li] = dwp[:N, :K].contiguous()
+            g = g_in
+        return (None, None, None, None, *grads)
+
+
+class _VocabCrossEntropy(torch.autograd.Function):
+    """mean over the selected rows of CE(E[rows] W^T + b, targets[rows]); the (rows, V) logits are never stored (phenaki_pytorch.py:640-643)"""
+
+    @staticmethod
+    def forward(ctx, embeds, weight, bias, targets, rows, dtype, slab):
         L.require_device(embeds, 'embeds')
-        M, D = embeds.shape
+        R, D = embeds.shape
         V = weight.shape[0]
         dev = embeds.device
         E = embeds.detach().float().contiguous()
+        M = R if rows is None else rows.numel()
+        # the rows the head works on, gathered once: the operand of the forward products and of both gradient products
         td = L.tdtype(dtype)
-        A = E.to(td) if td != torch.float32 else E
+        if rows is None:
+            A = E.to(td) if td != torch.float32 else E
+        else:
+            A = torch.empty((M, D), device=dev, dtype=td)
+            L.pack(E, M, D, False, A, D, 1 if td == torch.bfloat16 else 0, rows=rows)
         Wp = _operand(weight.detach().float(), dtype)
         b = bias.detach().float().contiguous() if bias is not None else torch.zeros((V,), device=dev)
         tg = targets.detach().long().contiguous()
@@ -41,27 +426,29 @@ class _VocabCrossEntropy(torch.autograd.Function):
         L.vocab_sample(dtype, A, Wp, b, M, V, D, 1.0, None, None, 0, True, partials, no_noise=True)
         loss_rows = torch.empty((M,), device=dev, dtype=torch.float32)
         lse = torch.empty((M,), device=dev, dtype=torch.float32)
-        L.vocab_ce(dtype, partials, M, V, A, Wp, b, D, tg, None, loss_rows, lse=lse)
-        ctx.save_for_backward(E, weight, b, tg, lse)
+        L.vocab_ce(dtype, partials, M, V, A, Wp, b, D, tg, rows, loss_rows, lse=lse)
+        ctx.save_for_backward(E, weight, b, tg, lse, rows)
         ctx.dtype, ctx.slab, ctx.has_bias = dtype, slab, bias is not None
         ctx.A, ctx.Wp = A, Wp
-        return loss_rows.mean()
+        return L.colsum(loss_rows.view(M, 1), M, 1, torch.empty((1,), device=dev, dtype=torch.float32), scale=1.0 / M).reshape(())
 
     @staticmethod
     def backward(ctx, grad_out):
-        E, weight, b, tg, lse = ctx.saved_tensors
+        E, weight, b, tg, lse, rows = ctx.saved_tensors
         dtype, slab = ctx.dtype, ctx.slab
         A, Wp = ctx.A, ctx.Wp
-        M, D = E.shape
+        R, D = E.shape
+        M = A.shape[0]
         V = weight.shape[0]
         dev = E.device
         td = L.tdtype(dtype)
-        q = 64 if dtype == L.BF16 else 32
-        Mp, Vp = round_up(M, q), round_up(V, q)
+        q = _q(dtype)
+        Mp = round_up(M, q)
         scale = float(grad_out) / M
         # operands of the two gradient products (W-side images: rows = output features, K along the contraction)
-        Wt = _operand(weight.detach().float().t().contiguous(), dtype)         # (D, Vp): dE = g @ W   -> "W" operand = W^T, K = vocabulary
-        Et = _operand(E.t().contiguous(), dtype)                               # (D, Mp): dW = g^T @ E -> "W" operand = E^T, K = rows
+        Wt = pack_operand(weight.detach(), dtype, transpose=True)               # (D, Vp): dE = g @ W   -> "W" operand = W^T, K = vocabulary
+        Af = A.float() if A.dtype != torch.float32 else A
+        Et = pack_operand(Af, dtype, transpose=True)                             # (D, Mp): dW = g^T @ E -> "W" operand = E^T, K = rows
         dE = torch.empty((M, D), device=dev, dtype=torch.float32)
         dW = torch.empty((V, D), device=dev, dtype=torch.float32)
         db = torch.empty((V,), device=dev, dtype=torch.float32)
@@ -74,26 +461,215 @@ class _VocabCrossEntropy(torch.autograd.Function):
             Vs = min(slab, V - v0)
             # logits of the slab: the same A / W rows / bias as the forward pass (rows [v0, v0 + Vs) of the packed weight)
             L.gemm(dtype, A, Wp[v0:v0 + Vs], M, Vs, D, C=logits, bias=b[v0:v0 + Vs], ldc=logits.stride(0))
-            L.ce_grad_slab(logits, lse, tg, None, M, Vs, v0, scale, g, gT, db=db[v0:v0 + Vs])
+            L.ce_grad_slab(logits, lse, tg, rows, M, Vs, v0, scale, g, gT, db=db[v0:v0 + Vs])
             # dE (+)= g @ W_slab: contraction over the slab's columns = columns [v0, v0 + Vs) of the W^T image (k offset on the operand)
-            L.gemm(dtype, g, _k_slice(Wt, v0, dtype), M, D, Vs, C=dE, res=None if first else dE, lda=g.stride(0))
+            L.gemm(dtype, g, Wt[:, v0:], M, D, Vs, C=dE, res=None if first else dE, lda=g.stride(0))
             # dW_slab = g^T @ E (K = the rows, padded to the k-tile: gT's pad columns are zeroed by the kernel, E^T is zero-padded)
             L.gemm(dtype, gT, Et, Vs, D, Mp, C=dW[v0:v0 + Vs], lda=gT.stride(0))
             first = False
-        return dE.to(ctx.saved_tensors[0].dtype), dW, (db if ctx.has_bias else None), None, None, None
+        if rows is not None:
+            full = _zeros((R, D), dev)
+            L.scatter_rows(dE, rows, full, M, D)
+            dE = full
+        return dE, dW, (db if ctx.has_bias else None), None, None, None, None
 
 
-def _k_slice(Wimg, k0, dtype):
-    """the operand image `Wimg` (N, Kpad) viewed from contraction index k0 on (k0 a multiple of the k-tile): a column-offset view with
-    the same row stride.  Valid for all three layouts -- plain f32 / bf16 rows, and the split-bf16 image whose 32-element blocks keep
-    4 bytes per element."""
-    return Wimg[:, k0:]
+class _BCEHead(torch.autograd.Function):
+    """mean BCE-with-logits of (e w^T + b) against the labels (phenaki_pytorch.py:246-249 / :320-322 heads, :673-676 loss)"""
+
+    @staticmethod
+    def forward(ctx, e, w, b, labels):
+        M, D = e.shape
+        loss_rows = _f32((M, 1), e.device)
+        L.bce_head(e, w.detach().reshape(-1), b.detach(), labels, M, D, loss_rows=loss_rows)
+        ctx.save_for_backward(e, w, b, labels)
+        return L.colsum(loss_rows, M, 1, _f32((1,), e.device), scale=1.0 / M).reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        e, w, b, labels = ctx.saved_tensors
+        M, D = e.shape
+        de = _f32((M, D), e.device)
+        dw, db = L.bce_head(e, w.detach().reshape(-1), b.detach(), labels, M, D, scale=float(grad_out) / M, de=de)
+        return de, dw.reshape(w.shape), db.reshape(b.shape), None
 
 
-def vocab_cross_entropy(embeds, weight, bias, targets, compute_dtype='bf16x3', slab=2048):
-    """mean_m CE(embeds[m] @ weight^T + bias, targets[m]) with gradients for embeds / weight / bias; logits never stored.
-    embeds (M, D) f32 on the HIP device, weight (V, D), bias (V,) or None, targets (M,) int64 in [0, V).  slab: vocabulary columns per
-    backward step (a multiple of 64)."""
+# ------------------------------------------------------------------------------------------------------------ modules -> blocks
+
+def vocab_cross_entropy(embeds, weight, bias, targets, compute_dtype='bf16x3', slab=2048, rows=None):
+    """mean_m CE(embeds[r_m] @ weight^T + bias, targets[r_m]) with gradients for embeds / weight / bias; logits never stored.
+    embeds (R, D) f32 on the HIP device, weight (V, D), bias (V,) or None, targets (R,) int64 in [0, V); rows (M,) int32: the rows r_m the
+    loss is taken over (None: all).  slab: vocabulary columns per backward step (a multiple of 64)."""
     assert slab % 64 == 0 and slab > 0
     assert weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0, 'vocabulary size and embedding width must be multiples of 8'
-    return _VocabCrossEntropy.apply(embeds, weight, bias, targets, resolve_dtype(compute_dtype), int(slab))
+    return _VocabCrossEntropy.apply(embeds, weight, bias, targets, rows, resolve_dtype(compute_dtype), int(slab))
+
+
+def layernorm_train(ln: LayerNorm, x2d):
+    return _LayerNormFn.apply(x2d, ln.gamma, ln.beta, ln.eps)
+
+
+def feedforward_train(ff: FeedForwardSeq, x2d, dtype):
+    ln, lin1, lin2 = ff[0], ff[1], ff[4]
+    assert ff[3].p == 0., 'the training kernels are built for ff_dropout = 0 (the reference default)'
+    return _FFBlock.apply(x2d, ln.weight, ln.bias, lin1.weight, lin2.weight, dtype, ln.eps)
+
+
+def peg_train(peg: PEG, x2d, shape):
+    return _PEGBlock.apply(x2d, peg.dsconv.weight, peg.dsconv.bias, tuple(shape), peg.causal)
+
+
+def attention_train(attn: Attention, x2d, S, n, dtype, *, context2d=None, n_ctx=None, attn_bias=None, kmask=None):
+    assert not attn.causal, 'the training kernels cover the non-causal trunk attention (MaskGit / TokenCritic)'
+    assert attn.attn_dropout.p == 0., 'the training kernels are built for attn_dropout = 0 (the reference default)'
+    cn = attn.context_norm if isinstance(attn.context_norm, LayerNorm) else None
+    meta = (dtype, S, n, n_ctx, attn.heads, float(attn.scale), attn.norm.eps)
+    return _AttnBlock.apply(x2d, context2d, attn.norm.gamma, attn.norm.beta, cn.gamma if (cn is not None and context2d is not None) else None,
+                            cn.beta if cn is not None else None, attn.to_q.weight, attn.to_kv.weight, attn.null_kv, attn.q_scale, attn.k_scale,
+                            attn.to_out.weight, attn_bias, kmask, meta)
+
+
+def position_bias_train(cpb, dims, device):
+    feats, code, off = _rel_table(tuple(dims), device)
+    n = 1
+    for d in dims:
+        n *= d
+    params = []
+    for layer in cpb.net:
+        lin = layer[0] if isinstance(layer, torch.nn.Sequential) else layer
+        params += [lin.weight, lin.bias]
+    return _PositionBias.apply(feats, code, off, n, *params)
+
+
+def transformer_train(tr, x2d, S, n, dtype, *, video_shape=None, attn_bias=None, context2d=None, n_ctx=None, self_attn_mask=None,
+                      cross_attn_context_mask=None):
+    """attention.py:315-332 on (S n, D) f32 rows, every block an autograd Function"""
+    x = x2d
+    for peg, self_attn, cross_attn, ff in tr.layers:
+        if exists(peg):
+            x = peg_train(peg, x, video_shape)
+        x = attention_train(self_attn, x, S, n, dtype, attn_bias=attn_bias, kmask=self_attn_mask)
+        if exists(cross_attn) and exists(context2d):
+            x = attention_train(cross_attn, x, S, n, dtype, context2d=context2d, n_ctx=n_ctx, kmask=cross_attn_context_mask)
+        x = feedforward_train(ff, x, dtype)
+    return layernorm_train(tr.norm_out, x)
+
+
+def _u8(mask):
+    return None if mask is None else mask.to(torch.uint8).contiguous()
+
+
+def trunk_train(model, ids2d, video_patch_shape, *, context=None, text_mask=None, video_mask=None, use_bias=False, use_cross=True, alpha=1.0):
+    """MaskGit.forward(return_embeds=True) / the TokenCritic trunk with gradients: (b n, D) f32 rows of norm_out"""
+    b, n = ids2d.shape
+    dt = compute_dtype_of(model)
+    x = _Embed.apply(model.token_emb.weight, model.pos_emb.weight, ids2d.long().contiguous(), float(alpha))
+    bias = position_bias_train(model.continuous_pos_bias, video_patch_shape, x.device) if use_bias else None
+    ctx2, n_ctx = None, None
+    if use_cross and exists(context):
+        n_ctx = context.shape[1]
+        ctx2 = context.reshape(b * n_ctx, context.shape[-1]).float().contiguous()
+    return transformer_train(model.transformer, x, b, n, dt, video_shape=(b, *video_patch_shape), attn_bias=bias, context2d=ctx2, n_ctx=n_ctx,
+                             self_attn_mask=_u8(video_mask), cross_attn_context_mask=_u8(text_mask) if ctx2 is not None else None)
+
+
+def phenaki_loss(ph, videos=None, *, texts=None, video_codebook_ids=None, video_frame_mask=None, text_embeds=None, cond_drop_prob=None,
+                 only_train_generator=False, only_train_critic=False, _draws=None):
+    """phenaki_pytorch.py:562-687 with an autograd graph over the MaskGit / critic parameters (the C-ViViT and the T5 encoder are frozen there
+    too).  _draws (tests): dict(rand_step, perm_noise, gumbel_u) replaces the three random draws, as in `Phenaki.objective_value`."""
+    from .phenaki import SelfCritic, TokenCritic
+    assert not (only_train_generator and only_train_critic)
+    assert not (only_train_critic and not exists(ph.critic)), 'only_train_critic needs a critic (Phenaki(critic=...) or self_token_critic=True)'
+    assert exists(videos) ^ exists(video_codebook_ids), 'either raw video or video codebook ids must be given'
+    assert not (exists(videos) and not exists(ph.cvivit)), 'cvivit must be provided if one wants to encode the videos live during training'
+    assert (exists(text_embeds) ^ exists(texts)) ^ ph.unconditional, \
+        'either raw text of text embeds must be given, and if unconditional, none should be given'
+    assert not (exists(text_embeds) and text_embeds.shape[-1] != ph.text_embed_dim), 'text embedding dimension is not correct'
+    mg, critic = ph.maskgit, ph.critic
+    with torch.no_grad():
+        if not exists(video_codebook_ids):
+            assert videos.ndim in {4, 5}
+            if videos.ndim == 4:
+                videos = videos.unsqueeze(2)
+            video_codebook_ids = ph.cvivit(videos, return_only_codebook_ids=True)
+        L.require_device(video_codebook_ids, 'video_codebook_ids')
+        assert video_codebook_ids.ndim == 4, 'video codebook ids must be (batch, frames, height, width): MaskGit takes the patch shape from it'
+        device = video_codebook_ids.device
+        patch_shape = tuple(video_codebook_ids.shape[1:])
+        text_mask = None
+        if not ph.unconditional:
+            if not exists(text_embeds):
+                text_embeds = ph.encode_texts(texts, output_device=device)
+            text_embeds = text_embeds.to(device).float()
+            text_mask = torch.any(text_embeds != 0, dim=-1)
+        video_mask = None
+        if exists(video_frame_mask):
+            video_mask = ph.cvivit.calculate_video_token_mask(videos, video_frame_mask=video_frame_mask)
+        ids = video_codebook_ids.reshape(video_codebook_ids.shape[0], -1).long().contiguous()
+        b, n = ids.shape
+        draws = _draws or {}
+        rand_step = draws['rand_step'].to(device) if 'rand_step' in draws else torch.randint(0, ph.steps, (b,), device=device)
+        mask_token_prob = torch.cos(rand_step * math.pi * 0.5 / ph.steps)
+        vm = video_mask if exists(video_mask) else torch.ones((b, n), device=device, dtype=torch.bool)
+        num_tokens = vm.sum(dim=-1)                                                     # get_mask_subset_with_prob (phenaki_pytorch.py:43-55)
+        num_masked = (mask_token_prob * num_tokens).round().clamp(min=1)
+        perm_noise = draws['perm_noise'].to(device) if 'perm_noise' in draws else torch.rand((b, n), device=device)
+        perm = perm_noise.argsort(dim=-1) - (n - num_tokens)[:, None]
+        perm = perm.masked_fill(perm < 0, n)
+        mask_token_mask = perm < num_masked[:, None]
+        masked_input = torch.where(mask_token_mask, ph.mask_id, ids)
+        rows = mask_token_mask.reshape(-1).nonzero().reshape(-1).int()
+
+    dt = compute_dtype_of(mg)
+    D, V = mg.dim, mg.to_logits.weight.shape[0]
+    ctx_mg = torch.no_grad() if only_train_critic else torch.enable_grad()
+    with ctx_mg:
+        e = trunk_train(mg, masked_input, patch_shape, context=text_embeds, text_mask=text_mask, video_mask=video_mask, use_bias=True,
+                        use_cross=not mg.unconditional, alpha=mg.gradient_shrink_alpha)
+    loss = None
+    if not only_train_critic:
+        loss = _VocabCrossEntropy.apply(e, mg.to_logits.weight, mg.to_logits.bias, ids.reshape(-1), rows, dt, 2048)
+    need_critic = exists(critic) and not only_train_generator
+    if not need_critic:
+        return loss
+    # the critic's input: gumbel-sampled predictions at every position (phenaki_pytorch.py:653-659), no gradient through the ids
+    with torch.no_grad():
+        M = b * n
+        ed = e.detach()
+        A = ed.to(L.tdtype(dt)) if L.tdtype(dt) != torch.float32 else ed
+        w_logits = pack_operand(mg.to_logits.weight.detach(), dt)
+        partials = torch.empty((5 * L.vocab_ntiles(V) * M,), device=device, dtype=torch.float32)
+        U = draws['gumbel_u'].to(device).float().contiguous() if 'gumbel_u' in draws else None
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if U is None else 0
+        L.vocab_sample(dt, A, w_logits, mg.to_logits.bias.detach(), M, V, D, float(ph.critic_train_sample_temperature), U, None, seed, False, partials)
+        pred = torch.empty((M,), device=device, dtype=torch.long)
+        L.vocab_reduce(partials, M, V, None, None, None, pred, None, False)
+        pred = pred.view(b, n)
+        critic_input = torch.where(mask_token_mask, pred, ids)
+        labels = (ids != pred).float().reshape(-1).contiguous()
+    if isinstance(critic, SelfCritic):
+        ce = trunk_train(critic.maskgit, critic_input, patch_shape, context=text_embeds, text_mask=text_mask, video_mask=video_mask, use_bias=True,
+                         use_cross=not critic.maskgit.unconditional, alpha=critic.maskgit.gradient_shrink_alpha)
+        head = critic.to_pred[0]
+    else:
+        assert isinstance(critic, TokenCritic)
+        ce = trunk_train(critic, critic_input, patch_shape, context=text_embeds if critic.has_cross_attn else None, text_mask=text_mask,
+                         video_mask=video_mask, use_bias=False, use_cross=critic.has_cross_attn, alpha=1.0)
+        head = critic.to_logits[0]
+    critic_loss = _BCEHead.apply(ce, head.weight, head.bias, labels)
+    if only_train_critic:
+        return critic_loss
+    return _Axpy.apply(loss, critic_loss, float(ph.critic_loss_weight))
+
+
+class _Axpy(torch.autograd.Function):
+    """a + w * b on 0-d device tensors without an ATen kernel chain in the graph (two scalar gradients)"""
+
+    @staticmethod
+    def forward(ctx, a, b, w):
+        ctx.w = w
+        return a + b * w
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g * ctx.w, None

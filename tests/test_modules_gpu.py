@@ -917,9 +917,10 @@ def test_sample_graph_is_recaptured_when_weights_change():
         ph.enable_sample_graph(False)
 
 
-def test_forward_returns_value_and_backward_raises():
+def test_forward_returns_value_and_backward_raises_or_trains():
     """`loss = phenaki(...)` / `loss = cvivit(video)` work in the default state (grad mode on, trainable parameters),
-    as with the reference; `.backward()` on the value raises instead of silently training nothing."""
+    as with the reference.  C-ViViT (no backward kernels): `.backward()` raises instead of silently training nothing.  Phenaki: the loss is
+    the training step's (train.py), `.backward()` fills the MaskGit / critic gradients (values: tests/test_train_gpu.py)."""
     cv, _, _, ph = load_product('tiny', TINY)
     H = TINY['cvivit']['image_size']
     video = weights.synthetic_video(1, 5, H, H, seed=6).cuda()
@@ -934,8 +935,10 @@ def test_forward_returns_value_and_backward_raises():
         torch.manual_seed(3)
         loss = ph(videos=video, text_embeds=ctx)
         assert loss.requires_grad and torch.isfinite(loss.detach())
-        with pytest.raises(RuntimeError, match='no backward kernels'):
-            loss.backward()
+        loss.backward()
+        for name, prm in list(ph.maskgit.named_parameters()) + list(ph.critic.named_parameters()):
+            assert prm.grad is not None and torch.isfinite(prm.grad).all(), name
+        assert all(prm.grad is None for prm in cv.parameters()), 'the tokenizer is frozen in Phenaki.forward (phenaki_pytorch.py:580-584)'
 
 
 @pytest.mark.parametrize('dtype,tol', [('fp32', 1e-3), ('bf16x3', 1e-3), ('bf16', 3e-2)])

@@ -1,0 +1,300 @@
+"""GPU parity tests of the training-step kernels: every autograd block of phenaki_pytorch_amd/train.py against torch
+autograd of the oracle's restatement of the same reference lines on CPU, f32 / split-bf16 at 1e-3 (bf16: its own tolerance); the whole
+`Phenaki.forward` gradient against the REAL reference's autograd is in test_modules_gpu.py (golden)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import os
+
+from oracle import phenaki_oracle as O
+from oracle import weights
+from oracle.configs import TINY
+from tests.util import close, load_product, record_parity
+
+pytestmark = pytest.mark.gpu
+
+MODES = [('fp32', 1e-3), ('bf16x3', 1e-3), ('bf16', 6e-2)]
+
+
+@pytest.fixture(autouse=True)
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    torch.cuda.set_device(0)
+    with torch.enable_grad():                      # other test modules switch grad mode off process-wide at import
+        yield
+
+
+def _leaf(t):
+    return t.clone().requires_grad_()
+
+
+def test_pack_colsum_scatter_kernels():
+    from phenaki_pytorch_amd import _lib as L
+    g = torch.Generator().manual_seed(0)
+    src = torch.randn(133, 71, generator=g).cuda()
+    for tr in (False, True):
+        R, K = (71, 133) if tr else (133, 71)
+        want = (src.t() if tr else src).contiguous()
+        for kind, q in ((0, 32), (1, 64), (2, 32)):
+            Kp = (K + q - 1) // q * q
+            out = torch.full((R, Kp), 7.0, device='cuda', dtype=torch.bfloat16 if kind == 1 else torch.float32)
+            L.pack(src, R, K, tr, out, Kp, kind)
+            if kind == 2:                                        # (hi | lo) planes per 32-element block
+                img = out.view(torch.bfloat16).view(R, Kp // 32, 2, 32).float()
+                got = (img[:, :, 0] + img[:, :, 1]).reshape(R, Kp)
+                tol = 2e-5
+            else:
+                got, tol = out.float(), (0 if kind == 0 else 4e-3)
+            assert (got[:, K:] == 0).all(), 'pad columns must be zero'
+            assert (got[:, :K] - want).abs().max() <= tol * want.abs().max()
+    rows = torch.tensor([5, 0, 132, 7, 7], dtype=torch.int32).cuda()
+    out = torch.empty((5, 96), device='cuda')
+    L.pack(src, 5, 71, False, out, 96, 0, rows=rows)
+    assert torch.equal(out[:, :71], src[rows.long()]) and (out[:, 71:] == 0).all()
+    out = torch.empty((71, 32), device='cuda')
+    L.pack(src, 71, 5, True, out, 32, 0, rows=rows)
+    assert torch.equal(out[:, :5], src[rows.long()].t())
+    big = torch.randn(5000, 200, generator=g).cuda()
+    cs = L.colsum(big, 5000, 200, torch.empty(200, device='cuda'), scale=0.5)
+    close(cs.cpu(), 0.5 * big.cpu().double().sum(0).float(), 1e-5, 'colsum')
+    cs2 = L.colsum(big, 5000, 200, cs.clone(), accumulate=True)
+    close(cs2.cpu(), 1.5 * big.cpu().double().sum(0).float(), 1e-5, 'colsum accumulate')
+    dst = torch.zeros((133, 72), device='cuda')
+    r4 = torch.tensor([3, 100, 9], dtype=torch.int32).cuda()
+    s4 = torch.randn(3, 72, generator=g).cuda()
+    L.scatter_rows(s4, r4, dst, 3, 72)
+    assert torch.equal(dst[r4.long()], s4) and float(dst.abs().sum()) == pytest.approx(float(s4.abs().sum()), rel=1e-6)
+
+
+@pytest.mark.parametrize('D', [512, 768, 64])
+def test_layernorm_backward(D):
+    from phenaki_pytorch_amd import _lib as L
+    g = torch.Generator().manual_seed(1)
+    M = 333
+    x, gam, bet = torch.randn(M, D, generator=g) * 2 + 0.5, torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g)
+    dy, add = torch.randn(M, D, generator=g), torch.randn(M, D, generator=g)
+    xl, gl, bl = _leaf(x), _leaf(gam), _leaf(bet)
+    F.layer_norm(xl, (D,), gl, bl).backward(dy)
+    dx = torch.empty((M, D), device='cuda')
+    dg, db = L.layernorm_bwd(x.cuda(), gam.cuda(), dy.cuda(), dx, M, D, add=add.cuda(), want_beta=True)
+    close(dx.cpu(), xl.grad + add, 1e-4, 'ln dx')
+    close(dg.cpu(), gl.grad, 1e-4, 'ln dgamma')
+    close(db.cpu(), bl.grad, 1e-4, 'ln dbeta')
+
+
+@pytest.mark.parametrize('dtype,tol', MODES)
+def test_feedforward_block_gradients(dtype, tol):
+    """x + FeedForward(x) (attention.py:45-52, inner 1365 -> padded 1368 inside the block) vs torch autograd of the oracle"""
+    import phenaki_pytorch_amd as P
+    from phenaki_pytorch_amd.train import feedforward_train
+    from phenaki_pytorch_amd.attention import resolve_dtype
+    torch.manual_seed(2)
+    D, M = 512, 200
+    ff = P.attention.FeedForward(dim=D)
+    with torch.no_grad():
+        ff[0].weight.uniform_(0.5, 1.5)
+        ff[0].bias.normal_(0, 0.3)
+    sd = {k: _leaf(v.detach()) for k, v in ff.state_dict().items()}
+    x, G = torch.randn(M, D), torch.randn(M, D)
+    xl = _leaf(x)
+    (O.feedforward(sd, '', xl[None])[0] + xl).backward(G)
+    ff = ff.cuda()
+    xc = x.cuda().requires_grad_()
+    with torch.enable_grad():
+        y = feedforward_train(ff, xc, resolve_dtype(dtype))
+    y.backward(G.cuda())
+    errs = dict(dx=close(xc.grad.cpu(), xl.grad, tol, 'ff dx'),
+                dw1=close(ff[1].weight.grad.cpu(), sd['1.weight'].grad, tol, 'ff dW1'),
+                dw2=close(ff[4].weight.grad.cpu(), sd['4.weight'].grad, tol, 'ff dW2'),
+                dlnw=close(ff[0].weight.grad.cpu(), sd['0.weight'].grad, tol, 'ff d ln weight'),
+                dlnb=close(ff[0].bias.grad.cpu(), sd['0.bias'].grad, tol, 'ff d ln bias'))
+    record_parity('train_ff_block', dict(dtype=dtype, **errs))
+
+
+@pytest.mark.parametrize('dtype,tol', MODES)
+@pytest.mark.parametrize('case', ['self_bias', 'cross_null_mask', 'self_mask'])
+def test_attention_block_gradients(case, dtype, tol):
+    """x + Attention(x) (attention.py:89-182): position bias gradient, null keys, key mask, l2norm / learned scales; n = 70 (ragged tiles)"""
+    import phenaki_pytorch_amd as P
+    from phenaki_pytorch_amd.train import attention_train
+    from phenaki_pytorch_amd.attention import resolve_dtype
+    torch.manual_seed(3)
+    D, heads, S, n = 128, 2, 3, 70
+    cross = case == 'cross_null_mask'
+    attn = P.attention.Attention(dim=D, dim_context=96 if cross else None, heads=heads, num_null_kv=2 if cross else 0)
+    with torch.no_grad():
+        attn.q_scale.uniform_(0.5, 1.5)
+        attn.k_scale.uniform_(0.5, 1.5)
+        attn.norm.gamma.uniform_(0.5, 1.5)
+        if cross:
+            attn.context_norm.gamma.uniform_(0.5, 1.5)
+    sd = {k: _leaf(v.detach()) for k, v in attn.state_dict().items()}
+    sd['norm.beta'] = attn.norm.beta.detach()
+    x, G = torch.randn(S, n, D), torch.randn(S, n, D)
+    xl = _leaf(x)
+    ctx = mask = bias = None
+    n_ctx = None
+    if cross:
+        n_ctx = 13
+        ctx = torch.randn(S, n_ctx, 96)
+        mask = torch.rand(S, n_ctx) > 0.3
+        mask[:, 0] = True
+        sd['context_norm.beta'] = attn.context_norm.beta.detach()
+    elif case == 'self_bias':
+        bias = _leaf(torch.randn(heads, n, n))
+    else:
+        mask = torch.rand(S, n) > 0.2
+        mask[:, 0] = True
+    (O.attention(sd, '', xl, heads=heads, context=ctx, mask=mask, attn_bias=bias) + xl).backward(G)
+    attn = attn.cuda()
+    xc = x.reshape(S * n, D).cuda().requires_grad_()
+    bc = bias.detach().cuda().requires_grad_() if bias is not None else None
+    with torch.enable_grad():
+        y = attention_train(attn, xc, S, n, resolve_dtype(dtype), context2d=ctx.reshape(S * n_ctx, 96).cuda() if cross else None, n_ctx=n_ctx,
+                            attn_bias=bc, kmask=mask.to(torch.uint8).cuda() if mask is not None else None)
+    y.backward(G.reshape(S * n, D).cuda())
+    errs = dict(dx=close(xc.grad.cpu(), xl.grad.reshape(S * n, D), tol, 'attn dx'))
+    for name in ('to_q.weight', 'to_kv.weight', 'to_out.weight', 'q_scale', 'k_scale', 'norm.gamma') + (('null_kv', 'context_norm.gamma') if cross else ()):
+        mod = attn
+        for part in name.split('.'):
+            mod = getattr(mod, part)
+        errs[name] = close(mod.grad.cpu(), sd[name].grad, tol, f'attn d {name}')
+    if bias is not None:
+        errs['bias'] = close(bc.grad.cpu(), bias.grad, tol, 'attn d bias')
+    record_parity('train_attention_block', dict(case=case, dtype=dtype, **errs))
+
+
+@pytest.mark.parametrize('causal', [False, True])
+def test_peg_block_gradients(causal):
+    import phenaki_pytorch_amd as P
+    from phenaki_pytorch_amd.train import peg_train
+    torch.manual_seed(4)
+    D, shape = 64, (2, 5, 4, 3)
+    peg = P.attention.PEG(dim=D, causal=causal)
+    sd = {k: _leaf(v.detach()) for k, v in peg.state_dict().items()}
+    M = shape[0] * shape[1] * shape[2] * shape[3]
+    x, G = torch.randn(M, D), torch.randn(M, D)
+    xl = _leaf(x)
+    (O.peg(sd, '', xl.reshape(shape[0], -1, D), shape, causal).reshape(M, D) + xl).backward(G)
+    peg = peg.cuda()
+    xc = x.cuda().requires_grad_()
+    with torch.enable_grad():
+        y = peg_train(peg, xc, shape)
+    y.backward(G.cuda())
+    close(xc.grad.cpu(), xl.grad, 1e-4, 'peg dx')
+    close(peg.dsconv.weight.grad.cpu(), sd['dsconv.weight'].grad, 1e-4, 'peg d weight')
+    close(peg.dsconv.bias.grad.cpu(), sd['dsconv.bias'].grad, 1e-4, 'peg d bias')
+
+
+@pytest.mark.parametrize('heads', [4, 2, 8])
+def test_position_bias_gradients(heads):
+    """ContinuousPositionBias on the relative-position table (prod(2 d - 1) rows instead of n^2) == the reference's n^2 form, values and gradients"""
+    import phenaki_pytorch_amd as P
+    from phenaki_pytorch_amd.train import position_bias_train
+    torch.manual_seed(5)
+    dims = (3, 4, 2)
+    cpb = P.attention.ContinuousPositionBias(dim=32, heads=heads, num_dims=3)
+    sd = {k: _leaf(v.detach()) for k, v in cpb.state_dict().items()}
+    n = 24
+    G = torch.randn(heads, n, n)
+    ref = O.continuous_position_bias(sd, '', dims)
+    ref.backward(G)
+    cpb = cpb.cuda()
+    with torch.enable_grad():
+        out = position_bias_train(cpb, dims, torch.device('cuda'))
+    close(out.detach().cpu(), ref.detach(), 1e-5, 'position bias value')
+    out.backward(G.cuda())
+    for k, v in cpb.named_parameters():
+        close(v.grad.cpu(), sd[k].grad, 2e-4, f'position bias d {k}')
+
+
+def test_embed_and_bce_head_gradients():
+    from phenaki_pytorch_amd.train import _BCEHead, _Embed
+    g = torch.Generator().manual_seed(6)
+    V1, P_, D, b, n = 50, 40, 64, 3, 17
+    tok, pos = torch.randn(V1, D, generator=g), torch.randn(P_, D, generator=g)
+    ids = torch.randint(0, V1, (b, n), generator=g)
+    ids[:, ::3] = V1 - 1
+    G = torch.randn(b * n, D, generator=g)
+    tl, pl = _leaf(tok), _leaf(pos)
+    xr = (tl[ids] + pl[:n][None]).reshape(b * n, D)
+    (xr * 0.1 + xr.detach() * 0.9).backward(G)
+    tc, pc = tok.cuda().requires_grad_(), pos.cuda().requires_grad_()
+    with torch.enable_grad():
+        x = _Embed.apply(tc, pc, ids.cuda(), 0.1)
+    close(x.detach().cpu(), xr.detach(), 1e-6, 'embed value')
+    x.backward(G.cuda())
+    close(tc.grad.cpu(), tl.grad, 1e-5, 'd token_emb')
+    close(pc.grad.cpu(), pl.grad, 1e-5, 'd pos_emb')
+    # critic head + BCE
+    M = 77
+    e, w, bb = torch.randn(M, D, generator=g), torch.randn(1, D, generator=g) * 0.3, torch.randn(1, generator=g)
+    y = (torch.rand(M, generator=g) > 0.5).float()
+    el, wl, bl = _leaf(e), _leaf(w), _leaf(bb)
+    ref = F.binary_cross_entropy_with_logits((el @ wl.t()).squeeze(-1) + bl, y)
+    (ref * 1.7).backward()
+    ec, wc, bc = e.cuda().requires_grad_(), w.cuda().requires_grad_(), bb.cuda().requires_grad_()
+    with torch.enable_grad():
+        loss = _BCEHead.apply(ec, wc, bc, y.cuda())
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    (loss * 1.7).backward()
+    close(ec.grad.cpu(), el.grad, 1e-4, 'bce de')
+    close(wc.grad.cpu(), wl.grad, 1e-4, 'bce dw')
+    close(bc.grad.cpu(), bl.grad, 1e-4, 'bce db')
+
+
+@pytest.mark.parametrize('dtype,tol', [('fp32', 1e-3), ('bf16x3', 1e-3), ('bf16', 1e-1)])
+def test_training_step_matches_reference_autograd(golden_dir, dtype, tol):
+    """loss = Phenaki.forward(...); loss.backward() against the REAL reference's autograd (tiny config, the reference's
+    three random draws injected): the loss and the gradient of all 100 MaskGit + TokenCritic parameters; generator-only / critic-only
+    variants train exactly the parameters the reference trains."""
+    g = torch.load(os.path.join(golden_dir, 'forward_grads_tiny.pt'), weights_only=False)
+    cv, mg, cr, ph = load_product('tiny', TINY, dtype=dtype)
+    batch = g['batch']
+    ctx = weights.synthetic_context(batch, g['ctx_len'], TINY['maskgit']['dim_context'], seed=3, pad_last=2).cuda()
+    ids = g['ids'].cuda()
+    n = ids[0].numel()
+    draws = dict(rand_step=g['rand_step'], perm_noise=weights.uniform_noise((batch, n), 700),
+                 gumbel_u=weights.uniform_noise((batch, n, TINY['maskgit']['num_tokens']), 701))
+    named = {f'maskgit.{k}': v for k, v in mg.named_parameters()}
+    named.update({f'critic.{k}': v for k, v in cr.named_parameters()})
+
+    def step(**kw):
+        for v in named.values():
+            v.grad = None
+        loss = ph(video_codebook_ids=ids, text_embeds=ctx, _draws=draws, **kw)
+        loss.backward()
+        return loss.detach()
+
+    loss = step()
+    assert abs(float(loss) - float(g['loss_total'])) <= min(tol, 2e-2) * abs(float(g['loss_total']))
+    assert sorted(k for k, v in named.items() if v.grad is not None) == sorted(g['grads_total'])
+    errs = {}
+    top = max(float(v.abs().max()) for v in g['grads_total'].values() if v.numel())
+    for k, ref in g['grads_total'].items():
+        if ref.numel() == 0:
+            continue
+        if dtype == 'bf16' and k.startswith('critic.'):
+            # bf16 logits flip a few gumbel-argmax near-ties (audited in the sampler tests): the critic then sees other input ids than the
+            # reference's critic did, so its gradients are those of a different batch -- finite is all that can be asked here
+            assert torch.isfinite(named[k].grad).all()
+            continue
+        if float(ref.abs().max()) < 1e-6 * top:
+            # structurally zero (the last position-bias Linear's bias shifts every score of a row by the same amount: softmax does not see
+            # it) -- the reference's own value is rounding noise; ours must be noise of the same kind, measured against the real gradients
+            assert float(named[k].grad.abs().max()) <= 1e-2 * tol * top, f'd {k} should vanish'
+            continue
+        errs[k] = close(named[k].grad.cpu(), ref, tol, f'd {k} ({dtype})')
+    worst = max(errs, key=errs.get)
+    record_parity('training_step_vs_reference_autograd', dict(dtype=dtype, parameters=len(errs), worst=worst, worst_rel_err=errs[worst],
+                                                              median_rel_err=sorted(errs.values())[len(errs) // 2]))
+    for name in ('generator', 'critic'):
+        l2 = step(**{f'only_train_{name}': True})
+        assert abs(float(l2) - float(g[f'loss_{name}'])) <= min(tol, 2e-2) * abs(float(g[f'loss_{name}']))
+        got = sorted(k for k, v in named.items() if v.grad is not None)
+        assert got == g[f'grad_keys_{name}'], f'only_train_{name}: parameters with a gradient differ from the reference'
+        pk, pv = g[f'grad_probe_{name}']
+        if not (dtype == 'bf16' and name == 'critic'):
+            close(named[pk].grad.cpu(), pv, tol, f'only_train_{name}: d {pk}')
