@@ -392,6 +392,9 @@ def maskgit_forward(sd, cfg, ids, *, video_patch_shape, context=None, text_mask=
     if null_cond:
         text_mask = torch.zeros_like(text_mask)
     x = maskgit_embed(sd, ids)
+    alpha = cfg.get('gradient_shrink_alpha', 0.1)                    # :199 -- the identity in value, scales the embedding gradients
+    if x.requires_grad:
+        x = x * alpha + x.detach() * (1 - alpha)
     x = transformer(sd, 'transformer.', x, depth=cfg['depth'], heads=cfg['heads'], peg_on=True,
                     cross=not cfg.get('unconditional', False), video_shape=(b, *video_patch_shape),
                     attn_bias=bias, context=context, self_attn_mask=video_mask,

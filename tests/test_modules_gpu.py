@@ -936,8 +936,12 @@ def test_forward_returns_value_and_backward_raises_or_trains():
         loss = ph(videos=video, text_embeds=ctx)
         assert loss.requires_grad and torch.isfinite(loss.detach())
         loss.backward()
-        for name, prm in list(ph.maskgit.named_parameters()) + list(ph.critic.named_parameters()):
-            assert prm.grad is not None and torch.isfinite(prm.grad).all(), name
+        trained = set(torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'forward_grads_tiny.pt'), weights_only=False)['grads_total'])
+        for name, prm in [(f'maskgit.{k}', v) for k, v in ph.maskgit.named_parameters()] + [(f'critic.{k}', v) for k, v in ph.critic.named_parameters()]:
+            if name in trained:                   # (the unused context_norm of the self-attention blocks gets no gradient in the reference either)
+                assert prm.grad is not None and torch.isfinite(prm.grad).all(), name
+            else:
+                assert prm.grad is None, name
         assert all(prm.grad is None for prm in cv.parameters()), 'the tokenizer is frozen in Phenaki.forward (phenaki_pytorch.py:580-584)'
 
 

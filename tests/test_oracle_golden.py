@@ -289,6 +289,40 @@ def test_vocab_ce_grads_match_reference_autograd(golden_dir):
     close(r['d_bias'], g['d_bias'], 1e-4)
 
 
+def test_training_step_gradients_match_reference_autograd(golden_dir):
+    """torch autograd through the oracle's restatement of Phenaki.forward against the REAL reference's loss.backward() (all 100 MaskGit +
+    TokenCritic parameter gradients, oracle/make_golden.py forward_grads_golden): pins the oracle blocks tests/test_train_gpu.py
+    differentiates to check the MI355X backward kernels"""
+    g = load(golden_dir, 'forward_grads_tiny.pt')
+    _, mg, cr = state_dicts('tiny')
+    _, mgc, crc = oracle_cfgs(TINY)
+    mg = {k: (v.clone().requires_grad_() if v.is_floating_point() and not k.endswith('.beta') else v) for k, v in mg.items()}
+    cr = {k: (v.clone().requires_grad_() if v.is_floating_point() and not k.endswith('.beta') else v) for k, v in cr.items()}
+    batch, n = g['batch'], g['ids'][0].numel()
+    ctx = weights.synthetic_context(batch, g['ctx_len'], TINY['maskgit']['dim_context'], seed=3, pad_last=2)
+    with torch.enable_grad():
+        out = O.phenaki_forward_loss(mg, mgc, cr, crc, g['ids'].flatten(1), patch_shape=tuple(g['ids'].shape[1:]), context=ctx, steps=TINY['steps'],
+                                     rand_step=g['rand_step'], perm_noise=weights.uniform_noise((batch, n), 700),
+                                     gumbel_u=weights.uniform_noise((batch, n, TINY['maskgit']['num_tokens']), 701),
+                                     mask_id=TINY['maskgit']['num_tokens'])
+        out['loss'].backward()
+    assert abs(float(out['loss']) - float(g['loss_total'])) <= 1e-5 * abs(float(g['loss_total']))
+    top = max(float(v.abs().max()) for v in g['grads_total'].values() if v.numel())
+    checked = 0
+    for k, ref in g['grads_total'].items():
+        net, name = k.split('.', 1)
+        got = (mg if net == 'maskgit' else cr)[name].grad
+        if ref.numel() == 0:
+            continue
+        assert got is not None, k
+        if float(ref.abs().max()) < 1e-6 * top:                     # structurally zero (softmax-invariant bias of the position MLP): noise vs noise
+            assert float(got.abs().max()) < 1e-5 * top
+            continue
+        close(got, ref, 1e-4)
+        checked += 1
+    assert checked >= 90
+
+
 @pytest.mark.parametrize('tag', ['tiny', 'base'])
 def test_t5_encoder_oracle_matches_huggingface(golden_dir, tag):
     """oracle/t5_oracle.py (restated from transformers' modeling_t5.py) against the REAL HuggingFace T5EncoderModel -- the module the
