@@ -63,7 +63,7 @@ def parse():
     ap.add_argument('--no-parity-mode', action='store_true', help='skip the exact-f32 timing')
     ap.add_argument('--no-kernels', action='store_true', help='skip the per-kernel roofline table')
     ap.add_argument('--encode-only', action='store_true', help='only the headline leg (profiling runs)')
-    ap.add_argument('--legs', default='decode,encode_b32,sample,sample_cfg3,sample_b32,make_video,objective',
+    ap.add_argument('--legs', default='decode,encode_b32,sample,sample_cfg3,sample_b32,make_video,objective,train_step',
                     help='comma list of the legs reported beside the headline encode leg')
     ap.add_argument('--sample-batch', type=int, default=8)
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -631,6 +631,49 @@ def bench_objective(ph, args, ws):
                      'cross entropy (logits never written) + TokenCritic trunk + BCE; random-init weights, random ids')
 
 
+def bench_train_step(args, ws, mode):
+    """ONE training step of the reference's PhenakiTrainer inner loop (phenaki_trainer.py:351-388) at BASELINE geometry --
+    zero_grad, loss = Phenaki.forward(token ids, text embeddings) [MaskGit CE + TokenCritic BCE], loss.backward(), AdamW step on the MaskGit
+    and critic parameters -- every arithmetic kernel this library's (train.py, optim.py).  videos/sec; its own models (grad mode on)."""
+    import phenaki_pytorch_amd as P
+    B = args.sample_batch
+    cv, mg, cr, ph = build_models(mode, True)
+    for m in (mg, cr):
+        m.train()
+    ctx = synthetic_context(B, 12, 768, seed=1).cuda()
+    g = torch.Generator(device='cpu')
+    g.manual_seed(4)
+    ids = torch.randint(0, 65536, (B, 9, 8, 8), generator=g).cuda()
+    params = [p for p in list(mg.parameters()) + list(cr.parameters()) if p.requires_grad]
+    opt = P.get_optimizer(params, lr=1e-4, wd=1e-2)
+    torch.manual_seed(0)
+    losses = []
+
+    def step(i):
+        with torch.enable_grad():
+            opt.zero_grad(set_to_none=True)
+            loss = ph(video_codebook_ids=ids, text_embeds=ctx)
+            loss.backward()
+        if ws > 1:
+            P.all_reduce_gradients(params)
+        opt.step()
+        losses.append(loss.detach())
+
+    step(0)
+    step(1)                                                        # warm-up (allocator, optimizer state)
+    torch.cuda.reset_peak_memory_stats()
+    ts = timed_groups(step, 3, 3, ws)
+    dt = statistics.median(ts) / 3
+    out = dict(metric='phenaki_train_step_videos_per_sec', value=B * ws / dt, unit='videos/s', ms_per_step=dt * 1e3, dtype=mode, batch_per_gpu=B,
+               tokens_per_video=576, trained_parameters=sum(p.numel() for p in params), loss_first=float(losses[0]), loss_last=float(losses[-1]),
+               peak_memory_gb=torch.cuda.max_memory_allocated() / 2 ** 30, optimizer='AdamW (pk_adamw), lr 1e-4, wd 1e-2',
+               note='forward + backward + optimizer step on fixed token ids / text embeddings (the tokenizer and T5 are frozen in the reference\'s '
+                    'step too); activations f32, every block keeps what its backward needs')
+    del cv, mg, cr, ph, opt
+    torch.cuda.empty_cache()
+    return out
+
+
 def bench_parity_mode(args, ws, mode='bf16x3'):
     """a PARITY-GRADE mode -- a configuration the parity tests hold to bit-exact ids (margin-audited) / 1e-3 against the REAL
     reference -- timed on the same workloads:
@@ -747,6 +790,14 @@ def main():
         result['kernels'] = [{k: (round(r[k], 4) if isinstance(r[k], float) else r[k]) for k in keep if k in r} for r in kernels]
     del cv, mg, cr, ph
     torch.cuda.empty_cache()
+    if sampler and 'train_step' in legs:
+        try:
+            result['train_step'] = bench_train_step(args, ws, 'bf16x3' if args.dtype == 'bf16' else args.dtype)
+            if args.dtype == 'bf16':
+                result['train_step_bf16'] = bench_train_step(args, ws, 'bf16')
+        except Exception as e:                                  # noqa: BLE001 -- a training-leg failure must not cost the headline line
+            print(f'[bench] train_step leg failed ({type(e).__name__}: {e})', file=sys.stderr)
+            torch.cuda.synchronize()
     if not (args.no_parity_mode or args.encode_only) and args.dtype == 'bf16':
         result['parity_mode'] = bench_parity_mode(args, ws, 'bf16x3')
         result['parity_mode_f32'] = bench_parity_mode(args, ws, 'fp32')

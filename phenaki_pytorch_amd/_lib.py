@@ -74,6 +74,7 @@ SIGNATURES = {
     'pk_bce_head': [_P, _LL, _P, _P, _P, _F, _P, _P, _P, _LL, _P, _P, _I, _I, _P],
     'pk_attn_train_prep': [_P, _LL, _P, _LL, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'pk_attn_train_prep_bwd': [_P, _LL, _P, _LL, _P, _P, _P, _F, _P, _P, _P, _P, _LL, _P, _LL, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'pk_adamw': [_P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _LL, _P],
     'pk_attn_bwd': [_P, _P, _P, _P, _LL, _I, _P, _LL, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
 }
 
@@ -545,3 +546,8 @@ def attn_bwd(Qh, Kh, Vh, O, dO, dQh, dKh, dVh, S, h, n, n_kv, nnull, *, bias=Non
     rc = load().pk_attn_bwd(ptr(Qh), ptr(Kh), ptr(Vh), ptr(O), O.stride(-2), 1 if O.dtype == torch.bfloat16 else 0, ptr(dO), dO.stride(-2), ptr(bias), ptr(kmask),
                             ptr(dQh), ptr(dKh), ptr(dVh), ptr(dS), ptr(lse), ptr(drow), S, h, n, n_kv, nnull, stream(Qh))
     _check(rc, 'pk_attn_bwd')
+
+
+def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step):
+    rc = load().pk_adamw(ptr(p), ptr(g), ptr(m), ptr(v), float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step), p.numel(), stream(p))
+    _check(rc, 'pk_adamw')

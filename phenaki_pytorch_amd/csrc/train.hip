@@ -374,6 +374,21 @@ __global__ __launch_bounds__(256) void bce_head_kernel(const float* __restrict__
     if (threadIdx.x == 0) pb[blockIdx.x] = (redb[0] + redb[1]) + (redb[2] + redb[3]);
 }
 
+// ---- AdamW / Adam parameter update (reference optimizer.py:11-37 -> torch.optim.AdamW / Adam; one launch per parameter tensor) ----------------
+// m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p = p (1 - lr wd) - (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                    float lr, float b1, float b2, float eps, float wd, float bc1, float rsqrt_bc2, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
+        p[i] = p[i] * (1.0f - lr * wd) - (lr / bc1) * (mi / denom);
+    }
+}
+
 }  // namespace pk
 
 using namespace pk;
@@ -516,6 +531,15 @@ extern "C" int pk_bce_head(const float* e, long lde, const float* w, const float
     if ((D & 3) || (lde & 3) || (ldde & 3) || !al16(e) || !al16(w) || (de && !al16(de)) || (pw && !al16(pw))) return PK_EALIGN;
     const int P = pk_ln_bwd_parts(M), rpb = (M + P - 1) / P;
     hipLaunchKernelGGL(bce_head_kernel, dim3(P), dim3(256), 0, STREAM(stream), e, lde, w, b, labels, scale, logits, loss_rows, de, ldde, pw, pb, M, D, rpb);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+// step = 1, 2, ...: the number of this update (bias corrections 1 - beta^step); wd = 0: plain Adam
+extern "C" int pk_adamw(float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2, float eps, float wd, int step, long n, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || step <= 0) return PK_EINVAL;
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(n)), dim3(256), 0, STREAM(stream), p, g, m, v, lr, beta1, beta2, eps, wd, bc1, 1.0f / sqrtf(bc2), n);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

@@ -298,3 +298,91 @@ def test_training_step_matches_reference_autograd(golden_dir, dtype, tol):
         pk, pv = g[f'grad_probe_{name}']
         if not (dtype == 'bf16' and name == 'critic'):
             close(named[pk].grad.cpu(), pv, tol, f'only_train_{name}: d {pk}')
+
+
+def test_hip_adamw_matches_torch_adamw_and_bumps_versions():
+    """optim.py (reference optimizer.py:11-37): get_optimizer's grouping and the pk_adamw update against torch.optim.AdamW / Adam on CPU"""
+    import phenaki_pytorch_amd as P
+    g = torch.Generator().manual_seed(8)
+    shapes = [(33, 17), (129,), (4, 3, 3)]
+    for wd in (1e-2, 0.0):
+        ref_p = [torch.randn(*s, generator=g).requires_grad_() for s in shapes]
+        hip_p = [p.detach().clone().cuda().requires_grad_() for p in ref_p]
+        if wd == 0:
+            ref = torch.optim.Adam(ref_p, lr=3e-3, betas=(0.9, 0.99), eps=1e-8)
+        else:
+            wdp, nowd = [p for p in ref_p if p.ndim >= 2], [p for p in ref_p if p.ndim < 2]
+            ref = torch.optim.AdamW([{'params': wdp}, {'params': nowd, 'weight_decay': 0}], lr=3e-3, weight_decay=wd, betas=(0.9, 0.99), eps=1e-8)
+        opt = P.get_optimizer(hip_p, lr=3e-3, wd=wd)
+        assert isinstance(opt, P.HipAdamW) and len(opt.param_groups) == (1 if wd == 0 else 2)
+        for it in range(4):
+            grads = [torch.randn(*s, generator=g) for s in shapes]
+            for p, q, gr in zip(ref_p, hip_p, grads):
+                p.grad, q.grad = gr.clone(), gr.cuda()
+            v0 = [q._version for q in hip_p]
+            ref.step()
+            opt.step()
+            assert all(q._version > v for q, v in zip(hip_p, v0)), 'the update must be visible to version-keyed caches'
+            for p, q in zip(ref_p, hip_p):
+                close(q.detach().cpu(), p.detach(), 1e-5, f'adamw step {it} wd {wd}')
+        sd = opt.state_dict()
+        assert len(sd['state']) == 3 and sd['state'][0]['step'] == 4
+
+
+@pytest.mark.parametrize('variant', ['self_critic', 'unconditional', 'no_critic_video_mask'])
+def test_training_step_variants_run_and_match_oracle_autograd(variant):
+    """the other constructions Phenaki.forward trains (phenaki_pytorch.py:353-372 self_token_critic, unconditional MaskGit, a video frame mask):
+    loss and a few gradients against torch autograd through the oracle on the same draws"""
+    import phenaki_pytorch_amd as P
+    from oracle.configs import oracle_cfgs, state_dicts
+    cv, mg, cr, ph = load_product('tiny', TINY)
+    _, mg_sd, cr_sd = state_dicts('tiny')
+    _, mgc, crc = oracle_cfgs(TINY)
+    batch, n = 2, 48
+    g = torch.Generator().manual_seed(9)
+    ids = torch.randint(0, TINY['maskgit']['num_tokens'], (batch, 3, 4, 4), generator=g)
+    ctx = weights.synthetic_context(batch, 6, TINY['maskgit']['dim_context'], seed=3, pad_last=2)
+    draws = dict(rand_step=torch.tensor([1, 3]), perm_noise=weights.uniform_noise((batch, n), 710),
+                 gumbel_u=weights.uniform_noise((batch, n, TINY['maskgit']['num_tokens']), 711))
+    okw = dict(patch_shape=(3, 4, 4), steps=TINY['steps'], mask_id=TINY['maskgit']['num_tokens'], **draws)
+    leaf = lambda sd: {k: (v.clone().requires_grad_() if v.is_floating_point() and not k.endswith('.beta') else v) for k, v in sd.items()}
+    mgl = leaf(mg_sd)
+    if variant == 'self_critic':
+        ph2 = P.Phenaki(maskgit=mg, cvivit=cv, self_token_critic=True, steps=TINY['steps'], text_embed_dim=TINY['maskgit']['dim_context']).cuda()
+        torch.manual_seed(0)
+        with torch.no_grad():
+            ph2.critic.to_pred[0].weight.normal_(0, 0.1)
+        head = {'to_pred.0.weight': ph2.critic.to_pred[0].weight.detach().cpu().clone().requires_grad_(),
+                'to_pred.0.bias': ph2.critic.to_pred[0].bias.detach().cpu().clone().requires_grad_()}
+        ref = O.phenaki_forward_loss(mgl, mgc, head, dict(self_critic=(mgl, mgc)), ids.flatten(1), context=ctx, **okw)
+        loss = ph2(video_codebook_ids=ids.cuda(), text_embeds=ctx.cuda(), _draws=draws)
+        probes = [(mg.to_logits.weight, mgl['to_logits.weight']), (mg.token_emb.weight, mgl['token_emb.weight']),
+                  (ph2.critic.to_pred[0].weight, head['to_pred.0.weight']), (mg.transformer.layers[0][2].null_kv, mgl['transformer.layers.0.2.null_kv'])]
+    elif variant == 'unconditional':
+        mgu = P.MaskGit(unconditional=True, **TINY['maskgit'])
+        sdu = {k: v for k, v in mg_sd.items() if k in mgu.state_dict()}
+        mgu.load_state_dict(sdu)
+        mgu = mgu.cuda()
+        ph2 = P.Phenaki(maskgit=mgu, cvivit=cv, steps=TINY['steps'], text_embed_dim=TINY['maskgit']['dim_context']).cuda()
+        mgl = leaf(sdu)
+        ref = O.phenaki_forward_loss(mgl, dict(mgc, unconditional=True), None, None, ids.flatten(1), context=None, **okw)
+        loss = ph2(video_codebook_ids=ids.cuda(), _draws=draws)
+        probes = [(mgu.to_logits.bias, mgl['to_logits.bias']), (mgu.pos_emb.weight, mgl['pos_emb.weight']),
+                  (mgu.transformer.layers[1][3][1].weight, mgl['transformer.layers.1.3.1.weight'])]
+    else:
+        ph2 = P.Phenaki(maskgit=mg, cvivit=cv, steps=TINY['steps'], text_embed_dim=TINY['maskgit']['dim_context']).cuda()
+        H = TINY['cvivit']['image_size']
+        video = weights.synthetic_video(batch, 5, H, H, seed=5)
+        fmask = torch.tensor([[True] * 5, [True] * 3 + [False] * 2])
+        with torch.no_grad():
+            vids = cv(video.cuda(), return_only_codebook_ids=True)
+            vmask = cv.calculate_video_token_mask(video.cuda(), video_frame_mask=fmask.cuda()).cpu()
+        ref = O.phenaki_forward_loss(mgl, mgc, None, None, vids.cpu().flatten(1), context=ctx, video_mask=vmask, **okw)
+        loss = ph2(video.cuda(), text_embeds=ctx.cuda(), video_frame_mask=fmask.cuda(), _draws=draws)
+        probes = [(mg.to_logits.weight, mgl['to_logits.weight']), (mg.transformer.layers[0][1].to_kv.weight, mgl['transformer.layers.0.1.to_kv.weight']),
+                  (mg.continuous_pos_bias.net[0][0].weight, mgl['continuous_pos_bias.net.0.0.weight'])]
+    ref['loss'].backward()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref['loss'].detach())) <= 2e-4 * abs(float(ref['loss'].detach()))
+    for got, want in probes:
+        close(got.grad.cpu(), want.grad, 1e-3, f'{variant} gradient probe')
