@@ -7,9 +7,10 @@
 //                  dS = P * (dO V^T - D), dQ^ = dS K^   [+ dS written out for the position-bias gradient]
 //                  kernel KV (one workgroup per 64 keys of a head): dV = P^T dO, dK^ = dS^T Q^ over all query tiles
 //   pk_attn_train_prep_bwd : l2norm / scale / null-key backward -> dq, dkv, dq_scale, dk_scale, dnull_kv
-// All tile products are 64 x 64 x 64 on v_mfma_f32_16x16x4_f32 from f32 LDS tiles (rows padded to 68 floats: the A-side fragment read
-// (row = lane & 15, k = lane >> 4) touches 64 distinct banks).  No pipelining: 13 GFLOP per MaskGit layer at B = 8, a few hundred
-// microseconds; the GEMMs of the backward pass dominate the step.  Every result is owned by exactly one workgroup (no atomics).
+// All tile products are 64 x 64 x 64 on v_mfma_f32_16x16x4_f32 from f32 LDS tiles [row][k] (rows padded to 68 floats), both operands read as
+// 8-element fragment chunks; products whose contraction index is not the contiguous one of the global layout read a tile that was transposed
+// on its way into LDS (K^T in kernel Q, Q^T / dO^T in kernel KV).  No software pipelining.  Every result is owned by exactly one workgroup
+// (no atomics): the gradients are bit-reproducible.
 #include "common.hpp"
 
 namespace pk {
@@ -120,18 +121,21 @@ __global__ __launch_bounds__(64) void null_kv_bwd_kernel(const float* __restrict
 }
 
 // ---- 64 x 64 x 64 tile product on the f32 matrix cores -------------------------------------------------------------------------------
-// acc[nb] (rows m0 + (lane >> 4) * 4 + i, column nb * 16 + (lane & 15)) += sum_k A(m, k) B(n, k),  A(m, k) = As[m * sam + k * sak],
-// B(n, k) = Bs[n * sbn + k * sbk]
-__device__ __forceinline__ void mma64(const float* As, int sam, int sak, const float* Bs, int sbn, int sbk, f32x4 (&acc)[4], int m0, int lane) {
+// acc[nb] (rows m0 + (lane >> 4) * 4 + i, column nb * 16 + (lane & 15)) += sum_k A[m][k] B[n][k] for two LDS tiles [row][k] (k contiguous, row
+// stride TLD): fragment chunks of 8 consecutive k per lane (two ds_read_b128) feed eight v_mfma_f32_16x16x4_f32 each (common.hpp mma(Frag<float>));
+// the first version read one float per MFMA (80 ds_read_b32 per 64 MFMAs) and was LDS-issue bound at 17 % of the f32 matrix peak.
+__device__ __forceinline__ void mma64(const float* As, const float* Bs, f32x4 (&acc)[4], int m0, int lane) {
     const int r = lane & 15, kq = lane >> 4;
-    const float* ap = As + (m0 + r) * sam + kq * sak;
-    const float* bp = Bs + r * sbn + kq * sbk;
-#pragma unroll 4
-    for (int k0 = 0; k0 < 64; k0 += 4) {
-        const float a = ap[k0 * sak];
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[nb * 16 * sbn + k0 * sbk], acc[nb], 0, 0, 0);
+    for (int c = 0; c < 2; ++c) {
+        Frag<float> a;
+        frag_load(a, As + (m0 + r) * TLD + c * 32 + kq * 8);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            Frag<float> b;
+            frag_load(b, Bs + (nb * 16 + r) * TLD + c * 32 + kq * 8);
+            acc[nb] = mma(a, b, acc[nb]);
+        }
     }
 }
 
@@ -147,22 +151,19 @@ struct AttnBwdArgs {
     int S, heads, n, nkt, nnull;
 };
 
-// rows [r0, r0 + 64) x 64 floats of a [rows_total][64] matrix -> LDS tile (zero rows beyond rows_total)
-__device__ __forceinline__ void load_tile(float* dst, const float* src, int r0, int rows_total) {
-    for (int e = threadIdx.x; e < 64 * 16; e += 256) {
-        const int r = e >> 4, c = (e & 15) * 4;
-        f32x4 v = f32x4{0, 0, 0, 0};
-        if (r0 + r < rows_total) v = *reinterpret_cast<const f32x4*>(src + (long)(r0 + r) * 64 + c);
-        *reinterpret_cast<f32x4*>(dst + r * TLD + c) = v;
-    }
-}
-// the (s, h) slice of a (M, ld) row-major activation: rows s * n + i, columns h * 64 ..
-__device__ __forceinline__ void load_tile_rows(float* dst, const float* src, long ld, int r0, int rows_total) {
+// rows [r0, r0 + 64) of a (rows_total, ld) matrix, 64 columns -> LDS tile [row][col] (zero rows beyond rows_total); T: the transposed tile [col][row]
+template <bool T>
+__device__ __forceinline__ void load_tile(float* dst, const float* src, long ld, int r0, int rows_total) {
     for (int e = threadIdx.x; e < 64 * 16; e += 256) {
         const int r = e >> 4, c = (e & 15) * 4;
         f32x4 v = f32x4{0, 0, 0, 0};
         if (r0 + r < rows_total) v = *reinterpret_cast<const f32x4*>(src + (long)(r0 + r) * ld + c);
-        *reinterpret_cast<f32x4*>(dst + r * TLD + c) = v;
+        if (T) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[(c + q) * TLD + r] = v[q];
+        } else {
+            *reinterpret_cast<f32x4*>(dst + r * TLD + c) = v;
+        }
     }
 }
 
@@ -177,16 +178,18 @@ __device__ __forceinline__ bool score(const AttnBwdArgs& p, int s, int h, int gi
     return true;
 }
 
+#define PK_ZERO4 {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}
+
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* Qs = sm; float* dOs = sm + TSZ; float* Ks = sm + 2 * TSZ; float* Vs = sm + 3 * TSZ; float* Ps = sm + 4 * TSZ;
+    float* Qs = sm; float* dOs = sm + TSZ; float* Ks = sm + 2 * TSZ; float* Vs = sm + 3 * TSZ; float* Ps = sm + 4 * TSZ; float* Kt = sm + 5 * TSZ;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
     const int nqt = (p.n + 63) / 64;
     const int qt = blockIdx.x % nqt, sh = blockIdx.x / nqt, h = sh % p.heads, s = sh / p.heads;
     const int i0 = qt * 64, m0 = wv * 16;
     const int nreal = p.nkt - p.nnull;
-    load_tile(Qs, p.Qh + (long)sh * p.n * 64, i0, p.n);
-    load_tile_rows(dOs, p.dO + (long)s * p.n * p.lddo + h * 64, p.lddo, i0, p.n);
+    load_tile<false>(Qs, p.Qh + (long)sh * p.n * 64, 64, i0, p.n);
+    load_tile<false>(dOs, p.dO + (long)s * p.n * p.lddo + h * 64, p.lddo, i0, p.n);
     // D = rowsum(dO * O) for this wave's 16 rows
     float Dl[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -207,11 +210,13 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
     // ---- pass 1: log-sum-exp of every row (online, per lane over its 4 rows x 16 columns per tile; lanes of a row merged at the end)
     float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, l[4] = {0.f, 0.f, 0.f, 0.f};
     const int nkt_tiles = (p.nkt + 63) / 64;
+    const float* Kbase = p.Kh + (long)sh * p.nkt * 64;
+    const float* Vbase = p.Vh + (long)sh * p.nkt * 64;
     for (int kt = 0; kt < nkt_tiles; ++kt) {
-        load_tile(Ks, p.Kh + (long)sh * p.nkt * 64, kt * 64, p.nkt);
+        load_tile<false>(Ks, Kbase, 64, kt * 64, p.nkt);
         __syncthreads();
-        f32x4 acc[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-        mma64(Qs, TLD, 1, Ks, TLD, 1, acc, m0, lane);
+        f32x4 acc[4] = PK_ZERO4;
+        mma64(Qs, Ks, acc, m0, lane);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
@@ -240,15 +245,16 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
         if (r == 0 && gi < p.n) p.lse[(long)sh * p.n + gi] = lse[i];
     }
     // ---- pass 2: dS and dQ^
-    f32x4 accQ[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    f32x4 accQ[4] = PK_ZERO4;
     for (int kt = 0; kt < nkt_tiles; ++kt) {
-        load_tile(Ks, p.Kh + (long)sh * p.nkt * 64, kt * 64, p.nkt);
-        load_tile(Vs, p.Vh + (long)sh * p.nkt * 64, kt * 64, p.nkt);
+        load_tile<false>(Ks, Kbase, 64, kt * 64, p.nkt);
+        load_tile<true>(Kt, Kbase, 64, kt * 64, p.nkt);
+        load_tile<false>(Vs, Vbase, 64, kt * 64, p.nkt);
         __syncthreads();
-        f32x4 accS[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-        f32x4 accP[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-        mma64(Qs, TLD, 1, Ks, TLD, 1, accS, m0, lane);
-        mma64(dOs, TLD, 1, Vs, TLD, 1, accP, m0, lane);
+        f32x4 accS[4] = PK_ZERO4;
+        f32x4 accP[4] = PK_ZERO4;
+        mma64(Qs, Ks, accS, m0, lane);
+        mma64(dOs, Vs, accP, m0, lane);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
@@ -259,8 +265,8 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
                 Ps[(m0 + kq * 4 + i) * TLD + nb * 16 + r] = ds;
                 if (p.dS && gi < p.n && j >= p.nnull && j < p.nkt) p.dS[((long)sh * p.n + gi) * nreal + (j - p.nnull)] = ds;
             }
-        // this wave's 16 rows of Ps are its own: no workgroup barrier needed before reading them back
-        mma64(Ps, TLD, 1, Ks, 1, TLD, accQ, m0, lane);
+        // this wave's 16 rows of Ps are its own: no workgroup barrier needed before reading them back.  dQ^[i][d] += sum_j dS[i][j] K^[j][d]
+        mma64(Ps, Kt, accQ, m0, lane);
         __syncthreads();
     }
 #pragma unroll
@@ -272,44 +278,55 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
         }
 }
 
+// one workgroup per 64 keys of a head; the scores are computed TRANSPOSED (rows = this wave's 16 keys, columns = the query tile), so P^T / dS^T
+// land in the orientation the dV / dK^ products read them and stay private to the wave
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* Qs = sm; float* dOs = sm + TSZ; float* Ks = sm + 2 * TSZ; float* Vs = sm + 3 * TSZ; float* Ps = sm + 4 * TSZ; float* Ss = sm + 5 * TSZ;
+    float* Ks = sm; float* Vs = sm + TSZ; float* Qs = sm + 2 * TSZ; float* dOs = sm + 3 * TSZ; float* Qt = sm + 4 * TSZ; float* dOt = sm + 5 * TSZ;
+    float* Pt = sm + 6 * TSZ; float* St = sm + 7 * TSZ; float* lse_s = sm + 8 * TSZ; float* D_s = lse_s + 64;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
     const int nkt_tiles = (p.nkt + 63) / 64;
     const int kt = blockIdx.x % nkt_tiles, sh = blockIdx.x / nkt_tiles, h = sh % p.heads, s = sh / p.heads;
     const int j0 = kt * 64, m0 = wv * 16;
-    load_tile(Ks, p.Kh + (long)sh * p.nkt * 64, j0, p.nkt);
-    load_tile(Vs, p.Vh + (long)sh * p.nkt * 64, j0, p.nkt);
-    f32x4 accK[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-    f32x4 accV[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    load_tile<false>(Ks, p.Kh + (long)sh * p.nkt * 64, 64, j0, p.nkt);
+    load_tile<false>(Vs, p.Vh + (long)sh * p.nkt * 64, 64, j0, p.nkt);
+    f32x4 accK[4] = PK_ZERO4;
+    f32x4 accV[4] = PK_ZERO4;
     const int nqt = (p.n + 63) / 64;
+    const float* Qbase = p.Qh + (long)sh * p.n * 64;
+    const float* dObase = p.dO + (long)s * p.n * p.lddo + h * 64;
     for (int qt = 0; qt < nqt; ++qt) {
         const int i0 = qt * 64;
-        __syncthreads();                                          // the previous iteration's readers of Qs / dOs / Ps / Ss are done
-        load_tile(Qs, p.Qh + (long)sh * p.n * 64, i0, p.n);
-        load_tile_rows(dOs, p.dO + (long)s * p.n * p.lddo + h * 64, p.lddo, i0, p.n);
-        __syncthreads();
-        f32x4 accS[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-        f32x4 accP[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-        mma64(Qs, TLD, 1, Ks, TLD, 1, accS, m0, lane);
-        mma64(dOs, TLD, 1, Vs, TLD, 1, accP, m0, lane);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int gi = i0 + m0 + kq * 4 + i;
-            const float lse = gi < p.n ? p.lse[(long)sh * p.n + gi] : 0.f, Dr = gi < p.n ? p.Drow[(long)sh * p.n + gi] : 0.f;
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                float sc, pr = 0.f;
-                if (score(p, s, h, gi, j0 + nb * 16 + r, accS[nb][i], sc)) pr = __expf(sc - lse);
-                Ps[(m0 + kq * 4 + i) * TLD + nb * 16 + r] = pr;
-                Ss[(m0 + kq * 4 + i) * TLD + nb * 16 + r] = pr * (accP[nb][i] - Dr);
-            }
+        __syncthreads();                                          // the previous iteration's readers of the query-side tiles are done
+        load_tile<false>(Qs, Qbase, 64, i0, p.n);
+        load_tile<true>(Qt, Qbase, 64, i0, p.n);
+        load_tile<false>(dOs, dObase, p.lddo, i0, p.n);
+        load_tile<true>(dOt, dObase, p.lddo, i0, p.n);
+        if (threadIdx.x < 64) {
+            const int gi = i0 + threadIdx.x;
+            lse_s[threadIdx.x] = gi < p.n ? p.lse[(long)sh * p.n + gi] : 0.f;
+            D_s[threadIdx.x] = gi < p.n ? p.Drow[(long)sh * p.n + gi] : 0.f;
         }
         __syncthreads();
-        // rows of the results = this wave's 16 keys; contraction over the 64 query rows of the tile (transposed reads of Ps / Ss)
-        mma64(Ps, 1, TLD, dOs, 1, TLD, accV, m0, lane);
-        mma64(Ss, 1, TLD, Qs, 1, TLD, accK, m0, lane);
+        f32x4 accS[4] = PK_ZERO4;
+        f32x4 accP[4] = PK_ZERO4;
+        mma64(Ks, Qs, accS, m0, lane);                            // S^T[j][i]
+        mma64(Vs, dOs, accP, m0, lane);                           // dP^T[j][i] = sum_d V[j][d] dO[i][d]
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const int ci = nb * 16 + r, gi = i0 + ci;
+            const float lse = lse_s[ci], Dr = D_s[ci];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float sc, pr = 0.f;
+                if (score(p, s, h, gi, j0 + m0 + kq * 4 + i, accS[nb][i], sc)) pr = __expf(sc - lse);
+                Pt[(m0 + kq * 4 + i) * TLD + ci] = pr;
+                St[(m0 + kq * 4 + i) * TLD + ci] = pr * (accP[nb][i] - Dr);
+            }
+        }
+        // dV[j][d] += sum_i P^T[j][i] dO^T[d][i];  dK^[j][d] += sum_i dS^T[j][i] Q^T[d][i]   (A rows = this wave's own 16 rows of Pt / St)
+        mma64(Pt, dOt, accV, m0, lane);
+        mma64(St, Qt, accK, m0, lane);
     }
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
@@ -369,13 +386,13 @@ extern "C" int pk_attn_bwd(const float* Qh, const float* Kh, const float* Vh, co
     hipStream_t s = STREAM(stream);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * TSZ * 4) != hipSuccess) return PK_ELAUNCH;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * TSZ * 4) != hipSuccess) return PK_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * TSZ * 4) != hipSuccess) return PK_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TSZ * 4 + 512) != hipSuccess) return PK_ELAUNCH;
         attr_done = true;
     }
     const int nqt = (n + 63) / 64, nktt = (p.nkt + 63) / 64;
-    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3((unsigned)((long)S * heads * nqt)), dim3(256), 5 * TSZ * 4, s, p);
-    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3((unsigned)((long)S * heads * nktt)), dim3(256), 6 * TSZ * 4, s, p);
+    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3((unsigned)((long)S * heads * nqt)), dim3(256), 6 * TSZ * 4, s, p);
+    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3((unsigned)((long)S * heads * nktt)), dim3(256), 8 * TSZ * 4 + 512, s, p);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

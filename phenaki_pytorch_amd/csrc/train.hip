@@ -463,7 +463,8 @@ extern "C" int pk_leaky_bwd(const float* y, long ldy, const float* dy, long lddy
 }
 
 // dx = dy + transposed stencil of dy;  part: (pk_peg_wgrad_parts(rows), 27, D) partial tap gradients (finish with pk_colsum over 27 * D columns)
-extern "C" int pk_peg_wgrad_parts(long rows) { long p = (rows + 127) / 128; return (int)(p < 1 ? 1 : (p > 512 ? 512 : p)); }
+// ~16 positions per block (2 row lanes at D = 512): 288 blocks at 4608 positions -- 36 blocks of 128 positions left 7 of 8 CUs idle (346 us)
+extern "C" int pk_peg_wgrad_parts(long rows) { long p = (rows + 15) / 16; return (int)(p < 1 ? 1 : (p > 1024 ? 1024 : p)); }
 extern "C" int pk_peg_bwd(const float* dy, const float* x, const float* wt, float* dx, float* part, int B, int T, int H, int W, int D, int causal, void* stream) {
     if (!dy || !wt || !dx || B <= 0 || T <= 0 || H <= 0 || W <= 0 || D <= 0 || (part && !x)) return PK_EINVAL;
     const int dv = D >> 2;
