@@ -9,7 +9,7 @@ import os
 
 from oracle import phenaki_oracle as O
 from oracle import weights
-from oracle.configs import TINY
+from oracle.configs import FULL, TINY, oracle_cfgs, state_dicts
 from tests.util import close, load_product, record_parity
 
 pytestmark = pytest.mark.gpu
@@ -386,3 +386,39 @@ def test_training_step_variants_run_and_match_oracle_autograd(variant):
     assert abs(float(loss.detach()) - float(ref['loss'].detach())) <= 2e-4 * abs(float(ref['loss'].detach()))
     for got, want in probes:
         close(got.grad.cpu(), want.grad, 1e-3, f'{variant} gradient probe')
+
+
+@pytest.mark.parametrize('dtype,tol', [('fp32', 1e-3), ('bf16x3', 1e-3)])
+def test_training_step_full_config_matches_oracle_autograd(dtype, tol):
+    """BASELINE geometry (dim 512, depth 6 + 6, 8 heads, n = 576 = 9 key tiles, vocab 65 536 in 32 slabs, inner 1365, context 12 + 2 null keys):
+    loss.backward() of Phenaki.forward against torch autograd through the (reference-pinned) oracle on CPU, same three draws; all
+    gradients of both networks"""
+    _, mg_sd, cr_sd = state_dicts('full')
+    _, mgc, crc = oracle_cfgs(FULL)
+    _, mg, cr, ph = load_product('full', FULL, dtype=dtype)
+    gen = torch.Generator().manual_seed(78)
+    ids = torch.randint(0, 65536, (1, 576), generator=gen)
+    ctx = weights.synthetic_context(1, 12, 768, seed=1, pad_last=3)
+    draws = dict(rand_step=torch.tensor([7]), perm_noise=weights.uniform_noise((1, 576), 710),
+                 gumbel_u=weights.uniform_noise((1, 576, 65536), 711))
+    leaf = lambda sd: {k: (v.clone().requires_grad_() if v.is_floating_point() and not k.endswith('.beta') else v) for k, v in sd.items()}
+    mgl, crl = leaf(mg_sd), leaf(cr_sd)
+    ref = O.phenaki_forward_loss(mgl, mgc, crl, crc, ids, patch_shape=(9, 8, 8), context=ctx, steps=FULL['steps'], mask_id=65536, **draws)
+    ref['loss'].backward()
+    loss = ph(video_codebook_ids=ids.view(1, 9, 8, 8).cuda(), text_embeds=ctx.cuda(), _draws=draws)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref['loss'].detach())) <= 2e-4 * abs(float(ref['loss'].detach()))
+    named = [(f'maskgit.{k}', v, mgl[k]) for k, v in mg.named_parameters()] + [(f'critic.{k}', v, crl[k]) for k, v in cr.named_parameters()]
+    top = max(float(r.grad.abs().max()) for _, _, r in named if r.grad is not None and r.numel())
+    errs = {}
+    for name, prm, r in named:
+        if r.grad is None or r.numel() == 0:
+            assert prm.grad is None or prm.numel() == 0, name
+            continue
+        if float(r.grad.abs().max()) < 1e-6 * top:
+            assert float(prm.grad.abs().max()) <= 1e-2 * tol * top, name
+            continue
+        errs[name] = close(prm.grad.cpu(), r.grad, tol, f'd {name} ({dtype})')
+    worst = max(errs, key=errs.get)
+    record_parity('training_step_full_vs_oracle_autograd', dict(dtype=dtype, parameters=len(errs), worst=worst, worst_rel_err=errs[worst],
+                                                                median_rel_err=sorted(errs.values())[len(errs) // 2]))
