@@ -27,11 +27,12 @@ def shard_batch(n_items, rank=None, world_size=None):
     return lo, hi
 
 
-def all_gather_batch(local, n_items, group=None):
+def all_gather_batch(local, n_items, group=None, force=False):
     """concatenate per-rank (b_r, ...) tensors along dim 0 into (n_items, ...); ONE collective (all_gather of
-    equal-sized shards; ragged tails are padded to the largest shard and trimmed)."""
+    equal-sized shards; ragged tails are padded to the largest shard and trimmed).  force: issue the collective even in a one-rank
+    group (diagnostics: runs the RCCL path on a single-GPU box)."""
     rank, ws = world()
-    if ws == 1:
+    if ws == 1 and not (force and dist.is_available() and dist.is_initialized()):
         return local
     sizes = [shard_batch(n_items, r, ws) for r in range(ws)]
     bmax = max(hi - lo for lo, hi in sizes)
@@ -55,7 +56,7 @@ def _slice(x, lo, hi):
     return x[lo:hi]
 
 
-def sample_sharded(phenaki, *, num_frames, texts=None, prime_frames=None, batch_size=1, gather=True, **kwargs):
+def sample_sharded(phenaki, *, num_frames, texts=None, prime_frames=None, batch_size=1, gather=True, _force_collective=False, **kwargs):
     """`Phenaki.sample` with the batch split over the ranks; every rank returns the full (B, C, F, H, W) video
     (gather=True) or only its shard."""
     if isinstance(texts, str):
@@ -66,7 +67,7 @@ def sample_sharded(phenaki, *, num_frames, texts=None, prime_frames=None, batch_
     assert hi > lo, f'rank {rank} received an empty shard: batch {n_items} < world size {ws}'
     local = phenaki.sample(num_frames=num_frames, texts=_slice(texts, lo, hi), prime_frames=_slice(prime_frames, lo, hi),
                            batch_size=hi - lo, **kwargs)
-    return all_gather_batch(local, n_items) if gather else local
+    return all_gather_batch(local, n_items, force=_force_collective) if gather else local
 
 
 def make_video_sharded(phenaki, texts_per_item, num_frames, prime_lengths, make_video_fn=None, gather=True):
@@ -93,9 +94,9 @@ def make_video_sharded(phenaki, texts_per_item, num_frames, prime_lengths, make_
 
 # ---------------------------------------------------------------------------------------------- training: gradient exchange
 # The reference trains data-parallel through HF accelerate -> torch DDP (cvivit_trainer.py:241-249, phenaki_trainer.py:378-386:
-# `accelerator.backward(loss)` all-reduces the gradients before `clip_grad_norm_` / `opt.step()`).  The MI355X build has no autograd
-# hooks to hang DDP on (its first backward kernel, train.vocab_cross_entropy, is called explicitly), so the exchange is an explicit
-# step: average the .grad of the given parameters over the ranks in BUCKETS.  xGMI is point-to-point (7 links x ~153 GB/s per GPU):
+# `accelerator.backward(loss)` all-reduces the gradients before `clip_grad_norm_` / `opt.step()`).  The MI355X build keeps the exchange an
+# explicit step between `loss.backward()` (train.py) and `opt.step()` (optim.py) instead of DDP's per-parameter autograd hooks: average the
+# .grad of the given parameters over the ranks in BUCKETS.  xGMI is point-to-point (7 links x ~153 GB/s per GPU):
 # a ring all-reduce is bound by one link, ~2 (R-1)/R x bytes / 153 GB/s, so buckets are sized for link efficiency (64 MB default:
 # ~0.8 ms each at 8 ranks, far above RCCL's per-call latency) and kept few -- the 134 MB of the vocabulary head's weight gradient is
 # 3 buckets.  Each bucket is one flat contiguous buffer (one collective per bucket, not per tensor), reduced in f32.
@@ -114,12 +115,13 @@ def bucket_plan(numels, bucket_elems):
     return plan
 
 
-def all_reduce_gradients(params, bucket_mb=64.0, average=True, group=None):
+def all_reduce_gradients(params, bucket_mb=64.0, average=True, group=None, force=False):
     """in place: p.grad <- mean (or sum) over the ranks of p.grad, for every parameter in `params` that has a gradient.  Identical
-    parameter order on every rank is the caller's contract (as with DDP).  Returns the number of collectives issued."""
+    parameter order on every rank is the caller's contract (as with DDP).  Returns the number of collectives issued.  force: run the
+    collectives even in a one-rank group (diagnostics)."""
     rank, ws = world()
-    grads = [p.grad for p in params if p.grad is not None]
-    if ws == 1 or not grads:
+    grads = [p.grad for p in params if p.grad is not None and p.grad.numel()]
+    if (ws == 1 and not (force and dist.is_available() and dist.is_initialized())) or not grads:
         return 0
     bucket_elems = max(1, int(bucket_mb * (1 << 20) / 4))
     plan = bucket_plan([g.numel() for g in grads], bucket_elems)

@@ -116,3 +116,41 @@ def test_bench_gpus2_launches_two_ranks_by_itself(tmp_path):
         env.pop('PK_BENCH_ONE_DEVICE')
         r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--encode-only'], env=env, capture_output=True, text=True, timeout=300)
         assert r2.returncode != 0 and 'HIP device(s) visible' in (r2.stderr + r2.stdout)
+
+
+def _rccl_one_rank(rank, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    from oracle import weights
+    from oracle.configs import TINY
+    from tests.util import load_product
+    import phenaki_pytorch_amd as P
+    torch.set_grad_enabled(False)
+    _, mg, _, ph = load_product('tiny', TINY, device='cuda:0')
+    ctx_row = weights.synthetic_context(1, 6, TINY['maskgit']['dim_context'], seed=2).cuda()
+    ph.encode_texts = lambda texts, output_device=None: ctx_row.expand(len(texts), -1, -1).contiguous()
+    torch.manual_seed(5)
+    full = P.sample_sharded(ph, texts=['p'] * 3, num_frames=5, cond_scale=5., _force_collective=True)     # all_gather_into_tensor through RCCL
+    seed_used = ph._pk_last_seed
+    direct = ph.sample(texts=['p'] * 3, num_frames=5, cond_scale=5., _seed=seed_used)
+    assert torch.equal(full, direct)
+    params = [torch.nn.Parameter(torch.randn(300, 70, device='cuda')), torch.nn.Parameter(torch.randn(33, device='cuda'))]
+    for p in params:
+        p.grad = torch.randn_like(p)
+    before = [p.grad.clone() for p in params]
+    assert P.all_reduce_gradients(params, bucket_mb=0.05, force=True) == 2             # two buckets, all_reduce through RCCL, averaged over 1 rank
+    assert all(torch.equal(p.grad, b) for p, b in zip(params, before))
+    torch.save(dict(ok=True, version=torch.cuda.nccl.version()), os.path.join(out_dir, 'rccl.pt'))
+    dist.destroy_process_group()
+
+
+def test_rccl_executes_the_collectives_on_this_box(tmp_path):
+    """a ONE-rank RCCL communicator (the most a single-GPU box allows) runs the two collectives of the package on device tensors -- the
+    sampler's all_gather_into_tensor and the training step's bucketed all_reduce -- so the RCCL code path itself is exercised here, not
+    only gloo's; the multi-rank variants above cover ordering and per-rank streams"""
+    mp.spawn(_rccl_one_rank, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(os.path.join(str(tmp_path), 'rccl.pt'), weights_only=False)
+    assert r['ok'] and r['version']
