@@ -538,14 +538,16 @@ class Attention(PackedModule):
         # a position bias given as a BiasSpec reaches the bf16 LDS attention kernel (n >= 64 keys and queries, no null keys / mask /
         # causal) as a 15 KB relative-position table instead of the (heads, n, n) matrix; every other consumer takes the matrix
         bias_table = None
-        if (isinstance(attn_bias, BiasSpec) and _BIAS_TABLE and dtype == L.BF16 and not is_cross and nnull == 0 and n >= 64 and
+        spec = attn_bias if isinstance(attn_bias, BiasSpec) else None
+        x3_lds = dtype == L.BF16X3 and n >= 128                 # split-bf16: the LDS-staged kernel exists in its fixed-offset form only (128-row workgroups)
+        if (isinstance(attn_bias, BiasSpec) and _BIAS_TABLE and (dtype == L.BF16 or x3_lds) and not is_cross and nnull == 0 and n >= 64 and
                 not (_SHORT_FUSED and n <= 64) and kmask is None and not self.causal):
             bias_table, attn_bias = attn_bias.table(), None
         attn_bias = _full_bias(attn_bias)
         # fixed-offset softmax for the long self-attention (pk_attn_fwd score_bound): q^ / k^ are unit vectors times q_scale / k_scale,
         # so |sim| <= scale * max|q_scale . k_scale| (+ 1/64 for the bf16 rounding of the operand images); the table knows its extremes
         score_bound = None
-        if (_ATTN_FIXED and dtype == L.BF16 and not is_cross and nnull == 0 and n > 64 and kmask is None and not self.causal and
+        if (_ATTN_FIXED and (dtype == L.BF16 or x3_lds) and not is_cross and nnull == 0 and n > 64 and kmask is None and not self.causal and
                 (attn_bias is None)):
             c = _cache(self).get(('qk_bound',), [self.q_scale, self.k_scale],
                                  lambda: float((self.q_scale.detach().float() * self.k_scale.detach().float()).abs().max()))
@@ -553,6 +555,8 @@ class Attention(PackedModule):
             lo, hi = (bias_table[3], bias_table[4]) if bias_table is not None else (0., 0.)
             if math.isfinite(qk + hi - lo) and (2 * qk + hi - lo) * 1.4427 < 64:       # else: exponent range too wide for one offset
                 score_bound = qk + hi
+        if dtype == L.BF16X3 and bias_table is not None and score_bound is None:
+            bias_table, attn_bias = None, spec.full            # no single exponent offset covers the range: the matrix form on the running-max kernel
 
         fq = self._folded_q(dtype) if ln_fold_enabled(dtype) else None
         if fq is not None:

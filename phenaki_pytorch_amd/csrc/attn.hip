@@ -383,7 +383,22 @@ __device__ __forceinline__ void lds_frag_vt(Frag<bf16>& f, const char* tile, int
     f.v = *reinterpret_cast<const u32x4*>(tile + row * 128 + (slot << 4));
 }
 
-// ---- LDS-staged variant (bf16): one workgroup = 4 waves = 64*QF query rows of ONE (sequence, head).  K and V^T tiles of
+// split-bf16 images (common.hpp bf16x3p): a 64-element row is two 128-byte blocks [hi x 32 | lo x 32]; block c of every row of a tile forms a
+// sub-tile [64 rows][128 B] with the same slot swizzle as the bf16 tile, hi in slots 0..3, lo in slots 4..7 (tile = the sub-tile of chunk c)
+__device__ __forceinline__ void lds_frag_k(Frag<bf16x3p>& f, const char* tile, int row, int chunk, int g) {
+    const char* base = tile + chunk * 8192 + row * 128;
+    f.hi = *reinterpret_cast<const u32x4*>(base + ((g ^ attn_ksw(row)) << 4));
+    f.lo = *reinterpret_cast<const u32x4*>(base + (((4 + g) ^ attn_ksw(row)) << 4));
+}
+__device__ __forceinline__ void lds_frag_vt(Frag<bf16x3p>& f, const char* tile, int row, int kc, int g) {
+    const char* base = tile + kc * 8192 + row * 128;
+    f.hi = *reinterpret_cast<const u32x4*>(base + ((g ^ (row & 7)) << 4));
+    f.lo = *reinterpret_cast<const u32x4*>(base + (((4 + g) ^ (row & 7)) << 4));
+}
+__device__ __forceinline__ void frag_ones(Frag<bf16>& f) { f.v = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}; }
+__device__ __forceinline__ void frag_ones(Frag<bf16x3p>& f) { f.hi = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}; f.lo = u32x4{0, 0, 0, 0}; }
+
+// ---- LDS-staged variant (bf16; T = bf16x3p: the split-bf16 images, tiles twice as large): one workgroup = 4 waves = 64*QF query rows of ONE (sequence, head).  K and V^T tiles of
 // 64 keys are fetched once per workgroup in full 128-byte lines by LDS-DMA (buffer_load ... lds) into a 2-stage ring
 // and read back as MFMA fragments with ds_read_b128 / ds_read_b64 (XOR-swizzled on the DMA source side, conflict-free),
 // instead of every wave pulling fragment-shaped pieces (16 rows x 64 B per instruction) through the texture path.
@@ -392,9 +407,12 @@ typedef __attribute__((address_space(3))) void* attn_lds_ptr;
 // The K / V^T ring has 2 stages: 3- and 4-stage rings behind a counted vmcnt were measured slower (35.1 / 43.3 vs 32.7 us at
 // n = 576, profiles/attn_variants_r02.txt -- the loop is bound by its VALU stream, not by DMA latency) and were removed.
 // FIX: fixed-offset softmax (AttnArgs::off2), host-selected when there is no key mask and no causal mask.
-template <int QF, bool PF, bool TAB = false, bool FIX = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (PF ? 4 : (TAB ? 3 : 5)) : ((FIX && !TAB) ? 4 : 3)))) void attn_fwd_lds_kernel(const AttnArgs p, uint32_t kv_bytes) {
+template <int QF, bool PF, bool TAB = false, bool FIX = false, typename T = bf16>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 1 : (QF == 1 ? (PF ? 4 : (TAB ? 3 : 5)) : ((FIX && !TAB) ? 4 : 3))))) void attn_fwd_lds_kernel(const AttnArgs p, uint32_t kv_bytes) {
     constexpr int STAGES = 2;
+    constexpr bool X3 = sizeof(T) == 4;                                   // split-bf16 image: 4 bytes per element, two 128-byte blocks per 64-element row
+    constexpr int NB = X3 ? 2 : 1;                                        // 128-byte blocks per tile row
+    constexpr int KT = 8192 * NB;                                         // bytes of a K (or V^T) tile of 64 keys
 #ifdef PK_TIMELINE
     const int tl_wg = blockIdx.x == 0 ? 0 : blockIdx.x == 8 ? 1 : blockIdx.x == 1 ? 2 : blockIdx.x == gridDim.x / 2 ? 3 :
                       blockIdx.x == gridDim.x - 8 ? 4 : blockIdx.x == 256 ? 5 : blockIdx.x == 300 ? 6 : blockIdx.x == 511 ? 7 : -1;
@@ -402,7 +420,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
     PK_ATL_K(0);
 #endif
     extern __shared__ __attribute__((aligned(16))) char smem[];          // STAGES x (K 8 KB | V^T 8 KB) [| bias table | position codes]
-    constexpr int STAGE = 16384;
+    constexpr int STAGE = 2 * KT;
     float* tab = reinterpret_cast<float*>(smem + STAGES * STAGE);         // TAB: this head's bias table, then the position codes of all keys
     int* codes = reinterpret_cast<int*>(smem + STAGES * STAGE + ((p.tab_len * 4 + 15) & ~15));
     const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
@@ -424,20 +442,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = (wave * 2 + i) * 8 + prow;                        // 0..63
-        offK[i] = ((uint32_t)sh * p.nk_pad + row) * 128u + (uint32_t)((pslot ^ attn_ksw(row)) * 16);
-        offV[i] = ((uint32_t)sh * 64u + row) * (uint32_t)p.nk_pad * 2u + (uint32_t)((pslot ^ (row & 7)) * 16);
+        offK[i] = ((uint32_t)sh * p.nk_pad + row) * (128u * NB) + (uint32_t)((pslot ^ attn_ksw(row)) * 16);
+        offV[i] = ((uint32_t)sh * 64u + row) * (uint32_t)p.nk_pad * (2u * NB) + (uint32_t)((pslot ^ (row & 7)) * 16);
     }
     auto issue = [&](int kb, int stage) {
         char* base = smem + stage * STAGE;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (attn_lds_ptr)(base + (wave * 2 + i) * 1024), 16, offK[i], kb * 128, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (attn_lds_ptr)(base + 8192 + (wave * 2 + i) * 1024), 16, offV[i], kb * 2, 0, 0);
-        }
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {                                 // block c of the rows -> sub-tile c
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (attn_lds_ptr)(base + c * 8192 + (wave * 2 + i) * 1024), 16, offK[i] + c * 128, kb * 128 * NB, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (attn_lds_ptr)(base + KT + c * 8192 + (wave * 2 + i) * 1024), 16, offV[i] + c * 128, kb * 2 * NB, 0, 0);
+            }
     };
 
-    const bf16* Qp = reinterpret_cast<const bf16*>(p.Qp) + ((size_t)sh * p.nq_pad + (active ? q0 : 0)) * DH;
-    Frag<bf16> fq[QF][2];
+    const T* Qp = reinterpret_cast<const T*>(p.Qp) + ((size_t)sh * p.nq_pad + (active ? q0 : 0)) * DH;
+    Frag<T> fq[QF][2];
 #pragma unroll
     for (int qf = 0; qf < QF; ++qf)
 #pragma unroll
@@ -512,16 +532,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
             // tail tile (wave-uniform, at most once per workgroup): the V^T columns of keys >= nk carry p = 0 but may hold anything
             // (pk_qkv_project never writes them; 0 * NaN = NaN) -> zero them in the LDS image, all 256 threads, one extra barrier.
             // (Masking the fragments in registers instead cost 13 VGPRs and spilled the main loop.)
-            char* vz = smem + (t % STAGES) * STAGE + 8192;
+            char* vz = smem + (t % STAGES) * STAGE + KT;
             const int d = threadIdx.x >> 2, k0 = (threadIdx.x & 3) * 16;
             for (int kk = k0; kk < k0 + 16; ++kk)
-                if (kb + kk >= nk) *reinterpret_cast<u16*>(vz + d * 128 + ((((kk >> 3) ^ (d & 7))) << 4) + (kk & 7) * 2) = 0;
+                if (kb + kk >= nk) {
+                    if (X3) {                                              // key kk: sub-tile kk >> 5, position kk & 31 in both planes of the block
+                        char* blk = vz + (kk >> 5) * 8192 + d * 128;
+                        const int pos = kk & 31;
+                        *reinterpret_cast<u16*>(blk + ((((pos >> 3)) ^ (d & 7)) << 4) + (pos & 7) * 2) = 0;
+                        *reinterpret_cast<u16*>(blk + (((4 + (pos >> 3)) ^ (d & 7)) << 4) + (pos & 7) * 2) = 0;
+                    } else {
+                        *reinterpret_cast<u16*>(vz + d * 128 + ((((kk >> 3) ^ (d & 7))) << 4) + (kk & 7) * 2) = 0;
+                    }
+                }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
         if (!active) continue;
         const char* kt = smem + (t % STAGES) * STAGE;
-        const char* vt = kt + 8192;
+        const char* vt = kt + KT;
         const bool simple = (kb + 64 <= nk) && !km && !p.causal;
         const bool vbias = vb_all && simple;
         const bool plain = simple && (!bias || vbias);
@@ -538,7 +567,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
         for (int f = 0; f < 4; ++f)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                Frag<bf16> fk;
+                Frag<T> fk;
                 lds_frag_k(fk, kt, attn_kperm(f, lr), c, g);
 #pragma unroll
                 for (int qf = 0; qf < QF; ++qf) st[qf][f] = mma(fk, fq[qf][c], st[qf][f]);
@@ -644,16 +673,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
         }
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
-            Frag<bf16> fp[QF];
+            Frag<T> fp[QF];
 #pragma unroll
             for (int qf = 0; qf < QF; ++qf) {
                 const float (&src)[16] = pr[qf];
-                fp[qf].v = u32x4{pack_bf2(src[kc * 8 + 0], src[kc * 8 + 1]), pack_bf2(src[kc * 8 + 2], src[kc * 8 + 3]),
-                                 pack_bf2(src[kc * 8 + 4], src[kc * 8 + 5]), pack_bf2(src[kc * 8 + 6], src[kc * 8 + 7])};
+                const float p8[8] = {src[kc * 8 + 0], src[kc * 8 + 1], src[kc * 8 + 2], src[kc * 8 + 3], src[kc * 8 + 4], src[kc * 8 + 5], src[kc * 8 + 6], src[kc * 8 + 7]};
+                frag_from_f32(fp[qf], p8);
             }
 #pragma unroll
             for (int df = 0; df < 4; ++df) {
-                Frag<bf16> fv;
+                Frag<T> fv;
                 lds_frag_vt(fv, vt, df * 16 + lr, kc, g);
 #pragma unroll
                 for (int qf = 0; qf < QF; ++qf) o[qf][df] = mma(fv, fp[qf], o[qf][df]);
@@ -661,8 +690,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QF == 1 ? (
             if (FIX) {
                 // row sums on the matrix core: a V^T block of ones gives l = sum_j bf16(p_j) in every lane of the query row -- the SAME
                 // rounded weights the numerator uses (a dominant key contributes exactly p / p), no VALU adds, no cross-lane fold
-                Frag<bf16> ones;
-                ones.v = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+                Frag<T> ones;
+                frag_ones(ones);
 #pragma unroll
                 for (int qf = 0; qf < QF; ++qf) lsum[qf] = mma(ones, fp[qf], lsum[qf]);
             }
@@ -934,6 +963,34 @@ extern "C" int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void
         } else {
             if (pf) hipLaunchKernelGGL((attn_fwd_lds_kernel<1, true>), g2, block, 32768, s, a, kv_bytes);
             else hipLaunchKernelGGL((attn_fwd_lds_kernel<1, false>), g2, block, 32768, s, a, kv_bytes);
+        }
+        PK_CHECK_LAUNCH();
+        return PK_OK;
+    }
+    if (dtype == 2 && use_lds && nnull + n_kv >= 64 && nq >= 128 && score_bound == score_bound && fabsf(score_bound) < 1e4f && !kmask && !causal && !bias &&
+        out_is_f32 && (size_t)S * h * nk_pad * 256 < 0xFFFFFFF0ull &&
+        !((reinterpret_cast<uintptr_t>(Qp) | reinterpret_cast<uintptr_t>(Kp) | reinterpret_cast<uintptr_t>(Vt)) & 127)) {
+        // split-bf16 images, fixed-offset softmax (round 3): the same LDS-staged kernel on tiles twice as large (64 KB ring + the bias table:
+        // one workgroup of 128 query rows per CU); 167 us for the LDS-free running-max kernel at S*h = 128, n = 576
+        const int qblocks = (nq_pad + 127) / 128;
+        const uint32_t kv_bytes = (uint32_t)((size_t)S * h * nk_pad * 256);
+        const size_t lds = (size_t)2 * 32768 + (bias_tab ? (((size_t)tab_len * 4 + 15) & ~(size_t)15) + (((size_t)n_kv * 4 + 15) & ~(size_t)15) : 0);
+        if (lds > 160 * 1024) return PK_EINVAL;
+        static bool attr_tab = false, attr_plain = false;
+        a.off2 = ceilf(score_bound * ATTN_LOG2E);
+        dim3 g2((unsigned)(S * h * qblocks));
+        if (bias_tab) {
+            if (!attr_tab) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_lds_kernel<2, false, true, true, bf16x3p>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return PK_ELAUNCH;
+                attr_tab = true;
+            }
+            hipLaunchKernelGGL((attn_fwd_lds_kernel<2, false, true, true, bf16x3p>), g2, block, lds, s, a, kv_bytes);
+        } else {
+            if (!attr_plain) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_lds_kernel<2, false, false, true, bf16x3p>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return PK_ELAUNCH;
+                attr_plain = true;
+            }
+            hipLaunchKernelGGL((attn_fwd_lds_kernel<2, false, false, true, bf16x3p>), g2, block, lds, s, a, kv_bytes);
         }
         PK_CHECK_LAUNCH();
         return PK_OK;

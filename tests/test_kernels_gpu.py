@@ -926,6 +926,46 @@ def test_attention_fixed_offset_ignores_poisoned_pad_rows(L, dims, heads):
                 close(o.float(), ref, 1.2e-2, f'{tag}, pads = {poison}, {"fixed offset" if sb else "running max"}')
 
 
+@pytest.mark.parametrize('dims,S,heads', [((9, 8, 8), 2, 8), ((4, 9, 9), 2, 2), ((3, 8, 8), 3, 2), ((2, 9, 12), 1, 1)])
+def test_attention_split_bf16_fixed_offset_lds_kernel(L, dims, S, heads):
+    """round 3: the LDS-staged fixed-offset attention on split-bf16 images (pk_attn_fwd dtype 2 with score_bound, 128-row workgroups, bias
+    table in LDS or no bias) against an f64 softmax of the same f32 operands -- f32-grade -- and against the LDS-free running-max kernel;
+    pad rows / columns poisoned (n % 64 != 0 cases)."""
+    from phenaki_pytorch_amd.attention import ContinuousPositionBias
+    n = dims[0] * dims[1] * dims[2]
+    torch.manual_seed(12)
+    cpb = ContinuousPositionBias(dim=64, heads=heads, num_dims=3).cuda()
+    nq_pad, nk_pad = L.attn_pads(n, n, 0)
+    Q32 = torch.randn(S * heads, nq_pad, 64, generator=g(291)) * 0.35
+    K32 = torch.randn(S * heads, nk_pad, 64, generator=g(292)) * 0.35
+    V32 = torch.randn(S * heads, 64, nk_pad, generator=g(293))
+    Q, K, V = Q32[:, :n].double(), K32[:, :n].double(), V32[:, :, :n].double()
+    for poison in (0.0, float('nan'), float('inf')):
+        Qx, Kx, Vx = Q32.clone(), K32.clone(), V32.clone()
+        if n < nq_pad:
+            Qx[:, n:] = poison
+        if n < nk_pad:
+            Kx[:, n:] = poison
+            Vx[:, :, n:] = poison
+        Qp = L.split_planes(Qx.reshape(-1, 64).cuda()).reshape(-1)
+        Kp = L.split_planes(Kx.reshape(-1, 64).cuda()).reshape(-1)
+        Vt = L.split_planes(Vx.reshape(-1, nk_pad).cuda()).reshape(-1)
+        for tag, kw, extra in (('no bias', {}, 0.), ('table', dict(bias_table=cpb.table(*dims)), cpb(*dims).double().cpu().repeat(S, 1, 1))):
+            sim = Q @ K.transpose(1, 2) + extra
+            ref = (sim.softmax(-1) @ V.transpose(1, 2)).view(S, heads, n, 64).permute(0, 2, 1, 3).reshape(S * n, heads * 64)
+            bound = float(sim.max()) + 0.3
+            o_fix = torch.full((S * n, heads * 64), float('nan'), device='cuda')
+            L.attn_fwd(L.BF16X3, Qp, Kp, Vt, o_fix, S, heads, n, n, 0, score_bound=bound, **kw)
+            close(o_fix, ref, 2e-4, f'split-bf16 fixed-offset attention vs f64 softmax ({tag}, pads {poison}, {dims})')
+            o_far = torch.full_like(o_fix, float('nan'))
+            L.attn_fwd(L.BF16X3, Qp, Kp, Vt, o_far, S, heads, n, n, 0, score_bound=bound + 9, **kw)
+            close(o_far, ref, 2e-4, f'split-bf16 fixed-offset attention, loose bound ({tag})')
+            if tag == 'no bias':
+                o_run = torch.full_like(o_fix, float('nan'))
+                L.attn_fwd(L.BF16X3, Qp, Kp, Vt, o_run, S, heads, n, n, 0)
+                close(o_fix, o_run, 2e-4, 'fixed-offset LDS kernel vs running-max kernel (split-bf16)')
+
+
 @pytest.mark.parametrize('variant', [0, 3, 8, 9, 24, 27])
 @pytest.mark.parametrize('M,N,K', [(300, 200, 96), (1000, 520, 1368), (4608, 512, 512), (129, 2736, 512), (512, 512, 6144), (77, 4, 64)])
 def test_gemm_split_bf16(L, variant, M, N, K):
