@@ -187,9 +187,21 @@ class MaskGit(_TokenTrunk):
         L.cfg_mix(e, b, n, 0, None, b * n, float(cond_scale), True, mixed, self.dim)
         return self._logits(mixed, b * n, b, n)
 
-    @torch.no_grad()
     def forward(self, x, cond_drop_prob=0., text_mask=None, video_mask=None, video_patch_shape=None,
                 return_embeds=False, **kwargs):
+        """phenaki_pytorch.py:163-213.  Grad mode on + trainable parameters: the logits / embeddings carry an autograd graph over this
+        library's backward kernels (train.py); otherwise the fused inference path."""
+        from .train import maskgit_forward_train, wants_grad
+        if wants_grad(self):
+            context = kwargs.pop('context', None)
+            assert not kwargs, f'unexpected arguments {sorted(kwargs)}'
+            return maskgit_forward_train(self, x, cond_drop_prob=cond_drop_prob, text_mask=text_mask, video_mask=video_mask,
+                                         video_patch_shape=video_patch_shape, return_embeds=return_embeds, context=context)
+        with torch.no_grad():
+            return self._forward_value(x, cond_drop_prob, text_mask, video_mask, video_patch_shape, return_embeds, **kwargs)
+
+    def _forward_value(self, x, cond_drop_prob=0., text_mask=None, video_mask=None, video_patch_shape=None,
+                       return_embeds=False, **kwargs):
         x, vps = self._prepare(x, text_mask, video_patch_shape)
         b, n = x.shape
         context = kwargs.pop('context', None)
@@ -260,8 +272,16 @@ class TokenCritic(_TokenTrunk):
         with_null = cond_scale != 1 and exists(context)      # without context both passes are identical
         return self._scores(x, vps, context, kwargs.get('text_mask'), kwargs.get('video_mask'), cond_scale, with_null)
 
-    @torch.no_grad()
     def forward(self, x, text_mask=None, cond_drop_prob=None, context=None, video_mask=None, video_patch_shape=None, **kwargs):
+        """phenaki_pytorch.py:265-302; under grad mode with trainable parameters: with an autograd graph (train.py)"""
+        from .train import critic_forward_train, wants_grad
+        if wants_grad(self):
+            return critic_forward_train(self, x, text_mask=text_mask, cond_drop_prob=cond_drop_prob, context=context, video_mask=video_mask,
+                                        video_patch_shape=video_patch_shape)
+        with torch.no_grad():
+            return self._forward_value(x, text_mask, cond_drop_prob, context, video_mask, video_patch_shape)
+
+    def _forward_value(self, x, text_mask=None, cond_drop_prob=None, context=None, video_mask=None, video_patch_shape=None):
         x, vps = self._flatten(x, video_patch_shape)
         b = x.shape[0]
         if exists(context) and not exists(text_mask):
@@ -306,8 +326,19 @@ class SelfCritic(PackedModule):
         L.critic_head(e, w, bias, e.shape[1], b, n, 0, with_null, float(cond_scale), None, 0., out)
         return out
 
-    @torch.no_grad()
     def forward(self, x, *args, **kwargs):
+        """phenaki_pytorch.py:334-336; under grad mode with trainable parameters: with an autograd graph (train.py)"""
+        from .train import critic_forward_train, wants_grad
+        if wants_grad(self):
+            names = ('cond_drop_prob', 'text_mask', 'video_mask', 'video_patch_shape')
+            kw = dict(zip(names, args))
+            kw.update(kwargs)
+            return critic_forward_train(self, x, text_mask=kw.get('text_mask'), cond_drop_prob=kw.get('cond_drop_prob'), context=kw.get('context'),
+                                        video_mask=kw.get('video_mask'), video_patch_shape=kw.get('video_patch_shape'))
+        with torch.no_grad():
+            return self._forward_value(x, *args, **kwargs)
+
+    def _forward_value(self, x, *args, **kwargs):
         embeds = self.maskgit(x, *args, return_embeds=True, **kwargs)
         b, n, d = embeds.shape
         w, bias = self.head()

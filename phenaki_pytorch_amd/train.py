@@ -474,6 +474,49 @@ class _VocabCrossEntropy(torch.autograd.Function):
         return dE, dW, (db if ctx.has_bias else None), None, None, None, None
 
 
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b on (M, K) f32 rows (MaskGit.to_logits when a caller wants the logits themselves under autograd)"""
+
+    @staticmethod
+    def forward(ctx, x, W, b, dtype):
+        ctx.save_for_backward(x, W)
+        ctx.dtype, ctx.has_bias = dtype, b is not None
+        return linear_fwd(dtype, x, W.detach(), bias=b.detach() if b is not None else None)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx, dW = linear_bwd(ctx.dtype, x, W.detach(), dy, need_dx=ctx.needs_input_grad[0])
+        db = L.colsum(dy, dy.shape[0], dy.shape[1], _f32((dy.shape[1],), dy.device)) if ctx.has_bias else None
+        return dx, dW, db, None
+
+
+class _RowDot(torch.autograd.Function):
+    """z = e w^T + b for a single output unit (the critic heads: Linear(dim, 1) + Rearrange('... 1 -> ...'), phenaki_pytorch.py:246-249)"""
+
+    @staticmethod
+    def forward(ctx, e, w, b):
+        M, D = e.shape
+        z = _f32((M,), e.device)
+        L.bce_head(e, w.detach().reshape(-1), b.detach(), None, M, D, logits=z)
+        ctx.save_for_backward(e, w)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        e, w = ctx.saved_tensors
+        M, D = e.shape
+        dev = e.device
+        dzp = _f32((M, 4), dev)                                         # the one output unit padded to 4 columns for the GEMM's vector epilogue
+        L.pack(dz.contiguous().view(M, 1), M, 1, False, dzp, 4, 0)
+        wp = _zeros((4, D), dev)
+        L.pack(w.detach().reshape(1, D), 1, D, False, wp, D, 0)
+        de, dwp = linear_bwd(L.F32, e, wp, dzp)
+        db = L.colsum(dzp, M, 1, _f32((1,), dev), ld=4)
+        return de, dwp[:1].reshape(w.shape).contiguous(), db
+
+
 class _BCEHead(torch.autograd.Function):
     """mean BCE-with-logits of (e w^T + b) against the labels (phenaki_pytorch.py:246-249 / :320-322 heads, :673-676 loss)"""
 
@@ -571,6 +614,51 @@ def trunk_train(model, ids2d, video_patch_shape, *, context=None, text_mask=None
         ctx2 = context.reshape(b * n_ctx, context.shape[-1]).float().contiguous()
     return transformer_train(model.transformer, x, b, n, dt, video_shape=(b, *video_patch_shape), attn_bias=bias, context2d=ctx2, n_ctx=n_ctx,
                              self_attn_mask=_u8(video_mask), cross_attn_context_mask=_u8(text_mask) if ctx2 is not None else None)
+
+
+def wants_grad(*modules):
+    """grad mode on and some parameter of the given modules is trainable: the call has to build an autograd graph"""
+    return torch.is_grad_enabled() and any(p.requires_grad for m in modules if m is not None for p in m.parameters())
+
+
+def maskgit_forward_train(mg, x, *, cond_drop_prob=0., text_mask=None, video_mask=None, video_patch_shape=None, return_embeds=False, context=None):
+    """MaskGit.forward (phenaki_pytorch.py:163-213) with an autograd graph: logits (b, n, num_tokens) or, return_embeds, the trunk output"""
+    from .phenaki import prob_mask_like
+    x, vps = mg._prepare(x, text_mask, video_patch_shape)
+    b, n = x.shape
+    if exists(context) and not exists(text_mask):
+        text_mask = torch.ones(context.shape[:2], device=x.device, dtype=torch.bool)
+    if cond_drop_prob > 0 and exists(text_mask):
+        keep_mask = prob_mask_like((b,), 1 - cond_drop_prob, device=x.device)
+        text_mask = keep_mask[:, None] & text_mask
+    e = trunk_train(mg, x, vps, context=context, text_mask=text_mask, video_mask=video_mask, use_bias=True, use_cross=not mg.unconditional,
+                    alpha=mg.gradient_shrink_alpha)
+    if return_embeds:
+        return e.view(b, n, mg.dim)
+    logits = _Linear.apply(e, mg.to_logits.weight, mg.to_logits.bias, compute_dtype_of(mg))
+    return logits.view(b, n, -1)
+
+
+def critic_forward_train(critic, x, *, text_mask=None, cond_drop_prob=None, context=None, video_mask=None, video_patch_shape=None):
+    """TokenCritic.forward (phenaki_pytorch.py:265-302) / SelfCritic.forward (:334-336) with an autograd graph: scores (b, n)"""
+    from .phenaki import SelfCritic, prob_mask_like
+    if isinstance(critic, SelfCritic):
+        e = maskgit_forward_train(critic.maskgit, x, cond_drop_prob=cond_drop_prob or 0., text_mask=text_mask, video_mask=video_mask,
+                                  video_patch_shape=video_patch_shape, return_embeds=True, context=context)
+        b, n, D = e.shape
+        head = critic.to_pred[0]
+        return _RowDot.apply(e.reshape(b * n, D), head.weight, head.bias).view(b, n)
+    x, vps = critic._flatten(x, video_patch_shape)
+    b, n = x.shape
+    if exists(context) and not exists(text_mask):
+        text_mask = torch.ones(context.shape[:2], device=x.device, dtype=torch.bool)
+    if exists(context) and exists(cond_drop_prob) and cond_drop_prob > 0:
+        keep_mask = prob_mask_like((b,), 1 - cond_drop_prob, device=x.device)
+        text_mask = keep_mask[:, None] & text_mask
+    e = trunk_train(critic, x, vps, context=context if critic.has_cross_attn else None, text_mask=text_mask, video_mask=video_mask,
+                    use_bias=False, use_cross=critic.has_cross_attn, alpha=1.0)
+    head = critic.to_logits[0]
+    return _RowDot.apply(e, head.weight, head.bias).view(b, n)
 
 
 def phenaki_loss(ph, videos=None, *, texts=None, video_codebook_ids=None, video_frame_mask=None, text_embeds=None, cond_drop_prob=None,

@@ -238,7 +238,7 @@ def test_embed_and_bce_head_gradients():
     ec, wc, bc = e.cuda().requires_grad_(), w.cuda().requires_grad_(), bb.cuda().requires_grad_()
     with torch.enable_grad():
         loss = _BCEHead.apply(ec, wc, bc, y.cuda())
-    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-5 * abs(float(ref.detach()))
     (loss * 1.7).backward()
     close(ec.grad.cpu(), el.grad, 1e-4, 'bce de')
     close(wc.grad.cpu(), wl.grad, 1e-4, 'bce dw')
@@ -422,3 +422,52 @@ def test_training_step_full_config_matches_oracle_autograd(dtype, tol):
     worst = max(errs, key=errs.get)
     record_parity('training_step_full_vs_oracle_autograd', dict(dtype=dtype, parameters=len(errs), worst=worst, worst_rel_err=errs[worst],
                                                                 median_rel_err=sorted(errs.values())[len(errs) // 2]))
+
+
+def test_module_forwards_carry_autograd_graphs():
+    """MaskGit.forward / TokenCritic.forward / SelfCritic.forward called directly under grad mode (a user's own loss on the logits, as the
+    reference allows): values equal the no_grad inference path, gradients equal torch autograd through the oracle"""
+    import phenaki_pytorch_amd as P
+    cv, mg, cr, ph = load_product('tiny', TINY)
+    _, mg_sd, cr_sd = state_dicts('tiny')
+    _, mgc, crc = oracle_cfgs(TINY)
+    leaf = lambda sd: {k: (v.clone().requires_grad_() if v.is_floating_point() and not k.endswith('.beta') else v) for k, v in sd.items()}
+    mgl, crl = leaf(mg_sd), leaf(cr_sd)
+    g = torch.Generator().manual_seed(13)
+    b, shape = 2, (3, 4, 4)
+    ids = torch.randint(0, TINY['maskgit']['num_tokens'] + 1, (b, *shape), generator=g)
+    ctx = weights.synthetic_context(b, 6, TINY['maskgit']['dim_context'], seed=4, pad_last=1)
+    tmask = torch.any(ctx != 0, dim=-1)
+    G = torch.randn(b, 48, TINY['maskgit']['num_tokens'], generator=g)
+    ref = O.maskgit_forward(mgl, mgc, ids.flatten(1), video_patch_shape=shape, context=ctx, text_mask=tmask)
+    ref.backward(G)
+    with torch.no_grad():
+        val = mg(ids.cuda(), context=ctx.cuda(), text_mask=tmask.cuda())
+    out = mg(ids.cuda(), context=ctx.cuda(), text_mask=tmask.cuda())
+    assert out.requires_grad and not val.requires_grad
+    close(out.detach().cpu(), ref.detach(), 1e-3, 'MaskGit.forward logits (autograd path)')
+    close(out.detach(), val, 1e-3, 'autograd path vs inference path')
+    out.backward(G.cuda())
+    for name in ('to_logits.weight', 'to_logits.bias', 'token_emb.weight', 'transformer.layers.1.2.to_kv.weight', 'continuous_pos_bias.net.1.0.weight'):
+        prm = dict(mg.named_parameters())[name]
+        close(prm.grad.cpu(), mgl[name].grad, 1e-3, f'MaskGit.forward d {name}')
+    # TokenCritic
+    Gc = torch.randn(b, 48, generator=g)
+    refc = O.critic_forward(crl, crc, ids.flatten(1).clamp(max=TINY['critic']['num_tokens'] - 1), video_patch_shape=shape, context=ctx, text_mask=tmask)
+    refc.backward(Gc)
+    cids = ids.clamp(max=TINY['critic']['num_tokens'] - 1).cuda()
+    outc = cr(cids, context=ctx.cuda(), text_mask=tmask.cuda())
+    assert outc.requires_grad and tuple(outc.shape) == (b, 48)
+    close(outc.detach().cpu(), refc.detach(), 1e-3, 'TokenCritic.forward (autograd path)')
+    outc.backward(Gc.cuda())
+    for name in ('to_logits.0.weight', 'to_logits.0.bias', 'pos_emb.weight', 'transformer.layers.0.3.1.weight'):
+        prm = dict(cr.named_parameters())[name]
+        close(prm.grad.cpu(), crl[name].grad, 1e-3, f'TokenCritic.forward d {name}')
+    # SelfCritic: same trunk as MaskGit + to_pred
+    sc = P.SelfCritic(mg).cuda()
+    for prm in mg.parameters():
+        prm.grad = None
+    outs = sc(ids.cuda(), context=ctx.cuda(), text_mask=tmask.cuda())
+    assert outs.requires_grad and tuple(outs.shape) == (b, 48)
+    outs.sum().backward()
+    assert sc.to_pred[0].weight.grad is not None and mg.token_emb.weight.grad is not None
