@@ -471,3 +471,67 @@ def test_module_forwards_carry_autograd_graphs():
     assert outs.requires_grad and tuple(outs.shape) == (b, 48)
     outs.sum().backward()
     assert sc.to_pred[0].weight.grad is not None and mg.token_emb.weight.grad is not None
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16x3'])
+def test_training_loop_tracks_torch_adamw_on_the_oracle(dtype):
+    """four optimizer steps of the reference's inner loop (phenaki_trainer.py:351-388: zero_grad, loss, backward, AdamW from optimizer.py) on the
+    product against the same loop on the oracle with torch.optim.AdamW on CPU, same draws per step: losses per step and the parameters
+    after the last step; then the INFERENCE path must see the trained weights (packed-weight caches are keyed on the tensors' versions,
+    which pk_adamw's raw-pointer writes have to bump)"""
+    import phenaki_pytorch_amd as P
+    cv, mg, cr, ph = load_product('tiny', TINY, dtype=dtype)
+    _, mg_sd, cr_sd = state_dicts('tiny')
+    _, mgc, crc = oracle_cfgs(TINY)
+    leaf = lambda sd: {k: (v.clone().requires_grad_() if v.is_floating_point() and not k.endswith('.beta') else v) for k, v in sd.items()}
+    mgl, crl = leaf(mg_sd), leaf(cr_sd)
+    b, shape, n = 2, (3, 4, 4), 48
+    g = torch.Generator().manual_seed(21)
+    ids = torch.randint(0, TINY['maskgit']['num_tokens'], (b, *shape), generator=g)
+    ctx = weights.synthetic_context(b, 6, TINY['maskgit']['dim_context'], seed=3, pad_last=2)
+    with torch.no_grad():
+        before = mg(ids.cuda(), context=ctx.cuda(), text_mask=torch.any(ctx != 0, dim=-1).cuda()).cpu()      # packs the inference weights
+    hip_params = [p for p in list(mg.parameters()) + list(cr.parameters())]
+    opt = P.get_optimizer(hip_params, lr=2e-3, wd=1e-2)
+    ref_params = [v for sd in (mgl, crl) for v in sd.values() if v.requires_grad]
+    ref_opt = torch.optim.AdamW([{'params': [p for p in ref_params if p.ndim >= 2]}, {'params': [p for p in ref_params if p.ndim < 2], 'weight_decay': 0}],
+                                lr=2e-3, weight_decay=1e-2, betas=(0.9, 0.99), eps=1e-8)
+    for it in range(4):
+        draws = dict(rand_step=torch.tensor([1 + it, 3]), perm_noise=weights.uniform_noise((b, n), 720 + it),
+                     gumbel_u=weights.uniform_noise((b, n, TINY['maskgit']['num_tokens']), 730 + it))
+        opt.zero_grad(set_to_none=True)
+        loss = ph(video_codebook_ids=ids.cuda(), text_embeds=ctx.cuda(), _draws=draws)
+        loss.backward()
+        opt.step()
+        ref_opt.zero_grad(set_to_none=True)
+        ref = O.phenaki_forward_loss(mgl, mgc, crl, crc, ids.flatten(1), patch_shape=shape, context=ctx, steps=TINY['steps'],
+                                     mask_id=TINY['maskgit']['num_tokens'], **draws)['loss']
+        ref.backward()
+        ref_opt.step()
+        assert abs(float(loss.detach()) - float(ref.detach())) <= 2e-3 * abs(float(ref.detach())), f'step {it}: {float(loss.detach())} vs {float(ref.detach())}'
+    # parameters after 4 steps (Adam turns a noise-level gradient into a full-size +-lr step: the structurally gradient-free bias of the
+    # position MLP's last layer is excluded; everything else has a real gradient)
+    worst = 0.
+    for net, mod, sd in (('maskgit', mg, mgl), ('critic', cr, crl)):
+        for k, v in mod.named_parameters():
+            if v.numel() == 0 or not sd[k].requires_grad or sd[k].grad is None or k.endswith('continuous_pos_bias.net.2.bias'):
+                continue
+            got, want_p = v.detach().cpu(), sd[k].detach()
+            if dtype == 'fp32':
+                worst = max(worst, close(got, want_p, 2e-3, f'{net}.{k} after 4 AdamW steps'))
+            else:
+                # Adam normalises every element's gradient by its own running magnitude: an element whose gradient sits at the split-bf16 noise
+                # floor (1e-5 of the tensor's scale) can take one +-lr step the other way.  Bound: no element further off than one step,
+                # and the tensor as a whole (rms) within 2e-3
+                d = (got - want_p)
+                assert float(d.abs().max()) <= 2e-3 + 1e-6, f'{net}.{k}: an element is more than one AdamW step (lr) off'
+                rel = float(d.pow(2).mean().sqrt() / want_p.pow(2).mean().sqrt().clamp_min(1e-12))
+                assert rel <= 2e-3, f'{net}.{k} after 4 AdamW steps: rms error {rel:.2e}'
+                worst = max(worst, rel)
+    record_parity('training_loop_4_steps_vs_torch_adamw', dict(dtype=dtype, worst_param_rel_err=worst))
+    with torch.no_grad():
+        after = mg(ids.cuda(), context=ctx.cuda(), text_mask=torch.any(ctx != 0, dim=-1).cuda()).cpu()
+        want = O.maskgit_forward({k: v.detach() for k, v in mgl.items()}, mgc, ids.flatten(1), video_patch_shape=shape, context=ctx,
+                                 text_mask=torch.any(ctx != 0, dim=-1))
+    assert (after - before).abs().max() > 1e-3, 'training must change the logits'
+    close(after, want, 2e-3, 'inference path after training (stale packed weights?)')
