@@ -250,7 +250,8 @@ int pk_vocab_ce(int dtype, const void* partials, int M, int V, const void* A, in
  * dW GEMM), both f32 or bf16 (out_bf16); db [Vs] (or NULL) receives the column sums of g.  The caller then runs dE += g W_slab and
  * dW_slab = gT E through pk_gemm: the (M, V) logits / probabilities never exist. */
 int pk_ce_grad_slab(int out_bf16, const float* logits, int ldl, const float* lse, const long long* targets, const int* rows,
-                    int M, int Vs, int v0, float scale, void* g, int ldg, void* gT, int ldgt, float* db, void* stream);
+                    int M, int Vs, int v0, float scale, const float* scale_dev, void* g, int ldg, void* gT, int ldgt, float* db, void* stream);
+/* scale_dev (or NULL): a device scalar multiplied into scale -- the upstream gradient of the loss, read on the device */
 
 /* phenaki_pytorch.py:488-491: mask = zeros.scatter(1, scores.topk(k).indices, 1).bool(); ids = where(mask, mask_id, ids).
  * rows_out (B*k int32, or NULL) receives the flat positions b*n + i of the masked tokens: only those rows need the vocab
@@ -302,7 +303,7 @@ int pk_bias_scatter(const float* dbias, const int* code, int off, float* dtab, i
 int pk_sum_batch(const float* src, long long stride, int S, float* out, long long E, void* stream);
 /* critic head + BCE-with-logits forward and backward in one pass (phenaki_pytorch.py:246-249, :673-676): logits / loss_rows (M) optional;
  * labels NULL: logits only; de = dz w with dz = (sigmoid(z) - y) scale; pw (pk_ln_bwd_parts(M), D) / pb (pk_ln_bwd_parts(M)) partials of dw / db */
-int pk_bce_head(const float* e, long long lde, const float* w, const float* b, const float* labels, float scale, float* logits, float* loss_rows,
+int pk_bce_head(const float* e, long long lde, const float* w, const float* b, const float* labels, float scale, const float* scale_dev, float* logits, float* loss_rows,
                 float* de, long long ldde, float* pw, float* pb, int M, int D, void* stream);
 /* AdamW / Adam update of one parameter tensor (reference optimizer.py:11-37 hands MaskGit's parameters to torch.optim.AdamW / Adam):
  * m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2; p = p (1 - lr wd) - lr / (1 - b1^step) * m / (sqrt(v / (1 - b2^step)) + eps); step = 1, 2, ... */

@@ -53,7 +53,7 @@ SIGNATURES = {
     'pk_vocab_sample': [_I, _P, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P, _ULL, _P, _I, _P, _P],
     'pk_vocab_reduce': [_P, _I, _I, _P, _P, _P, _P, _P, _I, _P],
     'pk_vocab_ce': [_I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P],
-    'pk_ce_grad_slab': [_I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _P, _I, _P, _I, _P, _P],
+    'pk_ce_grad_slab': [_I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _P, _P, _I, _P, _I, _P, _P],
     'pk_topk_mask': [_P, _I, _I, _I, _LL, _P, _P, _P, _P, _P],
     'pk_critic_head': [_P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P, _F, _ULL, _P, _P, _P],
     'pk_pack': [_P, _LL, _P, _I, _I, _I, _P, _LL, _I, _I, _P],
@@ -71,7 +71,7 @@ SIGNATURES = {
     'pk_bias_gather': [_P, _I, _P, _I, _P, _I, _I, _P],
     'pk_bias_scatter': [_P, _P, _I, _P, _I, _I, _I, _P],
     'pk_sum_batch': [_P, _LL, _I, _P, _LL, _P],
-    'pk_bce_head': [_P, _LL, _P, _P, _P, _F, _P, _P, _P, _LL, _P, _P, _I, _I, _P],
+    'pk_bce_head': [_P, _LL, _P, _P, _P, _F, _P, _P, _P, _P, _LL, _P, _P, _I, _I, _P],
     'pk_attn_train_prep': [_P, _LL, _P, _LL, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'pk_attn_train_prep_bwd': [_P, _LL, _P, _LL, _P, _P, _P, _F, _P, _P, _P, _P, _LL, _P, _LL, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'pk_adamw': [_P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _LL, _P],
@@ -390,10 +390,10 @@ def vocab_ce(dtype, partials, M, V, A, W, bias, D, targets, rows, loss, lse=None
     _check(rc, 'pk_vocab_ce')
 
 
-def ce_grad_slab(logits, lse, targets, rows, M, Vs, v0, scale, g, gT, db=None):
-    """g / gT <- (softmax - onehot) * scale of one slab of vocabulary columns (see the header); logits (M, >= Vs) f32"""
+def ce_grad_slab(logits, lse, targets, rows, M, Vs, v0, scale, g, gT, db=None, scale_dev=None):
+    """g / gT <- (softmax - onehot) * scale [* scale_dev[0]] of one slab of vocabulary columns (see the header); logits (M, >= Vs) f32"""
     rc = load().pk_ce_grad_slab(1 if g.dtype == torch.bfloat16 else 0, ptr(logits), logits.stride(0), ptr(lse), ptr(targets), ptr(rows), M, Vs, v0,
-                                float(scale), ptr(g), g.stride(0), ptr(gT), gT.stride(0), ptr(db), stream(logits))
+                                float(scale), ptr(scale_dev), ptr(g), g.stride(0), ptr(gT), gT.stride(0), ptr(db), stream(logits))
     _check(rc, 'pk_ce_grad_slab')
 
 
@@ -498,14 +498,14 @@ def sum_batch(src, S, out, E):
     _check(rc, 'pk_sum_batch')
 
 
-def bce_head(e, w, b, labels, M, D, *, scale=0.0, logits=None, loss_rows=None, de=None):
+def bce_head(e, w, b, labels, M, D, *, scale=0.0, logits=None, loss_rows=None, de=None, scale_dev=None):
     """returns (dw (D,), db (1,)) when de is given, else None"""
     pw = pb = None
     P = load().pk_ln_bwd_parts(M)
     if de is not None:
         pw = torch.empty((P, D), device=e.device, dtype=torch.float32)
         pb = torch.empty((P, 1), device=e.device, dtype=torch.float32)
-    rc = load().pk_bce_head(ptr(e), e.stride(-2), f32p(w, 'critic head weight'), f32p(b, 'critic head bias'), ptr(labels), float(scale), ptr(logits), ptr(loss_rows),
+    rc = load().pk_bce_head(ptr(e), e.stride(-2), f32p(w, 'critic head weight'), f32p(b, 'critic head bias'), ptr(labels), float(scale), ptr(scale_dev), ptr(logits), ptr(loss_rows),
                             ptr(de), de.stride(-2) if de is not None else 0, ptr(pw), ptr(pb), M, D, stream(e))
     _check(rc, 'pk_bce_head')
     if de is None:

@@ -332,8 +332,10 @@ __global__ __launch_bounds__(256) void vocab_ce_kernel(const float* __restrict__
 template <typename TO>
 __global__ __launch_bounds__(256) void ce_grad_slab_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ lse,
                                                            const long long* __restrict__ targets, const int* __restrict__ rows, int M, int Vs,
-                                                           int v0, float scale, TO* __restrict__ g, int ldg, TO* __restrict__ gT, int ldgt) {
+                                                           int v0, float scale_, const float* __restrict__ scale_dev, TO* __restrict__ g, int ldg,
+                                                           TO* __restrict__ gT, int ldgt) {
     __shared__ float tile[32][33];
+    const float scale = scale_dev ? scale_ * scale_dev[0] : scale_;       // the upstream gradient stays on the device (no host read in backward)
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8 threads, 4 rows each
     const int mb = blockIdx.y * 32, vb = blockIdx.x * 32;
 #pragma unroll
@@ -478,16 +480,16 @@ extern "C" int pk_vocab_reduce(const void* partials, int M, int V, const int* ro
 // call made with need_lse bit 0 set on the SAME A / W / bias (phenaki_pytorch.py:640-643 F.cross_entropy, reduction left to
 // the caller).  targets must be < V.
 extern "C" int pk_ce_grad_slab(int out_bf16, const float* logits, int ldl, const float* lse, const long long* targets, const int* rows,
-                               int M, int Vs, int v0, float scale, void* g, int ldg, void* gT, int ldgt, float* db, void* stream) {
+                               int M, int Vs, int v0, float scale, const float* scale_dev, void* g, int ldg, void* gT, int ldgt, float* db, void* stream) {
     if (!logits || !lse || !targets || !g || !gT || M <= 0 || Vs <= 0 || v0 < 0 || ldl < Vs || ldg < Vs || ldgt < M) return PK_EINVAL;
     dim3 grid((Vs + 31) / 32, (ldgt + 31) / 32);
     hipStream_t s = STREAM(stream);
     if (out_bf16) {
-        hipLaunchKernelGGL((ce_grad_slab_kernel<bf16>), grid, dim3(256), 0, s, logits, ldl, lse, targets, rows, M, Vs, v0, scale,
+        hipLaunchKernelGGL((ce_grad_slab_kernel<bf16>), grid, dim3(256), 0, s, logits, ldl, lse, targets, rows, M, Vs, v0, scale, scale_dev,
                            reinterpret_cast<bf16*>(g), ldg, reinterpret_cast<bf16*>(gT), ldgt);
         if (db) hipLaunchKernelGGL((rowsum_kernel<bf16>), dim3((Vs + 3) / 4), dim3(256), 0, s, reinterpret_cast<const bf16*>(gT), ldgt, Vs, M, db);
     } else {
-        hipLaunchKernelGGL((ce_grad_slab_kernel<float>), grid, dim3(256), 0, s, logits, ldl, lse, targets, rows, M, Vs, v0, scale,
+        hipLaunchKernelGGL((ce_grad_slab_kernel<float>), grid, dim3(256), 0, s, logits, ldl, lse, targets, rows, M, Vs, v0, scale, scale_dev,
                            reinterpret_cast<float*>(g), ldg, reinterpret_cast<float*>(gT), ldgt);
         if (db) hipLaunchKernelGGL((rowsum_kernel<float>), dim3((Vs + 3) / 4), dim3(256), 0, s, reinterpret_cast<const float*>(gT), ldgt, Vs, M, db);
     }

@@ -323,10 +323,11 @@ __global__ __launch_bounds__(256) void sum_batch_kernel(const float* __restrict_
 // ---- critic head + BCE-with-logits, forward and backward in one pass (phenaki_pytorch.py:246-249 / :306-336 to_pred, :673-676) --------------
 // logit = e . w + b;  loss_row = max(z, 0) - z y + log(1 + exp(-|z|));  dz = (sigmoid(z) - y) * scale;  de = dz * w;  dw / db as block partials
 __global__ __launch_bounds__(256) void bce_head_kernel(const float* __restrict__ e, long lde, const float* __restrict__ w, const float* __restrict__ b,
-                                                       const float* __restrict__ labels, float scale, float* __restrict__ logits, float* __restrict__ loss_rows,
+                                                       const float* __restrict__ labels, float scale_, const float* __restrict__ scale_dev, float* __restrict__ logits, float* __restrict__ loss_rows,
                                                        float* __restrict__ de, long ldde, float* __restrict__ pw, float* __restrict__ pb, int M, int D, int rpb) {
     __shared__ f32x4 red[4][256];
     __shared__ float redb[4];
+    const float scale = scale_dev ? scale_ * scale_dev[0] : scale_;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nv = D >> 2;
     f32x4 aw[4];
 #pragma unroll
@@ -526,12 +527,13 @@ extern "C" int pk_sum_batch(const float* src, long stride, int S, float* out, lo
 }
 
 // labels null: logits only (inference-style forward).  pw (pk_ln_bwd_parts(M), D) / pb (pk_ln_bwd_parts(M),) partials of dw / db
-extern "C" int pk_bce_head(const float* e, long lde, const float* w, const float* b, const float* labels, float scale, float* logits, float* loss_rows,
+extern "C" int pk_bce_head(const float* e, long lde, const float* w, const float* b, const float* labels, float scale, const float* scale_dev, float* logits,
+                           float* loss_rows,
                            float* de, long ldde, float* pw, float* pb, int M, int D, void* stream) {
     if (!e || !w || M <= 0 || D <= 0 || D > 1024 || (de && !labels) || (pw && (!pb || !de))) return PK_EINVAL;
     if ((D & 3) || (lde & 3) || (ldde & 3) || !al16(e) || !al16(w) || (de && !al16(de)) || (pw && !al16(pw))) return PK_EALIGN;
     const int P = pk_ln_bwd_parts(M), rpb = (M + P - 1) / P;
-    hipLaunchKernelGGL(bce_head_kernel, dim3(P), dim3(256), 0, STREAM(stream), e, lde, w, b, labels, scale, logits, loss_rows, de, ldde, pw, pb, M, D, rpb);
+    hipLaunchKernelGGL(bce_head_kernel, dim3(P), dim3(256), 0, STREAM(stream), e, lde, w, b, labels, scale, scale_dev, logits, loss_rows, de, ldde, pw, pb, M, D, rpb);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

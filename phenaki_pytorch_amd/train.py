@@ -320,7 +320,18 @@ class _Embed(torch.autograd.Function):
         return dtok, dpos, None, None
 
 
+_REL_TABLES = {}
+
+
 def _rel_table(dims, device):
+    """cached per (grid, device): see _build_rel_table"""
+    key = (tuple(dims), str(device))
+    if key not in _REL_TABLES:
+        _REL_TABLES[key] = _build_rel_table(dims, device)
+    return _REL_TABLES[key]
+
+
+def _build_rel_table(dims, device):
     """relative-position table of a grid (attention.py:257-268): features (Lt, 8) f32 = sign(d) log(|d| + 1) per axis (zero-padded to 8
     columns), the mixed-radix position code (n,) int32 and its offset: bias[h][i][j] = mlp(features)[code[i] - code[j] + off][h]"""
     strides, acc = [], 1
@@ -444,7 +455,8 @@ class _VocabCrossEntropy(torch.autograd.Function):
         td = L.tdtype(dtype)
         q = _q(dtype)
         Mp = round_up(M, q)
-        scale = float(grad_out) / M
+        scale = 1.0 / M
+        gdev = grad_out.detach().float().reshape(1).contiguous()         # the upstream gradient is read on the device: no host sync in backward
         # operands of the two gradient products (W-side images: rows = output features, K along the contraction)
         Wt = pack_operand(weight.detach(), dtype, transpose=True)               # (D, Vp): dE = g @ W   -> "W" operand = W^T, K = vocabulary
         Af = A.float() if A.dtype != torch.float32 else A
@@ -461,7 +473,7 @@ class _VocabCrossEntropy(torch.autograd.Function):
             Vs = min(slab, V - v0)
             # logits of the slab: the same A / W rows / bias as the forward pass (rows [v0, v0 + Vs) of the packed weight)
             L.gemm(dtype, A, Wp[v0:v0 + Vs], M, Vs, D, C=logits, bias=b[v0:v0 + Vs], ldc=logits.stride(0))
-            L.ce_grad_slab(logits, lse, tg, rows, M, Vs, v0, scale, g, gT, db=db[v0:v0 + Vs])
+            L.ce_grad_slab(logits, lse, tg, rows, M, Vs, v0, scale, g, gT, db=db[v0:v0 + Vs], scale_dev=gdev)
             # dE (+)= g @ W_slab: contraction over the slab's columns = columns [v0, v0 + Vs) of the W^T image (k offset on the operand)
             L.gemm(dtype, g, Wt[:, v0:], M, D, Vs, C=dE, res=None if first else dE, lda=g.stride(0))
             # dW_slab = g^T @ E (K = the rows, padded to the k-tile: gT's pad columns are zeroed by the kernel, E^T is zero-padded)
@@ -533,7 +545,8 @@ class _BCEHead(torch.autograd.Function):
         e, w, b, labels = ctx.saved_tensors
         M, D = e.shape
         de = _f32((M, D), e.device)
-        dw, db = L.bce_head(e, w.detach().reshape(-1), b.detach(), labels, M, D, scale=float(grad_out) / M, de=de)
+        dw, db = L.bce_head(e, w.detach().reshape(-1), b.detach(), labels, M, D, scale=1.0 / M, de=de,
+                            scale_dev=grad_out.detach().float().reshape(1).contiguous())
         return de, dw.reshape(w.shape), db.reshape(b.shape), None
 
 
@@ -696,17 +709,28 @@ def phenaki_loss(ph, videos=None, *, texts=None, video_codebook_ids=None, video_
         ids = video_codebook_ids.reshape(video_codebook_ids.shape[0], -1).long().contiguous()
         b, n = ids.shape
         draws = _draws or {}
-        rand_step = draws['rand_step'].to(device) if 'rand_step' in draws else torch.randint(0, ph.steps, (b,), device=device)
+        # the step index is drawn on the HOST (reference: on the device, :620): the number of masked tokens per sample -- hence the row
+        # count of the vocabulary head -- is then known without reading anything back, and the host can run a whole step ahead of the GPU
+        rand_step = draws['rand_step'].cpu() if 'rand_step' in draws else torch.randint(0, ph.steps, (b,))
         mask_token_prob = torch.cos(rand_step * math.pi * 0.5 / ph.steps)
-        vm = video_mask if exists(video_mask) else torch.ones((b, n), device=device, dtype=torch.bool)
-        num_tokens = vm.sum(dim=-1)                                                     # get_mask_subset_with_prob (phenaki_pytorch.py:43-55)
-        num_masked = (mask_token_prob * num_tokens).round().clamp(min=1)
         perm_noise = draws['perm_noise'].to(device) if 'perm_noise' in draws else torch.rand((b, n), device=device)
-        perm = perm_noise.argsort(dim=-1) - (n - num_tokens)[:, None]
-        perm = perm.masked_fill(perm < 0, n)
-        mask_token_mask = perm < num_masked[:, None]
+        if exists(video_mask):                                                          # token counts live on the device: one read-back
+            vm = video_mask
+            num_tokens = vm.sum(dim=-1)                                                 # get_mask_subset_with_prob (phenaki_pytorch.py:43-55)
+            num_masked = (mask_token_prob.to(device) * num_tokens).round().clamp(min=1)
+            perm = perm_noise.argsort(dim=-1) - (n - num_tokens)[:, None]
+            perm = perm.masked_fill(perm < 0, n)
+            mask_token_mask = perm < num_masked[:, None]
+            rows = mask_token_mask.reshape(-1).nonzero().reshape(-1).int()
+        else:
+            num_masked_host = (mask_token_prob * n).round().clamp(min=1)
+            M_rows = int(num_masked_host.sum())
+            # (pinned + non_blocking: a pageable host-to-device copy would wait for the stream, i.e. for the previous step)
+            num_masked_dev = num_masked_host.pin_memory().to(device, non_blocking=True)
+            mask_token_mask = perm_noise.argsort(dim=-1) < num_masked_dev[:, None]
+            # the flat positions of the masked tokens in ascending order, with a size the host already knows (no nonzero() read-back)
+            rows = torch.argsort((~mask_token_mask).reshape(-1).to(torch.uint8), stable=True)[:M_rows].int()
         masked_input = torch.where(mask_token_mask, ph.mask_id, ids)
-        rows = mask_token_mask.reshape(-1).nonzero().reshape(-1).int()
 
     dt = compute_dtype_of(mg)
     D, V = mg.dim, mg.to_logits.weight.shape[0]
