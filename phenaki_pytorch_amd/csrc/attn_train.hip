@@ -7,10 +7,11 @@
 //                  dS = P * (dO V^T - D), dQ^ = dS K^   [+ dS written out for the position-bias gradient]
 //                  kernel KV (one workgroup per 64 keys of a head): dV = P^T dO, dK^ = dS^T Q^ over all query tiles
 //   pk_attn_train_prep_bwd : l2norm / scale / null-key backward -> dq, dkv, dq_scale, dk_scale, dnull_kv
-// All tile products are 64 x 64 x 64 on v_mfma_f32_16x16x4_f32 from f32 LDS tiles [row][k] (rows padded to 68 floats), both operands read as
-// 8-element fragment chunks; products whose contraction index is not the contiguous one of the global layout read a tile that was transposed
-// on its way into LDS (K^T in kernel Q, Q^T / dO^T in kernel KV).  No software pipelining.  Every result is owned by exactly one workgroup
-// (no atomics): the gradients are bit-reproducible.
+// All tile products run on v_mfma_f32_16x16x4_f32 from 8-element fragment chunks; a workgroup's own rows (the A side) stay in registers, B
+// operands are shared through f32 LDS tiles [row][k] (rows padded to 68 / 36 floats); products whose contraction index is not the contiguous one
+// of the global layout read a tile that was transposed on its way into LDS (K^T in kernel Q, q^T / dO^T in kernel KV); the next tile is
+// fetched into registers while the current one is multiplied.  Every result is owned by exactly one workgroup (no atomics): the gradients
+// are bit-reproducible.
 #include "common.hpp"
 
 namespace pk {
@@ -120,20 +121,34 @@ __global__ __launch_bounds__(64) void null_kv_bwd_kernel(const float* __restrict
     dnull[((long)h * 2 * nnull + 2 * j + 1) * 64 + lane] = gv;
 }
 
-// ---- 64 x 64 x 64 tile product on the f32 matrix cores -------------------------------------------------------------------------------
-// acc[nb] (rows m0 + (lane >> 4) * 4 + i, column nb * 16 + (lane & 15)) += sum_k A[m][k] B[n][k] for two LDS tiles [row][k] (k contiguous, row
-// stride TLD): fragment chunks of 8 consecutive k per lane (two ds_read_b128) feed eight v_mfma_f32_16x16x4_f32 each (common.hpp mma(Frag<float>));
-// the first version read one float per MFMA (80 ds_read_b32 per 64 MFMAs) and was LDS-issue bound at 17 % of the f32 matrix peak.
-__device__ __forceinline__ void mma64(const float* As, const float* Bs, f32x4 (&acc)[4], int m0, int lane) {
+// ---- tile products on the f32 matrix cores ------------------------------------------------------------------------------------------------
+// Operands are f32 [row][k] with k contiguous, read as 8-element fragment chunks (lane: row = lane & 15, k = (lane >> 4) * 8 + 0..7; two 16-byte
+// reads feed eight v_mfma_f32_16x16x4_f32, common.hpp mma(Frag<float>)).  The A side of every product is either held in REGISTERS for the whole
+// kernel (the workgroup's own q^ / dO rows in kernel Q, its k^ / v rows in kernel KV) or a wave-private LDS tile (P / dS, written in the
+// accumulator layout and read back as fragments); only B operands are shared through LDS.  acc[nb]: rows (lane >> 4) * 4 + i, column nb * 16 + (lane & 15).
+template <int NBLK, int NCHUNK>
+__device__ __forceinline__ void mma_regA(const Frag<float> (&a)[NCHUNK], const float* Bs, int ldb, f32x4 (&acc)[NBLK], int lane) {
     const int r = lane & 15, kq = lane >> 4;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        Frag<float> a;
-        frag_load(a, As + (m0 + r) * TLD + c * 32 + kq * 8);
+    for (int c = 0; c < NCHUNK; ++c)
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
+        for (int nb = 0; nb < NBLK; ++nb) {
             Frag<float> b;
-            frag_load(b, Bs + (nb * 16 + r) * TLD + c * 32 + kq * 8);
+            frag_load(b, Bs + (nb * 16 + r) * ldb + c * 32 + kq * 8);
+            acc[nb] = mma(a[c], b, acc[nb]);
+        }
+}
+template <int NBLK, int NCHUNK>
+__device__ __forceinline__ void mma_ldsA(const float* As, int lda, int m0, const float* Bs, int ldb, f32x4 (&acc)[NBLK], int lane) {
+    const int r = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+        Frag<float> a;
+        frag_load(a, As + (m0 + r) * lda + c * 32 + kq * 8);
+#pragma unroll
+        for (int nb = 0; nb < NBLK; ++nb) {
+            Frag<float> b;
+            frag_load(b, Bs + (nb * 16 + r) * ldb + c * 32 + kq * 8);
             acc[nb] = mma(a, b, acc[nb]);
         }
     }
@@ -151,18 +166,36 @@ struct AttnBwdArgs {
     int S, heads, n, nkt, nnull;
 };
 
-// rows [r0, r0 + 64) of a (rows_total, ld) matrix, 64 columns -> LDS tile [row][col] (zero rows beyond rows_total); T: the transposed tile [col][row]
-template <bool T>
-__device__ __forceinline__ void load_tile(float* dst, const float* src, long ld, int r0, int rows_total) {
-    for (int e = threadIdx.x; e < 64 * 16; e += 256) {
-        const int r = e >> 4, c = (e & 15) * 4;
-        f32x4 v = f32x4{0, 0, 0, 0};
-        if (r0 + r < rows_total) v = *reinterpret_cast<const f32x4*>(src + (long)(r0 + r) * ld + c);
-        if (T) {
+// this wave's 16 rows [row0, row0 + 16) x 64 columns of a (rows_total, ld) matrix as two fragment chunks (zero rows beyond rows_total)
+__device__ __forceinline__ void load_rows_frag(Frag<float> (&f)[2], const float* src, long ld, int row0, int rows_total, int lane) {
+    const int r = lane & 15, kq = lane >> 4;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dst[(c + q) * TLD + r] = v[q];
-        } else {
-            *reinterpret_cast<f32x4*>(dst + r * TLD + c) = v;
+    for (int c = 0; c < 2; ++c) {
+        if (row0 + r < rows_total) frag_load(f[c], src + (long)(row0 + r) * ld + c * 32 + kq * 8);
+        else frag_zero(f[c]);
+    }
+}
+// a thread's share of a [ROWS x 64] tile of a (rows_total, ld) matrix: ROWS / 16 pieces of 4 floats (piece u: row (tid >> 4) + 16 u, columns (tid & 15) * 4 ..)
+template <int ROWS>
+__device__ __forceinline__ void fetch_tile(f32x4 (&v)[ROWS / 16], const float* src, long ld, int r0, int rows_total) {
+    const int rr = threadIdx.x >> 4, c = (threadIdx.x & 15) * 4;
+#pragma unroll
+    for (int u = 0; u < ROWS / 16; ++u) {
+        const int row = r0 + rr + 16 * u;
+        v[u] = row < rows_total ? *reinterpret_cast<const f32x4*>(src + (long)row * ld + c) : f32x4{0, 0, 0, 0};
+    }
+}
+// ... into LDS as [row][col] (stride ld_n) and / or transposed [col][row] (stride ld_t)
+template <int ROWS>
+__device__ __forceinline__ void stash_tile(const f32x4 (&v)[ROWS / 16], float* normal, int ld_n, float* transposed, int ld_t) {
+    const int rr = threadIdx.x >> 4, c = (threadIdx.x & 15) * 4;
+#pragma unroll
+    for (int u = 0; u < ROWS / 16; ++u) {
+        const int row = rr + 16 * u;
+        if (normal) *reinterpret_cast<f32x4*>(normal + row * ld_n + c) = v[u];
+        if (transposed) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) transposed[(c + q) * ld_t + row] = v[u][q];
         }
     }
 }
@@ -179,17 +212,22 @@ __device__ __forceinline__ bool score(const AttnBwdArgs& p, int s, int h, int gi
 }
 
 #define PK_ZERO4 {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}
+#define PK_ZERO2 {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}
 
+// kernel Q: one workgroup per 64 query rows of a head (4 waves x 16 rows).  q^ and dO fragments live in registers; LDS holds K^ [64][68],
+// K^T [64][68], V [64][68] of the current 64-key tile and the wave-private dS rows (70 KB: two workgroups per CU).  The next tile's K^ / V rows
+// are fetched into registers while the current one is being multiplied.
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* Qs = sm; float* dOs = sm + TSZ; float* Ks = sm + 2 * TSZ; float* Vs = sm + 3 * TSZ; float* Ps = sm + 4 * TSZ; float* Kt = sm + 5 * TSZ;
+    float* Ks = sm; float* Vs = sm + TSZ; float* Kt = sm + 2 * TSZ; float* Ps = sm + 3 * TSZ;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
     const int nqt = (p.n + 63) / 64;
     const int qt = blockIdx.x % nqt, sh = blockIdx.x / nqt, h = sh % p.heads, s = sh / p.heads;
     const int i0 = qt * 64, m0 = wv * 16;
     const int nreal = p.nkt - p.nnull;
-    load_tile<false>(Qs, p.Qh + (long)sh * p.n * 64, 64, i0, p.n);
-    load_tile<false>(dOs, p.dO + (long)s * p.n * p.lddo + h * 64, p.lddo, i0, p.n);
+    Frag<float> fq[2], fdo[2];
+    load_rows_frag(fq, p.Qh + (long)sh * p.n * 64, 64, i0 + m0, p.n, lane);
+    load_rows_frag(fdo, p.dO + (long)s * p.n * p.lddo + h * 64, p.lddo, i0 + m0, p.n, lane);
     // D = rowsum(dO * O) for this wave's 16 rows
     float Dl[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -206,17 +244,20 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
         if ((rr >> 2) == kq) Dl[rr & 3] = v;
         if (lane == 0 && gi < p.n) p.Drow[(long)sh * p.n + gi] = v;
     }
-    __syncthreads();
-    // ---- pass 1: log-sum-exp of every row (online, per lane over its 4 rows x 16 columns per tile; lanes of a row merged at the end)
-    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, l[4] = {0.f, 0.f, 0.f, 0.f};
-    const int nkt_tiles = (p.nkt + 63) / 64;
+    const int ntl = (p.nkt + 63) / 64;
     const float* Kbase = p.Kh + (long)sh * p.nkt * 64;
     const float* Vbase = p.Vh + (long)sh * p.nkt * 64;
-    for (int kt = 0; kt < nkt_tiles; ++kt) {
-        load_tile<false>(Ks, Kbase, 64, kt * 64, p.nkt);
+    // ---- pass 1: log-sum-exp of every row (online, per lane over its 4 rows x 16 columns per tile; lanes of a row merged at the end)
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, l[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 kreg[4], vreg[4];
+    fetch_tile<64>(kreg, Kbase, 64, 0, p.nkt);
+    for (int kt = 0; kt < ntl; ++kt) {
+        __syncthreads();                                          // the previous tile's readers are done
+        stash_tile<64>(kreg, Ks, TLD, nullptr, 0);
+        if (kt + 1 < ntl) fetch_tile<64>(kreg, Kbase, 64, (kt + 1) * 64, p.nkt);
         __syncthreads();
         f32x4 acc[4] = PK_ZERO4;
-        mma64(Qs, Ks, acc, m0, lane);
+        mma_regA<4, 2>(fq, Ks, TLD, acc, lane);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
@@ -227,7 +268,6 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
                 l[i] = l[i] * __expf(mx[i] - mn) + __expf(sc - mn);
                 mx[i] = mn;
             }
-        __syncthreads();
     }
     float lse[4];
 #pragma unroll
@@ -246,15 +286,21 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
     }
     // ---- pass 2: dS and dQ^
     f32x4 accQ[4] = PK_ZERO4;
-    for (int kt = 0; kt < nkt_tiles; ++kt) {
-        load_tile<false>(Ks, Kbase, 64, kt * 64, p.nkt);
-        load_tile<true>(Kt, Kbase, 64, kt * 64, p.nkt);
-        load_tile<false>(Vs, Vbase, 64, kt * 64, p.nkt);
+    fetch_tile<64>(kreg, Kbase, 64, 0, p.nkt);
+    fetch_tile<64>(vreg, Vbase, 64, 0, p.nkt);
+    for (int kt = 0; kt < ntl; ++kt) {
+        __syncthreads();
+        stash_tile<64>(kreg, Ks, TLD, Kt, TLD);
+        stash_tile<64>(vreg, Vs, TLD, nullptr, 0);
+        if (kt + 1 < ntl) {
+            fetch_tile<64>(kreg, Kbase, 64, (kt + 1) * 64, p.nkt);
+            fetch_tile<64>(vreg, Vbase, 64, (kt + 1) * 64, p.nkt);
+        }
         __syncthreads();
         f32x4 accS[4] = PK_ZERO4;
         f32x4 accP[4] = PK_ZERO4;
-        mma64(Qs, Ks, accS, m0, lane);
-        mma64(dOs, Vs, accP, m0, lane);
+        mma_regA<4, 2>(fq, Ks, TLD, accS, lane);
+        mma_regA<4, 2>(fdo, Vs, TLD, accP, lane);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
@@ -265,9 +311,8 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
                 Ps[(m0 + kq * 4 + i) * TLD + nb * 16 + r] = ds;
                 if (p.dS && gi < p.n && j >= p.nnull && j < p.nkt) p.dS[((long)sh * p.n + gi) * nreal + (j - p.nnull)] = ds;
             }
-        // this wave's 16 rows of Ps are its own: no workgroup barrier needed before reading them back.  dQ^[i][d] += sum_j dS[i][j] K^[j][d]
-        mma64(Ps, Kt, accQ, m0, lane);
-        __syncthreads();
+        // this wave's 16 rows of Ps are its own: no workgroup barrier before reading them back.  dQ^[i][d] += sum_j dS[i][j] K^T[d][j]
+        mma_ldsA<4, 2>(Ps, TLD, m0, Kt, TLD, accQ, lane);
     }
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
@@ -278,55 +323,70 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
         }
 }
 
-// one workgroup per 64 keys of a head; the scores are computed TRANSPOSED (rows = this wave's 16 keys, columns = the query tile), so P^T / dS^T
-// land in the orientation the dV / dK^ products read them and stay private to the wave
+// kernel KV: one workgroup per 64 keys of a head (4 waves x 16 keys); k^ and v fragments live in registers.  Query rows come in tiles of 32:
+// LDS holds q^ [32][68], dO [32][68] (B operands of the TRANSPOSED scores S^T[j][i], dP^T[j][i]), their transposes [64][36] (B operands of
+// dV = P^T dO, dK^ = dS^T q^) and one wave-private [64][36] buffer that carries P^T and then dS^T (46 KB: three workgroups per CU).
+constexpr int QT = 32, TLQ = 36;
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* Ks = sm; float* Vs = sm + TSZ; float* Qs = sm + 2 * TSZ; float* dOs = sm + 3 * TSZ; float* Qt = sm + 4 * TSZ; float* dOt = sm + 5 * TSZ;
-    float* Pt = sm + 6 * TSZ; float* St = sm + 7 * TSZ; float* lse_s = sm + 8 * TSZ; float* D_s = lse_s + 64;
+    float* Qs = sm; float* dOs = sm + QT * TLD; float* Qt = sm + 2 * QT * TLD; float* dOt = Qt + 64 * TLQ; float* PS = dOt + 64 * TLQ;
+    float* lse_s = PS + 64 * TLQ; float* D_s = lse_s + QT;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
-    const int nkt_tiles = (p.nkt + 63) / 64;
-    const int kt = blockIdx.x % nkt_tiles, sh = blockIdx.x / nkt_tiles, h = sh % p.heads, s = sh / p.heads;
+    const int ntl = (p.nkt + 63) / 64;
+    const int kt = blockIdx.x % ntl, sh = blockIdx.x / ntl, h = sh % p.heads, s = sh / p.heads;
     const int j0 = kt * 64, m0 = wv * 16;
-    load_tile<false>(Ks, p.Kh + (long)sh * p.nkt * 64, 64, j0, p.nkt);
-    load_tile<false>(Vs, p.Vh + (long)sh * p.nkt * 64, 64, j0, p.nkt);
+    Frag<float> fk[2], fv[2];
+    load_rows_frag(fk, p.Kh + (long)sh * p.nkt * 64, 64, j0 + m0, p.nkt, lane);
+    load_rows_frag(fv, p.Vh + (long)sh * p.nkt * 64, 64, j0 + m0, p.nkt, lane);
     f32x4 accK[4] = PK_ZERO4;
     f32x4 accV[4] = PK_ZERO4;
-    const int nqt = (p.n + 63) / 64;
+    const int nqt = (p.n + QT - 1) / QT;
     const float* Qbase = p.Qh + (long)sh * p.n * 64;
     const float* dObase = p.dO + (long)s * p.n * p.lddo + h * 64;
+    f32x4 qreg[2], dreg[2];
+    fetch_tile<QT>(qreg, Qbase, 64, 0, p.n);
+    fetch_tile<QT>(dreg, dObase, p.lddo, 0, p.n);
     for (int qt = 0; qt < nqt; ++qt) {
-        const int i0 = qt * 64;
-        __syncthreads();                                          // the previous iteration's readers of the query-side tiles are done
-        load_tile<false>(Qs, Qbase, 64, i0, p.n);
-        load_tile<true>(Qt, Qbase, 64, i0, p.n);
-        load_tile<false>(dOs, dObase, p.lddo, i0, p.n);
-        load_tile<true>(dOt, dObase, p.lddo, i0, p.n);
-        if (threadIdx.x < 64) {
+        const int i0 = qt * QT;
+        __syncthreads();                                          // the previous tile's readers are done
+        stash_tile<QT>(qreg, Qs, TLD, Qt, TLQ);
+        stash_tile<QT>(dreg, dOs, TLD, dOt, TLQ);
+        if (threadIdx.x < QT) {
             const int gi = i0 + threadIdx.x;
             lse_s[threadIdx.x] = gi < p.n ? p.lse[(long)sh * p.n + gi] : 0.f;
             D_s[threadIdx.x] = gi < p.n ? p.Drow[(long)sh * p.n + gi] : 0.f;
         }
+        if (qt + 1 < nqt) {
+            fetch_tile<QT>(qreg, Qbase, 64, i0 + QT, p.n);
+            fetch_tile<QT>(dreg, dObase, p.lddo, i0 + QT, p.n);
+        }
         __syncthreads();
-        f32x4 accS[4] = PK_ZERO4;
-        f32x4 accP[4] = PK_ZERO4;
-        mma64(Ks, Qs, accS, m0, lane);                            // S^T[j][i]
-        mma64(Vs, dOs, accP, m0, lane);                           // dP^T[j][i] = sum_d V[j][d] dO[i][d]
+        f32x4 accS[2] = PK_ZERO2;
+        f32x4 accP[2] = PK_ZERO2;
+        mma_regA<2, 2>(fk, Qs, TLD, accS, lane);                  // S^T[j][i]
+        mma_regA<2, 2>(fv, dOs, TLD, accP, lane);                 // dP^T[j][i] = sum_d V[j][d] dO[i][d]
+        float pr[2][4], dsv[2][4];
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
+        for (int nb = 0; nb < 2; ++nb) {
             const int ci = nb * 16 + r, gi = i0 + ci;
             const float lse = lse_s[ci], Dr = D_s[ci];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float sc, pr = 0.f;
-                if (score(p, s, h, gi, j0 + m0 + kq * 4 + i, accS[nb][i], sc)) pr = __expf(sc - lse);
-                Pt[(m0 + kq * 4 + i) * TLD + ci] = pr;
-                St[(m0 + kq * 4 + i) * TLD + ci] = pr * (accP[nb][i] - Dr);
+                float sc;
+                pr[nb][i] = 0.f;
+                if (score(p, s, h, gi, j0 + m0 + kq * 4 + i, accS[nb][i], sc)) pr[nb][i] = __expf(sc - lse);
+                dsv[nb][i] = pr[nb][i] * (accP[nb][i] - Dr);
+                PS[(m0 + kq * 4 + i) * TLQ + ci] = pr[nb][i];
             }
         }
-        // dV[j][d] += sum_i P^T[j][i] dO^T[d][i];  dK^[j][d] += sum_i dS^T[j][i] Q^T[d][i]   (A rows = this wave's own 16 rows of Pt / St)
-        mma64(Pt, dOt, accV, m0, lane);
-        mma64(St, Qt, accK, m0, lane);
+        // dV[j][d] += sum_i P^T[j][i] dO^T[d][i]   (A rows = this wave's own 16 rows of PS: program order is enough)
+        mma_ldsA<4, 1>(PS, TLQ, m0, dOt, TLQ, accV, lane);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) PS[(m0 + kq * 4 + i) * TLQ + nb * 16 + r] = dsv[nb][i];
+        // dK^[j][d] += sum_i dS^T[j][i] q^T[d][i]
+        mma_ldsA<4, 1>(PS, TLQ, m0, Qt, TLQ, accK, lane);
     }
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
@@ -345,6 +405,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnBwdArgs p) {
 using namespace pk;
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static constexpr int KV_SMEM = (2 * QT * TLD + 3 * 64 * TLQ + 2 * QT) * 4;
 
 extern "C" int pk_attn_train_prep(const float* q, long ldq, const float* kv, long ldkv, const float* null_kv, const float* q_scale, const float* k_scale,
                                   float scale, float* Qh, float* Kh, float* Vh, int S, int heads, int n, int n_kv, int nnull, void* stream) {
@@ -386,13 +447,13 @@ extern "C" int pk_attn_bwd(const float* Qh, const float* Kh, const float* Vh, co
     hipStream_t s = STREAM(stream);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * TSZ * 4) != hipSuccess) return PK_ELAUNCH;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TSZ * 4 + 512) != hipSuccess) return PK_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TSZ * 4) != hipSuccess) return PK_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, KV_SMEM) != hipSuccess) return PK_ELAUNCH;
         attr_done = true;
     }
     const int nqt = (n + 63) / 64, nktt = (p.nkt + 63) / 64;
-    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3((unsigned)((long)S * heads * nqt)), dim3(256), 6 * TSZ * 4, s, p);
-    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3((unsigned)((long)S * heads * nktt)), dim3(256), 8 * TSZ * 4 + 512, s, p);
+    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3((unsigned)((long)S * heads * nqt)), dim3(256), 4 * TSZ * 4, s, p);
+    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3((unsigned)((long)S * heads * nktt)), dim3(256), KV_SMEM, s, p);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }
