@@ -305,6 +305,10 @@ int pk_sum_batch(const float* src, long long stride, int S, float* out, long lon
  * labels NULL: logits only; de = dz w with dz = (sigmoid(z) - y) scale; pw (pk_ln_bwd_parts(M), D) / pb (pk_ln_bwd_parts(M)) partials of dw / db */
 int pk_bce_head(const float* e, long long lde, const float* w, const float* b, const float* labels, float scale, const float* scale_dev, float* logits, float* loss_rows,
                 float* de, long long ldde, float* pw, float* pb, int M, int D, void* stream);
+/* split-K product for the weight gradients (dW = dY^T X contracts over the rows of the batch): C[z] = A[:, z Kc : (z + 1) Kc] W[:, z Kc : (z + 1) Kc]^T,
+ * Kc = K / splits (a multiple of the k-tile), z < splits, as `splits` partial (M, N) f32 matrices at C + z * M * ldc; add them with pk_sum_batch.
+ * A: T for dtype 1, f32 for dtype 0 / 2; W: the operand image of the dtype. */
+int pk_gemm_splitk(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, int splits, float* C, int ldc, void* stream);
 /* AdamW / Adam update of one parameter tensor (reference optimizer.py:11-37 hands MaskGit's parameters to torch.optim.AdamW / Adam):
  * m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2; p = p (1 - lr wd) - lr / (1 - b1^step) * m / (sqrt(v / (1 - b2^step)) + eps); step = 1, 2, ... */
 int pk_adamw(float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2, float eps, float wd, int step, long long n, void* stream);

@@ -74,6 +74,7 @@ SIGNATURES = {
     'pk_bce_head': [_P, _LL, _P, _P, _P, _F, _P, _P, _P, _P, _LL, _P, _P, _I, _I, _P],
     'pk_attn_train_prep': [_P, _LL, _P, _LL, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'pk_attn_train_prep_bwd': [_P, _LL, _P, _LL, _P, _P, _P, _F, _P, _P, _P, _P, _LL, _P, _LL, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'pk_gemm_splitk': [_I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P],
     'pk_adamw': [_P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _LL, _P],
     'pk_attn_bwd': [_P, _P, _P, _P, _LL, _I, _P, _LL, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
 }
@@ -551,3 +552,9 @@ def attn_bwd(Qh, Kh, Vh, O, dO, dQh, dKh, dVh, S, h, n, n_kv, nnull, *, bias=Non
 def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step):
     rc = load().pk_adamw(ptr(p), ptr(g), ptr(m), ptr(v), float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step), p.numel(), stream(p))
     _check(rc, 'pk_adamw')
+
+
+def gemm_splitk(dtype, A, W, M, N, K, splits, C):
+    """C (splits, M, N) f32 <- the K-slices of A @ W^T (see the header); reduce with sum_batch"""
+    rc = load().pk_gemm_splitk(dtype, ptr(A), A.stride(-2), ptr(W), W.stride(0), M, N, K, splits, ptr(C), N, stream(C))
+    _check(rc, 'pk_gemm_splitk')

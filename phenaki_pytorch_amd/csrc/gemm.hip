@@ -282,6 +282,41 @@ void gemm_dma_kernel(const GemmOperands p, const GemmEpilogue e, int a_nrows) {
     }
 }
 
+// split-K form of the plain LDS-DMA GEMM (training: dW = dY^T X contracts over the ROWS of the batch -- K = 4608 .. 36 864 against 64 .. 344
+// output tiles, so a single launch leaves most CUs idle): grid.y slices the contraction, slice z reads A / W from column z * Kc on and writes
+// its partial product to C + z * M * ldc; the caller adds the slices in index order (pk_sum_batch: deterministic).  A separate kernel so the
+// inference GEMMs keep their register budget.
+template <typename T, int TM, int TN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(64 * WM * WN)
+__attribute__((amdgpu_waves_per_eu(lds_waves_per_simd<GemmDma<T, TM, TN, WM, WN, STAGES, 128, 0>>(), 8)))
+void gemm_dma_splitk_kernel(GemmOperands p, GemmEpilogue e, int a_nrows, long batch_a, long batch_w, long batch_c) {
+    using Tile = GemmDma<T, TM, TN, WM, WN, STAGES, 128, 0>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int z = blockIdx.y;
+    p.A = reinterpret_cast<const char*>(p.A) + (size_t)z * batch_a;
+    p.W = reinterpret_cast<const char*>(p.W) + (size_t)z * batch_w;
+    e.C = reinterpret_cast<char*>(e.C) + (size_t)z * batch_c;
+    const int MT = (p.M + Tile::BM - 1) / Tile::BM, NTn = (p.N + Tile::BN - 1) / Tile::BN;
+    if ((int)blockIdx.x >= MT * NTn) return;
+    const int m0 = (blockIdx.x % MT) * Tile::BM, n0 = (blockIdx.x / MT) * Tile::BN;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    if (!Tile::run(p, a_nrows, m0, n0, smem, acc)) return;
+    gemm_epilogue<T, TM, TN, WN>(acc, p.M, p.N, e, m0, n0);
+}
+
+template <typename T>
+static int launch_splitk(const GemmOperands& p, const GemmEpilogue& e, int a_nrows, int splits, long ba, long bw, long bc, hipStream_t s) {
+    using Tile = GemmDma<T, 2, 2, 2, 2, 2, 128, 0>;
+    const int MT = (p.M + Tile::BM - 1) / Tile::BM, NT = (p.N + Tile::BN - 1) / Tile::BN;
+    hipLaunchKernelGGL((gemm_dma_splitk_kernel<T, 2, 2, 2, 2, 2>), dim3(MT * NT, splits), dim3(Tile::THREADS), Tile::SMEM, s, p, e, a_nrows, ba, bw, bc);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
 template <typename T, typename TA, int TM, int TN>
 static int launch_v1(const GemmOperands& p, const GemmEpilogue& e, hipStream_t s) {
     using Tile = GemmTile<T, TA, TM, TN>;
@@ -469,4 +504,23 @@ extern "C" int pk_gemm(int dtype, int a_is_f32, const void* A, int lda, const vo
     }
     return pk_gemm_ex(dtype, a_is_f32, A, lda, W, ldw, M, N, K, bias, res, ldr, C, ldc, out_is_f32, act, nullptr, M, 0,
                       nullptr, 0, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, 0, stream);
+}
+
+// C[z] = A[:, z Kc : (z + 1) Kc] W[:, z Kc : (z + 1) Kc]^T for z < splits, Kc = K / splits (a multiple of the k-tile: 64 bf16 / 32 otherwise):
+// the K-slices of one product as `splits` partial (M, N) f32 matrices, C + z * M * ldc -- sum them with pk_sum_batch.  A: T (dtype 1) or f32
+// (dtype 0 / 2), W: the operand image of the dtype; both K-padded as for pk_gemm.
+extern "C" int pk_gemm_splitk(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, int splits, float* C, int ldc, void* stream) {
+    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || splits < 1 || splits > 64 || (dtype != 0 && dtype != 1 && dtype != 2)) return PK_EINVAL;
+    const int bk = dtype == 1 ? 64 : 32, esz = dtype == 1 ? 2 : 4;
+    if (K % (splits * bk) || (N & 3) || (ldc & 3) || ldc < N) return PK_EINVAL;
+    if (!al16(A) || !al16(W) || !al16(C) || lda % (16 / esz) || ldw % (16 / esz)) return PK_EALIGN;
+    if (!dma_possible(dtype, dtype == 1 ? 0 : 1, N, K, lda, ldw, M)) return PK_EINVAL;
+    const int Kc = K / splits;
+    GemmOperands p{A, W, nullptr, lda, ldw, M, N, Kc, 1, 0};
+    GemmEpilogue e{nullptr, nullptr, C, 0, ldc, 1, ACT_NONE, 1};
+    const long ba = (long)Kc * esz, bw = (long)Kc * esz, bc = (long)M * ldc * 4;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == 1) return launch_splitk<bf16>(p, e, M, splits, ba, bw, bc, s);
+    if (dtype == 2) return launch_splitk<bf16x3>(p, e, M, splits, ba, bw, bc, s);
+    return launch_splitk<float>(p, e, M, splits, ba, bw, bc, s);
 }

@@ -69,6 +69,26 @@ def linear_fwd(dtype, x, W, *, bias=None, res=None, act=L.ACT_NONE):
     return y
 
 
+def _weight_grad_gemm(dtype, dyT, xT, N, K, Mp, dW):
+    """dW (N, K) = dyT (N, Mp) @ xT (K, Mp)^T: the contraction runs over the rows of the batch (Mp = 4608 at B = 8) while the output has only
+    ceil(N / 64) ceil(K / 64) tiles -- 64 for a 512 x 512 projection on 256 CUs -- so the product is cut into K-slices (pk_gemm_splitk) that are
+    added in index order (pk_sum_batch: deterministic)."""
+    q = _q(dtype)
+    tiles = ((N + 63) // 64) * ((K + 63) // 64)
+    splits = 1
+    if K % 4 == 0 and dW.is_contiguous():
+        for cand in (8, 4, 2):
+            if tiles * cand <= 768 and Mp % (cand * q) == 0 and Mp // cand >= 4 * q:
+                splits = cand
+                break
+    if splits == 1:
+        L.gemm(dtype, dyT, xT, N, K, Mp, C=dW)
+        return
+    part = torch.empty((splits, N * K), device=dW.device, dtype=torch.float32)
+    L.gemm_splitk(dtype, dyT, xT, N, K, Mp, splits, part)
+    L.sum_batch(part, splits, dW, N * K)
+
+
 def linear_bwd(dtype, x, W, dy, *, need_dx=True, add=None, need_dw=True, dw_out=None):
     """gradients of y = x W^T: dx = dy W [+ add] (M, K), dW = dy^T x (N, K).  dw_out: preallocated (N, K) destination (may be a row slice)."""
     M, K = x.shape
@@ -82,7 +102,7 @@ def linear_bwd(dtype, x, W, dy, *, need_dx=True, add=None, need_dw=True, dw_out=
         dyT = pack_operand(dy, dtype, transpose=True, side='a')          # (N, Mp)
         xT = pack_operand(x, dtype, transpose=True)                      # (K, Mp)
         dW = dw_out if dw_out is not None else _f32((N, K), x.device)
-        L.gemm(dtype, dyT, xT, N, K, Mp, C=dW)
+        _weight_grad_gemm(dtype, dyT, xT, N, K, Mp, dW)
     return dx, dW
 
 
@@ -155,7 +175,7 @@ class _FFBlock(torch.autograd.Function):
         dyT = pack_operand(dy, dtype, transpose=True, side='a')           # (D, Mp)
         aT = pack_operand(a, dtype, transpose=True)                       # (Fp, Mp)
         dW2 = _f32((D, F), dev)
-        L.gemm(dtype, dyT, aT, D, F, Mp, C=dW2)
+        _weight_grad_gemm(dtype, dyT, aT, D, F, Mp, dW2)
         # ---- GEGLU
         dh = _f32((M, 2 * Fp), dev)
         L.geglu_bwd(h, Fp, da, dh, M, Fp)
@@ -173,8 +193,8 @@ class _FFBlock(torch.autograd.Function):
         dhT = pack_operand(dh, dtype, transpose=True, side='a')           # (2 Fp, Mp)
         xnT = pack_operand(xn, dtype, transpose=True)                     # (D, Mp)
         dW1 = _f32((2 * F, D), dev)
-        L.gemm(dtype, dhT[:F], xnT, F, D, Mp, C=dW1[:F])
-        L.gemm(dtype, dhT[Fp:Fp + F], xnT, F, D, Mp, C=dW1[F:])
+        _weight_grad_gemm(dtype, dhT[:F], xnT, F, D, Mp, dW1[:F])
+        _weight_grad_gemm(dtype, dhT[Fp:Fp + F], xnT, F, D, Mp, dW1[F:])
         # ---- LayerNorm + residual
         dx = _f32((M, D), dev)
         dg, db = L.layernorm_bwd(x, ln_w.detach(), dxn, dx, M, D, add=dy, want_beta=True, eps=ctx.eps)

@@ -535,3 +535,31 @@ def test_training_loop_tracks_torch_adamw_on_the_oracle(dtype):
                                  text_mask=torch.any(ctx != 0, dim=-1))
     assert (after - before).abs().max() > 1e-3, 'training must change the logits'
     close(after, want, 2e-3, 'inference path after training (stale packed weights?)')
+
+
+@pytest.mark.parametrize('dtype,tol', [('fp32', 1e-5), ('bf16x3', 2e-4), ('bf16', 2e-2)])
+def test_gemm_splitk_matches_plain_product(dtype, tol):
+    """pk_gemm_splitk + pk_sum_batch (the weight-gradient product of the training step) against an f64 product, ragged M / N tiles"""
+    from phenaki_pytorch_amd import _lib as L
+    from phenaki_pytorch_amd.attention import resolve_dtype
+    from phenaki_pytorch_amd.train import pack_operand, _weight_grad_gemm
+    dt = resolve_dtype(dtype)
+    g = torch.Generator().manual_seed(31)
+    rows, N, K = 1000, 200, 136                     # dW (N, K) = dy^T (N, rows) x (rows, K)
+    dy, x = torch.randn(rows, N, generator=g), torch.randn(rows, K, generator=g)
+    want = (dy.double().t() @ x.double()).float()
+    q = 64 if dtype == 'bf16' else 32
+    Mp = (rows + q - 1) // q * q
+    dyT = pack_operand(dy.cuda(), dt, transpose=True, side='a')
+    xT = pack_operand(x.cuda(), dt, transpose=True)
+    for splits in (2, 4):
+        if Mp % (splits * q):
+            continue
+        part = torch.empty((splits, N * K), device='cuda')
+        L.gemm_splitk(dt, dyT, xT, N, K, Mp, splits, part)
+        out = torch.empty((N, K), device='cuda')
+        L.sum_batch(part, splits, out, N * K)
+        close(out.cpu(), want, tol, f'split-K x{splits} ({dtype})')
+    out2 = torch.empty((N, K), device='cuda')
+    _weight_grad_gemm(dt, dyT, xT, N, K, Mp, out2)
+    close(out2.cpu(), want, tol, f'weight-gradient product ({dtype})')
