@@ -304,7 +304,7 @@ def test_hip_adamw_matches_torch_adamw_and_bumps_versions():
     """optim.py (reference optimizer.py:11-37): get_optimizer's grouping and the pk_adamw update against torch.optim.AdamW / Adam on CPU"""
     import phenaki_pytorch_amd as P
     g = torch.Generator().manual_seed(8)
-    shapes = [(33, 17), (129,), (4, 3, 3)]
+    shapes = [(33, 17), (129,), (4, 3, 3), (100, 90), (5000,), (7, 3)]      # >= 4 tensors per group: the one-launch pointer-table path; 3 chunks for (100, 90)
     for wd in (1e-2, 0.0):
         ref_p = [torch.randn(*s, generator=g).requires_grad_() for s in shapes]
         hip_p = [p.detach().clone().cuda().requires_grad_() for p in ref_p]
@@ -326,7 +326,7 @@ def test_hip_adamw_matches_torch_adamw_and_bumps_versions():
             for p, q in zip(ref_p, hip_p):
                 close(q.detach().cpu(), p.detach(), 1e-5, f'adamw step {it} wd {wd}')
         sd = opt.state_dict()
-        assert len(sd['state']) == 3 and sd['state'][0]['step'] == 4
+        assert len(sd['state']) == len(shapes) and sd['state'][0]['step'] == 4
 
 
 @pytest.mark.parametrize('variant', ['self_critic', 'unconditional', 'no_critic_video_mask'])
