@@ -174,8 +174,13 @@ class _FFBlock(torch.autograd.Function):
         L.gemm(dtype, dy, w2t, M, Fp, D, C=da)
         dyT = pack_operand(dy, dtype, transpose=True, side='a')           # (D, Mp)
         aT = pack_operand(a, dtype, transpose=True)                       # (Fp, Mp)
-        dW2 = _f32((D, F), dev)
-        _weight_grad_gemm(dtype, dyT, aT, D, F, Mp, dW2)
+        dW2 = None if F % 4 else _f32((D, F), dev)
+        if F % 4:                                                        # inner 1365: the product on the padded width (a's pad columns are zero), then the slice
+            dW2p = _f32((D, Fp), dev)
+            _weight_grad_gemm(dtype, dyT, aT, D, Fp, Mp, dW2p)
+            dW2 = dW2p[:, :F].contiguous()
+        else:
+            _weight_grad_gemm(dtype, dyT, aT, D, F, Mp, dW2)
         # ---- GEGLU
         dh = _f32((M, 2 * Fp), dev)
         L.geglu_bwd(h, Fp, da, dh, M, Fp)
@@ -497,7 +502,7 @@ class _VocabCrossEntropy(torch.autograd.Function):
             # dE (+)= g @ W_slab: contraction over the slab's columns = columns [v0, v0 + Vs) of the W^T image (k offset on the operand)
             L.gemm(dtype, g, Wt[:, v0:], M, D, Vs, C=dE, res=None if first else dE, lda=g.stride(0))
             # dW_slab = g^T @ E (K = the rows, padded to the k-tile: gT's pad columns are zeroed by the kernel, E^T is zero-padded)
-            L.gemm(dtype, gT, Et, Vs, D, Mp, C=dW[v0:v0 + Vs], lda=gT.stride(0))
+            _weight_grad_gemm(dtype, gT[:Vs], Et, Vs, D, Mp, dW[v0:v0 + Vs])
             first = False
         if rows is not None:
             full = _zeros((R, D), dev)
