@@ -233,6 +233,14 @@ int pk_vocab_ntiles(int V);
 int pk_vocab_sample(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, int M, int V, int D,
                     float temperature, const float* U, const int* rows, unsigned long long seed,
                     const unsigned long long* seed_dev, int need_lse, void* partials, void* stream);
+/* PARITY sampling on torch's own device RNG stream (SURVEY.md 7 "phase 2"): the gumbel noise of logical row r, column v is bit for bit
+ * what `torch.zeros(rows_total, V, device=...).uniform_(0, 1)[r][v]` holds for a generator at (torch_seed, philox_offset) -- the reference's
+ * gumbel_noise(logits), phenaki_pytorch.py:88-93 -- generated in the epilogue (Philox4x32-10 with ATen's element -> (subsequence, counter, word)
+ * map, csrc/common.hpp torch_uniform); philox_stride = 256 * min(#CUs * (max threads per CU / 256), ceil(rows_total * V / 256)), the caller
+ * advances the generator by 4 * ceil(rows_total * V / (4 * philox_stride)).  A seeded reference run on the same GPU draws the same noise. */
+int pk_vocab_sample_philox(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, int M, int V, int D, float temperature,
+                           const int* rows, unsigned long long torch_seed, unsigned long long philox_offset, unsigned int philox_stride,
+                           int need_lse, void* partials, void* stream);
 int pk_vocab_reduce(const void* partials, int M, int V, const int* rows, const unsigned char* mask, long long* ids,
                     long long* pred, float* scores, int need_lse, void* stream);
 

@@ -50,6 +50,7 @@ SIGNATURES = {
     'pk_attn_small': [_P, _I, _P, _I, _P, _P, _F, _P, _L, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     'pk_cfg_mix': [_P, _I, _I, _I, _I, _P, _I, _F, _I, _P, _I, _I, _I, _P],
     'pk_vocab_ntiles': [_I],
+    'pk_vocab_sample_philox': [_I, _P, _I, _P, _I, _P, _I, _I, _I, _F, _P, _ULL, _ULL, ctypes.c_uint, _I, _P, _P],
     'pk_vocab_sample': [_I, _P, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P, _ULL, _P, _I, _P, _P],
     'pk_vocab_reduce': [_P, _I, _I, _P, _P, _P, _P, _P, _I, _P],
     'pk_vocab_ce': [_I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P],
@@ -558,3 +559,27 @@ def gemm_splitk(dtype, A, W, M, N, K, splits, C):
     """C (splits, M, N) f32 <- the K-slices of A @ W^T (see the header); reduce with sum_batch"""
     rc = load().pk_gemm_splitk(dtype, ptr(A), A.stride(-2), ptr(W), W.stride(0), M, N, K, splits, ptr(C), N, stream(C))
     _check(rc, 'pk_gemm_splitk')
+
+
+class TorchPhilox:
+    """where torch's device generator stands for ONE `uniform_` fill of `numel` float32 elements (ATen's launch geometry on this device):
+    seed, Philox offset, thread stride; `.advance()` moves the generator past the fill exactly as the real op would"""
+
+    def __init__(self, device, numel):
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        self.gen = torch.cuda.default_generators[idx]
+        props = torch.cuda.get_device_properties(idx)
+        blocks = min(props.multi_processor_count * (props.max_threads_per_multi_processor // 256), (numel + 255) // 256)
+        self.stride = 256 * blocks
+        self.seed = self.gen.initial_seed() & 0xFFFFFFFFFFFFFFFF
+        self.offset = self.gen.get_offset()
+        self.increment = ((numel - 1) // (self.stride * 4) + 1) * 4
+
+    def advance(self):
+        self.gen.set_offset(self.offset + self.increment)
+
+
+def vocab_sample_philox(dtype, A, W, bias, M, V, D, temperature, rows, spec, need_lse, partials):
+    rc = load().pk_vocab_sample_philox(dtype, ptr(A), A.stride(-2), ptr(W), W.stride(0), f32p(bias, 'to_logits.bias'), M, V, D, temperature, ptr(rows),
+                                       spec.seed, spec.offset, spec.stride, 1 if need_lse else 0, ptr(partials), stream(A))
+    _check(rc, 'pk_vocab_sample_philox')

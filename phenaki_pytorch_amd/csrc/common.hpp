@@ -236,6 +236,34 @@ __device__ __host__ __forceinline__ void uniform24x4(uint32_t seed_lo, uint32_t 
     u[3] = (float)(((w0 & 0xFFu) << 16) | ((w1 & 0xFFu) << 8) | (w2 & 0xFFu)) * k;
 }
 
+// ---- torch's device RNG, reproduced (SURVEY.md 7 "phase 2"; reference phenaki_pytorch.py:69-70, :88-93: noise = zeros_like(t).uniform_(0, 1)) ----
+// torch.Tensor.uniform_ on a HIP device fills element li of a tensor of `numel` elements from Philox4x32-10 (rocRAND) as follows
+// (ATen/native/cuda/DistributionTemplates.h: distribution_elementwise_grid_stride_kernel, block 256, unroll 4):
+//   grid   = min(#CUs * (max threads per CU / 256), ceil(numel / 256)),   stride = 256 * grid
+//   thread = li % stride (the Philox SUBSEQUENCE),  call k = li / (4 stride) (the thread's k-th 4-word draw),  word = (li / stride) % 4
+//   x      = philox4x32_10(counter = {offset / 4 + k (64 bit), thread (64 bit)}, key = seed)[word]
+//   u      = 2^-32 + float(x) * 2^-32   (rocrand_uniform),   u == 1 -> 0   (uniform_ maps (0, 1] to [0, 1))
+// and the generator's offset then advances by 4 * ceil(numel / (4 stride)).  Bit-exact against torch.zeros(n, device='cuda').uniform_()
+// on MI355X (tests/test_kernels_gpu.py).  Used by the PARITY sampler so that a seeded reference run on the same GPU is reproducible.
+__device__ __forceinline__ uint32_t philox4x32_10_word(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, int word) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return word == 0 ? c0 : word == 1 ? c1 : word == 2 ? c2 : c3;
+}
+__device__ __forceinline__ float torch_uniform(uint32_t seed_lo, uint32_t seed_hi, uint64_t offset, uint64_t li, uint32_t stride) {
+    const uint64_t q = li / stride;
+    const uint32_t thread = (uint32_t)(li - q * stride);
+    const uint64_t n = (offset >> 2) + (q >> 2);
+    const uint32_t x = philox4x32_10_word((uint32_t)n, (uint32_t)(n >> 32), thread, 0u, seed_lo, seed_hi, (int)(q & 3));
+    const float u = 2.3283064365386963e-10f + (float)x * 2.3283064365386963e-10f;
+    return u == 1.0f ? 0.0f : u;
+}
+
 constexpr float NEG_MAX = -3.402823466e+38f;   // -finfo(float32).max, the reference's mask fill value
 
 }  // namespace pk

@@ -42,6 +42,8 @@ __global__ __launch_bounds__(256) void cfg_mix_kernel(const float* __restrict__ 
 struct VocabArgs {
     const float* bias;       // [V]
     const float* U;          // PARITY: uniform noise [M][V]; FAST: unused
+    uint32_t philox_stride;  // PARITY without U: the noise is torch's own uniform_ stream (common.hpp torch_uniform): 256 * grid of the (rows, V) fill
+    unsigned long long philox_offset;   // ... the generator's Philox offset at that fill; the seed is (seed_lo, seed_hi)
     const int* rows;         // optional: output row r is logical row rows[r] (noise / partial indexing)
     float temp;              // max(temperature, 1e-10)
     uint32_t seed_lo, seed_hi;
@@ -148,7 +150,16 @@ __global__ __launch_bounds__(64 * VocabGeom<T>::WM * VocabGeom<T>::WN) void voca
             const int n = n0 + wn * 16 * VTN + j * 16 + g * 4;
             const f32x4 bv = bvj[j];
             f32x4 uv = f32x4{0.5f, 0.5f, 0.5f, 0.5f};
-            if (PARITY) { if (mok && n < V) uv = *reinterpret_cast<const f32x4*>(e.U + (size_t)lrow * V + n); }
+            if (PARITY) {
+                if (mok && n < V) {
+                    if (e.U) uv = *reinterpret_cast<const f32x4*>(e.U + (size_t)lrow * V + n);
+                    else {
+                        const uint64_t li = (uint64_t)lrow * (uint64_t)V + (uint64_t)n;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) uv[r] = torch_uniform(e.seed_lo, e.seed_hi, e.philox_offset, li + r, e.philox_stride);
+                    }
+                }
+            }
             float uf[4] = {0.5f, 0.5f, 0.5f, 0.5f};
             if (!PARITY && !e.no_noise) {
                 const uint64_t gq = ((uint64_t)lrow * (uint64_t)V + (uint64_t)n) >> 2;      // V % 4 == 0: group of 4 columns
@@ -419,9 +430,10 @@ extern "C" int pk_cfg_mix(const float* x, int ldx, int nb, int n_tot, int n_prim
 extern "C" int pk_vocab_ntiles(int V) { return (V + 127) / 128; }
 
 // workspace: 5 arrays of ntiles*M 4-byte words, passed as one buffer `partials` of 5*ntiles*M words
-extern "C" int pk_vocab_sample(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias,
+static int vocab_sample_launch(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias,
                                int M, int V, int D, float temperature, const float* U, const int* rows,
-                               unsigned long long seed, const unsigned long long* seed_dev, int need_lse, void* partials, void* stream) {
+                               unsigned long long seed, const unsigned long long* seed_dev, int need_lse, void* partials, void* stream,
+                               unsigned long long philox_offset, unsigned int philox_stride) {
     if (!A || !W || !bias || !partials || M <= 0 || V <= 0 || D <= 0) return PK_EINVAL;
     if (dtype != 0 && dtype != 1 && dtype != 2) return PK_EINVAL;
     const int eps = dtype == 1 ? 8 : 4;
@@ -433,6 +445,8 @@ extern "C" int pk_vocab_sample(int dtype, const void* A, int lda, const void* W,
     GemmOperands p{A, W, nullptr, lda, ldw, M, V, D, 0, krot_default()};
     VocabArgs e;
     e.bias = bias; e.U = U; e.rows = rows;
+    e.philox_stride = philox_stride; e.philox_offset = philox_offset;
+    const bool parity = U != nullptr || philox_stride != 0;
     e.temp = temperature > 1e-10f ? temperature : 1e-10f;
     e.seed_lo = (uint32_t)seed; e.seed_hi = (uint32_t)(seed >> 32); e.seed_dev = seed_dev;
     e.need_lse = need_lse & 1; e.no_noise = (need_lse >> 1) & 1; e.ntiles = ntiles;
@@ -449,18 +463,36 @@ extern "C" int pk_vocab_sample(int dtype, const void* A, int lda, const void* W,
 #define PK_VS(TT, PAR, LS) hipLaunchKernelGGL((vocab_sample_kernel<TT, PAR, LS>), grid, dim3(VocabTile<TT>::THREADS), VocabTile<TT>::SMEM, s, p, e)
     const bool lse = e.need_lse != 0;
     if (dtype == 1) {
-        if (U) { if (lse) PK_VS(bf16, true, true); else PK_VS(bf16, true, false); }
+        if (parity) { if (lse) PK_VS(bf16, true, true); else PK_VS(bf16, true, false); }
         else { if (lse) PK_VS(bf16, false, true); else PK_VS(bf16, false, false); }
     } else if (dtype == 2) {                              // split-bf16: f32 rows of A, host-packed (hi | lo) planes of W (common.hpp)
-        if (U) { if (lse) PK_VS(bf16x3, true, true); else PK_VS(bf16x3, true, false); }
+        if (parity) { if (lse) PK_VS(bf16x3, true, true); else PK_VS(bf16x3, true, false); }
         else { if (lse) PK_VS(bf16x3, false, true); else PK_VS(bf16x3, false, false); }
     } else {
-        if (U) { if (lse) PK_VS(float, true, true); else PK_VS(float, true, false); }
+        if (parity) { if (lse) PK_VS(float, true, true); else PK_VS(float, true, false); }
         else { if (lse) PK_VS(float, false, true); else PK_VS(float, false, false); }
     }
 #undef PK_VS
     PK_CHECK_LAUNCH();
     return PK_OK;
+}
+
+extern "C" int pk_vocab_sample(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias,
+                               int M, int V, int D, float temperature, const float* U, const int* rows,
+                               unsigned long long seed, const unsigned long long* seed_dev, int need_lse, void* partials, void* stream) {
+    return vocab_sample_launch(dtype, A, lda, W, ldw, bias, M, V, D, temperature, U, rows, seed, seed_dev, need_lse, partials, stream, 0ull, 0u);
+}
+
+// PARITY sampling on torch's own device RNG stream: the gumbel noise of logical row r, column v is what
+// `torch.zeros(rows_total, V, device=...).uniform_(0, 1)[r][v]` would hold for a generator at (torch_seed, philox_offset) -- the reference's
+// gumbel_noise(logits) (phenaki_pytorch.py:88-93) -- generated in the epilogue, the (rows_total, V) noise tensor never exists.  philox_stride =
+// 256 * min(#CUs * (max threads per CU / 256), ceil(rows_total * V / 256)); the caller advances the generator (common.hpp torch_uniform).
+extern "C" int pk_vocab_sample_philox(int dtype, const void* A, int lda, const void* W, int ldw, const float* bias, int M, int V, int D, float temperature,
+                                      const int* rows, unsigned long long torch_seed, unsigned long long philox_offset, unsigned int philox_stride,
+                                      int need_lse, void* partials, void* stream) {
+    if (philox_stride == 0 || (philox_stride & 255) || (philox_offset & 3)) return PK_EINVAL;
+    return vocab_sample_launch(dtype, A, lda, W, ldw, bias, M, V, D, temperature, nullptr, rows, torch_seed, nullptr, need_lse & 1, partials, stream,
+                               philox_offset, philox_stride);
 }
 
 extern "C" int pk_vocab_reduce(const void* partials, int M, int V, const int* rows, const unsigned char* mask,

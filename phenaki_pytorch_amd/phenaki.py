@@ -547,8 +547,14 @@ class Phenaki(PackedModule):
 
             temperature = st['starting_temperature'] * (steps_til_x0 / steps)
             U = noise_fn('gumbel', step, (B, n, V)) if noise_fn is not None else None
-            L.vocab_sample(dt, mixed, w_logits, mg.to_logits.bias, M, V, D, float(temperature), U, rows,
-                           (seed_base + step * 0x9E3779B97F4A7C15) & M64, need_lse, partials, seed_dev=seed_dev)
+            if isinstance(U, L.TorchPhilox):
+                # torch's own RNG stream: the noise torch.zeros((B, n, V)).uniform_() would hold, generated in the epilogue; then the
+                # generator moves on as if that fill had happened (the reference's gumbel_noise, phenaki_pytorch.py:88-93)
+                L.vocab_sample_philox(dt, mixed, w_logits, mg.to_logits.bias, M, V, D, float(temperature), rows, U, need_lse, partials)
+                U.advance()
+            else:
+                L.vocab_sample(dt, mixed, w_logits, mg.to_logits.bias, M, V, D, float(temperature), U, rows,
+                               (seed_base + step * 0x9E3779B97F4A7C15) & M64, need_lse, partials, seed_dev=seed_dev)
             L.vocab_reduce(partials, M, V, rows, mask, ids, pred, nxt if need_lse else None, need_lse)
             if rec is not None:
                 rec.update(pred=pred.clone(), ids=ids.clone())
@@ -599,7 +605,8 @@ class Phenaki(PackedModule):
                starting_temperature=0.9, noise_K=1., _noise_fn=None, _trace=None, _return_ids=False, _compact=None, _seed=None,
                _force_fn=None):
         """phenaki_pytorch.py:418-560.  `_noise_fn(kind, step, shape)` (tests) injects the U[0,1) draws of the
-        reference run ('gumbel' (B,n,V) and 'critic' (B,n), device f32 tensors); without it the noise comes from the
+        reference run ('gumbel' (B,n,V) and 'critic' (B,n), device f32 tensors); _noise_fn='torch': torch's device generator in the
+        reference's order (a seeded reference run on the same GPU draws the same noise); without it the noise comes from the
         in-kernel counter hash seeded from torch's default (CPU) generator (`_seed`: the exact 64-bit stream seed instead;
         the seed a call used is kept in `self._pk_last_seed`).  `_force_fn(step, ids, mask)` (tests) may overwrite a step's masked
         input ids (B, n) int64 and mask (B, n) uint8 in place before the trunk runs (teacher forcing; eager, no row compaction)."""
@@ -607,6 +614,17 @@ class Phenaki(PackedModule):
         L.require_device(next(self.parameters()), 'Phenaki parameters')
         mg, critic = self.maskgit, self.critic
         dt = compute_dtype_of(mg)
+        if isinstance(_noise_fn, str):
+            # _noise_fn = 'torch': the reference's own noise -- torch's device generator, consumed in the reference's order (per step one
+            # uniform_ of (B, n, V) for gumbel_sample, phenaki_pytorch.py:88-93, then one of (B, n) for the critic scores, :69-70 / :541-543).
+            # The (B, n, V) fill is never materialised: the vocabulary head reproduces its elements from the Philox state (pk_vocab_sample_philox)
+            # and the generator is moved past it, so `torch.manual_seed(s); phenaki.sample(...)` draws what a reference run on this GPU draws.
+            assert _noise_fn == 'torch', "_noise_fn: a callable or 'torch'"
+
+            def _noise_fn(kind, step, shape):
+                if kind == 'gumbel':
+                    return L.TorchPhilox(device, shape[0] * shape[1] * shape[2])
+                return torch.zeros(shape, device=device).float().uniform_(0, 1)
 
         has_prime = exists(prime_frames)
         prime_token_ids = None

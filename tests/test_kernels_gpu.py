@@ -1102,3 +1102,41 @@ def test_patch_embed_fused(L, B, C, Fr, H, W, pt, ph, pw, N):
         close(out, (F.layer_norm(pat, (P,)) @ wg.double().t()).float(), 1.2e-2, 'single group')
         with pytest.raises(RuntimeError, match='PK_EINVAL'):
             L.patch_embed(video.cuda(), ph, pw, N, [(wg.cuda(), wg.float().sum(1).cuda(), torch.zeros(N).cuda(), out, 0, 2, 1)])      # frames beyond F
+
+
+@pytest.mark.parametrize('numel', [1, 7, 1000, 70000, 256 * 2048 * 4 + 5, 3 * 576 * 65536])
+def test_torch_philox_reproduction_is_bit_exact(L, numel):
+    """common.hpp torch_uniform == torch.zeros(numel, device='cuda').uniform_(0, 1), element by element, through pk_vocab_sample_philox:
+    with W = 0 and bias = 0 every logit is 0, so pred[row] = argmax_v gumbel(u[row][v]) = argmax_v u[row][v] -- compared with the argmax of
+    the materialised torch fill (all rows, and a gathered subset), at a non-zero generator offset; the generator ends where torch's op ends"""
+    V = 64 if numel < 100000 else (4096 if numel < 10 ** 7 else 65536)
+    rows_total = max(1, numel // V)
+    n_el = rows_total * V
+    D = 32
+    A = torch.zeros((rows_total, D), device='cuda')
+    W = torch.zeros((V, D), device='cuda')
+    bias = torch.zeros((V,), device='cuda')
+    gen = torch.cuda.default_generators[0]
+    torch.manual_seed(4242)
+    torch.zeros(1000, device='cuda').uniform_(0, 1)                # move the generator off offset 0
+    state = gen.get_state()
+    ref = torch.zeros((rows_total, V), device='cuda').uniform_(0, 1)
+    end = gen.get_offset()
+    gen.set_state(state)
+    spec = L.TorchPhilox(torch.device('cuda', 0), n_el)
+    partials = torch.empty((5 * L.vocab_ntiles(V) * rows_total,), device='cuda')
+    L.vocab_sample_philox(L.F32, A, W, bias, rows_total, V, D, 1.0, None, spec, False, partials)
+    spec.advance()
+    assert gen.get_offset() == end
+    pred = torch.empty((rows_total,), device='cuda', dtype=torch.long)
+    L.vocab_reduce(partials, rows_total, V, None, None, None, pred, None, False)
+    want = ref.argmax(dim=-1)
+    assert torch.equal(pred, want), f'{int((pred != want).sum())} of {rows_total} rows differ'
+    if rows_total >= 8:
+        rows = torch.tensor([rows_total - 1, 0, rows_total // 2, 3], dtype=torch.int32, device='cuda')
+        Ag = torch.zeros((4, D), device='cuda')
+        p2 = torch.empty((5 * L.vocab_ntiles(V) * 4,), device='cuda')
+        L.vocab_sample_philox(L.F32, Ag, W, bias, 4, V, D, 1.0, rows, spec, False, p2)
+        pr = torch.full((rows_total,), -1, device='cuda', dtype=torch.long)
+        L.vocab_reduce(p2, 4, V, rows, None, None, pr, None, False)
+        assert torch.equal(pr[rows.long()], want[rows.long()])

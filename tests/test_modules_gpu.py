@@ -1013,3 +1013,30 @@ def test_t5_encoder_matches_huggingface_golden(golden_dir, tag, dtype, tol):
         n1 = int(g['mask'][1].sum())
         solo = enc(g['ids'][1:2, :n1].cuda())
         close(solo[0], out[1, :n1], 1e-4, 'ragged row vs the same sequence alone')
+
+
+@pytest.mark.parametrize('with_critic', [True, False])
+def test_sample_on_torch_rng_stream_equals_explicit_torch_noise(with_critic):
+    """SURVEY.md 7 "phase 2" (VERDICT r2 missing #6): with _noise_fn='torch' the sampler consumes torch's device generator exactly as the
+    reference does -- per step one uniform_ of (B, n, V) (gumbel_noise) and one of (B, n) (critic) -- but reproduces the elements of the big
+    fill inside the vocabulary head (pk_vocab_sample_philox) instead of materialising it.  Against the SAME run fed the explicitly
+    materialised torch.zeros(shape).uniform_() tensors: ids and video bit-equal, and the generator ends at the same offset."""
+    cv, mg, cr, ph = load_product('tiny', TINY, with_critic=with_critic)
+    ctx = weights.synthetic_context(2, 6, TINY['maskgit']['dim_context'], seed=2).cuda()
+    ph.encode_texts = lambda texts, output_device=None: ctx[:len(texts)]
+    gen = torch.cuda.default_generators[0]
+
+    def explicit(kind, step, shape):
+        return torch.zeros(shape, device='cuda').float().uniform_(0, 1)
+
+    torch.manual_seed(77)
+    va, ia = ph.sample(texts=['a', 'b'], num_frames=5, cond_scale=3., _noise_fn='torch', _return_ids=True)
+    off_a = gen.get_offset()
+    torch.manual_seed(77)
+    vb, ib = ph.sample(texts=['a', 'b'], num_frames=5, cond_scale=3., _noise_fn=explicit, _return_ids=True)
+    off_b = gen.get_offset()
+    assert off_a == off_b and off_a > 0, (off_a, off_b)
+    assert torch.equal(ia, ib) and torch.equal(va, vb)
+    torch.manual_seed(78)
+    _, ic = ph.sample(texts=['a', 'b'], num_frames=5, cond_scale=3., _noise_fn='torch', _return_ids=True)
+    assert not torch.equal(ia, ic), 'another torch seed must give another sample'
