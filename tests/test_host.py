@@ -286,3 +286,13 @@ def test_loss_value_forwards_carry_a_raising_backward():
         assert value_without_graph(ph, 'x', val) is val
         with pytest.raises(AssertionError, match='needs a critic'):
             ph(video_codebook_ids=torch.zeros(1, 3, 4, 4, dtype=torch.long), text_embeds=torch.randn(1, 4, 96), only_train_critic=True)
+
+
+def test_torch_library_ops_are_registered_without_a_cpu_kernel():
+    """SURVEY.md 8b: the core kernels as torch.library custom ops (phenaki_mi355x::*); schemas register without a GPU, and a CPU tensor
+    finds no kernel (the product has no CPU fallback)"""
+    import phenaki_pytorch_amd.ops as ops
+    for name in ops.OPS:
+        assert hasattr(torch.ops.phenaki_mi355x, name), name
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.phenaki_mi355x.layernorm(torch.randn(4, 8), torch.ones(8), None, torch.empty(4, 8), 1e-5)

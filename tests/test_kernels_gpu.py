@@ -1140,3 +1140,33 @@ def test_torch_philox_reproduction_is_bit_exact(L, numel):
         pr = torch.full((rows_total,), -1, device='cuda', dtype=torch.long)
         L.vocab_reduce(p2, 4, V, rows, None, None, pr, None, False)
         assert torch.equal(pr[rows.long()], want[rows.long()])
+
+
+def test_torch_library_ops_match_the_direct_wrappers(L):
+    """phenaki_mi355x::gemm / layernorm / vocab_sample + vocab_reduce through the dispatcher == the ctypes wrappers the modules call"""
+    import phenaki_pytorch_amd.ops  # noqa: F401
+    from phenaki_pytorch_amd.attention import pack_linear_weight
+    ops = torch.ops.phenaki_mi355x
+    x = torch.randn(300, 512, generator=g(401)).cuda()
+    w = (torch.randn(256, 512, generator=g(402)) / 22).cuda()
+    b = torch.randn(256, generator=g(403)).cuda()
+    for dt in (L.F32, L.BF16X3):
+        wp = pack_linear_weight(w, dt)
+        want = torch.empty((300, 256), device='cuda')
+        L.gemm(dt, x, wp, 300, 256, 512, C=want, bias=b)
+        got = ops.gemm(x, wp, b, None, torch.empty((300, 256), device='cuda'), dt, 0)
+        assert torch.equal(got, want)
+    gam = (torch.rand(512, generator=g(404)) + 0.5).cuda()
+    y = ops.layernorm(x, gam, None, torch.empty_like(x), 1e-5)
+    close(y.cpu(), torch.nn.functional.layer_norm(x.cpu(), (512,), gam.cpu(), None), 1e-5, 'layernorm op')
+    V = 1024
+    wv = pack_linear_weight((torch.randn(V, 512, generator=g(405)) / 22).cuda(), L.F32)
+    bv = torch.zeros(V, device='cuda')
+    p1 = torch.empty((5 * L.vocab_ntiles(V) * 300,), device='cuda')
+    p2 = torch.empty_like(p1)
+    L.vocab_sample(L.F32, x, wv, bv, 300, V, 512, 0.7, None, None, 1234, False, p1)
+    ops.vocab_sample(x, wv, bv, None, None, p2, L.F32, 0.7, 1234, False)
+    a1, a2 = torch.empty(300, device='cuda', dtype=torch.long), torch.empty(300, device='cuda', dtype=torch.long)
+    L.vocab_reduce(p1, 300, V, None, None, None, a1, None, False)
+    ops.vocab_reduce(p2, None, None, None, a2, None, V, False)
+    assert torch.equal(a1, a2)
