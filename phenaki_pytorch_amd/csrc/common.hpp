@@ -74,20 +74,6 @@ __device__ __forceinline__ f32x4 mma(const Frag<float>& a, const Frag<float>& b,
     return c;
 }
 
-// 32 x 32 x 16 form (one 8-element chunk per lane is 32 rows x 16 k: lane l holds row l & 31, k = (l >> 5) * 8 + 0..7).  Measured on this
-// MI355X (tools/mfma_peak.hip): back-to-back v_mfma_f32_32x32x16_bf16 sustain 2.49 PFLOP/s, v_mfma_f32_16x16x32_bf16 1.35 PFLOP/s -- the
-// 16-row shape issues at half the flops per cycle, so MFMA-heavy loops want the 32-row shape.  acc: reg v of lane l = D[8 (v / 4) + 4 (l >> 5) + v % 4][l & 31].
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-__device__ __forceinline__ f32x16 mma32(const Frag<bf16>& a, const Frag<bf16>& b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a.v), __builtin_bit_cast(bf16x8_t, b.v), c, 0, 0, 0);
-}
-template <typename TS>
-__device__ __forceinline__ f32x16 mma32_split(const Frag<TS>& a, const Frag<TS>& b, f32x16 c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a.hi), __builtin_bit_cast(bf16x8_t, b.lo), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a.lo), __builtin_bit_cast(bf16x8_t, b.hi), c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a.hi), __builtin_bit_cast(bf16x8_t, b.hi), c, 0, 0, 0);
-}
-
 // split-bf16: 3 MFMAs per fragment pair, small cross terms first
 template <typename TS>
 __device__ __forceinline__ f32x4 mma_split(const Frag<TS>& a, const Frag<TS>& b, f32x4 c) {
@@ -96,7 +82,6 @@ __device__ __forceinline__ f32x4 mma_split(const Frag<TS>& a, const Frag<TS>& b,
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a.hi), __builtin_bit_cast(bf16x8_t, b.hi), c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x4 mma(const Frag<bf16x3>& a, const Frag<bf16x3>& b, f32x4 c) { return mma_split(a, b, c); }
-__device__ __forceinline__ f32x16 mma32(const Frag<bf16x3>& a, const Frag<bf16x3>& b, f32x16 c) { return mma32_split(a, b, c); }
 __device__ __forceinline__ f32x4 mma(const Frag<bf16x3p>& a, const Frag<bf16x3p>& b, f32x4 c) { return mma_split(a, b, c); }
 
 // 8 f32 values -> (hi, lo) bf16 planes: 4 v_cvt_pk (hi, RNE) + 8 shift/and (hi back to f32) + 8 v_sub (exact: Sterbenz-like, the

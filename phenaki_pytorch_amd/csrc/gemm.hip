@@ -42,31 +42,19 @@ struct GemmEpilogue {
 constexpr int STATS_CHUNK = 32;      // columns per partial: the 16 * TN columns one wave owns in every TN = 2 kernel
 
 // scalar epilogue (N not a multiple of 4, e.g. heads = 2 or a 1-wide critic head): no LayerNorm fold, C2, scatter or stats_out (host refuses)
-// accumulator coordinate maps.  MAP32 = false: acc[i][j] is a 16 x 16 block of the 16-row MFMA (lane: row i * 16 + (l & 15), columns j * 16 + (l >> 4) * 4
-// + r).  MAP32 = true: the view of TM x TN blocks of 32 x 32 (gemm_dma.hpp run32) as acc[TM][4 TN] register quads: row i * 32 + (l & 31),
-// columns (j >> 2) * 32 + (j & 3) * 8 + (l >> 5) * 4 + r.  Either way a lane owns 4 consecutive columns of one row per quad.
-template <bool MAP32> struct AccMap {
-    static constexpr int MS = MAP32 ? 32 : 16;                           // rows per block index i
-    static constexpr int NS = MAP32 ? 8 : 16;                            // mean columns per quad index j (wave tile = NS * TN columns)
-    static __device__ __forceinline__ int mlane(int lane) { return MAP32 ? (lane & 31) : (lane & 15); }
-    static __device__ __forceinline__ int nlane(int lane) { return MAP32 ? (lane >> 5) * 4 : (lane >> 4) * 4; }
-    static __device__ __forceinline__ int ncol(int j) { return MAP32 ? (j >> 2) * 32 + (j & 3) * 8 : j * 16; }
-};
-
-template <typename T, int TM, int TN, int WN, bool MAP32 = false>
+template <typename T, int TM, int TN, int WN>
 __device__ __forceinline__ void gemm_epilogue_scalar(const f32x4 (&acc)[TM][TN], int M, int N, const GemmEpilogue& e, int m0, int n0) {
-    using Map = AccMap<MAP32>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int wm = wave / WN, wn = wave % WN, g = lane >> 4, lr = lane & 15;
     float* Cf = reinterpret_cast<float*>(e.C);
     T* Ct = reinterpret_cast<T*>(e.C);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * Map::MS * TM + i * Map::MS + Map::mlane(lane);
+        const int m = m0 + wm * 16 * TM + i * 16 + lr;
         if (m >= M) continue;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * Map::NS * TN + Map::ncol(j) + Map::nlane(lane);
+            const int n = n0 + wn * 16 * TN + j * 16 + g * 4;
             const f32x4 v = acc[i][j];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -97,25 +85,24 @@ __device__ __forceinline__ void gemm_epilogue_scalar(const f32x4 (&acc)[TM][TN],
 // rows blocks (of 16 rows) per load round of the epilogue: IB * TN residual vectors in flight per lane
 template <int TM> constexpr int epi_rows_per_round() { return TM > 2 ? 2 : TM; }
 
-template <typename T, int TM, int TN, int WN = 2, bool LNF = false, bool MAP32 = false>
+template <typename T, int TM, int TN, int WN = 2, bool LNF = false>
 __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[TM][TN], int M, int N, const GemmEpilogue& e, int m0, int n0,
                                               const float* rsum = nullptr, const float* rsq = nullptr, int K = 1) {
-    using Map = AccMap<MAP32>;
     if (!e.vec_ok) {
-        if (!LNF) gemm_epilogue_scalar<T, TM, TN, WN, MAP32>(acc, M, N, e, m0, n0);
+        if (!LNF) gemm_epilogue_scalar<T, TM, TN, WN>(acc, M, N, e, m0, n0);
         return;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave / WN, wn = wave % WN, g = lane >> 4;
+    const int wm = wave / WN, wn = wave % WN, g = lane >> 4, lr = lane & 15;
     float* __restrict__ Cf = reinterpret_cast<float*>(e.C);
     T* __restrict__ Ct = reinterpret_cast<T*>(e.C);
-    const int mb = m0 + wm * Map::MS * TM + Map::mlane(lane), nb = n0 + wn * Map::NS * TN + Map::nlane(lane);      // + i * MS, + ncol(j)
+    const int mb = m0 + wm * 16 * TM + lr, nb = n0 + wn * 16 * TN + g * 4;      // + i*16, + j*16
     // N % 4 == 0 and N >= 4 here, so N - 4 is a valid clamped column; values loaded through a clamped index are never stored
     f32x4 b4[TN], s4[TN], t4[TN];
     int coff[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int nj = min(nb + Map::ncol(j), N - 4);
+        const int nj = min(nb + j * 16, N - 4);
         b4[j] = e.bias ? *reinterpret_cast<const f32x4*>(e.bias + nj) : f32x4{0, 0, 0, 0};
         if (LNF) {
             s4[j] = *reinterpret_cast<const f32x4*>(e.ln_s + nj);
@@ -131,11 +118,11 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[TM][TN], int M,
         int roff[IB];
 #pragma unroll
         for (int ii = 0; ii < IB; ++ii) {
-            const int mi = min(mb + (i0 + ii) * Map::MS, M - 1);
+            const int mi = min(mb + (i0 + ii) * 16, M - 1);
             roff[ii] = e.row_off ? e.row_off[mi] : 0;
             if (!LNF && e.res && e.act != ACT_GEGLU) {      // (a folded GEMM with a residual -- no such call on the hot path -- loads it in phase 2)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) r4[ii][j] = *reinterpret_cast<const f32x4*>(e.res + (size_t)mi * e.ldr + min(nb + Map::ncol(j), N - 4));
+                for (int j = 0; j < TN; ++j) r4[ii][j] = *reinterpret_cast<const f32x4*>(e.res + (size_t)mi * e.ldr + min(nb + j * 16, N - 4));
             } else {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) r4[ii][j] = f32x4{0, 0, 0, 0};
@@ -144,7 +131,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[TM][TN], int M,
         // ---- phase 2: math and stores
 #pragma unroll
         for (int ii = 0; ii < IB; ++ii) {
-            const int i = i0 + ii, m = mb + i * Map::MS;
+            const int i = i0 + ii, m = mb + i * 16;
             float mean = 0.f, rstd = 1.f;
             if (LNF) {                                      // statistics of row m over its K features (biased variance, eps inside the sqrt)
                 const float inv_k = 1.0f / (float)K;        // (uniform: one scalar division)
@@ -154,7 +141,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[TM][TN], int M,
             float ps = 0.f, pq = 0.f;                       // stats_out partial of this lane's 4 * TN columns of row m
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int n = nb + Map::ncol(j);
+                const int n = nb + j * 16;
                 const bool live = m < M && n < N;
                 f32x4 v = acc[i][j];
                 if (LNF) {
@@ -183,7 +170,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[TM][TN], int M,
                         if (e.out_f32) store4(Cf + od, v); else store4(Ct + od, v);
                         if (e.C2) store4(reinterpret_cast<bf16*>(e.C2) + (size_t)(m + e.dup_rows) * e.ldc2 + n, v);
                     }
-                    if (!MAP32 && TN == 2 && e.stats_out) {
+                    if (TN == 2 && e.stats_out) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float x = (sizeof(T) == 2 && (e.C2 || !e.out_f32)) ? bf2f(f2bf(v[r])) : v[r];
@@ -192,7 +179,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[TM][TN], int M,
                     }
                 }
             }
-            if (!MAP32 && TN == 2 && e.stats_out) {                   // uniform branch; the 4 lane groups g hold the 4 column quarters of the chunk
+            if (TN == 2 && e.stats_out) {                   // uniform branch; the 4 lane groups g hold the 4 column quarters of the chunk
                 ps += __shfl_xor(ps, 16); pq += __shfl_xor(pq, 16);
                 ps += __shfl_xor(ps, 32); pq += __shfl_xor(pq, 32);
                 const int chunk = (n0 + wn * 16 * TN) / STATS_CHUNK;
@@ -330,71 +317,6 @@ static int launch_splitk(const GemmOperands& p, const GemmEpilogue& e, int a_nro
     return PK_OK;
 }
 
-// the LDS-DMA GEMM on v_mfma_f32_32x32x16_bf16 (gemm_dma.hpp run32; bf16 and split-bf16 operands): same tiles, ring, tile order and epilogue
-// features except the LayerNorm folds / row-statistics hand-over (those stay on the 16-row kernels)
-template <typename T, int TM, int TN, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(64 * WM * WN)
-__attribute__((amdgpu_waves_per_eu(lds_waves_per_simd<GemmDma<T, TM, TN, WM, WN, STAGES, 128, 0>>(), 8)))
-void gemm_dma32_kernel(const GemmOperands p, const GemmEpilogue e, int a_nrows) {
-    using Tile = GemmDma<T, TM, TN, WM, WN, STAGES, 128, 0>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int MT = (p.M + Tile::BM - 1) / Tile::BM, cmax = (MT + 7) / 8, NTn = (p.N + Tile::BN - 1) / Tile::BN;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int mstart = xcd * MT / 8, mcount = (xcd + 1) * MT / 8 - mstart;
-    int m0, n0;
-    if (p.plain_map) {
-        if ((int)blockIdx.x >= MT * NTn) return;
-        m0 = (blockIdx.x % MT) * Tile::BM;
-        n0 = (blockIdx.x / MT) * Tile::BN;
-    } else {
-        int ml, ntile;
-        if (!xcd_panel_tile(idx, cmax, mcount, NTn, p.panel, ml, ntile)) return;
-        m0 = (mstart + ml) * Tile::BM;
-        n0 = ntile * Tile::BN;
-    }
-    f32x16 acc[TM / 2][TN / 2];
-#pragma unroll
-    for (int i = 0; i < TM / 2; ++i)
-#pragma unroll
-        for (int j = 0; j < TN / 2; ++j)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-    if (!Tile::run32(p, a_nrows, m0, n0, smem, acc)) return;
-    // the register-quad view the epilogue works on: view[i][4 J + q] = registers 4 q .. 4 q + 3 of block (i, J)
-    f32x4 view[TM / 2][2 * TN];
-#pragma unroll
-    for (int i = 0; i < TM / 2; ++i)
-#pragma unroll
-        for (int j = 0; j < TN / 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) view[i][4 * j + q] = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-    gemm_epilogue<T, TM / 2, 2 * TN, WN, false, true>(view, p.M, p.N, e, m0, n0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-template <typename T, int TM, int TN, int STAGES, int WM = 2, int WN = 2>
-static int launch_dma32(const GemmOperands& p, const GemmEpilogue& e, int a_nrows, hipStream_t s) {
-    using Tile = GemmDma<T, TM, TN, WM, WN, STAGES, 128, 0>;
-    if (Tile::SMEM > 65536) {
-        static bool attr_set[64] = {};
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PK_ELAUNCH;
-        if (!attr_set[dev]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma32_kernel<T, TM, TN, WM, WN, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    Tile::SMEM) != hipSuccess) return PK_ELAUNCH;
-            attr_set[dev] = true;
-        }
-    }
-    const int MT = (p.M + Tile::BM - 1) / Tile::BM, NT = (p.N + Tile::BN - 1) / Tile::BN;
-    dim3 grid(8 * ((MT + 7) / 8) * NT);
-    GemmOperands pp = p;
-    static const int panel_env = [] { const char* e_ = getenv("PK_GEMM_PANEL"); return e_ ? atoi(e_) : -1; }();
-    pp.panel = panel_env >= 0 ? panel_env : xcd_panel_rows(Tile::BM, p.K, (int)sizeof(T));
-    hipLaunchKernelGGL((gemm_dma32_kernel<T, TM, TN, WM, WN, STAGES>), grid, dim3(Tile::THREADS), Tile::SMEM, s, pp, e, a_nrows);
-    PK_CHECK_LAUNCH();
-    return PK_OK;
-}
-
 template <typename T, typename TA, int TM, int TN>
 static int launch_v1(const GemmOperands& p, const GemmEpilogue& e, hipStream_t s) {
     using Tile = GemmTile<T, TA, TM, TN>;
@@ -504,7 +426,7 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
     const bool dma_ok = dma_possible(dtype, a_is_f32, N, K, lda, ldw, a_nrows);
-    if (variant >= 100 && variant < 200) { p.plain_map = 1; variant -= 100; }      // 1xx: variant xx with the row-major tile order (A/B knob)
+    if (variant >= 100) { p.plain_map = 1; variant -= 100; }
     if (variant == 0) variant = auto_variant(dtype, a_is_f32, M, N, K, lda, ldw, a_nrows);
     if (variant >= 3 && !dma_ok) return PK_EINVAL;
     if (ln_s) {
@@ -531,12 +453,6 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
             case 24: return launch_dma<bf16, 4, 2, 2, 2, 4>(p, e, a_nrows, s);          // 128x128, 8 waves (2x4), 2 stages (64 KB: 16 waves/CU)
             case 33: return launch_dma<bf16, 2, 2, 3, 2, 2, 128, 2>(p, e, a_nrows, s);  // 64x64, 4 consumers + 2 producers, 3 stages (long K)
             case 27: return launch_dma<bf16, 4, 2, 2, 2, 2>(p, e, a_nrows, s);          // 128x64, 4 waves (wave tile 64x32), 2 stages (48 KB: 3 WG/CU)
-            // 2xx: the same tile on v_mfma_f32_32x32x16_bf16 (gemm_dma32_kernel): no LayerNorm fold / statistics hand-over
-            case 208: if (ln_s || stats_out) return PK_EINVAL; return launch_dma32<bf16, 2, 2, 2>(p, e, a_nrows, s);
-            case 209: if (ln_s || stats_out) return PK_EINVAL; return launch_dma32<bf16, 4, 4, 2>(p, e, a_nrows, s);
-            case 224: if (ln_s || stats_out) return PK_EINVAL; return launch_dma32<bf16, 4, 2, 2, 2, 4>(p, e, a_nrows, s);
-            case 227: if (ln_s || stats_out) return PK_EINVAL; return launch_dma32<bf16, 4, 2, 2, 2, 2>(p, e, a_nrows, s);
-            case 203: if (ln_s || stats_out) return PK_EINVAL; return launch_dma32<bf16, 2, 2, 4>(p, e, a_nrows, s);      // 64x64, 4 stages (long K)
             // (256x256 / 256x128 / 128x256 8-wave instantiations were measured again in round 3 against the torch.mm yardstick and removed:
             //  profiles/gemm_bigtile_r03.txt -- 552 vs 653 TFLOP/s on the vocabulary-head shape, 1081 vs 1011 at 8192^3)
             default: return PK_EINVAL;
@@ -552,11 +468,6 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
             case 9: return launch_dma<bf16x3, 4, 4, 2>(p, e, a_nrows, s);
             case 24: return launch_dma<bf16x3, 4, 2, 2, 2, 4>(p, e, a_nrows, s);
             case 27: return launch_dma<bf16x3, 4, 2, 2, 2, 2>(p, e, a_nrows, s);
-            case 203: return launch_dma32<bf16x3, 2, 2, 4>(p, e, a_nrows, s);
-            case 208: return launch_dma32<bf16x3, 2, 2, 2>(p, e, a_nrows, s);
-            case 209: return launch_dma32<bf16x3, 4, 4, 2>(p, e, a_nrows, s);
-            case 224: return launch_dma32<bf16x3, 4, 2, 2, 2, 4>(p, e, a_nrows, s);
-            case 227: return launch_dma32<bf16x3, 4, 2, 2, 2, 2>(p, e, a_nrows, s);
             default: return PK_EINVAL;
         }
     }

@@ -232,136 +232,6 @@ struct GemmDma {
         __builtin_amdgcn_s_barrier();                     // the ring is dead: callers may reuse smem
         return computes;
     }
-
-    // fragment reads of the 32-row loop: the images of lds_frag_a / lds_frag_w with the slot ^ ((row >> 1) & 7) swizzle
-    static __device__ __forceinline__ void frag32_a(Frag<bf16>& f, const char* tile, int row, int chunk, int g) {
-        f.v = *reinterpret_cast<const u32x4*>(tile + row * 128 + ((((chunk * 4 + g)) ^ ((row >> 1) & 7)) << 4));
-    }
-    static __device__ __forceinline__ void frag32_w(Frag<bf16>& f, const char* tile, int row, int chunk, int g) { frag32_a(f, tile, row, chunk, g); }
-    static __device__ __forceinline__ void frag32_a(Frag<bf16x3>& f, const char* tile, int row, int /*chunk*/, int g) {
-        const int sw = (row >> 1) & 7;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(tile + row * 128 + (((2 * g) ^ sw) << 4));
-        const f32x4 b = *reinterpret_cast<const f32x4*>(tile + row * 128 + (((2 * g + 1) ^ sw) << 4));
-        split8(a, b, f.hi, f.lo);
-    }
-    static __device__ __forceinline__ void frag32_w(Frag<bf16x3>& f, const char* tile, int row, int /*chunk*/, int g) {
-        const int sw = (row >> 1) & 7;
-        f.hi = *reinterpret_cast<const u32x4*>(tile + row * 128 + ((g ^ sw) << 4));
-        f.lo = *reinterpret_cast<const u32x4*>(tile + row * 128 + (((4 + g) ^ sw) << 4));
-    }
-
-    // the same ring and tile geometry on v_mfma_f32_32x32x16_bf16 (common.hpp mma32): the wave tile (16 TM x 16 TN) is TM / 2 x TN / 2 blocks of
-    // 32 x 32, a k-tile is BK / 16 steps; lane l feeds row l & 31 of a block and the 8 k-elements of half l >> 5 of the step -- the same LDS
-    // image, read as slot group 2 s + (l >> 5).  acc32[I][J]: the weight tile is the MFMA's A operand as in the 16-row loop, so reg v of lane l
-    // is output row m = I * 32 + (l & 31), column n = J * 32 + 8 (v / 4) + 4 (l >> 5) + v % 4: again 4 consecutive columns per register quad.
-    static __device__ __forceinline__ bool run32(const GemmOperands& p, int a_nrows, int m0, int n0, char* smem, f32x16 (&acc)[TM / 2][TN / 2]) {
-        static_assert(TM % 2 == 0 && TN % 2 == 0 && PW == 0, "32 x 32 blocks");
-        constexpr int STATS = 0;
-        float rsum[1], rsq[1];
-        const int tid = threadIdx.x, lane = tid & 63;
-        const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const bool loads = PW == 0 || wave_all >= NW;
-        const bool computes = PW == 0 || wave_all < NW;
-        const int wave = PW == 0 ? wave_all : (loads ? wave_all - NW : 0);      // index among the loading waves
-        const int cw = computes ? wave_all : 0;                                 // index among the compute waves
-        const int wm = cw / WN, wn = cw % WN, g = lane >> 4, lr = lane & 15;
-        constexpr int SZ = (int)sizeof(T);
-
-        const uint32_t bytesA = (uint32_t)a_nrows * (uint32_t)p.lda * SZ;
-        const uint32_t bytesW = (uint32_t)p.N * (uint32_t)p.ldw * SZ;
-        __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, bytesA, 0x00020000);
-        __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, bytesW, 0x00020000);
-
-        // per-lane source offsets (bytes) at k = 0; the k-tile advance goes through the scalar offset.
-        // lane -> (row within the instruction's RPI rows, 16-byte slot); the slot is swizzled on the SOURCE side
-        // swizzle of the 32-row loop: slot ^ ((row >> 1) & 7).  A 32-row fragment read touches rows l & 31 at one logical slot; the LDS serves a
-        // ds_read_b128 in 16-lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... whose same-parity rows are 2 apart or >= 8 apart, so
-        // (row >> 1) & 7 is distinct inside every group (row & 7 of the 16-row loop is not: rows 12 and 20 of a group would share a slot)
-        const int lrow = lane / SLOTS, lslot = lane % SLOTS;
-        const int ktail_bytes0 = (p.K * SZ) % ROWB;
-        uint32_t offA[IA], offW[IW];
-        bool tailA[IA], tailW[IW];                                    // this lane's piece of the LAST k-tile starts inside K
-#pragma unroll
-        for (int i = 0; i < IA; ++i) {
-            const int row = (wave * IA + i) * RPI + lrow;
-            const int srcslot = lslot ^ ((row >> 1) & 7);
-            int gm = m0 + row;
-            const bool ok = gm < p.M;
-            if (ok && p.a_rows) gm = p.a_rows[gm];
-            offA[i] = ok ? (uint32_t)gm * (uint32_t)p.lda * SZ + srcslot * 16 : bytesA;
-            tailA[i] = ktail_bytes0 == 0 || srcslot * 16 < ktail_bytes0;
-        }
-#pragma unroll
-        for (int i = 0; i < IW; ++i) {
-            const int row = (wave * IW + i) * RPI + lrow;
-            const int srcslot = lslot ^ ((row >> 1) & 7);
-            const int gn = n0 + row + ((p.w_gap_from > 0 && row >= p.w_gap_from) ? p.w_gap_rows : 0);
-            offW[i] = gn < p.N ? (uint32_t)gn * (uint32_t)p.ldw * SZ + srcslot * 16 : bytesW;
-            tailW[i] = true;
-        }
-        (void)tailW;
-
-        // k-rotation: every workgroup of a launch reads the SAME 128-byte column slab of A and W at the same time, and
-        // with power-of-two row strides (1 KiB for K = 512 bf16) a slab lives on a fraction of the L2 channels: the
-        // workgroups queue on those while the others idle.  Starting workgroup b at k-tile (b >> 3) % nt (b >> 3 = its
-        // index inside its XCD) spreads the concurrent slabs over all channels; the sum over k only changes order.
-        const int nt = (p.K + BK - 1) / BK;
-        const int rot = (p.krot && nt > 1) ? (int)(((blockIdx.x >> 3) + blockIdx.y) % (unsigned)nt) : 0;
-        auto issue = [&](int kt, int slot) {
-            char* base = smem + slot * STAGE_BYTES;
-            int kk = kt + rot;
-            if (kk >= nt) kk -= nt;
-            const int koff = kk * ROWB;
-            const bool last = kk == nt - 1;                          // pieces of the last k-tile that lie beyond K are pointed out of bounds
-#pragma unroll
-            for (int i = 0; i < IA; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(base + (wave * IA + i) * 1024), 16, (last && !tailA[i]) ? bytesA : offA[i], koff, 0, 0);
-#pragma unroll
-            for (int i = 0; i < IW; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(base + BM * ROWB + (wave * IW + i) * 1024), 16, offW[i], koff, 0, 0);
-        };
-
-        const int pre = nt < STAGES - 1 ? nt : STAGES - 1;
-        if (loads)
-            for (int s = 0; s < pre; ++s) issue(s, s);
-        if (PW > 0 && computes) __builtin_amdgcn_s_setprio(1);      // consumers win issue arbitration against their SIMD's producer
-#ifdef PK_TIMELINE
-        const int tl_wg = pk_tl_wg();
-        const bool tl_on = tl_wg >= 0 && tid == 0;
-#endif
-        for (int kt = 0; kt < nt; ++kt) {
-            const int issued = (kt + STAGES - 1 < nt) ? kt + STAGES - 1 : nt;      // tiles issued so far
-            PK_TL(0);
-            if (loads) wait_outstanding(issued - (kt + 1));
-            PK_TL(1);
-            __builtin_amdgcn_s_barrier();                 // tile kt landed for every wave; everyone is done with tile kt-1
-            PK_TL(2);
-            if (loads && kt + STAGES - 1 < nt) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
-            PK_TL(3);
-            if (!computes) continue;
-            const char* a = smem + (kt % STAGES) * STAGE_BYTES;
-            const char* w = a + BM * ROWB;
-#pragma unroll
-            for (int st = 0; st < BK / 16; ++st) {
-                const int gi = 2 * st + (lane >> 5);                   // 8-element group of the k-tile this lane feeds in step st
-                const int fc = gi >> 2, fg = gi & 3;                   // (chunk, group) of the 16-row readers (split-bf16: one chunk, 4 groups)
-                Frag<T> fa[TM / 2], fw[TN / 2];
-#pragma unroll
-                for (int i = 0; i < TM / 2; ++i) frag32_a(fa[i], a, wm * 16 * TM + i * 32 + (lane & 31), fc, fg);
-#pragma unroll
-                for (int j = 0; j < TN / 2; ++j) frag32_w(fw[j], w, wn * 16 * TN + j * 32 + (lane & 31), fc, fg);
-#pragma unroll
-                for (int i = 0; i < TM / 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN / 2; ++j) acc[i][j] = mma32(fw[j], fa[i], acc[i][j]);
-            }
-            PK_TL(4);
-        }
-        (void)rsum; (void)rsq; (void)STATS; (void)g; (void)lr;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                     // the ring is dead: callers may reuse smem
-        return computes;
-    }
 };
 
 }  // namespace pk

@@ -91,8 +91,7 @@ def test_gemm_geglu_leaky_gather_and_T_output(L, mode):
     close(C3, h[idx.long()], 2e-5, 'gather')
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 8, 9, 24, ('f32only', 3), ('bf16only', 27), ('bf16only', 33), ('bf16only', 203), ('bf16only', 208),
-                                     ('bf16only', 209), ('bf16only', 224), ('bf16only', 227)])
+@pytest.mark.parametrize('variant', [0, 1, 2, 8, 9, 24, ('f32only', 3), ('bf16only', 27), ('bf16only', 33)])
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])
 @pytest.mark.parametrize('M,N,K', [(300, 200, 96), (1000, 520, 1368), (4608, 512, 512), (129, 2736, 512)])
 def test_gemm_main_loop_variants(L, variant, mode, M, N, K):
@@ -967,7 +966,7 @@ def test_attention_split_bf16_fixed_offset_lds_kernel(L, dims, S, heads):
                 close(o_fix, o_run, 2e-4, 'fixed-offset LDS kernel vs running-max kernel (split-bf16)')
 
 
-@pytest.mark.parametrize('variant', [0, 3, 8, 9, 24, 27, 203, 208, 209, 224, 227])
+@pytest.mark.parametrize('variant', [0, 3, 8, 9, 24, 27])
 @pytest.mark.parametrize('M,N,K', [(300, 200, 96), (1000, 520, 1368), (4608, 512, 512), (129, 2736, 512), (512, 512, 6144), (77, 4, 64)])
 def test_gemm_split_bf16(L, variant, M, N, K):
     """the split-bf16 ("bf16x3") main loops: f32 A rows split into (hi, lo) bf16 planes in registers, host-packed W planes, three bf16

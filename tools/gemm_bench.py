@@ -30,10 +30,8 @@ SHAPES = [  # (M, N, K, note)
     (4608, 65536, 512, 'vocab head as plain GEMM'),
     (8192, 8192, 8192, 'square 8k (kernel ceiling)'),
 ]
-VARIANTS = {'bf16': {8: 'd64s2', 9: 'd128s2', 24: 'd128w8s2', 27: 'd128x64w4', 33: 'pc64 4+2 s3', 208: 'm32 d64s2', 209: 'm32 d128s2', 224: 'm32 d128w8s2',
-                     227: 'm32 d128x64w4', 203: 'm32 d64s4'},
-            'bf16x3': {8: 'd64s2', 24: 'd128w8s2', 27: 'd128x64w4', 9: 'd128s2', 3: 'd64s4', 208: 'm32 d64s2', 209: 'm32 d128s2', 224: 'm32 d128w8s2',
-                       227: 'm32 d128x64w4', 203: 'm32 d64s4'},
+VARIANTS = {'bf16': {8: 'd64s2', 9: 'd128s2', 24: 'd128w8s2', 27: 'd128x64w4', 33: 'pc64 4+2 s3'},
+            'bf16x3': {8: 'd64s2', 24: 'd128w8s2', 27: 'd128x64w4', 9: 'd128s2', 3: 'd64s4'},
             'f32': {8: 'd64s2', 24: 'd128w8s2', 9: 'd128s2', 3: 'd64s4'}}
 
 
