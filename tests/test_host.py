@@ -296,3 +296,39 @@ def test_torch_library_ops_are_registered_without_a_cpu_kernel():
         assert hasattr(torch.ops.phenaki_mi355x, name), name
     with pytest.raises((NotImplementedError, RuntimeError)):
         torch.ops.phenaki_mi355x.layernorm(torch.randn(4, 8), torch.ones(8), None, torch.empty(4, 8), 1e-5)
+
+
+def test_data_io_gif_roundtrip_datasets_and_collate(tmp_path):
+    """reference data.py:48-265 on PIL: GIF write / read of a (c, f, h, w) tensor, the image / video folder datasets (resize of the shorter
+    side, centre crop, frame-count cast) and the string-aware collate"""
+    from PIL import Image
+    from phenaki_pytorch_amd import data as D
+    g = torch.Generator().manual_seed(3)
+    # a video with few distinct colours survives GIF's palette exactly
+    frames = (torch.randint(0, 4, (3, 6, 1, 1), generator=g).float() / 3).expand(3, 6, 20, 28).contiguous()
+    path = tmp_path / 'v.gif'
+    D.video_tensor_to_gif(frames, str(path))
+    back = D.gif_to_tensor(str(path))
+    assert tuple(back.shape) == (3, 6, 20, 28) and (back - frames).abs().max() <= 1 / 255 + 1e-6
+    ds = D.VideoDataset(str(tmp_path), image_size=16, num_frames=9)
+    v = ds[0]
+    assert len(ds) == 1 and tuple(v.shape) == (3, 9, 16, 16) and float(v[:, 6:].abs().max()) == 0.0       # padded to 9 frames
+    assert (v[:, :6, 0, 0] - frames[:, :, 0, 0]).abs().max() <= 2 / 255
+    assert tuple(D.cast_num_frames(v, frames=4).shape) == (3, 4, 16, 16)
+    Image.fromarray((torch.rand(30, 50, 3, generator=g) * 255).byte().numpy()).save(tmp_path / 'a.png')
+    Image.fromarray((torch.rand(40, 24, generator=g) * 255).byte().numpy(), mode='L').save(tmp_path / 'b.jpg')
+    ids = D.ImageDataset(str(tmp_path), image_size=16)
+    assert len(ids) == 2 and all(tuple(ids[i].shape) == (3, 16, 16) and 0 <= float(ids[i].min()) and float(ids[i].max()) <= 1 for i in range(2))
+    out = D.collate_tensors_and_strings([(torch.zeros(2), 'a'), (torch.ones(2), 'b')])
+    assert tuple(out[0].shape) == (2, 2) and out[1] == ['a', 'b']
+    assert tuple(D.collate_tensors_and_strings([torch.zeros(2), torch.ones(2)])[0].shape) == (2, 2)
+    dl = D.DataLoader(ids, batch_size=2)
+    assert tuple(next(iter(dl))[0].shape) == (2, 3, 16, 16)
+    if not _has('cv2'):
+        with pytest.raises(ImportError, match='OpenCV'):
+            D.video_to_tensor(str(tmp_path / 'x.mp4'))
+
+
+def _has(mod):
+    import importlib.util
+    return importlib.util.find_spec(mod) is not None
