@@ -1,18 +1,18 @@
-"""Image / video I/O and datasets of the reference (`/root/reference/phenaki_pytorch/data.py:48-265`), host side, on PIL + numpy + torch
-(this build depends on neither torchvision nor OpenCV): folders of images / GIFs as datasets of `(c, h, w)` / `(c, f, h, w)` f32 tensors in
-[0, 1], GIF read / write for sampled videos, the string-aware collate of the trainers' DataLoader.  MP4 read / write goes through OpenCV
-exactly as in the reference when `cv2` is importable and says so when it is not.  SURVEY.md 8f row 4 (data formats either side of the path).
+"""Host-side image / video I/O and datasets with the reference's names and call signatures (`/root/reference/phenaki_pytorch/data.py:48-265`:
+ImageDataset, VideoDataset, video_tensor_to_gif, gif_to_tensor, video_to_tensor, tensor_to_video, DataLoader), built on PIL + numpy + torch
+only -- this build depends on neither torchvision nor OpenCV.  Tensors are f32 in [0, 1], images (c, h, w), videos (c, f, h, w).  MP4 files go
+through OpenCV when `cv2` is importable (as in the reference) and fail with a clear message when it is not.  SURVEY.md 8f row 4.
 """
 import random
-from functools import partial
 from pathlib import Path
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 from PIL import Image
-from torch.utils.data import DataLoader as PytorchDataLoader
-from torch.utils.data import Dataset
+from torch.utils import data as torch_data
+
+_PIL_MODE = {1: 'L', 3: 'RGB', 4: 'RGBA'}
+CHANNELS_TO_MODE = _PIL_MODE                      # (the reference's public name)
 
 
 def exists(val):
@@ -27,211 +27,211 @@ def pair(val):
     return val if isinstance(val, tuple) else (val, val)
 
 
-def cast_num_frames(t, *, frames):
-    """(c, f, h, w): cut or zero-pad the frame axis to `frames` (data.py:30-39)"""
-    f = t.shape[1]
-    if f == frames:
-        return t
-    if f > frames:
-        return t[:, :frames]
-    return F.pad(t, (0, 0, 0, 0, 0, frames - f))
+# ------------------------------------------------------------------------------------------ frame geometry (what torchvision did for the reference)
 
-
-# ---- the torchvision transforms the reference composes (Resize -> [RandomHorizontalFlip] -> CenterCrop -> ToTensor), on PIL
-
-def _resize(img, size):
-    """T.Resize: an int scales the SHORTER side to it (aspect kept, bilinear + antialias); a pair is (h, w)"""
+def _fit_short_side(img, size):
+    """torchvision's Resize: an int scales the SHORTER side to `size` keeping the aspect ratio; a pair is an explicit (height, width)"""
     if isinstance(size, (tuple, list)):
-        return img.resize((size[1], size[0]), Image.BILINEAR)
-    w, h = img.size
-    if (w <= h and w == size) or (h <= w and h == size):
+        return img.resize((int(size[1]), int(size[0])), Image.BILINEAR)
+    width, height = img.size
+    short, long_ = (width, height) if width <= height else (height, width)
+    if short == size:
         return img
-    if w < h:
-        return img.resize((size, int(size * h / w)), Image.BILINEAR)
-    return img.resize((int(size * w / h), size), Image.BILINEAR)
+    scaled_long = int(size * long_ / short)
+    target = (size, scaled_long) if width <= height else (scaled_long, size)
+    return img.resize(target, Image.BILINEAR)
 
 
-def _center_crop(img, size):
-    ch, cw = pair(size)
-    w, h = img.size
-    if w < cw or h < ch:                                     # torchvision pads with zeros first
-        canvas = Image.new(img.mode, (max(w, cw), max(h, ch)))
-        canvas.paste(img, ((max(w, cw) - w) // 2, (max(h, ch) - h) // 2))
-        img, (w, h) = canvas, canvas.size
-    left, top = int(round((w - cw) / 2.)), int(round((h - ch) / 2.))
-    return img.crop((left, top, left + cw, top + ch))
+def _crop_middle(img, size):
+    """torchvision's CenterCrop (zero padding first when the image is smaller than the crop)"""
+    crop_h, crop_w = pair(size)
+    width, height = img.size
+    if width < crop_w or height < crop_h:
+        padded = Image.new(img.mode, (max(width, crop_w), max(height, crop_h)))
+        padded.paste(img, ((padded.size[0] - width) // 2, (padded.size[1] - height) // 2))
+        img = padded
+        width, height = img.size
+    x0 = int(round((width - crop_w) / 2.0))
+    y0 = int(round((height - crop_h) / 2.0))
+    return img.crop((x0, y0, x0 + crop_w, y0 + crop_h))
 
 
 def to_tensor(img):
-    """T.ToTensor: PIL image -> (c, h, w) f32 in [0, 1]"""
-    a = np.asarray(img, dtype=np.uint8)
-    if a.ndim == 2:
-        a = a[:, :, None]
-    return torch.from_numpy(a.copy()).permute(2, 0, 1).float().div_(255.)
+    """PIL image -> (c, h, w) f32 in [0, 1]"""
+    pixels = np.array(img, dtype=np.uint8)
+    if pixels.ndim == 2:
+        pixels = pixels[..., None]
+    return torch.from_numpy(pixels).movedim(-1, 0).to(torch.float32) / 255.0
 
 
-def to_pil_image(t):
-    """T.ToPILImage for a (c, h, w) float tensor in [0, 1] (or a uint8 one)"""
-    if t.is_floating_point():
-        t = t.detach().cpu().mul(255).byte()
-    a = t.cpu().permute(1, 2, 0).numpy()
-    return Image.fromarray(a[:, :, 0], mode='L') if a.shape[2] == 1 else Image.fromarray(a, mode=CHANNELS_TO_MODE[a.shape[2]])
+def to_pil_image(frame):
+    """(c, h, w) tensor -> PIL image; floats are taken as [0, 1]"""
+    if frame.is_floating_point():
+        frame = (frame.detach().cpu() * 255).to(torch.uint8)
+    hwc = frame.cpu().movedim(0, -1).numpy()
+    channels = hwc.shape[-1]
+    assert channels in _PIL_MODE, f'channels {channels} invalid'
+    return Image.fromarray(hwc[..., 0] if channels == 1 else hwc, mode=_PIL_MODE[channels])
 
 
-class _Transform:
-    def __init__(self, image_size, flip, to_rgb):
-        self.image_size, self.flip, self.to_rgb = image_size, flip, to_rgb
+class FrameTransform:
+    """resize -> optional random mirror -> centre crop -> tensor, per frame"""
+
+    def __init__(self, image_size, mirror=False, force_rgb=False):
+        self.image_size, self.mirror, self.force_rgb = image_size, mirror, force_rgb
 
     def __call__(self, img):
-        if self.to_rgb and img.mode != 'RGB':
+        if self.force_rgb and img.mode != 'RGB':
             img = img.convert('RGB')
-        img = _resize(img, self.image_size)
-        if self.flip and random.random() < 0.5:
+        img = _fit_short_side(img, self.image_size)
+        if self.mirror and random.random() < 0.5:
             img = img.transpose(Image.FLIP_LEFT_RIGHT)
-        return to_tensor(_center_crop(img, self.image_size))
+        return to_tensor(_crop_middle(img, self.image_size))
 
 
-class ImageDataset(Dataset):
-    """data.py:48-78: every jpg / jpeg / png under `folder` as a (3, image_size, image_size) tensor (random horizontal flip)"""
-
-    def __init__(self, folder, image_size, exts=['jpg', 'jpeg', 'png']):
-        super().__init__()
-        self.folder = folder
-        self.image_size = image_size
-        self.paths = [p for ext in exts for p in Path(f'{folder}').glob(f'**/*.{ext}')]
-        print(f'{len(self.paths)} training samples found at {folder}')
-        self.transform = _Transform(image_size, flip=True, to_rgb=True)
-
-    def __len__(self):
-        return len(self.paths)
-
-    def __getitem__(self, index):
-        return self.transform(Image.open(self.paths[index]))
+def cast_num_frames(t, *, frames):
+    """(c, f, h, w) with exactly `frames` frames: surplus frames dropped, missing ones zero-filled"""
+    have = t.shape[1]
+    if have >= frames:
+        return t[:, :frames]
+    filler = t.new_zeros((t.shape[0], frames - have, *t.shape[2:]))
+    return torch.cat((t, filler), dim=1)
 
 
-# ---- GIF <-> (channels, frames, height, width) tensor (data.py:84-128)
-
-CHANNELS_TO_MODE = {1: 'L', 3: 'RGB', 4: 'RGBA'}
-
+# ------------------------------------------------------------------------------------------ GIF
 
 def seek_all_images(img, channels=3):
-    assert channels in CHANNELS_TO_MODE, f'channels {channels} invalid'
-    mode = CHANNELS_TO_MODE[channels]
-    i = 0
-    while True:
-        try:
-            img.seek(i)
-            yield img.convert(mode)
-        except EOFError:
-            break
-        i += 1
+    """every frame of an (animated) PIL image, converted to the mode of `channels`"""
+    assert channels in _PIL_MODE, f'channels {channels} invalid'
+    for index in range(getattr(img, 'n_frames', 1)):
+        img.seek(index)
+        yield img.convert(_PIL_MODE[channels])
 
 
 def video_tensor_to_gif(tensor, path, duration=120, loop=0, optimize=True):
-    images = list(map(to_pil_image, tensor.unbind(dim=1)))
-    first_img, *rest_imgs = images
-    first_img.save(path, save_all=True, append_images=rest_imgs, duration=duration, loop=loop, optimize=optimize)
-    return images
+    """(c, f, h, w) in [0, 1] -> animated GIF at `path`; returns the PIL frames"""
+    pil_frames = [to_pil_image(tensor[:, f]) for f in range(tensor.shape[1])]
+    pil_frames[0].save(path, save_all=True, append_images=pil_frames[1:], duration=duration, loop=loop, optimize=optimize)
+    return pil_frames
 
 
 def gif_to_tensor(path, channels=3, transform=to_tensor):
-    img = Image.open(path)
-    tensors = tuple(map(transform, seek_all_images(img, channels=channels)))
-    return torch.stack(tensors, dim=1)
+    """animated GIF -> (c, f, h, w)"""
+    with Image.open(path) as img:
+        return torch.stack([transform(frame) for frame in seek_all_images(img, channels=channels)], dim=1)
 
 
-# ---- MP4 through OpenCV, as the reference does (data.py:132-195)
+# ------------------------------------------------------------------------------------------ MP4 (OpenCV, when present)
 
-def _cv2():
+def _opencv():
     try:
         import cv2
-        return cv2
-    except ImportError as e:
-        raise ImportError('MP4 read / write goes through OpenCV (cv2), which is not installed here; GIFs need only PIL') from e
+    except ImportError as err:
+        raise ImportError('MP4 read / write goes through OpenCV (cv2), which is not installed here; GIFs need only PIL') from err
+    return cv2
 
 
 def crop_center(img, cropx, cropy):
-    y, x, c = img.shape
-    startx = x // 2 - cropx // 2
-    starty = y // 2 - cropy // 2
-    return img[starty:(starty + cropy), startx:(startx + cropx), :]
+    """centre window of an (h, w, c) array"""
+    height, width = img.shape[:2]
+    top, left = height // 2 - cropy // 2, width // 2 - cropx // 2
+    return img[top: top + cropy, left: left + cropx]
 
 
 def video_to_tensor(path, num_frames=-1, crop_size=None):
-    """-> (channels, frames, height, width) f32 (0..255, as in the reference: data.py:158-160)"""
-    cv2 = _cv2()
-    video = cv2.VideoCapture(path)
-    frames = []
-    check = True
-    while check:
-        check, frame = video.read()
-        if not check:
-            continue
-        if exists(crop_size):
-            frame = crop_center(frame, *pair(crop_size))
-        frames.append(frame[None])
-    frames = np.array(np.concatenate(frames[:-1], axis=0))            # (the reference drops the last frame: data.py:155)
-    frames_torch = torch.tensor(frames).permute(3, 0, 1, 2).float()
-    return frames_torch[:, :num_frames, :, :]
+    """MP4 -> (channels, frames, height, width) f32 with OpenCV's 0..255 BGR values, the final decoded frame left out and the frame axis
+    cut with `[:num_frames]`, all as the reference does (data.py:132-160)"""
+    cv2 = _opencv()
+    capture = cv2.VideoCapture(path)
+    decoded = []
+    while True:
+        ok, frame = capture.read()
+        if not ok:
+            break
+        decoded.append(crop_center(frame, *pair(crop_size)) if exists(crop_size) else frame)
+    capture.release()
+    clip = np.stack(decoded[:-1], axis=0)                               # (f, h, w, c)
+    return torch.from_numpy(clip).movedim(-1, 0).float()[:, :num_frames]
 
 
 def tensor_to_video(tensor, path, fps=25, video_format='MP4V'):
-    cv2 = _cv2()
-    tensor = tensor.cpu()
-    num_frames, height, width = tensor.shape[-3:]
-    fourcc = cv2.VideoWriter_fourcc(*video_format)
-    video = cv2.VideoWriter(path, fourcc, fps, (width, height))
-    for idx in range(num_frames):
-        video.write(np.uint8(tensor[:, idx, :, :].permute(1, 2, 0).numpy()))
-    video.release()
-    return video
+    """(c, f, h, w) with 0..255 values -> MP4 at `path`"""
+    cv2 = _opencv()
+    clip = tensor.detach().cpu()
+    frames, height, width = clip.shape[-3:]
+    writer = cv2.VideoWriter(path, cv2.VideoWriter_fourcc(*video_format), fps, (width, height))
+    for f in range(frames):
+        writer.write(clip[:, f].movedim(0, -1).numpy().astype(np.uint8))
+    writer.release()
+    return writer
 
 
-class VideoDataset(Dataset):
-    """data.py:199-243: every gif / mp4 under `folder` as a (channels, num_frames, image_size, image_size) tensor"""
+# ------------------------------------------------------------------------------------------ folder datasets
 
-    def __init__(self, folder, image_size, channels=3, num_frames=17, horizontal_flip=False, force_num_frames=True, exts=['gif', 'mp4']):
+class _FolderDataset(torch_data.Dataset):
+    """every file below `folder` with one of the extensions `exts`"""
+
+    def __init__(self, folder, exts):
         super().__init__()
         self.folder = folder
-        self.image_size = image_size
-        self.channels = channels
-        self.paths = [p for ext in exts for p in Path(f'{folder}').glob(f'**/*.{ext}')]
-        self.transform = _Transform(image_size, flip=horizontal_flip, to_rgb=False)
-        self.gif_to_tensor = partial(gif_to_tensor, channels=self.channels, transform=self.transform)
-        self.mp4_to_tensor = partial(video_to_tensor, crop_size=self.image_size)
-        self.cast_num_frames_fn = partial(cast_num_frames, frames=num_frames) if force_num_frames else identity
+        root = Path(f'{folder}')
+        self.paths = [p for ext in exts for p in root.glob(f'**/*.{ext}')]
 
     def __len__(self):
         return len(self.paths)
 
+
+class ImageDataset(_FolderDataset):
+    """images as (3, image_size, image_size) tensors: RGB, shorter side resized, random mirror, centre crop"""
+
+    def __init__(self, folder, image_size, exts=['jpg', 'jpeg', 'png']):
+        super().__init__(folder, exts)
+        self.image_size = image_size
+        print(f'{len(self.paths)} training samples found at {folder}')
+        self.transform = FrameTransform(image_size, mirror=True, force_rgb=True)
+
+    def __getitem__(self, index):
+        with Image.open(self.paths[index]) as img:
+            return self.transform(img)
+
+
+class VideoDataset(_FolderDataset):
+    """GIFs / MP4s as (channels, num_frames, image_size, image_size) tensors"""
+
+    def __init__(self, folder, image_size, channels=3, num_frames=17, horizontal_flip=False, force_num_frames=True, exts=['gif', 'mp4']):
+        super().__init__(folder, exts)
+        self.image_size, self.channels = image_size, channels
+        self.num_frames = num_frames if force_num_frames else None
+        self.transform = FrameTransform(image_size, mirror=horizontal_flip)
+
     def __getitem__(self, index):
         path = self.paths[index]
-        ext = path.suffix
-        if ext == '.gif':
-            tensor = self.gif_to_tensor(path)
-        elif ext == '.mp4':
-            tensor = self.mp4_to_tensor(str(path))
+        kind = path.suffix.lower()
+        if kind == '.gif':
+            clip = gif_to_tensor(path, channels=self.channels, transform=self.transform)
+        elif kind == '.mp4':
+            clip = video_to_tensor(str(path), crop_size=self.image_size)
         else:
-            raise ValueError(f'unknown extension {ext}')
-        return self.cast_num_frames_fn(tensor)
+            raise ValueError(f'unknown extension {path.suffix}')
+        return clip if self.num_frames is None else cast_num_frames(clip, frames=self.num_frames)
 
 
-# ---- DataLoader that can collate strings beside tensors (data.py:247-268)
+# ------------------------------------------------------------------------------------------ batches of tensors and strings
 
-def collate_tensors_and_strings(data):
-    if all(isinstance(d, torch.Tensor) for d in data):
-        return (torch.stack(data, dim=0),)
-    output = []
-    for datum in zip(*data):
-        if all(isinstance(d, torch.Tensor) for d in datum):
-            datum = torch.stack(datum, dim=0)
-        elif all(isinstance(d, str) for d in datum):
-            datum = list(datum)
+def collate_tensors_and_strings(samples):
+    """a list of tensors -> (stacked,); a list of tuples -> per position a stacked tensor or a list of strings"""
+    if all(torch.is_tensor(s) for s in samples):
+        return (torch.stack(samples, dim=0),)
+    columns = []
+    for column in zip(*samples):
+        if all(torch.is_tensor(c) for c in column):
+            columns.append(torch.stack(column, dim=0))
+        elif all(isinstance(c, str) for c in column):
+            columns.append(list(column))
         else:
             raise ValueError('detected invalid type being passed from dataset')
-        output.append(datum)
-    return tuple(output)
+    return tuple(columns)
 
 
 def DataLoader(*args, **kwargs):
-    return PytorchDataLoader(*args, collate_fn=collate_tensors_and_strings, **kwargs)
+    return torch_data.DataLoader(*args, collate_fn=collate_tensors_and_strings, **kwargs)
