@@ -154,3 +154,67 @@ def test_rccl_executes_the_collectives_on_this_box(tmp_path):
     mp.spawn(_rccl_one_rank, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
     r = torch.load(os.path.join(str(tmp_path), 'rccl.pt'), weights_only=False)
     assert r['ok'] and r['version']
+
+
+def _ddp_rank(rank, ws, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    dev = rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    two = torch.cuda.device_count() >= 2
+    if two:
+        dist.init_process_group('nccl', rank=rank, world_size=ws, device_id=torch.device('cuda', dev))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=ws)
+    from oracle import weights
+    from oracle.configs import TINY
+    from tests.util import load_product
+    import phenaki_pytorch_amd as P
+    _, mg, cr, ph = load_product('tiny', TINY, device=f'cuda:{dev}')
+    params = [p for p in list(mg.parameters()) + list(cr.parameters())]
+    g = torch.Generator().manual_seed(40)
+    ids = torch.randint(0, TINY['maskgit']['num_tokens'], (4, 3, 4, 4), generator=g)
+    ctx = weights.synthetic_context(4, 6, TINY['maskgit']['dim_context'], seed=3, pad_last=1)
+    n = 48
+
+    def draws_of(r):
+        return dict(rand_step=torch.tensor([1 + r, 4]), perm_noise=weights.uniform_noise((2, n), 750 + r),
+                    gumbel_u=weights.uniform_noise((2, n, TINY['maskgit']['num_tokens']), 760 + r))
+
+    lo = 2 * rank
+    with torch.enable_grad():
+        loss = ph(video_codebook_ids=ids[lo:lo + 2].to(f'cuda:{dev}'), text_embeds=ctx[lo:lo + 2].to(f'cuda:{dev}'), _draws=draws_of(rank))
+        loss.backward()
+    n_coll = P.all_reduce_gradients(params, bucket_mb=0.25)
+    assert n_coll >= 2
+    torch.save(dict(loss=float(loss.detach()), grads={i: p.grad.cpu() for i, p in enumerate(params) if p.grad is not None and p.numel()}),
+               os.path.join(out_dir, f'ddp{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        # the same two half-batches in ONE process, gradients accumulated with the 1 / world_size weight DDP's averaging implies
+        for p in params:
+            p.grad = None
+        with torch.enable_grad():
+            for r in range(ws):
+                l = ph(video_codebook_ids=ids[2 * r:2 * r + 2].to(f'cuda:{dev}'), text_embeds=ctx[2 * r:2 * r + 2].to(f'cuda:{dev}'), _draws=draws_of(r))
+                (l / ws).backward()
+        torch.save({i: p.grad.cpu() for i, p in enumerate(params) if p.grad is not None and p.numel()}, os.path.join(out_dir, 'single.pt'))
+
+
+def test_data_parallel_training_step_equals_single_process_accumulation(tmp_path):
+    """SURVEY.md 8f row 3 on the real path: two ranks each run Phenaki.forward + backward on their half of the batch and average the
+    gradients with the bucketed all-reduce (RCCL across two devices when there are two, gloo with both ranks on the one GPU otherwise);
+    every rank must end with the gradients one process gets by accumulating the two half-batch losses with weight 1/2"""
+    ws, port = 2, _free_port()
+    mp.spawn(_ddp_rank, args=(ws, port, str(tmp_path)), nprocs=ws, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), f'ddp{r}.pt'), weights_only=False) for r in range(2))
+    single = torch.load(os.path.join(str(tmp_path), 'single.pt'), weights_only=False)
+    assert r0['loss'] != r1['loss'], 'the ranks must have seen different half-batches'
+    assert r0['grads'].keys() == r1['grads'].keys() == single.keys()
+    for i, ref in single.items():
+        assert torch.equal(r0['grads'][i], r1['grads'][i]), 'ranks disagree after the all-reduce'
+        scale = float(ref.abs().max())
+        if scale > 1e-6:                                    # (the structurally zero position-bias bias is noise on both sides)
+            assert float((r0['grads'][i] - ref).abs().max()) <= 1e-4 * scale + 1e-7, f'parameter {i}'
