@@ -648,14 +648,15 @@ def bench_train_step(args, ws, mode):
     opt = P.get_optimizer(params, lr=1e-4, wd=1e-2)
     torch.manual_seed(0)
     losses = []
+    reducer = P.GradientReducer(params) if ws > 1 else None         # 64 MB buckets, each all-reduced (RCCL) as soon as backward has filled it
 
     def step(i):
         with torch.enable_grad():
             opt.zero_grad(set_to_none=True)
             loss = ph(video_codebook_ids=ids, text_embeds=ctx)
             loss.backward()
-        if ws > 1:
-            P.all_reduce_gradients(params)
+        if reducer is not None:
+            reducer.finish()
         opt.step()
         losses.append(loss.detach())
 

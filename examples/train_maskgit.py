@@ -45,6 +45,7 @@ def main():
     text_embeds = torch.randn(args.batch, 12, ctx_dim, device='cuda')            # ... and phenaki.encode_texts(texts) (t5.py / T5Encoder)
     with torch.no_grad():
         ids = phenaki.cvivit(videos, return_only_codebook_ids=True)              # the tokenizer is frozen: encode once per batch
+    reducer = P.GradientReducer(params) if ws > 1 else None
     t0 = None
     for step in range(args.steps):
         if step == 3:
@@ -53,8 +54,8 @@ def main():
         opt.zero_grad(set_to_none=True)
         loss = phenaki(video_codebook_ids=ids, text_embeds=text_embeds)
         loss.backward()
-        if ws > 1:
-            P.all_reduce_gradients(params)
+        if reducer is not None:
+            reducer.finish()                                                     # the buckets were all-reduced while backward ran (dist.py)
         opt.step()
         if step % 5 == 0 or step == args.steps - 1:
             print(f'step {step:4d}  loss {float(loss.detach()):.4f}', flush=True)

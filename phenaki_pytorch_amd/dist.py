@@ -136,3 +136,89 @@ def all_reduce_gradients(params, bucket_mb=64.0, average=True, group=None, force
             grads[i].copy_(flat[off:off + n].view_as(grads[i]))
             off += n
     return len(plan)
+
+
+class GradientReducer:
+    """`all_reduce_gradients` OVERLAPPED with the backward pass: a bucket's all-reduce is started (async, on RCCL's own stream) the moment
+    the last of its parameters has received its gradient, while the remaining backward kernels keep the compute stream busy; `finish()` --
+    called between `loss.backward()` and `opt.step()` -- waits for the collectives in flight, reduces whatever is left (parameters that got
+    no gradient this step never complete their bucket) and writes the averaged gradients back.  Buckets are fixed at construction in REVERSE
+    parameter order (the order backward produces gradients in), so every rank issues the same collectives in the same order.
+
+        reducer = GradientReducer(params)            # once
+        loss.backward(); reducer.finish(); opt.step()
+        with reducer.no_sync(): loss.backward()      # gradient accumulation: no collectives for this backward
+    """
+
+    def __init__(self, params, bucket_mb=64.0, average=True, group=None):
+        self.params = [p for p in params if p.requires_grad and p.numel()]
+        self.average, self.group = average, group
+        order = list(range(len(self.params)))[::-1]
+        bucket_elems = max(1, int(bucket_mb * (1 << 20) / 4))
+        self.buckets = [[order[j] for j in idxs] for idxs in bucket_plan([self.params[i].numel() for i in order], bucket_elems)]
+        self._bucket_of = {i: b for b, idxs in enumerate(self.buckets) for i in idxs}
+        self._ready = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._pending = []
+        self._enabled = True
+        self.collectives = 0
+        self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
+
+    def _make_hook(self, i):
+        def hook(_param):
+            if not self._enabled or world()[1] == 1:
+                return
+            b = self._bucket_of[i]
+            self._ready[b] += 1
+            if self._ready[b] == len(self.buckets[b]) and not self._launched[b]:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        idxs = [i for i in self.buckets[b] if self.params[i].grad is not None]
+        self._launched[b] = True
+        if not idxs:
+            return
+        flat = torch.cat([self.params[i].grad.reshape(-1).float() for i in idxs])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append((idxs, flat, work))
+        self.collectives += 1
+
+    def finish(self):
+        """wait for the collectives in flight, reduce the incomplete buckets, write the (averaged) gradients back; returns #collectives"""
+        rank, ws = world()
+        if ws > 1 and self._enabled:
+            for b in range(len(self.buckets)):                  # in bucket order on every rank
+                if not self._launched[b]:
+                    self._launch(b)
+            for idxs, flat, work in self._pending:
+                work.wait()
+                if self.average:
+                    flat /= ws
+                off = 0
+                for i in idxs:
+                    g = self.params[i].grad
+                    g.copy_(flat[off:off + g.numel()].view_as(g))
+                    off += g.numel()
+        n = self.collectives
+        self._pending.clear()
+        self._ready = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self.collectives = 0
+        return n
+
+    def no_sync(self):
+        reducer = self
+
+        class _NoSync:
+            def __enter__(self_inner):
+                reducer._enabled = False
+
+            def __exit__(self_inner, *exc):
+                reducer._enabled = True
+        return _NoSync()
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

@@ -156,7 +156,7 @@ def test_rccl_executes_the_collectives_on_this_box(tmp_path):
     assert r['ok'] and r['version']
 
 
-def _ddp_rank(rank, ws, port, out_dir):
+def _ddp_rank(rank, ws, port, out_dir, overlapped):
     import sys
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
@@ -183,10 +183,17 @@ def _ddp_rank(rank, ws, port, out_dir):
                     gumbel_u=weights.uniform_noise((2, n, TINY['maskgit']['num_tokens']), 760 + r))
 
     lo = 2 * rank
+    reducer = P.GradientReducer(params, bucket_mb=0.25) if overlapped else None     # hooks: buckets go out while backward is still running
     with torch.enable_grad():
         loss = ph(video_codebook_ids=ids[lo:lo + 2].to(f'cuda:{dev}'), text_embeds=ctx[lo:lo + 2].to(f'cuda:{dev}'), _draws=draws_of(rank))
         loss.backward()
-    n_coll = P.all_reduce_gradients(params, bucket_mb=0.25)
+    if overlapped:
+        started_in_backward = reducer.collectives
+        n_coll = reducer.finish()
+        assert started_in_backward >= 1 and n_coll == len(reducer.buckets)
+        reducer.remove()
+    else:
+        n_coll = P.all_reduce_gradients(params, bucket_mb=0.25)
     assert n_coll >= 2
     torch.save(dict(loss=float(loss.detach()), grads={i: p.grad.cpu() for i, p in enumerate(params) if p.grad is not None and p.numel()}),
                os.path.join(out_dir, f'ddp{rank}.pt'))
@@ -203,12 +210,14 @@ def _ddp_rank(rank, ws, port, out_dir):
         torch.save({i: p.grad.cpu() for i, p in enumerate(params) if p.grad is not None and p.numel()}, os.path.join(out_dir, 'single.pt'))
 
 
-def test_data_parallel_training_step_equals_single_process_accumulation(tmp_path):
+@pytest.mark.parametrize('overlapped', [False, True])
+def test_data_parallel_training_step_equals_single_process_accumulation(tmp_path, overlapped):
     """SURVEY.md 8f row 3 on the real path: two ranks each run Phenaki.forward + backward on their half of the batch and average the
     gradients with the bucketed all-reduce (RCCL across two devices when there are two, gloo with both ranks on the one GPU otherwise);
-    every rank must end with the gradients one process gets by accumulating the two half-batch losses with weight 1/2"""
+    every rank must end with the gradients one process gets by accumulating the two half-batch losses with weight 1/2.  overlapped:
+    the same through GradientReducer, whose hooks start each bucket's all-reduce during backward"""
     ws, port = 2, _free_port()
-    mp.spawn(_ddp_rank, args=(ws, port, str(tmp_path)), nprocs=ws, join=True)
+    mp.spawn(_ddp_rank, args=(ws, port, str(tmp_path), overlapped), nprocs=ws, join=True)
     r0, r1 = (torch.load(os.path.join(str(tmp_path), f'ddp{r}.pt'), weights_only=False) for r in range(2))
     single = torch.load(os.path.join(str(tmp_path), 'single.pt'), weights_only=False)
     assert r0['loss'] != r1['loss'], 'the ranks must have seen different half-batches'

@@ -203,6 +203,30 @@ def _grad_worker(rank, ws, port, q):
         p_.grad = b * (rank + 1)
     all_reduce_gradients(params, bucket_mb=64., average=False)      # one bucket, plain sum
     ok = ok and all(torch.allclose(p_.grad, b * sum(r + 1 for r in range(ws)), rtol=1e-6, atol=1e-7) for p_, b in zip(params, base))
+    # the overlapped form: hooks start a bucket's all-reduce while backward is still producing the other gradients
+    from phenaki_pytorch_amd.dist import GradientReducer
+    torch.manual_seed(11)
+    net = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.Tanh(), torch.nn.Linear(300, 300), torch.nn.Tanh(), torch.nn.Linear(300, 7))
+    unused = torch.nn.Parameter(torch.zeros(9))                    # never receives a gradient: its bucket is flushed by finish()
+    plist = list(net.parameters()) + [unused]
+    red = GradientReducer(plist, bucket_mb=0.05)
+    x = torch.randn(16, 40, generator=torch.Generator().manual_seed(100 + rank))
+    with torch.enable_grad():
+        net(x).square().mean().backward()
+    started_early = red.collectives                                # buckets completed during backward were launched from the hooks
+    nred = red.finish()
+    mine = [p_.grad.clone() for p_ in net.parameters()]
+    # reference: every rank recomputes both ranks' gradients locally and averages them
+    want = [torch.zeros_like(p_) for p_ in net.parameters()]
+    for r in range(ws):
+        net.zero_grad()
+        xr = torch.randn(16, 40, generator=torch.Generator().manual_seed(100 + r))
+        with red.no_sync(), torch.enable_grad():
+            net(xr).square().mean().backward()
+        for w_, p_ in zip(want, net.parameters()):
+            w_ += p_.grad / ws
+    ok = ok and all(torch.allclose(a, b, rtol=1e-5, atol=1e-7) for a, b in zip(mine, want)) and unused.grad is None
+    ok = ok and started_early >= 1 and nred == len(red.buckets) and red.collectives == 0
     q.put((rank, bool(ok), ncoll))
     dist.destroy_process_group()
 
