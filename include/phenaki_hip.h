@@ -82,7 +82,8 @@ int pk_layernorm(const float* x, int ldx, const float* gamma, const float* beta,
                  int goff, int pb, int pc, void* stream);
 
 /* cvivit.py:273-285: Rearrange 'b c (t pt) (h p1) (w p2) -> b t h w (c pt p1 p2)' of frames [f0, f0 + nt*pt) of the
- * (B,C,F,H,W) f32 video, fused with nn.LayerNorm(P), P = C*pt*ph*pw; out[(b,t,h,w)][P] is T (out_kind 1) or f32. */
+ * (B,C,F,H,W) f32 video, fused with nn.LayerNorm(P), P = C*pt*ph*pw; out[(b,t,h,w)][P] is T (out_kind 1) or f32.
+ * weight = bias = NULL: the rearranged rows themselves (no LayerNorm). */
 int pk_patchify_ln(const float* video, int B, int C, int F, int H, int W, int f0, int nt, int pt, int ph, int pw,
                    const float* weight, const float* bias, float eps, void* out, int ldo, int out_kind, void* stream);
 
@@ -296,6 +297,12 @@ int pk_layernorm_bwd(const float* x, long long ldx, const float* gamma, const fl
 int pk_geglu(const float* h, long long ldh, int goff, float* out, long long ldo, int M, int F, void* stream);
 int pk_geglu_bwd(const float* h, long long ldh, int goff, const float* dout, long long ldd, float* dh, long long lddh, int M, int F, void* stream);
 /* dz = dy * (y > 0 ? 1 : slope): LeakyReLU backward from the activation's output (position-bias MLP, attention.py:243-247) */
+/* the tokenizer's reconstruction step (cvivit.py:585-591 under autograd; the LFQ's straight-through estimator):
+ * pk_scaled_diff: out = (a - b) * scale (* *scale_dev when given) over n floats (n % 4 == 0) -- d/da of (scale / 2) sum (a - b)^2;
+ * pk_sign: out = z > 0 ? +value : -value (the code of an LFQ projection, cvivit.py:570 -> vector_quantize_pytorch LFQ.forward). */
+int pk_scaled_diff(const float* a, const float* b, float scale, const float* scale_dev, float* out, long long n, void* stream);
+int pk_sign(const float* z, float value, float* out, long long n, void* stream);
+int pk_mul(const float* a, const float* b, float* out, long long n, void* stream);     /* out = a * b (may alias a), n % 4 == 0 */
 int pk_leaky_bwd(const float* y, long long ldy, const float* dy, long long lddy, float* dz, long long lddz, int M, int N, float slope, void* stream);
 /* PEG backward (attention.py:57-85 + residual :323): dx = dy + transposed stencil of dy; part (NULL: skip): (pk_peg_wgrad_parts(rows), 27, D)
  * partial tap gradients sum dy[pos] x[pos + tap], finished by pk_colsum over 27 D columns (the conv bias gradient is pk_colsum of dy) */
@@ -323,7 +330,8 @@ int pk_adamw(float* p, const float* g, float* m, float* v, float lr, float beta1
 /* attention backward (attention.py:132-182).  pk_attn_train_prep: the f32 operands q^ = l2norm(q) q_scale scale -> Qh (S heads, n, 64),
  * k^ = l2norm([null_k ; k]) k_scale -> Kh, [null_v ; v] -> Vh (S heads, nnull + n_kv, 64) from the projection outputs q (S n, ldq), kv (S n_kv, ldkv).
  * pk_attn_bwd: dQh / dKh / dVh from those, the forward output O (f32 or bf16) and dO; bias (heads, n, n_kv) / kmask (S, n_kv) cover the real keys;
- * dS (S heads, n, n_kv; optional) = the score gradient for the position-bias gradient (pk_sum_batch over S); lse / Drow: (S heads n) scratch.
+ * dS (S heads, n, n_kv; optional) = the score gradient for the position-bias gradient (pk_sum_batch over S); lse / Drow: (S heads n) scratch;
+ *   causal (attention.py:166-172, the C-ViViT temporal transformers): ALiBi slopes [heads] over all nnull + n keys and the causal mask.
  * pk_attn_train_prep_bwd: back through l2norm / scales / null keys: dq, dkv, partials pq / pk (1024, 64) of dq_scale / dk_scale, dnull (heads, 2 nnull, 64). */
 int pk_attn_train_prep(const float* q, long long ldq, const float* kv, long long ldkv, const float* null_kv, const float* q_scale, const float* k_scale,
                        float scale, float* Qh, float* Kh, float* Vh, int S, int heads, int n, int n_kv, int nnull, void* stream);
@@ -331,8 +339,8 @@ int pk_attn_train_prep_bwd(const float* q, long long ldq, const float* kv, long 
                            float scale, const float* dQh, const float* dKh, const float* dVh, float* dq, long long lddq, float* dkv, long long lddkv,
                            float* pq, float* pk, float* dnull, int S, int heads, int n, int n_kv, int nnull, void* stream);
 int pk_attn_bwd(const float* Qh, const float* Kh, const float* Vh, const void* O, long long ldo, int o_bf16, const float* dO, long long lddo,
-                const float* bias, const unsigned char* kmask, float* dQh, float* dKh, float* dVh, float* dS, float* lse, float* Drow,
-                int S, int heads, int n, int n_kv, int nnull, void* stream);
+                const float* bias, const unsigned char* kmask, const float* slopes, int causal, float* dQh, float* dKh, float* dVh, float* dS,
+                float* lse, float* Drow, int S, int heads, int n, int n_kv, int nnull, void* stream);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,9 @@ Published behaviour restated (eval mode, num_codebooks = 1), SURVEY.md 8c:
   buffer mask = 2 ** arange(codebook_dim - 1, -1, -1)  (MSB first);
   forward: x = project_in(x); q = where(x > 0, +1, -1); indices = sum((q > 0) * mask) (int64);
   returns (project_out(q), indices, aux_loss = 0);
+  training mode (module.train()): the straight-through estimator, q <- x + (q - x).detach(), so d project_in(x) = d q.  The entropy /
+  commitment auxiliary loss of the published module is NOT restated (returned as 0): the reference consumes it only in the GAN branch
+  (cvivit.py:667), which is out of scope -- the use_vgg_and_gan = False step returns the reconstruction loss alone (cvivit.py:624-627);
   indices_to_codes(ids): bits = (ids[..., None] & mask) != 0; codes = bits * 2 - 1; project_out(codes).
 PARITY UNPINNED: the upstream package is absent, no golden vectors exist for it.
 """
@@ -51,6 +54,8 @@ class LFQ(nn.Module):
         scale = torch.full_like(x, self.codebook_scale)
         q = torch.where(x > 0, scale, -scale)
         indices = ((q > 0).long() * self.mask.long()).sum(dim=-1)
+        if self.training:
+            q = x + (q - x).detach()
         return self.project_out(q), indices, torch.zeros((), device=x.device)
 
 

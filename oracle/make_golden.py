@@ -307,6 +307,35 @@ def recon_loss_golden(R, cfgs, tag):
     print(f'recon_loss_{tag}: {float(loss):.6f} masked {float(loss_masked):.6f} image {float(loss_img):.6f}')
 
 
+def cvivit_grads_golden(R, cfgs, tag):
+    """the REAL reference's tokenizer training step -- CViViT(use_vgg_and_gan=False).train()(video) (cvivit.py:518-627:
+    the reconstruction MSE through the straight-through LFQ of oracle/lfq.py) + loss.backward(): loss and the gradient of every parameter,
+    for a video batch and for a 4-D image batch."""
+    cv, _, _, _ = build_reference(R, cfgs, with_phenaki=False)
+    H = cfgs['cvivit']['image_size']
+    video = weights.synthetic_video(2, 5, H, H, seed=8)
+    out = {}
+    for name, x in (('video', video), ('image', video[:, :, 2])):
+        cv.train()
+        cv.zero_grad(set_to_none=True)
+        loss = cv(x)
+        loss.backward()
+        out[f'loss_{name}'] = loss.detach().clone()
+        # per parameter: the 2-norm of the whole gradient (f64) and every stride-th element of it (<= 4096 values): the fixture stays small
+        grads = {}
+        for k, v in cv.named_parameters():
+            if v.grad is None:
+                continue
+            flat = v.grad.detach().reshape(-1)
+            stride = max(1, -(-flat.numel() // 4096))
+            grads[k] = dict(norm=float(flat.double().norm()), stride=stride, sample=flat[::stride].clone(), shape=tuple(v.shape))
+        out[f'grads_{name}'] = grads
+    cv.eval()
+    torch.save(out, os.path.join(OUT, f'cvivit_grads_{tag}.pt'))
+    print(f'cvivit_grads_{tag}: loss {float(out["loss_video"]):.6f} ({len(out["grads_video"])} gradients), image {float(out["loss_image"]):.6f} '
+          f'({len(out["grads_image"])} gradients)')
+
+
 def selfcritic_golden(R, cfgs, tag):
     """Phenaki(self_token_critic=True) of the real reference (phenaki_pytorch.py:306-336, 374-375): the SelfCritic scores (plain and
     with classifier-free guidance) on fixed ids, and a full free-running sample whose score step is the self critic."""
@@ -488,6 +517,8 @@ def main():
         ce_grad_golden(R, TINY, tag='tiny')
     if 'tiny' in which or 'grads' in which or 'fwdgrads' in which:
         forward_grads_golden(R, TINY, batch=3, frames=5, ctx_len=6, tag='tiny')
+    if 'tiny' in which or 'grads' in which or 'cvgrads' in which:
+        cvivit_grads_golden(R, TINY, tag='tiny')
     if 'tiny' in which or 'critics' in which:
         selfcritic_golden(R, TINY, tag='tiny')
         unconditional_golden(R, TINY, tag='tiny')

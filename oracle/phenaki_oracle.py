@@ -374,6 +374,22 @@ def cvivit_recon_loss(sd, cfg, video, mask=None):
     return el[mask[:, None, :].expand(-1, video.shape[1], -1)].mean()
 
 
+def cvivit_recon_loss_train(sd, cfg, video):
+    """the differentiable form of cvivit_recon_loss (the module in training mode): the LFQ output is the straight-through
+    `proj + (sign(proj) - proj).detach()` of oracle/lfq.py, everything else as cvivit.py:518-627.  Autograd over the tensors of `sd`."""
+    import torch.nn.functional as F
+    if video.ndim == 4:
+        video = video.unsqueeze(2)
+    tokens = cvivit_patch_embed(sd, cfg, video)
+    tokens = cvivit_encode(sd, cfg, tokens)
+    b, t, h, w, d = tokens.shape
+    proj = lfq_project(sd, tokens.reshape(b, t * h * w, d))
+    q = torch.where(proj > 0, torch.ones_like(proj), -torch.ones_like(proj))
+    q = proj + (q - proj).detach()
+    codes = q @ sd['vq.project_out.weight'].t() + sd['vq.project_out.bias']
+    return F.mse_loss(video, cvivit_decode(sd, cfg, codes))
+
+
 # --------------------------------------------------------------------------- MaskGit / critic
 
 def maskgit_embed(sd, ids):

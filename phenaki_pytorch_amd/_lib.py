@@ -66,6 +66,9 @@ SIGNATURES = {
     'pk_geglu': [_P, _LL, _I, _P, _LL, _I, _I, _P],
     'pk_geglu_bwd': [_P, _LL, _I, _P, _LL, _P, _LL, _I, _I, _P],
     'pk_leaky_bwd': [_P, _LL, _P, _LL, _P, _LL, _I, _I, _F, _P],
+    'pk_scaled_diff': [_P, _P, _F, _P, _P, _LL, _P],
+    'pk_sign': [_P, _F, _P, _LL, _P],
+    'pk_mul': [_P, _P, _P, _LL, _P],
     'pk_peg_wgrad_parts': [_LL],
     'pk_peg_bwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'pk_embed_bwd': [_P, _P, _F, _P, _P, _I, _I, _I, _P],
@@ -77,7 +80,7 @@ SIGNATURES = {
     'pk_attn_train_prep_bwd': [_P, _LL, _P, _LL, _P, _P, _P, _F, _P, _P, _P, _P, _LL, _P, _LL, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'pk_gemm_splitk': [_I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P],
     'pk_adamw': [_P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _LL, _P],
-    'pk_attn_bwd': [_P, _P, _P, _P, _LL, _I, _P, _LL, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'pk_attn_bwd': [_P, _P, _P, _P, _LL, _I, _P, _LL, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
 }
 
 _ERR = {-1: 'PK_EINVAL (bad shape/size/flag)', -2: 'PK_EALIGN (pointer/stride alignment)', -3: 'PK_ELAUNCH (HIP launch failed)'}
@@ -207,7 +210,7 @@ def layernorm(x, gamma, beta, M, D, *, out=None, out2=None, raw=None, eps=1e-5, 
 
 def patchify_ln(video, f0, nt, pt, ph, pw, weight, bias, out, eps=1e-5):
     B, C, F, H, W = video.shape
-    rc = load().pk_patchify_ln(f32p(video, 'video'), B, C, F, H, W, f0, nt, pt, ph, pw, f32p(weight, 'LayerNorm weight'), f32p(bias, 'LayerNorm bias'), eps,
+    rc = load().pk_patchify_ln(f32p(video, 'video'), B, C, F, H, W, f0, nt, pt, ph, pw, f32p(weight, 'LayerNorm weight'), f32p(bias, 'LayerNorm bias'), eps,   # weight = bias = None: raw rows
                                ptr(out), out.stride(0), 1 if out.dtype == torch.bfloat16 else 0, stream(video))
     _check(rc, 'pk_patchify_ln')
 
@@ -461,6 +464,25 @@ def geglu_bwd(h, goff, dout, dh, M, F):
     _check(rc, 'pk_geglu_bwd')
 
 
+def scaled_diff(a, b, scale, out, scale_dev=None):
+    """out = (a - b) * scale (* scale_dev[0]) over contiguous f32 tensors of the same size"""
+    rc = load().pk_scaled_diff(f32p(a, 'a'), f32p(b, 'b'), float(scale), ptr(scale_dev), ptr(out), a.numel(), stream(a))
+    _check(rc, 'pk_scaled_diff')
+    return out
+
+
+def mul(a, b, out):
+    rc = load().pk_mul(f32p(a, 'a'), f32p(b, 'b'), ptr(out), a.numel(), stream(a))
+    _check(rc, 'pk_mul')
+    return out
+
+
+def sign(z, out, value=1.0):
+    rc = load().pk_sign(f32p(z, 'z'), float(value), ptr(out), z.numel(), stream(z))
+    _check(rc, 'pk_sign')
+    return out
+
+
 def leaky_bwd(y, dy, dz, M, N, slope=0.1):
     rc = load().pk_leaky_bwd(ptr(y), y.stride(-2), ptr(dy), dy.stride(-2), ptr(dz), dz.stride(-2), M, N, slope, stream(y))
     _check(rc, 'pk_leaky_bwd')
@@ -541,12 +563,12 @@ def attn_train_prep_bwd(q, kv, null_kv, q_scale, k_scale, scale, dQh, dKh, dVh, 
     return dqs, dks, dnull
 
 
-def attn_bwd(Qh, Kh, Vh, O, dO, dQh, dKh, dVh, S, h, n, n_kv, nnull, *, bias=None, kmask=None, dS=None):
+def attn_bwd(Qh, Kh, Vh, O, dO, dQh, dKh, dVh, S, h, n, n_kv, nnull, *, bias=None, kmask=None, dS=None, slopes=None, causal=False):
     dev = Qh.device
     lse = torch.empty((S * h * n,), device=dev, dtype=torch.float32)
     drow = torch.empty((S * h * n,), device=dev, dtype=torch.float32)
     rc = load().pk_attn_bwd(ptr(Qh), ptr(Kh), ptr(Vh), ptr(O), O.stride(-2), 1 if O.dtype == torch.bfloat16 else 0, ptr(dO), dO.stride(-2), ptr(bias), ptr(kmask),
-                            ptr(dQh), ptr(dKh), ptr(dVh), ptr(dS), ptr(lse), ptr(drow), S, h, n, n_kv, nnull, stream(Qh))
+                            f32p(slopes, 'ALiBi slopes') if causal else None, 1 if causal else 0, ptr(dQh), ptr(dKh), ptr(dVh), ptr(dS), ptr(lse), ptr(drow), S, h, n, n_kv, nnull, stream(Qh))
     _check(rc, 'pk_attn_bwd')
 
 

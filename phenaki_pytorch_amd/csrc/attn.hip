@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
                         else {
                             if (bias && j >= 0 && qi < p.nq) sv += bias[(size_t)qi * p.bias_ld + j];
                             bool masked = km && j >= 0 && !km[j];
-                            if (p.causal && j >= 0) {
+                            if (p.causal) {                          // ALiBi runs over the null keys too (j < 0: never masked), attention.py:198-227
                                 const int dj = j - (qi + coff);
                                 sv -= fabsf((float)dj) * slope;
                                 masked = masked || dj > 0;
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                             if (TAB) { if (j >= 0 && qi < p.nq) sv += tab[cq[qf] - codes[j]]; }
                             else if (bias && j >= 0 && qi < p.nq) sv += bias[(size_t)qi * p.bias_ld + j];
                             bool masked = km && j >= 0 && !km[j];
-                            if (p.causal && j >= 0) {
+                            if (p.causal) {                          // ALiBi runs over the null keys too (j < 0: never masked), attention.py:198-227
                                 const int dj = j - (qi + coff);
                                 sv -= fabsf((float)dj) * slope;
                                 masked = masked || dj > 0;

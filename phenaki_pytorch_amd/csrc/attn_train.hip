@@ -160,6 +160,7 @@ struct AttnBwdArgs {
     const float* dO; long lddo;                              // (M, >= heads * 64) f32
     const float* bias;                                       // [heads][n][nkt - nnull] or null (columns = real keys)
     const unsigned char* kmask;                              // [S][nkt - nnull] or null
+    const float* slopes; int causal;                         // causal: ALiBi -|j - (nkt - n + i)| slopes[h] over ALL keys + the causal mask
     float* dQh; float* dKh; float* dVh;
     float* dS;                                               // [S*h][n][nkt - nnull] or null (real-key columns only)
     float* lse; float* Drow;                                 // [S*h][n] scratch written by kernel Q, read by kernel KV
@@ -207,6 +208,10 @@ __device__ __forceinline__ bool score(const AttnBwdArgs& p, int s, int h, int gi
     float v = raw;
     if (p.bias && jr >= 0) v += p.bias[((long)h * p.n + gi) * (p.nkt - p.nnull) + jr];
     if (p.kmask && jr >= 0 && !p.kmask[(long)s * (p.nkt - p.nnull) + jr]) v = NEG_MAX;
+    if (p.causal) {                                            // attention.py:166-172: the null keys sit in front and are never masked
+        const int d = j - (p.nkt - p.n + gi);
+        v = d > 0 ? NEG_MAX : v + (float)d * p.slopes[h];     // d <= 0: -|d| slope = d slope
+    }
     out = v;
     return true;
 }
@@ -437,13 +442,15 @@ extern "C" int pk_attn_train_prep_bwd(const float* q, long ldq, const float* kv,
 
 // O: the forward output (M = S n rows, ldo elements per row; o_bf16 = 1: bf16), dO its gradient (f32).  bias (heads, n, n_kv) / kmask (S, n_kv)
 // cover the REAL keys (the nnull leading null keys carry no bias and are never masked, attention.py:151-158).  dS (S heads, n, n_kv) optional.
+// causal (self-attention, attention.py:166-172): ALiBi with slopes [heads] over all nnull + n keys, then key j > nnull + i masked.
 // lse / Drow: (S heads n) f32 scratch
 extern "C" int pk_attn_bwd(const float* Qh, const float* Kh, const float* Vh, const void* O, long ldo, int o_bf16, const float* dO, long lddo,
-                           const float* bias, const unsigned char* kmask, float* dQh, float* dKh, float* dVh, float* dS, float* lse, float* Drow,
-                           int S, int heads, int n, int n_kv, int nnull, void* stream) {
+                           const float* bias, const unsigned char* kmask, const float* slopes, int causal, float* dQh, float* dKh, float* dVh, float* dS,
+                           float* lse, float* Drow, int S, int heads, int n, int n_kv, int nnull, void* stream) {
     if (!Qh || !Kh || !Vh || !O || !dO || !dQh || !dKh || !dVh || !lse || !Drow || S <= 0 || heads <= 0 || n <= 0 || n_kv <= 0 || nnull < 0) return PK_EINVAL;
     if (!al16(Qh) || !al16(Kh) || !al16(Vh) || !al16(dO) || (lddo & 3)) return PK_EALIGN;
-    AttnBwdArgs p{Qh, Kh, Vh, O, ldo, o_bf16, dO, lddo, bias, kmask, dQh, dKh, dVh, dS, lse, Drow, S, heads, n, nnull + n_kv, nnull};
+    if (causal && (!slopes || n != n_kv)) return PK_EINVAL;
+    AttnBwdArgs p{Qh, Kh, Vh, O, ldo, o_bf16, dO, lddo, bias, kmask, slopes, causal, dQh, dKh, dVh, dS, lse, Drow, S, heads, n, nnull + n_kv, nnull};
     hipStream_t s = STREAM(stream);
     static bool attr_done = false;
     if (!attr_done) {

@@ -80,6 +80,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     for (int i = 0; i < VMAX; ++i) {
         const int c = threadIdx.x + i * 256;
         if (c < nv) {
+            if (!weight) {                                    // no LayerNorm: the raw patch rows (the training step keeps them, train_cvivit.py)
+                store4(out + (size_t)row * ldo + c * 4, v[i]);
+                continue;
+            }
             const f32x4 wv = *reinterpret_cast<const f32x4*>(weight + c * 4);
             const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c * 4);
             f32x4 y;
@@ -143,13 +147,13 @@ static int check_geom(const PatchGeom& g) {
     return PK_OK;
 }
 
-// video (B,C,F,H,W) f32, frames [f0, f0 + nt*pt) -> out[(b,tt,hh,ww)][P] = LayerNorm_P(patch) (f32 or bf16)
+// video (B,C,F,H,W) f32, frames [f0, f0 + nt*pt) -> out[(b,tt,hh,ww)][P] = LayerNorm_P(patch) (f32 or bf16); weight = bias = null: the raw patch
 extern "C" int pk_patchify_ln(const float* video, int B, int C, int F, int H, int W, int f0, int nt,
                               int pt, int ph, int pw, const float* weight, const float* bias, float eps,
                               void* out, int ldo, int out_kind, void* stream) {
     PatchGeom g{B, C, F, H, W, f0, nt, pt, ph, pw, ph ? H / ph : 0, pw ? W / pw : 0};
     if (int rc = check_geom(g)) return rc;
-    if (!video || !weight || !bias || !out || (ldo & 3)) return PK_EINVAL;
+    if (!video || (!weight != !bias) || !out || (ldo & 3)) return PK_EINVAL;
     const int P = C * pt * ph * pw;
     if ((P >> 2) > 256 * 8 || C * pt * ph > PATCH_MAX_ROWS || (size_t)C * F * H * W >= 0x7FFFFFFFull) return PK_EINVAL;
     const int rows = B * nt * g.nh * g.nw;

@@ -185,6 +185,26 @@ __global__ __launch_bounds__(256) void leaky_bwd_kernel(const float* __restrict_
     }
 }
 
+// ---- C-ViViT reconstruction step (cvivit.py:585-591, LFQ straight-through): elementwise pieces -----------------------------------------
+// out = (a - b) * scale [* *scale_dev]: the gradient of sum (a - b)^2 * (scale / 2) w.r.t. a
+__global__ __launch_bounds__(256) void scaled_diff_kernel(const float* __restrict__ a, const float* __restrict__ b, float scale,
+                                                          const float* __restrict__ scale_dev, float* __restrict__ out, long total4) {
+    const float sc = scale * (scale_dev ? *scale_dev : 1.0f);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(a + idx * 4), y = *reinterpret_cast<const f32x4*>(b + idx * 4);
+        *reinterpret_cast<f32x4*>(out + idx * 4) = (x - y) * sc;
+    }
+}
+// out = a * b (the summand of the patch LayerNorm's weight gradient: dz (.) x^)
+__global__ __launch_bounds__(256) void mul_kernel(const float* a, const float* b, float* out, long total4) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256)
+        *reinterpret_cast<f32x4*>(out + idx * 4) = *reinterpret_cast<const f32x4*>(a + idx * 4) * *reinterpret_cast<const f32x4*>(b + idx * 4);
+}
+// out = z > 0 ? +value : -value (the LFQ code of a projection)
+__global__ __launch_bounds__(256) void sign_kernel(const float* __restrict__ z, float value, float* __restrict__ out, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) out[idx] = z[idx] > 0.f ? value : -value;
+}
+
 // ---- PEG backward (attention.py:57-85 + the residual of :323: y = x + dsconv(pad(x)) + b) ------------------------------------------------
 // dx = dy + sum_taps w[tap] * dy[shifted the other way];  tfront = 2 causal / 1 centred frame padding, as in pk_peg
 __global__ __launch_bounds__(256) void peg_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ wt, float* __restrict__ dx,
@@ -459,6 +479,29 @@ extern "C" int pk_leaky_bwd(const float* y, long ldy, const float* dy, long lddy
     if (!y || !dy || !dz || M <= 0 || N <= 0) return PK_EINVAL;
     const long total = (long)M * N;
     hipLaunchKernelGGL(leaky_bwd_kernel, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), y, ldy, dy, lddy, dz, lddz, N, slope, total);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+extern "C" int pk_scaled_diff(const float* a, const float* b, float scale, const float* scale_dev, float* out, long n, void* stream) {
+    if (!a || !b || !out || n <= 0) return PK_EINVAL;
+    if ((n & 3) || !al16(a) || !al16(b) || !al16(out)) return PK_EALIGN;
+    hipLaunchKernelGGL(scaled_diff_kernel, dim3(nblocks(n >> 2)), dim3(256), 0, STREAM(stream), a, b, scale, scale_dev, out, n >> 2);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+extern "C" int pk_mul(const float* a, const float* b, float* out, long n, void* stream) {
+    if (!a || !b || !out || n <= 0) return PK_EINVAL;
+    if ((n & 3) || !al16(a) || !al16(b) || !al16(out)) return PK_EALIGN;
+    hipLaunchKernelGGL(mul_kernel, dim3(nblocks(n >> 2)), dim3(256), 0, STREAM(stream), a, b, out, n >> 2);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+extern "C" int pk_sign(const float* z, float value, float* out, long n, void* stream) {
+    if (!z || !out || n <= 0) return PK_EINVAL;
+    hipLaunchKernelGGL(sign_kernel, dim3(nblocks(n)), dim3(256), 0, STREAM(stream), z, value, out, n);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

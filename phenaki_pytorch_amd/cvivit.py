@@ -372,18 +372,23 @@ class CViViT(PackedModule):
 
     def forward(self, video, mask=None, return_recons=False, return_recons_only=False, return_discr_loss=False,
                 apply_grad_penalty=True, return_only_codebook_ids=False):
+        if not (return_only_codebook_ids or return_recons_only or return_discr_loss):
+            from .train import wants_grad
+            if wants_grad(self):
+                # grad mode on and trainable parameters: the tokenizer's training step (train_cvivit.py)
+                from .train_cvivit import cvivit_loss_train
+                self._check_video(video, mask)
+                return cvivit_loss_train(self, video, mask=mask, return_recons=return_recons)
         out = self._forward(video, mask, return_recons, return_recons_only, return_discr_loss, apply_grad_penalty,
                             return_only_codebook_ids)
         if return_only_codebook_ids or return_recons_only:
             return out
         return value_without_graph(self, 'CViViT.forward (reconstruction loss)', out)
 
-    @torch.no_grad()
-    def _forward(self, video, mask=None, return_recons=False, return_recons_only=False, return_discr_loss=False,
-                 apply_grad_penalty=True, return_only_codebook_ids=False):
+    def _check_video(self, video, mask):
+        """the asserts of cvivit.py:529-540"""
         assert video.ndim in {4, 5}
-        is_image = video.ndim == 4
-        if is_image:
+        if video.ndim == 4:
             video = video.unsqueeze(2)
             assert not exists(mask)
         b, c, f, *image_dims = video.shape
@@ -391,6 +396,14 @@ class CViViT(PackedModule):
         assert not exists(mask) or mask.shape[-1] == f
         assert divisible_by(f - 1, self.temporal_patch_size), \
             f'number of frames ({f}) minus one ({f - 1}) must be divisible by temporal patch size ({self.temporal_patch_size})'
+        return video
+
+    @torch.no_grad()
+    def _forward(self, video, mask=None, return_recons=False, return_recons_only=False, return_discr_loss=False,
+                 apply_grad_penalty=True, return_only_codebook_ids=False):
+        is_image = video.ndim == 4
+        video = self._check_video(video, mask)
+        b, c, f, *image_dims = video.shape
         L.require_device(video, 'video')
         video = video.float().contiguous()
 

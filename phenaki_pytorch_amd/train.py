@@ -20,7 +20,7 @@ Every block of the trunk is ONE torch.autograd.Function whose forward and backwa
 Activations and gradients are f32 in HBM (288 GB: every block keeps what its backward needs instead of recomputing it); the GEMMs run in the
 module's compute dtype ('fp32' | 'bf16x3' | 'bf16').  Matrix products of the backward pass: dX = dY W through pk_gemm on pk_pack(W^T),
 dW = dY^T X through pk_gemm on pk_pack(dY^T) and pk_pack(X^T) (contraction over the rows, zero-padded to the k-tile).
-Limits (asserted): dropout 0 (the reference default), non-causal trunk attention (MaskGit / TokenCritic), no C-ViViT training.
+Limits (asserted): dropout 0 (the reference default).  The tokenizer's own reconstruction step is train_cvivit.py.
 """
 import math
 
@@ -238,7 +238,7 @@ class _AttnBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, context, gamma, beta, cgamma, cbeta, wq, wkv, null_kv, q_scale, k_scale, wo, bias, kmask, meta):
-        dtype, S, n, n_ctx, heads, scale, eps = meta
+        dtype, S, n, n_ctx, heads, scale, eps, slopes = meta
         dev = x.device
         M, D = x.shape
         inner = wq.shape[0]
@@ -265,7 +265,7 @@ class _AttnBlock(torch.autograd.Function):
         Vt = torch.empty((S * heads * nk_pad * 64,), device=dev, dtype=td)
         L.attn_prep(dtype, q, kv, null_kv.detach(), q_scale.detach(), k_scale.detach(), float(scale), Qp, Kp, Vt, S, heads, n, n_kv, nnull)
         o = _f32((M, inner), dev)
-        L.attn_fwd(dtype, Qp, Kp, Vt, o, S, heads, n, n_kv, nnull, bias=bias, kmask=kmask)
+        L.attn_fwd(dtype, Qp, Kp, Vt, o, S, heads, n, n_kv, nnull, bias=bias, kmask=kmask, slopes=slopes, causal=slopes is not None)
         y = _f32((M, D), dev)
         L.gemm(dtype, o, pack_operand(wo, dtype), M, D, inner, C=y, res=x)
         ctx.save_for_backward(x, context, gamma, cgamma, wq, wkv, null_kv, q_scale, k_scale, wo, bias, kmask, xn, src, q, kv, o)
@@ -275,7 +275,7 @@ class _AttnBlock(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, context, gamma, cgamma, wq, wkv, null_kv, q_scale, k_scale, wo, bias, kmask, xn, src, q, kv, o = ctx.saved_tensors
-        dtype, S, n, n_ctx, heads, scale, eps = ctx.meta
+        dtype, S, n, n_ctx, heads, scale, eps, slopes = ctx.meta
         dev = x.device
         M, D = x.shape
         inner = wq.shape[0]
@@ -292,7 +292,7 @@ class _AttnBlock(torch.autograd.Function):
         dQh, dKh, dVh = torch.empty_like(Qh), torch.empty_like(Kh), torch.empty_like(Vh)
         want_dbias = bias is not None and ctx.needs_input_grad[12]
         dS = _f32((S, heads * n * n_kv), dev) if want_dbias else None
-        L.attn_bwd(Qh, Kh, Vh, o, do, dQh, dKh, dVh, S, heads, n, n_kv, nnull, bias=bias, kmask=kmask, dS=dS)
+        L.attn_bwd(Qh, Kh, Vh, o, do, dQh, dKh, dVh, S, heads, n, n_kv, nnull, bias=bias, kmask=kmask, dS=dS, slopes=slopes, causal=slopes is not None)
         dbias = None
         if want_dbias:
             dbias = _f32(tuple(bias.shape), dev)
@@ -601,10 +601,11 @@ def peg_train(peg: PEG, x2d, shape):
 
 
 def attention_train(attn: Attention, x2d, S, n, dtype, *, context2d=None, n_ctx=None, attn_bias=None, kmask=None):
-    assert not attn.causal, 'the training kernels cover the non-causal trunk attention (MaskGit / TokenCritic)'
     assert attn.attn_dropout.p == 0., 'the training kernels are built for attn_dropout = 0 (the reference default)'
+    assert not (attn.causal and context2d is not None), 'causal attention is self-attention (attention.py:166-172)'
     cn = attn.context_norm if isinstance(attn.context_norm, LayerNorm) else None
-    meta = (dtype, S, n, n_ctx, attn.heads, float(attn.scale), attn.norm.eps)
+    slopes = attn.rel_pos_bias.slopes.reshape(-1).contiguous() if attn.causal else None     # ALiBi + causal mask inside the kernels
+    meta = (dtype, S, n, n_ctx, attn.heads, float(attn.scale), attn.norm.eps, slopes)
     return _AttnBlock.apply(x2d, context2d, attn.norm.gamma, attn.norm.beta, cn.gamma if (cn is not None and context2d is not None) else None,
                             cn.beta if cn is not None else None, attn.to_q.weight, attn.to_kv.weight, attn.null_kv, attn.q_scale, attn.k_scale,
                             attn.to_out.weight, attn_bias, kmask, meta)

@@ -323,6 +323,49 @@ def test_training_step_gradients_match_reference_autograd(golden_dir):
     assert checked >= 90
 
 
+def cvivit_grad_check(get_grad, g_grads, rtol, min_checked):
+    """gradients against the fixture of cvivit_grads_golden (per parameter: norm of the whole gradient + every stride-th element)"""
+    top = max(v['norm'] for v in g_grads.values())
+    checked = 0
+    for k, ref in g_grads.items():
+        if not ref['sample'].numel():
+            continue
+        got = get_grad(k)
+        assert got is not None, k
+        got = got.detach().float().cpu().reshape(-1)
+        if ref['norm'] < 1e-6 * top:                                # structurally zero (the position MLP's last bias): noise vs noise
+            assert float(got.double().norm()) < 1e-4 * top, k
+            continue
+        scale = float(ref['sample'].abs().max()) + 1e-30
+        assert float((got[::ref['stride']] - ref['sample']).abs().max()) <= rtol * scale, k
+        assert abs(float(got.double().norm()) - ref['norm']) <= rtol * ref['norm'], k
+        checked += 1
+    assert checked >= min_checked, checked
+
+
+@pytest.mark.parametrize('kind', ['video', 'image'])
+def test_cvivit_training_step_gradients_match_reference_autograd(golden_dir, kind):
+    """torch autograd through the oracle's differentiable C-ViViT (straight-through LFQ) against the REAL reference's
+    CViViT(use_vgg_and_gan=False).train()(video).backward() (oracle/make_golden.py cvivit_grads_golden): pins what tests/test_train_gpu.py
+    differentiates at full size to check the tokenizer's MI355X training step"""
+    g = load(golden_dir, 'cvivit_grads_tiny.pt')
+    cv, _, _ = state_dicts('tiny')
+    cvc, _, _ = oracle_cfgs(TINY)
+    cv = {k: (v.clone().requires_grad_() if v.is_floating_point() and not k.endswith('.beta') else v) for k, v in cv.items()}
+    H = TINY['cvivit']['image_size']
+    video = weights.synthetic_video(2, 5, H, H, seed=8)
+    x = video if kind == 'video' else video[:, :, 2]
+    with torch.enable_grad():
+        loss = O.cvivit_recon_loss_train(cv, cvc, x)
+        loss.backward()
+    assert abs(float(loss) - float(g[f'loss_{kind}'])) <= 1e-5 * float(g[f'loss_{kind}'])
+    if kind == 'image':                                             # the reference runs its rest-frame modules on empty tensors: zero gradients
+        grads = {k: v for k, v in g['grads_image'].items() if v['norm'] > 0}
+    else:
+        grads = g['grads_video']
+    cvivit_grad_check(lambda k: cv[k].grad, grads, 1e-4, 100 if kind == 'video' else 90)
+
+
 @pytest.mark.parametrize('tag', ['tiny', 'base'])
 def test_t5_encoder_oracle_matches_huggingface(golden_dir, tag):
     """oracle/t5_oracle.py (restated from transformers' modeling_t5.py) against the REAL HuggingFace T5EncoderModel -- the module the

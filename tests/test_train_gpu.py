@@ -114,16 +114,20 @@ def test_feedforward_block_gradients(dtype, tol):
 
 
 @pytest.mark.parametrize('dtype,tol', MODES)
-@pytest.mark.parametrize('case', ['self_bias', 'cross_null_mask', 'self_mask'])
+@pytest.mark.parametrize('case', ['self_bias', 'cross_null_mask', 'self_mask', 'causal_short', 'causal_long'])
 def test_attention_block_gradients(case, dtype, tol):
-    """x + Attention(x) (attention.py:89-182): position bias gradient, null keys, key mask, l2norm / learned scales; n = 70 (ragged tiles)"""
+    """x + Attention(x) (attention.py:89-182): position bias gradient, null keys, key mask, l2norm / learned scales; n = 70 (ragged tiles);
+    causal_*: ALiBi over the null + real keys and the causal mask (the C-ViViT temporal transformers: n = 9, and n = 70 across key tiles)"""
     import phenaki_pytorch_amd as P
     from phenaki_pytorch_amd.train import attention_train
     from phenaki_pytorch_amd.attention import resolve_dtype
     torch.manual_seed(3)
     D, heads, S, n = 128, 2, 3, 70
     cross = case == 'cross_null_mask'
-    attn = P.attention.Attention(dim=D, dim_context=96 if cross else None, heads=heads, num_null_kv=2 if cross else 0)
+    causal = case.startswith('causal')
+    if case == 'causal_short':
+        S, n = 40, 9
+    attn = P.attention.Attention(dim=D, dim_context=96 if cross else None, heads=heads, num_null_kv=2 if (cross or causal) else 0, causal=causal)
     with torch.no_grad():
         attn.q_scale.uniform_(0.5, 1.5)
         attn.k_scale.uniform_(0.5, 1.5)
@@ -144,10 +148,10 @@ def test_attention_block_gradients(case, dtype, tol):
         sd['context_norm.beta'] = attn.context_norm.beta.detach()
     elif case == 'self_bias':
         bias = _leaf(torch.randn(heads, n, n))
-    else:
+    elif not causal:
         mask = torch.rand(S, n) > 0.2
         mask[:, 0] = True
-    (O.attention(sd, '', xl, heads=heads, context=ctx, mask=mask, attn_bias=bias) + xl).backward(G)
+    (O.attention(sd, '', xl, heads=heads, context=ctx, mask=mask, attn_bias=bias, causal=causal) + xl).backward(G)
     attn = attn.cuda()
     xc = x.reshape(S * n, D).cuda().requires_grad_()
     bc = bias.detach().cuda().requires_grad_() if bias is not None else None
@@ -156,7 +160,8 @@ def test_attention_block_gradients(case, dtype, tol):
                             attn_bias=bc, kmask=mask.to(torch.uint8).cuda() if mask is not None else None)
     y.backward(G.reshape(S * n, D).cuda())
     errs = dict(dx=close(xc.grad.cpu(), xl.grad.reshape(S * n, D), tol, 'attn dx'))
-    for name in ('to_q.weight', 'to_kv.weight', 'to_out.weight', 'q_scale', 'k_scale', 'norm.gamma') + (('null_kv', 'context_norm.gamma') if cross else ()):
+    for name in ('to_q.weight', 'to_kv.weight', 'to_out.weight', 'q_scale', 'k_scale', 'norm.gamma') + (('null_kv',) if (cross or causal) else ()) + \
+            (('context_norm.gamma',) if cross else ()):
         mod = attn
         for part in name.split('.'):
             mod = getattr(mod, part)
