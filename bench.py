@@ -24,6 +24,8 @@ The same JSON line carries
   parity_mode  : the split-bf16 ("bf16x3") mode -- held by the tests to bit-exact ids / 1e-3 against the reference, like exact f32 --
                  timed on the same legs; parity_mode_f32: the exact-f32 mode beside it;
   encode_b32 / sample_b32 : the same legs with 32 videos per GPU (what the kernels reach when the GPU is full);
+  train_step / cvivit_train_step : one full training step (forward + backward + AdamW) of Phenaki.forward on token ids, and of the tokenizer on
+                 its reconstruction loss (SURVEY.md 8f rows 1 and 4);
   cpu_baseline : the CPU oracle (a port of the reference algorithm, oracle/phenaki_oracle.py) on a bounded sample of
                  the same workload on this box's host cores.
 """
@@ -63,7 +65,7 @@ def parse():
     ap.add_argument('--no-parity-mode', action='store_true', help='skip the exact-f32 timing')
     ap.add_argument('--no-kernels', action='store_true', help='skip the per-kernel roofline table')
     ap.add_argument('--encode-only', action='store_true', help='only the headline leg (profiling runs)')
-    ap.add_argument('--legs', default='decode,encode_b32,sample,sample_cfg3,sample_b32,make_video,objective,train_step',
+    ap.add_argument('--legs', default='decode,encode_b32,sample,sample_cfg3,sample_b32,make_video,objective,train_step,cvivit_train_step',
                     help='comma list of the legs reported beside the headline encode leg')
     ap.add_argument('--sample-batch', type=int, default=8)
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -675,6 +677,45 @@ def bench_train_step(args, ws, mode):
     return out
 
 
+def bench_cvivit_train_step(args, ws, mode):
+    """ONE step of the reference's CViViTTrainer generator loop without the GAN terms (cvivit_trainer.py:241-249 with
+    use_vgg_and_gan = False) at BASELINE geometry -- zero_grad, loss = CViViT.forward(video) [reconstruction MSE through the straight-through
+    LFQ], loss.backward(), AdamW step on every tokenizer parameter (train_cvivit.py).  frames/sec, comparable with the encode headline."""
+    import phenaki_pytorch_amd as P
+    B = args.batch
+    torch.manual_seed(0)
+    cv = P.CViViT(use_vgg_and_gan=False, **BASELINE_CFG['cvivit']).cuda().train()
+    P.set_compute_dtype(cv, mode)
+    video = synthetic_video(B, 17, 256, 5).cuda()
+    params = [p for p in cv.parameters() if p.requires_grad]
+    opt = P.get_optimizer(params, lr=1e-4, wd=0.)
+    reducer = P.GradientReducer(params) if ws > 1 else None
+    losses = []
+
+    def step(i):
+        with torch.enable_grad():
+            opt.zero_grad(set_to_none=True)
+            loss = cv(video)
+            loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+        losses.append(loss.detach())
+
+    step(0)
+    step(1)
+    torch.cuda.reset_peak_memory_stats()
+    ts = timed_groups(step, 3, 3, ws)
+    dt = statistics.median(ts) / 3
+    out = dict(metric='cvivit_train_step_frames_per_sec', value=B * 17 * ws / dt, unit='frames/s', ms_per_step=dt * 1e3, dtype=mode, batch_per_gpu=B,
+               frames_per_video=17, trained_parameters=sum(p.numel() for p in params), loss_first=float(losses[0]), loss_last=float(losses[-1]),
+               peak_memory_gb=torch.cuda.max_memory_allocated() / 2 ** 30, optimizer='AdamW (pk_adamw), lr 1e-4',
+               note='forward + backward + optimizer step of the tokenizer on the reconstruction loss (use_vgg_and_gan = False); the GAN / VGG terms are not built')
+    del cv, opt
+    torch.cuda.empty_cache()
+    return out
+
+
 def bench_parity_mode(args, ws, mode='bf16x3'):
     """a PARITY-GRADE mode -- a configuration the parity tests hold to bit-exact ids (margin-audited) / 1e-3 against the REAL
     reference -- timed on the same workloads:
@@ -798,6 +839,12 @@ def main():
                 result['train_step_bf16'] = bench_train_step(args, ws, 'bf16')
         except Exception as e:                                  # noqa: BLE001 -- a training-leg failure must not cost the headline line
             print(f'[bench] train_step leg failed ({type(e).__name__}: {e})', file=sys.stderr)
+            torch.cuda.synchronize()
+    if 'cvivit_train_step' in legs and not args.encode_only:
+        try:
+            result['cvivit_train_step'] = bench_cvivit_train_step(args, ws, 'bf16x3' if args.dtype == 'bf16' else args.dtype)
+        except Exception as e:                                  # noqa: BLE001
+            print(f'[bench] cvivit_train_step leg failed ({type(e).__name__}: {e})', file=sys.stderr)
             torch.cuda.synchronize()
     if not (args.no_parity_mode or args.encode_only) and args.dtype == 'bf16':
         result['parity_mode'] = bench_parity_mode(args, ws, 'bf16x3')

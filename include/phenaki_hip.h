@@ -104,6 +104,11 @@ int pk_patch_embed(const float* video, int B, int C, int F, int H, int W, int ph
 int pk_unpatchify(const float* pix, int ldp, float* video, int B, int C, int F, int H, int W, int f0, int nt,
                   int pt, int ph, int pw, void* stream);
 
+/* cvivit.py:585-589 in patch layout: dst[(b,tt,hh,ww)][(c,dt,y,x)] = fmask[b][f0 + tt*pt + dt] ? src[..] : 0 for a (rows, P) f32 matrix
+ * (fmask (B, F) uint8; dst may be src): the frame mask of variable-length training where the training step takes its loss (train_cvivit.py). */
+int pk_patch_frame_mask(const float* src, long long lds, float* dst, long long ldd, const unsigned char* fmask, int B, int C, int F, int H, int W,
+                        int f0, int nt, int pt, int ph, int pw, void* stream);
+
 /* Numerator of the reconstruction loss of cvivit.py:585-591 (F.mse_loss(video, recon), optionally over the frames a
  * (B, F) mask keeps): partials[i], i < PK_SQDIFF_BLOCKS, are per-workgroup double sums of (a - b)^2 over two contiguous
  * (B, C, F, H, W) f32 videos; the caller adds them and divides by the kept element count. */

@@ -310,15 +310,17 @@ def recon_loss_golden(R, cfgs, tag):
 def cvivit_grads_golden(R, cfgs, tag):
     """the REAL reference's tokenizer training step -- CViViT(use_vgg_and_gan=False).train()(video) (cvivit.py:518-627:
     the reconstruction MSE through the straight-through LFQ of oracle/lfq.py) + loss.backward(): loss and the gradient of every parameter,
-    for a video batch and for a 4-D image batch."""
+    for a video batch, for a 4-D image batch and for the video batch under a frame mask (variable-length training, :585-589)."""
     cv, _, _, _ = build_reference(R, cfgs, with_phenaki=False)
     H = cfgs['cvivit']['image_size']
     video = weights.synthetic_video(2, 5, H, H, seed=8)
     out = {}
-    for name, x in (('video', video), ('image', video[:, :, 2])):
+    mask = torch.tensor([[True] * 5, [True] * 3 + [False] * 2])
+    out['mask'] = mask
+    for name, x in (('video', video), ('image', video[:, :, 2]), ('masked', video)):
         cv.train()
         cv.zero_grad(set_to_none=True)
-        loss = cv(x)
+        loss = cv(x, mask=mask) if name == 'masked' else cv(x)
         loss.backward()
         out[f'loss_{name}'] = loss.detach().clone()
         # per parameter: the 2-norm of the whole gradient (f64) and every stride-th element of it (<= 4096 values): the fixture stays small

@@ -374,7 +374,7 @@ def cvivit_recon_loss(sd, cfg, video, mask=None):
     return el[mask[:, None, :].expand(-1, video.shape[1], -1)].mean()
 
 
-def cvivit_recon_loss_train(sd, cfg, video):
+def cvivit_recon_loss_train(sd, cfg, video, mask=None):
     """the differentiable form of cvivit_recon_loss (the module in training mode): the LFQ output is the straight-through
     `proj + (sign(proj) - proj).detach()` of oracle/lfq.py, everything else as cvivit.py:518-627.  Autograd over the tensors of `sd`."""
     import torch.nn.functional as F
@@ -387,7 +387,11 @@ def cvivit_recon_loss_train(sd, cfg, video):
     q = torch.where(proj > 0, torch.ones_like(proj), -torch.ones_like(proj))
     q = proj + (q - proj).detach()
     codes = q @ sd['vq.project_out.weight'].t() + sd['vq.project_out.bias']
-    return F.mse_loss(video, cvivit_decode(sd, cfg, codes))
+    recon = cvivit_decode(sd, cfg, codes)
+    if mask is None:
+        return F.mse_loss(video, recon)
+    el = F.mse_loss(video, recon, reduction='none')
+    return el[mask[:, None, :].expand(-1, video.shape[1], -1)].mean()
 
 
 # --------------------------------------------------------------------------- MaskGit / critic

@@ -33,6 +33,7 @@ SIGNATURES = {
     'pk_patch_embed': [_P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I,
                        _P, _I, _P, _P, _P, _I, _I, _I,
                        _P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
+    'pk_patch_frame_mask': [_P, _LL, _P, _LL, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'pk_unpatchify': [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'pk_sqdiff_partials': [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     'pk_peg': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -227,6 +228,14 @@ def patch_embed(video, ph, pw, N, groups, eps=1e-5):
     ldo = groups[0][3].stride(0)
     rc = load().pk_patch_embed(f32p(video, 'video'), B, C, F, H, W, ph, pw, N, eps, len(groups), *flat, ldo, stream(video))
     _check(rc, 'pk_patch_embed')
+
+
+def patch_frame_mask(src, dst, fmask, video_shape, f0, nt, pt, ph, pw):
+    """dst = src with the patch-layout elements of the frames `fmask` (B, F) uint8 drops set to zero"""
+    B, C, F, H, W = video_shape
+    rc = load().pk_patch_frame_mask(ptr(src), src.stride(0), ptr(dst), dst.stride(0), ptr(fmask), B, C, F, H, W, f0, nt, pt, ph, pw, stream(src))
+    _check(rc, 'pk_patch_frame_mask')
+    return dst
 
 
 def unpatchify(pix, video, f0, nt, pt, ph, pw):

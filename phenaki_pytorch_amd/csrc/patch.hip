@@ -111,6 +111,23 @@ __global__ __launch_bounds__(256) void unpatchify_kernel(const float* __restrict
 }
 
 
+// dst[row][col] = fmask[b][f0 + tt*pt + dt] ? src[row][col] : 0 on a (rows, P) patch-layout matrix (row = (b, tt, hh, ww), col = (c, dt, y, x)):
+// the frame mask of variable-length training (cvivit.py:585-589) applied where the reconstruction loss is taken in patch layout
+__global__ __launch_bounds__(256) void patch_frame_mask_kernel(const float* __restrict__ src, long lds, float* __restrict__ dst, long ldd, PatchGeom g,
+                                                               const unsigned char* __restrict__ fmask, long total_vec) {
+    const int P = g.C * g.pt * g.ph * g.pw, nv = P >> 2, per_dt = g.ph * g.pw;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total_vec; idx += (long)gridDim.x * 256) {
+        const int c4 = (int)(idx % nv);
+        const long row = idx / nv;
+        const long bt = row / ((long)g.nh * g.nw);
+        const int tt = (int)(bt % g.nt), b = (int)(bt / g.nt);
+        const int dt = ((c4 * 4) / per_dt) % g.pt;
+        const bool keep = fmask[(long)b * g.F + g.f0 + tt * g.pt + dt] != 0;
+        const f32x4 v = keep ? *reinterpret_cast<const f32x4*>(src + row * lds + c4 * 4) : f32x4{0, 0, 0, 0};
+        *reinterpret_cast<f32x4*>(dst + row * ldd + c4 * 4) = v;
+    }
+}
+
 // sum over kept frames of (a - b)^2 for two (B, C, F, H, W) f32 videos (cvivit.py:585-591 F.mse_loss numerator): every
 // workgroup folds a grid-stride slice into ONE double partial (deterministic: fixed slice per workgroup, fixed tree), the
 // caller adds the <= 1024 partials.  fmask (B*F bytes, 1 = keep) or null.
@@ -166,6 +183,19 @@ extern "C" int pk_patchify_ln(const float* video, int B, int C, int F, int H, in
         if (small) hipLaunchKernelGGL((patchify_ln_kernel<bf16, 4>), dim3(rows), dim3(256), 0, s, video, g, weight, bias, eps, (bf16*)out, ldo);
         else hipLaunchKernelGGL((patchify_ln_kernel<bf16, 8>), dim3(rows), dim3(256), 0, s, video, g, weight, bias, eps, (bf16*)out, ldo);
     }
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+extern "C" int pk_patch_frame_mask(const float* src, long lds, float* dst, long ldd, const unsigned char* fmask, int B, int C, int F, int H, int W,
+                                   int f0, int nt, int pt, int ph, int pw, void* stream) {
+    PatchGeom g{B, C, F, H, W, f0, nt, pt, ph, pw, ph ? H / ph : 0, pw ? W / pw : 0};
+    if (int rc = check_geom(g)) return rc;
+    if (!src || !dst || !fmask || (lds & 3) || (ldd & 3) || ((ph * pw) & 3)) return PK_EINVAL;
+    const int P = C * pt * ph * pw;
+    const long total = (long)B * nt * g.nh * g.nw * (P >> 2);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(patch_frame_mask_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, lds, dst, ldd, g, fmask, total);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

@@ -18,8 +18,8 @@ forward and backward kernels, the PEG with causal frame padding); this file adds
     _PatchMSE       mean (to_pixels(tokens) - patches(video))^2 -- un-patchify is a     pk_patchify_ln (raw rows), pk_sqdiff_partials
                     bijection of the pixels, so the loss is taken in patch layout        / pk_scaled_diff
 
-Not built: the frame `mask` of variable-length training under autograd (its loss VALUE is served by CViViT.forward under no_grad), and the
-discriminator / VGG / adaptive-weight branch (cvivit.py:604-671: torchvision's pretrained VGG16 is not available offline).
+The frame `mask` of variable-length training (cvivit.py:585-589) zeroes the dropped frames on both sides of the difference (pk_patch_frame_mask).
+Not built: the discriminator / VGG / adaptive-weight branch (cvivit.py:604-671: torchvision's pretrained VGG16 is not available offline).
 """
 import torch
 
@@ -184,31 +184,34 @@ class _PatchMSE(torch.autograd.Function):
     so mean (video - recon)^2 = [sum_g sum (pix_g - patches_g(video))^2] / video.numel() -- the reconstruction is never laid out as a video."""
 
     @staticmethod
-    def forward(ctx, pix_first, pix_rest, video, geoms):
+    def forward(ctx, pix_first, pix_rest, video, geoms, fmask, count):
+        """fmask (B, F) uint8 or None: the frames the loss keeps (cvivit.py:585-589); count = the number of kept video elements (host float)"""
         dev = video.device
-        raws, total = [], None
+        pairs, total = [], None
         for pix, (f0, nt, pt, ph, pw) in zip((pix_first, pix_rest), geoms):
             if pix is None:
-                raws.append(None)
                 continue
             raw = _f32(tuple(pix.shape), dev)
             L.patchify_ln(video, f0, nt, pt, ph, pw, None, None, raw)
-            part = L.sqdiff_sum(pix.detach().view(1, 1, 1, *pix.shape), raw.view(1, 1, 1, *raw.shape))
+            a = pix.detach()
+            if fmask is not None:                                    # dropped frames: zero on both sides -> no loss, no gradient
+                a = L.patch_frame_mask(a, _f32(tuple(pix.shape), dev), fmask, video.shape, f0, nt, pt, ph, pw)
+                L.patch_frame_mask(raw, raw, fmask, video.shape, f0, nt, pt, ph, pw)
+            part = L.sqdiff_sum(a.view(1, 1, 1, *a.shape), raw.view(1, 1, 1, *raw.shape))
             total = part if total is None else total + part
-            raws.append(raw)
-        ctx.save_for_backward(pix_first, pix_rest, *[r for r in raws if r is not None])
-        ctx.numel, ctx.has_rest = video.numel(), pix_rest is not None
-        return (total / video.numel()).float()
+            pairs += [a, raw]
+        ctx.save_for_backward(*pairs)
+        ctx.count, ctx.has_rest = count, pix_rest is not None
+        return (total / count).float()
 
     @staticmethod
     def backward(ctx, grad_out):
-        pix_first, pix_rest = ctx.saved_tensors[:2]
-        raws = ctx.saved_tensors[2:]
+        pairs = ctx.saved_tensors
         g = grad_out.detach().float().reshape(1).contiguous()
         outs = []
-        for pix, raw in zip((pix_first, pix_rest) if ctx.has_rest else (pix_first,), raws):
-            outs.append(L.scaled_diff(pix.detach(), raw, 2.0 / ctx.numel, _f32(tuple(pix.shape), pix.device), scale_dev=g))
-        return outs[0], (outs[1] if ctx.has_rest else None), None, None
+        for a, raw in zip(pairs[0::2], pairs[1::2]):
+            outs.append(L.scaled_diff(a, raw, 2.0 / ctx.count, _f32(tuple(a.shape), a.device), scale_dev=g))
+        return outs[0], (outs[1] if ctx.has_rest else None), None, None, None, None
 
 
 def _patch_embed_train(seq, video, geom, dtype):
@@ -218,9 +221,6 @@ def _patch_embed_train(seq, video, geom, dtype):
 
 def cvivit_loss_train(cv, video, *, mask=None, return_recons=False):
     """CViViT.forward (cvivit.py:518-627, use_vgg_and_gan = False) with an autograd graph over the C-ViViT parameters"""
-    if mask is not None:
-        raise NotImplementedError('training with a frame mask (cvivit.py:585-589) is not built: the masked reconstruction loss is available as a '
-                                  'value under torch.no_grad()')
     if cv.use_vgg_and_gan:
         raise NotImplementedError('the discriminator / VGG / adaptive-weight losses (cvivit.py:604-671) are outside the MI355X build; '
                                   'construct CViViT(use_vgg_and_gan=False) to train on the reconstruction loss')
@@ -263,7 +263,12 @@ def cvivit_loss_train(cv, video, *, mask=None, return_recons=False):
     else:
         x_first, pix_rest = x, None
     pix_first = _Linear.apply(x_first, lin_first.weight, lin_first.bias, dt)
-    loss = _PatchMSE.apply(pix_first, pix_rest, video, (geom_first, geom_rest))
+    fmask, count = None, float(video.numel())
+    if mask is not None:                                                              # variable-length training: the loss over the kept frames
+        L.require_device(mask, 'mask')
+        fmask = mask.to(torch.uint8).contiguous()
+        count = float(mask.sum().item()) * c * H * W                                  # (one host read per step: the divisor of the mean)
+    loss = _PatchMSE.apply(pix_first, pix_rest, video, (geom_first, geom_rest), fmask, count)
     if not return_recons:
         return loss
     recon = torch.empty_like(video)

@@ -343,7 +343,7 @@ def cvivit_grad_check(get_grad, g_grads, rtol, min_checked):
     assert checked >= min_checked, checked
 
 
-@pytest.mark.parametrize('kind', ['video', 'image'])
+@pytest.mark.parametrize('kind', ['video', 'image', 'masked'])
 def test_cvivit_training_step_gradients_match_reference_autograd(golden_dir, kind):
     """torch autograd through the oracle's differentiable C-ViViT (straight-through LFQ) against the REAL reference's
     CViViT(use_vgg_and_gan=False).train()(video).backward() (oracle/make_golden.py cvivit_grads_golden): pins what tests/test_train_gpu.py
@@ -354,16 +354,16 @@ def test_cvivit_training_step_gradients_match_reference_autograd(golden_dir, kin
     cv = {k: (v.clone().requires_grad_() if v.is_floating_point() and not k.endswith('.beta') else v) for k, v in cv.items()}
     H = TINY['cvivit']['image_size']
     video = weights.synthetic_video(2, 5, H, H, seed=8)
-    x = video if kind == 'video' else video[:, :, 2]
+    x = video[:, :, 2] if kind == 'image' else video
     with torch.enable_grad():
-        loss = O.cvivit_recon_loss_train(cv, cvc, x)
+        loss = O.cvivit_recon_loss_train(cv, cvc, x, mask=g['mask'] if kind == 'masked' else None)
         loss.backward()
     assert abs(float(loss) - float(g[f'loss_{kind}'])) <= 1e-5 * float(g[f'loss_{kind}'])
     if kind == 'image':                                             # the reference runs its rest-frame modules on empty tensors: zero gradients
         grads = {k: v for k, v in g['grads_image'].items() if v['norm'] > 0}
     else:
-        grads = g['grads_video']
-    cvivit_grad_check(lambda k: cv[k].grad, grads, 1e-4, 100 if kind == 'video' else 90)
+        grads = g[f'grads_{kind}']
+    cvivit_grad_check(lambda k: cv[k].grad, grads, 1e-4, 90 if kind == 'image' else 100)
 
 
 @pytest.mark.parametrize('tag', ['tiny', 'base'])

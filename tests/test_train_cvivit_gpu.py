@@ -21,7 +21,7 @@ def _gpu():
         yield
 
 
-@pytest.mark.parametrize('kind', ['video', 'image'])
+@pytest.mark.parametrize('kind', ['video', 'image', 'masked'])
 @pytest.mark.parametrize('dtype,tol', [('fp32', 1e-3), ('bf16x3', 1e-3), ('bf16', None)])
 def test_cvivit_training_step_matches_reference_autograd(golden_dir, dtype, tol, kind):
     """loss = cvivit(video); loss.backward() on the MI355X kernels == the reference's CViViT(use_vgg_and_gan=False).train() step: the loss and
@@ -32,8 +32,8 @@ def test_cvivit_training_step_matches_reference_autograd(golden_dir, dtype, tol,
     cv.train()
     H = TINY['cvivit']['image_size']
     video = weights.synthetic_video(2, 5, H, H, seed=8).cuda()
-    x = video if kind == 'video' else video[:, :, 2]
-    loss = cv(x)
+    x = video[:, :, 2] if kind == 'image' else video
+    loss = cv(x, mask=g['mask'].cuda()) if kind == 'masked' else cv(x)     # masked: variable-length training, the loss over the kept frames
     assert loss.requires_grad and loss.ndim == 0
     loss.backward()
     ref_loss = float(g[f'loss_{kind}'])
@@ -46,7 +46,7 @@ def test_cvivit_training_step_matches_reference_autograd(golden_dir, dtype, tol,
                 assert named[k].grad is not None and torch.isfinite(named[k].grad).all(), k
         return
     assert abs(float(loss.detach()) - ref_loss) <= 1e-4 * ref_loss
-    cvivit_grad_check(lambda k: named[k].grad, grads, tol, 100 if kind == 'video' else 90)
+    cvivit_grad_check(lambda k: named[k].grad, grads, tol, 90 if kind == 'image' else 100)
     record_parity('cvivit_training_step_vs_reference_autograd', dict(dtype=dtype, kind=kind, loss=float(loss.detach()), ref_loss=ref_loss,
                                                                      parameters=len(grads)))
 
@@ -65,8 +65,8 @@ def test_cvivit_forward_routes_and_returns_recons(golden_dir):
     assert abs(float(value) - float(loss.detach())) <= 1e-5 * float(value)
     close(recon, recon_v, 1e-4, 'reconstruction of the training forward vs the inference forward')
     assert abs(float(((recon - video) ** 2).mean()) - float(loss.detach())) <= 1e-5 * float(value)
-    with pytest.raises(NotImplementedError):
-        cv(video, mask=torch.ones(2, 5, dtype=torch.bool, device='cuda'))
+    full = cv(video, mask=torch.ones(2, 5, dtype=torch.bool, device='cuda'))            # an all-true frame mask is the plain loss
+    assert abs(float(full.detach()) - float(loss.detach())) <= 1e-6 * float(value)
     ids = cv(video, return_only_codebook_ids=True)                       # the inference surface is untouched by grad mode
     assert ids.dtype == torch.int64 and not ids.requires_grad
     for p in cv.parameters():
