@@ -150,9 +150,11 @@ class GradientReducer:
         with reducer.no_sync(): loss.backward()      # gradient accumulation: no collectives for this backward
     """
 
-    def __init__(self, params, bucket_mb=64.0, average=True, group=None):
+    def __init__(self, params, bucket_mb=64.0, average=True, group=None, force=False):
+        """force: issue the collectives even in a one-rank group (diagnostics: the RCCL path on a single-GPU box)"""
         self.params = [p for p in params if p.requires_grad and p.numel()]
         self.average, self.group = average, group
+        self.force = bool(force)
         order = list(range(len(self.params)))[::-1]
         bucket_elems = max(1, int(bucket_mb * (1 << 20) / 4))
         self.buckets = [[order[j] for j in idxs] for idxs in bucket_plan([self.params[i].numel() for i in order], bucket_elems)]
@@ -166,13 +168,16 @@ class GradientReducer:
 
     def _make_hook(self, i):
         def hook(_param):
-            if not self._enabled or world()[1] == 1:
+            if not self._enabled or not self._active():
                 return
             b = self._bucket_of[i]
             self._ready[b] += 1
             if self._ready[b] == len(self.buckets[b]) and not self._launched[b]:
                 self._launch(b)
         return hook
+
+    def _active(self):
+        return world()[1] > 1 or (self.force and dist.is_available() and dist.is_initialized())
 
     def _launch(self, b):
         idxs = [i for i in self.buckets[b] if self.params[i].grad is not None]
@@ -187,7 +192,7 @@ class GradientReducer:
     def finish(self):
         """wait for the collectives in flight, reduce the incomplete buckets, write the (averaged) gradients back; returns #collectives"""
         rank, ws = world()
-        if ws > 1 and self._enabled:
+        if self._active() and self._enabled:
             for b in range(len(self.buckets)):                  # in bucket order on every rank
                 if not self._launched[b]:
                     self._launch(b)

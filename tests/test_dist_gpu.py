@@ -143,13 +143,34 @@ def _rccl_one_rank(rank, port, out_dir):
     before = [p.grad.clone() for p in params]
     assert P.all_reduce_gradients(params, bucket_mb=0.05, force=True) == 2             # two buckets, all_reduce through RCCL, averaged over 1 rank
     assert all(torch.equal(p.grad, b) for p, b in zip(params, before))
+    # the overlapped reducer on RCCL: async all_reduce issued from the autograd thread's hooks during a real backward, waited in finish()
+    for m in (mg,):
+        m.train()
+    torch.set_grad_enabled(True)
+    mparams = list(mg.parameters())
+    g = torch.Generator().manual_seed(40)
+    ids = torch.randint(0, TINY['maskgit']['num_tokens'], (2, 3, 4, 4), generator=g).cuda()
+    ctx = weights.synthetic_context(2, 6, TINY['maskgit']['dim_context'], seed=3).cuda()
+    draws = dict(rand_step=torch.tensor([1, 4]), perm_noise=weights.uniform_noise((2, 48), 750), gumbel_u=weights.uniform_noise((2, 48, TINY['maskgit']['num_tokens']), 760))
+    ph(video_codebook_ids=ids, text_embeds=ctx, _draws=draws, only_train_generator=True).backward()
+    plain = [p.grad.clone() if p.grad is not None else None for p in mparams]
+    for p in mparams:
+        p.grad = None
+    reducer = P.GradientReducer(mparams, bucket_mb=0.25, force=True)
+    ph(video_codebook_ids=ids, text_embeds=ctx, _draws=draws, only_train_generator=True).backward()
+    in_backward = reducer.collectives
+    n_coll = reducer.finish()
+    assert in_backward >= 1 and n_coll == len(reducer.buckets) >= 2
+    assert all((a is None and p.grad is None) or torch.allclose(a, p.grad, rtol=1e-4, atol=1e-7) for a, p in zip(plain, mparams)), \
+        'a one-rank average must return the gradients unchanged (embedding rows are float atomics: not bit-equal run to run)'
     torch.save(dict(ok=True, version=torch.cuda.nccl.version()), os.path.join(out_dir, 'rccl.pt'))
     dist.destroy_process_group()
 
 
 def test_rccl_executes_the_collectives_on_this_box(tmp_path):
     """a ONE-rank RCCL communicator (the most a single-GPU box allows) runs the two collectives of the package on device tensors -- the
-    sampler's all_gather_into_tensor and the training step's bucketed all_reduce -- so the RCCL code path itself is exercised here, not
+    sampler's all_gather_into_tensor, the training step's bucketed all_reduce and the overlapped GradientReducer (async all_reduce from the
+    autograd hooks of a real backward) -- so the RCCL code path itself is exercised here, not
     only gloo's; the multi-rank variants above cover ordering and per-rank streams"""
     mp.spawn(_rccl_one_rank, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
     r = torch.load(os.path.join(str(tmp_path), 'rccl.pt'), weights_only=False)
