@@ -122,3 +122,46 @@ def test_cvivit_training_loop_reduces_the_reconstruction_loss():
         opt.step()
         losses.append(float(loss.detach()))
     assert all(l == l for l in losses) and losses[-1] < 0.9 * losses[0], losses
+
+
+@pytest.mark.parametrize('geom', ['non_square', 'temporal_patch_3', 'single_video_long'])
+def test_cvivit_training_step_other_geometries_match_oracle_autograd(geom):
+    """the row maps of the step ('(b t)(h w)' <-> '(b h w) t', first-frame | rest) and the patch-layout loss away from the square 4 x 4 / 8 x 8
+    grids: h != w with different patch extents, temporal patch 3, one long video -- every gradient against autograd through the oracle"""
+    import phenaki_pytorch_amd as P
+    cfg = dict(dim=128, codebook_size=256, image_size=(32, 96), patch_size=(8, 16), temporal_patch_size=2, spatial_depth=1, temporal_depth=1,
+               dim_head=64, heads=2)
+    batch, frames = 2, 5
+    if geom == 'temporal_patch_3':
+        cfg.update(image_size=(32, 32), patch_size=(8, 8), temporal_patch_size=3)
+        frames = 7
+    elif geom == 'single_video_long':
+        cfg.update(image_size=(32, 32), patch_size=(16, 16))
+        batch, frames = 1, 23
+    cv = P.CViViT(use_vgg_and_gan=False, **cfg)
+    weights.fill_module(cv, salt=7)
+    sd = {k: v.detach().clone() for k, v in cv.state_dict().items()}
+    cvc = dict(image_size=tuple(cfg['image_size']), patch_size=tuple(cfg['patch_size']), temporal_patch_size=cfg['temporal_patch_size'],
+               spatial_depth=1, temporal_depth=1, heads=2, channels=3)
+    H, W = cfg['image_size']
+    video = weights.synthetic_video(batch, frames, H, W, seed=11)
+    leaf = {k: (v.clone().requires_grad_() if v.is_floating_point() and not k.endswith('.beta') else v) for k, v in sd.items()}
+    ref = O.cvivit_recon_loss_train(leaf, cvc, video)
+    ref.backward()
+    cv = cv.cuda().train()
+    P.set_compute_dtype(cv, 'fp32')
+    loss = cv(video.cuda())
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-4 * float(ref.detach())
+    top = max(float(v.grad.abs().max()) for v in leaf.values() if getattr(v, 'grad', None) is not None and v.numel())
+    checked = 0
+    for name, prm in cv.named_parameters():
+        r = leaf[name]
+        if r.grad is None or r.numel() == 0:
+            continue
+        assert prm.grad is not None, name
+        if float(r.grad.abs().max()) < 1e-6 * top:
+            continue
+        close(prm.grad.cpu(), r.grad, 1e-3, f'd {name} ({geom})')
+        checked += 1
+    assert checked >= 50
