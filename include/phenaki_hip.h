@@ -332,6 +332,9 @@ int pk_gemm_splitk(int dtype, const void* A, int lda, const void* W, int ldw, in
 /* AdamW / Adam update of one parameter tensor (reference optimizer.py:11-37 hands MaskGit's parameters to torch.optim.AdamW / Adam):
  * m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2; p = p (1 - lr wd) - lr / (1 - b1^step) * m / (sqrt(v / (1 - b2^step)) + eps); step = 1, 2, ... */
 int pk_adamw(float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2, float eps, float wd, int step, long long n, void* stream);
+/* the same update for `count` tensors sharing hyper-parameters and step in a handful of launches: table = HOST array of count x 5 64-bit
+ * words {p, g, m, v, numel} (device pointers of contiguous f32 tensors).  Bit-identical to per-tensor pk_adamw calls. */
+int pk_adamw_multi(const long long* table, int count, float lr, float beta1, float beta2, float eps, float wd, int step, void* stream);
 /* attention backward (attention.py:132-182).  pk_attn_train_prep: the f32 operands q^ = l2norm(q) q_scale scale -> Qh (S heads, n, 64),
  * k^ = l2norm([null_k ; k]) k_scale -> Kh, [null_v ; v] -> Vh (S heads, nnull + n_kv, 64) from the projection outputs q (S n, ldq), kv (S n_kv, ldkv).
  * pk_attn_bwd: dQh / dKh / dVh from those, the forward output O (f32 or bf16) and dO; bias (heads, n, n_kv) / kmask (S, n_kv) cover the real keys;

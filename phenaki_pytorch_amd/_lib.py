@@ -81,6 +81,7 @@ SIGNATURES = {
     'pk_attn_train_prep_bwd': [_P, _LL, _P, _LL, _P, _P, _P, _F, _P, _P, _P, _P, _LL, _P, _LL, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'pk_gemm_splitk': [_I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P],
     'pk_adamw': [_P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _LL, _P],
+    'pk_adamw_multi': [_P, _I, _F, _F, _F, _F, _F, _I, _P],
     'pk_attn_bwd': [_P, _P, _P, _P, _LL, _I, _P, _LL, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
 }
 
@@ -584,6 +585,17 @@ def attn_bwd(Qh, Kh, Vh, O, dO, dQh, dKh, dVh, S, h, n, n_kv, nnull, *, bias=Non
 def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step):
     rc = load().pk_adamw(ptr(p), ptr(g), ptr(m), ptr(v), float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step), p.numel(), stream(p))
     _check(rc, 'pk_adamw')
+
+
+def adamw_multi(entries, lr, beta1, beta2, eps, wd, step, device):
+    """entries: list of (p, g, m, v) contiguous f32 device tensors updated with one hyper-parameter set and step number"""
+    import numpy as np
+    table = np.empty((len(entries), 5), dtype=np.int64)
+    for i, (p, g, m, v) in enumerate(entries):
+        table[i] = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel())
+    rc = load().pk_adamw_multi(table.ctypes.data, len(entries), float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step),
+                               torch.cuda.current_stream(device).cuda_stream)
+    _check(rc, 'pk_adamw_multi')
 
 
 def gemm_splitk(dtype, A, W, M, N, K, splits, C):

@@ -410,6 +410,37 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// many small tensors in ONE launch: the table travels by value in the kernel arguments (no device-side pointer table to upload); block b
+// updates chunk bc[b] (ADAM_CHUNK elements) of tensor bt[b]
+constexpr int ADAM_T = 40, ADAM_B = 512, ADAM_CHUNK = 2048;
+struct AdamMulti {
+    float* p[ADAM_T]; const float* g[ADAM_T]; float* m[ADAM_T]; float* v[ADAM_T];
+    int n[ADAM_T];
+    unsigned short bc[ADAM_B];
+    unsigned char bt[ADAM_B];
+};
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamMulti a, float lr, float b1, float b2, float eps, float wd, float bc1, float rsqrt_bc2) {
+    const int t = a.bt[blockIdx.x];
+    const long base = (long)a.bc[blockIdx.x] * ADAM_CHUNK;
+    float* __restrict__ p = a.p[t];
+    const float* __restrict__ g = a.g[t];
+    float* __restrict__ m = a.m[t];
+    float* __restrict__ v = a.v[t];
+    const long n = a.n[t];
+#pragma unroll
+    for (int u = 0; u < ADAM_CHUNK / 256; ++u) {
+        const long i = base + u * 256 + threadIdx.x;
+        if (i >= n) break;
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
+        p[i] = p[i] * (1.0f - lr * wd) - (lr / bc1) * (mi / denom);
+    }
+}
+
 }  // namespace pk
 
 using namespace pk;
@@ -577,6 +608,45 @@ extern "C" int pk_bce_head(const float* e, long lde, const float* w, const float
     if ((D & 3) || (lde & 3) || (ldde & 3) || !al16(e) || !al16(w) || (de && !al16(de)) || (pw && !al16(pw))) return PK_EALIGN;
     const int P = pk_ln_bwd_parts(M), rpb = (M + P - 1) / P;
     hipLaunchKernelGGL(bce_head_kernel, dim3(P), dim3(256), 0, STREAM(stream), e, lde, w, b, labels, scale, scale_dev, logits, loss_rows, de, ldde, pw, pb, M, D, rpb);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+// the same update for `count` tensors of one hyper-parameter set and step: table[i] = {p, g, m, v, n} (HOST array of 5 x 64-bit words per tensor).
+// Tensors of >= 256 Ki elements get their own launch (bandwidth-bound anyway); the small ones -- a transformer has hundreds: LayerNorm
+// gains, biases, scales, position-MLP layers -- are packed ADAM_T tensors / ADAM_B blocks per launch (256 per-tensor launches -> ~10).
+extern "C" int pk_adamw_multi(const long long* table, int count, float lr, float beta1, float beta2, float eps, float wd, int step, void* stream) {
+    if (!table || count <= 0 || step <= 0) return PK_EINVAL;
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step), rs = 1.0f / sqrtf(bc2);
+    hipStream_t s = STREAM(stream);
+    AdamMulti a;
+    int nt = 0, nb = 0;
+    auto flush = [&]() {
+        if (nb > 0) hipLaunchKernelGGL(adamw_multi_kernel, dim3(nb), dim3(256), 0, s, a, lr, beta1, beta2, eps, wd, bc1, rs);
+        nt = 0; nb = 0;
+    };
+    for (int i = 0; i < count; ++i) {
+        const long long* e = table + 5 * (long)i;
+        float* p = reinterpret_cast<float*>(e[0]);
+        const float* g = reinterpret_cast<const float*>(e[1]);
+        float* m = reinterpret_cast<float*>(e[2]);
+        float* v = reinterpret_cast<float*>(e[3]);
+        const long n = e[4];
+        if (!p || !g || !m || !v || n <= 0) return PK_EINVAL;
+        if (n >= 262144) {
+            hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(n)), dim3(256), 0, s, p, g, m, v, lr, beta1, beta2, eps, wd, bc1, rs, n);
+            continue;
+        }
+        const int chunks = (int)((n + ADAM_CHUNK - 1) / ADAM_CHUNK);
+        int c = 0;
+        while (c < chunks) {
+            if (nt == ADAM_T || nb == ADAM_B) flush();
+            a.p[nt] = p; a.g[nt] = g; a.m[nt] = m; a.v[nt] = v; a.n[nt] = (int)n;
+            while (c < chunks && nb < ADAM_B) { a.bt[nb] = (unsigned char)nt; a.bc[nb] = (unsigned short)c; ++nb; ++c; }
+            ++nt;
+        }
+    }
+    flush();
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

@@ -1,6 +1,6 @@
 """Optimizer of the training step on the MI355X kernels -- reference /root/reference/phenaki_pytorch/optimizer.py:1-37 (`get_optimizer`:
 Adam when wd == 0, else AdamW with the parameters of fewer than 2 dimensions excluded from the decay), called by phenaki_trainer.py:284.
-`HipAdamW` is a torch.optim.Optimizer (state_dict / param_groups / zero_grad as usual) whose update is pk_adamw, one launch per tensor."""
+`HipAdamW` is a torch.optim.Optimizer (state_dict / param_groups / zero_grad as usual) whose update is pk_adamw_multi: the large tensors one launch each, the hundreds of small ones packed 40 per launch."""
 import torch
 
 from . import _lib as L
@@ -27,6 +27,7 @@ class HipAdamW(torch.optim.Optimizer):
                 loss = closure()
         for group in self.param_groups:
             b1, b2 = group['betas']
+            batches = {}                                        # step number -> [(p, g, m, v)]: one pk_adamw_multi call per (group, step)
             for p in group['params']:
                 if p.grad is None or p.numel() == 0:            # (the self-attention blocks carry an empty null_kv)
                     continue
@@ -40,9 +41,13 @@ class HipAdamW(torch.optim.Optimizer):
                     st['exp_avg_sq'] = torch.zeros_like(p)
                 st['step'] += 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                L.adamw(p, g.float() if g.dtype != torch.float32 else g, st['exp_avg'], st['exp_avg_sq'], group['lr'], b1, b2, group['eps'],
-                        group['weight_decay'], st['step'])
-                torch.autograd.graph.increment_version(p)      # the kernel wrote through the raw pointer: packed-weight caches / captured graphs key on _version
+                g = g.float() if g.dtype != torch.float32 else g
+                batches.setdefault((st['step'], p.device), []).append((p, g, st['exp_avg'], st['exp_avg_sq']))
+            for (step, device), entries in batches.items():
+                # the small tensors of the batch (LayerNorm gains, biases, scales: most of a transformer's parameter LIST) share launches
+                L.adamw_multi(entries, group['lr'], b1, b2, group['eps'], group['weight_decay'], step, device)
+                for p, _, _, _ in entries:
+                    torch.autograd.graph.increment_version(p)  # the kernel wrote through the raw pointer: packed-weight caches / captured graphs key on _version
         return loss
 
 

@@ -309,7 +309,9 @@ def test_hip_adamw_matches_torch_adamw_and_bumps_versions():
     """optim.py (reference optimizer.py:11-37): get_optimizer's grouping and the pk_adamw update against torch.optim.AdamW / Adam on CPU"""
     import phenaki_pytorch_amd as P
     g = torch.Generator().manual_seed(8)
-    shapes = [(33, 17), (129,), (4, 3, 3), (100, 90), (5000,), (7, 3)]      # >= 4 tensors per group: the one-launch pointer-table path; 3 chunks for (100, 90)
+    # pk_adamw_multi packs 40 tensors / 512 chunks of 2048 elements per launch and gives tensors of >= 256 Ki elements their own launch:
+    # 45 small vectors (two launches), six 98-chunk tensors (a tensor split across launches), one large matrix, odd sizes
+    shapes = [(33, 17), (129,), (4, 3, 3), (100, 90), (5000,), (7, 3), (1,)] + [(64,)] * 45 + [(200000,)] * 6 + [(600, 500)]
     for wd in (1e-2, 0.0):
         ref_p = [torch.randn(*s, generator=g).requires_grad_() for s in shapes]
         hip_p = [p.detach().clone().cuda().requires_grad_() for p in ref_p]
