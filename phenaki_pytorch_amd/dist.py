@@ -171,6 +171,9 @@ class GradientReducer:
             if not self._enabled or not self._active():
                 return
             b = self._bucket_of[i]
+            if self._launched[b]:
+                raise RuntimeError('GradientReducer: a second backward reached a bucket that is already being reduced -- call finish() after every '
+                                   'backward (or run the accumulation backwards under no_sync())')
             self._ready[b] += 1
             if self._ready[b] == len(self.buckets[b]) and not self._launched[b]:
                 self._launch(b)
