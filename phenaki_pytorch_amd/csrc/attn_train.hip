@@ -12,6 +12,7 @@
 // of the global layout read a tile that was transposed on its way into LDS (K^T in kernel Q, q^T / dO^T in kernel KV); the next tile is
 // fetched into registers while the current one is multiplied.  Every result is owned by exactly one workgroup (no atomics): the gradients
 // are bit-reproducible.
+#include <cstdlib>
 #include "common.hpp"
 
 namespace pk {
@@ -165,7 +166,30 @@ struct AttnBwdArgs {
     float* dS;                                               // [S*h][n][nkt - nnull] or null (real-key columns only)
     float* lse; float* Drow;                                 // [S*h][n] scratch written by kernel Q, read by kernel KV
     int S, heads, n, nkt, nnull;
+    // PACKED short sequences (pack_n > 0; self-attention without null keys, pack_n <= 32): one workgroup tile holds pack_g = 64 / pack_n whole
+    // (sequence, head) groups -- the fields above then describe VIRTUAL heads (S = number of tiles, heads = 1, n = nkt = pack_g * pack_n rows of the
+    // flat [S*h][n][64] arrays) and scores exist only inside a group (block-diagonal); act_heads / act_groups = the real heads / S * heads.
+    int pack_n, pack_g, act_heads; long act_groups;
 };
+
+// element offset of row vr (of this workgroup's virtual head sh) in the heads-merged O / dO matrices, or -1 beyond the data
+__device__ __forceinline__ long merged_row_offset(const AttnBwdArgs& p, int sh, int vr, long ld) {
+    if (p.pack_n == 0) {
+        if (vr >= p.n) return -1;
+        const int h = sh % p.heads, s = sh / p.heads;
+        return ((long)s * p.n + vr) * ld + h * 64;
+    }
+    const int g = vr / p.pack_n;
+    const long group = (long)sh * p.pack_g + g;
+    if (g >= p.pack_g || group >= p.act_groups) return -1;
+    return ((group / p.act_heads) * p.pack_n + (vr - g * p.pack_n)) * ld + (group % p.act_heads) * 64;
+}
+// rows of the flat per-head arrays this workgroup may touch
+__device__ __forceinline__ int live_rows(const AttnBwdArgs& p, int sh) {
+    if (p.pack_n == 0) return p.n;
+    const long left = p.act_groups * p.pack_n - (long)sh * p.n;
+    return left < p.n ? (int)left : p.n;
+}
 
 // this wave's 16 rows [row0, row0 + 16) x 64 columns of a (rows_total, ld) matrix as two fragment chunks (zero rows beyond rows_total)
 __device__ __forceinline__ void load_rows_frag(Frag<float> (&f)[2], const float* src, long ld, int row0, int rows_total, int lane) {
@@ -174,6 +198,25 @@ __device__ __forceinline__ void load_rows_frag(Frag<float> (&f)[2], const float*
     for (int c = 0; c < 2; ++c) {
         if (row0 + r < rows_total) frag_load(f[c], src + (long)(row0 + r) * ld + c * 32 + kq * 8);
         else frag_zero(f[c]);
+    }
+}
+// the same from the heads-merged O / dO matrices (row addresses through merged_row_offset)
+__device__ __forceinline__ void load_rows_frag_merged(Frag<float> (&f)[2], const float* src, long ld, const AttnBwdArgs& p, int sh, int row0, int lane) {
+    const int r = lane & 15, kq = lane >> 4;
+    const long off = merged_row_offset(p, sh, row0 + r, ld);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        if (off >= 0) frag_load(f[c], src + off + c * 32 + kq * 8);
+        else frag_zero(f[c]);
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ void fetch_tile_merged(f32x4 (&v)[ROWS / 16], const float* src, long ld, const AttnBwdArgs& p, int sh, int r0) {
+    const int rr = threadIdx.x >> 4, c = (threadIdx.x & 15) * 4;
+#pragma unroll
+    for (int u = 0; u < ROWS / 16; ++u) {
+        const long off = merged_row_offset(p, sh, r0 + rr + 16 * u, ld);
+        v[u] = off >= 0 ? *reinterpret_cast<const f32x4*>(src + off + c) : f32x4{0, 0, 0, 0};
     }
 }
 // a thread's share of a [ROWS x 64] tile of a (rows_total, ld) matrix: ROWS / 16 pieces of 4 floats (piece u: row (tid >> 4) + 16 u, columns (tid & 15) * 4 ..)
@@ -204,6 +247,23 @@ __device__ __forceinline__ void stash_tile(const f32x4 (&v)[ROWS / 16], float* n
 // score of (query row gi, key j) from the raw product, or "excluded"
 __device__ __forceinline__ bool score(const AttnBwdArgs& p, int s, int h, int gi, int j, float raw, float& out) {
     if (j >= p.nkt || gi >= p.n) return false;
+    if (p.pack_n) {                                            // s = the virtual head (tile) index: (gi, j) interact only inside one real group
+        const int g = gi / p.pack_n;
+        if (j / p.pack_n != g) return false;
+        const long group = (long)s * p.pack_g + g;
+        if (g >= p.pack_g || group >= p.act_groups) return false;
+        const int li = gi - g * p.pack_n, lj = j - g * p.pack_n, hh = (int)(group % p.act_heads);
+        const long ss = group / p.act_heads;
+        float v = raw;
+        if (p.bias) v += p.bias[((long)hh * p.pack_n + li) * p.pack_n + lj];
+        if (p.kmask && !p.kmask[ss * p.pack_n + lj]) v = NEG_MAX;
+        if (p.causal) {
+            const int d = lj - li;
+            v = d > 0 ? NEG_MAX : v + (float)d * p.slopes[hh];
+        }
+        out = v;
+        return true;
+    }
     const int jr = j - p.nnull;                                // real-key column
     float v = raw;
     if (p.bias && jr >= 0) v += p.bias[((long)h * p.n + gi) * (p.nkt - p.nnull) + jr];
@@ -230,36 +290,37 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
     const int qt = blockIdx.x % nqt, sh = blockIdx.x / nqt, h = sh % p.heads, s = sh / p.heads;
     const int i0 = qt * 64, m0 = wv * 16;
     const int nreal = p.nkt - p.nnull;
+    const int nlive = live_rows(p, sh);
     Frag<float> fq[2], fdo[2];
-    load_rows_frag(fq, p.Qh + (long)sh * p.n * 64, 64, i0 + m0, p.n, lane);
-    load_rows_frag(fdo, p.dO + (long)s * p.n * p.lddo + h * 64, p.lddo, i0 + m0, p.n, lane);
+    load_rows_frag(fq, p.Qh + (long)sh * p.n * 64, 64, i0 + m0, nlive, lane);
+    load_rows_frag_merged(fdo, p.dO, p.lddo, p, sh, i0 + m0, lane);
     // D = rowsum(dO * O) for this wave's 16 rows
     float Dl[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) {
         const int gi = i0 + m0 + rr;
         float v = 0.f;
-        if (gi < p.n) {
-            const long orow = ((long)s * p.n + gi);
-            const float o = p.o_bf16 ? bf2f(reinterpret_cast<const u16*>(p.O)[orow * p.ldo_ + h * 64 + lane])
-                                     : reinterpret_cast<const float*>(p.O)[orow * p.ldo_ + h * 64 + lane];
-            v = o * p.dO[orow * p.lddo + h * 64 + lane];
+        const long oo = merged_row_offset(p, sh, gi, p.ldo_), od = merged_row_offset(p, sh, gi, p.lddo);
+        if (oo >= 0) {
+            const float o = p.o_bf16 ? bf2f(reinterpret_cast<const u16*>(p.O)[oo + lane]) : reinterpret_cast<const float*>(p.O)[oo + lane];
+            v = o * p.dO[od + lane];
         }
         v = wave_sum(v);
         if ((rr >> 2) == kq) Dl[rr & 3] = v;
-        if (lane == 0 && gi < p.n) p.Drow[(long)sh * p.n + gi] = v;
+        if (lane == 0 && gi < nlive) p.Drow[(long)sh * p.n + gi] = v;
     }
     const int ntl = (p.nkt + 63) / 64;
     const float* Kbase = p.Kh + (long)sh * p.nkt * 64;
     const float* Vbase = p.Vh + (long)sh * p.nkt * 64;
     // ---- pass 1: log-sum-exp of every row (online, per lane over its 4 rows x 16 columns per tile; lanes of a row merged at the end)
     float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, l[4] = {0.f, 0.f, 0.f, 0.f};
+    const int klive = p.pack_n ? nlive : p.nkt;
     f32x4 kreg[4], vreg[4];
-    fetch_tile<64>(kreg, Kbase, 64, 0, p.nkt);
+    fetch_tile<64>(kreg, Kbase, 64, 0, klive);
     for (int kt = 0; kt < ntl; ++kt) {
         __syncthreads();                                          // the previous tile's readers are done
         stash_tile<64>(kreg, Ks, TLD, nullptr, 0);
-        if (kt + 1 < ntl) fetch_tile<64>(kreg, Kbase, 64, (kt + 1) * 64, p.nkt);
+        if (kt + 1 < ntl) fetch_tile<64>(kreg, Kbase, 64, (kt + 1) * 64, klive);
         __syncthreads();
         f32x4 acc[4] = PK_ZERO4;
         mma_regA<4, 2>(fq, Ks, TLD, acc, lane);
@@ -287,19 +348,19 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
         }
         lse[i] = mx[i] + __logf(l[i]);
         const int gi = i0 + m0 + kq * 4 + i;
-        if (r == 0 && gi < p.n) p.lse[(long)sh * p.n + gi] = lse[i];
+        if (r == 0 && gi < nlive) p.lse[(long)sh * p.n + gi] = lse[i];
     }
     // ---- pass 2: dS and dQ^
     f32x4 accQ[4] = PK_ZERO4;
-    fetch_tile<64>(kreg, Kbase, 64, 0, p.nkt);
-    fetch_tile<64>(vreg, Vbase, 64, 0, p.nkt);
+    fetch_tile<64>(kreg, Kbase, 64, 0, klive);
+    fetch_tile<64>(vreg, Vbase, 64, 0, klive);
     for (int kt = 0; kt < ntl; ++kt) {
         __syncthreads();
         stash_tile<64>(kreg, Ks, TLD, Kt, TLD);
         stash_tile<64>(vreg, Vs, TLD, nullptr, 0);
         if (kt + 1 < ntl) {
-            fetch_tile<64>(kreg, Kbase, 64, (kt + 1) * 64, p.nkt);
-            fetch_tile<64>(vreg, Vbase, 64, (kt + 1) * 64, p.nkt);
+            fetch_tile<64>(kreg, Kbase, 64, (kt + 1) * 64, klive);
+            fetch_tile<64>(vreg, Vbase, 64, (kt + 1) * 64, klive);
         }
         __syncthreads();
         f32x4 accS[4] = PK_ZERO4;
@@ -324,7 +385,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int gi = i0 + m0 + kq * 4 + i;
-            if (gi < p.n) p.dQh[((long)sh * p.n + gi) * 64 + nb * 16 + r] = accQ[nb][i];
+            if (gi < nlive) p.dQh[((long)sh * p.n + gi) * 64 + nb * 16 + r] = accQ[nb][i];
         }
 }
 
@@ -340,17 +401,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnBwdArgs p) {
     const int ntl = (p.nkt + 63) / 64;
     const int kt = blockIdx.x % ntl, sh = blockIdx.x / ntl, h = sh % p.heads, s = sh / p.heads;
     const int j0 = kt * 64, m0 = wv * 16;
+    const int nlive = live_rows(p, sh), klive = p.pack_n ? nlive : p.nkt;
     Frag<float> fk[2], fv[2];
-    load_rows_frag(fk, p.Kh + (long)sh * p.nkt * 64, 64, j0 + m0, p.nkt, lane);
-    load_rows_frag(fv, p.Vh + (long)sh * p.nkt * 64, 64, j0 + m0, p.nkt, lane);
+    load_rows_frag(fk, p.Kh + (long)sh * p.nkt * 64, 64, j0 + m0, klive, lane);
+    load_rows_frag(fv, p.Vh + (long)sh * p.nkt * 64, 64, j0 + m0, klive, lane);
     f32x4 accK[4] = PK_ZERO4;
     f32x4 accV[4] = PK_ZERO4;
     const int nqt = (p.n + QT - 1) / QT;
     const float* Qbase = p.Qh + (long)sh * p.n * 64;
-    const float* dObase = p.dO + (long)s * p.n * p.lddo + h * 64;
     f32x4 qreg[2], dreg[2];
-    fetch_tile<QT>(qreg, Qbase, 64, 0, p.n);
-    fetch_tile<QT>(dreg, dObase, p.lddo, 0, p.n);
+    fetch_tile<QT>(qreg, Qbase, 64, 0, nlive);
+    fetch_tile_merged<QT>(dreg, p.dO, p.lddo, p, sh, 0);
     for (int qt = 0; qt < nqt; ++qt) {
         const int i0 = qt * QT;
         __syncthreads();                                          // the previous tile's readers are done
@@ -358,12 +419,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnBwdArgs p) {
         stash_tile<QT>(dreg, dOs, TLD, dOt, TLQ);
         if (threadIdx.x < QT) {
             const int gi = i0 + threadIdx.x;
-            lse_s[threadIdx.x] = gi < p.n ? p.lse[(long)sh * p.n + gi] : 0.f;
-            D_s[threadIdx.x] = gi < p.n ? p.Drow[(long)sh * p.n + gi] : 0.f;
+            lse_s[threadIdx.x] = gi < nlive ? p.lse[(long)sh * p.n + gi] : 0.f;
+            D_s[threadIdx.x] = gi < nlive ? p.Drow[(long)sh * p.n + gi] : 0.f;
         }
         if (qt + 1 < nqt) {
-            fetch_tile<QT>(qreg, Qbase, 64, i0 + QT, p.n);
-            fetch_tile<QT>(dreg, dObase, p.lddo, i0 + QT, p.n);
+            fetch_tile<QT>(qreg, Qbase, 64, i0 + QT, nlive);
+            fetch_tile_merged<QT>(dreg, p.dO, p.lddo, p, sh, i0 + QT);
         }
         __syncthreads();
         f32x4 accS[2] = PK_ZERO2;
@@ -398,7 +459,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnBwdArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int gj = j0 + m0 + kq * 4 + i;
-            if (gj < p.nkt) {
+            if (gj < klive) {
                 p.dKh[((long)sh * p.nkt + gj) * 64 + nb * 16 + r] = accK[nb][i];
                 p.dVh[((long)sh * p.nkt + gj) * 64 + nb * 16 + r] = accV[nb][i];
             }
@@ -450,7 +511,17 @@ extern "C" int pk_attn_bwd(const float* Qh, const float* Kh, const float* Vh, co
     if (!Qh || !Kh || !Vh || !O || !dO || !dQh || !dKh || !dVh || !lse || !Drow || S <= 0 || heads <= 0 || n <= 0 || n_kv <= 0 || nnull < 0) return PK_EINVAL;
     if (!al16(Qh) || !al16(Kh) || !al16(Vh) || !al16(dO) || (lddo & 3)) return PK_EALIGN;
     if (causal && (!slopes || n != n_kv)) return PK_EINVAL;
-    AttnBwdArgs p{Qh, Kh, Vh, O, ldo, o_bf16, dO, lddo, bias, kmask, slopes, causal, dQh, dKh, dVh, dS, lse, Drow, S, heads, n, nnull + n_kv, nnull};
+    AttnBwdArgs p{Qh, Kh, Vh, O, ldo, o_bf16, dO, lddo, bias, kmask, slopes, causal, dQh, dKh, dVh, dS, lse, Drow, S, heads, n, nnull + n_kv, nnull, 0, 0, heads, (long)S * heads};
+    static const bool pack_on = !(getenv("PK_ATTN_BWD_PACK") && getenv("PK_ATTN_BWD_PACK")[0] == '0');      // A/B switch
+    if (pack_on && nnull == 0 && n == n_kv && n <= 32 && !dS) {
+        // short self-attention (the C-ViViT temporal transformers: n = 9 at 512 sequences x 8 heads): 64 / n whole (sequence, head) groups per tile
+        // instead of one -- the flat [S*h][n][64] arrays are the same memory either way
+        p.pack_n = n;
+        p.pack_g = 64 / n;
+        p.n = p.nkt = p.pack_g * n;
+        p.heads = 1;
+        p.S = (int)((p.act_groups + p.pack_g - 1) / p.pack_g);
+    }
     hipStream_t s = STREAM(stream);
     static bool attr_done = false;
     if (!attr_done) {
@@ -458,9 +529,9 @@ extern "C" int pk_attn_bwd(const float* Qh, const float* Kh, const float* Vh, co
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, KV_SMEM) != hipSuccess) return PK_ELAUNCH;
         attr_done = true;
     }
-    const int nqt = (n + 63) / 64, nktt = (p.nkt + 63) / 64;
-    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3((unsigned)((long)S * heads * nqt)), dim3(256), 4 * TSZ * 4, s, p);
-    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3((unsigned)((long)S * heads * nktt)), dim3(256), KV_SMEM, s, p);
+    const int nqt = (p.n + 63) / 64, nktt = (p.nkt + 63) / 64;
+    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3((unsigned)((long)p.S * p.heads * nqt)), dim3(256), 4 * TSZ * 4, s, p);
+    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3((unsigned)((long)p.S * p.heads * nktt)), dim3(256), KV_SMEM, s, p);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

@@ -114,10 +114,12 @@ def test_feedforward_block_gradients(dtype, tol):
 
 
 @pytest.mark.parametrize('dtype,tol', MODES)
-@pytest.mark.parametrize('case', ['self_bias', 'cross_null_mask', 'self_mask', 'causal_short', 'causal_long'])
+@pytest.mark.parametrize('case', ['self_bias', 'cross_null_mask', 'self_mask', 'causal_short', 'causal_long', 'causal_packed', 'packed_mask'])
 def test_attention_block_gradients(case, dtype, tol):
     """x + Attention(x) (attention.py:89-182): position bias gradient, null keys, key mask, l2norm / learned scales; n = 70 (ragged tiles);
-    causal_*: ALiBi over the null + real keys and the causal mask (the C-ViViT temporal transformers: n = 9, and n = 70 across key tiles)"""
+    causal_*: ALiBi over the null + real keys and the causal mask (the C-ViViT temporal transformers: n = 9, and n = 70 across key tiles);
+    *packed*: no null keys and n <= 32 -- pk_attn_bwd packs 64 / n whole (sequence, head) groups into one tile (80 groups of 9 rows = 11 full
+    tiles + a partial one; 22 groups of 12 rows with a key mask)"""
     import phenaki_pytorch_amd as P
     from phenaki_pytorch_amd.train import attention_train
     from phenaki_pytorch_amd.attention import resolve_dtype
@@ -125,9 +127,13 @@ def test_attention_block_gradients(case, dtype, tol):
     D, heads, S, n = 128, 2, 3, 70
     cross = case == 'cross_null_mask'
     causal = case.startswith('causal')
-    if case == 'causal_short':
+    packed = 'packed' in case
+    if case in ('causal_short', 'causal_packed'):
         S, n = 40, 9
-    attn = P.attention.Attention(dim=D, dim_context=96 if cross else None, heads=heads, num_null_kv=2 if (cross or causal) else 0, causal=causal)
+    elif case == 'packed_mask':
+        S, n = 11, 12
+    nnull = 2 if (cross or (causal and not packed)) else 0
+    attn = P.attention.Attention(dim=D, dim_context=96 if cross else None, heads=heads, num_null_kv=nnull, causal=causal)
     with torch.no_grad():
         attn.q_scale.uniform_(0.5, 1.5)
         attn.k_scale.uniform_(0.5, 1.5)
@@ -160,7 +166,7 @@ def test_attention_block_gradients(case, dtype, tol):
                             attn_bias=bc, kmask=mask.to(torch.uint8).cuda() if mask is not None else None)
     y.backward(G.reshape(S * n, D).cuda())
     errs = dict(dx=close(xc.grad.cpu(), xl.grad.reshape(S * n, D), tol, 'attn dx'))
-    for name in ('to_q.weight', 'to_kv.weight', 'to_out.weight', 'q_scale', 'k_scale', 'norm.gamma') + (('null_kv',) if (cross or causal) else ()) + \
+    for name in ('to_q.weight', 'to_kv.weight', 'to_out.weight', 'q_scale', 'k_scale', 'norm.gamma') + (('null_kv',) if nnull else ()) + \
             (('context_norm.gamma',) if cross else ()):
         mod = attn
         for part in name.split('.'):
