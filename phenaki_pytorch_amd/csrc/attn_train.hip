@@ -169,7 +169,7 @@ struct AttnBwdArgs {
     // PACKED short sequences (pack_n > 0; self-attention without null keys, pack_n <= 32): one workgroup tile holds pack_g = 64 / pack_n whole
     // (sequence, head) groups -- the fields above then describe VIRTUAL heads (S = number of tiles, heads = 1, n = nkt = pack_g * pack_n rows of the
     // flat [S*h][n][64] arrays) and scores exist only inside a group (block-diagonal); act_heads / act_groups = the real heads / S * heads.
-    int pack_n, pack_g, act_heads; long act_groups;
+    int pack_n, pack_g, act_heads, act_groups, pack_inv;     // pack_inv = 65536 / pack_n + 1: row / pack_n = (row * pack_inv) >> 16 for row < 64
 };
 
 // element offset of row vr (of this workgroup's virtual head sh) in the heads-merged O / dO matrices, or -1 beyond the data
@@ -179,15 +179,15 @@ __device__ __forceinline__ long merged_row_offset(const AttnBwdArgs& p, int sh, 
         const int h = sh % p.heads, s = sh / p.heads;
         return ((long)s * p.n + vr) * ld + h * 64;
     }
-    const int g = vr / p.pack_n;
-    const long group = (long)sh * p.pack_g + g;
+    const int g = (vr * p.pack_inv) >> 16;
+    const int group = sh * p.pack_g + g;
     if (g >= p.pack_g || group >= p.act_groups) return -1;
-    return ((group / p.act_heads) * p.pack_n + (vr - g * p.pack_n)) * ld + (group % p.act_heads) * 64;
+    return ((long)(group / p.act_heads) * p.pack_n + (vr - g * p.pack_n)) * ld + (group % p.act_heads) * 64;
 }
 // rows of the flat per-head arrays this workgroup may touch
 __device__ __forceinline__ int live_rows(const AttnBwdArgs& p, int sh) {
     if (p.pack_n == 0) return p.n;
-    const long left = p.act_groups * p.pack_n - (long)sh * p.n;
+    const long left = (long)p.act_groups * p.pack_n - (long)sh * p.n;
     return left < p.n ? (int)left : p.n;
 }
 
@@ -248,18 +248,17 @@ __device__ __forceinline__ void stash_tile(const f32x4 (&v)[ROWS / 16], float* n
 __device__ __forceinline__ bool score(const AttnBwdArgs& p, int s, int h, int gi, int j, float raw, float& out) {
     if (j >= p.nkt || gi >= p.n) return false;
     if (p.pack_n) {                                            // s = the virtual head (tile) index: (gi, j) interact only inside one real group
-        const int g = gi / p.pack_n;
-        if (j / p.pack_n != g) return false;
-        const long group = (long)s * p.pack_g + g;
+        const int g = (gi * p.pack_inv) >> 16;
+        if (((j * p.pack_inv) >> 16) != g) return false;
+        const int group = s * p.pack_g + g;
         if (g >= p.pack_g || group >= p.act_groups) return false;
-        const int li = gi - g * p.pack_n, lj = j - g * p.pack_n, hh = (int)(group % p.act_heads);
-        const long ss = group / p.act_heads;
+        const int li = gi - g * p.pack_n, lj = j - g * p.pack_n;
         float v = raw;
-        if (p.bias) v += p.bias[((long)hh * p.pack_n + li) * p.pack_n + lj];
-        if (p.kmask && !p.kmask[ss * p.pack_n + lj]) v = NEG_MAX;
+        if (p.bias) v += p.bias[((long)(group % p.act_heads) * p.pack_n + li) * p.pack_n + lj];
+        if (p.kmask && !p.kmask[(long)(group / p.act_heads) * p.pack_n + lj]) v = NEG_MAX;
         if (p.causal) {
             const int d = lj - li;
-            v = d > 0 ? NEG_MAX : v + (float)d * p.slopes[hh];
+            v = d > 0 ? NEG_MAX : v + (float)d * p.slopes[group % p.act_heads];
         }
         out = v;
         return true;
@@ -294,20 +293,36 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
     Frag<float> fq[2], fdo[2];
     load_rows_frag(fq, p.Qh + (long)sh * p.n * 64, 64, i0 + m0, nlive, lane);
     load_rows_frag_merged(fdo, p.dO, p.lddo, p, sh, i0 + m0, lane);
-    // D = rowsum(dO * O) for this wave's 16 rows
-    float Dl[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-        const int gi = i0 + m0 + rr;
-        float v = 0.f;
-        const long oo = merged_row_offset(p, sh, gi, p.ldo_), od = merged_row_offset(p, sh, gi, p.lddo);
+    // D = rowsum(dO * O) for this wave's 16 rows, from the dO fragments already in registers and the matching O fragments: a lane multiplies
+    // its 16 elements of row (lane & 15), the four k-quarters are folded with two shuffles, and the accumulator layout's rows (kq * 4 + i) are
+    // picked from the lanes that hold them (before: 16 dependent rounds of two global loads + a 64-lane reduction -- 70 of the kernel's 107 us
+    // at n = 64)
+    float Dl[4];
+    {
+        const long oo = merged_row_offset(p, sh, i0 + m0 + r, p.ldo_);
+        float part = 0.f;
         if (oo >= 0) {
-            const float o = p.o_bf16 ? bf2f(reinterpret_cast<const u16*>(p.O)[oo + lane]) : reinterpret_cast<const float*>(p.O)[oo + lane];
-            v = o * p.dO[od + lane];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                f32x4 olo, ohi;
+                if (p.o_bf16) {
+                    const u32x4 raw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const u16*>(p.O) + oo + c * 32 + kq * 8);
+                    olo = f32x4{__uint_as_float(raw[0] << 16), __uint_as_float(raw[0] & 0xffff0000u), __uint_as_float(raw[1] << 16), __uint_as_float(raw[1] & 0xffff0000u)};
+                    ohi = f32x4{__uint_as_float(raw[2] << 16), __uint_as_float(raw[2] & 0xffff0000u), __uint_as_float(raw[3] << 16), __uint_as_float(raw[3] & 0xffff0000u)};
+                } else {
+                    const float* op = reinterpret_cast<const float*>(p.O) + oo + c * 32 + kq * 8;
+                    olo = *reinterpret_cast<const f32x4*>(op);
+                    ohi = *reinterpret_cast<const f32x4*>(op + 4);
+                }
+                const f32x4 t = olo * fdo[c].lo + ohi * fdo[c].hi;
+                part += (t[0] + t[1]) + (t[2] + t[3]);
+            }
         }
-        v = wave_sum(v);
-        if ((rr >> 2) == kq) Dl[rr & 3] = v;
-        if (lane == 0 && gi < nlive) p.Drow[(long)sh * p.n + gi] = v;
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);                         // every lane of row r now holds D[row r]
+        if (kq == 0 && i0 + m0 + r < nlive) p.Drow[(long)sh * p.n + i0 + m0 + r] = part;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Dl[i] = __shfl(part, kq * 4 + i, 64);
     }
     const int ntl = (p.nkt + 63) / 64;
     const float* Kbase = p.Kh + (long)sh * p.nkt * 64;
@@ -509,14 +524,16 @@ extern "C" int pk_attn_bwd(const float* Qh, const float* Kh, const float* Vh, co
                            const float* bias, const unsigned char* kmask, const float* slopes, int causal, float* dQh, float* dKh, float* dVh, float* dS,
                            float* lse, float* Drow, int S, int heads, int n, int n_kv, int nnull, void* stream) {
     if (!Qh || !Kh || !Vh || !O || !dO || !dQh || !dKh || !dVh || !lse || !Drow || S <= 0 || heads <= 0 || n <= 0 || n_kv <= 0 || nnull < 0) return PK_EINVAL;
-    if (!al16(Qh) || !al16(Kh) || !al16(Vh) || !al16(dO) || (lddo & 3)) return PK_EALIGN;
+    if (!al16(Qh) || !al16(Kh) || !al16(Vh) || !al16(dO) || (lddo & 3) || !al16(O) || (ldo & (o_bf16 ? 7 : 3))) return PK_EALIGN;
+    if ((long)S * heads > 0x7fffffffL / 64) return PK_EINVAL;
     if (causal && (!slopes || n != n_kv)) return PK_EINVAL;
-    AttnBwdArgs p{Qh, Kh, Vh, O, ldo, o_bf16, dO, lddo, bias, kmask, slopes, causal, dQh, dKh, dVh, dS, lse, Drow, S, heads, n, nnull + n_kv, nnull, 0, 0, heads, (long)S * heads};
+    AttnBwdArgs p{Qh, Kh, Vh, O, ldo, o_bf16, dO, lddo, bias, kmask, slopes, causal, dQh, dKh, dVh, dS, lse, Drow, S, heads, n, nnull + n_kv, nnull, 0, 0, heads, S * heads, 0};
     static const bool pack_on = !(getenv("PK_ATTN_BWD_PACK") && getenv("PK_ATTN_BWD_PACK")[0] == '0');      // A/B switch
     if (pack_on && nnull == 0 && n == n_kv && n <= 32 && !dS) {
         // short self-attention (the C-ViViT temporal transformers: n = 9 at 512 sequences x 8 heads): 64 / n whole (sequence, head) groups per tile
         // instead of one -- the flat [S*h][n][64] arrays are the same memory either way
         p.pack_n = n;
+        p.pack_inv = 65536 / n + 1;
         p.pack_g = 64 / n;
         p.n = p.nkt = p.pack_g * n;
         p.heads = 1;
