@@ -339,7 +339,8 @@ int pk_adamw_multi(const long long* table, int count, float lr, float beta1, flo
  * k^ = l2norm([null_k ; k]) k_scale -> Kh, [null_v ; v] -> Vh (S heads, nnull + n_kv, 64) from the projection outputs q (S n, ldq), kv (S n_kv, ldkv).
  * pk_attn_bwd: dQh / dKh / dVh from those, the forward output O (f32 or bf16) and dO; bias (heads, n, n_kv) / kmask (S, n_kv) cover the real keys;
  * dS (S heads, n, n_kv; optional) = the score gradient for the position-bias gradient (pk_sum_batch over S); lse / Drow: (S heads n) scratch;
- *   causal (attention.py:166-172, the C-ViViT temporal transformers): ALiBi slopes [heads] over all nnull + n keys and the causal mask.
+ *   causal (attention.py:166-172, the C-ViViT temporal transformers): ALiBi slopes [heads] over all nnull + n keys and the causal mask;
+ *   split_bf16 = 1: the tile products on the bf16 matrix cores from (hi, lo) splits of the f32 operands (the bf16x3 / bf16 modes), 0: exact f32.
  * pk_attn_train_prep_bwd: back through l2norm / scales / null keys: dq, dkv, partials pq / pk (1024, 64) of dq_scale / dk_scale, dnull (heads, 2 nnull, 64). */
 int pk_attn_train_prep(const float* q, long long ldq, const float* kv, long long ldkv, const float* null_kv, const float* q_scale, const float* k_scale,
                        float scale, float* Qh, float* Kh, float* Vh, int S, int heads, int n, int n_kv, int nnull, void* stream);
@@ -348,7 +349,7 @@ int pk_attn_train_prep_bwd(const float* q, long long ldq, const float* kv, long 
                            float* pq, float* pk, float* dnull, int S, int heads, int n, int n_kv, int nnull, void* stream);
 int pk_attn_bwd(const float* Qh, const float* Kh, const float* Vh, const void* O, long long ldo, int o_bf16, const float* dO, long long lddo,
                 const float* bias, const unsigned char* kmask, const float* slopes, int causal, float* dQh, float* dKh, float* dVh, float* dS,
-                float* lse, float* Drow, int S, int heads, int n, int n_kv, int nnull, void* stream);
+                float* lse, float* Drow, int S, int heads, int n, int n_kv, int nnull, int split_bf16, void* stream);
 
 #ifdef __cplusplus
 }

@@ -82,7 +82,7 @@ SIGNATURES = {
     'pk_gemm_splitk': [_I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P],
     'pk_adamw': [_P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _LL, _P],
     'pk_adamw_multi': [_P, _I, _F, _F, _F, _F, _F, _I, _P],
-    'pk_attn_bwd': [_P, _P, _P, _P, _LL, _I, _P, _LL, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'pk_attn_bwd': [_P, _P, _P, _P, _LL, _I, _P, _LL, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
 }
 
 _ERR = {-1: 'PK_EINVAL (bad shape/size/flag)', -2: 'PK_EALIGN (pointer/stride alignment)', -3: 'PK_ELAUNCH (HIP launch failed)'}
@@ -573,12 +573,12 @@ def attn_train_prep_bwd(q, kv, null_kv, q_scale, k_scale, scale, dQh, dKh, dVh, 
     return dqs, dks, dnull
 
 
-def attn_bwd(Qh, Kh, Vh, O, dO, dQh, dKh, dVh, S, h, n, n_kv, nnull, *, bias=None, kmask=None, dS=None, slopes=None, causal=False):
+def attn_bwd(Qh, Kh, Vh, O, dO, dQh, dKh, dVh, S, h, n, n_kv, nnull, *, bias=None, kmask=None, dS=None, slopes=None, causal=False, split_bf16=False):
     dev = Qh.device
     lse = torch.empty((S * h * n,), device=dev, dtype=torch.float32)
     drow = torch.empty((S * h * n,), device=dev, dtype=torch.float32)
     rc = load().pk_attn_bwd(ptr(Qh), ptr(Kh), ptr(Vh), ptr(O), O.stride(-2), 1 if O.dtype == torch.bfloat16 else 0, ptr(dO), dO.stride(-2), ptr(bias), ptr(kmask),
-                            f32p(slopes, 'ALiBi slopes') if causal else None, 1 if causal else 0, ptr(dQh), ptr(dKh), ptr(dVh), ptr(dS), ptr(lse), ptr(drow), S, h, n, n_kv, nnull, stream(Qh))
+                            f32p(slopes, 'ALiBi slopes') if causal else None, 1 if causal else 0, ptr(dQh), ptr(dKh), ptr(dVh), ptr(dS), ptr(lse), ptr(drow), S, h, n, n_kv, nnull, 1 if split_bf16 else 0, stream(Qh))
     _check(rc, 'pk_attn_bwd')
 
 

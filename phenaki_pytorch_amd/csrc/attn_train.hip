@@ -127,29 +127,46 @@ __global__ __launch_bounds__(64) void null_kv_bwd_kernel(const float* __restrict
 // reads feed eight v_mfma_f32_16x16x4_f32, common.hpp mma(Frag<float>)).  The A side of every product is either held in REGISTERS for the whole
 // kernel (the workgroup's own q^ / dO rows in kernel Q, its k^ / v rows in kernel KV) or a wave-private LDS tile (P / dS, written in the
 // accumulator layout and read back as fragments); only B operands are shared through LDS.  acc[nb]: rows (lane >> 4) * 4 + i, column nb * 16 + (lane & 15).
-template <int NBLK, int NCHUNK>
-__device__ __forceinline__ void mma_regA(const Frag<float> (&a)[NCHUNK], const float* Bs, int ldb, f32x4 (&acc)[NBLK], int lane) {
+// X3 = split-bf16 tile products (the bf16x3 / bf16 compute modes): the f32 fragments are split into (hi, lo) bf16 planes in registers
+// (common.hpp split8, 24 VALU per 8 values) and every 16 x 16 x 32 block costs three v_mfma_f32_16x16x32_bf16 (3 x 16 cycles) instead of eight
+// v_mfma_f32_16x16x4_f32 (8 x 32 cycles).  Same-box A/B: training step 37.3 -> 36.0 ms (bf16x3), 31.7 -> 30.5 ms (bf16).  Keeping the tiles in
+// LDS as ready-made (hi | lo) bf16 planes (split once per workgroup when stashed, no conversions in the inner loops) was built and measured
+// too: no further gain (the loops wait on LDS / barriers, not on the VALU splits), so the simpler f32 tiles stay.
+// ~2^-17 relative per product, as everywhere else in the bf16x3 mode.  X3 = false: exact f32 (the 'fp32' mode).
+template <bool X3> struct OpFragOf { typedef Frag<float> type; };
+template <> struct OpFragOf<true> { typedef Frag<bf16x3p> type; };
+__device__ __forceinline__ void to_operand(Frag<float>& o, const Frag<float>& f) { o = f; }
+__device__ __forceinline__ void to_operand(Frag<bf16x3p>& o, const Frag<float>& f) { split8(f.lo, f.hi, o.hi, o.lo); }
+
+template <int NBLK, int NCHUNK, typename OF>
+__device__ __forceinline__ void mma_regA(const OF (&a)[NCHUNK], const float* Bs, int ldb, f32x4 (&acc)[NBLK], int lane) {
     const int r = lane & 15, kq = lane >> 4;
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c)
 #pragma unroll
         for (int nb = 0; nb < NBLK; ++nb) {
-            Frag<float> b;
-            frag_load(b, Bs + (nb * 16 + r) * ldb + c * 32 + kq * 8);
+            Frag<float> bf;
+            frag_load(bf, Bs + (nb * 16 + r) * ldb + c * 32 + kq * 8);
+            OF b;
+            to_operand(b, bf);
             acc[nb] = mma(a[c], b, acc[nb]);
         }
 }
-template <int NBLK, int NCHUNK>
+template <int NBLK, int NCHUNK, typename OF>
 __device__ __forceinline__ void mma_ldsA(const float* As, int lda, int m0, const float* Bs, int ldb, f32x4 (&acc)[NBLK], int lane) {
     const int r = lane & 15, kq = lane >> 4;
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c) {
-        Frag<float> a;
-        frag_load(a, As + (m0 + r) * lda + c * 32 + kq * 8);
+        Frag<float> af;
+        frag_load(af, As + (m0 + r) * lda + c * 32 + kq * 8);
+        OF a;
+        to_operand(a, af);
 #pragma unroll
         for (int nb = 0; nb < NBLK; ++nb) {
-            Frag<float> b;
-            frag_load(b, Bs + (nb * 16 + r) * ldb + c * 32 + kq * 8);
+            Frag<float> bf;
+            frag_load(bf, Bs + (nb * 16 + r) * ldb + c * 32 + kq * 8);
+            OF b;
+            to_operand(b, bf);
             acc[nb] = mma(a, b, acc[nb]);
         }
     }
@@ -281,7 +298,9 @@ __device__ __forceinline__ bool score(const AttnBwdArgs& p, int s, int h, int gi
 // kernel Q: one workgroup per 64 query rows of a head (4 waves x 16 rows).  q^ and dO fragments live in registers; LDS holds K^ [64][68],
 // K^T [64][68], V [64][68] of the current 64-key tile and the wave-private dS rows (70 KB: two workgroups per CU).  The next tile's K^ / V rows
 // are fetched into registers while the current one is being multiplied.
+template <bool X3>
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
+    typedef typename OpFragOf<X3>::type OF;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Ks = sm; float* Vs = sm + TSZ; float* Kt = sm + 2 * TSZ; float* Ps = sm + 3 * TSZ;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
@@ -293,6 +312,9 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
     Frag<float> fq[2], fdo[2];
     load_rows_frag(fq, p.Qh + (long)sh * p.n * 64, 64, i0 + m0, nlive, lane);
     load_rows_frag_merged(fdo, p.dO, p.lddo, p, sh, i0 + m0, lane);
+    OF fqx[2], fdox[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { to_operand(fqx[c], fq[c]); to_operand(fdox[c], fdo[c]); }
     // D = rowsum(dO * O) for this wave's 16 rows, from the dO fragments already in registers and the matching O fragments: a lane multiplies
     // its 16 elements of row (lane & 15), the four k-quarters are folded with two shuffles, and the accumulator layout's rows (kq * 4 + i) are
     // picked from the lanes that hold them (before: 16 dependent rounds of two global loads + a 64-lane reduction -- 70 of the kernel's 107 us
@@ -338,7 +360,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
         if (kt + 1 < ntl) fetch_tile<64>(kreg, Kbase, 64, (kt + 1) * 64, klive);
         __syncthreads();
         f32x4 acc[4] = PK_ZERO4;
-        mma_regA<4, 2>(fq, Ks, TLD, acc, lane);
+        mma_regA<4, 2, OF>(fqx, Ks, TLD, acc, lane);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
@@ -380,8 +402,8 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
         __syncthreads();
         f32x4 accS[4] = PK_ZERO4;
         f32x4 accP[4] = PK_ZERO4;
-        mma_regA<4, 2>(fq, Ks, TLD, accS, lane);
-        mma_regA<4, 2>(fdo, Vs, TLD, accP, lane);
+        mma_regA<4, 2, OF>(fqx, Ks, TLD, accS, lane);
+        mma_regA<4, 2, OF>(fdox, Vs, TLD, accP, lane);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
@@ -393,7 +415,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
                 if (p.dS && gi < p.n && j >= p.nnull && j < p.nkt) p.dS[((long)sh * p.n + gi) * nreal + (j - p.nnull)] = ds;
             }
         // this wave's 16 rows of Ps are its own: no workgroup barrier before reading them back.  dQ^[i][d] += sum_j dS[i][j] K^T[d][j]
-        mma_ldsA<4, 2>(Ps, TLD, m0, Kt, TLD, accQ, lane);
+        mma_ldsA<4, 2, OF>(Ps, TLD, m0, Kt, TLD, accQ, lane);
     }
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
@@ -408,7 +430,9 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
 // LDS holds q^ [32][68], dO [32][68] (B operands of the TRANSPOSED scores S^T[j][i], dP^T[j][i]), their transposes [64][36] (B operands of
 // dV = P^T dO, dK^ = dS^T q^) and one wave-private [64][36] buffer that carries P^T and then dS^T (46 KB: three workgroups per CU).
 constexpr int QT = 32, TLQ = 36;
+template <bool X3>
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnBwdArgs p) {
+    typedef typename OpFragOf<X3>::type OF;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Qs = sm; float* dOs = sm + QT * TLD; float* Qt = sm + 2 * QT * TLD; float* dOt = Qt + 64 * TLQ; float* PS = dOt + 64 * TLQ;
     float* lse_s = PS + 64 * TLQ; float* D_s = lse_s + QT;
@@ -420,6 +444,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnBwdArgs p) {
     Frag<float> fk[2], fv[2];
     load_rows_frag(fk, p.Kh + (long)sh * p.nkt * 64, 64, j0 + m0, klive, lane);
     load_rows_frag(fv, p.Vh + (long)sh * p.nkt * 64, 64, j0 + m0, klive, lane);
+    OF fkx[2], fvx[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { to_operand(fkx[c], fk[c]); to_operand(fvx[c], fv[c]); }
     f32x4 accK[4] = PK_ZERO4;
     f32x4 accV[4] = PK_ZERO4;
     const int nqt = (p.n + QT - 1) / QT;
@@ -444,8 +471,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnBwdArgs p) {
         __syncthreads();
         f32x4 accS[2] = PK_ZERO2;
         f32x4 accP[2] = PK_ZERO2;
-        mma_regA<2, 2>(fk, Qs, TLD, accS, lane);                  // S^T[j][i]
-        mma_regA<2, 2>(fv, dOs, TLD, accP, lane);                 // dP^T[j][i] = sum_d V[j][d] dO[i][d]
+        mma_regA<2, 2, OF>(fkx, Qs, TLD, accS, lane);             // S^T[j][i]
+        mma_regA<2, 2, OF>(fvx, dOs, TLD, accP, lane);                 // dP^T[j][i] = sum_d V[j][d] dO[i][d]
         float pr[2][4], dsv[2][4];
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
@@ -461,13 +488,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnBwdArgs p) {
             }
         }
         // dV[j][d] += sum_i P^T[j][i] dO^T[d][i]   (A rows = this wave's own 16 rows of PS: program order is enough)
-        mma_ldsA<4, 1>(PS, TLQ, m0, dOt, TLQ, accV, lane);
+        mma_ldsA<4, 1, OF>(PS, TLQ, m0, dOt, TLQ, accV, lane);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
             for (int i = 0; i < 4; ++i) PS[(m0 + kq * 4 + i) * TLQ + nb * 16 + r] = dsv[nb][i];
         // dK^[j][d] += sum_i dS^T[j][i] q^T[d][i]
-        mma_ldsA<4, 1>(PS, TLQ, m0, Qt, TLQ, accK, lane);
+        mma_ldsA<4, 1, OF>(PS, TLQ, m0, Qt, TLQ, accK, lane);
     }
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
@@ -522,7 +549,7 @@ extern "C" int pk_attn_train_prep_bwd(const float* q, long ldq, const float* kv,
 // lse / Drow: (S heads n) f32 scratch
 extern "C" int pk_attn_bwd(const float* Qh, const float* Kh, const float* Vh, const void* O, long ldo, int o_bf16, const float* dO, long lddo,
                            const float* bias, const unsigned char* kmask, const float* slopes, int causal, float* dQh, float* dKh, float* dVh, float* dS,
-                           float* lse, float* Drow, int S, int heads, int n, int n_kv, int nnull, void* stream) {
+                           float* lse, float* Drow, int S, int heads, int n, int n_kv, int nnull, int split_bf16, void* stream) {
     if (!Qh || !Kh || !Vh || !O || !dO || !dQh || !dKh || !dVh || !lse || !Drow || S <= 0 || heads <= 0 || n <= 0 || n_kv <= 0 || nnull < 0) return PK_EINVAL;
     if (!al16(Qh) || !al16(Kh) || !al16(Vh) || !al16(dO) || (lddo & 3) || !al16(O) || (ldo & (o_bf16 ? 7 : 3))) return PK_EALIGN;
     if ((long)S * heads > 0x7fffffffL / 64) return PK_EINVAL;
@@ -542,13 +569,22 @@ extern "C" int pk_attn_bwd(const float* Qh, const float* Kh, const float* Vh, co
     hipStream_t s = STREAM(stream);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TSZ * 4) != hipSuccess) return PK_ELAUNCH;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, KV_SMEM) != hipSuccess) return PK_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TSZ * 4) != hipSuccess) return PK_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TSZ * 4) != hipSuccess) return PK_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, KV_SMEM) != hipSuccess) return PK_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, KV_SMEM) != hipSuccess) return PK_ELAUNCH;
         attr_done = true;
     }
     const int nqt = (p.n + 63) / 64, nktt = (p.nkt + 63) / 64;
-    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3((unsigned)((long)p.S * p.heads * nqt)), dim3(256), 4 * TSZ * 4, s, p);
-    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3((unsigned)((long)p.S * p.heads * nktt)), dim3(256), KV_SMEM, s, p);
+    const dim3 gq((unsigned)((long)p.S * p.heads * nqt)), gk((unsigned)((long)p.S * p.heads * nktt));
+    static const bool split_on = !(getenv("PK_ATTN_BWD_SPLIT") && getenv("PK_ATTN_BWD_SPLIT")[0] == '0');     // A/B switch
+    if (split_bf16 && split_on) {
+        hipLaunchKernelGGL(attn_bwd_q_kernel<true>, gq, dim3(256), 4 * TSZ * 4, s, p);
+        hipLaunchKernelGGL(attn_bwd_kv_kernel<true>, gk, dim3(256), KV_SMEM, s, p);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_q_kernel<false>, gq, dim3(256), 4 * TSZ * 4, s, p);
+        hipLaunchKernelGGL(attn_bwd_kv_kernel<false>, gk, dim3(256), KV_SMEM, s, p);
+    }
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

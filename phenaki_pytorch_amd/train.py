@@ -292,7 +292,8 @@ class _AttnBlock(torch.autograd.Function):
         dQh, dKh, dVh = torch.empty_like(Qh), torch.empty_like(Kh), torch.empty_like(Vh)
         want_dbias = bias is not None and ctx.needs_input_grad[12]
         dS = _f32((S, heads * n * n_kv), dev) if want_dbias else None
-        L.attn_bwd(Qh, Kh, Vh, o, do, dQh, dKh, dVh, S, heads, n, n_kv, nnull, bias=bias, kmask=kmask, dS=dS, slopes=slopes, causal=slopes is not None)
+        L.attn_bwd(Qh, Kh, Vh, o, do, dQh, dKh, dVh, S, heads, n, n_kv, nnull, bias=bias, kmask=kmask, dS=dS, slopes=slopes, causal=slopes is not None,
+                   split_bf16=dtype != L.F32)
         dbias = None
         if want_dbias:
             dbias = _f32(tuple(bias.shape), dev)
