@@ -193,7 +193,9 @@ __device__ __forceinline__ void mask_vt_tail(Frag<float>& f, int kb, int g, int 
 }
 
 template <typename T, int QF>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
+// QF = 2 on f32 / split-bf16 operands (the training step's n = 576 forward, the f32 / bf16x3 parity modes): the compiler's free choice was
+// ~250 VGPRs + 32 AGPRs = one wave per SIMD, 256 resident workgroups for the 320 of a B = 8 call; two waves per SIMD put them in one round
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((QF == 2 && sizeof(T) != 2) ? 2 : 1))) void attn_fwd_kernel(const AttnArgs p) {
     const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
     const int qtiles = p.nq_pad / (16 * QF);
     const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -298,8 +298,10 @@ __device__ __forceinline__ bool score(const AttnBwdArgs& p, int s, int h, int gi
 // kernel Q: one workgroup per 64 query rows of a head (4 waves x 16 rows).  q^ and dO fragments live in registers; LDS holds K^ [64][68],
 // K^T [64][68], V [64][68] of the current 64-key tile and the wave-private dS rows (70 KB: two workgroups per CU).  The next tile's K^ / V rows
 // are fetched into registers while the current one is being multiplied.
+// 2 waves per SIMD (two workgroups per CU, which the 70 KB of LDS allow): without the bound the compiler took 255 VGPRs + 42 AGPRs = ONE wave per
+// SIMD -- 256 resident workgroups, so the 576 of a B = 8 step ran in three rounds
 template <bool X3>
-__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_q_kernel(const AttnBwdArgs p) {
     typedef typename OpFragOf<X3>::type OF;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Ks = sm; float* Vs = sm + TSZ; float* Kt = sm + 2 * TSZ; float* Ps = sm + 3 * TSZ;
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const AttnBwdArgs p) {
 // dV = P^T dO, dK^ = dS^T q^) and one wave-private [64][36] buffer that carries P^T and then dS^T (46 KB: three workgroups per CU).
 constexpr int QT = 32, TLQ = 36;
 template <bool X3>
-__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const AttnBwdArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_kv_kernel(const AttnBwdArgs p) {
     typedef typename OpFragOf<X3>::type OF;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Qs = sm; float* dOs = sm + QT * TLD; float* Qt = sm + 2 * QT * TLD; float* dOt = Qt + 64 * TLQ; float* PS = dOt + 64 * TLQ;
