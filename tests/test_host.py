@@ -356,3 +356,20 @@ def test_data_io_gif_roundtrip_datasets_and_collate(tmp_path):
 def _has(mod):
     import importlib.util
     return importlib.util.find_spec(mod) is not None
+
+
+def test_tokenizer_training_row_maps_are_the_reference_rearranges():
+    """train_cvivit._frame_indices: the int32 row maps of the tokenizer's training step against the reference's einops patterns
+    ('b t h w d -> (b h w) t d' and back, cvivit.py:456-470; tokens[:, :1] / tokens[:, 1:], :505) on a tagged tensor.  Host logic only."""
+    from phenaki_pytorch_amd.train_cvivit import _frame_indices
+    b, t, h, w = 3, 4, 2, 5
+    hw = h * w
+    to_temporal, to_spatial, first, rest = (x.long() for x in _frame_indices(b, t, hw, torch.device('cpu')))
+    x = torch.arange(b * t * hw, dtype=torch.float32).view(b, t, h, w, 1)
+    spatial_rows = x.reshape(b * t * hw, 1)                                     # '(b t) (h w)' row order
+    temporal_rows = x.permute(0, 2, 3, 1, 4).reshape(b * hw * t, 1)             # '(b h w) t'
+    assert torch.equal(spatial_rows[to_temporal], temporal_rows)
+    assert torch.equal(temporal_rows[to_spatial], spatial_rows)
+    assert torch.equal(to_temporal[to_spatial], torch.arange(b * t * hw)) and torch.equal(to_spatial[to_temporal], torch.arange(b * t * hw))
+    assert torch.equal(spatial_rows[first], x[:, :1].reshape(-1, 1)) and torch.equal(spatial_rows[rest], x[:, 1:].reshape(-1, 1))
+    assert sorted(torch.cat((first, rest)).tolist()) == list(range(b * t * hw))
