@@ -179,6 +179,71 @@ def sample_golden(R, cfgs, batch, frames_list, prime_len, ctx_len, tag, keep_log
     print(f'sample_{tag}: {len(rec.steps)} step records, {dt:.1f}s')
 
 
+def make_video_golden(R, cfgs, frames, prime_lengths, ctx_lens, tag, keep_videos, steps=None):
+    """the reference's OWN make_video (phenaki_pytorch.py:691-714) -- one text per scene, each scene primed by the last K frames of the
+    previous one -- with the noise injected per (scene, step) as in sample_golden.  Every scene gets its own text context (different lengths).
+    Batch is 1 (make_video hands `sample` a single str).  Recorded per step: the MaskGit input ids (prime tokens included), the predicted ids,
+    the critic input; per scene the video (whole, or sub-sampled + checksums at full size)."""
+    cv, mg, cr, ph = build_reference(R, cfgs, with_phenaki=True, with_critic=True, steps=steps)
+    texts = [f'scene {i}' for i in range(len(frames))]
+    ctxs = {t: weights.synthetic_context(1, L, cfgs['maskgit']['dim_context'], seed=20 + i) for i, (t, L) in enumerate(zip(texts, ctx_lens))}
+    ph.encode_texts = lambda tx, output_device=None: torch.cat([ctxs[t] for t in tx], 0)
+    rec = Recorder(R, ph, noise_seed_base=500)
+    rec.keep_logits = False
+    rec.install()
+    orig_sample = ph.sample
+    calls = []
+
+    def sample(**kw):
+        rec.scene = len(calls)
+        calls.append(dict(num_frames=kw['num_frames'], prime_frames=None if kw.get('prime_frames') is None else kw['prime_frames'].shape[2],
+                          text=kw['texts']))
+        return orig_sample(**kw)
+    ph.sample = sample
+    t0 = time.time()
+    try:
+        with torch.no_grad():
+            whole, scenes = R.module.make_video(ph, texts, frames, prime_lengths)
+    finally:
+        rec.uninstall()
+        del ph.sample
+    dt = time.time() - t0
+    out = dict(steps=rec.steps, frames=tuple(frames), prime_lengths=prime_lengths, ctx_lens=tuple(ctx_lens), texts=texts, calls=calls,
+               whole_shape=tuple(whole.shape), t_ref_cpu=dt)
+    if keep_videos:
+        out['scenes'] = scenes
+    else:
+        out['scenes_sub'] = [v[:, :, ::3, ::8, ::8].clone() for v in scenes]
+        out['scenes_sum'] = [v.double().sum().item() for v in scenes]
+        out['scenes_abs'] = [v.double().abs().sum().item() for v in scenes]
+    torch.save(out, os.path.join(OUT, f'make_video_{tag}.pt'))
+    print(f'make_video_{tag}: {len(rec.steps)} step records over {len(calls)} scenes, whole {tuple(whole.shape)}, {dt:.1f}s')
+
+
+def sample_ragged_golden(R, cfgs, batch, frames, ctx_lens, tag):
+    """Phenaki.sample at batch > 1 with captions of DIFFERENT lengths: t5_encode_text zero-fills the pads (t5.py:94-103), the per-row
+    text_mask is any(embeds != 0) (phenaki_pytorch.py:455-463).  cond_scale 5, TokenCritic, full step count; ids per step + sub-sampled video."""
+    cv, mg, cr, ph = build_reference(R, cfgs, with_phenaki=True, with_critic=True)
+    ctx = weights.ragged_context(ctx_lens, cfgs['maskgit']['dim_context'], seed=6)
+    assert ctx.shape[0] == batch
+    ph.encode_texts = lambda texts, output_device=None: ctx
+    rec = Recorder(R, ph, noise_seed_base=700)
+    rec.keep_logits = False
+    rec.install()
+    t0 = time.time()
+    try:
+        with torch.no_grad():
+            v = ph.sample(texts=['x'] * batch, num_frames=frames, cond_scale=5.)
+    finally:
+        rec.uninstall()
+    dt = time.time() - t0
+    out = dict(steps=rec.steps, frames=frames, ctx_lens=tuple(ctx_lens), batch=batch, t_sample_ref_cpu=dt,
+               video_sub=v[:, :, ::4, ::8, ::8].clone(), video_sum=v.double().sum().item(), video_abs=v.double().abs().sum().item())
+    torch.save(out, os.path.join(OUT, f'sample_{tag}.pt'))
+    print(f'sample_{tag}: {len(rec.steps)} step records, {dt:.1f}s')
+
+
+
 def forward_golden(R, cfgs, batch, frames, ctx_len, tag):
     """Phenaki.forward (the training objective, value only) of the real reference with its three random draws replaced
     by deterministic ones (torch.randint / torch.rand patched for the duration of the call, gumbel_noise as in the
@@ -524,6 +589,16 @@ def main():
     if 'tiny' in which or 'critics' in which:
         selfcritic_golden(R, TINY, tag='tiny')
         unconditional_golden(R, TINY, tag='tiny')
+    if 'tiny' in which or 'make_video' in which:
+        make_video_golden(R, TINY, frames=(5, 4, 4), prime_lengths=3, ctx_lens=(5, 7, 4), tag='tiny', keep_videos=True)
+        make_video_golden(R, TINY, frames=(5, 4, 6), prime_lengths=(3, 1), ctx_lens=(6, 3, 8), tag='tiny_perscene', keep_videos=True)
+        sample_ragged_golden(R, TINY, batch=3, frames=5, ctx_lens=(6, 3, 5), tag='tiny_ragged')
+    if 'full' in which or 'make_video_full' in which:
+        # BASELINE configs[4]: 3 scenes (17, 14, 14 frames), K = 5 -> scenes 2 / 3 run n = 192 prime + 448 new tokens, patch shape (10, 8, 8)
+        make_video_golden(R, FULL, frames=(17, 14, 14), prime_lengths=5, ctx_lens=(12, 9, 14), tag='full', keep_videos=False)
+    if 'full' in which or 'ragged_full' in which:
+        # BASELINE configs[3]'s per-GPU share: B = 4, CFG 5, two caption lengths (zero-filled pads -> per-row text_mask)
+        sample_ragged_golden(R, FULL, batch=4, frames=17, ctx_lens=(12, 7, 12, 7), tag='full_b4_ragged')
     if 'full' in which:
         cvivit_golden(R, FULL, batch=2, frames=17, tag='full', subsample=True)
         maskgit_golden(R, FULL, batch=1, frames=17, ctx_len=12, tag='full', col_stride=512)

@@ -580,6 +580,26 @@ def sample(cv, cv_cfg, mg, mg_cfg, cr, cr_cfg, *, num_frames, batch_size, contex
     return video, ids
 
 
+def make_video(cv, cv_cfg, mg, mg_cfg, cr, cr_cfg, *, contexts, num_frames, prime_lengths, steps=18, noise_fn_for_scene=None, traces=None, **kw):
+    """phenaki_pytorch.py:691-714: one text (here: one cached context of shape (1, L_i, dim_context)) per scene; scene i+1 is primed with the
+    last prime_lengths[i] frames of scene i; the last scene primes nothing.  `sample` is called with its DEFAULT cond_scale (3), as the reference
+    does (:708).  ``noise_fn_for_scene(i)`` returns scene i's noise_fn; ``traces`` (a list) receives one list of step records per scene."""
+    num_scenes = len(contexts)
+    num_frames = tuple(num_frames) if isinstance(num_frames, (tuple, list)) else (num_frames,) * num_scenes
+    prime_lengths = tuple(prime_lengths) if isinstance(prime_lengths, (tuple, list)) else (prime_lengths,) * (num_scenes - 1)
+    prime_lengths = (*prime_lengths, 0)
+    prime, scenes = None, []
+    for i, (ctx, nf, k) in enumerate(zip(contexts, num_frames, prime_lengths)):
+        tr = [] if traces is not None else None
+        video, _ = sample(cv, cv_cfg, mg, mg_cfg, cr, cr_cfg, num_frames=nf, batch_size=1, context=ctx, prime_frames=prime, steps=steps,
+                          noise_fn=noise_fn_for_scene(i), trace=tr, **kw)
+        if traces is not None:
+            traces.append(tr)
+        scenes.append(video)
+        prime = video[:, :, -k:]            # k = 0 -> the whole scene, as the reference's slice gives; never used (last scene)
+    return torch.cat(scenes, dim=2), scenes
+
+
 # --------------------------------------------------------------------------- training objective (value only)
 
 def mask_subset_with_prob(mask, prob, perm_noise):

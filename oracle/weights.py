@@ -83,3 +83,12 @@ def uniform_noise(shape, seed):
     g = torch.Generator(device='cpu')
     g.manual_seed(3000 + seed)
     return torch.rand(shape, generator=g)
+
+
+def ragged_context(lengths, dim, seed=1):
+    """what t5_encode_text hands over for captions of different lengths (t5.py:94-103): (B, max(lengths), dim) with row b's positions
+    >= lengths[b] zero-filled -- Phenaki derives the per-row text_mask from exactly those zeros (phenaki_pytorch.py:461)."""
+    ctx = synthetic_context(len(lengths), max(lengths), dim, seed=seed)
+    for b, n in enumerate(lengths):
+        ctx[b, n:] = 0.
+    return ctx

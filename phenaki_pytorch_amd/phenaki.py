@@ -539,7 +539,7 @@ class Phenaki(PackedModule):
 
             rec = None
             if trace is not None:
-                rec = dict(step=step, masked_ids=ids.clone(), mask=mask.bool().clone())
+                rec = dict(step=step, masked_ids=ids.clone(), mask=mask.bool().clone(), prime_ids=st['prime_ids'])
 
             e = mg.embeds(ids, replicas=2 if with_null else 1, ids_prime=st['prime_ids'], video_patch_shape=st['patch_shape'],
                           context=st['ctx_r'], text_mask=st['tm_r'], kv_cache=mg_cache)
@@ -603,13 +603,14 @@ class Phenaki(PackedModule):
     @torch.no_grad()
     def sample(self, *, num_frames, texts=None, prime_frames=None, batch_size=1, cond_scale=3.,
                starting_temperature=0.9, noise_K=1., _noise_fn=None, _trace=None, _return_ids=False, _compact=None, _seed=None,
-               _force_fn=None):
+               _force_fn=None, _prime_ids=None):
         """phenaki_pytorch.py:418-560.  `_noise_fn(kind, step, shape)` (tests) injects the U[0,1) draws of the
         reference run ('gumbel' (B,n,V) and 'critic' (B,n), device f32 tensors); _noise_fn='torch': torch's device generator in the
         reference's order (a seeded reference run on the same GPU draws the same noise); without it the noise comes from the
         in-kernel counter hash seeded from torch's default (CPU) generator (`_seed`: the exact 64-bit stream seed instead;
         the seed a call used is kept in `self._pk_last_seed`).  `_force_fn(step, ids, mask)` (tests) may overwrite a step's masked
-        input ids (B, n) int64 and mask (B, n) uint8 in place before the trunk runs (teacher forcing; eager, no row compaction)."""
+        input ids (B, n) int64 and mask (B, n) uint8 in place before the trunk runs (teacher forcing; eager, no row compaction);
+        `_prime_ids` (tests, with prime_frames given) replaces the token ids the tokenizer would produce for the prime frames."""
         device = next(self.parameters()).device
         L.require_device(next(self.parameters()), 'Phenaki parameters')
         mg, critic = self.maskgit, self.critic
@@ -633,6 +634,9 @@ class Phenaki(PackedModule):
         if has_prime:
             prime_token_ids = self.cvivit(prime_frames, return_only_codebook_ids=True)
             prime_token_ids = prime_token_ids.reshape(prime_token_ids.shape[0], -1).contiguous()
+            if _prime_ids is not None:
+                assert tuple(_prime_ids.shape) == tuple(prime_token_ids.shape)
+                prime_token_ids = _prime_ids.to(device=device, dtype=prime_token_ids.dtype).contiguous()
             prime_token_length = prime_token_ids.shape[-1]
             prime_num_frames = prime_frames.shape[2]
 

@@ -96,6 +96,50 @@ def test_sample_matches_reference_free_running(golden_dir, tag, with_critic):
         prime = video[:, :, -g['prime_len']:] if g['prime_len'] else None
 
 
+def _check_make_video(g, cfgs, tagw, slow_close=None):
+    cv, mg, cr = state_dicts(tagw)
+    cvc, mgc, crc = oracle_cfgs(cfgs)
+    dc = cfgs['maskgit']['dim_context']
+    ctxs = [weights.synthetic_context(1, L, dc, seed=20 + i) for i, L in enumerate(g['ctx_lens'])]
+    traces = []
+    whole, scenes = O.make_video(cv, cvc, mg, mgc, cr, crc, contexts=ctxs, num_frames=g['frames'], prime_lengths=g['prime_lengths'],
+                                 steps=cfgs['steps'], noise_fn_for_scene=lambda i: _noise_fn(500, i), traces=traces)
+    assert tuple(whole.shape) == tuple(g['whole_shape'])
+    for si, tr in enumerate(traces):
+        recs = [s for s in g['steps'] if s['scene'] == si]
+        assert len(recs) == len(tr) == cfgs['steps']
+        for r, t in zip(recs, tr):
+            npr = r['mg_input'].shape[1] - t['masked_ids'].shape[1]
+            assert torch.equal(r['mg_input'][:, npr:], t['masked_ids']), f"scene {si} step {r['step']}: input ids differ"
+            assert torch.equal(r['pred'], t['pred']), f"scene {si} step {r['step']}: pred differs"
+            assert torch.equal(r['critic_input'][:, npr:], t['ids']) if 'critic_input' in r else True
+    return whole, scenes
+
+
+@pytest.mark.parametrize('tag', ['tiny', 'tiny_perscene'])
+def test_make_video_matches_the_references_own_make_video(golden_dir, tag):
+    """oracle.make_video against R.make_video (phenaki_pytorch.py:691-714) itself: three scenes with their own texts, scalar and per-scene K."""
+    g = load(golden_dir, f'make_video_{tag}.pt')
+    whole, scenes = _check_make_video(g, TINY, 'tiny')
+    for a, b in zip(scenes, g['scenes']):
+        close(a, b)
+
+
+def test_sample_ragged_captions_matches_reference(golden_dir):
+    """B = 3 with three caption lengths: zero-filled pads -> per-row text_mask (phenaki_pytorch.py:455-463, t5.py:94-103)."""
+    g = load(golden_dir, 'sample_tiny_ragged.pt')
+    cv, mg, cr = state_dicts('tiny')
+    cvc, mgc, crc = oracle_cfgs(TINY)
+    ctx = weights.ragged_context(g['ctx_lens'], TINY['maskgit']['dim_context'], seed=6)
+    trace = []
+    video, _ = O.sample(cv, cvc, mg, mgc, cr, crc, num_frames=g['frames'], batch_size=g['batch'], context=ctx, steps=TINY['steps'],
+                        cond_scale=5., noise_fn=_noise_fn(700, 0), trace=trace)
+    assert len(trace) == len(g['steps'])
+    for r, t in zip(g['steps'], trace):
+        assert torch.equal(r['mg_input'], t['masked_ids']) and torch.equal(r['pred'], t['pred']), f"step {r['step']}"
+    close(video[:, :, ::4, ::8, ::8], g['video_sub'])
+
+
 # ---------------------------------------------------------------------------------------------------------
 # full BASELINE geometry (dim 512, 65 536 codes, 256x256, n = 576): goldens are sub-sampled outputs of the
 # REAL reference (oracle/make_golden.py full)
@@ -380,3 +424,56 @@ def test_t5_encoder_oracle_matches_huggingface(golden_dir, tag):
     out = T.t5_encode(sd, cfg, ids, mask)
     close(out[:, :, ::g['sub']], g['out'], 5e-5)
     assert (out[~mask] == 0).all()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# LFQ / VectorQuantize restatement (oracle/lfq.py): the upstream package is absent (parity unpinned at this sub-step), so what CAN be held is
+# the published module's algebra -- the invariants every call site of the reference relies on (cvivit.py:439, 570; phenaki_pytorch.py:553-555)
+
+def test_lfq_restatement_invariants():
+    from oracle.lfq import LFQ, VectorQuantize
+    torch.manual_seed(3)
+    q = LFQ(dim=48, codebook_size=65536).eval()
+    # bit order: MSB first -- mask = 2 ** arange(15, -1, -1)
+    assert torch.equal(q.mask, 2 ** torch.arange(15, -1, -1))
+    x = torch.randn(2, 37, 48)
+    quant, idx, aux = q(x)
+    assert idx.dtype == torch.int64 and idx.shape == (2, 37) and float(aux) == 0.
+    assert int(idx.min()) >= 0 and int(idx.max()) < 65536
+    # indices_to_codes inverts the forward: decode(encode(x).indices) == encode(x).quantized  (what Phenaki.sample decodes, :553-555)
+    assert torch.equal(q.indices_to_codes(idx), quant)
+    # the ids are exactly the sign bits of the projection, MSB first; x == 0 -> -1 (bit 0)
+    proj = q.project_in(x)
+    bits = (proj > 0).long()
+    assert torch.equal(idx, (bits * (2 ** torch.arange(15, -1, -1))).sum(-1))
+    codes = q.indices_to_codes(idx, project_out=False)
+    assert torch.equal(codes, torch.where(proj > 0, 1., -1.))
+    z = LFQ(dim=16, codebook_size=65536).eval()            # dim == codebook_dim -> identity projections
+    zq, zi, _ = z(torch.zeros(1, 3, 16))
+    assert torch.equal(zq, -torch.ones(1, 3, 16)) and torch.equal(zi, torch.zeros(1, 3, dtype=torch.int64))
+    # every id round-trips: codes -> ids -> codes over the whole codebook
+    all_ids = torch.arange(65536)
+    c = z.indices_to_codes(all_ids)
+    _, back, _ = z(c)
+    assert torch.equal(back, all_ids)
+    # ids with >= 3 dims: the feature dim moves to position 1 (published behaviour; not on Phenaki.sample's path, which passes 2-D ids)
+    assert z.indices_to_codes(torch.zeros(2, 3, 4, 5, dtype=torch.long)).shape == (2, 16, 3, 4, 5)
+    # straight-through in training mode: same values, gradient of the quantized output w.r.t. the projection is the identity
+    q.train()
+    xt = torch.randn(5, 48)
+    with torch.enable_grad():
+        cap = {}
+        def keep(m, i, o):
+            o.retain_grad()
+            cap['p'] = o
+        h = q.project_in.register_forward_hook(keep)
+        out, _, _ = q(xt)
+        out.sum().backward()
+        h.remove()
+    assert torch.allclose(cap['p'].grad, q.project_out.weight.sum(0).expand_as(cap['p']), atol=1e-6)
+    # cosine-sim VectorQuantize: argmax of normalised dot products, codebook rows are what comes back
+    vq = VectorQuantize(dim=32, codebook_size=128).eval()
+    xv = torch.randn(4, 9, 32)
+    out, ids, _ = vq(xv)
+    cb = torch.nn.functional.normalize(vq.codebook, dim=-1)
+    assert torch.equal(ids, (torch.nn.functional.normalize(xv, dim=-1) @ cb.t()).argmax(-1)) and torch.equal(out, cb[ids])
