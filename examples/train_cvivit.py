@@ -34,7 +34,7 @@ def main():
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
         dist.init_process_group('nccl')
     rank = dist.get_rank() if ws > 1 else 0
-    torch.manual_seed(1 + rank)
+    torch.manual_seed(1)                   # the model is built under a rank-INDEPENDENT seed (and GradientReducer broadcasts rank 0's weights anyway)
 
     dim, size, patch, vocab = (128, 64, 16, 256) if args.small else (512, 256, 32, 65536)
     cvivit = P.CViViT(dim=dim, codebook_size=vocab, image_size=size, patch_size=patch, temporal_patch_size=2, spatial_depth=2 if args.small else 4,
@@ -42,7 +42,8 @@ def main():
     P.set_compute_dtype(cvivit, args.dtype)
     params = list(cvivit.parameters())
     opt = P.get_optimizer(params, lr=3e-4, wd=0.)
-    reducer = P.GradientReducer(params) if ws > 1 else None
+    reducer = P.GradientReducer(params, buffers=list(cvivit.buffers())) if ws > 1 else None     # broadcasts rank 0's parameters, as DDP does at wrap time
+    torch.manual_seed(1 + rank)            # from here on (data order, frame masks) every rank draws its own stream
 
     if args.folder:
         loader = DataLoader(VideoDataset(args.folder, size, num_frames=args.frames), batch_size=args.batch, shuffle=True, drop_last=True)

@@ -28,7 +28,8 @@ def main():
     if ws > 1:
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
         dist.init_process_group('nccl')
-    torch.manual_seed(1 + (dist.get_rank() if ws > 1 else 0))
+    rank = dist.get_rank() if ws > 1 else 0
+    torch.manual_seed(1)                   # models (incl. the frozen tokenizer) are built under a rank-INDEPENDENT seed: every rank tokenizes alike
 
     dim, size, patch, vocab, ctx_dim = (128, 64, 16, 256, 96) if args.small else (512, 256, 32, 65536, 768)
     cvivit = P.CViViT(dim=dim, codebook_size=vocab, image_size=size, patch_size=patch, temporal_patch_size=2, spatial_depth=2 if args.small else 4,
@@ -41,11 +42,14 @@ def main():
     params = list(maskgit.parameters()) + list(critic.parameters())
     opt = P.get_optimizer(params, lr=1e-4, wd=1e-2)
 
+    if ws > 1:
+        P.broadcast_module(phenaki)        # every replica starts from rank 0's weights and buffers (what accelerate / DDP do at wrap time)
+    torch.manual_seed(1 + rank)            # from here on (data, mask draws) every rank has its own stream
     videos = torch.randn(args.batch, 3, 17, size, size, device='cuda')          # a dataset would go here
     text_embeds = torch.randn(args.batch, 12, ctx_dim, device='cuda')            # ... and phenaki.encode_texts(texts) (t5.py / T5Encoder)
     with torch.no_grad():
         ids = phenaki.cvivit(videos, return_only_codebook_ids=True)              # the tokenizer is frozen: encode once per batch
-    reducer = P.GradientReducer(params) if ws > 1 else None
+    reducer = P.GradientReducer(params, broadcast=False) if ws > 1 else None
     t0 = None
     for step in range(args.steps):
         if step == 3:

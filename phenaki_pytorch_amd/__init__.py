@@ -7,9 +7,9 @@ optim.py); the compute is hand-written HIP in libphenaki_hip.so (build: `python 
 from .attention import set_compute_dtype, invalidate_packed
 from .cvivit import CViViT
 from .phenaki import MaskGit, TokenCritic, SelfCritic, Phenaki, make_video
-from .dist import shard_batch, sample_sharded, make_video_sharded, all_reduce_gradients, GradientReducer
+from .dist import shard_batch, sample_sharded, make_video_sharded, all_reduce_gradients, GradientReducer, broadcast_parameters, broadcast_module
 from .train import vocab_cross_entropy
 from .optim import HipAdamW, get_optimizer
 
 __all__ = ['CViViT', 'MaskGit', 'TokenCritic', 'SelfCritic', 'Phenaki', 'make_video', 'set_compute_dtype', 'invalidate_packed',
-           'shard_batch', 'sample_sharded', 'make_video_sharded', 'vocab_cross_entropy', 'all_reduce_gradients', 'GradientReducer', 'HipAdamW', 'get_optimizer']
+           'shard_batch', 'sample_sharded', 'make_video_sharded', 'vocab_cross_entropy', 'all_reduce_gradients', 'GradientReducer', 'broadcast_parameters', 'broadcast_module', 'HipAdamW', 'get_optimizer']

@@ -115,11 +115,52 @@ def bucket_plan(numels, bucket_elems):
     return plan
 
 
+def _group_size(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group)
+    return 1
+
+
+def broadcast_parameters(tensors, src=0, group=None, bucket_mb=64.0, force=False):
+    """in place: every tensor in `tensors` (parameters AND buffers of the trained modules) <- rank `src`'s copy, in flat buckets (one
+    broadcast per bucket and dtype).  What DDP does when it wraps a module (the reference trains through accelerate -> DDP,
+    cvivit_trainer.py / phenaki_trainer.py): averaging gradients is data-parallel training only if every replica STARTS from the same weights.
+    `src` is a rank of `group`.  Returns the number of collectives."""
+    if _group_size(group) == 1 and not (force and dist.is_available() and dist.is_initialized()):
+        return 0
+    src_global = dist.get_global_rank(group, src) if group is not None else src
+    ts = [t for t in tensors if t is not None and t.numel()]
+    n = 0
+    for dtype in sorted({t.dtype for t in ts}, key=str):
+        same = [t for t in ts if t.dtype == dtype]
+        elems = max(1, int(bucket_mb * (1 << 20) / max(1, same[0].element_size())))
+        for idxs in bucket_plan([t.numel() for t in same], elems):
+            flat = torch.cat([same[i].detach().reshape(-1) for i in idxs])
+            dist.broadcast(flat, src=src_global, group=group)
+            off = 0
+            with torch.no_grad():
+                for i in idxs:
+                    k = same[i].numel()
+                    same[i].copy_(flat[off:off + k].view_as(same[i]))
+                    off += k
+            n += 1
+    return n
+
+
+def broadcast_module(module, src=0, group=None):
+    """parameters and buffers of `module` <- rank `src`'s (call once before training; packed-weight caches are dropped)"""
+    n = broadcast_parameters(list(module.parameters()) + list(module.buffers()), src=src, group=group)
+    if n:
+        from .attention import invalidate_packed
+        invalidate_packed(module)
+    return n
+
+
 def all_reduce_gradients(params, bucket_mb=64.0, average=True, group=None, force=False):
-    """in place: p.grad <- mean (or sum) over the ranks of p.grad, for every parameter in `params` that has a gradient.  Identical
+    """in place: p.grad <- mean (or sum) over the ranks of `group` of p.grad, for every parameter in `params` that has a gradient.  Identical
     parameter order on every rank is the caller's contract (as with DDP).  Returns the number of collectives issued.  force: run the
     collectives even in a one-rank group (diagnostics)."""
-    rank, ws = world()
+    ws = _group_size(group)
     grads = [p.grad for p in params if p.grad is not None and p.grad.numel()]
     if (ws == 1 and not (force and dist.is_available() and dist.is_initialized())) or not grads:
         return 0
@@ -139,18 +180,24 @@ def all_reduce_gradients(params, bucket_mb=64.0, average=True, group=None, force
 
 
 class GradientReducer:
-    """`all_reduce_gradients` OVERLAPPED with the backward pass: a bucket's all-reduce is started (async, on RCCL's own stream) the moment
-    the last of its parameters has received its gradient, while the remaining backward kernels keep the compute stream busy; `finish()` --
-    called between `loss.backward()` and `opt.step()` -- waits for the collectives in flight, reduces whatever is left (parameters that got
-    no gradient this step never complete their bucket) and writes the averaged gradients back.  Buckets are fixed at construction in REVERSE
-    parameter order (the order backward produces gradients in), so every rank issues the same collectives in the same order.
+    """`all_reduce_gradients` OVERLAPPED with the backward pass, on a pre-allocated **flat gradient arena**: every bucket is ONE contiguous f32
+    buffer and each parameter's `.grad` is a view into it, so a bucket's all-reduce runs IN PLACE on the gradients themselves -- no flatten copy
+    before the collective, no copy back after it (torch DDP's gradient_as_bucket_view).  A bucket's all-reduce is started (async, on RCCL's own
+    stream) the moment the last of its parameters has received its gradient, while the remaining backward kernels keep the compute stream
+    busy; `finish()` -- called between `loss.backward()` and `opt.step()` -- launches what backward left incomplete (parameters that got no
+    gradient this step contribute zeros and keep `.grad = None`), waits, and averages.  Buckets are fixed at construction in REVERSE parameter
+    order (the order backward produces gradients in), so every rank issues the same collectives in the same order.
+    With `zero_grad(set_to_none=False)` the views persist and backward accumulates straight into the arena (zero copies per step); after
+    `zero_grad(set_to_none=True)` autograd hands each parameter a fresh tensor, which the hook moves into its view (one copy, half of what
+    flatten + copy-back cost).  At construction the parameters (and `buffers=`) are broadcast from rank 0 of the group, as DDP does at wrap time:
+    the replicas must start from the same weights for the averaged gradient to be the data-parallel one.
 
-        reducer = GradientReducer(params)            # once
+        reducer = GradientReducer(params)            # once (collective: every rank must construct it)
         loss.backward(); reducer.finish(); opt.step()
         with reducer.no_sync(): loss.backward()      # gradient accumulation: no collectives for this backward
     """
 
-    def __init__(self, params, bucket_mb=64.0, average=True, group=None, force=False):
+    def __init__(self, params, bucket_mb=64.0, average=True, group=None, force=False, broadcast=True, buffers=()):
         """force: issue the collectives even in a one-rank group (diagnostics: the RCCL path on a single-GPU box)"""
         self.params = [p for p in params if p.requires_grad and p.numel()]
         self.average, self.group = average, group
@@ -159,12 +206,36 @@ class GradientReducer:
         bucket_elems = max(1, int(bucket_mb * (1 << 20) / 4))
         self.buckets = [[order[j] for j in idxs] for idxs in bucket_plan([self.params[i].numel() for i in order], bucket_elems)]
         self._bucket_of = {i: b for b, idxs in enumerate(self.buckets) for i in idxs}
+        # the arena: one flat f32 buffer per bucket (allocated on the parameters' device), one view per parameter
+        self.arena, self._views = [], [None] * len(self.params)
+        for idxs in self.buckets:
+            dev = self.params[idxs[0]].device
+            assert all(self.params[i].device == dev and self.params[i].dtype == torch.float32 for i in idxs), 'GradientReducer: f32 parameters on one device'
+            flat = torch.zeros(sum(self.params[i].numel() for i in idxs), device=dev, dtype=torch.float32)
+            off = 0
+            for i in idxs:
+                k = self.params[i].numel()
+                self._views[i] = flat[off:off + k].view_as(self.params[i])
+                off += k
+            self.arena.append(flat)
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._pending = []
         self._enabled = True
         self.collectives = 0
+        self.broadcasts = broadcast_parameters(self.params + list(buffers), group=group) if broadcast and self._active() and not force else 0
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
+
+    def _adopt(self, i):
+        """make parameter i's gradient the arena view (moving a freshly allocated gradient in); returns False when it has none"""
+        p, v = self.params[i], self._views[i]
+        g = p.grad
+        if g is None:
+            return False
+        if g.data_ptr() != v.data_ptr() or g.stride() != v.stride():
+            v.copy_(g)
+            p.grad = v
+        return True
 
     def _make_hook(self, i):
         def hook(_param):
@@ -174,40 +245,36 @@ class GradientReducer:
             if self._launched[b]:
                 raise RuntimeError('GradientReducer: a second backward reached a bucket that is already being reduced -- call finish() after every '
                                    'backward (or run the accumulation backwards under no_sync())')
+            self._adopt(i)
             self._ready[b] += 1
             if self._ready[b] == len(self.buckets[b]) and not self._launched[b]:
                 self._launch(b)
         return hook
 
     def _active(self):
-        return world()[1] > 1 or (self.force and dist.is_available() and dist.is_initialized())
+        return _group_size(self.group) > 1 or (self.force and dist.is_available() and dist.is_initialized())
 
     def _launch(self, b):
-        idxs = [i for i in self.buckets[b] if self.params[i].grad is not None]
         self._launched[b] = True
-        if not idxs:
-            return
-        flat = torch.cat([self.params[i].grad.reshape(-1).float() for i in idxs])
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._pending.append((idxs, flat, work))
+        have = [self._adopt(i) for i in self.buckets[b]]
+        for i, ok in zip(self.buckets[b], have):
+            if not ok:
+                self._views[i].zero_()              # no gradient on this rank this step: contributes zeros (another rank may have one)
+        work = dist.all_reduce(self.arena[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append((b, work))
         self.collectives += 1
 
     def finish(self):
-        """wait for the collectives in flight, reduce the incomplete buckets, write the (averaged) gradients back; returns #collectives"""
-        rank, ws = world()
+        """wait for the collectives in flight, reduce the incomplete buckets, average in place; returns #collectives"""
         if self._active() and self._enabled:
+            ws = _group_size(self.group)
             for b in range(len(self.buckets)):                  # in bucket order on every rank
                 if not self._launched[b]:
                     self._launch(b)
-            for idxs, flat, work in self._pending:
+            for b, work in self._pending:
                 work.wait()
-                if self.average:
-                    flat /= ws
-                off = 0
-                for i in idxs:
-                    g = self.params[i].grad
-                    g.copy_(flat[off:off + g.numel()].view_as(g))
-                    off += g.numel()
+                if self.average and ws > 1:
+                    self.arena[b].div_(ws)
         n = self.collectives
         self._pending.clear()
         self._ready = [0] * len(self.buckets)

@@ -63,7 +63,10 @@ def t5_encode_text(texts, name=DEFAULT_T5_NAME, output_device=None):
     hip = _HIP_ENCODERS.get(name)
     if hip is not None:
         from transformers import T5Tokenizer
-        tok = _MODELS.setdefault(('tok', name), T5Tokenizer.from_pretrained(name))
+        key = ('tok', name)
+        if key not in _MODELS:                       # load the sentencepiece model once, not on every call
+            _MODELS[key] = T5Tokenizer.from_pretrained(name)
+        tok = _MODELS[key]
         enc = tok.batch_encode_plus(texts, return_tensors='pt', padding='longest', max_length=MAX_LENGTH, truncation=True)
         device = next(hip.parameters()).device
         out = hip(enc.input_ids.to(device), enc.attention_mask.to(device))

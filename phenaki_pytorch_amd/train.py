@@ -446,6 +446,7 @@ class _VocabCrossEntropy(torch.autograd.Function):
         L.require_device(embeds, 'embeds')
         R, D = embeds.shape
         V = weight.shape[0]
+        assert V % 8 == 0 and D % 8 == 0, 'vocab_cross_entropy: vocabulary size and dim must be multiples of 8 (16-byte operand rows)'
         dev = embeds.device
         E = embeds.detach().float().contiguous()
         M = R if rows is None else rows.numel()
@@ -464,16 +465,16 @@ class _VocabCrossEntropy(torch.autograd.Function):
         loss_rows = torch.empty((M,), device=dev, dtype=torch.float32)
         lse = torch.empty((M,), device=dev, dtype=torch.float32)
         L.vocab_ce(dtype, partials, M, V, A, Wp, b, D, tg, rows, loss_rows, lse=lse)
-        ctx.save_for_backward(E, weight, b, tg, lse, rows)
+        # A (the gathered operand rows) and Wp (the packed vocabulary weight: 64-134 MB at V = 65 536) go through save_for_backward like the rest,
+        # so they are released when autograd frees the saved tensors and take part in its version checks
+        ctx.save_for_backward(E, weight, b, tg, lse, rows, A, Wp)
         ctx.dtype, ctx.slab, ctx.has_bias = dtype, slab, bias is not None
-        ctx.A, ctx.Wp = A, Wp
         return L.colsum(loss_rows.view(M, 1), M, 1, torch.empty((1,), device=dev, dtype=torch.float32), scale=1.0 / M).reshape(())
 
     @staticmethod
     def backward(ctx, grad_out):
-        E, weight, b, tg, lse, rows = ctx.saved_tensors
+        E, weight, b, tg, lse, rows, A, Wp = ctx.saved_tensors
         dtype, slab = ctx.dtype, ctx.slab
-        A, Wp = ctx.A, ctx.Wp
         R, D = E.shape
         M = A.shape[0]
         V = weight.shape[0]
@@ -704,7 +705,9 @@ def critic_forward_train(critic, x, *, text_mask=None, cond_drop_prob=None, cont
 def phenaki_loss(ph, videos=None, *, texts=None, video_codebook_ids=None, video_frame_mask=None, text_embeds=None, cond_drop_prob=None,
                  only_train_generator=False, only_train_critic=False, _draws=None):
     """phenaki_pytorch.py:562-687 with an autograd graph over the MaskGit / critic parameters (the C-ViViT and the T5 encoder are frozen there
-    too).  _draws (tests): dict(rand_step, perm_noise, gumbel_u) replaces the three random draws, as in `Phenaki.objective_value`."""
+    too).  _draws (tests): dict(rand_step, perm_noise, gumbel_u) replaces the three random draws, as in `Phenaki.objective_value`.
+    `cond_drop_prob` is accepted for signature compatibility and HAS NO EFFECT: the reference overwrites it with 0 before use
+    (phenaki_pytorch.py:594 shadows the argument), so classifier-free-guidance dropout never fires in its training step either."""
     from .phenaki import SelfCritic, TokenCritic
     assert not (only_train_generator and only_train_critic)
     assert not (only_train_critic and not exists(ph.critic)), 'only_train_critic needs a critic (Phenaki(critic=...) or self_token_critic=True)'

@@ -205,11 +205,16 @@ def _grad_worker(rank, ws, port, q):
     ok = ok and all(torch.allclose(p_.grad, b * sum(r + 1 for r in range(ws)), rtol=1e-6, atol=1e-7) for p_, b in zip(params, base))
     # the overlapped form: hooks start a bucket's all-reduce while backward is still producing the other gradients
     from phenaki_pytorch_amd.dist import GradientReducer
-    torch.manual_seed(11)
-    net = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.Tanh(), torch.nn.Linear(300, 300), torch.nn.Tanh(), torch.nn.Linear(300, 7))
+    mk = lambda: torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.Tanh(), torch.nn.Linear(300, 300), torch.nn.Tanh(), torch.nn.Linear(300, 7))
+    torch.manual_seed(11 + rank)                                   # the replicas are built from DIFFERENT seeds ...
+    net = mk()
     unused = torch.nn.Parameter(torch.zeros(9))                    # never receives a gradient: its bucket is flushed by finish()
     plist = list(net.parameters()) + [unused]
-    red = GradientReducer(plist, bucket_mb=0.05)
+    group = dist.new_group([0, 1])                                 # a caller-supplied group: its size (not the global world's) is the divisor
+    red = GradientReducer(plist, bucket_mb=0.05, group=group)
+    torch.manual_seed(11)
+    ok = ok and red.broadcasts >= 1 and all(torch.equal(a, b) for a, b in zip(net.parameters(), mk().parameters()))   # ... and start from rank 0's weights
+    ok = ok and all(p_.grad is None for p_ in plist)
     x = torch.randn(16, 40, generator=torch.Generator().manual_seed(100 + rank))
     with torch.enable_grad():
         net(x).square().mean().backward()
@@ -227,6 +232,11 @@ def _grad_worker(rank, ws, port, q):
             w_ += p_.grad / ws
     ok = ok and all(torch.allclose(a, b, rtol=1e-5, atol=1e-7) for a, b in zip(mine, want)) and unused.grad is None
     ok = ok and started_early >= 1 and nred == len(red.buckets) and red.collectives == 0
+    # the gradients live in the flat arena: every .grad is a view of its bucket's buffer (the all-reduce ran in place, no flatten / copy-back)
+    with torch.enable_grad():
+        net(x).square().mean().backward()                          # accumulates INTO the views (zero_grad(set_to_none=False) regime)
+    red.finish()
+    ok = ok and all(p_.grad.data_ptr() == v.data_ptr() for p_, v in zip(red.params, red._views) if p_.grad is not None)
     q.put((rank, bool(ok), ncoll))
     dist.destroy_process_group()
 
