@@ -801,6 +801,9 @@ def compact_line(full):
     if sm:
         line['sample'] = {'metric': sm['metric'], 'value': _r(sm['value'], 1), 'unit': sm['unit'], 'ms': _r(sm['seconds_per_sample_call'] * 1e3, 3),
                           'batch_per_gpu': sm['batch_per_gpu'], 'launch_mode': sm['launch_mode']}
+        for k in ('global_batch', 'collective', 'backend', 'nccl_version', 'all_gather_us', 'shard_bytes'):      # what moved the videos (N > 1)
+            if k in sm:
+                line['sample'][k] = _r(sm[k])
         if sm.get('roofline'):
             line['sample']['roofline_frac'] = _r(sm['roofline']['frac'])
             line['sample']['roofline_kernel'] = sm['roofline']['kernel']

@@ -54,6 +54,10 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, v);
 }
 
+// the in-memory element type of the attention operand images (Q^ / K^ / V^T) a GEMM operand type writes: bf16 -> bf16, bf16x3 -> bf16x3p
+template <typename T> struct ImageOf { typedef T type; };
+template <> struct ImageOf<bf16x3> { typedef bf16x3p type; };
+
 // ---- per-type fragment chunk -------------------------------------------------------------
 template <typename T> struct Frag;
 template <> struct Frag<bf16> { u32x4 v; };                 // 8 bf16
@@ -158,6 +162,15 @@ __device__ __forceinline__ void store4(bf16x3p* p, f32x4 v) {
     const float r2 = v[2] - __builtin_bit_cast(float, h1 << 16), r3 = v[3] - __builtin_bit_cast(float, h1 & 0xFFFF0000u);
     *reinterpret_cast<u32x2*>(blk + o) = u32x2{h0, h1};
     *reinterpret_cast<u32x2*>(blk + 64 + o) = u32x2{pack_bf2(r0, r1), pack_bf2(r2, r3)};
+}
+// one element of a pre-split image (the V^T scatter of the projection kernels): hi and lo as two 2-byte stores into the block's planes
+__device__ __forceinline__ void store_elem(bf16x3p* p, float v) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    char* blk = reinterpret_cast<char*>(a & ~(uintptr_t)127);
+    const int o = (int)(a & 127) >> 1;
+    const u16 h = f2bf(v);
+    *reinterpret_cast<u16*>(blk + o) = h;
+    *reinterpret_cast<u16*>(blk + 64 + o) = f2bf(v - bf2f(h));
 }
 __device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ void store4(bf16* p, f32x4 v) {

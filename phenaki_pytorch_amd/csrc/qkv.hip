@@ -1,7 +1,7 @@
-// pk_qkv_project (bf16): to_q and to_kv (reference attention.py:142-146) as ONE MFMA GEMM launch whose epilogue is the whole
+// pk_qkv_project (bf16 / split-bf16): to_q and to_kv (reference attention.py:142-146) as ONE MFMA GEMM launch whose epilogue is the whole
 // attention pre-processing of attention.py:146-157 -- head split, l2norm of every 64-wide head row, q_scale / k_scale,
 // the similarity scale folded into q, V stored transposed -- writing the operand images pk_attn_fwd consumes
-//   Qp [S][h][nq_pad][64]   Kp [S][h][nk_pad][64]   Vt [S][h][64][nk_pad]     (bf16)
+//   Qp [S][h][nq_pad][64]   Kp [S][h][nk_pad][64]   Vt [S][h][64][nk_pad]     (bf16; split-bf16: the pre-split bf16x3p images, common.hpp)
 // so the f32 q / kv matrices never exist in HBM and pk_attn_prep's two launches disappear.
 // Tile: 64 rows x 64 columns = ONE head, 4 waves stacked along the rows (wave tile 16 x 64): a wave holds whole head rows,
 // the l2 norm is a 16-value in-lane sum plus a 4-lane-group shuffle.  Main loop: gemm_dma.hpp (LDS-DMA ring of 2).
@@ -25,11 +25,14 @@ struct QkvArgs {
 // TM = 1: 64-row tiles (wave tile 16 x 64); TM = 2: 128-row tiles (wave tile 32 x 64) -- the kernel is bound by the L1 -> LDS fill path
 // (3456 tiles x 128 KB = 442 MB per launch at 2 x 8 x 576 rows) and a 128-row tile moves 24 KB per k-tile for the work of two 64-row
 // tiles (2 x 16 KB): a quarter less fill traffic, still 48 KB of LDS = 3 workgroups per CU
-template <int TM> using QkvTileT = GemmDma<bf16, TM, 4, 4, 1, 2, 128>;
+// T = bf16x3 (round 4): x rows are f32 and split in registers, the weights are host-split planes (gemm_core.hpp), the images are written pre-split
+// (store4 / store_elem of bf16x3p) -- the exact-f32 LayerNorm + to_q GEMM + to_kv GEMM + pk_attn_prep of that mode become this one launch.
+template <typename T, int TM> using QkvTileT = GemmDma<T, TM, 4, 4, 1, 2, 128>;
 
-template <int TM>
+template <typename T, int TM>
 __global__ __launch_bounds__(256) void qkv_project_kernel(const QkvArgs a) {
-    using QkvTile = QkvTileT<TM>;
+    using QkvTile = QkvTileT<T, TM>;
+    typedef typename ImageOf<T>::type TI;
     constexpr int BM = 64 * TM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware tile map (see gemm.hip): XCD x owns a contiguous chunk of row tiles and walks all column tiles for it
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256) void qkv_project_kernel(const QkvArgs a) {
         const size_t sh = (size_t)s * a.h + hh;
         if (kind == 2) {
             // V^T: element (key = pos, d) -> Vt[sh][d][pos]
-            bf16* vt = reinterpret_cast<bf16*>(a.Vt) + sh * 64 * a.nk_pad + pos;
+            TI* vt = reinterpret_cast<TI*>(a.Vt) + sh * 64 * a.nk_pad + pos;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -109,8 +112,8 @@ __global__ __launch_bounds__(256) void qkv_project_kernel(const QkvArgs a) {
         ss += __shfl_xor(ss, 16, 64);
         ss += __shfl_xor(ss, 32, 64);
         const float inv = (kind == 0 ? a.scale : 1.0f) / fmaxf(sqrtf(ss), 1e-12f);        // F.normalize eps = 1e-12
-        bf16* dst = kind == 0 ? reinterpret_cast<bf16*>(a.Qp) + (sh * a.nq_pad + pos) * 64
-                              : reinterpret_cast<bf16*>(a.Kp) + (sh * a.nk_pad + pos) * 64;
+        TI* dst = kind == 0 ? reinterpret_cast<TI*>(a.Qp) + (sh * a.nq_pad + pos) * 64
+                            : reinterpret_cast<TI*>(a.Kp) + (sh * a.nk_pad + pos) * 64;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x4 v = acc[i][j];
@@ -124,35 +127,47 @@ __global__ __launch_bounds__(256) void qkv_project_kernel(const QkvArgs a) {
 }  // namespace pk
 using namespace pk;
 
-// bf16 only.  xq [M][ld] = LayerNorm(x) rows, xkv [M][ld] = x rows (or NULL: query side only); M = S * nseq.
+// dtype 1: bf16 (xq / xkv / weights bf16, K-tile 64); dtype 2: split-bf16 (xq / xkv f32 rows, weights = host-split planes counted in 4-byte
+// units, K-tile 32, images written as bf16x3p).  xq [M][ld] = LayerNorm(x) rows, xkv [M][ld] = x rows (or NULL: query side only); M = S * nseq.
 // q_ln_s != NULL: the LayerNorm is folded into to_q -- xq holds the un-normalised rows, wq = gamma (.) Wq, q_ln_s its row sums.
-extern "C" int pk_qkv_project(const void* xq, const void* xkv, int ld, const void* wq, const void* wkv, int ldw,
-                              int S, int nseq, int h, int K, const float* q_scale, const float* k_scale, float scale,
-                              void* Qp, void* Kp, void* Vt, int nq_pad, int nk_pad, const float* q_ln_s, void* stream) {
-    if (!xq || !wq || !q_scale || !Qp || S <= 0 || nseq <= 0 || h <= 0 || K <= 0) return PK_EINVAL;
-    if (xkv && (!wkv || !k_scale || !Kp || !Vt)) return PK_EINVAL;
-    if (nq_pad < nseq || (xkv && nk_pad < nseq)) return PK_EINVAL;
-    auto mis = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) != 0; };
-    if ((K & 7) || (ld & 7) || (ldw & 7) || mis(xq) || mis(wq) || mis(q_scale) || mis(Qp) ||
-        (xkv && (mis(xkv) || mis(wkv) || mis(k_scale) || mis(Kp) || (nk_pad & 3)))) return PK_EALIGN;
-    if (ldw < (K + 63) / 64 * 64) return PK_EINVAL;             // W zero-padded along K to the 64-wide k-tile
-    const long M = (long)S * nseq;
-    if ((size_t)M * ld * 2 >= 0xFFFFFFF0ull) return PK_EINVAL;
-    if (q_ln_s && mis(q_ln_s)) return PK_EALIGN;
-    QkvArgs a{xq, xkv, wq, wkv, ld, ldw, (int)M, K, h, nseq, q_scale, k_scale, scale, Qp, Kp, Vt, nq_pad, nk_pad, 0, q_ln_s};
-    const int NT = xkv ? 3 * h : h;
+template <typename T>
+static int qkv_project_launch(const QkvArgs& a, int NT, hipStream_t st) {
     // 128-row tiles once there are >= 4 of them per CU (tuning knob PK_QKV_TM: 1 / 2).  tools/qkv_bench.py, n = 576, 8 heads, K = 512:
     // S = 16 (1728 tiles of 128 rows) 29.4 vs 35.2 us; S = 8 (864) 18.4 vs 17.7 us; S = 4: 11.5 vs 11.2 us
     static const int tm_env = [] { const char* e = getenv("PK_QKV_TM"); return e ? atoi(e) : 0; }();
+    const long M = a.M;
     const long tiles128 = ((M + 127) / 128) * NT;
     const bool big = tm_env ? tm_env == 2 : tiles128 >= 4 * 256;
     if (big) {
         const int MT = (int)((M + 127) / 128);
-        hipLaunchKernelGGL(qkv_project_kernel<2>, dim3(8 * ((MT + 7) / 8) * NT), dim3(256), QkvTileT<2>::SMEM, reinterpret_cast<hipStream_t>(stream), a);
+        hipLaunchKernelGGL((qkv_project_kernel<T, 2>), dim3(8 * ((MT + 7) / 8) * NT), dim3(256), QkvTileT<T, 2>::SMEM, st, a);
     } else {
         const int MT = (int)((M + 63) / 64);
-        hipLaunchKernelGGL(qkv_project_kernel<1>, dim3(8 * ((MT + 7) / 8) * NT), dim3(256), QkvTileT<1>::SMEM, reinterpret_cast<hipStream_t>(stream), a);
+        hipLaunchKernelGGL((qkv_project_kernel<T, 1>), dim3(8 * ((MT + 7) / 8) * NT), dim3(256), QkvTileT<T, 1>::SMEM, st, a);
     }
     PK_CHECK_LAUNCH();
     return PK_OK;
+}
+
+extern "C" int pk_qkv_project(int dtype, const void* xq, const void* xkv, int ld, const void* wq, const void* wkv, int ldw,
+                              int S, int nseq, int h, int K, const float* q_scale, const float* k_scale, float scale,
+                              void* Qp, void* Kp, void* Vt, int nq_pad, int nk_pad, const float* q_ln_s, void* stream) {
+    if (dtype != 1 && dtype != 2) return PK_EINVAL;
+    if (!xq || !wq || !q_scale || !Qp || S <= 0 || nseq <= 0 || h <= 0 || K <= 0) return PK_EINVAL;
+    if (xkv && (!wkv || !k_scale || !Kp || !Vt)) return PK_EINVAL;
+    if (nq_pad < nseq || (xkv && nk_pad < nseq)) return PK_EINVAL;
+    auto mis = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) != 0; };
+    const int q = dtype == 1 ? 7 : 3, bk = dtype == 1 ? 64 : 32, esz = dtype == 1 ? 2 : 4;
+    if ((K & q) || (ld & q) || (ldw & q) || mis(xq) || mis(wq) || mis(q_scale) || mis(Qp) ||
+        (xkv && (mis(xkv) || mis(wkv) || mis(k_scale) || mis(Kp) || (nk_pad & 3)))) return PK_EALIGN;
+    if (dtype == 2 && ((nk_pad & 31) || (reinterpret_cast<uintptr_t>(Qp) & 127) || (xkv && ((reinterpret_cast<uintptr_t>(Kp) | reinterpret_cast<uintptr_t>(Vt)) & 127))))
+        return PK_EALIGN;                                       // pre-split images: 128-byte blocks of 32 elements
+    if (ldw < (K + bk - 1) / bk * bk) return PK_EINVAL;         // W zero-padded along K to the k-tile
+    const long M = (long)S * nseq;
+    if ((size_t)M * ld * esz >= 0xFFFFFFF0ull) return PK_EINVAL;
+    if (q_ln_s && mis(q_ln_s)) return PK_EALIGN;
+    QkvArgs a{xq, xkv, wq, wkv, ld, ldw, (int)M, K, h, nseq, q_scale, k_scale, scale, Qp, Kp, Vt, nq_pad, nk_pad, 0, q_ln_s};
+    const int NT = xkv ? 3 * h : h;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return dtype == 1 ? qkv_project_launch<bf16>(a, NT, st) : qkv_project_launch<bf16x3>(a, NT, st);
 }

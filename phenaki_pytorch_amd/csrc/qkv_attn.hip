@@ -1,4 +1,4 @@
-// pk_qkv_attn (bf16): a whole short-sequence self-attention block of the C-ViViT transformers (reference attention.py:142-182;
+// pk_qkv_attn (bf16 / split-bf16): a whole short-sequence self-attention block of the C-ViViT transformers (reference attention.py:142-182;
 // the spatial layers n = 64 with the continuous position bias, cvivit.py:460-466, and the causal temporal layers n = 9..10 with
 // ALiBi, cvivit.py:468-472) in ONE launch per layer:
 //   to_q / to_kv projections (MFMA, LDS-DMA ring)  ->  l2norm, q_scale / k_scale, similarity scale  ->  softmax(q k^T + bias) v
@@ -10,6 +10,9 @@
 // Two GEMM passes over the rows (q: 64 x 64 x K; k|v: 64 x 128 x K) on one 2-stage ring whose dead stages also stage q^ / k^ / v^T:
 // 48 KB, 3 workgroups per CU.
 // Roofline: MFMA (2 * R * 192 * K flops per workgroup) -- in practice bound by the L1 -> LDS fill rate like every short-K GEMM here.
+// T = bf16x3 (round 4, the parity-grade mode): x rows f32 (split in registers by the main loop), weights host-split; q^ / k^ / v^T are staged
+// as TWO bf16 planes (hi image + lo image 8 KB apart, the same slot swizzle in both), every attention product is three MFMAs (mma_split),
+// P is split in registers, O is written f32.  Same 48 KB of LDS.  Replaces that mode's LayerNorm + to_q + to_kv + pk_attn_prep + pk_attn_fwd.
 #include "gemm_dma.hpp"
 
 namespace pk {
@@ -28,15 +31,45 @@ struct QkvAttnArgs {
     const float* q_ln_s;                    // LayerNorm folded into to_q (see pk_qkv_project): xq = the un-normalised rows, wq = gamma (.) Wq
 };
 
-using QaTile = GemmDma<bf16, 1, 4, 4, 1, 2, 128>;          // 64 rows x 64 columns (one head), 4 waves stacked on the rows
-using QaKvTile = GemmDma<bf16, 1, 8, 4, 1, 2, 128>;        // 64 rows x 128 columns: the head's k | v columns in ONE pass over x
-constexpr int QA_SMEM = QaKvTile::SMEM;                   // 48 KB: the ring of the k|v pass; q^ / k^ / v^T staging aliases it
+template <typename T> using QaTile = GemmDma<T, 1, 4, 4, 1, 2, 128>;          // 64 rows x 64 columns (one head), 4 waves stacked on the rows
+template <typename T> using QaKvTile = GemmDma<T, 1, 8, 4, 1, 2, 128>;        // 64 rows x 128 columns: the head's k | v columns in ONE pass over x
+constexpr int QA_SMEM = QaKvTile<bf16>::SMEM;             // 48 KB (either type): the ring of the k|v pass; q^ / k^ / v^T staging aliases it
+static_assert(QaKvTile<bf16x3>::SMEM == QA_SMEM, "the split-bf16 ring has the same bytes");
+
+// staged images: one [64 rows][128 B] bf16 plane (bf16) or two of them 8 KB apart (split-bf16: hi, lo)
+constexpr int QA_PLANE = 8192;
+template <typename T> struct QaImg { static constexpr int PLANES = 1; };
+template <> struct QaImg<bf16x3> { static constexpr int PLANES = 2; };
+// 4 consecutive elements of a staged row: `off` = row * 128 + (slot << 4) + half * 8
+__device__ __forceinline__ void qa_put4(bf16, char* img, int off, f32x4 v) {
+    *reinterpret_cast<u32x2*>(img + off) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+}
+__device__ __forceinline__ void qa_put4(bf16x3, char* img, int off, f32x4 v) {
+    const uint32_t h0 = pack_bf2(v[0], v[1]), h1 = pack_bf2(v[2], v[3]);
+    const float r0 = v[0] - __builtin_bit_cast(float, h0 << 16), r1 = v[1] - __builtin_bit_cast(float, h0 & 0xFFFF0000u);
+    const float r2 = v[2] - __builtin_bit_cast(float, h1 << 16), r3 = v[3] - __builtin_bit_cast(float, h1 & 0xFFFF0000u);
+    *reinterpret_cast<u32x2*>(img + off) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(img + QA_PLANE + off) = u32x2{pack_bf2(r0, r1), pack_bf2(r2, r3)};
+}
+__device__ __forceinline__ void qa_put1(bf16, char* img, int off, float v) { *reinterpret_cast<u16*>(img + off) = f2bf(v); }
+__device__ __forceinline__ void qa_put1(bf16x3, char* img, int off, float v) {
+    const u16 h = f2bf(v);
+    *reinterpret_cast<u16*>(img + off) = h;
+    *reinterpret_cast<u16*>(img + QA_PLANE + off) = f2bf(v - bf2f(h));
+}
+// one fragment chunk (8 elements, one 16-byte slot) of a staged row
+__device__ __forceinline__ void qa_get(Frag<bf16>& f, const char* img, int off) { f.v = *reinterpret_cast<const u32x4*>(img + off); }
+__device__ __forceinline__ void qa_get(Frag<bf16x3>& f, const char* img, int off) {
+    f.hi = *reinterpret_cast<const u32x4*>(img + off);
+    f.lo = *reinterpret_cast<const u32x4*>(img + QA_PLANE + off);
+}
 
 // K tile rows permuted / swizzled exactly like pk_attn_fwd's LDS kernel (attn.hip): see attn_kperm / attn_ksw there
 __device__ __forceinline__ int qa_kperm(int f, int i) { return (f >> 1) * 32 + (i >> 2) * 8 + (f & 1) * 4 + (i & 3); }
 __device__ __forceinline__ int qa_ksw(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
 
 // q^ rows of one 64-row tile of head hh -> Qs [row][64] bf16 (16-B slot ^ (row & 7)); p.A / p.W / p.N / strides set by the caller
+template <typename T>
 __device__ __forceinline__ void qa_project_q(const GemmOperands& p, int M, int m0, int hh, int K, const float* q_scale, float scale,
                                              const float* q_ln_s, char* smem, char* Qs) {
     const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
@@ -46,7 +79,7 @@ __device__ __forceinline__ void qa_project_q(const GemmOperands& p, int M, int m
     for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0, 0, 0, 0};
     if (q_ln_s) {                                                   // LayerNorm folded into to_q; the l2norm cancels rstd: row mean and s suffice
         float rsum[1], rsq[1];
-        (void)QaTile::run_stats<1>(p, M, m0, hh * 64, smem, acc, rsum, rsq);
+        (void)QaTile<T>::template run_stats<1>(p, M, m0, hh * 64, smem, acc, rsum, rsq);
         const float mean = rsum[0] / (float)K;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -55,7 +88,7 @@ __device__ __forceinline__ void qa_project_q(const GemmOperands& p, int M, int m
             for (int r = 0; r < 4; ++r) acc[0][j][r] -= mean * s4[r];
         }
     } else {
-        (void)QaTile::run(p, M, m0, hh * 64, smem, acc);
+        (void)QaTile<T>::run(p, M, m0, hh * 64, smem, acc);
     }
     float ss = 0.f;
 #pragma unroll
@@ -72,17 +105,19 @@ __device__ __forceinline__ void qa_project_q(const GemmOperands& p, int M, int m
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] *= inv * sc[r];
         const int slot = (2 * j + (g >> 1)) ^ (rq & 7);
-        *reinterpret_cast<u32x2*>(Qs + rq * 128 + (slot << 4) + (g & 1) * 8) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        qa_put4(T{}, Qs, rq * 128 + (slot << 4) + (g & 1) * 8, v);
     }
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void qkv_attn_kernel(const QkvAttnArgs a) {
     // LDS: ONE 48 KB ring.  q pass (32 KB of it) -> q^ staged in the dead ring -> each lane pulls its two q^ fragments into 8 VGPRs ->
     // k|v pass (48 KB) -> k^ and v^T staged in the dead ring -> attention.  48 KB per workgroup: 3 workgroups per CU.
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NPL = QaImg<T>::PLANES;
     char* Qs = smem;
     char* Ks = smem;
-    char* Vts = smem + 8192;
+    char* Vts = smem + NPL * QA_PLANE;
     // block -> (row tile, head): the 8 heads of a row tile run on ONE XCD (block b is observed on XCD b % 8; speed only), so the
     // two A tiles they all read are fetched over the fabric once
     const int R = a.spt * a.n;
@@ -105,11 +140,11 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(const QkvAttnArgs a) {
 
     // ---- q^ = l2norm(LN(x) Wq^T) * q_scale * scale  -> Qs [row][64] bf16 (16-B slot ^ (row & 7)) -> this lane's fragments
     p.A = a.xq; p.W = a.wq; p.N = a.h * 64;
-    qa_project_q(p, M, m0, hh, a.K, a.q_scale, a.scale, a.q_ln_s, smem, Qs);
-    Frag<bf16> fq[2];
+    qa_project_q<T>(p, M, m0, hh, a.K, a.q_scale, a.scale, a.q_ln_s, smem, Qs);
+    Frag<T> fq[2];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // a wave reads only rows its own lanes wrote
 #pragma unroll
-    for (int c = 0; c < 2; ++c) fq[c].v = *reinterpret_cast<const u32x4*>(Qs + rq * 128 + (((c * 4 + g) ^ (rq & 7)) << 4));
+    for (int c = 0; c < 2; ++c) qa_get(fq[c], Qs, rq * 128 + (((c * 4 + g) ^ (rq & 7)) << 4));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                      // every wave holds its q^ : the ring may be refilled
 
@@ -120,7 +155,7 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(const QkvAttnArgs a) {
         for (int j = 0; j < 8; ++j) acc[0][j] = f32x4{0, 0, 0, 0};
         p.A = a.xkv; p.W = a.wkv; p.N = 2 * a.h * 64;
         p.w_gap_from = 64; p.w_gap_rows = (a.h - 1) * 64;
-        (void)QaKvTile::run(p, M, m0, hh * 64, smem, acc);              // ends with a barrier: the ring is dead
+        (void)QaKvTile<T>::run(p, M, m0, hh * 64, smem, acc);           // ends with a barrier: the ring is dead
         // k^ = l2norm(k) * k_scale -> Ks [key][64] bf16, slot ^ qa_ksw(key)
         float ss = 0.f;
 #pragma unroll
@@ -137,7 +172,7 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(const QkvAttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] *= inv * sc[r];
             const int slot = (2 * j + (g >> 1)) ^ qa_ksw(rq);
-            *reinterpret_cast<u32x2*>(Ks + rq * 128 + (slot << 4) + (g & 1) * 8) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            qa_put4(T{}, Ks, rq * 128 + (slot << 4) + (g & 1) * 8, v);
         }
         // v -> V^T [dim][64 keys] bf16, slot ^ (dim & 7)
 #pragma unroll
@@ -145,7 +180,7 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(const QkvAttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int d = j * 16 + g * 4 + r;
-                *reinterpret_cast<u16*>(Vts + d * 128 + ((((rq >> 3) ^ (d & 7))) << 4) + (rq & 7) * 2) = f2bf(acc[0][4 + j][r]);
+                qa_put1(T{}, Vts, d * 128 + ((((rq >> 3) ^ (d & 7))) << 4) + (rq & 7) * 2, acc[0][4 + j][r]);
             }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -160,8 +195,8 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(const QkvAttnArgs a) {
         const int krow = qa_kperm(f, lr);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            Frag<bf16> fk;
-            fk.v = *reinterpret_cast<const u32x4*>(Ks + krow * 128 + (((c * 4 + g) ^ qa_ksw(krow)) << 4));
+            Frag<T> fk;
+            qa_get(fk, Ks, krow * 128 + (((c * 4 + g) ^ qa_ksw(krow)) << 4));
             st[f] = mma(fk, fq[c], st[f]);
         }
     }
@@ -212,20 +247,22 @@ __global__ __launch_bounds__(256) void qkv_attn_kernel(const QkvAttnArgs a) {
     for (int df = 0; df < 4; ++df) o[df] = f32x4{0, 0, 0, 0};
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) {
-        Frag<bf16> fp;
-        fp.v = u32x4{pack_bf2(pr[kc * 8 + 0], pr[kc * 8 + 1]), pack_bf2(pr[kc * 8 + 2], pr[kc * 8 + 3]),
-                     pack_bf2(pr[kc * 8 + 4], pr[kc * 8 + 5]), pack_bf2(pr[kc * 8 + 6], pr[kc * 8 + 7])};
+        Frag<T> fp;
+        {
+            const float p8[8] = {pr[kc * 8 + 0], pr[kc * 8 + 1], pr[kc * 8 + 2], pr[kc * 8 + 3], pr[kc * 8 + 4], pr[kc * 8 + 5], pr[kc * 8 + 6], pr[kc * 8 + 7]};
+            frag_from_f32(fp, p8);
+        }
 #pragma unroll
         for (int df = 0; df < 4; ++df) {
             const int d = df * 16 + lr;
-            Frag<bf16> fv;
-            fv.v = *reinterpret_cast<const u32x4*>(Vts + d * 128 + (((kc * 4 + g) ^ (d & 7)) << 4));
+            Frag<T> fv;
+            qa_get(fv, Vts, d * 128 + (((kc * 4 + g) ^ (d & 7)) << 4));
             o[df] = mma(fv, fp, o[df]);
         }
     }
     if (!qvalid) return;
     const float inv = 1.0f / ls;
-    bf16* orow = reinterpret_cast<bf16*>(a.O) + (size_t)(m0 + rq) * a.ldo + hh * 64;
+    T* orow = reinterpret_cast<T*>(a.O) + (size_t)(m0 + rq) * a.ldo + hh * 64;
 #pragma unroll
     for (int df = 0; df < 4; ++df) store4(orow + df * 16 + g * 4, o[df] * inv);
 }
@@ -244,11 +281,13 @@ struct QAttnCachedArgs {
     void* O; int ldo;
 };
 
-template <bool NK64>
+template <typename T, bool NK64>
 __global__ __launch_bounds__(256) void q_attn_cached_kernel(const QAttnCachedArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];       // [ring 32 KB | Qs 8 KB | Ks 8 KB]; V^T reuses the ring
-    char* Qs = smem + QaTile::SMEM;
-    char* Ks = Qs + 8192;
+    // [ring 32 KB | Qs | Ks]  (Qs / Ks: 8 KB each for bf16, 16 KB = two planes each for split-bf16); V^T reuses the dead ring
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NPL = QaImg<T>::PLANES;
+    char* Qs = smem + QaTile<T>::SMEM;
+    char* Ks = Qs + NPL * QA_PLANE;
     char* Vts = smem;
     const int M = a.S * a.n;
     const int tiles = M / 64;
@@ -268,31 +307,52 @@ __global__ __launch_bounds__(256) void q_attn_cached_kernel(const QAttnCachedArg
     p.plain_map = 0; p.krot = 0;
     p.w_gap_from = 0; p.w_gap_rows = 0;
     p.A = a.xq; p.W = a.wq; p.N = a.h * 64;
-    qa_project_q(p, M, m0, hh, a.K, a.q_scale, a.scale, a.q_ln_s, smem, Qs);      // its main loop ends with a barrier: the ring is dead
+    qa_project_q<T>(p, M, m0, hh, a.K, a.q_scale, a.scale, a.q_ln_s, smem, Qs);   // its main loop ends with a barrier: the ring is dead
 
     // K^ [key][64] -> Ks (slot ^ qa_ksw(key)), V^T [dim][keys] -> Vts (64-key rows of 128 B, slot ^ (dim & 7)); keys >= nk_pad: zeros
     {
         const size_t sh = (size_t)s * a.h + hh;
-        const int row = threadIdx.x >> 2, part = threadIdx.x & 3;          // 64 rows x 4 parts of 2 slots (32 B)
+        const int row = threadIdx.x >> 2, part = threadIdx.x & 3;          // 64 rows x 4 parts
         const u32x4 zero = u32x4{0, 0, 0, 0};
-        const bf16* krow = reinterpret_cast<const bf16*>(a.Kp) + (sh * a.nk_pad + row) * 64;
-        const bf16* vrow = reinterpret_cast<const bf16*>(a.Vt) + (sh * 64 + row) * a.nk_pad;
+        if constexpr (NPL == 1) {
+            const bf16* krow = reinterpret_cast<const bf16*>(a.Kp) + (sh * a.nk_pad + row) * 64;
+            const bf16* vrow = reinterpret_cast<const bf16*>(a.Vt) + (sh * 64 + row) * a.nk_pad;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int slot = part * 2 + q;
-            const u32x4 kv = row < a.nk_pad ? *reinterpret_cast<const u32x4*>(krow + slot * 8) : zero;
-            *reinterpret_cast<u32x4*>(Ks + row * 128 + ((slot ^ qa_ksw(row)) << 4)) = kv;
-            const u32x4 vv = slot * 8 < a.nk_pad ? *reinterpret_cast<const u32x4*>(vrow + slot * 8) : zero;     // nk_pad % 32 == 0
-            *reinterpret_cast<u32x4*>(Vts + row * 128 + ((slot ^ (row & 7)) << 4)) = vv;
+            for (int q = 0; q < 2; ++q) {
+                const int slot = part * 2 + q;
+                const u32x4 kv = row < a.nk_pad ? *reinterpret_cast<const u32x4*>(krow + slot * 8) : zero;
+                *reinterpret_cast<u32x4*>(Ks + row * 128 + ((slot ^ qa_ksw(row)) << 4)) = kv;
+                const u32x4 vv = slot * 8 < a.nk_pad ? *reinterpret_cast<const u32x4*>(vrow + slot * 8) : zero;     // nk_pad % 32 == 0
+                *reinterpret_cast<u32x4*>(Vts + row * 128 + ((slot ^ (row & 7)) << 4)) = vv;
+            }
+        } else {
+            // pre-split images (common.hpp bf16x3p): a row is 128-byte blocks of 32 elements, [hi x 32 | lo x 32]; 16-byte piece sp of a row:
+            // block = sp >> 3, plane = (sp >> 2) & 1, position inside the plane's 64 bytes = sp & 3  ->  staged slot block * 4 + (sp & 3)
+            const char* krow = reinterpret_cast<const char*>(a.Kp) + (sh * a.nk_pad + row) * 256;
+            const char* vrow = reinterpret_cast<const char*>(a.Vt) + (sh * 64 + row) * (size_t)a.nk_pad * 4;
+            u32x4 kv[4], vv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                                  // loads first, then the LDS stores
+                const int sp = part * 4 + q;
+                kv[q] = row < a.nk_pad ? *reinterpret_cast<const u32x4*>(krow + sp * 16) : zero;
+                vv[q] = (sp >> 3) * 32 < a.nk_pad ? *reinterpret_cast<const u32x4*>(vrow + sp * 16) : zero;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int sp = part * 4 + q;
+                const int plane = (sp >> 2) & 1, slot = (sp >> 3) * 4 + (sp & 3);
+                *reinterpret_cast<u32x4*>(Ks + plane * QA_PLANE + row * 128 + ((slot ^ qa_ksw(row)) << 4)) = kv[q];
+                *reinterpret_cast<u32x4*>(Vts + plane * QA_PLANE + row * 128 + ((slot ^ (row & 7)) << 4)) = vv[q];
+            }
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     constexpr int NF = NK64 ? 4 : 2;                              // 16-key blocks that can hold real keys
-    Frag<bf16> fq[2];
+    Frag<T> fq[2];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) fq[c].v = *reinterpret_cast<const u32x4*>(Qs + rq * 128 + (((c * 4 + g) ^ (rq & 7)) << 4));
+    for (int c = 0; c < 2; ++c) qa_get(fq[c], Qs, rq * 128 + (((c * 4 + g) ^ (rq & 7)) << 4));
     f32x4 st[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
@@ -300,8 +360,8 @@ __global__ __launch_bounds__(256) void q_attn_cached_kernel(const QAttnCachedArg
         const int krow = qa_kperm(f, lr);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            Frag<bf16> fk;
-            fk.v = *reinterpret_cast<const u32x4*>(Ks + krow * 128 + (((c * 4 + g) ^ qa_ksw(krow)) << 4));
+            Frag<T> fk;
+            qa_get(fk, Ks, krow * 128 + (((c * 4 + g) ^ qa_ksw(krow)) << 4));
             st[f] = mma(fk, fq[c], st[f]);
         }
     }
@@ -331,19 +391,21 @@ __global__ __launch_bounds__(256) void q_attn_cached_kernel(const QAttnCachedArg
     for (int df = 0; df < 4; ++df) o[df] = f32x4{0, 0, 0, 0};
 #pragma unroll
     for (int kc = 0; kc < NF / 2; ++kc) {
-        Frag<bf16> fp;
-        fp.v = u32x4{pack_bf2(pr[kc * 8 + 0], pr[kc * 8 + 1]), pack_bf2(pr[kc * 8 + 2], pr[kc * 8 + 3]),
-                     pack_bf2(pr[kc * 8 + 4], pr[kc * 8 + 5]), pack_bf2(pr[kc * 8 + 6], pr[kc * 8 + 7])};
+        Frag<T> fp;
+        {
+            const float p8[8] = {pr[kc * 8 + 0], pr[kc * 8 + 1], pr[kc * 8 + 2], pr[kc * 8 + 3], pr[kc * 8 + 4], pr[kc * 8 + 5], pr[kc * 8 + 6], pr[kc * 8 + 7]};
+            frag_from_f32(fp, p8);
+        }
 #pragma unroll
         for (int df = 0; df < 4; ++df) {
             const int d = df * 16 + lr;
-            Frag<bf16> fv;
-            fv.v = *reinterpret_cast<const u32x4*>(Vts + d * 128 + (((kc * 4 + g) ^ (d & 7)) << 4));
+            Frag<T> fv;
+            qa_get(fv, Vts, d * 128 + (((kc * 4 + g) ^ (d & 7)) << 4));
             o[df] = mma(fv, fp, o[df]);
         }
     }
     const float inv = 1.0f / ls;
-    bf16* orow = reinterpret_cast<bf16*>(a.O) + (size_t)(m0 + rq) * a.ldo + hh * 64;
+    T* orow = reinterpret_cast<T*>(a.O) + (size_t)(m0 + rq) * a.ldo + hh * 64;
 #pragma unroll
     for (int df = 0; df < 4; ++df) store4(orow + df * 16 + g * 4, o[df] * inv);
 }
@@ -351,19 +413,22 @@ __global__ __launch_bounds__(256) void q_attn_cached_kernel(const QAttnCachedArg
 }  // namespace pk
 using namespace pk;
 
-// bf16 only.  xq [S*n][ld] = LayerNorm(x), xkv [S*n][ld] = x (both bf16); wq [h*64][ldw], wkv [2*h*64][ldw] bf16 with K zero-padded
-// to a multiple of 64; bias [h][n][n] f32 (or NULL), slopes [h] with causal; O [S*n][ldo] bf16 receives softmax(q k^T + bias) v
-// with the heads merged (column hh*64 + d).  n <= 64, no null keys, no key mask.  q_ln_s != NULL: LayerNorm folded into to_q (xq = x).
-extern "C" int pk_qkv_attn(const void* xq, const void* xkv, int ld, const void* wq, const void* wkv, int ldw, int S, int n, int h,
+// dtype 1: bf16 -- xq [S*n][ld] = LayerNorm(x), xkv [S*n][ld] = x (both bf16); wq [h*64][ldw], wkv [2*h*64][ldw] bf16 with K zero-padded to a
+// multiple of 64; O bf16.  dtype 2: split-bf16 -- xq / xkv f32 rows, weights = host-split planes (4-byte units, K padded to 32), O f32.
+// bias [h][n][n] f32 (or NULL), slopes [h] with causal; O [S*n][ldo] receives softmax(q k^T + bias) v with the heads merged (column hh*64 + d).
+// n <= 64, no null keys, no key mask.  q_ln_s != NULL: LayerNorm folded into to_q (xq = x).
+extern "C" int pk_qkv_attn(int dtype, const void* xq, const void* xkv, int ld, const void* wq, const void* wkv, int ldw, int S, int n, int h,
                            int K, const float* q_scale, const float* k_scale, float scale, const float* bias, long bias_hstride,
                            int bias_ld, const float* slopes, int causal, void* O, int ldo, const float* q_ln_s, void* stream) {
+    if (dtype != 1 && dtype != 2) return PK_EINVAL;
     if (!xq || !xkv || !wq || !wkv || !q_scale || !k_scale || !O || S <= 0 || n <= 0 || n > 64 || h <= 0 || K <= 0) return PK_EINVAL;
     auto mis = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) != 0; };
-    if ((K & 7) || (ld & 7) || (ldw & 7) || (ldo & 3) || mis(xq) || mis(xkv) || mis(wq) || mis(wkv) || mis(q_scale) || mis(k_scale) ||
-        (reinterpret_cast<uintptr_t>(O) & 7) || (bias && mis(bias))) return PK_EALIGN;
-    if (ldw < (K + 63) / 64 * 64) return PK_EINVAL;             // W zero-padded along K to the 64-wide k-tile
+    const int q = dtype == 1 ? 7 : 3, bk = dtype == 1 ? 64 : 32, esz = dtype == 1 ? 2 : 4;
+    if ((K & q) || (ld & q) || (ldw & q) || (ldo & 3) || mis(xq) || mis(xkv) || mis(wq) || mis(wkv) || mis(q_scale) || mis(k_scale) ||
+        (reinterpret_cast<uintptr_t>(O) & (dtype == 1 ? 7 : 15)) || (bias && mis(bias))) return PK_EALIGN;
+    if (ldw < (K + bk - 1) / bk * bk) return PK_EINVAL;         // W zero-padded along K to the k-tile
     const long M = (long)S * n;
-    if ((size_t)M * ld * 2 >= 0xFFFFFFF0ull || (size_t)2 * h * 64 * ldw * 2 >= 0xFFFFFFF0ull) return PK_EINVAL;
+    if ((size_t)M * ld * esz >= 0xFFFFFFF0ull || (size_t)2 * h * 64 * ldw * esz >= 0xFFFFFFF0ull) return PK_EINVAL;
     QkvAttnArgs a;
     a.xq = xq; a.xkv = xkv; a.wq = wq; a.wkv = wkv; a.ld = ld; a.ldw = ldw;
     a.S = S; a.n = n; a.h = h; a.K = K; a.spt = 64 / n;
@@ -376,32 +441,45 @@ extern "C" int pk_qkv_attn(const void* xq, const void* xkv, int ld, const void* 
     if (q_ln_s && mis(q_ln_s)) return PK_EALIGN;
     const int tiles = (S + a.spt - 1) / a.spt;
     dim3 grid(8 * ((tiles + 7) / 8) * h);
-    hipLaunchKernelGGL(qkv_attn_kernel, grid, dim3(256), QA_SMEM, reinterpret_cast<hipStream_t>(stream), a);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == 1) hipLaunchKernelGGL(qkv_attn_kernel<bf16>, grid, dim3(256), QA_SMEM, st, a);
+    else hipLaunchKernelGGL(qkv_attn_kernel<bf16x3>, grid, dim3(256), QA_SMEM, st, a);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }
 
-// bf16 only.  Cross-attention of S sequences of n tokens (n % 64 == 0) against cached K^ / V^T images of nk = nnull + n_kv <= 64 keys
-// (layouts of pk_attn_prep with nk_pad = pk_attn_pads(...)): O [S*n][ldo] bf16 <- softmax(l2norm(xq Wq^T) K^^T) V, heads merged.
-// kmask [S][n_kv] uint8 over the real keys or NULL; q_ln_s: LayerNorm folded into to_q (xq = the un-normalised rows) or NULL.
-extern "C" int pk_q_attn_cached(const void* xq, int ld, const void* wq, int ldw, int S, int n, int h, int K, const float* q_scale,
+// Cross-attention of S sequences of n tokens (n % 64 == 0) against cached K^ / V^T images of nk = nnull + n_kv <= 64 keys
+// (layouts of pk_attn_prep with nk_pad = pk_attn_pads(...); dtype 2: its pre-split bf16x3p images): O [S*n][ldo] (bf16 / f32) <-
+// softmax(l2norm(xq Wq^T) K^^T) V, heads merged.  kmask [S][n_kv] uint8 over the real keys or NULL; q_ln_s: LayerNorm folded into to_q
+// (xq = the un-normalised rows) or NULL.  Operand types per dtype as for pk_qkv_attn.
+extern "C" int pk_q_attn_cached(int dtype, const void* xq, int ld, const void* wq, int ldw, int S, int n, int h, int K, const float* q_scale,
                                 float scale, const float* q_ln_s, const void* Kp, const void* Vt, int nk_pad, int n_kv, int nnull,
                                 const unsigned char* kmask, void* O, int ldo, void* stream) {
+    if (dtype != 1 && dtype != 2) return PK_EINVAL;
     if (!xq || !wq || !q_scale || !Kp || !Vt || !O || S <= 0 || n <= 0 || (n & 63) || h <= 0 || K <= 0 || n_kv <= 0 || nnull < 0) return PK_EINVAL;
     const int nk = nnull + n_kv;
     if (nk > 64 || nk_pad < nk || nk_pad > 64 || (nk_pad & 31)) return PK_EINVAL;
     auto mis = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) != 0; };
-    if ((K & 7) || (ld & 7) || (ldw & 7) || (ldo & 3) || mis(xq) || mis(wq) || mis(q_scale) || mis(Kp) || mis(Vt) ||
-        (reinterpret_cast<uintptr_t>(O) & 7) || (q_ln_s && mis(q_ln_s))) return PK_EALIGN;
-    if (ldw < (K + 63) / 64 * 64) return PK_EINVAL;
+    const int q = dtype == 1 ? 7 : 3, bk = dtype == 1 ? 64 : 32, esz = dtype == 1 ? 2 : 4;
+    if ((K & q) || (ld & q) || (ldw & q) || (ldo & 3) || mis(xq) || mis(wq) || mis(q_scale) || mis(Kp) || mis(Vt) ||
+        (reinterpret_cast<uintptr_t>(O) & (dtype == 1 ? 7 : 15)) || (q_ln_s && mis(q_ln_s))) return PK_EALIGN;
+    if (dtype == 2 && ((reinterpret_cast<uintptr_t>(Kp) | reinterpret_cast<uintptr_t>(Vt)) & 127)) return PK_EALIGN;      // 128-byte blocks
+    if (ldw < (K + bk - 1) / bk * bk) return PK_EINVAL;
     const long M = (long)S * n;
-    if ((size_t)M * ld * 2 >= 0xFFFFFFF0ull || (size_t)h * 64 * ldw * 2 >= 0xFFFFFFF0ull) return PK_EINVAL;
+    if ((size_t)M * ld * esz >= 0xFFFFFFF0ull || (size_t)h * 64 * ldw * esz >= 0xFFFFFFF0ull) return PK_EINVAL;
     QAttnCachedArgs a{xq, wq, ld, ldw, S, n, h, K, q_scale, scale, q_ln_s, Kp, Vt, nk_pad, nk, nnull, kmask, n_kv, O, ldo};
     const int tiles = (int)(M / 64);
     dim3 grid(8 * ((tiles + 7) / 8) * h);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (nk_pad > 32) hipLaunchKernelGGL((q_attn_cached_kernel<true>), grid, dim3(256), QaTile::SMEM + 16384, st, a);
-    else hipLaunchKernelGGL((q_attn_cached_kernel<false>), grid, dim3(256), QaTile::SMEM + 16384, st, a);
+    if (dtype == 1) {
+        constexpr int lds = QaTile<bf16>::SMEM + 2 * QA_PLANE;
+        if (nk_pad > 32) hipLaunchKernelGGL((q_attn_cached_kernel<bf16, true>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((q_attn_cached_kernel<bf16, false>), grid, dim3(256), lds, st, a);
+    } else {
+        constexpr int lds = QaTile<bf16x3>::SMEM + 4 * QA_PLANE;           // 64 KB
+        if (nk_pad > 32) hipLaunchKernelGGL((q_attn_cached_kernel<bf16x3, true>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((q_attn_cached_kernel<bf16x3, false>), grid, dim3(256), lds, st, a);
+    }
     PK_CHECK_LAUNCH();
     return PK_OK;
 }
