@@ -18,7 +18,8 @@
  *     W [N][ldw] is the PRE-SPLIT image of the zero-padded f32 weight: per row and per block of 32 k-elements 128 bytes =
  *     [hi x 32 | lo x 32] bf16 (ldw counted in 4-byte units, a multiple of 32; _lib.split_planes); the attention operand
  *     images Qp / Kp / Vt use the same blocked (hi | lo) format per row (same sizes as dtype 0, 128-byte aligned bases).
- *     LDS-DMA main loops only; no LayerNorm fold / C2 / row statistics (those are dtype 1 features);
+ *     LDS-DMA main loops only; LayerNorm fold (ln_s / ln_t), row statistics (stats_out / ln_stats) and dup_rows work as for dtype 1
+ *     (round 4; the rows ARE f32, so no C2 copy exists or is needed);
  *   - activations in HBM are f32 unless a parameter says T; rows are row-major with an explicit leading
  *     dimension (ld*, in elements);
  *   - dim_head is fixed at 64 in the attention kernels.
@@ -172,28 +173,31 @@ int pk_attn_prep(int dtype, const float* q, int ldq, const float* kv, int ldkv, 
                  const float* q_scale, const float* k_scale, float scale, void* Qp, void* Kp, void* Vt,
                  int S, int h, int nq, int n_kv, int nnull, void* stream);
 
-/* attention.py:142-157 in ONE launch (bf16): to_q (A = xq = LayerNorm(x)) and to_kv (A = xkv = the un-normalised x, or NULL
+/* attention.py:142-157 in ONE launch (dtype 1 = bf16: bf16 rows / weights / images; dtype 2 = split-bf16, round 4: f32 rows split in
+ * registers, host-split weight planes as for pk_gemm, images written pre-split as for pk_attn_prep(dtype 2)): to_q (A = xq = LayerNorm(x)) and to_kv (A = xkv = the un-normalised x, or NULL
  * for the query side only) as one MFMA GEMM whose epilogue does the head split, l2norm, q/k scales (sim scale folded in
  * q) and the V transpose, writing Qp / Kp / Vt (layouts above) directly: the f32 q / kv matrices never reach HBM and
  * pk_attn_prep is not needed.  Self-attention only on the kv side (no null keys); M = S * nseq rows. */
-int pk_qkv_project(const void* xq, const void* xkv, int ld, const void* wq, const void* wkv, int ldw, int S, int nseq,
+int pk_qkv_project(int dtype, const void* xq, const void* xkv, int ld, const void* wq, const void* wkv, int ldw, int S, int nseq,
                    int h, int K, const float* q_scale, const float* k_scale, float scale, void* Qp, void* Kp, void* Vt,
                    int nq_pad, int nk_pad, const float* q_ln_s, void* stream);
 /* q_ln_s ([h*64] f32, or NULL): the attention's LayerNorm folded into to_q -- xq then holds the un-normalised rows (= xkv), wq holds
  * gamma (.) Wq and q_ln_s its row sums; q = l2norm(x (gamma.Wq)^T - mean(x) q_ln_s) (the l2norm cancels the LayerNorm's rstd). */
 
-/* attention.py:142-182 for SHORT self-attention sequences (n <= 64, no null keys, no key mask; bf16) in ONE launch: the
+/* attention.py:142-182 for SHORT self-attention sequences (n <= 64, no null keys, no key mask; dtype 1 bf16 / 2 split-bf16) in ONE launch: the
  * to_q / to_kv projections, l2norm + scales, and softmax(q k^T + bias (+ ALiBi, causal)) v -- what pk_qkv_project + pk_attn_fwd
  * compute, without Qp / Kp / Vt ever reaching HBM.  A workgroup owns one head of floor(64 / n) whole sequences.  xq = LayerNorm(x)
- * rows, xkv = x rows (both bf16 [S*n][ld]); bias [h][n][n] f32 or NULL; slopes [h] with causal; O bf16 [S*n][ldo], heads merged. */
-int pk_qkv_attn(const void* xq, const void* xkv, int ld, const void* wq, const void* wkv, int ldw, int S, int n, int h, int K,
+ * rows, xkv = x rows (both [S*n][ld], bf16 / f32 by dtype); bias [h][n][n] f32 or NULL; slopes [h] with causal; O [S*n][ldo] (bf16 / f32),
+ * heads merged.  dtype 2 stages q^ / k^ / v^T as (hi, lo) bf16 planes in LDS and computes every product as three MFMAs. */
+int pk_qkv_attn(int dtype, const void* xq, const void* xkv, int ld, const void* wq, const void* wkv, int ldw, int S, int n, int h, int K,
                 const float* q_scale, const float* k_scale, float scale, const float* bias, long bias_hstride, int bias_ld,
                 const float* slopes, int causal, void* O, int ldo, const float* q_ln_s, void* stream);
 
 /* Cross-attention against CACHED key / value images (the step-invariant text context, attention.py:142-182 with context) in ONE launch:
  * to_q (+ the folded LayerNorm, q_ln_s as in pk_qkv_project) + l2norm + softmax(q k^T (+ key mask)) v.  Kp / Vt are the images
- * pk_attn_prep wrote for nnull + n_kv <= 64 keys (nk_pad from pk_attn_pads); n % 64 == 0; kmask [S][n_kv] uint8 or NULL; O bf16. */
-int pk_q_attn_cached(const void* xq, int ld, const void* wq, int ldw, int S, int n, int h, int K, const float* q_scale, float scale,
+ * pk_attn_prep wrote (same dtype) for nnull + n_kv <= 64 keys (nk_pad from pk_attn_pads); n % 64 == 0; kmask [S][n_kv] uint8 or NULL;
+ * O bf16 (dtype 1) / f32 (dtype 2). */
+int pk_q_attn_cached(int dtype, const void* xq, int ld, const void* wq, int ldw, int S, int n, int h, int K, const float* q_scale, float scale,
                      const float* q_ln_s, const void* Kp, const void* Vt, int nk_pad, int n_kv, int nnull,
                      const unsigned char* kmask, void* O, int ldo, void* stream);
 
@@ -327,8 +331,11 @@ int pk_bce_head(const float* e, long long lde, const float* w, const float* b, c
                 float* de, long long ldde, float* pw, float* pb, int M, int D, void* stream);
 /* split-K product for the weight gradients (dW = dY^T X contracts over the rows of the batch): C[z] = A[:, z Kc : (z + 1) Kc] W[:, z Kc : (z + 1) Kc]^T,
  * Kc = K / splits (a multiple of the k-tile), z < splits, as `splits` partial (M, N) f32 matrices at C + z * M * ldc; add them with pk_sum_batch.
- * A: T for dtype 1, f32 for dtype 0 / 2; W: the operand image of the dtype. */
-int pk_gemm_splitk(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, int splits, float* C, int ldc, void* stream);
+ * A: T for dtype 1, f32 for dtype 0 / 2; W: the operand image of the dtype.
+ * bias ([N] or NULL) is added by slice 0 only (the sum of the slices carries it once); tile 0: 64 x 64 tiles, 1: 128 x 128 (long K-slices of a large
+ * (M, N): the patch-embedding product of the exact-f32 / split-bf16 modes, K = 6144). */
+int pk_gemm_splitk(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, int splits, float* C, int ldc,
+                   const float* bias, int tile, void* stream);
 /* AdamW / Adam update of one parameter tensor (reference optimizer.py:11-37 hands MaskGit's parameters to torch.optim.AdamW / Adam):
  * m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2; p = p (1 - lr wd) - lr / (1 - b1^step) * m / (sqrt(v / (1 - b2^step)) + eps); step = 1, 2, ... */
 int pk_adamw(float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2, float eps, float wd, int step, long long n, void* stream);

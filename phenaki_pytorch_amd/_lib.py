@@ -44,9 +44,9 @@ SIGNATURES = {
     'pk_cpb_input': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     'pk_attn_pads': [_I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I)],
     'pk_attn_prep': [_I, _P, _I, _P, _I, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    'pk_qkv_project': [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _P],
-    'pk_qkv_attn': [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _L, _I, _P, _I, _P, _I, _P, _P],
-    'pk_q_attn_cached': [_P, _I, _P, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P],
+    'pk_qkv_project': [_I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _P],
+    'pk_qkv_attn': [_I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _L, _I, _P, _I, _P, _I, _P, _P],
+    'pk_q_attn_cached': [_I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P],
     'pk_attn_fwd': [_I, _P, _P, _P, _P, _L, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _F, _P],
     'pk_attn_small': [_P, _I, _P, _I, _P, _P, _F, _P, _L, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     'pk_cfg_mix': [_P, _I, _I, _I, _I, _P, _I, _F, _I, _P, _I, _I, _I, _P],
@@ -79,7 +79,7 @@ SIGNATURES = {
     'pk_bce_head': [_P, _LL, _P, _P, _P, _F, _P, _P, _P, _P, _LL, _P, _P, _I, _I, _P],
     'pk_attn_train_prep': [_P, _LL, _P, _LL, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'pk_attn_train_prep_bwd': [_P, _LL, _P, _LL, _P, _P, _P, _F, _P, _P, _P, _P, _LL, _P, _LL, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    'pk_gemm_splitk': [_I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P],
+    'pk_gemm_splitk': [_I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     'pk_adamw': [_P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _LL, _P],
     'pk_adamw_multi': [_P, _I, _F, _F, _F, _F, _F, _I, _P],
     'pk_attn_bwd': [_P, _P, _P, _P, _LL, _I, _P, _LL, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -323,24 +323,34 @@ def gated_gelu_tanh(h, out, M, F):
     _check(rc, 'pk_gated_gelu_tanh')
 
 
+def _qkv_dtype(xq):
+    """operand type of the fused projection kernels from the rows they read: bf16 rows -> 1 (bf16), f32 rows -> 2 (split-bf16)"""
+    if xq.dtype == torch.bfloat16:
+        return BF16
+    if xq.dtype == torch.float32:
+        return BF16X3
+    raise RuntimeError(f'fused projection kernels take bf16 (bf16 mode) or f32 (bf16x3 mode) rows, got {xq.dtype}')
+
+
 def qkv_project(xq, xkv, wq, wkv, S, nseq, h, K, q_scale, k_scale, scale, Qp, Kp, Vt, nq_pad, nk_pad, q_ln_s=None):
-    rc = load().pk_qkv_project(ptr(xq), ptr(xkv), xq.stride(-2), ptr(wq), ptr(wkv), wq.stride(0), S, nseq, h, K, f32p(q_scale, 'q_scale'),
+    rc = load().pk_qkv_project(_qkv_dtype(xq), ptr(xq), ptr(xkv), xq.stride(-2), ptr(wq), ptr(wkv), wq.stride(0), S, nseq, h, K, f32p(q_scale, 'q_scale'),
                                 f32p(k_scale, 'k_scale'), scale, ptr(Qp), ptr(Kp), ptr(Vt), nq_pad, nk_pad, ptr(q_ln_s), stream(xq))
     _check(rc, 'pk_qkv_project')
 
 
 def qkv_attn(xq, xkv, wq, wkv, S, n, h, K, q_scale, k_scale, scale, O, *, bias=None, slopes=None, causal=False, q_ln_s=None):
-    """O (S*n, h*64) bf16 <- softmax(l2norm(xq Wq^T) l2norm(xkv Wk^T)^T * scale + bias) (xkv Wv^T), n <= 64 (one launch)"""
+    """O (S*n, h*64) <- softmax(l2norm(xq Wq^T) l2norm(xkv Wk^T)^T * scale + bias) (xkv Wv^T), n <= 64 (one launch); bf16 rows / bf16 O, or
+    f32 rows / f32 O with split-bf16 products"""
     bh, bld = (bias.stride(0), bias.stride(1)) if bias is not None else (0, 0)
-    rc = load().pk_qkv_attn(ptr(xq), ptr(xkv), xq.stride(-2), ptr(wq), ptr(wkv), wq.stride(0), S, n, h, K, f32p(q_scale, 'q_scale'),
+    rc = load().pk_qkv_attn(_qkv_dtype(xq), ptr(xq), ptr(xkv), xq.stride(-2), ptr(wq), ptr(wkv), wq.stride(0), S, n, h, K, f32p(q_scale, 'q_scale'),
                             f32p(k_scale, 'k_scale'), scale, f32p(bias, 'attention bias'), bh, bld, f32p(slopes, 'ALiBi slopes'),
                             1 if causal else 0, ptr(O), O.stride(-2), ptr(q_ln_s), stream(xq))
     _check(rc, 'pk_qkv_attn')
 
 
 def q_attn_cached(xq, wq, S, n, h, K, q_scale, scale, Kp, Vt, nk_pad, n_kv, nnull, O, *, kmask=None, q_ln_s=None):
-    """O (S*n, h*64) bf16 <- cross-attention of the rows of xq against the cached K^ / V^T images (one launch; n % 64 == 0, <= 64 keys)"""
-    rc = load().pk_q_attn_cached(ptr(xq), xq.stride(-2), ptr(wq), wq.stride(0), S, n, h, K, f32p(q_scale, 'q_scale'), scale, ptr(q_ln_s),
+    """O (S*n, h*64) <- cross-attention of the rows of xq against the cached K^ / V^T images (one launch; n % 64 == 0, <= 64 keys)"""
+    rc = load().pk_q_attn_cached(_qkv_dtype(xq), ptr(xq), xq.stride(-2), ptr(wq), wq.stride(0), S, n, h, K, f32p(q_scale, 'q_scale'), scale, ptr(q_ln_s),
                                  ptr(Kp), ptr(Vt), nk_pad, n_kv, nnull, ptr(kmask), ptr(O), O.stride(-2), stream(xq))
     _check(rc, 'pk_q_attn_cached')
 
@@ -598,9 +608,9 @@ def adamw_multi(entries, lr, beta1, beta2, eps, wd, step, device):
     _check(rc, 'pk_adamw_multi')
 
 
-def gemm_splitk(dtype, A, W, M, N, K, splits, C):
-    """C (splits, M, N) f32 <- the K-slices of A @ W^T (see the header); reduce with sum_batch"""
-    rc = load().pk_gemm_splitk(dtype, ptr(A), A.stride(-2), ptr(W), W.stride(0), M, N, K, splits, ptr(C), N, stream(C))
+def gemm_splitk(dtype, A, W, M, N, K, splits, C, bias=None, tile=0):
+    """C (splits, M, N) f32 <- the K-slices of A @ W^T (see the header; bias on slice 0; tile 1: 128 x 128 tiles); reduce with sum_batch"""
+    rc = load().pk_gemm_splitk(dtype, ptr(A), A.stride(-2), ptr(W), W.stride(0), M, N, K, splits, ptr(C), N, f32p(bias, 'bias'), int(tile), stream(C))
     _check(rc, 'pk_gemm_splitk')
 
 

@@ -171,16 +171,26 @@ def ff_fold_mode(rows):
     return _LN_FOLD_FF if (_LN_FOLD_FF_MAX_ROWS <= 0 or rows <= _LN_FOLD_FF_MAX_ROWS) else 0
 
 
+# the split-bf16 (bf16x3) mode folds its LayerNorms the same way (round 4): the rows it reads ARE the f32 residual stream (no bf16 copy), the
+# fused projection + attention kernels exist for it, and the same fold arithmetic runs on f32-grade products.  PK_LN_FOLD_X3=0: the round-3
+# path (separate LayerNorm, q / kv GEMMs, pk_attn_prep, LDS-free short attention) for A/B timing.
+_LN_FOLD_X3 = os.environ.get('PK_LN_FOLD_X3', '1') != '0'
+
+
 def ln_fold_enabled(dtype):
-    return _LN_FOLD and dtype == L.BF16
+    return _LN_FOLD and (dtype == L.BF16 or (dtype == L.BF16X3 and _LN_FOLD_X3))
 
 
 def folded_weight(owner, key, w_f32, gamma, beta, dtype, params):
     """(packed gamma (.) W in T, s, t, beta_is_zero) for the (N, K) f32 weight `w_f32` (a callable building it), cached on `owner`"""
     def build():
         w = w_f32().float()
-        wg = pack_linear_weight(w * gamma.detach().float()[None, :], dtype)
-        s = wg[:, :w.shape[1]].float().sum(dim=1).contiguous()            # from the ROUNDED operand the MFMAs see
+        wgf = w * gamma.detach().float()[None, :]
+        wg = pack_linear_weight(wgf, dtype)
+        if dtype == L.BF16:
+            s = wg[:, :w.shape[1]].float().sum(dim=1).contiguous()        # from the ROUNDED operand the MFMAs see
+        else:
+            s = wgf.sum(dim=1).contiguous()                               # f32 / split-bf16 (hi + lo = the f32 value to 2^-17): the f32 row sums
         if beta is None:
             t, bz = torch.zeros_like(s), True
         else:
@@ -507,7 +517,8 @@ class Attention(PackedModule):
         out = torch.empty((dup * M, D), device=x2d.device, dtype=torch.float32)
         out_t = torch.empty((dup * M, D), device=x2d.device, dtype=torch.bfloat16) if (want_t and dtype == L.BF16) else None
         stats = None
-        if want_t == 'stats' and out_t is not None and D % 4 == 0 and dup == 1:
+        if want_t == 'stats' and (out_t is not None or dtype == L.BF16X3) and D % 4 == 0 and dup == 1:
+            # (split-bf16: the statistics of the f32 rows themselves, which is what its folded feed-forward GEMM reads)
             stats = torch.empty((M, (D + 31) // 32, 2), device=x2d.device, dtype=torch.float32)
         L.gemm(dtype, o, linear_weight(self.to_out, dtype), M, D, o.shape[1], C=out, res=x2d, C2=out_t, stats_out=stats,
                dup_rows=M if dup == 2 else 0)
@@ -727,7 +738,8 @@ class Transformer(PackedModule):
                 # block BEFORE it writes beside the f32 one (only when somebody will read it)
                 has_cross = exists(cross_attn) and exists(context2d)
                 if exists(peg):
-                    x, xt = peg.run(x, video_shape if S_cur == S else (video_shape[0] * S_cur // S, *video_shape[1:]), want_t=True)
+                    x, xt = _unpack(peg.run(x, video_shape if S_cur == S else (video_shape[0] * S_cur // S, *video_shape[1:]),
+                                            want_t=dtype == L.BF16))[:2]           # (split-bf16 reads the f32 rows: no copy)
                 ff_wants = {0: False, 1: True, 2: 'stats'}[ff_fold_mode(S * n)]           # what the block in front of the FF leaves for it
                 x, xt, stats = _unpack(self_attn.run(x, S_cur, n, dtype, attn_bias=attn_bias, kmask=self_attn_mask, xt=xt,
                                                      want_t=True if has_cross else ff_wants, dup=S // S_cur))

@@ -250,20 +250,22 @@ void gemm_dma_kernel(const GemmOperands p, const GemmEpilogue e, int a_nrows) {
         // the row's partials.  The loads are issued here and ride under the main loop (whose first vmcnt(0) covers them); sums, the
         // 4-lane fold and the hand-over through LDS happen after it.  (Waiting for them up front cost 12 us per launch: ~1.5 tiles per
         // CU slot, each starting with dependent L2 round trips; 16 dependent loads per lane in the epilogue cost 45 us.)
-        static_assert(Tile::THREADS == 4 * Tile::BM, "4 threads per tile row");
-        const int srow = threadIdx.x >> 2, sq4 = threadIdx.x & 3;
-        const int per = (e.stats_np + 3) >> 2, c0 = sq4 * per, c1 = min(c0 + per, e.stats_np);
+        constexpr int TPR = Tile::THREADS / Tile::BM;      // threads per tile row: 4 (64x64 / 8-wave 128x128) or 2 (4-wave 128x128, split-bf16)
+        static_assert(Tile::THREADS == TPR * Tile::BM && (TPR == 2 || TPR == 4), "2 or 4 threads per tile row");
+        constexpr int NPRE = 16 / TPR;                     // partials prefetched per thread: all of them for K = 512 (16 chunks of 32)
+        const int srow = threadIdx.x / TPR, sq4 = threadIdx.x % TPR;
+        const int per = (e.stats_np + TPR - 1) / TPR, c0 = sq4 * per, c1 = min(c0 + per, e.stats_np);
         const float2* st = reinterpret_cast<const float2*>(e.ln_stats) + (size_t)min(m0 + srow, p.M - 1) * e.stats_np;
         float su = 0.f, sq = 0.f;
-        for (int c = c0 + 4; c < c1; ++c) { const float2 pr = st[c]; su += pr.x; sq += pr.y; }      // K > 512 only
-        float2 pre[4];
+        for (int c = c0 + NPRE; c < c1; ++c) { const float2 pr = st[c]; su += pr.x; sq += pr.y; }      // K > 512 only
+        float2 pre[NPRE];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) pre[u] = c0 + u < c1 ? st[c0 + u] : float2{0.f, 0.f};
+        for (int u = 0; u < NPRE; ++u) pre[u] = c0 + u < c1 ? st[c0 + u] : float2{0.f, 0.f};
         if (!Tile::run(p, a_nrows, m0, n0, smem, acc)) return;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { su += pre[u].x; sq += pre[u].y; }
+        for (int u = 0; u < NPRE; ++u) { su += pre[u].x; sq += pre[u].y; }
         su += __shfl_xor(su, 1); sq += __shfl_xor(sq, 1);
-        su += __shfl_xor(su, 2); sq += __shfl_xor(sq, 2);
+        if (TPR == 4) { su += __shfl_xor(su, 2); sq += __shfl_xor(sq, 2); }
         __syncthreads();                                  // the last k-tile's fragments have been read: the ring can be reused
         float2* ls = reinterpret_cast<float2*>(smem);
         if (sq4 == 0) ls[srow] = float2{su, sq};
@@ -296,6 +298,7 @@ void gemm_dma_splitk_kernel(GemmOperands p, GemmEpilogue e, int a_nrows, long ba
     p.A = reinterpret_cast<const char*>(p.A) + (size_t)z * batch_a;
     p.W = reinterpret_cast<const char*>(p.W) + (size_t)z * batch_w;
     e.C = reinterpret_cast<char*>(e.C) + (size_t)z * batch_c;
+    if (z != 0) e.bias = nullptr;                         // a bias rides on slice 0 only: the slices' sum then carries it once
     const int MT = (p.M + Tile::BM - 1) / Tile::BM, NTn = (p.N + Tile::BN - 1) / Tile::BN;
     if ((int)blockIdx.x >= MT * NTn) return;
     const int m0 = (blockIdx.x % MT) * Tile::BM, n0 = (blockIdx.x / MT) * Tile::BN;
@@ -308,11 +311,12 @@ void gemm_dma_splitk_kernel(GemmOperands p, GemmEpilogue e, int a_nrows, long ba
     gemm_epilogue<T, TM, TN, WN>(acc, p.M, p.N, e, m0, n0);
 }
 
-template <typename T>
+template <typename T, int TM = 2, int TN = 2>
 static int launch_splitk(const GemmOperands& p, const GemmEpilogue& e, int a_nrows, int splits, long ba, long bw, long bc, hipStream_t s) {
-    using Tile = GemmDma<T, 2, 2, 2, 2, 2, 128, 0>;
+    using Tile = GemmDma<T, TM, TN, 2, 2, 2, 128, 0>;        // 4 waves as 2 x 2: 64 x 64 (TM = TN = 2) or 128 x 128 (TM = TN = 4) tiles
+    constexpr int lds = Tile::SMEM;
     const int MT = (p.M + Tile::BM - 1) / Tile::BM, NT = (p.N + Tile::BN - 1) / Tile::BN;
-    hipLaunchKernelGGL((gemm_dma_splitk_kernel<T, 2, 2, 2, 2, 2>), dim3(MT * NT, splits), dim3(Tile::THREADS), Tile::SMEM, s, p, e, a_nrows, ba, bw, bc);
+    hipLaunchKernelGGL((gemm_dma_splitk_kernel<T, TM, TN, 2, 2, 2>), dim3(MT * NT, splits), dim3(Tile::THREADS), lds, s, p, e, a_nrows, ba, bw, bc);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }
@@ -405,7 +409,7 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
     if (dtype == 1 && a_is_f32 && (K % 8)) return PK_EALIGN;
     if (!al16(A) || !al16(W)) return PK_EALIGN;
     if (dtype != 1 && !a_is_f32) return PK_EINVAL;               // exact-f32 and split-bf16 modes keep every activation f32
-    if (dtype == 2 && (ln_s || ln_stats || stats_out || C2)) return PK_EINVAL;      // LayerNorm fold / bf16 copies are bf16-mode features
+    if (dtype == 2 && C2) return PK_EINVAL;      // the bf16 copy is a bf16-mode feature (split-bf16 consumers read the f32 rows themselves)
     if (act == ACT_GEGLU && (N & 1)) return PK_EINVAL;
     if (a_rows && a_nrows <= 0) return PK_EINVAL;
     if (!a_rows) a_nrows = M;
@@ -435,13 +439,16 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
         const bool big = variant == 24 || variant == 2 || variant == 9;
         if (ln_stats) {
             if (dtype == 1) return big ? launch_dma<bf16, 4, 2, 2, 2, 4, 128, 0, 2>(p, e, a_nrows, s) : launch_dma<bf16, 2, 2, 2, 2, 2, 128, 0, 2>(p, e, a_nrows, s);
+            // split-bf16 (round 4): the 4-wave 128x128 tile of that mode (2 threads per row fetch the partials)
+            if (dtype == 2) return big ? launch_dma<bf16x3, 4, 4, 2, 2, 2, 128, 0, 2>(p, e, a_nrows, s) : launch_dma<bf16x3, 2, 2, 2, 2, 2, 128, 0, 2>(p, e, a_nrows, s);
             return big ? launch_dma<float, 4, 2, 2, 2, 4, 128, 0, 2>(p, e, a_nrows, s) : launch_dma<float, 2, 2, 2, 2, 2, 128, 0, 2>(p, e, a_nrows, s);
         }
         if (dtype == 1) return big ? launch_dma<bf16, 4, 2, 2, 2, 4, 128, 0, 1>(p, e, a_nrows, s) : launch_dma<bf16, 2, 2, 2, 2, 2, 128, 0, 1>(p, e, a_nrows, s);
+        if (dtype == 2) return big ? launch_dma<bf16x3, 4, 4, 2, 2, 2, 128, 0, 1>(p, e, a_nrows, s) : launch_dma<bf16x3, 2, 2, 2, 2, 2, 128, 0, 1>(p, e, a_nrows, s);
         return big ? launch_dma<float, 4, 2, 2, 2, 4, 128, 0, 1>(p, e, a_nrows, s) : launch_dma<float, 2, 2, 2, 2, 2, 128, 0, 1>(p, e, a_nrows, s);
     }
     // stats_out is written by the TN = 2 LDS-DMA kernels only (one 32-column chunk per wave)
-    if (stats_out && !(dma_ok && (variant == 8 || variant == 24 || variant == 27 || variant == 33 || (variant == 3 && dtype == 0)))) return PK_EINVAL;
+    if (stats_out && !(dma_ok && (variant == 8 || variant == 24 || variant == 27 || variant == 33 || (variant == 3 && dtype != 1)))) return PK_EINVAL;
     // the main-loop variants that survived round 1's sweep (profiles/gemm_variants*_r01.txt; the 35 losers -- deeper rings, k-tile 32,
     // 128x256 / 256x256 tiles, other wave layouts, other producer / consumer splits -- were deleted in round 2)
     if (dtype == 1) {
@@ -506,20 +513,27 @@ extern "C" int pk_gemm(int dtype, int a_is_f32, const void* A, int lda, const vo
                       nullptr, 0, nullptr, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, 0, stream);
 }
 
-// C[z] = A[:, z Kc : (z + 1) Kc] W[:, z Kc : (z + 1) Kc]^T for z < splits, Kc = K / splits (a multiple of the k-tile: 64 bf16 / 32 otherwise):
+// C[z] = A[:, z Kc : (z + 1) Kc] W[:, z Kc : (z + 1) Kc]^T (+ bias on slice 0) for z < splits, Kc = K / splits (a multiple of the k-tile: 64 bf16 / 32 otherwise):
 // the K-slices of one product as `splits` partial (M, N) f32 matrices, C + z * M * ldc -- sum them with pk_sum_batch.  A: T (dtype 1) or f32
 // (dtype 0 / 2), W: the operand image of the dtype; both K-padded as for pk_gemm.
-extern "C" int pk_gemm_splitk(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, int splits, float* C, int ldc, void* stream) {
+extern "C" int pk_gemm_splitk(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, int splits, float* C, int ldc,
+                              const float* bias, int tile, void* stream) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || splits < 1 || splits > 64 || (dtype != 0 && dtype != 1 && dtype != 2)) return PK_EINVAL;
+    if (tile != 0 && tile != 1) return PK_EINVAL;
     const int bk = dtype == 1 ? 64 : 32, esz = dtype == 1 ? 2 : 4;
     if (K % (splits * bk) || (N & 3) || (ldc & 3) || ldc < N) return PK_EINVAL;
-    if (!al16(A) || !al16(W) || !al16(C) || lda % (16 / esz) || ldw % (16 / esz)) return PK_EALIGN;
+    if (!al16(A) || !al16(W) || !al16(C) || (bias && !al16(bias)) || lda % (16 / esz) || ldw % (16 / esz)) return PK_EALIGN;
     if (!dma_possible(dtype, dtype == 1 ? 0 : 1, N, K, lda, ldw, M)) return PK_EINVAL;
     const int Kc = K / splits;
     GemmOperands p{A, W, nullptr, lda, ldw, M, N, Kc, 1, 0};
-    GemmEpilogue e{nullptr, nullptr, C, 0, ldc, 1, ACT_NONE, 1};
+    GemmEpilogue e{bias, nullptr, C, 0, ldc, 1, ACT_NONE, 1};
     const long ba = (long)Kc * esz, bw = (long)Kc * esz, bc = (long)M * ldc * 4;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (tile == 1) {                                       // 128 x 128 tiles: half the fill bytes per flop; for LONG K-slices of a big (M, N)
+        if (dtype == 1) return launch_splitk<bf16, 4, 4>(p, e, M, splits, ba, bw, bc, s);
+        if (dtype == 2) return launch_splitk<bf16x3, 4, 4>(p, e, M, splits, ba, bw, bc, s);
+        return launch_splitk<float, 4, 4>(p, e, M, splits, ba, bw, bc, s);
+    }
     if (dtype == 1) return launch_splitk<bf16>(p, e, M, splits, ba, bw, bc, s);
     if (dtype == 2) return launch_splitk<bf16x3>(p, e, M, splits, ba, bw, bc, s);
     return launch_splitk<float>(p, e, M, splits, ba, bw, bc, s);

@@ -55,7 +55,7 @@ __device__ __forceinline__ int pk_tl_wg() {
 #define PK_TL(slot) do {} while (0)
 #endif
 
-__device__ __forceinline__ void frag_stats(const Frag<bf16x3>& f, float& s, float& q, bool want_sq) {      // (no LayerNorm fold in split mode: unused)
+__device__ __forceinline__ void frag_stats(const Frag<bf16x3>& f, float& s, float& q, bool want_sq) {      // hi + lo planes: the f32 row sums to ~2^-17
     const uint32_t ones = 0x3f803f80u;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {

@@ -140,10 +140,12 @@ static int qkv_project_launch(const QkvArgs& a, int NT, hipStream_t st) {
     const bool big = tm_env ? tm_env == 2 : tiles128 >= 4 * 256;
     if (big) {
         const int MT = (int)((M + 127) / 128);
-        hipLaunchKernelGGL((qkv_project_kernel<T, 2>), dim3(8 * ((MT + 7) / 8) * NT), dim3(256), QkvTileT<T, 2>::SMEM, st, a);
+        constexpr int lds = QkvTileT<T, 2>::SMEM;
+        hipLaunchKernelGGL((qkv_project_kernel<T, 2>), dim3(8 * ((MT + 7) / 8) * NT), dim3(256), lds, st, a);
     } else {
         const int MT = (int)((M + 63) / 64);
-        hipLaunchKernelGGL((qkv_project_kernel<T, 1>), dim3(8 * ((MT + 7) / 8) * NT), dim3(256), QkvTileT<T, 1>::SMEM, st, a);
+        constexpr int lds = QkvTileT<T, 1>::SMEM;
+        hipLaunchKernelGGL((qkv_project_kernel<T, 1>), dim3(8 * ((MT + 7) / 8) * NT), dim3(256), lds, st, a);
     }
     PK_CHECK_LAUNCH();
     return PK_OK;

@@ -17,10 +17,11 @@ import os
 
 from .attention import (ContinuousPositionBias, PackedModule, Transformer, compute_dtype_of, exists, folded_weight, invalidate_packed,
                         linear_weight, ln_fold_enabled, value_without_graph, set_compute_dtype)
+from .quantize import LFQ, VectorQuantize
 
 # PK_PATCH_FUSED=0: the bf16 patch embedding keeps pk_patchify_ln + pk_gemm (A/B timing of the fused pk_patch_embed)
-_PATCH_FUSED = os.environ.get('PK_PATCH_FUSED', '1') != '0' 
-from .quantize import LFQ, VectorQuantize
+_PATCH_FUSED = os.environ.get('PK_PATCH_FUSED', '1') != '0'
+_PE_SPLITK = int(os.environ.get('PK_PE_SPLITK', '4'))          # K-slices of the split-bf16 patch-embedding GEMM (1: one plain launch)
 
 
 def pair(val):
@@ -179,7 +180,7 @@ class CViViT(PackedModule):
         dev = video.device
         tokens = torch.empty((B * T * hw, self.dim), device=dev, dtype=torch.float32)
         # bf16 copy for the first transformer block (its LayerNorm is folded into its first GEMM, which reads bf16 rows)
-        tokens_t = torch.empty((B * T * hw, self.dim), device=dev, dtype=td) if ln_fold_enabled(dt) else None
+        tokens_t = torch.empty((B * T * hw, self.dim), device=dev, dtype=td) if (ln_fold_enabled(dt) and dt == L.BF16) else None
 
         groups = [(self.to_patch_emb, 1, nt, pt, hw)] if nt > 0 else []
         groups.append((self.to_patch_emb_first_frame, 0, 1, 1, 0))                     # long-K group first
@@ -210,7 +211,15 @@ class CViViT(PackedModule):
             patches = torch.empty((rows, P), device=dev, dtype=td)
             L.patchify_ln(video, f0, ntg, ptg, ph, pw, ln1.weight, ln1.bias, patches, eps=ln1.eps)
             tmp = torch.empty((rows, self.dim), device=dev, dtype=torch.float32)
-            L.gemm(dt, patches, linear_weight(lin, dt), rows, self.dim, P, C=tmp, bias=lin.bias)
+            # split-bf16, the long-K group (P = 6144, 4096 rows at B = 8): 128 x 128 tiles alone are 128 workgroups; K-slices bring every CU in
+            # (pk_gemm_splitk tile = 1, bias on slice 0; slices added in index order: deterministic)
+            splits = _PE_SPLITK if (dt == L.BF16X3 and rows >= 1024 and P >= 4096 and P % (32 * _PE_SPLITK) == 0 and self.dim % 4 == 0) else 1
+            if splits > 1:
+                part = torch.empty((splits, rows * self.dim), device=dev, dtype=torch.float32)
+                L.gemm_splitk(dt, patches, linear_weight(lin, dt), rows, self.dim, P, splits, part, bias=lin.bias, tile=1)
+                L.sum_batch(part, splits, tmp, rows * self.dim)
+            else:
+                L.gemm(dt, patches, linear_weight(lin, dt), rows, self.dim, P, C=tmp, bias=lin.bias)
             L.layernorm(tmp, ln2.weight, ln2.bias, rows, self.dim, out=tokens_t, out2=tokens, eps=ln2.eps, remap=(ntg * hw, T * hw, goff))
 
         group(self.to_patch_emb_first_frame, 0, 1, 1, 0)
@@ -235,7 +244,7 @@ class CViViT(PackedModule):
         scrambled view (cvivit.py:456,468-470) and so must we."""
         h, w = self.patch_height_width
         dt = compute_dtype_of(self)
-        if want_t and ln_fold_enabled(dt):
+        if want_t and ln_fold_enabled(dt) and dt == L.BF16:        # (split-bf16 folds too, but reads the f32 rows: no second copy)
             # the final norm_out writes its rows twice: f32 (residual stream of the next transformer) and bf16 (its first GEMM operand)
             out = torch.empty_like(xt2d)
             out_t = torch.empty(xt2d.shape, device=xt2d.device, dtype=L.tdtype(dt))

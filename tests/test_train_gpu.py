@@ -576,3 +576,13 @@ def test_gemm_splitk_matches_plain_product(dtype, tol):
     out2 = torch.empty((N, K), device='cuda')
     _weight_grad_gemm(dt, dyT, xT, N, K, Mp, out2)
     close(out2.cpu(), want, tol, f'weight-gradient product ({dtype})')
+    # round 4: 128 x 128 tiles and a bias carried by slice 0 (the split-bf16 patch-embedding product)
+    bias = torch.randn(K, generator=g)
+    for splits in (2, 4):
+        if Mp % (splits * q):
+            continue
+        part = torch.full((splits, N * K), float('nan'), device='cuda')
+        L.gemm_splitk(dt, dyT, xT, N, K, Mp, splits, part, bias=bias.cuda(), tile=1)
+        out = torch.empty((N, K), device='cuda')
+        L.sum_batch(part, splits, out, N * K)
+        close(out.cpu(), want + bias, tol, f'split-K x{splits}, 128-wide tiles + bias ({dtype})')
