@@ -288,6 +288,25 @@ class KernelProfiler:
             B, C, F, H, W = video.shape
             fl = sum(2.0 * (B * nt * (H // ph) * (W // pw)) * N * (C * pt * ph * pw) for (_, _, _, _, f0, nt, pt) in groups)
             return 'patch_embed_kernel', 'mfma', fl
+        if name == 'patch_embed_splitk':
+            # the patch embedding is HBM-bound on paper (13.37 MB of f32 video per 17-frame clip, read once); algorithmic bytes =
+            # the video frames the groups cover + the token rows the finish writes (f32 + bf16), per launch pair -- reported on the HBM axis
+            video, ph, pw, N, groups = a[:5]
+            B, C, F, H, W = video.shape
+            by = sum(4.0 * B * C * nt * pt * H * W for (_, _, _, f0, nt, pt) in groups)
+            return 'patch_embed_wide_kernel', 'hbm', by
+        if name == 'patch_embed_finish':
+            part = a[0]
+            ns, rows, N = part.shape
+            outs = sum(_esz(kw.get(k)) for k in ('out2', 'out'))
+            return 'patch_embed_finish_kernel', 'hbm', rows * N * (4.0 * ns + outs)
+        if name == 'gemm_splitk':
+            dtype, A, W, M, N, K = a[:6]
+            t = {lib.BF16: 'pk::bf16', lib.BF16X3: 'pk::bf16x3'}.get(dtype, 'float')
+            return f'gemm_dma_splitk_kernel<{t}>', 'mfma', 2.0 * M * N * K
+        if name == 'sum_batch':
+            src, S, out, E = a[:4]
+            return 'sum_batch_kernel', 'hbm', 4.0 * E * (S + 1)
         if name == 'unpatchify':
             pix, video, f0, nt, pt, ph, pw = a[:7]
             B, C, F, H, W = video.shape
@@ -323,7 +342,7 @@ class KernelProfiler:
         self._lib = _lib
         self._orig = {}
         prof = self
-        names = ['gemm', 'patch_embed', 'qkv_project', 'qkv_attn', 'q_attn_cached', 'attn_fwd', 'attn_small', 'vocab_sample', 'layernorm', 'layernorm_lfq', 'patchify_ln',
+        names = ['gemm', 'patch_embed', 'patch_embed_splitk', 'patch_embed_finish', 'gemm_splitk', 'sum_batch', 'qkv_project', 'qkv_attn', 'q_attn_cached', 'attn_fwd', 'attn_small', 'vocab_sample', 'layernorm', 'layernorm_lfq', 'patchify_ln',
                  'unpatchify', 'peg', 'lfq_encode', 'lfq_decode', 'embed', 'cfg_mix', 'critic_head', 'attn_prep', 'vocab_reduce',
                  'topk_mask', 'l2norm_rows']
 
@@ -888,6 +907,14 @@ def main():
     if enc_rows:
         result['roofline'] = roofline_of(enc_rows, args.dtype)
         kernels += enc_rows
+        pe = [r for r in enc_rows if r['kernel'].startswith(('patch_embed', 'patchify_ln', 'gemm_dma_splitk', 'sum_batch'))]
+        if pe:
+            # the north star's first-named kernel on the axis SURVEY 8d prescribes for it: the whole patch embedding (every launch it takes in
+            # this mode) against the f32 video bytes it has to read once + the token rows it writes
+            us = sum(r['us_total'] for r in pe)
+            alg = args.batch * 3 * 17 * 256 * 256 * 4.0 + args.batch * 576 * 512 * 6.0
+            result['roofline_hbm'] = {'kernel': 'patch embedding (' + ' + '.join(sorted({r['kernel'] for r in pe})) + ')', 'bound': 'hbm', 'us': us,
+                                      'algorithmic_bytes': alg, 'achieved': alg / us / 1e3, 'unit': 'GB/s', 'peak': PEAK_HBM_GBS, 'frac': alg / us / 1e3 / PEAK_HBM_GBS}
     legs = set() if args.encode_only else set(x for x in args.legs.split(',') if x)
     if 'decode' in legs:
         result['decode'], dec_rows = bench_decode(cv, args, ws, want_k)

@@ -101,6 +101,20 @@ int pk_patch_embed(const float* video, int B, int C, int F, int H, int W, int ph
                    const void* W1, int ldw1, const float* s1, const float* t1, float* out1, int f01, int nt1, int pt1,
                    int ldo, void* stream);
 
+/* The same product as ROW PANELS x ALL COLUMNS x K-SLICES (round 4; cvivit.py:273-285): a workgroup owns 128 patch rows, all N <= 512 output
+ * columns and one K-slice of 1024 features -- the f32 video is read exactly once, 204 workgroups at B = 8.  pk_patch_embed_splitk writes, per
+ * group, the raw partial products part_g [slices_g][rows_g][N] f32 (sum_k bf16(x_k - c) W_g[n][k] over the slice) and the partial row statistics
+ * stats_g [slices_g][rows_g][2] f32 (sum, sum of squares of x - c); slices_g = pk_patch_embed_slices(C*pt_g*ph*pw).  pk_patch_embed_finish adds
+ * the slices in index order, applies the folded nn.LayerNorm(P) (s, t = W beta + bias, eps1, K = P) AND the nn.LayerNorm(N) that follows
+ * (gamma2, beta2, eps2), writing the token rows: out2 f32 and / or out bf16, row r -> (r / remap_in) * remap_out + remap_off + r % remap_in. */
+int pk_patch_embed_slices(int K);
+int pk_patch_embed_splitk(const float* video, int B, int C, int F, int H, int W, int ph, int pw, int N, int ngroups,
+                          const void* W0, int ldw0, float* part0, float* stats0, int f00, int nt0, int pt0,
+                          const void* W1, int ldw1, float* part1, float* stats1, int f01, int nt1, int pt1, void* stream);
+int pk_patch_embed_finish(const float* part, const float* stats, int nslices, int rows, int N, int K, const float* s, const float* t,
+                          float eps1, const float* gamma2, const float* beta2, float eps2, float* out2, int ldo2, void* out, int ldo,
+                          int remap_in, int remap_out, int remap_off, void* stream);
+
 /* cvivit.py:326-334: Rearrange 'b t h w (c pt p1 p2) -> b c (t pt) (h p1) (w p2)' into frames [f0, f0 + nt*pt). */
 int pk_unpatchify(const float* pix, int ldp, float* video, int B, int C, int F, int H, int W, int f0, int nt,
                   int pt, int ph, int pw, void* stream);

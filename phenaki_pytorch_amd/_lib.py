@@ -33,6 +33,11 @@ SIGNATURES = {
     'pk_patch_embed': [_P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I,
                        _P, _I, _P, _P, _P, _I, _I, _I,
                        _P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
+    'pk_patch_embed_slices': [_I],
+    'pk_patch_embed_splitk': [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I,
+                              _P, _I, _P, _P, _I, _I, _I,
+                              _P, _I, _P, _P, _I, _I, _I, _P],
+    'pk_patch_embed_finish': [_P, _P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _F, _P, _I, _P, _I, _I, _I, _I, _P],
     'pk_patch_frame_mask': [_P, _LL, _P, _LL, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'pk_unpatchify': [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'pk_sqdiff_partials': [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
@@ -229,6 +234,33 @@ def patch_embed(video, ph, pw, N, groups, eps=1e-5):
     ldo = groups[0][3].stride(0)
     rc = load().pk_patch_embed(f32p(video, 'video'), B, C, F, H, W, ph, pw, N, eps, len(groups), *flat, ldo, stream(video))
     _check(rc, 'pk_patch_embed')
+
+
+def patch_embed_slices(K):
+    return load().pk_patch_embed_slices(int(K))
+
+
+def patch_embed_splitk(video, ph, pw, N, groups):
+    """row panels x all columns x K-slices (the header): groups = 1 or 2 tuples (Wg (N, Kpad) bf16, part (slices, rows, N) f32,
+    stats (slices, rows, 2) f32, f0, nt, pt), long-K group first; finish every group with patch_embed_finish"""
+    B, C, F, H, W = video.shape
+    flat = []
+    for (Wg, part, stats, f0, nt, pt) in groups:
+        flat += [ptr(Wg), Wg.stride(0), ptr(part), ptr(stats), f0, nt, pt]
+    if len(groups) == 1:
+        flat += [None, 0, None, None, 0, 0, 0]
+    rc = load().pk_patch_embed_splitk(f32p(video, 'video'), B, C, F, H, W, ph, pw, N, len(groups), *flat, stream(video))
+    _check(rc, 'pk_patch_embed_splitk')
+
+
+def patch_embed_finish(part, stats, K, s, t, eps1, gamma2, beta2, eps2, *, out2=None, out=None, remap=(0, 0, 0)):
+    """tokens of one frame group from its K-slices: folded LayerNorm(P) + bias, then LayerNorm(N); out2 f32 / out bf16 rows (remapped)"""
+    nslices, rows, N = part.shape
+    rc = load().pk_patch_embed_finish(ptr(part), ptr(stats), nslices, rows, N, int(K), f32p(s, 'folded s'), f32p(t, 'folded t'), float(eps1),
+                                      f32p(gamma2, 'LayerNorm weight'), f32p(beta2, 'LayerNorm bias'), float(eps2),
+                                      ptr(out2), out2.stride(-2) if out2 is not None else 0, ptr(out), out.stride(-2) if out is not None else 0,
+                                      *remap, stream(part))
+    _check(rc, 'pk_patch_embed_finish')
 
 
 def patch_frame_mask(src, dst, fmask, video_shape, f0, nt, pt, ph, pw):

@@ -301,6 +301,296 @@ void patch_embed_kernel_n128(const PatchEmbedArgs a) {
     patch_embed_body<4>(a, smem);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// Round 4: the same product as ROW PANELS x ALL COLUMNS x K-SLICES (pk_patch_embed_splitk + pk_patch_embed_finish).
+// The 128 x 128 tiling above re-reads the f32 video lines once per column tile (4 x 107 MB through the CU's 64 B/clk L1 path at B = 8) and has
+// only 144 workgroups; its PMC fetch was 1.58 x the algorithmic bytes.  Here a workgroup owns 128 patch rows x ALL N <= 512 output columns x one
+// K-slice of PW_KS = 1024 features: the video is read exactly once (each line by one workgroup), W (bf16, L2-resident) streams through a 2-stage
+// LDS-DMA ring of 64 KB k-tiles, 8 waves as 2 x 4 hold 64 x 128 accumulator tiles, and the 6 (P = 6144) / 3 (P = 3072) slices of a row panel
+// bring 32 x 6 + 4 x 3 = 204 workgroups to the 256 CUs in ONE round.  Per k-tile a workgroup moves 32 KB of f32 lines + 64 KB of W for
+// 8.4 MFLOP (87 flop per L1 byte against 65 for 128 x 128 tiles).  Every slice writes its raw partial product and the partial (sum, sum of
+// squares) of its centred rows; pk_patch_embed_finish adds the slices in index order (deterministic), applies the folded LayerNorm(P), the
+// Linear's bias, and the LayerNorm(dim) that follows -- the launch that used to be pk_layernorm -- writing the token rows (f32 + bf16 copy).
+constexpr int PW_BN = 512, PW_WSTAGE = PW_BN * 128, PW_KS = 1024, PW_SMEM = 2 * PE_ASTAGE + 2 * PW_WSTAGE;      // 160 KB: the whole LDS of a CU
+
+struct PatchWideGroup {
+    const void* W; int ldw, K;
+    int f0, nt, pt, rows, mtiles, nslices;
+    float* part;              // [nslices][rows][N] f32 raw partial products x' (gamma.W)^T
+    float* stats;             // [nslices][rows][2] f32 partial (sum x', sum x'^2)
+};
+struct PatchWideArgs {
+    const float* video;
+    int B, C, F, H, W, ph, pw, nh, nw;
+    int N;
+    uint32_t video_bytes;
+    int ngroups;
+    int dbg;                  // diagnostics (PK_PATCH_DBG; results are WRONG when set): 1 = no MFMAs, 2 = no W stream, 4 = no A conversion
+    PatchWideGroup g[2];
+};
+
+__device__ __forceinline__ void patch_embed_wide_body(const PatchWideArgs& a, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- work list: (group, slice, m-tile) in SLICE-MAJOR order, long-K group first; XCD x (workgroup b runs on XCD b % 8: speed only) owns a
+    // contiguous chunk of it, i.e. the row panels of one or two K-slices: their 1 MB of W is fetched over the fabric once per XCD and then
+    // served by its L2, instead of every workgroup streaming its own slice from the Infinity Cache (measured: 204 MB of W fabric traffic, 48.7 us)
+    const int n0w = a.g[0].mtiles * a.g[0].nslices;
+    const int nwork = n0w + (a.ngroups > 1 ? a.g[1].mtiles * a.g[1].nslices : 0);
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int wstart = xcd * nwork / 8, wcount = (xcd + 1) * nwork / 8 - wstart;
+    if (idx >= wcount) return;
+    int w = wstart + idx;
+    const int gi = (a.ngroups > 1 && w >= n0w) ? 1 : 0;
+    if (gi) w -= n0w;
+    const PatchWideGroup& G = a.g[gi];
+    const int slice = w / G.mtiles, mt = w - slice * G.mtiles;
+    const int m0 = mt * PE_BM;
+    const int K = G.K, ntk = K >> 6;                         // k-tiles of the whole row
+    const int kt0 = slice * (PW_KS >> 6);
+    const int nts = min(PW_KS >> 6, ntk - kt0);              // k-tiles of this slice (host: K % 64 == 0)
+
+    // ---- A side (as in patch_embed_body): lane -> (octet o = 8 lanes sharing a row, 16-byte piece p)
+    const int o = lane >> 3, p = lane & 7;
+    const int rr = ((o & 1) << 2) | (o >> 1);
+    const int pw = a.pw;
+    const int dline = pw < 32 ? (p * 4) / pw : 0, xin = pw < 32 ? (p * 4) % pw : p * 4;
+    const int per_b = G.nt * a.nh * a.nw;
+    uint32_t rowoff[2];
+    float cen[2];
+#pragma unroll
+    for (int hrow = 0; hrow < 2; ++hrow) {
+        const int r = m0 + wave * 16 + hrow * 8 + rr;
+        const bool ok = r < G.rows;
+        const int rc = ok ? r : 0;
+        const int b = rc / per_b, rem = rc - b * per_b;
+        const int tt = rem / (a.nh * a.nw), hw = rem - tt * (a.nh * a.nw);
+        const int hh = hw / a.nw, ww = hw - hh * a.nw;
+        const uint32_t org = (((uint32_t)(b * a.C) * a.F + (G.f0 + tt * G.pt)) * a.H + hh * a.ph) * a.W + ww * a.pw;
+        // the SAME centre for every slice of a row: the mean of the patch's first 32 features
+        const f32x4 c4 = *reinterpret_cast<const f32x4*>(a.video + org + (uint32_t)dline * a.W + xin);
+        float cs = (c4[0] + c4[1]) + (c4[2] + c4[3]);
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) cs += __shfl_xor(cs, off, 64);
+        cen[hrow] = ok ? cs * (1.0f / 32.0f) : 0.f;
+        rowoff[hrow] = ok ? (org + (uint32_t)dline * a.W + xin) * 4u : a.video_bytes;
+    }
+    const uintptr_t vb = reinterpret_cast<uintptr_t>(a.video);
+    const u32x4 rsrc = u32x4{(uint32_t)vb, (uint32_t)(vb >> 32) & 0xFFFFu, a.video_bytes, 0x00020000u};
+    const int lph = pw < 32 ? 32 / pw : 1;
+    int hx0, hy, hdt, hcc;
+    {
+        const int e0 = kt0 * 64, line0 = e0 / pw;
+        hx0 = e0 - line0 * pw;
+        hy = line0 % a.ph;
+        const int r2 = line0 / a.ph;
+        hdt = r2 % G.pt; hcc = r2 / G.pt;
+    }
+    auto next_soff = [&]() {
+        const uint32_t so = ((((uint32_t)hcc * a.F + hdt) * a.H + hy) * a.W + hx0) * 4u;
+        hx0 += 32;
+        if (hx0 >= pw) {
+            hx0 = 0; hy += lph;
+            if (hy >= a.ph) { hy = 0; if (++hdt == G.pt) { hdt = 0; if (++hcc == a.C) hcc = 0; } }
+        }
+        return so;
+    };
+    auto issue_a = [&](f32x4 (&r)[4]) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const uint32_t so = next_soff();
+            pe_load16(r[half * 2 + 0], rowoff[0], rsrc, so);
+            pe_load16(r[half * 2 + 1], rowoff[1], rsrc, so);
+        }
+    };
+
+    // ---- W side: a k-tile of all N columns = N / 8 DMA pieces, 8 per wave (rows past N read as zeros through the descriptor)
+    char* const wring = smem + 2 * PE_ASTAGE;
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const uint32_t bytesW = (uint32_t)a.N * (uint32_t)G.ldw * 2u;
+    __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(G.W), 0, bytesW, 0x00020000);
+    uint32_t offW[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int gn = (wave * 8 + i) * 8 + lrow;
+        offW[i] = gn < a.N ? (uint32_t)gn * (uint32_t)G.ldw * 2u + (uint32_t)((lslot ^ (lrow & 7)) * 16) : bytesW;
+    }
+    int wk = kt0;
+    auto issue_w = [&](int j) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (pe_lds_ptr)(wring + (j & 1) * PW_WSTAGE + (wave * 8 + i) * 1024), 16, offW[i], wk * 128, 0, 0);
+        if (++wk == ntk) wk = 0;
+    };
+
+    float rs[2] = {0.f, 0.f}, rq[2] = {0.f, 0.f};
+    auto convert_store = [&](const f32x4 (&r)[4], int stage) {
+        char* at = smem + stage * PE_ASTAGE;
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int hrow = 0; hrow < 2; ++hrow) {
+                f32x4 x = r[half * 2 + hrow];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x[e] -= cen[hrow];
+                    rs[hrow] += x[e];
+                    rq[hrow] = fmaf(x[e], x[e], rq[hrow]);
+                }
+                const int row = wave * 16 + hrow * 8 + rr;
+                const int slot = (half * 4 + (p >> 1)) ^ (row & 7);
+                *reinterpret_cast<u32x2*>(at + row * 128 + (slot << 4) + ((p & 1) << 3)) = u32x2{pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3])};
+            }
+    };
+
+    const int g = lane >> 4, lr = lane & 15;
+    const int wm = wave >> 2, wn = wave & 3;                // 2 x 4 waves: wave tile 64 rows x 128 columns
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    auto compute_half = [&](int j, int c) {                 // fragment chunk c (32 of the k-tile's 64 features): 32 MFMAs per wave
+        const char* at = smem + (j & 1) * PE_ASTAGE;
+        const char* wt = wring + (j & 1) * PW_WSTAGE;
+        Frag<bf16> fa[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lds_frag(fa[i], at, wm * 64 + i * 16 + lr, c, g);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            Frag<bf16> fw;
+            lds_frag(fw, wt, wn * 128 + jj * 16 + lr, c, g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][jj] = mma(fw, fa[i], acc[i][jj]);
+        }
+    };
+    // (measured and removed: waves w / w + 4 of a SIMD issuing their W pieces half an iteration apart -- 53.0 vs 52.6 us, no effect)
+
+    // ---- pipeline.  A(j) lives in register set j % 3, issued three k-tiles ahead, converted into LDS stage (j & 1) one k-tile ahead; W(j) goes by
+    // LDS-DMA into ring slot (j & 1), issued one k-tile ahead (the slot is free once every wave has passed the barrier that ended iteration j - 2's
+    // successor).  Iteration j issues [W(j+1) x 8][A(j+4) x 4] and ends waiting for all but the 4 most recent VMEM operations: that retires
+    // W(j+1) and every older A set.  Loads past the slice wrap to valid addresses and are never converted.
+    f32x4 r0[4], r1[4], r2[4];
+    issue_a(r0);                                            // A(0)
+    issue_w(0);                                             // W(0)
+    issue_a(r1);                                            // A(1)
+    issue_a(r2);                                            // A(2)
+    pe_wait<8>(r0);                                         // A(0) and W(0) landed (A(1), A(2) may fly)
+    __builtin_amdgcn_sched_barrier(0);
+    convert_store(r0, 0);
+    issue_a(r0);                                            // A(3)
+    pe_wait<8>(r1);                                         // A(1) landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    auto iteration = [&](int j, f32x4 (&nxt_regs)[4], f32x4 (&wait_regs)[4]) {
+        if (j + 1 < nts && !(a.dbg & 4)) convert_store(nxt_regs, (j + 1) & 1);   // A stage (j+1)&1 was last read in iteration j-1: every wave is past that barrier
+        if (!(a.dbg & 2)) issue_w(j + 1);                         // W slot (j+1)&1 was last read in iteration j-1 likewise
+        issue_a(nxt_regs);                                        // A(j+4): unconditional (see the toolchain note above)
+        if (j < nts && !(a.dbg & 1)) { compute_half(j, 0); compute_half(j, 1); }
+        pe_wait<4>(wait_regs);                                    // W(j+1) landed; wait_regs = A(j+2) (older) landed too
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int j = 0; j < nts; j += 3) {                      // the last round may run up to 2 iterations past the slice: they only issue and wait
+        iteration(j, r1, r2);
+        iteration(j + 1, r2, r0);
+        iteration(j + 2, r0, r1);
+    }
+    pe_wait<0>(r0);
+    pe_wait<0>(r1);
+    pe_wait<0>(r2);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- this slice's partial statistics of the wave's 16 rows (fold the 8 lanes of an octet)
+#pragma unroll
+    for (int hrow = 0; hrow < 2; ++hrow) {
+        float s = rs[hrow], q = rq[hrow];
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) { s += __shfl_xor(s, off, 64); q += __shfl_xor(q, off, 64); }
+        const int m = m0 + wave * 16 + hrow * 8 + rr;
+        if (p == 0 && m < G.rows) reinterpret_cast<float2*>(G.stats)[(size_t)slice * G.rows + m] = float2{s, q};
+    }
+    // ---- raw partial product: lane holds 4 consecutive columns of rows wm*64 + i*16 + lr
+    float* part = G.part + (size_t)slice * G.rows * a.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + lr;
+        if (m >= G.rows) continue;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = wn * 128 + j * 16 + g * 4;
+            if (n < a.N) store4(part + (size_t)m * a.N + n, acc[i][j]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * PE_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))       // the whole LDS: one workgroup per CU
+void patch_embed_wide_kernel(const PatchWideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    patch_embed_wide_body(a, smem);
+}
+
+// pk_patch_embed_finish: one wave per token row.  y = rstd (sum_s part_s - mean' s) + t over the row's P features (statistics = the slices'
+// partial sums), then LayerNorm(dim) of y (gamma2, beta2, eps2) -> out2 (f32) and / or out (bf16), rows remapped as pk_layernorm's remap does.
+struct PatchFinishArgs {
+    const float* part; const float* stats; int nslices, rows, N, K;
+    const float* s; const float* t; float eps1;
+    const float* gamma2; const float* beta2; float eps2;
+    float* out2; bf16* out; int ldo2, ldo;
+    int remap_in, remap_out, remap_off;
+};
+__global__ __launch_bounds__(256) void patch_embed_finish_kernel(const PatchFinishArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    float su = 0.f, sq = 0.f;
+    for (int sl = 0; sl < a.nslices; ++sl) {                 // slices in index order: deterministic
+        const float2 st = reinterpret_cast<const float2*>(a.stats)[(size_t)sl * a.rows + row];
+        su += st.x; sq += st.y;
+    }
+    const float inv_k = 1.0f / (float)a.K;
+    const float mean = su * inv_k;
+    const float rstd = 1.0f / sqrtf(fmaxf(sq * inv_k - mean * mean, 0.f) + a.eps1);
+    // N <= 512: up to two 4-column pieces per lane (columns lane*4 + q*256)
+    f32x4 y[2];
+    float ls = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int n = lane * 4 + q * 256;
+        y[q] = f32x4{0, 0, 0, 0};
+        if (n < a.N) {
+            f32x4 acc = f32x4{0, 0, 0, 0};
+            for (int sl = 0; sl < a.nslices; ++sl) acc += *reinterpret_cast<const f32x4*>(a.part + ((size_t)sl * a.rows + row) * a.N + n);
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.s + n), t4 = *reinterpret_cast<const f32x4*>(a.t + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { y[q][r] = rstd * (acc[r] - mean * s4[r]) + t4[r]; ls += y[q][r]; }
+        }
+    }
+    const float m2 = wave_sum(ls) / (float)a.N;
+    float lq = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (lane * 4 + q * 256 < a.N)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = y[q][r] - m2; lq = fmaf(d, d, lq); }
+    const float r2 = 1.0f / sqrtf(wave_sum(lq) / (float)a.N + a.eps2);
+    const int orow = a.remap_in > 0 ? (row / a.remap_in) * a.remap_out + a.remap_off + row % a.remap_in : row;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int n = lane * 4 + q * 256;
+        if (n >= a.N) continue;
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.gamma2 + n), b4 = *reinterpret_cast<const f32x4*>(a.beta2 + n);
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (y[q][r] - m2) * r2 * g4[r] + b4[r];
+        if (a.out2) store4(a.out2 + (size_t)orow * a.ldo2 + n, v);
+        if (a.out) store4(a.out + (size_t)orow * a.ldo + n, v);
+    }
+}
+
 }  // namespace pk
 using namespace pk;
 
@@ -357,6 +647,72 @@ extern "C" int pk_patch_embed(const float* video, int B, int C, int F, int H, in
         const int NT = (N + PeGeom<2>::BN - 1) / PeGeom<2>::BN;
         hipLaunchKernelGGL(patch_embed_kernel_n64, dim3(8 * ((MT + 7) / 8) * NT), dim3(64 * PE_WAVES), PeGeom<2>::SMEM, st, a);
     }
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+
+// K-slice length of pk_patch_embed_splitk (features per slice); the caller sizes part / stats with pk_patch_embed_slices(K)
+extern "C" int pk_patch_embed_slices(int K) { return K <= 0 ? 0 : (K + PW_KS - 1) / PW_KS; }
+
+// Row panels x all columns x K-slices (see the kernel): per group gi the raw partial products part_gi [slices_gi][rows_gi][N] f32 and the partial
+// row statistics stats_gi [slices_gi][rows_gi][2] f32, slices_gi = pk_patch_embed_slices(C * pt_gi * ph * pw); finish with pk_patch_embed_finish.
+// W_gi [N][ldw_gi] bf16 = gamma (.) W zero-padded along K to 64.  N <= 512, N % 4 == 0.
+extern "C" int pk_patch_embed_splitk(const float* video, int B, int C, int F, int H, int W, int ph, int pw, int N, int ngroups,
+                                     const void* W0, int ldw0, float* part0, float* stats0, int f00, int nt0, int pt0,
+                                     const void* W1, int ldw1, float* part1, float* stats1, int f01, int nt1, int pt1, void* stream) {
+    if (!video || B <= 0 || C <= 0 || F <= 0 || H <= 0 || W <= 0 || ph <= 0 || pw <= 0 || N <= 0 || N > PW_BN || (ngroups != 1 && ngroups != 2)) return PK_EINVAL;
+    if (H % ph || W % pw || (pw & (pw - 1)) || pw < 8 || pw > 128 || (W & 3) || (N & 3)) return PK_EINVAL;
+    if (pw < 32 && ph % (32 / pw)) return PK_EINVAL;
+    const size_t vbytes = (size_t)B * C * F * H * W * 4;
+    if (vbytes >= 0xFFFFFFF0ull) return PK_EINVAL;
+    auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+    PatchWideArgs a;
+    a.video = video; a.B = B; a.C = C; a.F = F; a.H = H; a.W = W; a.ph = ph; a.pw = pw; a.nh = H / ph; a.nw = W / pw;
+    a.N = N; a.video_bytes = (uint32_t)vbytes; a.ngroups = ngroups;
+    static const int dbg_env = [] { const char* e = getenv("PK_PATCH_DBG"); return e ? atoi(e) : 0; }();      // timing decomposition only
+    a.dbg = dbg_env;
+    const void* Ws[2] = {W0, W1}; const int ldws[2] = {ldw0, ldw1}; float* parts[2] = {part0, part1}; float* stt[2] = {stats0, stats1};
+    const int f0s[2] = {f00, f01}, nts[2] = {nt0, nt1}, pts[2] = {pt0, pt1};
+    int work = 0;
+    for (int gi = 0; gi < ngroups; ++gi) {
+        PatchWideGroup& G = a.g[gi];
+        if (!Ws[gi] || !parts[gi] || !stt[gi] || nts[gi] <= 0 || pts[gi] <= 0 || f0s[gi] < 0 || f0s[gi] + nts[gi] * pts[gi] > F) return PK_EINVAL;
+        if (mis(video) || mis(Ws[gi]) || mis(parts[gi]) || (reinterpret_cast<uintptr_t>(stt[gi]) & 7)) return PK_EALIGN;
+        G.W = Ws[gi]; G.ldw = ldws[gi]; G.part = parts[gi]; G.stats = stt[gi];
+        G.K = C * pts[gi] * ph * pw;
+        if (G.K % 64 || G.ldw < G.K || (G.ldw & 7) || (size_t)N * G.ldw * 2 >= 0xFFFFFFF0ull) return PK_EINVAL;
+        G.f0 = f0s[gi]; G.nt = nts[gi]; G.pt = pts[gi];
+        G.rows = B * nts[gi] * a.nh * a.nw;
+        G.mtiles = (G.rows + PE_BM - 1) / PE_BM;
+        G.nslices = (G.K + PW_KS - 1) / PW_KS;
+        work += G.mtiles * G.nslices;
+    }
+    if (ngroups == 1) a.g[1] = a.g[0];
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PK_ELAUNCH;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_embed_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PW_SMEM) != hipSuccess) return PK_ELAUNCH;
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(patch_embed_wide_kernel, dim3(8 * ((work + 7) / 8)), dim3(64 * PE_WAVES), PW_SMEM, reinterpret_cast<hipStream_t>(stream), a);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+// tokens of one frame group from its slices: LayerNorm(P) fold (s, t incl. the Linear's bias, eps1; K = P) -> LayerNorm(N) (gamma2, beta2, eps2);
+// out2 [.][ldo2] f32 and / or out [.][ldo] bf16; output row = (row / remap_in) * remap_out + remap_off + row % remap_in (remap_in = 0: identity).
+extern "C" int pk_patch_embed_finish(const float* part, const float* stats, int nslices, int rows, int N, int K, const float* s, const float* t,
+                                     float eps1, const float* gamma2, const float* beta2, float eps2, float* out2, int ldo2, void* out, int ldo,
+                                     int remap_in, int remap_out, int remap_off, void* stream) {
+    if (!part || !stats || !s || !t || !gamma2 || !beta2 || (!out2 && !out) || nslices <= 0 || rows <= 0 || N <= 0 || N > 512 || (N & 3) || K <= 0) return PK_EINVAL;
+    auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+    if (mis(part) || mis(s) || mis(t) || mis(gamma2) || mis(beta2) || (out2 && (mis(out2) || (ldo2 & 3))) || (out && ((reinterpret_cast<uintptr_t>(out) & 7) || (ldo & 3))) ||
+        (reinterpret_cast<uintptr_t>(stats) & 7)) return PK_EALIGN;
+    if (remap_in < 0 || (remap_in > 0 && (remap_out < remap_in || remap_off < 0))) return PK_EINVAL;
+    PatchFinishArgs a{part, stats, nslices, rows, N, K, s, t, eps1, gamma2, beta2, eps2, out2, reinterpret_cast<bf16*>(out), ldo2, ldo, remap_in, remap_out, remap_off};
+    hipLaunchKernelGGL(patch_embed_finish_kernel, dim3((rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

@@ -21,6 +21,8 @@ from .quantize import LFQ, VectorQuantize
 
 # PK_PATCH_FUSED=0: the bf16 patch embedding keeps pk_patchify_ln + pk_gemm (A/B timing of the fused pk_patch_embed)
 _PATCH_FUSED = os.environ.get('PK_PATCH_FUSED', '1') != '0'
+# PK_PATCH_WIDE=0: the round-3 tiling of the fused patch embedding (128 x 128 tiles, pk_patch_embed + pk_layernorm) for A/B timing
+_PATCH_WIDE = os.environ.get('PK_PATCH_WIDE', '1') != '0'
 _PE_SPLITK = int(os.environ.get('PK_PE_SPLITK', '4'))          # K-slices of the split-bf16 patch-embedding GEMM (1: one plain launch)
 
 
@@ -187,6 +189,24 @@ class CViViT(PackedModule):
         fused = (_PATCH_FUSED and dt == L.BF16 and pw in (8, 16, 32, 64, 128) and all((C * ptg * ph * pw) % 192 == 0 for _, _, _, ptg, _ in groups)
                  and (pw >= 32 or ph % (32 // pw) == 0) and self.dim % 4 == 0 and video.numel() * 4 < 0xFFFFFFF0 and
                  all(seq[1].eps == groups[0][0][1].eps for seq, *_ in groups))
+        if fused and _PATCH_WIDE and self.dim <= 512:
+            # round 4: row panels x all columns x K-slices (pk_patch_embed_splitk: the video read once, 204 workgroups at B = 8), then per group
+            # ONE finish launch = slice sum + folded LayerNorm(P) + bias + the LayerNorm(dim) that follows
+            spec, fin = [], []
+            for seq, f0, ntg, ptg, goff in groups:
+                ln1, lin, ln2 = seq[1], seq[2], seq[3]
+                P = C * ptg * ph * pw
+                wg, s_, t_, _ = folded_weight(lin, 'pe_ln', lambda lin=lin: lin.weight.detach(), ln1.weight, ln1.bias, dt, [lin.weight, ln1.weight, ln1.bias])
+                ns, rows = L.patch_embed_slices(P), B * ntg * hw
+                part = torch.empty((ns, rows, self.dim), device=dev, dtype=torch.float32)
+                stats = torch.empty((ns, rows, 2), device=dev, dtype=torch.float32)
+                spec.append((wg, part, stats, f0, ntg, ptg))
+                fin.append((part, stats, P, s_, _pe_bias(lin, t_), ln1.eps, ln2, (ntg * hw, T * hw, goff)))
+            L.patch_embed_splitk(video, ph, pw, self.dim, spec)
+            for part, stats, P, s_, tb, eps1, ln2, remap in fin:
+                L.patch_embed_finish(part, stats, P, s_, tb, eps1, ln2.weight, ln2.bias, ln2.eps, out2=tokens, out=tokens_t, remap=remap)
+            self.__dict__['_pk_tokens_t'] = tokens_t
+            return tokens, T
         if fused:
             # ONE launch: patch gather + LayerNorm(P) + Linear for both frame groups (pk_patch_embed), then the LayerNorm(dim) per group
             spec, tmps = [], []

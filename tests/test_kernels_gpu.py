@@ -1122,6 +1122,56 @@ def test_patch_embed_fused(L, B, C, Fr, H, W, pt, ph, pw, N):
             L.patch_embed(video.cuda(), ph, pw, N, [(wg.cuda(), wg.float().sum(1).cuda(), torch.zeros(N).cuda(), out, 0, 2, 1)])      # frames beyond F
 
 
+@pytest.mark.parametrize('B,C,Fr,H,W,pt,ph,pw,N', [(2, 3, 5, 64, 64, 2, 16, 16, 128), (1, 3, 17, 256, 256, 2, 32, 32, 512), (3, 3, 3, 32, 64, 2, 8, 32, 96),
+                                                   (2, 1, 1, 64, 64, 2, 32, 32, 64), (1, 3, 9, 96, 64, 2, 32, 32, 512)])
+def test_patch_embed_row_panels_splitk(L, B, C, Fr, H, W, pt, ph, pw, N):
+    """pk_patch_embed_splitk + pk_patch_embed_finish (round 4: row panels x all columns x K-slices, the LayerNorm(dim) that follows fused into the
+    finish) against the reference op sequence Rearrange -> LayerNorm(P) -> Linear -> LayerNorm(dim) (cvivit.py:273-285) in f64, both frame groups,
+    ragged row panels and short last slices, f32 and bf16 token rows with the (b t h w) remap, incl. the low-contrast / large-offset video."""
+    nh, nw = H // ph, W // pw
+    nt = (Fr - 1) // pt
+    T = 1 + nt
+    hw = nh * nw
+    for offset, contrast in ((0.0, 1.0), (40.0, 0.05)):
+        video = torch.randn(B, C, Fr, H, W, generator=g(300)) * contrast + offset
+        tokens = torch.full((B * T * hw, N), float('nan'), device='cuda')
+        tokens_t = torch.full((B * T * hw, N), float('nan'), device='cuda', dtype=torch.bfloat16)
+        want = torch.zeros(B, T, hw, N, dtype=torch.float64)
+        spec, fin = [], []
+        for f0, ntg, ptg, seed, goff in ((1, nt, pt, 1, hw), (0, 1, 1, 2, 0)):
+            if ntg <= 0:
+                continue
+            P = C * ptg * ph * pw
+            gamma = 1 + 0.1 * torch.randn(P, generator=g(301 + seed))
+            beta = 0.1 * torch.randn(P, generator=g(303 + seed))
+            Wl = torch.randn(N, P, generator=g(305 + seed)) / math.sqrt(P)
+            bl = 0.1 * torch.randn(N, generator=g(307 + seed))
+            g2, b2 = 1 + 0.1 * torch.randn(N, generator=g(309 + seed)), 0.1 * torch.randn(N, generator=g(311 + seed))
+            fr = video[:, :, f0:f0 + ntg * ptg]
+            pat = fr.reshape(B, C, ntg, ptg, nh, ph, nw, pw).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B * ntg * hw, P).double()
+            ref = F.layer_norm(F.layer_norm(pat, (P,), gamma.double(), beta.double()) @ Wl.double().t() + bl.double(), (N,), g2.double(), b2.double())
+            want[:, (0 if f0 == 0 else 1):(1 if f0 == 0 else T)] = ref.view(B, ntg, hw, N)
+            Kp = (P + 63) // 64 * 64
+            wg = torch.zeros(N, Kp)
+            wg[:, :P] = Wl * gamma[None, :]
+            wg = wg.to(torch.bfloat16)
+            ns, rows = L.patch_embed_slices(P), B * ntg * hw
+            assert ns == (P + 1023) // 1024
+            part = torch.full((ns, rows, N), float('nan'), device='cuda')
+            stats = torch.full((ns, rows, 2), float('nan'), device='cuda')
+            spec.append((wg.cuda(), part, stats, f0, ntg, ptg))
+            fin.append((part, stats, P, wg.float().sum(1).cuda(), (Wl @ beta + bl).cuda(), g2.cuda(), b2.cuda(), (ntg * hw, T * hw, goff)))
+        L.patch_embed_splitk(video.cuda(), ph, pw, N, spec)
+        for part, stats, P, s, t, g2, b2, remap in fin:
+            assert torch.isfinite(part).all() and torch.isfinite(stats).all()
+            L.patch_embed_finish(part, stats, P, s, t, 1e-5, g2, b2, 1e-5, out2=tokens, out=tokens_t, remap=remap)
+        ref = want.view(B * T * hw, N).float()
+        close(tokens, ref, 2e-2, f'tokens, offset {offset}')           # bf16 operands over P terms, then a LayerNorm
+        rms = ((tokens.cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+        assert rms < 5e-3, f'offset {offset}: rms error {rms:.2e}'
+        assert torch.equal(tokens_t.float().cpu(), bf(tokens.cpu())), 'the bf16 token rows are the rounding of the f32 ones'
+
+
 @pytest.mark.parametrize('numel', [1, 7, 1000, 70000, 256 * 2048 * 4 + 5, 3 * 576 * 65536])
 def test_torch_philox_reproduction_is_bit_exact(L, numel):
     """common.hpp torch_uniform == torch.zeros(numel, device='cuda').uniform_(0, 1), element by element, through pk_vocab_sample_philox:
