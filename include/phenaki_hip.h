@@ -372,6 +372,23 @@ int pk_attn_bwd(const float* Qh, const float* Kh, const float* Vh, const void* O
                 const float* bias, const unsigned char* kmask, const float* slopes, int causal, float* dQh, float* dKh, float* dVh, float* dS,
                 float* lse, float* Drow, int S, int heads, int n, int n_kv, int nnull, int split_bf16, void* stream);
 
+/* ---- the tokenizer's adversarial branch: cvivit.py:59-213 (Discriminator), :604-671 (hinge / gradient penalty / adaptive weight).
+ * Images are CHANNELS-LAST pixel rows x[(b, y, x)][c] (f32, C % 4 == 0), so every nn.Conv2d (cvivit.py:115-127, 191) is pk_gemm on a patch matrix:
+ * pk_im2col: cols[(b, yo, xo)][(ky * kw + kx) * C + c] = x[b][yo stride + ky - pad][xo stride + kx - pad][c], zero outside the image
+ *   (3x3 / pad 1: the net convolutions; 1x1 / stride 2: conv_res; 2x2 / stride 2: Rearrange('b c (h p1) (w p2) -> b (c p1 p2) h w') + 1x1 conv);
+ * pk_col2im: its adjoint in gather form (input gradient of the convolution; deterministic).
+ * pk_nchw_to_rows / pk_rows_to_nchw: (B, C, H, W) <-> rows[(b, y, x)][Cp] with channels C..Cp-1 zero / dropped (mutually adjoint).
+ * pk_pick_frames: pick_video_frame (cvivit.py:217-224) img[b] = video[b, :, frame[b]] (place = 0), or the adjoint into a zeroed video (place = 1).
+ * pk_bmm: C[z] = op(A[z]) op(B[z]) (+ C[z]) in exact f32 for any shape / leading dimension / batch stride (elements): the fallback product of the
+ *   second-order graph of gradient_penalty (cvivit.py:59-73) and of the 64-token attention block inside the discriminator (cvivit.py:166-168). */
+int pk_im2col(const float* x, int B, int H, int W, int C, int kh, int kw, int stride, int pad, float* cols, long long ldc, void* stream);
+int pk_col2im(const float* cols, long long ldc, int B, int H, int W, int C, int kh, int kw, int stride, int pad, float* dx, void* stream);
+int pk_nchw_to_rows(const float* img, int B, int C, int H, int W, int Cp, float* rows, void* stream);
+int pk_rows_to_nchw(const float* rows, int B, int C, int H, int W, int Cp, float* img, void* stream);
+int pk_pick_frames(float* video, const int* frame, int B, int C, int F, int H, int W, float* img, int place, void* stream);
+int pk_bmm(const float* A, long long lda, long long sA, int tA, const float* B, long long ldb, long long sB, int tB, float* C, long long ldc,
+           long long sC, int batch, int M, int N, int K, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

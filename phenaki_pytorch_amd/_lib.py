@@ -88,6 +88,12 @@ SIGNATURES = {
     'pk_adamw': [_P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _LL, _P],
     'pk_adamw_multi': [_P, _I, _F, _F, _F, _F, _F, _I, _P],
     'pk_attn_bwd': [_P, _P, _P, _P, _LL, _I, _P, _LL, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    'pk_im2col': [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _LL, _P],
+    'pk_col2im': [_P, _LL, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    'pk_nchw_to_rows': [_P, _I, _I, _I, _I, _I, _P, _P],
+    'pk_rows_to_nchw': [_P, _I, _I, _I, _I, _I, _P, _P],
+    'pk_pick_frames': [_P, _P, _I, _I, _I, _I, _I, _P, _I, _P],
+    'pk_bmm': [_P, _LL, _LL, _I, _P, _LL, _LL, _I, _P, _LL, _LL, _I, _I, _I, _I, _I, _P],
 }
 
 _ERR = {-1: 'PK_EINVAL (bad shape/size/flag)', -2: 'PK_EALIGN (pointer/stride alignment)', -3: 'PK_ELAUNCH (HIP launch failed)'}
@@ -644,6 +650,50 @@ def gemm_splitk(dtype, A, W, M, N, K, splits, C, bias=None, tile=0):
     """C (splits, M, N) f32 <- the K-slices of A @ W^T (see the header; bias on slice 0; tile 1: 128 x 128 tiles); reduce with sum_batch"""
     rc = load().pk_gemm_splitk(dtype, ptr(A), A.stride(-2), ptr(W), W.stride(0), M, N, K, splits, ptr(C), N, f32p(bias, 'bias'), int(tile), stream(C))
     _check(rc, 'pk_gemm_splitk')
+
+
+# ----------------------------------------------------------------------------- discriminator layout kernels (csrc/conv.hip)
+
+def conv_out_size(n, k, stride, pad):
+    return (n + 2 * pad - k) // stride + 1
+
+
+def im2col(x, B, H, W, C, kh, kw, stride, pad, cols):
+    """x (B H W, C) channels-last pixel rows -> cols (B Ho Wo, kh kw C), column (ky, kx, c)"""
+    _check(load().pk_im2col(ptr(x), B, H, W, C, kh, kw, stride, pad, ptr(cols), cols.stride(0), stream(x)), 'pk_im2col')
+    return cols
+
+
+def col2im(cols, B, H, W, C, kh, kw, stride, pad, dx):
+    """the adjoint of im2col: dx (B H W, C) <- sum of the patch-matrix entries that read each pixel"""
+    _check(load().pk_col2im(ptr(cols), cols.stride(0), B, H, W, C, kh, kw, stride, pad, ptr(dx), stream(cols)), 'pk_col2im')
+    return dx
+
+
+def nchw_to_rows(img, Cp, rows):
+    B, C, H, W = img.shape
+    _check(load().pk_nchw_to_rows(ptr(img), B, C, H, W, Cp, ptr(rows), stream(img)), 'pk_nchw_to_rows')
+    return rows
+
+
+def rows_to_nchw(rows, Cp, img):
+    B, C, H, W = img.shape
+    _check(load().pk_rows_to_nchw(ptr(rows), B, C, H, W, Cp, ptr(img), stream(rows)), 'pk_rows_to_nchw')
+    return img
+
+
+def pick_frames(video, frame, img, place=False):
+    """img (B, C, H, W) <- video[b, :, frame[b]] (cvivit.py:217-224), or the adjoint into a zeroed video when place"""
+    B, C, F, H, W = video.shape
+    _check(load().pk_pick_frames(ptr(video), ptr(frame), B, C, F, H, W, ptr(img), 1 if place else 0, stream(video)), 'pk_pick_frames')
+    return video if place else img
+
+
+def bmm(A, B, C, tA, tB, batch, M, N, K, *, lda, ldb, ldc, sA=0, sB=0, sC=0, accumulate=False):
+    """C[z] = op(A[z]) op(B[z]) in exact f32 (any shape / stride); op = transpose when tA / tB"""
+    _check(load().pk_bmm(ptr(A), lda, sA, 1 if tA else 0, ptr(B), ldb, sB, 1 if tB else 0, ptr(C), ldc, sC, batch, M, N, K,
+                         1 if accumulate else 0, stream(A)), 'pk_bmm')
+    return C
 
 
 class TorchPhilox:

@@ -11,14 +11,15 @@ grep -E "passed|failed|FAILED|Error" gpurun_out/tests_full.log | tail -8
 echo "== smoke"; date
 timeout 600 python __graft_entry__.py smoke 2>&1 | tail -2
 echo "== bench"; date
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_full.json 2> gpurun_out/bench_full.err; echo "bench rc=$?"
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_line.json 2> gpurun_out/bench_full.err; echo "bench rc=$?"
 tail -c 600 gpurun_out/bench_full.err
 python - <<'PY'
 import json
 d=json.load(open('gpurun_out/bench_full.json'))
 print('encode', round(d['value']), 'frames/s', round(d['ms_per_step'],4), 'ms; roofline', d['roofline']['kernel'], round(d['roofline']['frac'],3), 'traffic', d['roofline']['traffic'])
-print('decode', round(d['decode']['value']), 'sample', round(d['sample']['value']), d['sample']['seconds_by_launch_mode'], 'cfg3', round(d['sample_cfg3']['value']), 'make_video', d['make_video']['wall_clock_s'], round(d['make_video']['value']))
-print('parity_mode', round(d['parity_mode']['value']), round(d['parity_mode']['sample']['value']), d['parity_mode']['roofline']['frac'])
-print('cpu', d['cpu_baseline'])
+line=open('gpurun_out/bench_line.json').read().strip().splitlines()[-1]
+c=json.loads(line)
+print('compact line bytes', len(line), 'sample', c['sample']['value'], 'parity', c['parity'], 'legs', c['legs'])
+print('cpu', c['cpu_baseline'])
 PY
 echo "== done"; date
