@@ -89,3 +89,14 @@ def state_dicts(tag):
             sd[name] = v.to(dt)
         out.append(sd)
     return out
+
+
+def gan_state_dict(tag, discr_keys, requires_grad=False):
+    """the C-ViViT state_dict of state_dicts(tag) plus the discriminator's entries (`discr.*`: name -> shape, as stored in
+    tests/golden/gan_<tag>.pt) with the same name-keyed weights the golden generator gave the reference module (salt 1)"""
+    sd = dict(state_dicts(tag)[0])
+    for name, shape in discr_keys.items():
+        sd[name] = weights.fill_value(name, torch.empty(shape), 1)
+    if requires_grad:
+        sd = {k: (v.clone().requires_grad_() if v.is_floating_point() and not k.endswith('.beta') else v) for k, v in sd.items()}
+    return sd

@@ -546,6 +546,73 @@ def t5_golden(tag, cfg, B, L, sub):
     print(f't5_{tag}: out {tuple(out.shape)} absmax {out.abs().max().item():.3f}')
 
 
+def _grad_summary(module):
+    """per parameter: the 2-norm of the whole gradient (f64) and every stride-th element of it (<= 4096 values): the fixture stays small"""
+    grads = {}
+    for k, v in module.named_parameters():
+        if v.grad is None or k.startswith('vgg.'):
+            continue
+        flat = v.grad.detach().reshape(-1)
+        stride = max(1, -(-flat.numel() // 4096))
+        grads[k] = dict(norm=float(flat.double().norm()), stride=stride, sample=flat[::stride].clone(), shape=tuple(v.shape))
+    return grads
+
+
+def gan_golden(R, cfgs, tag, batch=2, frames=5):
+    """SURVEY.md 8f row 4, the adversarial half: the REAL reference's CViViT(use_vgg_and_gan=True, vgg=<stub>) in training mode --
+    (1) Discriminator logits on a fixed image batch; (2) forward(video, return_discr_loss=True) (cvivit.py:604-622: hinge + gradient penalty)
+    + backward: loss and every discriminator gradient; (3) forward(video) (cvivit.py:585-671: recon + perceptual + adaptive_weight * gen) +
+    backward: loss, its parts and every gradient; (4) the same under a frame mask.  The frame the reference picks (torch.randn on the host
+    generator after torch.manual_seed) is stored, so the oracle can be fed the same choice."""
+    H = cfgs['cvivit']['image_size']
+    vgg = weights.stub_vgg(H)
+    cv = R.CViViT(use_vgg_and_gan=True, vgg=vgg, **cfgs['cvivit'])
+    weights.fill_module(cv, salt=1)
+    cv.train()
+    video = weights.synthetic_video(batch, frames, H, H, seed=12)
+    mask = torch.tensor([[True] * frames, [True] * (frames - 2) + [False] * 2][:batch])
+    out = dict(mask=mask, discr_keys={k: list(v.shape) for k, v in cv.state_dict().items() if k.startswith('discr.')})
+    imgs = weights.synthetic_video(3, 1, H, H, seed=13)[:, :, 0]
+    with torch.no_grad():
+        out['logits'] = cv.discr(imgs).clone()
+
+    def frames_for(seed, m=None):
+        torch.manual_seed(seed)
+        logits = torch.randn(batch, frames)
+        if m is not None:
+            logits = logits.masked_fill(~m, -torch.finfo(logits.dtype).max)
+        return logits.topk(1, dim=-1).indices.reshape(-1)
+
+    # (2) discriminator step
+    out['frame_discr'] = frames_for(21)
+    cv.zero_grad(set_to_none=True)
+    torch.manual_seed(21)
+    loss = cv(video, return_discr_loss=True)
+    loss.backward()
+    out['loss_discr'] = loss.detach().clone()
+    out['grads_discr'] = {k: v for k, v in _grad_summary(cv).items() if k.startswith('discr.')}
+    # the two terms separately (the reference returns only their sum): hinge alone = the same call with the penalty's weight removed
+    with torch.no_grad():
+        recon = cv(video, return_recons_only=True)
+    real = R.cvivit.pick_video_frame(video, out['frame_discr'][:, None])
+    fake = R.cvivit.pick_video_frame(recon, out['frame_discr'][:, None])
+    with torch.no_grad():
+        out['hinge_discr'] = R.cvivit.hinge_discr_loss(cv.discr(fake), cv.discr(real)).clone()
+    # (3) generator step, (4) with a frame mask
+    for name, m, seed in (('gen', None, 22), ('gen_masked', mask, 23)):
+        out[f'frame_{name}'] = frames_for(seed, m)
+        cv.zero_grad(set_to_none=True)
+        torch.manual_seed(seed)
+        loss = cv(video, mask=m) if m is not None else cv(video)
+        loss.backward()
+        out[f'loss_{name}'] = loss.detach().clone()
+        out[f'grads_{name}'] = _grad_summary(cv)
+    torch.save(out, os.path.join(OUT, f'gan_{tag}.pt'))
+    print(f'gan_{tag}: discr loss {float(out["loss_discr"]):.6f} (hinge {float(out["hinge_discr"]):.6f}, {len(out["grads_discr"])} gradients), '
+          f'generator loss {float(out["loss_gen"]):.6f} ({len(out["grads_gen"])} gradients), masked {float(out["loss_gen_masked"]):.6f}; '
+          f'frames {out["frame_discr"].tolist()} {out["frame_gen"].tolist()} {out["frame_gen_masked"].tolist()}')
+
+
 def keys_golden(R):
     """state_dict contract: every key, shape and dtype of the reference modules."""
     import json
@@ -586,6 +653,8 @@ def main():
         forward_grads_golden(R, TINY, batch=3, frames=5, ctx_len=6, tag='tiny')
     if 'tiny' in which or 'grads' in which or 'cvgrads' in which:
         cvivit_grads_golden(R, TINY, tag='tiny')
+    if 'tiny' in which or 'gan' in which:
+        gan_golden(R, TINY, tag='tiny')
     if 'tiny' in which or 'critics' in which:
         selfcritic_golden(R, TINY, tag='tiny')
         unconditional_golden(R, TINY, tag='tiny')

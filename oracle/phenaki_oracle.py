@@ -374,12 +374,9 @@ def cvivit_recon_loss(sd, cfg, video, mask=None):
     return el[mask[:, None, :].expand(-1, video.shape[1], -1)].mean()
 
 
-def cvivit_recon_loss_train(sd, cfg, video, mask=None):
-    """the differentiable form of cvivit_recon_loss (the module in training mode): the LFQ output is the straight-through
-    `proj + (sign(proj) - proj).detach()` of oracle/lfq.py, everything else as cvivit.py:518-627.  Autograd over the tensors of `sd`."""
-    import torch.nn.functional as F
-    if video.ndim == 4:
-        video = video.unsqueeze(2)
+def cvivit_reconstruct_train(sd, cfg, video):
+    """video -> reconstruction with the module in training mode (differentiable): the LFQ output is the straight-through
+    `proj + (sign(proj) - proj).detach()` of oracle/lfq.py, everything else as cvivit.py:518-583.  Autograd over the tensors of `sd`."""
     tokens = cvivit_patch_embed(sd, cfg, video)
     tokens = cvivit_encode(sd, cfg, tokens)
     b, t, h, w, d = tokens.shape
@@ -387,11 +384,22 @@ def cvivit_recon_loss_train(sd, cfg, video, mask=None):
     q = torch.where(proj > 0, torch.ones_like(proj), -torch.ones_like(proj))
     q = proj + (q - proj).detach()
     codes = q @ sd['vq.project_out.weight'].t() + sd['vq.project_out.bias']
-    recon = cvivit_decode(sd, cfg, codes)
+    return cvivit_decode(sd, cfg, codes)
+
+
+def _masked_mse(video, recon, mask):
+    import torch.nn.functional as F
     if mask is None:
         return F.mse_loss(video, recon)
     el = F.mse_loss(video, recon, reduction='none')
     return el[mask[:, None, :].expand(-1, video.shape[1], -1)].mean()
+
+
+def cvivit_recon_loss_train(sd, cfg, video, mask=None):
+    """the differentiable form of cvivit_recon_loss (cvivit.py:518-627 with the module in training mode)"""
+    if video.ndim == 4:
+        video = video.unsqueeze(2)
+    return _masked_mse(video, cvivit_reconstruct_train(sd, cfg, video), mask)
 
 
 # --------------------------------------------------------------------------- MaskGit / critic

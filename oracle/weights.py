@@ -92,3 +92,15 @@ def ragged_context(lengths, dim, seed=1):
     for b, n in enumerate(lengths):
         ctx[b, n:] = 0.
     return ctx
+
+
+def stub_vgg(image_size, salt=9):
+    """a small stand-in for the perceptual network a caller passes as CViViT(vgg=...) (cvivit.py:346-347): (B, 3, H, W) -> (B, 32) features
+    through pooling and two Linears (no convolution: the GPU box runs it on ATen without a MIOpen find step); name-keyed weights"""
+    from torch import nn
+    H, W = (image_size, image_size) if isinstance(image_size, int) else image_size
+    net = nn.Sequential(nn.AvgPool2d(4), nn.Flatten(), nn.Linear(3 * (H // 4) * (W // 4), 64), nn.Tanh(), nn.Linear(64, 32))
+    fill_module(net, salt=salt)
+    for p_ in net.parameters():
+        p_.requires_grad_(False)
+    return net

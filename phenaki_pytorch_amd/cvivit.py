@@ -3,18 +3,19 @@
 Same constructor signature, attribute names and state_dict keys as the reference `CViViT`; `forward(...,
 return_only_codebook_ids=True)`, `forward(..., return_recons_only=True)`, `encode`, `decode`,
 `decode_from_codebook_indices` and the shape helpers run here; with `use_vgg_and_gan=False` the default `forward(video)`
-returns the VALUE of the reconstruction loss (cvivit.py:585-627, no autograd graph).  The discriminator / VGG / adaptive-
-weight branches (cvivit.py:604-671) need autograd, are out of scope for this build and raise.
+returns the VALUE of the reconstruction loss (cvivit.py:585-627, no autograd graph) under no_grad and the training step's loss
+with a graph otherwise (train_cvivit.py).  `use_vgg_and_gan=True` builds the Discriminator (discriminator.py); the perceptual /
+adversarial / adaptive-weight objective and `return_discr_loss=True` (cvivit.py:604-671) run in train_cvivit.py.
 """
+import contextlib
 import copy
+import os
 from pathlib import Path
 
 import torch
 from torch import nn
 
 from . import _lib as L
-import os
-
 from .attention import (ContinuousPositionBias, PackedModule, Transformer, compute_dtype_of, exists, folded_weight, invalidate_packed,
                         linear_weight, ln_fold_enabled, value_without_graph, set_compute_dtype)
 from .quantize import LFQ, VectorQuantize
@@ -92,11 +93,29 @@ class CViViT(PackedModule):
         self.to_pixels_first_frame = nn.Sequential(nn.Linear(dim, p1), _Rearrange())
         self.to_pixels = nn.Sequential(nn.Linear(dim, p2), _Rearrange())
 
-        # VQGAN training branch (cvivit.py:336-363) is not part of the inference hot path
+        # VQGAN training branch (cvivit.py:336-363): not on the inference hot path; the tokenizer's own training uses it (train_cvivit.py)
         self.vgg = None
         self.discr = None
         self.use_vgg_and_gan = use_vgg_and_gan
         self.use_hinge_loss = use_hinge_loss
+        if not use_vgg_and_gan:
+            return
+        if exists(vgg):
+            self.vgg = vgg
+        else:
+            # the reference default is torchvision's pretrained VGG16 with the last two classifier layers cut (cvivit.py:349-352); it needs
+            # torchvision and a download.  Without them the module still builds (inference and the discriminator step need no VGG); the
+            # generator's GAN step then asks for `vgg=` (train_cvivit.py).
+            try:
+                import torchvision
+                self.vgg = torchvision.models.vgg16(pretrained=True)
+                self.vgg.classifier = nn.Sequential(*self.vgg.classifier[:-2])
+            except Exception as e:                                    # noqa: BLE001  (ImportError offline, URLError without network, ...)
+                import warnings
+                warnings.warn(f'CViViT(use_vgg_and_gan=True): no perceptual network ({type(e).__name__}: {e}); pass vgg=<nn.Module> to train '
+                              'with the perceptual + adversarial losses')
+        from .discriminator import Discriminator
+        self.discr = Discriminator(image_size=self.image_size, dim=discr_base_dim, channels=channels, attn_res_layers=discr_attn_res_layers)
 
     # ---------------------------------------------------------------- host-side helpers (cvivit.py:365-447)
 
@@ -145,16 +164,33 @@ class CViViT(PackedModule):
         device = next(self.parameters()).device
         invalidate_packed(self)                       # packed device weights are rebuilt lazily, never copied
         vae_copy = copy.deepcopy(self)
-        if vae_copy.use_vgg_and_gan:
+        if vae_copy.use_vgg_and_gan:                  # cvivit.py:415-417 (`del`; here the attributes stay, as None: forward() reads them)
             vae_copy.discr = None
             vae_copy.vgg = None
         vae_copy.eval()
         return vae_copy.to(device)
 
+    @contextlib.contextmanager
+    def _without_vgg(self):
+        """@remove_vgg (cvivit.py:35-49): the perceptual network is never part of a checkpoint"""
+        vgg = self._modules.get('vgg')
+        if isinstance(vgg, nn.Module):
+            del self._modules['vgg']
+        try:
+            yield
+        finally:
+            if isinstance(vgg, nn.Module):
+                self._modules['vgg'] = vgg
+
+    def state_dict(self, *args, **kwargs):
+        with self._without_vgg():
+            return super().state_dict(*args, **kwargs)
+
     def load_state_dict(self, state_dict, *args, **kwargs):
-        # reference checkpoints may carry the GAN / VGG parts (cvivit.py:35-49, 336-363): not used here
-        sd = {k: v for k, v in state_dict.items() if not (k.startswith('vgg.') or k.startswith('discr.'))}
-        return super().load_state_dict(sd, *args, **kwargs)            # PackedModule: also drops the packed weight caches
+        # cvivit.py:424-426; a checkpoint of a GAN-trained tokenizer also loads into a module built without the discriminator
+        sd = {k: v for k, v in state_dict.items() if not (k.startswith('vgg.') or (self.discr is None and k.startswith('discr.')))}
+        with self._without_vgg():
+            return super().load_state_dict(sd, *args, **kwargs)        # PackedModule: also drops the packed weight caches
 
     def load(self, path):
         path = Path(path)
@@ -401,10 +437,16 @@ class CViViT(PackedModule):
 
     def forward(self, video, mask=None, return_recons=False, return_recons_only=False, return_discr_loss=False,
                 apply_grad_penalty=True, return_only_codebook_ids=False):
-        if not (return_only_codebook_ids or return_recons_only or return_discr_loss):
+        if return_discr_loss and not (return_only_codebook_ids or return_recons_only):
+            # cvivit.py:604-622: the discriminator's step (hinge + gradient penalty); a graph over self.discr's parameters when grad mode is on
+            from .train_cvivit import cvivit_discr_loss
+            self._check_video(video, mask)
+            return cvivit_discr_loss(self, video, mask=mask, apply_grad_penalty=apply_grad_penalty, return_recons=return_recons)
+        if not (return_only_codebook_ids or return_recons_only):
             from .train import wants_grad
-            if wants_grad(self):
-                # grad mode on and trainable parameters: the tokenizer's training step (train_cvivit.py)
+            if wants_grad(self) or self.use_vgg_and_gan:
+                # grad mode on and trainable parameters: the tokenizer's training step (train_cvivit.py); the GAN objective
+                # needs gradients for its adaptive weight (cvivit.py:657-662), so it takes this path whenever it is asked for
                 from .train_cvivit import cvivit_loss_train
                 self._check_video(video, mask)
                 return cvivit_loss_train(self, video, mask=mask, return_recons=return_recons)
@@ -439,10 +481,7 @@ class CViViT(PackedModule):
         if return_only_codebook_ids:
             return self.tokenize(video)
 
-        if not return_recons_only and (return_discr_loss or self.use_vgg_and_gan):
-            raise NotImplementedError('the discriminator / VGG / adaptive-weight losses (cvivit.py:604-671) need autograd and are '
-                                      'outside the MI355X build; the reconstruction loss (use_vgg_and_gan=False), '
-                                      'return_only_codebook_ids=True and return_recons_only=True are supported')
+        assert return_recons_only or not (return_discr_loss or self.use_vgg_and_gan), 'forward() routes the GAN objectives to train_cvivit.py'
         ids = self.tokenize(video).reshape(-1)
         T = 1 + (f - 1) // self.temporal_patch_size
         recon = self._decode2d(self.vq.codes_2d(ids, perm=(T, self.image_num_tokens)), b, T, temporal_rows=True)

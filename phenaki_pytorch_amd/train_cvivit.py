@@ -19,12 +19,24 @@ forward and backward kernels, the PEG with causal frame padding); this file adds
                     bijection of the pixels, so the loss is taken in patch layout        / pk_scaled_diff
 
 The frame `mask` of variable-length training (cvivit.py:585-589) zeroes the dropped frames on both sides of the difference (pk_patch_frame_mask).
-Not built: the discriminator / VGG / adaptive-weight branch (cvivit.py:604-671: torchvision's pretrained VGG16 is not available offline).
+
+With `use_vgg_and_gan = True` (cvivit.py:593-671) the same graph continues into the adversarial branch (discriminator.py):
+
+    _Unpatchify     pixel rows of both frame groups -> the reconstructed video             pk_unpatchify / pk_patchify_ln (raw rows) of the gradient
+    PickFrame       one random frame per sample (pick_video_frame, cvivit.py:217-224)      pk_pick_frames, both directions
+    perceptual loss F.mse_loss(vgg(frame), vgg(recon frame)) through the CALLER's `vgg=` module (cvivit.py:346-352: torchvision's pretrained VGG16
+                    is the reference default and is not available offline -- any nn.Module mapping (B, 3, H, W) to features works)
+    generator loss  -discr(recon frame).mean()  (hinge) through the Discriminator's HIP graph
+    adaptive weight ||d perceptual / d to_pixels.weight|| / ||d gen / d to_pixels.weight||  by torch.autograd.grad over these Functions
+    cvivit_discr_loss  `return_discr_loss=True` (cvivit.py:604-622): hinge loss on detached reconstructions + the gradient penalty, whose second
+                    derivatives run through the same kernels (discriminator.py)
 """
 import torch
+import torch.nn.functional as F
 
 from . import _lib as L
 from .attention import compute_dtype_of
+from .discriminator import PickFrame, bce_discr_loss, bce_gen_loss, gradient_penalty, hinge_discr_loss, hinge_gen_loss
 from .train import _Linear, _f32, linear_bwd, linear_fwd, position_bias_train, transformer_train
 
 _INDEX_CACHE = {}
@@ -214,6 +226,75 @@ class _PatchMSE(torch.autograd.Function):
         return outs[0], (outs[1] if ctx.has_rest else None), None, None, None, None
 
 
+class _Unpatchify(torch.autograd.Function):
+    """Rearrange 'b t h w (c pt p1 p2) -> b c (t pt) (h p1) (w p2)' of both frame groups + torch.cat along time (cvivit.py:326-334, 514): the
+    reconstructed video as one tensor; backward = the raw patch rows of the video gradient (the layout map is a bijection of the pixels)."""
+
+    @staticmethod
+    def forward(ctx, pix_first, pix_rest, geoms, shape):
+        video = _f32(shape, pix_first.device)
+        L.unpatchify(pix_first.detach().contiguous(), video, *geoms[0])
+        if pix_rest is not None:
+            L.unpatchify(pix_rest.detach().contiguous(), video, *geoms[1])
+        ctx.geoms, ctx.shapes = geoms, (tuple(pix_first.shape), tuple(pix_rest.shape) if pix_rest is not None else None)
+        return video
+
+    @staticmethod
+    def backward(ctx, dvideo):
+        dvideo = dvideo.contiguous()
+        outs = []
+        for shape, (f0, nt, pt, ph, pw) in zip(ctx.shapes, ctx.geoms):
+            if shape is None:
+                outs.append(None)
+                continue
+            d = _f32(shape, dvideo.device)
+            L.patchify_ln(dvideo, f0, nt, pt, ph, pw, None, None, d)
+            outs.append(d)
+        return outs[0], outs[1], None, None
+
+
+def _pick_frame_indices(b, f, mask, device):
+    """cvivit.py:593-602: one frame per sample, argmax of torch.randn(b, f) drawn on the HOST generator (as the reference does), masked frames excluded"""
+    logits = torch.randn(b, f)
+    if mask is not None:
+        logits = logits.masked_fill(~mask.detach().bool().cpu(), -torch.finfo(logits.dtype).max)
+    return logits.topk(1, dim=-1).indices.reshape(b).to(device=device, dtype=torch.int32)
+
+
+def _gan_losses_of(cv):
+    return (hinge_discr_loss, hinge_gen_loss) if cv.use_hinge_loss else (bce_discr_loss, bce_gen_loss)
+
+
+def _three_channels(t):
+    return t.expand(-1, 3, -1, -1) if t.shape[1] == 1 else t       # grayscale for the VGG (cvivit.py:640-641)
+
+
+def cvivit_discr_loss(cv, video, *, mask=None, apply_grad_penalty=True, return_recons=False):
+    """CViViT.forward(video, return_discr_loss=True) (cvivit.py:604-622): hinge (or BCE) loss of the discriminator on one random frame per sample of
+    the video and of its DETACHED reconstruction, plus the gradient penalty on the real frames.  The tokenizer runs without a graph (the
+    reference builds one and detaches).  apply_grad_penalty=False returns the discriminator loss alone (the reference leaves `loss` unbound there)."""
+    assert cv.discr is not None, 'discriminator must exist to train it'
+    is_image = video.ndim == 4
+    with torch.no_grad():
+        recon = cv._forward(video, mask, return_recons_only=True)
+    if is_image:
+        video, recon = video.unsqueeze(2), recon.unsqueeze(2)
+    video = video.detach().float().contiguous()
+    b, c, f = video.shape[:3]
+    frame = _pick_frame_indices(b, f, mask, video.device)
+    real_img = PickFrame.apply(video, frame).requires_grad_()
+    fake_img = PickFrame.apply(recon.detach().contiguous(), frame)
+    discr_loss_fn, _ = _gan_losses_of(cv)
+    fake_logits = cv.discr(fake_img)
+    real_logits = cv.discr(real_img, second_order=apply_grad_penalty)
+    loss = discr_loss_fn(fake_logits, real_logits)
+    if apply_grad_penalty:
+        loss = loss + gradient_penalty(real_img, real_logits)
+    if return_recons:
+        return loss, (recon.squeeze(2) if is_image else recon)
+    return loss
+
+
 def _patch_embed_train(seq, video, geom, dtype):
     _, ln1, lin, ln2 = seq
     return _PatchEmbedFn.apply(video, ln1.weight, ln1.bias, lin.weight, lin.bias, ln2.weight, ln2.bias, geom, dtype, ln1.eps, ln2.eps)
@@ -222,8 +303,9 @@ def _patch_embed_train(seq, video, geom, dtype):
 def cvivit_loss_train(cv, video, *, mask=None, return_recons=False):
     """CViViT.forward (cvivit.py:518-627, use_vgg_and_gan = False) with an autograd graph over the C-ViViT parameters"""
     if cv.use_vgg_and_gan:
-        raise NotImplementedError('the discriminator / VGG / adaptive-weight losses (cvivit.py:604-671) are outside the MI355X build; '
-                                  'construct CViViT(use_vgg_and_gan=False) to train on the reconstruction loss')
+        assert torch.is_grad_enabled(), 'the GAN objective differentiates its terms for the adaptive weight (cvivit.py:657-662): call it with grad mode on'
+        assert cv.vgg is not None, ('the perceptual loss needs a feature network: pass CViViT(vgg=<nn.Module>) -- the reference default, '
+                                    "torchvision's pretrained VGG16 (cvivit.py:346-352), is not available offline")
     assert cv.lookup_free_quantization, 'the training step is built for the LFQ tokenizer (the reference default)'
     is_image = video.ndim == 4
     if is_image:
@@ -269,10 +351,33 @@ def cvivit_loss_train(cv, video, *, mask=None, return_recons=False):
         fmask = mask.to(torch.uint8).contiguous()
         count = float(mask.sum().item()) * c * H * W                                  # (one host read per step: the divisor of the mean)
     loss = _PatchMSE.apply(pix_first, pix_rest, video, (geom_first, geom_rest), fmask, count)
+    recon = None
+    if cv.use_vgg_and_gan:
+        # cvivit.py:593-602, 631-667: perceptual + adversarial terms on one random frame per sample
+        recon = _Unpatchify.apply(pix_first, pix_rest, (geom_first, geom_rest), tuple(video.shape))
+        frame = _pick_frame_indices(b, f, mask, dev)
+        real_img = PickFrame.apply(video, frame)
+        recon_img = PickFrame.apply(recon, frame)
+        perceptual = F.mse_loss(cv.vgg(_three_channels(real_img)), cv.vgg(_three_channels(recon_img)))
+        _, gen_loss_fn = _gan_losses_of(cv)
+        gen_loss = gen_loss_fn(cv.discr(recon_img))
+        if pix_rest is not None:
+            last = lin_rest.weight                                                    # self.to_pixels[0].weight (cvivit.py:657)
+            g_gen, = torch.autograd.grad(gen_loss, last, retain_graph=True)
+            g_per, = torch.autograd.grad(perceptual, last, retain_graph=True)
+            adaptive = (g_per.detach().norm(p=2) / (g_gen.detach().norm(p=2) + 1e-8)).clamp_(max=1e4)
+        else:
+            # a 4-D image batch never reaches to_pixels (only to_pixels_first_frame): both gradient norms are 0 -> safe_div gives 0
+            adaptive = torch.zeros((), device=dev)
+        # vq_aux_loss (cvivit.py:667) is the third return of self.vq: 0 for the LFQ of quantize.py (the entropy / commitment terms of the
+        # un-vendored vector-quantize-pytorch are not restated)
+        loss = loss + perceptual + adaptive * gen_loss
     if not return_recons:
         return loss
-    recon = torch.empty_like(video)
-    L.unpatchify(pix_first.detach(), recon, *geom_first)
-    if pix_rest is not None:
-        L.unpatchify(pix_rest.detach(), recon, *geom_rest)
-    return loss, (recon.squeeze(2) if is_image else recon)
+    if recon is None:
+        recon = torch.empty_like(video)
+        L.unpatchify(pix_first.detach(), recon, *geom_first)
+        if pix_rest is not None:
+            L.unpatchify(pix_rest.detach(), recon, *geom_rest)
+    recon = recon.detach()
+    return loss, (recon.squeeze(2) if is_image else recon.clone())

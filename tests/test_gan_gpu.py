@@ -1,0 +1,294 @@
+"""The tokenizer's adversarial branch on the MI355X kernels (phenaki_pytorch_amd/discriminator.py, train_cvivit.py) against
+the REAL reference's CViViT(use_vgg_and_gan=True, vgg=<stub>) (tiny golden, oracle/make_golden.py gan_golden) and, at BASELINE geometry,
+against torch autograd through the reference-pinned oracle (oracle/gan_oracle.py)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import gan_oracle as G
+from oracle import weights
+from oracle.configs import FULL, TINY, gan_state_dict, oracle_cfgs
+from tests.test_oracle_golden import cvivit_grad_check, load
+from tests.util import close, record_parity
+
+pytestmark = pytest.mark.gpu
+
+MODES = [('fp32', 1e-3), ('bf16x3', 1e-3), ('bf16', None)]
+
+
+@pytest.fixture(autouse=True)
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    torch.cuda.set_device(0)
+    with torch.enable_grad():
+        yield
+
+
+def g32(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def gan_product(cfgs, discr_keys, dtype, tag='tiny'):
+    """product CViViT(use_vgg_and_gan=True, vgg=<stub>) with the name-keyed weights of the golden generator"""
+    import phenaki_pytorch_amd as P
+    sd = gan_state_dict(tag, discr_keys)
+    H = cfgs['cvivit']['image_size']
+    cv = P.CViViT(use_vgg_and_gan=True, vgg=weights.stub_vgg(H), **cfgs['cvivit'])
+    assert {k: list(v.shape) for k, v in cv.state_dict().items() if k.startswith('discr.')} == {k: list(v) for k, v in discr_keys.items()}
+    cv.load_state_dict(sd)
+    cv = cv.cuda().train()
+    P.set_compute_dtype(cv, dtype)
+    return cv, sd
+
+
+# ------------------------------------------------------------------------------------------------ kernels
+
+@pytest.mark.parametrize('k,stride,pad', [(3, 1, 1), (1, 2, 0), (2, 2, 0), (3, 2, 1)])
+def test_im2col_and_its_adjoint_match_unfold_fold(k, stride, pad):
+    from phenaki_pytorch_amd import _lib as L
+    B, H, W, C = 2, 6, 10, 8
+    x = torch.randn(B * H * W, C, generator=g32(1))
+    Ho, Wo = L.conv_out_size(H, k, stride, pad), L.conv_out_size(W, k, stride, pad)
+    cols = L.im2col(x.cuda(), B, H, W, C, k, k, stride, pad, torch.full((B * Ho * Wo, k * k * C), float('nan'), device='cuda'))
+    u = F.unfold(x.reshape(B, H, W, C).permute(0, 3, 1, 2), k, padding=pad, stride=stride)              # (B, C k k, L), rows (c, ky, kx)
+    ref = u.reshape(B, C, k * k, Ho * Wo).permute(0, 3, 2, 1).reshape(B * Ho * Wo, k * k * C)
+    assert torch.equal(cols.cpu(), ref)
+    d = torch.randn(B * Ho * Wo, k * k * C, generator=g32(2))
+    dx = L.col2im(d.cuda(), B, H, W, C, k, k, stride, pad, torch.full((B * H * W, C), float('nan'), device='cuda'))
+    fold = F.fold(d.reshape(B, Ho * Wo, k * k, C).permute(0, 3, 2, 1).reshape(B, C * k * k, Ho * Wo), (H, W), k, padding=pad, stride=stride)
+    close(dx.cpu(), fold.permute(0, 2, 3, 1).reshape(B * H * W, C), 1e-6, 'col2im')
+    # adjointness: <im2col(x), d> == <x, col2im(d)>
+    assert abs(float((cols.cpu().double() * d.double()).sum()) - float((x.double() * dx.cpu().double()).sum())) < 1e-3
+
+
+def test_pixel_row_and_frame_maps():
+    from phenaki_pytorch_amd import _lib as L
+    img = torch.randn(2, 3, 6, 8, generator=g32(3))
+    rows = L.nchw_to_rows(img.cuda(), 8, torch.full((2 * 48, 8), float('nan'), device='cuda')).cpu()
+    assert torch.equal(rows[:, :3], img.permute(0, 2, 3, 1).reshape(-1, 3)) and (rows[:, 3:] == 0).all()
+    back = L.rows_to_nchw(rows.cuda(), 8, torch.empty(2, 3, 6, 8, device='cuda')).cpu()
+    assert torch.equal(back, img)
+    video = torch.randn(3, 3, 5, 4, 8, generator=g32(4))
+    frame = torch.tensor([4, 0, 2], dtype=torch.int32)
+    pick = L.pick_frames(video.cuda(), frame.cuda(), torch.empty(3, 3, 4, 8, device='cuda')).cpu()
+    assert torch.equal(pick, G.pick_video_frame(video, frame))
+    placed = L.pick_frames(torch.zeros(3, 3, 5, 4, 8, device='cuda'), frame.cuda(), pick.cuda(), place=True).cpu()
+    ref = torch.zeros_like(video)
+    ref[torch.arange(3), :, frame.long()] = pick
+    assert torch.equal(placed, ref)
+
+
+@pytest.mark.parametrize('tA', [False, True])
+@pytest.mark.parametrize('tB', [False, True])
+def test_bmm_every_transposition_is_an_fmaf_chain(tA, tB):
+    from phenaki_pytorch_amd import _lib as L
+    Z, M, N, K = 3, 70, 33, 19
+    A = torch.randn((Z, K, M) if tA else (Z, M, K), generator=g32(5))
+    B = torch.randn((Z, N, K) if tB else (Z, K, N), generator=g32(6))
+    out = torch.full((Z, M, N), float('nan'), device='cuda')
+    L.bmm(A.cuda(), B.cuda(), out, tA, tB, Z, M, N, K, lda=A.shape[2], ldb=B.shape[2], ldc=N, sA=A[0].numel(), sB=B[0].numel(), sC=M * N)
+    ref = (A.transpose(1, 2) if tA else A).double() @ (B.transpose(1, 2) if tB else B).double()
+    close(out.cpu(), ref.float(), 1e-5, 'bmm')
+    acc = out.clone()
+    L.bmm(A.cuda(), B.cuda(), acc, tA, tB, Z, M, N, K, lda=A.shape[2], ldb=B.shape[2], ldc=N, sA=A[0].numel(), sB=B[0].numel(), sC=M * N, accumulate=True)
+    close(acc.cpu(), 2 * ref.float(), 1e-5, 'bmm accumulate')
+
+
+@pytest.mark.parametrize('shape', [(256, 64, 48), (40, 24, 7), (1024, 512, 32)])
+@pytest.mark.parametrize('tA,tB', [(False, True), (False, False), (True, False), (True, True)])
+def test_matrix_product_function_differentiates_twice(shape, tA, tB):
+    """_MM against torch.matmul: value, first derivatives and the derivative of a function of the first derivatives (what the gradient
+    penalty does), for GEMM-shaped operands (pk_gemm, split-K) and small ones (pk_bmm)"""
+    from phenaki_pytorch_amd import _lib as L
+    from phenaki_pytorch_amd.discriminator import mm
+    M, K, N = shape
+    A0 = torch.randn((K, M) if tA else (M, K), generator=g32(7))
+    B0 = torch.randn((N, K) if tB else (K, N), generator=g32(8)) / K ** 0.5
+    T = torch.randn(M, N, generator=g32(9))
+
+    def run(A, B, f):
+        C = f(A, B)
+        gA, gB = torch.autograd.grad((C * T.to(C.device)).sum() + (C ** 2).sum() * 0.5, (A, B), create_graph=True)
+        second = (gA ** 2).sum() + (gB ** 3).sum()
+        hA, hB = torch.autograd.grad(second, (A, B))
+        return C, gA, gB, hA, hB
+    ref = run(A0.clone().requires_grad_(), B0.clone().requires_grad_(), lambda a, b: (a.t() if tA else a) @ (b.t() if tB else b))
+    got = run(A0.cuda().requires_grad_(), B0.cuda().requires_grad_(), lambda a, b: mm(a, b, tA, tB, L.F32))
+    for name, r, o in zip(('C', 'dA', 'dB', 'd2A', 'd2B'), ref, got):
+        close(o.detach().cpu(), r.detach(), 2e-4, f'_MM {name} {shape} tA={tA} tB={tB}')
+
+
+# ------------------------------------------------------------------------------------------------ the discriminator
+
+@pytest.mark.parametrize('dtype,tol', MODES)
+@pytest.mark.parametrize('size,dim', [(64, 16), ((64, 32), 16), (32, 4)])
+def test_discriminator_logits_match_oracle(size, dim, dtype, tol):
+    import phenaki_pytorch_amd as P
+    from phenaki_pytorch_amd.discriminator import Discriminator
+    d = Discriminator(dim=dim, image_size=size)
+    weights.fill_module(d, salt=1)
+    sd = {'discr.' + k: v.clone() for k, v in d.state_dict().items()}
+    H, W = (size, size) if isinstance(size, int) else size
+    x = torch.randn(3, 3, H, W, generator=g32(10))
+    with torch.no_grad():
+        ref = G.discriminator(sd, x)
+        d = d.cuda()
+        P.set_compute_dtype(d, dtype)
+        got = d(x.cuda()).cpu()
+        got2 = d(x.cuda(), second_order=True).cpu()
+    close(got, ref, tol or 3e-2, f'discriminator logits ({dtype})')
+    close(got2, ref, tol or 3e-2, f'discriminator logits, second-order graph ({dtype})')
+
+
+@pytest.mark.parametrize('dtype,tol', MODES)
+def test_discriminator_step_matches_reference(golden_dir, dtype, tol):
+    """loss = cvivit(video, return_discr_loss=True); loss.backward() == the reference's: hinge + gradient penalty and every discriminator gradient
+    (the penalty's second derivatives run through pk_gemm / pk_im2col / pk_col2im / pk_bmm); the tokenizer's own parameters get none"""
+    g = load(golden_dir, 'gan_tiny.pt')
+    cv, _ = gan_product(TINY, g['discr_keys'], dtype)
+    H = TINY['cvivit']['image_size']
+    video = weights.synthetic_video(2, 5, H, H, seed=12).cuda()
+    torch.manual_seed(21)                                              # the reference draws its frame choice from the host generator
+    loss = cv(video, return_discr_loss=True)
+    assert loss.requires_grad and loss.ndim == 0
+    loss.backward()
+    ref = float(g['loss_discr'])
+    named = dict(cv.named_parameters())
+    assert all(v.grad is None for k, v in named.items() if not k.startswith('discr.'))
+    if tol is None:
+        assert abs(float(loss.detach()) - ref) <= 5e-2 * ref
+        assert all(torch.isfinite(named[k].grad).all() for k in g['grads_discr'] if named[k].numel())
+        return
+    assert abs(float(loss.detach()) - ref) <= 2e-4 * ref, (float(loss.detach()), ref)
+    cvivit_grad_check(lambda k: named[k].grad, g['grads_discr'], tol, 40)
+    with torch.no_grad():
+        torch.manual_seed(21)
+        hinge = cv(video, return_discr_loss=True, apply_grad_penalty=False)
+    assert abs(float(hinge) - float(g['hinge_discr'])) <= 2e-4
+    record_parity('discriminator_step_vs_reference', dict(dtype=dtype, loss=float(loss.detach()), ref_loss=ref, hinge=float(hinge),
+                                                          gradients=len(g['grads_discr'])))
+
+
+@pytest.mark.parametrize('kind', ['gen', 'gen_masked'])
+@pytest.mark.parametrize('dtype,tol', MODES)
+def test_generator_gan_step_matches_reference(golden_dir, dtype, tol, kind):
+    """loss = cvivit(video) with use_vgg_and_gan=True (reconstruction + perceptual through the caller's vgg + adaptive_weight * generator loss,
+    cvivit.py:585-671) and loss.backward(): the loss and every gradient (tokenizer AND discriminator) against the reference's"""
+    g = load(golden_dir, 'gan_tiny.pt')
+    cv, _ = gan_product(TINY, g['discr_keys'], dtype)
+    H = TINY['cvivit']['image_size']
+    video = weights.synthetic_video(2, 5, H, H, seed=12).cuda()
+    torch.manual_seed(22 if kind == 'gen' else 23)
+    loss = cv(video, mask=g['mask'].cuda()) if kind == 'gen_masked' else cv(video)
+    loss.backward()
+    ref = float(g[f'loss_{kind}'])
+    named = dict(cv.named_parameters())
+    grads = {k: v for k, v in g[f'grads_{kind}'].items() if v['norm'] > 0}
+    if tol is None:
+        assert abs(float(loss.detach()) - ref) <= 5e-2 * abs(ref)
+        assert all(named[k].grad is not None and torch.isfinite(named[k].grad).all() for k in grads if named[k].numel())
+        return
+    assert abs(float(loss.detach()) - ref) <= 2e-4 * abs(ref), (float(loss.detach()), ref)
+    cvivit_grad_check(lambda k: named[k].grad, grads, tol, 140)
+    record_parity('generator_gan_step_vs_reference', dict(dtype=dtype, kind=kind, loss=float(loss.detach()), ref_loss=ref, gradients=len(grads)))
+
+
+def test_gan_forward_surface():
+    """return_recons on both objectives, the 4-D image batch (adaptive weight 0: to_pixels is never reached), copy_for_eval, state_dict without vgg"""
+    g_keys = {k: list(v.shape) for k, v in _tiny_discr_state().items()}
+    cv, sd = gan_product(TINY, g_keys, 'bf16x3')
+    H = TINY['cvivit']['image_size']
+    video = weights.synthetic_video(2, 5, H, H, seed=12).cuda()
+    loss, recon = cv(video, return_recons=True)
+    assert recon.shape == video.shape and not recon.requires_grad and loss.requires_grad
+    dl, recon_d = cv(video, return_discr_loss=True, return_recons=True)
+    close(recon_d, recon, 1e-4, 'reconstruction of the two objectives')
+    img_loss = cv(video[:, :, 0])
+    img_loss.backward()
+    assert torch.isfinite(img_loss.detach())
+    with torch.no_grad():
+        assert cv(video, return_recons_only=True).shape == video.shape
+        assert cv(video, return_only_codebook_ids=True).dtype == torch.int64
+    ev = cv.copy_for_eval()
+    assert ev.discr is None and ev.vgg is None and cv.discr is not None
+    assert not any(k.startswith('vgg.') for k in cv.state_dict()) and any(k.startswith('discr.') for k in cv.state_dict())
+
+
+def _tiny_discr_state():
+    from phenaki_pytorch_amd.discriminator import Discriminator
+    d = Discriminator(dim=16, image_size=(TINY['cvivit']['image_size'],) * 2)
+    return {'discr.' + k: v for k, v in d.state_dict().items()}
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE geometry
+
+def _full_discr_keys():
+    from phenaki_pytorch_amd.discriminator import Discriminator
+    d = Discriminator(dim=16, image_size=(256, 256))
+    return {'discr.' + k: list(v.shape) for k, v in d.state_dict().items()}
+
+
+def _compare_grads(named, leaf, prefix, tol, what, dtype):
+    top = max(float(v.grad.abs().max()) for k, v in leaf.items() if getattr(v, 'grad', None) is not None and v.numel() and k.startswith(prefix))
+    errs = {}
+    for name, prm in named.items():
+        r = leaf.get(name)
+        if r is None or r.grad is None or r.numel() == 0 or not name.startswith(prefix):
+            continue
+        assert prm.grad is not None, name
+        if float(r.grad.abs().max()) < 1e-6 * top:
+            assert float(prm.grad.abs().max()) <= 1e-2 * tol * top, name
+            continue
+        errs[name] = close(prm.grad.cpu(), r.grad, tol, f'd {name} ({what}, {dtype})')
+    return errs
+
+
+@pytest.mark.parametrize('dtype,tol', [('fp32', 1e-3), ('bf16x3', 1e-3)])
+def test_discriminator_step_full_size_matches_oracle_autograd(dtype, tol):
+    """256 x 256 frames, the 7-block discriminator of BASELINE's C-ViViT (64 .. 512 channels, attention at 8 x 8): hinge + gradient penalty and
+    every discriminator gradient against torch autograd (double backward through F.conv2d) on the reference-pinned oracle"""
+    keys = _full_discr_keys()
+    cv, sd = gan_product(FULL, keys, dtype, tag='full')
+    cvc, _, _ = oracle_cfgs(FULL)
+    video = weights.synthetic_video(2, 5, 256, 256, seed=14)
+    torch.manual_seed(31)
+    frame = torch.randn(2, 5).topk(1, dim=-1).indices.reshape(-1)
+    leaf = {k: (v.clone().requires_grad_() if k.startswith('discr.') and v.is_floating_point() and not k.endswith('.beta') else v) for k, v in sd.items()}
+    ref = G.discr_loss(leaf, cvc, video, frame)
+    ref.backward()
+    torch.manual_seed(31)
+    loss = cv(video.cuda(), return_discr_loss=True)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 5e-4 * abs(float(ref.detach())), (float(loss.detach()), float(ref.detach()))
+    errs = _compare_grads(dict(cv.named_parameters()), leaf, 'discr.', tol, 'discriminator step', dtype)
+    assert len(errs) >= 55, len(errs)
+    worst = max(errs, key=errs.get)
+    record_parity('discriminator_step_full_vs_oracle_autograd', dict(dtype=dtype, loss=float(loss.detach()), ref_loss=float(ref.detach()),
+                                                                      gradients=len(errs), worst=worst, worst_rel_err=errs[worst]))
+
+
+@pytest.mark.parametrize('dtype,tol', [('fp32', 1e-3), ('bf16x3', 1e-3)])
+def test_generator_gan_step_full_size_matches_oracle_autograd(dtype, tol):
+    """BASELINE geometry: recon + perceptual + adaptive_weight * generator loss, every tokenizer and discriminator gradient vs the oracle"""
+    keys = _full_discr_keys()
+    cv, sd = gan_product(FULL, keys, dtype, tag='full')
+    cvc, _, _ = oracle_cfgs(FULL)
+    vgg = weights.stub_vgg(256)
+    video = weights.synthetic_video(1, 5, 256, 256, seed=15)
+    torch.manual_seed(32)
+    frame = torch.randn(1, 5).topk(1, dim=-1).indices.reshape(-1)
+    leaf = {k: (v.clone().requires_grad_() if v.is_floating_point() and not k.endswith('.beta') else v) for k, v in sd.items()}
+    parts = {}
+    ref = G.generator_loss(leaf, cvc, video, frame, vgg, parts=parts)
+    ref.backward()
+    torch.manual_seed(32)
+    loss = cv(video.cuda())
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 5e-4 * abs(float(ref.detach())), (float(loss.detach()), float(ref.detach()), parts)
+    errs = _compare_grads(dict(cv.named_parameters()), leaf, '', tol, 'generator step', dtype)
+    assert len(errs) >= 250, len(errs)
+    worst = max(errs, key=errs.get)
+    record_parity('generator_gan_step_full_vs_oracle_autograd', dict(dtype=dtype, loss=float(loss.detach()), ref_loss=float(ref.detach()),
+                                                                      parts={k: float(v) for k, v in parts.items()}, gradients=len(errs),
+                                                                      worst=worst, worst_rel_err=errs[worst]))

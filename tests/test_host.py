@@ -86,6 +86,32 @@ def test_reference_checkpoint_with_gan_keys_loads():
     cv.load_state_dict(sd)
 
 
+def test_gan_tokenizer_state_dict_contract(golden_dir):
+    """CViViT(use_vgg_and_gan=True, vgg=...) carries the reference's `discr.*` entries (names and shapes from the REAL reference,
+    tests/golden/gan_tiny.pt) and never the perceptual network's (cvivit.py:35-49 @remove_vgg); copy_for_eval drops both (:412-421)"""
+    import os
+    import warnings
+    import phenaki_pytorch_amd as P
+    from oracle import weights
+    from oracle.configs import gan_state_dict
+    g = torch.load(os.path.join(golden_dir, 'gan_tiny.pt'), weights_only=False)
+    cv = P.CViViT(use_vgg_and_gan=True, vgg=weights.stub_vgg(TINY['cvivit']['image_size']), **TINY['cvivit'])
+    sd = cv.state_dict()
+    assert {k: list(v.shape) for k, v in sd.items() if k.startswith('discr.')} == {k: list(v) for k, v in g['discr_keys'].items()}
+    assert not any(k.startswith('vgg.') for k in sd) and isinstance(cv.vgg, torch.nn.Module)
+    ref_sd = gan_state_dict('tiny', g['discr_keys'])
+    assert set(ref_sd) == set(sd)
+    cv.load_state_dict({**ref_sd, 'vgg.0.weight': torch.zeros(1)})         # a checkpoint that (wrongly) carries vgg entries still loads
+    assert torch.equal(cv.discr.blocks[0].conv_res.weight, ref_sd['discr.blocks.0.conv_res.weight'])
+    ev = cv.copy_for_eval()
+    assert ev.discr is None and ev.vgg is None and not any(k.startswith('discr.') for k in ev.state_dict())
+    # the default (no vgg=, no torchvision offline): the module still builds -- with its discriminator -- and says what the GAN step will need
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        d = P.CViViT(**TINY['cvivit'])
+    assert d.discr is not None and (d.vgg is not None or any('vgg' in str(x.message) for x in w))
+
+
 def test_shape_helpers_and_schedule():
     import phenaki_pytorch_amd as P
     from phenaki_pytorch_amd.phenaki import mask_schedule

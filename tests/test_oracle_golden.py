@@ -410,6 +410,39 @@ def test_cvivit_training_step_gradients_match_reference_autograd(golden_dir, kin
     cvivit_grad_check(lambda k: cv[k].grad, grads, 1e-4, 90 if kind == 'image' else 100)
 
 
+def test_gan_branch_oracle_matches_reference(golden_dir):
+    """oracle/gan_oracle.py (Discriminator, hinge loss, gradient penalty, perceptual + adaptive-weight generator objective) against the REAL
+    reference's CViViT(use_vgg_and_gan=True, vgg=<stub>): logits, both losses and every gradient (oracle/make_golden.py gan_golden)"""
+    from oracle import gan_oracle as G
+    from oracle.configs import gan_state_dict
+    g = load(golden_dir, 'gan_tiny.pt')
+    cvc, _, _ = oracle_cfgs(TINY)
+    H = TINY['cvivit']['image_size']
+    vgg = weights.stub_vgg(H)
+    video = weights.synthetic_video(2, 5, H, H, seed=12)
+    sd = gan_state_dict('tiny', g['discr_keys'])
+    imgs = weights.synthetic_video(3, 1, H, H, seed=13)[:, :, 0]
+    close(G.discriminator(sd, imgs), g['logits'], 1e-5)
+    # discriminator step: hinge + gradient penalty, gradients of the discriminator's parameters (second derivatives through the convolutions)
+    sd = gan_state_dict('tiny', g['discr_keys'], requires_grad=True)
+    with torch.enable_grad():
+        loss = G.discr_loss(sd, cvc, video, g['frame_discr'])
+        loss.backward()
+    assert abs(float(loss) - float(g['loss_discr'])) <= 1e-5 * float(g['loss_discr'])
+    with torch.no_grad():
+        assert abs(float(G.discr_loss(sd, cvc, video, g['frame_discr'], apply_grad_penalty=False)) - float(g['hinge_discr'])) <= 1e-5
+    cvivit_grad_check(lambda k: sd[k].grad, g['grads_discr'], 2e-4, 40)
+    assert all(v.grad is None for k, v in sd.items() if not k.startswith('discr.') and v.is_floating_point())
+    # generator step, plain and under a frame mask
+    for name, m in (('gen', None), ('gen_masked', g['mask'])):
+        sd = gan_state_dict('tiny', g['discr_keys'], requires_grad=True)
+        with torch.enable_grad():
+            loss = G.generator_loss(sd, cvc, video, g[f'frame_{name}'], vgg, mask=m)
+            loss.backward()
+        assert abs(float(loss) - float(g[f'loss_{name}'])) <= 1e-5 * abs(float(g[f'loss_{name}'])), name
+        cvivit_grad_check(lambda k: sd[k].grad, g[f'grads_{name}'], 2e-4, 140)
+
+
 @pytest.mark.parametrize('tag', ['tiny', 'base'])
 def test_t5_encoder_oracle_matches_huggingface(golden_dir, tag):
     """oracle/t5_oracle.py (restated from transformers' modeling_t5.py) against the REAL HuggingFace T5EncoderModel -- the module the
