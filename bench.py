@@ -735,6 +735,60 @@ def bench_cvivit_train_step(args, ws, mode):
     return out
 
 
+def bench_cvivit_gan_step(args, ws, mode):
+    """SURVEY.md 8f row 4, both halves of one CViViTTrainer.train_step (cvivit_trainer.py:226-270) at BASELINE geometry with use_vgg_and_gan = True:
+    (generator) loss = vae(video) [recon + perceptual through a caller-supplied feature network + adaptive_weight * hinge generator loss],
+    backward, AdamW on the tokenizer; (discriminator) loss = vae(video, return_discr_loss=True) [hinge + gradient penalty on 256 x 256 frames],
+    backward, AdamW on the discriminator.  The perceptual network here is a small pooling + Linear stand-in (torchvision's VGG16 is not available
+    offline): its cost is NOT the reference's VGG16 cost, everything else is the reference's step."""
+    import phenaki_pytorch_amd as P
+    from torch import nn
+    B = args.batch
+    torch.manual_seed(0)
+    vgg = nn.Sequential(nn.AvgPool2d(4), nn.Flatten(), nn.Linear(3 * 64 * 64, 64), nn.Tanh(), nn.Linear(64, 32))
+    for q in vgg.parameters():
+        q.requires_grad_(False)
+    cv = P.CViViT(use_vgg_and_gan=True, vgg=vgg, **BASELINE_CFG['cvivit']).cuda().train()
+    P.set_compute_dtype(cv, mode)
+    video = synthetic_video(B, 17, 256, 5).cuda()
+    gen_params = [p for n, p in cv.named_parameters() if p.requires_grad and not n.startswith('discr.')]
+    dis_params = [p for p in cv.discr.parameters() if p.requires_grad]
+    opt, dopt = P.get_optimizer(gen_params, lr=1e-4, wd=0.), P.get_optimizer(dis_params, lr=1e-4, wd=0.)
+    out = {}
+
+    def gen_step(i):
+        with torch.enable_grad():
+            opt.zero_grad(set_to_none=True)
+            loss = cv(video)
+            loss.backward()
+        opt.step()
+        out['gen_loss'] = loss.detach()
+
+    def discr_step(i, gp=True):
+        with torch.enable_grad():
+            dopt.zero_grad(set_to_none=True)
+            loss = cv(video, return_discr_loss=True, apply_grad_penalty=gp)
+            loss.backward()
+        dopt.step()
+        out['discr_loss'] = loss.detach()
+
+    for fn in (gen_step, discr_step, lambda i: discr_step(i, False)):
+        fn(0)
+    torch.cuda.reset_peak_memory_stats()
+    t_gen = statistics.median(timed_groups(gen_step, 2, 3, ws)) / 2
+    t_dis = statistics.median(timed_groups(discr_step, 2, 3, ws)) / 2
+    t_dis_nogp = statistics.median(timed_groups(lambda i: discr_step(i, False), 2, 3, ws)) / 2
+    # the discriminator's work per step (cvivit.py:141-213 at 256 x 256, B frames): 2 * MACs of its 7 blocks + head
+    res = dict(metric='cvivit_gan_step_frames_per_sec', value=B * 17 * ws / (t_gen + t_dis), unit='frames/s', dtype=mode, batch_per_gpu=B,
+               generator_step_ms=t_gen * 1e3, discriminator_step_ms=t_dis * 1e3, discriminator_step_no_penalty_ms=t_dis_nogp * 1e3,
+               gen_loss=float(out['gen_loss']), discr_loss=float(out['discr_loss']), peak_memory_gb=torch.cuda.max_memory_allocated() / 2 ** 30,
+               trained_parameters=dict(tokenizer=sum(p.numel() for p in gen_params), discriminator=sum(p.numel() for p in dis_params)),
+               note='one generator step + one discriminator step (gradient penalty on every step; the reference trainer applies it every 4th)')
+    del cv, opt, dopt
+    torch.cuda.empty_cache()
+    return res
+
+
 def bench_parity_mode(args, ws, mode='bf16x3'):
     """a PARITY-GRADE mode -- a configuration the parity tests hold to bit-exact ids (margin-audited) / 1e-3 against the REAL
     reference -- timed on the same workloads:
@@ -951,6 +1005,11 @@ def main():
         except Exception as e:                                  # noqa: BLE001 -- a training-leg failure must not cost the headline line
             print(f'[bench] train_step leg failed ({type(e).__name__}: {e})', file=sys.stderr)
             torch.cuda.synchronize()
+    if 'cvivit_gan_step' in legs and not args.encode_only:
+        try:
+            result['cvivit_gan_step'] = bench_cvivit_gan_step(args, ws, 'bf16x3' if args.dtype == 'bf16' else args.dtype)
+        except Exception as e:      # noqa: BLE001
+            print(f'[bench] cvivit_gan_step leg failed ({type(e).__name__}: {e})', file=sys.stderr)
     if 'cvivit_train_step' in legs and not args.encode_only:
         try:
             result['cvivit_train_step'] = bench_cvivit_train_step(args, ws, 'bf16x3' if args.dtype == 'bf16' else args.dtype)

@@ -106,7 +106,7 @@ class PackedModule(nn.Module):
 
 
 class _NoBackward(torch.autograd.Function):
-    """identity on a loss VALUE whose backward raises: the MI355X build has forward kernels only"""
+    """identity on a loss VALUE computed by the inference kernels (no autograd graph behind it): its backward raises instead of silently training nothing"""
 
     @staticmethod
     def forward(ctx, value, anchor, what):
@@ -115,8 +115,9 @@ class _NoBackward(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad):
-        raise RuntimeError(f'{ctx.what} returned the VALUE of the objective: the MI355X build has no backward kernels yet (forward '
-                           'kernels only, SURVEY.md 8f) -- train with the reference implementation, evaluate with this one')
+        raise RuntimeError(f'{ctx.what} returned the VALUE of the objective through the inference kernels -- no backward kernels ran behind this '
+                           'tensor.  The training steps are Phenaki.forward (train.py) and CViViT.forward (train_cvivit.py) with grad mode on and '
+                           'trainable parameters of the module being trained')
 
 
 def value_without_graph(module, what, value):

@@ -46,7 +46,9 @@ def cast_tuple(val, l=1):
 # ------------------------------------------------------------------------------------------------ matrix products, closed under differentiation
 
 def _fast_ok(M, N, K):
-    return K % 8 == 0 and K >= 32 and M >= 16 and N >= 16
+    """shapes pk_gemm takes: contraction a multiple of 8 (16-byte rows in every mode), vector epilogue (N % 4), enough rows to fill a tile.  The
+    8-channel pixel rows of the first block's 1x1 residual convolution (K = 8 forward, N = 8 in its weight gradient over 131072 rows) qualify."""
+    return K % 8 == 0 and K >= 8 and M >= 16 and N >= 8 and N % 4 == 0
 
 
 def _mm_raw(A, B, tA, tB, dtype):
@@ -70,7 +72,7 @@ def _mm_raw(A, B, tA, tB, dtype):
         if not tA:
             # A (M, K) rows against the operand image of op(B)^T = (N, K): B itself when tB, its transpose otherwise
             return L.gemm(dtype, A, pack_operand(B, dtype, transpose=not tB), M, N, K, C=out)
-        if not tB and K >= 4 * _q(dtype):
+        if not tB and K >= 4 * _q(dtype) and M % 4 == 0:
             # A^T B, contraction over the K rows both operands share: the weight-gradient shape (split-K, added in index order)
             Kp = round_up(K, _q(dtype))
             AT = pack_operand(A, dtype, transpose=True, side='a')          # (M, Kp)
@@ -119,7 +121,9 @@ class _SlopeMul(torch.autograd.Function):
         ctx.save_for_backward(y)
         g = g.contiguous()
         M, N = y.shape
-        return L.leaky_bwd(y, g, _f32((M, N), y.device), M, N, LEAK)
+        out = _f32((M, N), y.device)
+        L.leaky_bwd(y, g, out, M, N, LEAK)
+        return out
 
     @staticmethod
     def backward(ctx, gg):

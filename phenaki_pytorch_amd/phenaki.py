@@ -19,7 +19,7 @@ from torch import nn
 
 from . import _lib as L
 from .attention import (ContinuousPositionBias, PackedModule, Transformer, compute_dtype_of, exists, default, linear_weight,
-                        param_fingerprint, value_without_graph, set_compute_dtype)
+                        param_fingerprint, set_compute_dtype)
 from .cvivit import CViViT
 from .t5 import t5_encode_text, get_encoded_dim, DEFAULT_T5_NAME
 

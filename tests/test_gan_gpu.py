@@ -8,12 +8,19 @@ import torch.nn.functional as F
 from oracle import gan_oracle as G
 from oracle import weights
 from oracle.configs import FULL, TINY, gan_state_dict, oracle_cfgs
-from tests.test_oracle_golden import cvivit_grad_check, load
-from tests.util import close, record_parity
+from tests.test_oracle_golden import load
+from tests.util import close, kinked_close, record_parity
 
 pytestmark = pytest.mark.gpu
 
 MODES = [('fp32', 1e-3), ('bf16x3', 1e-3), ('bf16', None)]
+# end-to-end gradients pass through ~10^6..10^7 LeakyReLU units whose inputs differ from the reference's by f32 rounding (another summation order
+# in the tokenizer that produced the frame, in the convolutions): the few units within that rounding of 0 switch slope (1 <-> 0.1), and one
+# switched unit of the first block moves a whole row of a 1728-element weight gradient by ~0.1 % of the tensor's norm (measured: relative L2
+# 1.1e-3 .. 2.7e-3 on 3 of 224 tensors, 2e-6 on all of them when both sides see bit-identical frames: tools/gan_diag.py and the same-input test below)
+# The split-bf16 mode carries ~1e-5 per product instead of ~1e-7, so ~100x as many units sit within its rounding of 0: measured 5e-3 .. 9e-3 on
+# the smallest tensors (64-element biases).  The LOSSES -- continuous in the inputs -- are held to 2e-4 in both modes.
+KINK_L2 = {'fp32': 5e-3, 'bf16x3': 2e-2}
 
 
 @pytest.fixture(autouse=True)
@@ -23,6 +30,28 @@ def _gpu():
     torch.cuda.set_device(0)
     with torch.enable_grad():
         yield
+
+
+def golden_grad_check(get_grad, g_grads, dtype, min_checked):
+    """gradients against the fixture of gan_golden (per parameter: norm of the whole gradient + every stride-th element), with the criterion of
+    tests/util.kinked_close on the sampled elements and the norm held to rtol"""
+    top = max(v['norm'] for v in g_grads.values())
+    worst = 0.
+    checked = 0
+    for k, ref in g_grads.items():
+        if not ref['sample'].numel():
+            continue
+        got = get_grad(k)
+        assert got is not None, k
+        got = got.detach().float().cpu().reshape(-1)
+        if ref['norm'] < 1e-6 * top:
+            assert float(got.double().norm()) < 1e-4 * top, k
+            continue
+        worst = max(worst, kinked_close(got[::ref['stride']], ref['sample'], KINK_L2[dtype], k, outliers=4 * KINK_L2[dtype]))
+        assert abs(float(got.double().norm()) - ref['norm']) <= KINK_L2[dtype] * ref['norm'], k
+        checked += 1
+    assert checked >= min_checked, checked
+    return worst
 
 
 def g32(seed):
@@ -141,6 +170,35 @@ def test_discriminator_logits_match_oracle(size, dim, dtype, tol):
     close(got2, ref, tol or 3e-2, f'discriminator logits, second-order graph ({dtype})')
 
 
+def test_discriminator_objective_on_identical_frames_is_f32_exact():
+    """hinge + gradient penalty on the SAME real / fake frames as the oracle (no upstream rounding to flip a LeakyReLU unit): loss and every
+    gradient -- first and second order through pk_gemm / pk_im2col / pk_col2im / pk_bmm -- to 1e-4 in the exact-f32 mode (measured 3e-6)"""
+    import phenaki_pytorch_amd as P
+    from phenaki_pytorch_amd.discriminator import Discriminator, gradient_penalty, hinge_discr_loss
+    d = Discriminator(dim=16, image_size=64)
+    weights.fill_module(d, salt=1)
+    real = torch.randn(2, 3, 64, 64, generator=g32(10))
+    fake = torch.randn(2, 3, 64, 64, generator=g32(11))
+    sd = {'discr.' + k: v.detach().clone().requires_grad_(v.is_floating_point() and not k.endswith('beta')) for k, v in d.state_dict().items()}
+    ro = real.clone().requires_grad_()
+    rl = G.discriminator(sd, ro)
+    ref = G.hinge_discr_loss(G.discriminator(sd, fake), rl) + G.gradient_penalty(ro, rl)
+    ref.backward()
+    d = d.cuda()
+    P.set_compute_dtype(d, 'fp32')
+    rp = real.cuda().requires_grad_()
+    rlp = d(rp, second_order=True)
+    loss = hinge_discr_loss(d(fake.cuda()), rlp) + gradient_penalty(rp, rlp)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-5 * float(ref.detach())
+    worst = 0.
+    for k, v in d.named_parameters():
+        r = sd['discr.' + k].grad
+        if r is not None and r.numel() and float(r.abs().max()) > 0:
+            worst = max(worst, close(v.grad, r, 1e-4, f'd {k}'))
+    record_parity('discriminator_objective_identical_frames', dict(dtype='fp32', loss=float(loss.detach()), ref_loss=float(ref.detach()), worst_rel_err=worst))
+
+
 @pytest.mark.parametrize('dtype,tol', MODES)
 def test_discriminator_step_matches_reference(golden_dir, dtype, tol):
     """loss = cvivit(video, return_discr_loss=True); loss.backward() == the reference's: hinge + gradient penalty and every discriminator gradient
@@ -161,13 +219,13 @@ def test_discriminator_step_matches_reference(golden_dir, dtype, tol):
         assert all(torch.isfinite(named[k].grad).all() for k in g['grads_discr'] if named[k].numel())
         return
     assert abs(float(loss.detach()) - ref) <= 2e-4 * ref, (float(loss.detach()), ref)
-    cvivit_grad_check(lambda k: named[k].grad, g['grads_discr'], tol, 40)
+    worst = golden_grad_check(lambda k: named[k].grad, g['grads_discr'], dtype, 40)
     with torch.no_grad():
         torch.manual_seed(21)
         hinge = cv(video, return_discr_loss=True, apply_grad_penalty=False)
     assert abs(float(hinge) - float(g['hinge_discr'])) <= 2e-4
     record_parity('discriminator_step_vs_reference', dict(dtype=dtype, loss=float(loss.detach()), ref_loss=ref, hinge=float(hinge),
-                                                          gradients=len(g['grads_discr'])))
+                                                          gradients=len(g['grads_discr']), worst_rel_l2=worst))
 
 
 @pytest.mark.parametrize('kind', ['gen', 'gen_masked'])
@@ -190,8 +248,9 @@ def test_generator_gan_step_matches_reference(golden_dir, dtype, tol, kind):
         assert all(named[k].grad is not None and torch.isfinite(named[k].grad).all() for k in grads if named[k].numel())
         return
     assert abs(float(loss.detach()) - ref) <= 2e-4 * abs(ref), (float(loss.detach()), ref)
-    cvivit_grad_check(lambda k: named[k].grad, grads, tol, 140)
-    record_parity('generator_gan_step_vs_reference', dict(dtype=dtype, kind=kind, loss=float(loss.detach()), ref_loss=ref, gradients=len(grads)))
+    worst = golden_grad_check(lambda k: named[k].grad, grads, dtype, 140)
+    record_parity('generator_gan_step_vs_reference', dict(dtype=dtype, kind=kind, loss=float(loss.detach()), ref_loss=ref, gradients=len(grads),
+                                                          worst_rel_l2=worst))
 
 
 def test_gan_forward_surface():
@@ -229,18 +288,21 @@ def _full_discr_keys():
     return {'discr.' + k: list(v.shape) for k, v in d.state_dict().items()}
 
 
-def _compare_grads(named, leaf, prefix, tol, what, dtype):
-    top = max(float(v.grad.abs().max()) for k, v in leaf.items() if getattr(v, 'grad', None) is not None and v.numel() and k.startswith(prefix))
+def _compare_grads(named, leaf, group, tol, what, dtype):
+    """every gradient of one parameter group (the discriminator's `discr.*`, or the tokenizer's = everything else) against the oracle's"""
+    def member(k):
+        return k.startswith('discr.') == (group == 'discr.')
+    top = max(float(v.grad.abs().max()) for k, v in leaf.items() if getattr(v, 'grad', None) is not None and v.numel() and member(k))
     errs = {}
     for name, prm in named.items():
         r = leaf.get(name)
-        if r is None or r.grad is None or r.numel() == 0 or not name.startswith(prefix):
+        if r is None or r.grad is None or r.numel() == 0 or not member(name):
             continue
         assert prm.grad is not None, name
         if float(r.grad.abs().max()) < 1e-6 * top:
             assert float(prm.grad.abs().max()) <= 1e-2 * tol * top, name
             continue
-        errs[name] = close(prm.grad.cpu(), r.grad, tol, f'd {name} ({what}, {dtype})')
+        errs[name] = kinked_close(prm.grad, r.grad, KINK_L2[dtype], f'd {name} ({what}, {dtype})', outliers=4 * KINK_L2[dtype])
     return errs
 
 
@@ -265,7 +327,7 @@ def test_discriminator_step_full_size_matches_oracle_autograd(dtype, tol):
     assert len(errs) >= 55, len(errs)
     worst = max(errs, key=errs.get)
     record_parity('discriminator_step_full_vs_oracle_autograd', dict(dtype=dtype, loss=float(loss.detach()), ref_loss=float(ref.detach()),
-                                                                      gradients=len(errs), worst=worst, worst_rel_err=errs[worst]))
+                                                                      gradients=len(errs), worst=worst, worst_rel_l2=errs[worst]))
 
 
 @pytest.mark.parametrize('dtype,tol', [('fp32', 1e-3), ('bf16x3', 1e-3)])
@@ -286,9 +348,11 @@ def test_generator_gan_step_full_size_matches_oracle_autograd(dtype, tol):
     loss = cv(video.cuda())
     loss.backward()
     assert abs(float(loss.detach()) - float(ref.detach())) <= 5e-4 * abs(float(ref.detach())), (float(loss.detach()), float(ref.detach()), parts)
-    errs = _compare_grads(dict(cv.named_parameters()), leaf, '', tol, 'generator step', dtype)
-    assert len(errs) >= 250, len(errs)
+    errs = _compare_grads(dict(cv.named_parameters()), leaf, 'tokenizer', tol, 'generator step', dtype)
+    assert len(errs) >= 200, len(errs)
+    errs.update(_compare_grads(dict(cv.named_parameters()), leaf, 'discr.', tol, 'generator step', dtype))
+    assert len(errs) >= 255, len(errs)
     worst = max(errs, key=errs.get)
     record_parity('generator_gan_step_full_vs_oracle_autograd', dict(dtype=dtype, loss=float(loss.detach()), ref_loss=float(ref.detach()),
                                                                       parts={k: float(v) for k, v in parts.items()}, gradients=len(errs),
-                                                                      worst=worst, worst_rel_err=errs[worst]))
+                                                                      worst=worst, worst_rel_l2=errs[worst]))
