@@ -25,6 +25,7 @@ _PATCH_FUSED = os.environ.get('PK_PATCH_FUSED', '1') != '0'
 # PK_PATCH_WIDE=0: the round-3 tiling of the fused patch embedding (128 x 128 tiles, pk_patch_embed + pk_layernorm) for A/B timing
 _PATCH_WIDE = os.environ.get('PK_PATCH_WIDE', '1') != '0'
 _PE_SPLITK = int(os.environ.get('PK_PE_SPLITK', '4'))          # K-slices of the split-bf16 patch-embedding GEMM (1: one plain launch)
+_PE_SPLITK_FIRST = int(os.environ.get('PK_PE_SPLITK_FIRST', '8'))   # ... of its first-frame group (few rows, 64 x 64 tiles)
 
 
 def pair(val):
@@ -269,10 +270,17 @@ class CViViT(PackedModule):
             tmp = torch.empty((rows, self.dim), device=dev, dtype=torch.float32)
             # split-bf16, the long-K group (P = 6144, 4096 rows at B = 8): 128 x 128 tiles alone are 128 workgroups; K-slices bring every CU in
             # (pk_gemm_splitk tile = 1, bias on slice 0; slices added in index order: deterministic)
-            splits = _PE_SPLITK if (dt == L.BF16X3 and rows >= 1024 and P >= 4096 and P % (32 * _PE_SPLITK) == 0 and self.dim % 4 == 0) else 1
+            splits, tile = 1, 1
+            if dt == L.BF16X3 and self.dim % 4 == 0 and _PE_SPLITK > 1:
+                if rows >= 1024 and P >= 4096 and P % (32 * _PE_SPLITK) == 0:
+                    splits = _PE_SPLITK
+                elif _PE_SPLITK_FIRST > 1 and P >= 2048 and P % (32 * _PE_SPLITK_FIRST) == 0:
+                    # the first-frame group (512 rows at B = 8, P = 3072): 64 tiles of 64 x 64 walking 96 k-tiles each leave 3/4 of the CUs idle
+                    # (51.7 us); K-slices of 384 make it 512 workgroups
+                    splits, tile = _PE_SPLITK_FIRST, 0
             if splits > 1:
                 part = torch.empty((splits, rows * self.dim), device=dev, dtype=torch.float32)
-                L.gemm_splitk(dt, patches, linear_weight(lin, dt), rows, self.dim, P, splits, part, bias=lin.bias, tile=1)
+                L.gemm_splitk(dt, patches, linear_weight(lin, dt), rows, self.dim, P, splits, part, bias=lin.bias, tile=tile)
                 L.sum_batch(part, splits, tmp, rows * self.dim)
             else:
                 L.gemm(dt, patches, linear_weight(lin, dt), rows, self.dim, P, C=tmp, bias=lin.bias)

@@ -4,17 +4,20 @@ set -u
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-P=gpurun_out/prof_r03
+R=${PK_ROUND:-r04}
+P=gpurun_out/prof_$R
 rm -rf $P; mkdir -p $P
 echo "== kernel trace: encode leg"; date
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P/enc -o enc -- python bench.py --encode-only --groups 3 --steps 20 --warmup 3 > $P/enc.json 2> $P/enc.err; echo rc=$?
 echo "== kernel trace: whole bench (no cpu / parity mode)"; date
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $P/all -o all -- python bench.py --no-cpu --no-parity-mode --no-kernels --groups 3 --legs decode,sample,sample_cfg3,make_video,objective > $P/all.json 2> $P/all.err; echo rc=$?
+echo "== kernel trace: training legs (Phenaki step in bf16x3 + bf16, tokenizer step, tokenizer GAN step)"; date
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $P/train -o train -- python bench.py --no-cpu --no-parity-mode --no-kernels --groups 2 --legs train_step,cvivit_train_step,cvivit_gan_step > $P/train.json 2> $P/train.err; echo rc=$?
 echo "== PMC FETCH_SIZE"; date
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch -o p -- python bench.py --encode-only --no-graph --no-kernels --groups 1 --steps 3 --warmup 1 > /dev/null 2> $P/pmc_fetch.err; echo rc=$?
 echo "== PMC WRITE_SIZE"; date
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/pmc_write -o p -- python bench.py --encode-only --no-graph --no-kernels --groups 1 --steps 3 --warmup 1 > /dev/null 2> $P/pmc_write.err; echo rc=$?
-python tools/pmc_traffic.py $P/pmc_fetch $P/pmc_write $P/pmc_traffic_r03.json | head -20
+python tools/pmc_traffic.py $P/pmc_fetch $P/pmc_write $P/pmc_traffic_$R.json | head -20
 find $P -name "*kernel_stats.csv" | head
 # keep the merge-back small: drop the per-dispatch traces, keep the stats
 find $P -name "*kernel_trace.csv" -delete; find $P -name "*counter_collection.csv" -delete; find $P -name "*.db" -delete
