@@ -65,7 +65,7 @@ def parse():
     ap.add_argument('--no-parity-mode', action='store_true', help='skip the exact-f32 timing')
     ap.add_argument('--no-kernels', action='store_true', help='skip the per-kernel roofline table')
     ap.add_argument('--encode-only', action='store_true', help='only the headline leg (profiling runs)')
-    ap.add_argument('--legs', default='decode,encode_b32,sample,sample_cfg3,sample_b32,make_video,objective,train_step,cvivit_train_step',
+    ap.add_argument('--legs', default='decode,encode_b32,sample,sample_cfg3,sample_b32,make_video,objective,train_step,cvivit_train_step,cvivit_gan_step',
                     help='comma list of the legs reported beside the headline encode leg')
     ap.add_argument('--sample-batch', type=int, default=8)
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -896,7 +896,7 @@ def compact_line(full):
         if pf.get('sample'):
             line['parity_f32']['sample_tokens_per_sec'] = _r(pf['sample']['value'], 1)
     for leg, key in (('decode', 'value'), ('make_video', 'value'), ('train_step', 'ms_per_step'), ('train_step_bf16', 'ms_per_step'),
-                     ('cvivit_train_step', 'ms_per_step'), ('encode_b32', 'value'), ('sample_b32', 'value'), ('sample_cfg3', 'value')):
+                     ('cvivit_train_step', 'ms_per_step'), ('cvivit_gan_step', 'generator_step_ms'), ('encode_b32', 'value'), ('sample_b32', 'value'), ('sample_cfg3', 'value')):
         if leg in full and key in full[leg]:
             line.setdefault('legs', {})[leg] = {key: _r(full[leg][key], 3), 'unit': full[leg].get('unit')}
     line['full_report'] = 'gpurun_out/bench_full.json (also on stderr)'

@@ -343,13 +343,15 @@ def test_generator_gan_step_full_size_matches_oracle_autograd(dtype, tol):
     cvc, _, _ = oracle_cfgs(FULL)
     vgg = weights.stub_vgg(256)
     video = weights.synthetic_video(1, 5, 256, 256, seed=15)
-    torch.manual_seed(32)
+    torch.manual_seed(39)                   # this seed picks frame 3: a rest-frame, so to_pixels is on the path and the adaptive weight is not 0
     frame = torch.randn(1, 5).topk(1, dim=-1).indices.reshape(-1)
+    assert int(frame[0]) == 3
     leaf = {k: (v.clone().requires_grad_() if v.is_floating_point() and not k.endswith('.beta') else v) for k, v in sd.items()}
     parts = {}
     ref = G.generator_loss(leaf, cvc, video, frame, vgg, parts=parts)
     ref.backward()
-    torch.manual_seed(32)
+    assert float(parts['adaptive_weight']) > 0
+    torch.manual_seed(39)
     loss = cv(video.cuda())
     loss.backward()
     assert abs(float(loss.detach()) - float(ref.detach())) <= 5e-4 * abs(float(ref.detach())), (float(loss.detach()), float(ref.detach()), parts)

@@ -863,7 +863,7 @@ def test_cvivit_reconstruction_loss_matches_reference_golden(golden_dir, dtype, 
     assert rel(loss, g['loss']) <= tol and recon.shape == video.shape
     assert abs(recon.double().sum().item() - g['recon_sum']) <= tol * max(1.0, abs(g['recon_sum'])) * 50
     assert rel(cv(video[:, :, 0]), g['loss_image']) <= tol
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError, match='discriminator must exist'):           # cvivit.py:607: this module was built with use_vgg_and_gan=False
         cv(video, return_discr_loss=True)
     # the kernel alone against torch, with a mask that drops whole frames
     a, b = torch.randn(2, 3, 5, 16, 24, device='cuda'), torch.randn(2, 3, 5, 16, 24, device='cuda')
