@@ -77,8 +77,10 @@ def _weight_grad_gemm(dtype, dyT, xT, N, K, Mp, dW):
     tiles = ((N + 63) // 64) * ((K + 63) // 64)
     splits = 1
     if K % 4 == 0 and dW.is_contiguous():
-        for cand in (8, 4, 2):
-            if tiles * cand <= 768 and Mp % (cand * q) == 0 and Mp // cand >= 4 * q:
+        # up to 64 slices (the C ABI's limit) for the discriminator's convolution weights: a 64 x 576 gradient contracted over 524 288 pixel rows
+        # is 9 tiles -- with 8 slices each workgroup walked 2 048 k-tiles (2.2 ms); the trunk's shapes (>= 64 tiles) still resolve to <= 8
+        for cand in (64, 32, 16, 8, 4, 2):
+            if tiles * cand <= 768 and Mp % (cand * q) == 0 and Mp // cand >= (16 if cand > 8 else 4) * q:
                 splits = cand
                 break
     if splits == 1:
