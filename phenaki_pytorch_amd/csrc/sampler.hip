@@ -231,6 +231,221 @@ __global__ __launch_bounds__(64 * VocabGeom<T>::WM * VocabGeom<T>::WN) void voca
     }
 }
 
+// ---- pk_vocab_sample, bf16, D = 512, M >= 1024: the A-RESIDENT persistent form (round 4) ------------------------------------------------
+// The tiled kernel above fills BOTH operands of every 128 x 128 tile through the LDS-DMA ring (256 KB per 16.8 MFLOP) and starts a cold
+// 8-k-tile pipeline per tile; profiles/gemm_yardstick_r03.txt has it at 668 TF against the vendor GEMM's 842 on this shape, and the
+// fill-path benchmark (profiles/fill_path_r04.txt) shows that moving one operand to VGPR loads does not help by itself (same 64 B/clk L1 path).
+// What does halve the fill is not re-fetching A at all: with K = 512 a 128-row panel of A is 128 KB -- it FITS the 160 KB LDS.  So:
+//   * one workgroup per CU (128 KB of LDS, 8 waves), persistent: worker (xcd, s) owns a contiguous range of (row tile, group of 8 vocabulary
+//     tiles) units of its XCD's eighth of the vocabulary; the A panel is loaded once per row tile it visits (1-2 per worker, LDS-DMA);
+//   * inside a unit wave w owns vocabulary tile 8 * group + w and walks its 128 columns as 8 sub-blocks of 16.  The 16 x 512 slice of W of a
+//     sub-block goes global -> VGPR as the MFMA operand itself (a lane's fragment chunk is 16 contiguous bytes of one W row): 16 loads of 16 B
+//     per lane, issued ONE SUB-BLOCK AHEAD into a register ring of 8 k-tiles (64 VGPRs) -- 16 KB per wave / 128 KB per CU in flight, which
+//     is what the ~1 us L2 -> CU latency needs at this rate (the first version streamed W through a private 2-slice LDS ring, 4 KB per wave in
+//     flight: latency-bound at the tiled kernel's speed, profiles/vocab_resident_r04.txt).  No LDS-DMA, no s_waitcnt by hand and no
+//     workgroup barrier in the loop: the waves drift apart and fill the MFMA pipe through each other's waits;
+//   * 8 row fragments x 16 columns per wave: 16 MFMAs per k-tile against A fragments read from the resident panel (16 KB per wave per k-tile
+//     of the 256 B/clk LDS read path);
+//   * the gumbel-argmax / log-sum-exp epilogue runs per sub-block on the lane's 32 logits with a running (best, index, logit, max, sum) per
+//     row; after the 8th sub-block the 4 lane groups are folded and the tile's partial is written -- the SAME [tile][row] partials as the tiled
+//     kernel, so pk_vocab_reduce / pk_vocab_ce are unchanged.  Noise is indexed by (logical row, column) in both kernels: same draws.
+// Fill per 16.8 MFLOP: 128 KB (W only).  The k-tiles of a slice are walked from a per-wave rotation (L2 channel spread, as krot above).
+constexpr int VR_WAVES = 8, VR_THREADS = 64 * VR_WAVES, VR_NT = 8;
+constexpr int VR_SMEM = VR_NT * 128 * 128;                              // the A panel: 8 k-tile blocks of [128 rows][128 B]
+
+template <bool PARITY, bool LSE>
+__global__ __launch_bounds__(VR_THREADS) void vocab_resident_kernel(const GemmOperands p, const VocabArgs e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    constexpr int NT = VR_NT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, lr = lane & 15;
+    const int MT = (p.M + 127) / 128, V = p.N;
+    const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3, nworkers = gridDim.x >> 3;
+    const int CTX = (e.ntiles + 7) / 8;                                 // vocabulary tiles per XCD range
+    const int c_lo = xcd * CTX, c_hi = (c_lo + CTX < e.ntiles) ? c_lo + CTX : e.ntiles;
+    const int NG = (CTX + 7) / 8;                                       // groups of 8 tiles (one per wave)
+    const int U = MT * NG;                                              // units of this XCD, row tile major
+    const int u0 = (int)((long)s * U / nworkers), u1 = (int)((long)(s + 1) * U / nworkers);
+    if (u0 >= u1 || c_lo >= c_hi) return;                               // the whole workgroup leaves together
+    const int nu = u1 - u0;
+
+    const uint32_t bytesA = (uint32_t)p.M * (uint32_t)p.lda * 2u, bytesW = (uint32_t)V * (uint32_t)p.ldw * 2u;
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, bytesA, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, bytesW, 0x00020000);
+    const int lrow = lane >> 3, lslot = lane & 7, srcslot = lslot ^ lrow;          // A pieces: 8 rows x 8 slots per 1 KiB, swizzle on the source
+    const int rot = (wave + s) & (NT - 1);
+
+    // W slice of sub-block sb of vocabulary tile c -> the register ring: lane (g, lr) holds k = (ch * 4 + g) * 8 .. + 7 of W row c * 128 + sb * 16 + lr
+    u32x4 wreg[NT][2];
+    auto load_w = [&](int c, int sb) {
+        const int row = c * 128 + sb * 16 + lr;
+        const uint32_t base = (c < c_hi && row < V) ? (uint32_t)row * (uint32_t)p.ldw * 2u + g * 16 : bytesW;      // out of range: reads as 0
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const int kk = (kt + rot) & (NT - 1);
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch)
+                wreg[kt][ch] = __builtin_amdgcn_raw_buffer_load_b128(rsW, base + ch * 64, kk * 128, 0);
+        }
+    };
+    auto load_a = [&](int r) {
+        const int m0 = r * 128;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int piece = wave * 2 + j;
+                const int gm = m0 + piece * 8 + lrow;
+                const uint32_t off = gm < p.M ? (uint32_t)gm * (uint32_t)p.lda * 2u + srcslot * 16 : bytesA;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(smem + kt * 16384 + piece * 1024), 16, off, kt * 128, 0, 0);
+            }
+    };
+
+    uint32_t seed_lo = e.seed_lo, seed_hi = e.seed_hi;
+    if (!PARITY && e.seed_dev) {
+        const unsigned long long sd = (((unsigned long long)e.seed_hi << 32) | e.seed_lo) + *e.seed_dev;
+        seed_lo = (uint32_t)sd; seed_hi = (uint32_t)(sd >> 32);
+    }
+    const float inv_t = 1.0f / e.temp, inv_t_log2e = inv_t * 1.44269504088896340736f;
+
+    load_w(c_lo + (u0 % NG) * 8 + wave, 0);                             // the first sub-block's slice
+    int cur_r = -1;
+    int lrows[8];
+    for (int ui = 0; ui < nu; ++ui) {
+        const int u = u0 + ui, r = u / NG, cg = u - r * NG;
+        const int m0 = r * 128;
+        if (r != cur_r) {                                               // 1-2 times per worker: swap the resident panel
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                               // every wave is done reading the old panel
+            load_a(r);
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            cur_r = r;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = m0 + i * 16 + lr;
+                lrows[i] = m < p.M ? (e.rows ? e.rows[m] : m) : 0;
+            }
+        }
+        const int c = c_lo + cg * 8 + wave;
+        const bool okc = c < c_hi;
+        const int c_next = c_lo + ((u + 1) % NG) * 8 + wave;            // this wave's tile in the next unit
+        float best[8], blog[8], lmax[8], lsum[8];
+        int bidx[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; blog[i] = 0.f; bidx[i] = 0x7fffffff; lmax[i] = -INFINITY; lsum[i] = 0.f; }
+#pragma unroll 1
+        for (int sb = 0; sb < 8; ++sb) {
+            const int n = c * 128 + sb * 16 + g * 4;
+            const f32x4 bvs = (okc && n < V) ? *reinterpret_cast<const f32x4*>(e.bias + n) : f32x4{0, 0, 0, 0};
+            const bool has_next = sb < 7 || ui + 1 < nu;
+            const int nc = sb < 7 ? c : c_next, nsb = sb < 7 ? sb + 1 : 0;
+            const int nrow = nc * 128 + nsb * 16 + lr;
+            const uint32_t nbase = (has_next && nc < c_hi && nrow < V) ? (uint32_t)nrow * (uint32_t)p.ldw * 2u + g * 16 : bytesW;
+            f32x4 acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = f32x4{0, 0, 0, 0};
+            // 16 steps (k-tile, chunk), software-pipelined by one: the 8 A-fragment reads of step t + 1 are issued before the 8 MFMAs of step t, so
+            // their LDS latency runs under the matrix pipe; each consumed ring slot is refilled with the same k-tile of the NEXT sub-block
+            Frag<bf16> fa[2][8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) lds_frag(fa[0][i], smem + (rot & (NT - 1)) * 16384, i * 16 + lr, 0, g);
+#pragma unroll
+            for (int t = 0; t < 2 * NT; ++t) {
+                const int kt = t >> 1, ch = t & 1;
+                const int kk = (kt + rot) & (NT - 1);
+                if (t + 1 < 2 * NT) {
+                    const int kt1 = (t + 1) >> 1, ch1 = (t + 1) & 1;
+                    const char* ablk1 = smem + ((kt1 + rot) & (NT - 1)) * 16384;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) lds_frag(fa[(t + 1) & 1][i], ablk1, i * 16 + lr, ch1, g);
+                }
+                Frag<bf16> fw;
+                fw.v = wreg[kt][ch];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = mma(fw, fa[t & 1][i], acc[i]);
+                wreg[kt][ch] = __builtin_amdgcn_raw_buffer_load_b128(rsW, nbase + ch * 64, kk * 128, 0);     // (past the last sub-block: out of range, reads 0)
+                __builtin_amdgcn_sched_barrier(0);                      // keep this order (an unconstrained schedule hoisted every read and spilled)
+            }
+            // ---- epilogue of the sub-block: 8 row fragments x 4 consecutive columns per lane
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = m0 + i * 16 + lr;
+                const bool mok = m < p.M;
+                const long lrow_ = lrows[i];
+                f32x4 uv = f32x4{0.5f, 0.5f, 0.5f, 0.5f};
+                if (PARITY) {
+                    if (mok && okc && n < V) {
+                        if (e.U) uv = *reinterpret_cast<const f32x4*>(e.U + (size_t)lrow_ * V + n);
+                        else {
+                            const uint64_t li = (uint64_t)lrow_ * (uint64_t)V + (uint64_t)n;
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) uv[rr] = torch_uniform(e.seed_lo, e.seed_hi, e.philox_offset, li + rr, e.philox_stride);
+                        }
+                    }
+                }
+                float uf[4] = {0.5f, 0.5f, 0.5f, 0.5f};
+                if (!PARITY && !e.no_noise) {
+                    const uint64_t gq = ((uint64_t)lrow_ * (uint64_t)V + (uint64_t)n) >> 2;
+                    uniform24x4(seed_lo, seed_hi, (uint32_t)gq, (uint32_t)(gq >> 32), uf);
+                }
+                float lg[4];
+                float bmax = -INFINITY;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int nn = n + rr;
+                    const float logit = acc[i][rr] + bvs[rr];
+                    float noisy;
+                    if (PARITY) {
+                        const float gum = -logf(-logf(uv[rr] + 1e-10f) + 1e-10f);
+                        noisy = logit / e.temp + gum;
+                    } else {
+                        noisy = fmaf(logit, inv_t_log2e, -__log2f(-__log2f(uf[rr])));
+                    }
+                    if (e.no_noise) noisy = logit;
+                    const bool ok = okc && nn < V;
+                    if (LSE) { lg[rr] = ok ? logit : -INFINITY; bmax = fmaxf(bmax, lg[rr]); }
+                    if (ok && (noisy > best[i])) { best[i] = noisy; bidx[i] = nn; blog[i] = logit; }      // ascending nn: first max wins
+                }
+                if (LSE && bmax > -INFINITY) {
+                    const float nm = fmaxf(lmax[i], bmax);
+                    float add = 0.f;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) add += __expf(lg[rr] - nm);
+                    lsum[i] = (lmax[i] == -INFINITY ? 0.f : lsum[i] * __expf(lmax[i] - nm)) + add;
+                    lmax[i] = nm;
+                }
+            }
+        }
+        // ---- the tile is done: fold the 4 lane groups of every row and write the [tile][row] partial
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float b_ = best[i], l_ = blog[i], mx = lmax[i], sm = lsum[i];
+            int ix = bidx[i];
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                const float ob = __shfl_xor(b_, off, 64), ol = __shfl_xor(l_, off, 64);
+                const int oi = __shfl_xor(ix, off, 64);
+                if (ob > b_ || (ob == b_ && oi < ix)) { b_ = ob; ix = oi; l_ = ol; }
+                if (LSE) {
+                    const float om = __shfl_xor(mx, off, 64), os = __shfl_xor(sm, off, 64);
+                    const float nm = fmaxf(mx, om);
+                    sm = (mx == -INFINITY ? 0.f : sm * __expf(mx - nm)) + (om == -INFINITY ? 0.f : os * __expf(om - nm));
+                    mx = nm;
+                }
+            }
+            const int m = m0 + i * 16 + lr;
+            if (g == 0 && okc && m < p.M) {
+                const size_t o = (size_t)c * p.M + m;
+                e.p_val[o] = b_; e.p_idx[o] = ix; e.p_logit[o] = l_;
+                if (LSE) { e.p_max[o] = mx; e.p_sum[o] = sm; }
+            }
+        }
+    }
+}
+
 // fold the per-tile partials: a workgroup owns 32 consecutive rows (coalesced 128-byte reads of the [tile][row]
 // partial arrays), its 8 thread groups stride over the tiles and meet in LDS; then the (B, n) state is updated,
 // optionally scattered through rows[]
@@ -460,6 +675,28 @@ static int vocab_sample_launch(int dtype, const void* A, int lda, const void* W,
     e.p_sum = reinterpret_cast<float*>(partials) + 4 * sz;
     dim3 grid(8 * ((ntiles + 7) / 8) * ((M + 127) / 128));        // 1-D: see the tile order in the kernel
     hipStream_t s = STREAM(stream);
+    // bf16, K = 512, enough rows for every CU: the A-resident persistent kernel (PK_VOCAB_RESIDENT=0: the tiled kernel, for A/B timing)
+    static const int resident_env = [] { const char* v = getenv("PK_VOCAB_RESIDENT"); return v ? atoi(v) : 1; }();
+    if (dtype == 1 && resident_env && D == 64 * VR_NT && M >= 1024) {
+        const bool lse = e.need_lse != 0;
+        const void* fn = parity ? (lse ? (const void*)&vocab_resident_kernel<true, true> : (const void*)&vocab_resident_kernel<true, false>)
+                                : (lse ? (const void*)&vocab_resident_kernel<false, true> : (const void*)&vocab_resident_kernel<false, false>);
+        static bool attr_set[64][4] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PK_ELAUNCH;
+        const int vi = (parity ? 2 : 0) + (lse ? 1 : 0);
+        if (!attr_set[dev][vi]) {
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, VR_SMEM) != hipSuccess) return PK_ELAUNCH;
+            attr_set[dev][vi] = true;
+        }
+        const dim3 rgrid(256);                                         // 8 XCDs x 32 CUs: one workgroup per CU
+#define PK_VR(PAR, LS) hipLaunchKernelGGL((vocab_resident_kernel<PAR, LS>), rgrid, dim3(VR_THREADS), VR_SMEM, s, p, e)
+        if (parity) { if (lse) PK_VR(true, true); else PK_VR(true, false); }
+        else { if (lse) PK_VR(false, true); else PK_VR(false, false); }
+#undef PK_VR
+        PK_CHECK_LAUNCH();
+        return PK_OK;
+    }
 #define PK_VS(TT, PAR, LS) hipLaunchKernelGGL((vocab_sample_kernel<TT, PAR, LS>), grid, dim3(VocabTile<TT>::THREADS), VocabTile<TT>::SMEM, s, p, e)
     const bool lse = e.need_lse != 0;
     if (dtype == 1) {

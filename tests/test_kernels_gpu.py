@@ -556,6 +556,68 @@ def test_vocab_sample_fast_mode_matches_its_numpy_twin(L):
     assert torch.equal(pred3.cpu(), preds[0])
 
 
+@pytest.mark.parametrize('M,V', [(1100, 4136), (1024, 65536), (2500, 1024)])
+def test_vocab_head_resident_kernel(L, M, V):
+    """bf16, D = 512, M >= 1024 routes pk_vocab_sample to the A-resident persistent kernel (sampler.hip vocab_resident_kernel): rows that do not
+    fill the last 128-row panel, a vocabulary that does not fill its last tile / its XCD ranges unevenly (33 tiles over 8 XCDs), workers that
+    change row panels.  (1) PARITY noise from memory: gumbel-argmax ids outside near-ties, confidence scores; (2) cross entropy through the
+    log-sum-exp partials with the row indirection; (3) FAST noise against the numpy twin of the counter hash, seeded and deterministic."""
+    D = 512
+    e = torch.randn(M, D, generator=g(60))
+    W = torch.randn(V, D, generator=g(61)) / math.sqrt(D) * 3
+    b = torch.randn(V, generator=g(62)) * 0.1
+    logits = bf(e) @ bf(W).t() + b
+    A, Wd, bd = e.cuda().to(torch.bfloat16), W.cuda().to(torch.bfloat16), b.cuda()
+    partials = torch.empty(5 * L.vocab_ntiles(V) * M, device='cuda')
+
+    def reduce(need_lse, rows=None, mask=None, ids=None):
+        pred = torch.empty(M if rows is None else int(rows.max()) + 1, device='cuda', dtype=torch.int64)
+        scores = torch.empty_like(pred, dtype=torch.float32) if need_lse else None
+        L.vocab_reduce(partials, M, V, rows, mask, ids, pred, scores, need_lse)
+        return pred.cpu(), (scores.cpu() if need_lse else None)
+    # (1) PARITY with explicit uniforms (memory-bound on the noise: only for the two smaller vocabularies)
+    if M * V <= 5_000_000:
+        U = torch.rand(M, V, generator=g(63))
+        T = 0.45
+        noisy = logits / T + (-torch.log(-torch.log(U + 1e-10) + 1e-10))
+        partials.fill_(float('nan'))
+        L.vocab_sample(L.BF16, A, Wd, bd, M, V, D, T, U.cuda(), None, 0, True, partials)
+        pred, scores = reduce(True)
+        top2 = noisy.topk(2, dim=-1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 1e-4 * noisy.abs().max()
+        assert safe.float().mean() > 0.98 and torch.equal(pred[safe], noisy.argmax(-1)[safe])
+        same = pred == noisy.argmax(-1)
+        score_ref = 1 - logits.softmax(-1).gather(1, noisy.argmax(-1)[:, None]).squeeze(1)
+        close(scores[same], score_ref[same], 1e-4, 'confidence scores (resident kernel)')
+    # (2) cross entropy with a row indirection
+    total = 2 * M + 5
+    rows = torch.randperm(total, generator=g(64))[:M].int()
+    targets_full = torch.randint(0, V, (total,), generator=g(65))
+    partials.fill_(float('nan'))
+    L.vocab_sample(L.BF16, A, Wd, bd, M, V, D, 1.0, None, rows.cuda(), 7, True, partials, no_noise=True)
+    loss = torch.full((M,), float('nan'), device='cuda')
+    L.vocab_ce(L.BF16, partials, M, V, A, Wd, bd, D, targets_full.cuda(), rows.cuda(), loss)
+    close(loss, F.cross_entropy(logits, targets_full[rows.long()], reduction='none'), 2e-3, f'vocab_ce, resident kernel, V={V}')
+    pred_plain, _ = reduce(False)
+    top2 = logits.topk(2, dim=-1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 1e-4 * logits.abs().max()
+    assert torch.equal(pred_plain[:M][safe], logits.argmax(-1)[safe]), 'plain argmax (no_noise)'
+    # (3) FAST noise: the numpy twin of the hash, indexed by (logical row, column)
+    if M * V <= 5_000_000:
+        seed = 0x0FEDCBA987654321
+        outs = []
+        for _ in range(2):
+            partials.fill_(float('nan'))
+            L.vocab_sample(L.BF16, A, Wd, bd, M, V, D, 0.7, None, None, seed, False, partials)
+            outs.append(reduce(False)[0])
+        assert torch.equal(outs[0], outs[1])
+        Uf = torch.from_numpy(uniform24x4_np(seed, np.arange(M * V, dtype=np.uint64))).reshape(M, V)
+        noisy = logits / 0.7 + (-torch.log(-torch.log(Uf)))
+        top2 = noisy.topk(2, dim=-1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 1e-3 * noisy.abs().max()
+        assert safe.float().mean() > 0.95 and torch.equal(outs[0][safe], noisy.argmax(-1)[safe])
+
+
 @pytest.mark.parametrize('B,n,k', [(3, 48, 1), (3, 48, 47), (2, 576, 288), (1, 1024, 50)])
 def test_topk_mask(L, B, n, k):
     scores = torch.randn(B, n, generator=g(48))
