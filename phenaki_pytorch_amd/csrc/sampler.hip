@@ -250,14 +250,19 @@ __global__ __launch_bounds__(64 * VocabGeom<T>::WM * VocabGeom<T>::WN) void voca
 //     row; after the 8th sub-block the 4 lane groups are folded and the tile's partial is written -- the SAME [tile][row] partials as the tiled
 //     kernel, so pk_vocab_reduce / pk_vocab_ce are unchanged.  Noise is indexed by (logical row, column) in both kernels: same draws.
 // Fill per 16.8 MFLOP: 128 KB (W only).  The k-tiles of a slice are walked from a per-wave rotation (L2 channel spread, as krot above).
-constexpr int VR_WAVES = 8, VR_THREADS = 64 * VR_WAVES, VR_NT = 8;
+constexpr int VR_NT = 8;
 constexpr int VR_SMEM = VR_NT * 128 * 128;                              // the A panel: 8 k-tile blocks of [128 rows][128 B]
 
-template <bool PARITY, bool LSE>
-__global__ __launch_bounds__(VR_THREADS) void vocab_resident_kernel(const GemmOperands p, const VocabArgs e) {
+// NW waves per workgroup (8: 2 per SIMD, <= 256 VGPRs; 12: 3 per SIMD, <= 168 VGPRs), RING k-tiles of W in flight per lane (8 = one whole
+// sub-block ahead, 4 = half of one), FADB: the A fragments of step t + 1 are read before the MFMAs of step t (costs 32 VGPRs).
+// Work: the (row tile, vocabulary tile) pairs of the XCD's eighth of the vocabulary, row major; worker s takes a contiguous range of them, its
+// wave w every NW-th pair of each row tile's part of the range.
+template <int NW, int RING, bool FADB, bool PARITY, bool LSE>
+__global__ __launch_bounds__(64 * NW) void vocab_resident_kernel(const GemmOperands p, const VocabArgs e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
     constexpr int NT = VR_NT;
+    static_assert(RING == 4 || RING == 8, "ring of 4 or 8 k-tiles");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, lr = lane & 15;
@@ -265,42 +270,61 @@ __global__ __launch_bounds__(VR_THREADS) void vocab_resident_kernel(const GemmOp
     const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3, nworkers = gridDim.x >> 3;
     const int CTX = (e.ntiles + 7) / 8;                                 // vocabulary tiles per XCD range
     const int c_lo = xcd * CTX, c_hi = (c_lo + CTX < e.ntiles) ? c_lo + CTX : e.ntiles;
-    const int NG = (CTX + 7) / 8;                                       // groups of 8 tiles (one per wave)
-    const int U = MT * NG;                                              // units of this XCD, row tile major
-    const int u0 = (int)((long)s * U / nworkers), u1 = (int)((long)(s + 1) * U / nworkers);
-    if (u0 >= u1 || c_lo >= c_hi) return;                               // the whole workgroup leaves together
-    const int nu = u1 - u0;
-
+    const int CT = c_hi - c_lo;                                         // vocabulary tiles of this XCD
+    if (CT <= 0) return;
+    // Segments of this worker, in order: (1) `full` = MT / nworkers sweeps in which worker s owns row tile j * nworkers + s and walks ALL vocabulary
+    // tiles of the XCD's range -- the 32 workers of an XCD then read the same W tile at about the same time, so it is fetched into the XCD's L2
+    // once per sweep instead of once per row tile (a contiguous split of the row-major pair list had every worker at a different tile: the 8 MB range
+    // cycled through the 4 MB L2); (2) the pairs of the MT % nworkers left-over row tiles, split evenly (contiguous, row tile major).
+    const int full = MT / nworkers, R = MT - full * nworkers;
+    const int Pl = R * CT;
+    const int q0 = (int)((long)s * Pl / nworkers), q1 = (int)((long)(s + 1) * Pl / nworkers);
+    const int lrow0 = q0 / CT, nleft = q1 > q0 ? (q1 - 1) / CT - lrow0 + 1 : 0;
+    const int nseg = full + nleft;
+    if (nseg == 0) return;                                              // the whole workgroup leaves together
     const uint32_t bytesA = (uint32_t)p.M * (uint32_t)p.lda * 2u, bytesW = (uint32_t)V * (uint32_t)p.ldw * 2u;
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, bytesA, 0x00020000);
     __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, bytesW, 0x00020000);
     const int lrow = lane >> 3, lslot = lane & 7, srcslot = lslot ^ lrow;          // A pieces: 8 rows x 8 slots per 1 KiB, swizzle on the source
     const int rot = (wave + s) & (NT - 1);
 
-    // W slice of sub-block sb of vocabulary tile c -> the register ring: lane (g, lr) holds k = (ch * 4 + g) * 8 .. + 7 of W row c * 128 + sb * 16 + lr
-    u32x4 wreg[NT][2];
-    auto load_w = [&](int c, int sb) {
-        const int row = c * 128 + sb * 16 + lr;
-        const uint32_t base = (c < c_hi && row < V) ? (uint32_t)row * (uint32_t)p.ldw * 2u + g * 16 : bytesW;      // out of range: reads as 0
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            const int kk = (kt + rot) & (NT - 1);
-#pragma unroll
-            for (int ch = 0; ch < 2; ++ch)
-                wreg[kt][ch] = __builtin_amdgcn_raw_buffer_load_b128(rsW, base + ch * 64, kk * 128, 0);
+    // segment k: row tile r and the vocabulary tiles c_lo + [a, b) of it; this wave takes a + wave, + NW, ...
+    auto segment = [&](int k, int& r, int& a, int& b) {
+        if (k < full) { r = k * nworkers + s; a = 0; b = CT; return; }
+        const int l = lrow0 + (k - full), lo = l * CT;
+        r = full * nworkers + l;
+        a = (q0 > lo ? q0 : lo) - lo;
+        b = (q1 < lo + CT ? q1 : lo + CT) - lo;
+    };
+    // the tile after (segment k, cc) in this wave's order; k2 >= nseg when there is none
+    auto next_tile = [&](int k, int cc, int& k2, int& cc2) {
+        int r, a, b;
+        segment(k, r, a, b);
+        if (cc + NW < b) { k2 = k; cc2 = cc + NW; return; }
+        for (k2 = k + 1; k2 < nseg; ++k2) {
+            segment(k2, r, a, b);
+            if (a + wave < b) { cc2 = a + wave; return; }
         }
+        cc2 = 0;
+    };
+    // byte offset of this lane's fragment row of sub-block sb of vocabulary tile c (out of range: reads as 0)
+    auto w_base = [&](bool valid, int c, int sb) -> uint32_t {
+        const int row = c * 128 + sb * 16 + lr;
+        return (valid && row < V) ? (uint32_t)row * (uint32_t)p.ldw * 2u + g * 16 : bytesW;
     };
     auto load_a = [&](int r) {
         const int m0 = r * 128;
+        if (wave < 8) {                                                 // 128 pieces of 1 KiB: 16 per wave of the first eight
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
+            for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int piece = wave * 2 + j;
-                const int gm = m0 + piece * 8 + lrow;
-                const uint32_t off = gm < p.M ? (uint32_t)gm * (uint32_t)p.lda * 2u + srcslot * 16 : bytesA;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(smem + kt * 16384 + piece * 1024), 16, off, kt * 128, 0, 0);
-            }
+                for (int j = 0; j < 2; ++j) {
+                    const int piece = wave * 2 + j;
+                    const int gm = m0 + piece * 8 + lrow;
+                    const uint32_t off = gm < p.M ? (uint32_t)gm * (uint32_t)p.lda * 2u + srcslot * 16 : bytesA;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(smem + kt * 16384 + piece * 1024), 16, off, kt * 128, 0, 0);
+                }
+        }
     };
 
     uint32_t seed_lo = e.seed_lo, seed_hi = e.seed_hi;
@@ -310,138 +334,162 @@ __global__ __launch_bounds__(VR_THREADS) void vocab_resident_kernel(const GemmOp
     }
     const float inv_t = 1.0f / e.temp, inv_t_log2e = inv_t * 1.44269504088896340736f;
 
-    load_w(c_lo + (u0 % NG) * 8 + wave, 0);                             // the first sub-block's slice
-    int cur_r = -1;
+    // the first tile of this wave and the first RING k-tiles of its first sub-block
+    int tk, tcc;
+    {
+        int r, a, b;
+        segment(0, r, a, b);
+        if (a + wave < b) { tk = 0; tcc = a + wave; }
+        else next_tile(0, b, tk, tcc);                                  // (cc = b: nothing further in this segment)
+    }
+    u32x4 wreg[RING][2];
+    {
+        const uint32_t base = w_base(tk < nseg, c_lo + tcc, 0);
+#pragma unroll
+        for (int kt = 0; kt < RING; ++kt)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch)
+                wreg[kt][ch] = __builtin_amdgcn_raw_buffer_load_b128(rsW, base + ch * 64, ((kt + rot) & (NT - 1)) * 128, 0);
+    }
     int lrows[8];
-    for (int ui = 0; ui < nu; ++ui) {
-        const int u = u0 + ui, r = u / NG, cg = u - r * NG;
+    for (int k = 0; k < nseg; ++k) {
+        int r, sa, sb_;
+        segment(k, r, sa, sb_);
         const int m0 = r * 128;
-        if (r != cur_r) {                                               // 1-2 times per worker: swap the resident panel
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                               // every wave is done reading the old panel
-            load_a(r);
-            wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            cur_r = r;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = m0 + i * 16 + lr;
-                lrows[i] = m < p.M ? (e.rows ? e.rows[m] : m) : 0;
-            }
-        }
-        const int c = c_lo + cg * 8 + wave;
-        const bool okc = c < c_hi;
-        const int c_next = c_lo + ((u + 1) % NG) * 8 + wave;            // this wave's tile in the next unit
-        float best[8], blog[8], lmax[8], lsum[8];
-        int bidx[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; blog[i] = 0.f; bidx[i] = 0x7fffffff; lmax[i] = -INFINITY; lsum[i] = 0.f; }
-#pragma unroll 1
-        for (int sb = 0; sb < 8; ++sb) {
-            const int n = c * 128 + sb * 16 + g * 4;
-            const f32x4 bvs = (okc && n < V) ? *reinterpret_cast<const f32x4*>(e.bias + n) : f32x4{0, 0, 0, 0};
-            const bool has_next = sb < 7 || ui + 1 < nu;
-            const int nc = sb < 7 ? c : c_next, nsb = sb < 7 ? sb + 1 : 0;
-            const int nrow = nc * 128 + nsb * 16 + lr;
-            const uint32_t nbase = (has_next && nc < c_hi && nrow < V) ? (uint32_t)nrow * (uint32_t)p.ldw * 2u + g * 16 : bytesW;
-            f32x4 acc[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = f32x4{0, 0, 0, 0};
-            // 16 steps (k-tile, chunk), software-pipelined by one: the 8 A-fragment reads of step t + 1 are issued before the 8 MFMAs of step t, so
-            // their LDS latency runs under the matrix pipe; each consumed ring slot is refilled with the same k-tile of the NEXT sub-block
-            Frag<bf16> fa[2][8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) lds_frag(fa[0][i], smem + (rot & (NT - 1)) * 16384, i * 16 + lr, 0, g);
-#pragma unroll
-            for (int t = 0; t < 2 * NT; ++t) {
-                const int kt = t >> 1, ch = t & 1;
-                const int kk = (kt + rot) & (NT - 1);
-                if (t + 1 < 2 * NT) {
-                    const int kt1 = (t + 1) >> 1, ch1 = (t + 1) & 1;
-                    const char* ablk1 = smem + ((kt1 + rot) & (NT - 1)) * 16384;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) lds_frag(fa[(t + 1) & 1][i], ablk1, i * 16 + lr, ch1, g);
-                }
-                Frag<bf16> fw;
-                fw.v = wreg[kt][ch];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] = mma(fw, fa[t & 1][i], acc[i]);
-                wreg[kt][ch] = __builtin_amdgcn_raw_buffer_load_b128(rsW, nbase + ch * 64, kk * 128, 0);     // (past the last sub-block: out of range, reads 0)
-                __builtin_amdgcn_sched_barrier(0);                      // keep this order (an unconstrained schedule hoisted every read and spilled)
-            }
-            // ---- epilogue of the sub-block: 8 row fragments x 4 consecutive columns per lane
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = m0 + i * 16 + lr;
-                const bool mok = m < p.M;
-                const long lrow_ = lrows[i];
-                f32x4 uv = f32x4{0.5f, 0.5f, 0.5f, 0.5f};
-                if (PARITY) {
-                    if (mok && okc && n < V) {
-                        if (e.U) uv = *reinterpret_cast<const f32x4*>(e.U + (size_t)lrow_ * V + n);
-                        else {
-                            const uint64_t li = (uint64_t)lrow_ * (uint64_t)V + (uint64_t)n;
-#pragma unroll
-                            for (int rr = 0; rr < 4; ++rr) uv[rr] = torch_uniform(e.seed_lo, e.seed_hi, e.philox_offset, li + rr, e.philox_stride);
-                        }
-                    }
-                }
-                float uf[4] = {0.5f, 0.5f, 0.5f, 0.5f};
-                if (!PARITY && !e.no_noise) {
-                    const uint64_t gq = ((uint64_t)lrow_ * (uint64_t)V + (uint64_t)n) >> 2;
-                    uniform24x4(seed_lo, seed_hi, (uint32_t)gq, (uint32_t)(gq >> 32), uf);
-                }
-                float lg[4];
-                float bmax = -INFINITY;
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int nn = n + rr;
-                    const float logit = acc[i][rr] + bvs[rr];
-                    float noisy;
-                    if (PARITY) {
-                        const float gum = -logf(-logf(uv[rr] + 1e-10f) + 1e-10f);
-                        noisy = logit / e.temp + gum;
-                    } else {
-                        noisy = fmaf(logit, inv_t_log2e, -__log2f(-__log2f(uf[rr])));
-                    }
-                    if (e.no_noise) noisy = logit;
-                    const bool ok = okc && nn < V;
-                    if (LSE) { lg[rr] = ok ? logit : -INFINITY; bmax = fmaxf(bmax, lg[rr]); }
-                    if (ok && (noisy > best[i])) { best[i] = noisy; bidx[i] = nn; blog[i] = logit; }      // ascending nn: first max wins
-                }
-                if (LSE && bmax > -INFINITY) {
-                    const float nm = fmaxf(lmax[i], bmax);
-                    float add = 0.f;
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) add += __expf(lg[rr] - nm);
-                    lsum[i] = (lmax[i] == -INFINITY ? 0.f : lsum[i] * __expf(lmax[i] - nm)) + add;
-                    lmax[i] = nm;
-                }
-            }
-        }
-        // ---- the tile is done: fold the 4 lane groups of every row and write the [tile][row] partial
+        // ---- swap the resident panel (every wave takes part, with or without tiles in this segment)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                   // every wave is done reading the old panel
+        load_a(r);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float b_ = best[i], l_ = blog[i], mx = lmax[i], sm = lsum[i];
-            int ix = bidx[i];
+            const int m = m0 + i * 16 + lr;
+            lrows[i] = m < p.M ? (e.rows ? e.rows[m] : m) : 0;
+        }
+        while (tk == k) {
+            const int c = c_lo + tcc;
+            int nk, ncc;
+            next_tile(tk, tcc, nk, ncc);
+            float best[8], blog[8], lmax[8], lsum[8];
+            int bidx[8];
 #pragma unroll
-            for (int off = 16; off <= 32; off <<= 1) {
-                const float ob = __shfl_xor(b_, off, 64), ol = __shfl_xor(l_, off, 64);
-                const int oi = __shfl_xor(ix, off, 64);
-                if (ob > b_ || (ob == b_ && oi < ix)) { b_ = ob; ix = oi; l_ = ol; }
-                if (LSE) {
-                    const float om = __shfl_xor(mx, off, 64), os = __shfl_xor(sm, off, 64);
-                    const float nm = fmaxf(mx, om);
-                    sm = (mx == -INFINITY ? 0.f : sm * __expf(mx - nm)) + (om == -INFINITY ? 0.f : os * __expf(om - nm));
-                    mx = nm;
+            for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; blog[i] = 0.f; bidx[i] = 0x7fffffff; lmax[i] = -INFINITY; lsum[i] = 0.f; }
+#pragma unroll 1
+            for (int sb = 0; sb < 8; ++sb) {
+                const int n = c * 128 + sb * 16 + g * 4;
+                const f32x4 bvs = n < V ? *reinterpret_cast<const f32x4*>(e.bias + n) : f32x4{0, 0, 0, 0};
+                // refill targets: k-tiles RING.. of THIS sub-block (RING = 4) and the first RING k-tiles of the NEXT one
+                const uint32_t cbase = w_base(true, c, sb);
+                const uint32_t nbase = sb < 7 ? w_base(true, c, sb + 1) : w_base(nk < nseg, c_lo + ncc, 0);
+                f32x4 acc[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = f32x4{0, 0, 0, 0};
+                // 16 steps (k-tile, chunk); each consumed ring slot is refilled with the k-tile RING steps ahead
+                Frag<bf16> fa[FADB ? 2 : 1][8];
+                if (FADB) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) lds_frag(fa[0][i], smem + (rot & (NT - 1)) * 16384, i * 16 + lr, 0, g);
+                }
+#pragma unroll
+                for (int t = 0; t < 2 * NT; ++t) {
+                    const int kt = t >> 1, ch = t & 1;
+                    if (FADB) {
+                        if (t + 1 < 2 * NT) {
+                            const int kt1 = (t + 1) >> 1, ch1 = (t + 1) & 1;
+                            const char* ablk1 = smem + ((kt1 + rot) & (NT - 1)) * 16384;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) lds_frag(fa[(t + 1) & 1][i], ablk1, i * 16 + lr, ch1, g);
+                        }
+                    } else {
+                        const char* ablk = smem + ((kt + rot) & (NT - 1)) * 16384;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) lds_frag(fa[0][i], ablk, i * 16 + lr, ch, g);
+                    }
+                    Frag<bf16> fw;
+                    fw.v = wreg[kt % RING][ch];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] = mma(fw, fa[FADB ? (t & 1) : 0][i], acc[i]);
+                    const int tk = kt + RING;                           // the k-tile that takes this slot
+                    wreg[kt % RING][ch] = __builtin_amdgcn_raw_buffer_load_b128(rsW, (tk < NT ? cbase : nbase) + ch * 64,
+                                                                               (((tk & (NT - 1)) + rot) & (NT - 1)) * 128, 0);
+                    __builtin_amdgcn_sched_barrier(0);                  // keep this order (an unconstrained schedule hoisted every read and spilled)
+                }
+                // ---- epilogue of the sub-block: 8 row fragments x 4 consecutive columns per lane
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int m = m0 + i * 16 + lr;
+                    const bool mok = m < p.M;
+                    const long lrow_ = lrows[i];
+                    f32x4 uv = f32x4{0.5f, 0.5f, 0.5f, 0.5f};
+                    if (PARITY) {
+                        if (mok && n < V) {
+                            if (e.U) uv = *reinterpret_cast<const f32x4*>(e.U + (size_t)lrow_ * V + n);
+                            else {
+                                const uint64_t li = (uint64_t)lrow_ * (uint64_t)V + (uint64_t)n;
+#pragma unroll
+                                for (int rr = 0; rr < 4; ++rr) uv[rr] = torch_uniform(e.seed_lo, e.seed_hi, e.philox_offset, li + rr, e.philox_stride);
+                            }
+                        }
+                    }
+                    float uf[4] = {0.5f, 0.5f, 0.5f, 0.5f};
+                    if (!PARITY && !e.no_noise) {
+                        const uint64_t gq = ((uint64_t)lrow_ * (uint64_t)V + (uint64_t)n) >> 2;
+                        uniform24x4(seed_lo, seed_hi, (uint32_t)gq, (uint32_t)(gq >> 32), uf);
+                    }
+                    float lg[4];
+                    float bmax = -INFINITY;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int nn = n + rr;
+                        const float logit = acc[i][rr] + bvs[rr];
+                        float noisy;
+                        if (PARITY) {
+                            const float gum = -logf(-logf(uv[rr] + 1e-10f) + 1e-10f);
+                            noisy = logit / e.temp + gum;
+                        } else {
+                            noisy = fmaf(logit, inv_t_log2e, -__log2f(-__log2f(uf[rr])));
+                        }
+                        if (e.no_noise) noisy = logit;
+                        const bool ok = nn < V;
+                        if (LSE) { lg[rr] = ok ? logit : -INFINITY; bmax = fmaxf(bmax, lg[rr]); }
+                        if (ok && (noisy > best[i])) { best[i] = noisy; bidx[i] = nn; blog[i] = logit; }      // ascending nn: first max wins
+                    }
+                    if (LSE && bmax > -INFINITY) {
+                        const float nm = fmaxf(lmax[i], bmax);
+                        float add = 0.f;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) add += __expf(lg[rr] - nm);
+                        lsum[i] = (lmax[i] == -INFINITY ? 0.f : lsum[i] * __expf(lmax[i] - nm)) + add;
+                        lmax[i] = nm;
+                    }
                 }
             }
-            const int m = m0 + i * 16 + lr;
-            if (g == 0 && okc && m < p.M) {
-                const size_t o = (size_t)c * p.M + m;
-                e.p_val[o] = b_; e.p_idx[o] = ix; e.p_logit[o] = l_;
-                if (LSE) { e.p_max[o] = mx; e.p_sum[o] = sm; }
+            // ---- the tile is done: fold the 4 lane groups of every row and write the [tile][row] partial
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float b_ = best[i], l_ = blog[i], mx = lmax[i], sm = lsum[i];
+                int ix = bidx[i];
+#pragma unroll
+                for (int off = 16; off <= 32; off <<= 1) {
+                    const float ob = __shfl_xor(b_, off, 64), ol = __shfl_xor(l_, off, 64);
+                    const int oi = __shfl_xor(ix, off, 64);
+                    if (ob > b_ || (ob == b_ && oi < ix)) { b_ = ob; ix = oi; l_ = ol; }
+                    if (LSE) {
+                        const float om = __shfl_xor(mx, off, 64), os = __shfl_xor(sm, off, 64);
+                        const float nm = fmaxf(mx, om);
+                        sm = (mx == -INFINITY ? 0.f : sm * __expf(mx - nm)) + (om == -INFINITY ? 0.f : os * __expf(om - nm));
+                        mx = nm;
+                    }
+                }
+                const int m = m0 + i * 16 + lr;
+                if (g == 0 && m < p.M) {
+                    const size_t o = (size_t)c * p.M + m;
+                    e.p_val[o] = b_; e.p_idx[o] = ix; e.p_logit[o] = l_;
+                    if (LSE) { e.p_max[o] = mx; e.p_sum[o] = sm; }
+                }
             }
+            tk = nk; tcc = ncc;
         }
     }
 }
@@ -675,24 +723,33 @@ static int vocab_sample_launch(int dtype, const void* A, int lda, const void* W,
     e.p_sum = reinterpret_cast<float*>(partials) + 4 * sz;
     dim3 grid(8 * ((ntiles + 7) / 8) * ((M + 127) / 128));        // 1-D: see the tile order in the kernel
     hipStream_t s = STREAM(stream);
-    // bf16, K = 512, enough rows for every CU: the A-resident persistent kernel (PK_VOCAB_RESIDENT=0: the tiled kernel, for A/B timing)
-    static const int resident_env = [] { const char* v = getenv("PK_VOCAB_RESIDENT"); return v ? atoi(v) : 1; }();
-    if (dtype == 1 && resident_env && D == 64 * VR_NT && M >= 1024) {
+    // bf16, K = 512, enough rows for every CU: the A-resident persistent kernel.  Measured on 4608 x 65536 x 512 (profiles/vocab_resident_r04.txt):
+    // twelve waves with a ring of 4 k-tiles (3 waves per SIMD, 153 VGPRs) win when the epilogue carries the noise hash (432 vs 451 us), eight
+    // waves with a ring of 8 and double-buffered A fragments (2 per SIMD) when it carries the log-sum-exp state (the 12-wave build of that
+    // variant spills); below ~2048 rows the panel swap and the start-up are no longer amortised (1152 rows: 146 vs 139 us tiled).
+    // PK_VOCAB_RESIDENT: 0 = the tiled kernel, 1 / 2 = force the 8- / 12-wave build, unset = the rule above.
+    static const int resident_env = [] { const char* v = getenv("PK_VOCAB_RESIDENT"); return v ? atoi(v) : 3; }();
+    if (dtype == 1 && resident_env && D == 64 * VR_NT && M >= (resident_env == 3 ? 2048 : 1024)) {
         const bool lse = e.need_lse != 0;
-        const void* fn = parity ? (lse ? (const void*)&vocab_resident_kernel<true, true> : (const void*)&vocab_resident_kernel<true, false>)
-                                : (lse ? (const void*)&vocab_resident_kernel<false, true> : (const void*)&vocab_resident_kernel<false, false>);
-        static bool attr_set[64][4] = {};
+        const int vi = (parity ? 2 : 0) + (lse ? 1 : 0);
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PK_ELAUNCH;
-        const int vi = (parity ? 2 : 0) + (lse ? 1 : 0);
-        if (!attr_set[dev][vi]) {
-            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, VR_SMEM) != hipSuccess) return PK_ELAUNCH;
-            attr_set[dev][vi] = true;
-        }
         const dim3 rgrid(256);                                         // 8 XCDs x 32 CUs: one workgroup per CU
-#define PK_VR(PAR, LS) hipLaunchKernelGGL((vocab_resident_kernel<PAR, LS>), rgrid, dim3(VR_THREADS), VR_SMEM, s, p, e)
-        if (parity) { if (lse) PK_VR(true, true); else PK_VR(true, false); }
-        else { if (lse) PK_VR(false, true); else PK_VR(false, false); }
+#define PK_VR(NWV, RNG, FA, PAR, LS) do { \
+            static bool attr_set[64] = {}; \
+            if (!attr_set[dev]) { \
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vocab_resident_kernel<NWV, RNG, FA, PAR, LS>), \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, VR_SMEM) != hipSuccess) return PK_ELAUNCH; \
+                attr_set[dev] = true; \
+            } \
+            hipLaunchKernelGGL((vocab_resident_kernel<NWV, RNG, FA, PAR, LS>), rgrid, dim3(64 * NWV), VR_SMEM, s, p, e); } while (0)
+        if (resident_env == 2 || (resident_env == 3 && !lse)) {
+            switch (vi) { case 0: PK_VR(12, 4, false, false, false); break; case 1: PK_VR(12, 4, false, false, true); break;
+                          case 2: PK_VR(12, 4, false, true, false); break; default: PK_VR(12, 4, false, true, true); break; }
+        } else {
+            switch (vi) { case 0: PK_VR(8, 8, true, false, false); break; case 1: PK_VR(8, 8, true, false, true); break;
+                          case 2: PK_VR(8, 8, true, true, false); break; default: PK_VR(8, 8, true, true, true); break; }
+        }
 #undef PK_VR
         PK_CHECK_LAUNCH();
         return PK_OK;
