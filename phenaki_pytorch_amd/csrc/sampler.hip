@@ -254,10 +254,12 @@ constexpr int VR_NT = 8;
 constexpr int VR_SMEM = VR_NT * 128 * 128;                              // the A panel: 8 k-tile blocks of [128 rows][128 B]
 
 // NW waves per workgroup (8: 2 per SIMD, <= 256 VGPRs; 12: 3 per SIMD, <= 168 VGPRs), RING k-tiles of W in flight per lane (8 = one whole
-// sub-block ahead, 4 = half of one), FADB: the A fragments of step t + 1 are read before the MFMAs of step t (costs 32 VGPRs).
+// sub-block ahead, 4 = half of one), FADB: the A fragments of step t + 1 are read before the MFMAs of step t (costs 32 VGPRs), TNW: column
+// fragments per sub-block (1: 16 columns; 2: 32 columns -- every A fragment read from LDS then feeds two MFMAs, half the LDS traffic per flop; built and
+// measured: 256 VGPRs with spills, 399 - 423 us argmax-only vs 405, 493 - 531 us with the noise vs 424 - 443: not instantiated).
 // Work: the (row tile, vocabulary tile) pairs of the XCD's eighth of the vocabulary, row major; worker s takes a contiguous range of them, its
 // wave w every NW-th pair of each row tile's part of the range.
-template <int NW, int RING, bool FADB, bool PARITY, bool LSE>
+template <int NW, int RING, bool FADB, int TNW, bool PARITY, bool LSE>
 __global__ __launch_bounds__(64 * NW) void vocab_resident_kernel(const GemmOperands p, const VocabArgs e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -308,8 +310,9 @@ __global__ __launch_bounds__(64 * NW) void vocab_resident_kernel(const GemmOpera
         cc2 = 0;
     };
     // byte offset of this lane's fragment row of sub-block sb of vocabulary tile c (out of range: reads as 0)
-    auto w_base = [&](bool valid, int c, int sb) -> uint32_t {
-        const int row = c * 128 + sb * 16 + lr;
+    constexpr int NSB = 8 / TNW, SBW = 16 * TNW;                        // sub-blocks per vocabulary tile, columns per sub-block
+    auto w_base = [&](bool valid, int c, int sb, int j) -> uint32_t {
+        const int row = c * 128 + sb * SBW + j * 16 + lr;
         return (valid && row < V) ? (uint32_t)row * (uint32_t)p.ldw * 2u + g * 16 : bytesW;
     };
     auto load_a = [&](int r) {
@@ -342,14 +345,15 @@ __global__ __launch_bounds__(64 * NW) void vocab_resident_kernel(const GemmOpera
         if (a + wave < b) { tk = 0; tcc = a + wave; }
         else next_tile(0, b, tk, tcc);                                  // (cc = b: nothing further in this segment)
     }
-    u32x4 wreg[RING][2];
-    {
-        const uint32_t base = w_base(tk < nseg, c_lo + tcc, 0);
+    u32x4 wreg[RING][TNW][2];
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) {
+        const uint32_t base = w_base(tk < nseg, c_lo + tcc, 0, j);
 #pragma unroll
         for (int kt = 0; kt < RING; ++kt)
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch)
-                wreg[kt][ch] = __builtin_amdgcn_raw_buffer_load_b128(rsW, base + ch * 64, ((kt + rot) & (NT - 1)) * 128, 0);
+                wreg[kt][j][ch] = __builtin_amdgcn_raw_buffer_load_b128(rsW, base + ch * 64, ((kt + rot) & (NT - 1)) * 128, 0);
     }
     int lrows[8];
     for (int k = 0; k < nseg; ++k) {
@@ -376,15 +380,21 @@ __global__ __launch_bounds__(64 * NW) void vocab_resident_kernel(const GemmOpera
 #pragma unroll
             for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; blog[i] = 0.f; bidx[i] = 0x7fffffff; lmax[i] = -INFINITY; lsum[i] = 0.f; }
 #pragma unroll 1
-            for (int sb = 0; sb < 8; ++sb) {
-                const int n = c * 128 + sb * 16 + g * 4;
-                const f32x4 bvs = n < V ? *reinterpret_cast<const f32x4*>(e.bias + n) : f32x4{0, 0, 0, 0};
-                // refill targets: k-tiles RING.. of THIS sub-block (RING = 4) and the first RING k-tiles of the NEXT one
-                const uint32_t cbase = w_base(true, c, sb);
-                const uint32_t nbase = sb < 7 ? w_base(true, c, sb + 1) : w_base(nk < nseg, c_lo + ncc, 0);
-                f32x4 acc[8];
+            for (int sb = 0; sb < NSB; ++sb) {
+                f32x4 bvs[TNW];
+                uint32_t cbase[TNW], nbase[TNW];                        // refill targets: later k-tiles of THIS sub-block (RING = 4) / the first RING of the NEXT one
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] = f32x4{0, 0, 0, 0};
+                for (int j = 0; j < TNW; ++j) {
+                    const int nj = c * 128 + sb * SBW + j * 16 + g * 4;
+                    bvs[j] = nj < V ? *reinterpret_cast<const f32x4*>(e.bias + nj) : f32x4{0, 0, 0, 0};
+                    cbase[j] = w_base(true, c, sb, j);
+                    nbase[j] = sb < NSB - 1 ? w_base(true, c, sb + 1, j) : w_base(nk < nseg, c_lo + ncc, 0, j);
+                }
+                f32x4 acc[8][TNW];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < TNW; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
                 // 16 steps (k-tile, chunk); each consumed ring slot is refilled with the k-tile RING steps ahead
                 Frag<bf16> fa[FADB ? 2 : 1][8];
                 if (FADB) {
@@ -406,62 +416,69 @@ __global__ __launch_bounds__(64 * NW) void vocab_resident_kernel(const GemmOpera
 #pragma unroll
                         for (int i = 0; i < 8; ++i) lds_frag(fa[0][i], ablk, i * 16 + lr, ch, g);
                     }
-                    Frag<bf16> fw;
-                    fw.v = wreg[kt % RING][ch];
+                    const int fkt = kt + RING;                          // the k-tile that takes this ring slot
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) acc[i] = mma(fw, fa[FADB ? (t & 1) : 0][i], acc[i]);
-                    const int tk = kt + RING;                           // the k-tile that takes this slot
-                    wreg[kt % RING][ch] = __builtin_amdgcn_raw_buffer_load_b128(rsW, (tk < NT ? cbase : nbase) + ch * 64,
-                                                                               (((tk & (NT - 1)) + rot) & (NT - 1)) * 128, 0);
+                    for (int j = 0; j < TNW; ++j) {
+                        Frag<bf16> fw;
+                        fw.v = wreg[kt % RING][j][ch];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[i][j] = mma(fw, fa[FADB ? (t & 1) : 0][i], acc[i][j]);
+                        wreg[kt % RING][j][ch] = __builtin_amdgcn_raw_buffer_load_b128(rsW, (fkt < NT ? cbase[j] : nbase[j]) + ch * 64,
+                                                                                      (((fkt & (NT - 1)) + rot) & (NT - 1)) * 128, 0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);                  // keep this order (an unconstrained schedule hoisted every read and spilled)
                 }
-                // ---- epilogue of the sub-block: 8 row fragments x 4 consecutive columns per lane
+                // ---- epilogue of the sub-block: 8 row fragments x TNW groups of 4 consecutive columns per lane
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int m = m0 + i * 16 + lr;
                     const bool mok = m < p.M;
                     const long lrow_ = lrows[i];
-                    f32x4 uv = f32x4{0.5f, 0.5f, 0.5f, 0.5f};
-                    if (PARITY) {
-                        if (mok && n < V) {
-                            if (e.U) uv = *reinterpret_cast<const f32x4*>(e.U + (size_t)lrow_ * V + n);
-                            else {
-                                const uint64_t li = (uint64_t)lrow_ * (uint64_t)V + (uint64_t)n;
 #pragma unroll
-                                for (int rr = 0; rr < 4; ++rr) uv[rr] = torch_uniform(e.seed_lo, e.seed_hi, e.philox_offset, li + rr, e.philox_stride);
+                    for (int j = 0; j < TNW; ++j) {
+                        const int n = c * 128 + sb * SBW + j * 16 + g * 4;
+                        f32x4 uv = f32x4{0.5f, 0.5f, 0.5f, 0.5f};
+                        if (PARITY) {
+                            if (mok && n < V) {
+                                if (e.U) uv = *reinterpret_cast<const f32x4*>(e.U + (size_t)lrow_ * V + n);
+                                else {
+                                    const uint64_t li = (uint64_t)lrow_ * (uint64_t)V + (uint64_t)n;
+#pragma unroll
+                                    for (int rr = 0; rr < 4; ++rr) uv[rr] = torch_uniform(e.seed_lo, e.seed_hi, e.philox_offset, li + rr, e.philox_stride);
+                                }
                             }
                         }
-                    }
-                    float uf[4] = {0.5f, 0.5f, 0.5f, 0.5f};
-                    if (!PARITY && !e.no_noise) {
-                        const uint64_t gq = ((uint64_t)lrow_ * (uint64_t)V + (uint64_t)n) >> 2;
-                        uniform24x4(seed_lo, seed_hi, (uint32_t)gq, (uint32_t)(gq >> 32), uf);
-                    }
-                    float lg[4];
-                    float bmax = -INFINITY;
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int nn = n + rr;
-                        const float logit = acc[i][rr] + bvs[rr];
-                        float noisy;
-                        if (PARITY) {
-                            const float gum = -logf(-logf(uv[rr] + 1e-10f) + 1e-10f);
-                            noisy = logit / e.temp + gum;
-                        } else {
-                            noisy = fmaf(logit, inv_t_log2e, -__log2f(-__log2f(uf[rr])));
+                        float uf[4] = {0.5f, 0.5f, 0.5f, 0.5f};
+                        if (!PARITY && !e.no_noise) {
+                            const uint64_t gq = ((uint64_t)lrow_ * (uint64_t)V + (uint64_t)n) >> 2;
+                            uniform24x4(seed_lo, seed_hi, (uint32_t)gq, (uint32_t)(gq >> 32), uf);
                         }
-                        if (e.no_noise) noisy = logit;
-                        const bool ok = nn < V;
-                        if (LSE) { lg[rr] = ok ? logit : -INFINITY; bmax = fmaxf(bmax, lg[rr]); }
-                        if (ok && (noisy > best[i])) { best[i] = noisy; bidx[i] = nn; blog[i] = logit; }      // ascending nn: first max wins
-                    }
-                    if (LSE && bmax > -INFINITY) {
-                        const float nm = fmaxf(lmax[i], bmax);
-                        float add = 0.f;
+                        float lg[4];
+                        float bmax = -INFINITY;
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) add += __expf(lg[rr] - nm);
-                        lsum[i] = (lmax[i] == -INFINITY ? 0.f : lsum[i] * __expf(lmax[i] - nm)) + add;
-                        lmax[i] = nm;
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const int nn = n + rr;
+                            const float logit = acc[i][j][rr] + bvs[j][rr];
+                            float noisy;
+                            if (PARITY) {
+                                const float gum = -logf(-logf(uv[rr] + 1e-10f) + 1e-10f);
+                                noisy = logit / e.temp + gum;
+                            } else {
+                                noisy = fmaf(logit, inv_t_log2e, -__log2f(-__log2f(uf[rr])));
+                            }
+                            if (e.no_noise) noisy = logit;
+                            const bool ok = nn < V;
+                            if (LSE) { lg[rr] = ok ? logit : -INFINITY; bmax = fmaxf(bmax, lg[rr]); }
+                            if (ok && (noisy > best[i])) { best[i] = noisy; bidx[i] = nn; blog[i] = logit; }      // ascending nn: first max wins
+                        }
+                        if (LSE && bmax > -INFINITY) {
+                            const float nm = fmaxf(lmax[i], bmax);
+                            float add = 0.f;
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) add += __expf(lg[rr] - nm);
+                            lsum[i] = (lmax[i] == -INFINITY ? 0.f : lsum[i] * __expf(lmax[i] - nm)) + add;
+                            lmax[i] = nm;
+                        }
                     }
                 }
             }
@@ -735,20 +752,20 @@ static int vocab_sample_launch(int dtype, const void* A, int lda, const void* W,
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PK_ELAUNCH;
         const dim3 rgrid(256);                                         // 8 XCDs x 32 CUs: one workgroup per CU
-#define PK_VR(NWV, RNG, FA, PAR, LS) do { \
+#define PK_VR(NWV, RNG, FA, TW, PAR, LS) do { \
             static bool attr_set[64] = {}; \
             if (!attr_set[dev]) { \
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vocab_resident_kernel<NWV, RNG, FA, PAR, LS>), \
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&vocab_resident_kernel<NWV, RNG, FA, TW, PAR, LS>), \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, VR_SMEM) != hipSuccess) return PK_ELAUNCH; \
                 attr_set[dev] = true; \
             } \
-            hipLaunchKernelGGL((vocab_resident_kernel<NWV, RNG, FA, PAR, LS>), rgrid, dim3(64 * NWV), VR_SMEM, s, p, e); } while (0)
+            hipLaunchKernelGGL((vocab_resident_kernel<NWV, RNG, FA, TW, PAR, LS>), rgrid, dim3(64 * NWV), VR_SMEM, s, p, e); } while (0)
         if (resident_env == 2 || (resident_env == 3 && !lse)) {
-            switch (vi) { case 0: PK_VR(12, 4, false, false, false); break; case 1: PK_VR(12, 4, false, false, true); break;
-                          case 2: PK_VR(12, 4, false, true, false); break; default: PK_VR(12, 4, false, true, true); break; }
+            switch (vi) { case 0: PK_VR(12, 4, false, 1, false, false); break; case 1: PK_VR(12, 4, false, 1, false, true); break;
+                          case 2: PK_VR(12, 4, false, 1, true, false); break; default: PK_VR(12, 4, false, 1, true, true); break; }
         } else {
-            switch (vi) { case 0: PK_VR(8, 8, true, false, false); break; case 1: PK_VR(8, 8, true, false, true); break;
-                          case 2: PK_VR(8, 8, true, true, false); break; default: PK_VR(8, 8, true, true, true); break; }
+            switch (vi) { case 0: PK_VR(8, 8, true, 1, false, false); break; case 1: PK_VR(8, 8, true, 1, false, true); break;
+                          case 2: PK_VR(8, 8, true, 1, true, false); break; default: PK_VR(8, 8, true, 1, true, true); break; }
         }
 #undef PK_VR
         PK_CHECK_LAUNCH();
