@@ -90,20 +90,23 @@ def bmm(A, B, C, tA, tB, batch, M, N, K, *, lda, ldb, ldc, sA=0, sB=0, sC=0, acc
     return C
 
 
-def install():
-    for name, fn in dict(gemm=gemm, pack=pack, gemm_splitk=gemm_splitk, sum_batch=sum_batch, colsum=colsum, leaky_bwd=leaky_bwd, im2col=im2col,
-                         col2im=col2im, nchw_to_rows=nchw_to_rows, rows_to_nchw=rows_to_nchw, bmm=bmm).items():
-        setattr(L, name, fn)
-    L.require_device = lambda t, name='tensor': None
+EMULATED = dict(gemm=gemm, pack=pack, gemm_splitk=gemm_splitk, sum_batch=sum_batch, colsum=colsum, leaky_bwd=leaky_bwd, im2col=im2col,
+                col2im=col2im, nchw_to_rows=nchw_to_rows, rows_to_nchw=rows_to_nchw, bmm=bmm, require_device=lambda t, name='tensor': None)
 
 
-def main():
-    install()
+def install(setter=None):
+    """replace the C-ABI wrappers the discriminator's graph calls by the torch expressions above (setter: e.g. pytest's monkeypatch.setattr)"""
+    for name, fn in EMULATED.items():
+        (setter or setattr)(L, name, fn)
+
+
+def main(setter=None, cases=((32, 16), ((64, 32), 16), (64, 4))):
+    install(setter)
     from oracle import gan_oracle as G
     from oracle import weights
     from phenaki_pytorch_amd.discriminator import Discriminator, gradient_penalty, hinge_discr_loss
     worst = 0.
-    for size, dim in ((32, 16), ((64, 32), 16), (64, 4)):
+    for size, dim in cases:
         torch.manual_seed(0)
         d = Discriminator(dim=dim, image_size=size)
         weights.fill_module(d, salt=1)
@@ -135,6 +138,7 @@ def main():
         missing = [k for k, v in sd.items() if v.requires_grad and v.grad is not None and v.numel() and k[6:] not in got]
         assert not missing, missing
     print('ok: worst relative gradient error', worst)
+    return worst
 
 
 if __name__ == '__main__':
