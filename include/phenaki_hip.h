@@ -388,6 +388,19 @@ int pk_rows_to_nchw(const float* rows, int B, int C, int H, int W, int Cp, float
 int pk_pick_frames(float* video, const int* frame, int B, int C, int F, int H, int W, float* img, int place, void* stream);
 int pk_bmm(const float* A, long long lda, long long sA, int tA, const float* B, long long ldb, long long sB, int tB, float* C, long long ldc,
            long long sC, int batch, int M, int N, int K, int accumulate, void* stream);
+/* Row-wise pieces of the discriminator's attention block WITH their second derivatives (gradient_penalty differentiates the input gradient through the
+ * block: cvivit.py:59-73, 166-168; attention.py:29-36, 153-155, 176); one wave per row, contiguous f32 rows.
+ * pk_row_softmax   mode 0: out = softmax(a);  1: out = a (b - <a, b>)  (a = y, b = dy: the backward);  2: out = c (b - <a, b>) - b <c, a>  (the gradient
+ *                  of <c, backward> with respect to y; with respect to dy it is mode 1 with b = c).
+ * pk_row_l2scale   mode 0: o0 = x / |x| * sc  (F.normalize, then q_scale / k_scale);  1: o0 = dx, o1 = per-row contributions to dsc, from dz;
+ *                  2: o0 = grad_x, o1 = per-row contributions to grad_sc, o2 = grad_dz of <gx, dx> + <gsc, dsc>.
+ * pk_row_ln_bwd2   the same for the gamma-only LayerNorm's backward (pk_layernorm_bwd): u = upstream of dx [M][D], w = upstream of dgamma [D].
+ * The per-row contributions are summed over rows by pk_colsum. */
+int pk_row_softmax(const float* a, const float* b, const float* c, float* out, long long M, int n, int mode, void* stream);
+int pk_row_l2scale(const float* x, const float* sc, const float* dz, const float* gx, const float* gsc, float* o0, float* o1, float* o2,
+                   long long M, int d, int mode, void* stream);
+int pk_row_ln_bwd2(const float* x, const float* gamma, const float* dy, const float* u, const float* w, float eps, float* grad_x,
+                   float* grad_gamma_rows, float* grad_dy, long long M, int D, void* stream);
 
 #ifdef __cplusplus
 }

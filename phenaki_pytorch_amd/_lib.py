@@ -94,6 +94,9 @@ SIGNATURES = {
     'pk_rows_to_nchw': [_P, _I, _I, _I, _I, _I, _P, _P],
     'pk_pick_frames': [_P, _P, _I, _I, _I, _I, _I, _P, _I, _P],
     'pk_bmm': [_P, _LL, _LL, _I, _P, _LL, _LL, _I, _P, _LL, _LL, _I, _I, _I, _I, _I, _P],
+    'pk_row_softmax': [_P, _P, _P, _P, _LL, _I, _I, _P],
+    'pk_row_l2scale': [_P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _P],
+    'pk_row_ln_bwd2': [_P, _P, _P, _P, _P, _F, _P, _P, _P, _LL, _I, _P],
 }
 
 _ERR = {-1: 'PK_EINVAL (bad shape/size/flag)', -2: 'PK_EALIGN (pointer/stride alignment)', -3: 'PK_ELAUNCH (HIP launch failed)'}
@@ -694,6 +697,24 @@ def bmm(A, B, C, tA, tB, batch, M, N, K, *, lda, ldb, ldc, sA=0, sB=0, sC=0, acc
     _check(load().pk_bmm(ptr(A), lda, sA, 1 if tA else 0, ptr(B), ldb, sB, 1 if tB else 0, ptr(C), ldc, sC, batch, M, N, K,
                          1 if accumulate else 0, stream(A)), 'pk_bmm')
     return C
+
+
+def row_softmax(a, b, c, out, mode):
+    """rows of the last dimension (contiguous f32): mode 0 softmax(a); 1 a (b - <a, b>); 2 c (b - <a, b>) - b <c, a>  (see the header)"""
+    n = a.shape[-1]
+    _check(load().pk_row_softmax(ptr(a), ptr(b), ptr(c), ptr(out), a.numel() // n, n, mode, stream(a)), 'pk_row_softmax')
+    return out
+
+
+def row_l2scale(x, sc, dz, gx, gsc, o0, o1, o2, mode):
+    d = x.shape[-1]
+    _check(load().pk_row_l2scale(ptr(x), ptr(sc), ptr(dz), ptr(gx), ptr(gsc), ptr(o0), ptr(o1), ptr(o2), x.numel() // d, d, mode, stream(x)), 'pk_row_l2scale')
+
+
+def row_ln_bwd2(x, gamma, dy, u, w, eps, grad_x, grad_gamma_rows, grad_dy):
+    D = x.shape[-1]
+    _check(load().pk_row_ln_bwd2(ptr(x), ptr(gamma), ptr(dy), ptr(u), ptr(w), float(eps), ptr(grad_x), ptr(grad_gamma_rows), ptr(grad_dy),
+                                 x.numel() // D, D, stream(x)), 'pk_row_ln_bwd2')
 
 
 class TorchPhilox:

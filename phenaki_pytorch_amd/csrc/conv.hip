@@ -151,6 +151,143 @@ __global__ __launch_bounds__(256) void bmm_kernel(const float* __restrict__ A, l
     }
 }
 
+// ---- row-wise pieces of the discriminator's attention block WITH their second derivatives (the gradient penalty differentiates the input gradient through
+// the block, cvivit.py:59-73, 166-168): softmax over the keys, l2norm x scale vector (attention.py:153-155), and the backward-of-backward of the gamma-only
+// LayerNorm (attention.py:29-36; its forward / backward are pk_layernorm / pk_layernorm_bwd).  One wave per row, lanes stride the row; the sums over ROWS that
+// the parameter gradients need (d scale, d gamma) are left as per-row contributions for pk_colsum (deterministic two-stage sum).  Formulas (u = upstream):
+//   softmax      y = softmax(x);  B(y, dy) = y (dy - <y, dy>);  d<u, B>/dy_in = u (dy - <y, dy>) - dy <u, y>,  d<u, B>/d dy = B(y, u)
+//   l2 x scale   z = x^ sc, x^ = x / |x|;  dx = P t / |x| (t = dz sc, P = I - x^ x^T), dsc = sum_rows dz x^;
+//                second order: grad_dz = sc P gx / |x| + gsc x^,  grad_sc = sum_rows dz P gx / |x|,
+//                              grad_x = -[P (a gx + b t) + x^ <gx, t - x^ a>] / |x|^2 + P (gsc dz) / |x|,  a = <x^, t>, b = <gx, x^>
+//   LayerNorm    dx = (g^ - mean g^ - x^ mean(g^ x^)) / sigma (g^ = dy gamma), dgamma = sum_rows dy x^;
+//                second order (u for dx, w for dgamma): gg = (u - mean u - x^ mean(u x^)) / sigma, grad_dy = gamma gg + w x^, grad_gamma = sum_rows dy gg,
+//                              v = -(m2 u + c2 g^) / sigma + w dy,  grad_x = (v - mean v - x^ mean(v x^)) / sigma - S x^ / (D sigma^2),
+//                              S = <u, g^> - D c1 m1 - D c2 m2,  c1 = mean u, c2 = mean(u x^), m1 = mean g^, m2 = mean(g^ x^)
+// (each checked against torch.autograd on the CPU to 1e-15 before it was written down here, and against torch on the GPU in tests/test_gan_gpu.py)
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+#define PK_ROW_PROLOGUE \
+    const int lane = threadIdx.x & 63; \
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); \
+    if (row >= M) return;
+
+// mode 0: y = softmax(a);  1: out = a (b - <a, b>)  [a = y, b = dy];  2: out = c (b - <a, b>) - b <c, a>  [a = y, b = dy, c = upstream]
+__global__ __launch_bounds__(256) void row_softmax_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                          float* __restrict__ out, long M, int n, int mode) {
+    PK_ROW_PROLOGUE
+    const float* ar = a + row * n;
+    float* orow = out + row * n;
+    if (mode == 0) {
+        float mx = -INFINITY;
+        for (int j = lane; j < n; j += 64) mx = fmaxf(mx, ar[j]);
+        mx = wmax(mx);
+        float sm = 0.f;
+        for (int j = lane; j < n; j += 64) sm += __expf(ar[j] - mx);
+        sm = wsum(sm);
+        const float inv = 1.0f / sm;
+        for (int j = lane; j < n; j += 64) orow[j] = __expf(ar[j] - mx) * inv;
+        return;
+    }
+    const float* br = b + row * n;
+    float r = 0.f, q = 0.f;
+    for (int j = lane; j < n; j += 64) { r += ar[j] * br[j]; if (mode == 2) q += c[row * n + j] * ar[j]; }
+    r = wsum(r);
+    if (mode == 2) q = wsum(q);
+    for (int j = lane; j < n; j += 64)
+        orow[j] = mode == 1 ? ar[j] * (br[j] - r) : c[row * n + j] * (br[j] - r) - br[j] * q;
+}
+
+// mode 0: z = x^ sc;  1: dx, dsc_rows from dz;  2: grad_x, grad_sc_rows, grad_dz from (dz, gx, gsc)
+__global__ __launch_bounds__(256) void row_l2scale_kernel(const float* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ dz,
+                                                          const float* __restrict__ gx, const float* __restrict__ gsc, float* __restrict__ o0,
+                                                          float* __restrict__ o1, float* __restrict__ o2, long M, int d, int mode) {
+    PK_ROW_PROLOGUE
+    const float* xr = x + row * d;
+    float ss = 0.f;
+    for (int j = lane; j < d; j += 64) ss += xr[j] * xr[j];
+    const float nrm = fmaxf(sqrtf(wsum(ss)), 1e-12f), inv = 1.0f / nrm;      // F.normalize eps
+    if (mode == 0) {
+        for (int j = lane; j < d; j += 64) o0[row * d + j] = xr[j] * inv * sc[j];
+        return;
+    }
+    const float* dzr = dz + row * d;
+    float a = 0.f;                                                        // <x^, t>, t = dz sc
+    for (int j = lane; j < d; j += 64) a += xr[j] * inv * dzr[j] * sc[j];
+    a = wsum(a);
+    if (mode == 1) {
+        for (int j = lane; j < d; j += 64) {
+            const float u = xr[j] * inv, t = dzr[j] * sc[j];
+            o0[row * d + j] = (t - u * a) * inv;
+            o1[row * d + j] = dzr[j] * u;
+        }
+        return;
+    }
+    const float* gr = gx + row * d;
+    float b = 0.f, gt = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+    // b = <gx, x^>; gt = <gx, t>; e1 = <x^, a gx + b t> needs b first: two passes
+    for (int j = lane; j < d; j += 64) { const float u = xr[j] * inv; b += gr[j] * u; gt += gr[j] * dzr[j] * sc[j]; e3 += u * gsc[j] * dzr[j]; }
+    b = wsum(b); gt = wsum(gt); e3 = wsum(e3);
+    e1 = a * b + b * a;                                                   // <x^, a gx + b t> = a b + b a
+    e2 = gt - b * a;                                                      // <gx, t - x^ a>
+    for (int j = lane; j < d; j += 64) {
+        const float u = xr[j] * inv, t = dzr[j] * sc[j];
+        const float pg = gr[j] - u * b;                                   // (P gx)_j
+        o2[row * d + j] = sc[j] * pg * inv + gsc[j] * u;                  // grad_dz
+        o1[row * d + j] = dzr[j] * pg * inv;                              // grad_sc contribution of this row
+        const float w_ = a * gr[j] + b * t;
+        const float pw = w_ - u * e1;
+        const float pgd = gsc[j] * dzr[j] - u * e3;                       // (P (gsc dz))_j
+        o0[row * d + j] = -(pw + u * e2) * inv * inv + pgd * inv;         // grad_x
+    }
+}
+
+// backward-of-backward of the gamma-only LayerNorm: (grad_x, grad_gamma_rows, grad_dy) from (x, gamma, dy, u, w)
+__global__ __launch_bounds__(256) void row_ln_bwd2_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ dy,
+                                                          const float* __restrict__ u, const float* __restrict__ w, float eps, float* __restrict__ gxo,
+                                                          float* __restrict__ ggo, float* __restrict__ gdyo, long M, int D) {
+    PK_ROW_PROLOGUE
+    const float* xr = x + row * D;
+    const float* dyr = dy + row * D;
+    const float* ur = u + row * D;
+    const float invD = 1.0f / (float)D;
+    float s1 = 0.f;
+    for (int j = lane; j < D; j += 64) s1 += xr[j];
+    const float mu = wsum(s1) * invD;
+    float s2 = 0.f;
+    for (int j = lane; j < D; j += 64) { const float c = xr[j] - mu; s2 += c * c; }
+    const float sig = sqrtf(wsum(s2) * invD + eps), isig = 1.0f / sig;
+    float c1 = 0.f, c2 = 0.f, m1 = 0.f, m2 = 0.f, ug = 0.f;
+    for (int j = lane; j < D; j += 64) {
+        const float xh = (xr[j] - mu) * isig, gh = dyr[j] * gamma[j];
+        c1 += ur[j]; c2 += ur[j] * xh; m1 += gh; m2 += gh * xh; ug += ur[j] * gh;
+    }
+    c1 = wsum(c1) * invD; c2 = wsum(c2) * invD; m1 = wsum(m1) * invD; m2 = wsum(m2) * invD; ug = wsum(ug);
+    const float S = ug - (float)D * c1 * m1 - (float)D * c2 * m2;
+    float v1 = 0.f, v2 = 0.f;
+    for (int j = lane; j < D; j += 64) {
+        const float xh = (xr[j] - mu) * isig, gh = dyr[j] * gamma[j];
+        const float v = -(m2 * ur[j] + c2 * gh) * isig + w[j] * dyr[j];
+        v1 += v; v2 += v * xh;
+    }
+    v1 = wsum(v1) * invD; v2 = wsum(v2) * invD;
+    for (int j = lane; j < D; j += 64) {
+        const float xh = (xr[j] - mu) * isig, gh = dyr[j] * gamma[j];
+        const float gg = (ur[j] - c1 - xh * c2) * isig;
+        gdyo[row * D + j] = gamma[j] * gg + w[j] * xh;
+        ggo[row * D + j] = dyr[j] * gg;
+        const float v = -(m2 * ur[j] + c2 * gh) * isig + w[j] * dyr[j];
+        gxo[row * D + j] = (v - v1 - xh * v2) * isig - S * isig * isig * xh * invD;
+    }
+}
+
 inline int nblk(long total) { return (int)((total + 255) / 256); }
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -214,6 +351,31 @@ extern "C" int pk_bmm(const float* A, long lda, long sA, int tA, const float* B,
     const dim3 grid((N + BT - 1) / BT, (M + BT - 1) / BT, batch);
     if (grid.y > 65535) return PK_EINVAL;
     hipLaunchKernelGGL(bmm_kernel, grid, dim3(256), 0, STREAM(stream), A, lda, sA, tA, B, ldb, sB, tB, C, ldc, sC, M, N, K, accumulate);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+extern "C" int pk_row_softmax(const float* a, const float* b, const float* c, float* out, long M, int n, int mode, void* stream) {
+    if (!a || !out || M <= 0 || n <= 0 || mode < 0 || mode > 2 || (mode >= 1 && !b) || (mode == 2 && !c)) return PK_EINVAL;
+    hipLaunchKernelGGL(row_softmax_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, STREAM(stream), a, b, c, out, M, n, mode);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+extern "C" int pk_row_l2scale(const float* x, const float* sc, const float* dz, const float* gx, const float* gsc, float* o0, float* o1, float* o2,
+                              long M, int d, int mode, void* stream) {
+    if (!x || !sc || !o0 || M <= 0 || d <= 0 || mode < 0 || mode > 2) return PK_EINVAL;
+    if ((mode >= 1 && (!dz || !o1)) || (mode == 2 && (!gx || !gsc || !o2))) return PK_EINVAL;
+    hipLaunchKernelGGL(row_l2scale_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, STREAM(stream), x, sc, dz, gx, gsc, o0, o1, o2, M, d, mode);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+extern "C" int pk_row_ln_bwd2(const float* x, const float* gamma, const float* dy, const float* u, const float* w, float eps, float* grad_x,
+                              float* grad_gamma_rows, float* grad_dy, long M, int D, void* stream) {
+    if (!x || !gamma || !dy || !u || !w || !grad_x || !grad_gamma_rows || !grad_dy || M <= 0 || D <= 0) return PK_EINVAL;
+    hipLaunchKernelGGL(row_ln_bwd2_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, STREAM(stream), x, gamma, dy, u, w, eps, grad_x, grad_gamma_rows,
+                       grad_dy, M, D);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

@@ -15,9 +15,9 @@ parameter containers; the arithmetic is
 
 Every step is a torch.autograd.Function whose backward is again built from these Functions (`_MM` is closed under differentiation: the gradient
 of a matrix product is two matrix products), so `torch.autograd.grad(..., create_graph=True)` -- the gradient penalty of cvivit.py:59-73 --
-differentiates the input gradient through the same HIP kernels.  What stays on ATen: re-ordering / scaling of the (small) weight tensors, the
-scalar loss arithmetic on (B,) logits, and -- only in the graph that the gradient penalty differentiates twice -- the LayerNorm / l2norm / softmax
-of the ONE 64-token attention block (their second derivatives have no kernel here; its five matrix products per head stay on pk_gemm / pk_bmm).
+differentiates the input gradient through the same HIP kernels -- the LayerNorm / l2norm x scale / softmax of the ONE 64-token attention block included:
+they carry hand-derived second derivatives (pk_row_softmax / pk_row_l2scale / pk_row_ln_bwd2, formulas in csrc/conv.hip).  What stays on ATen:
+re-ordering / scaling of the (small) weight tensors, head split / merge copies, and the scalar loss arithmetic on (B,) logits and gradient norms.
 """
 import math
 
@@ -310,11 +310,124 @@ def _block_forward(block, x, B, H, W, C, dt):
     return out, H, W, Co
 
 
+class _Softmax(torch.autograd.Function):
+    """softmax over the last dimension; backward = _SoftmaxBwd (itself differentiable once more)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = L.row_softmax(x.contiguous(), None, None, torch.empty_like(x, memory_format=torch.contiguous_format), 0)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, = ctx.saved_tensors
+        return _SoftmaxBwd.apply(y, dy)
+
+
+class _SoftmaxBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, dy):
+        y, dy = y.contiguous(), dy.contiguous()
+        ctx.save_for_backward(y, dy)
+        return L.row_softmax(y, dy, None, torch.empty_like(y), 1)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        y, dy = ctx.saved_tensors
+        g = g.contiguous()
+        return L.row_softmax(y, dy, g, torch.empty_like(y), 2), L.row_softmax(y, g, None, torch.empty_like(y), 1)
+
+
+class _L2Scale(torch.autograd.Function):
+    """F.normalize(x, dim=-1) * sc (attention.py:153-155: l2norm, then q_scale / k_scale)"""
+
+    @staticmethod
+    def forward(ctx, x, sc):
+        x, sc = x.contiguous(), sc.contiguous()
+        z = torch.empty_like(x)
+        L.row_l2scale(x, sc, None, None, None, z, None, None, 0)
+        ctx.save_for_backward(x, sc)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, sc = ctx.saved_tensors
+        return _L2ScaleBwd.apply(x, sc, dz)
+
+
+class _L2ScaleBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, sc, dz):
+        x, sc, dz = x.contiguous(), sc.contiguous(), dz.contiguous()
+        d = x.shape[-1]
+        dx, rows = torch.empty_like(x), torch.empty_like(x)
+        L.row_l2scale(x, sc, dz, None, None, dx, rows, None, 1)
+        ctx.save_for_backward(x, sc, dz)
+        return dx, L.colsum(rows.view(-1, d), rows.numel() // d, d, _f32((d,), x.device))
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gx, gsc):
+        x, sc, dz = ctx.saved_tensors
+        d = x.shape[-1]
+        gx = torch.zeros_like(x) if gx is None else gx.contiguous()
+        gsc = torch.zeros_like(sc) if gsc is None else gsc.contiguous()
+        grad_x, rows, grad_dz = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        L.row_l2scale(x, sc, dz, gx, gsc, grad_x, rows, grad_dz, 2)
+        return grad_x, L.colsum(rows.view(-1, d), rows.numel() // d, d, _f32((d,), x.device)), grad_dz
+
+
+class _GammaLayerNorm(torch.autograd.Function):
+    """attention.py:29-36 (gamma parameter, zero beta buffer) on (M, D) rows: pk_layernorm / pk_layernorm_bwd / pk_row_ln_bwd2"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = x.contiguous()
+        M, D = x.shape
+        y = _f32((M, D), x.device)
+        L.layernorm(x, gamma.detach(), beta, M, D, out2=y, eps=eps)
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma = ctx.saved_tensors
+        dx, dg = _GammaLayerNormBwd.apply(x, gamma, dy, ctx.eps)
+        return dx, dg, None, None
+
+
+class _GammaLayerNormBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, dy, eps):
+        x, dy = x.contiguous(), dy.contiguous()
+        M, D = x.shape
+        dx = _f32((M, D), x.device)
+        dg, _ = L.layernorm_bwd(x, gamma.detach().contiguous(), dy, dx, M, D, eps=eps)
+        ctx.save_for_backward(x, gamma, dy)
+        ctx.eps = eps
+        return dx, dg
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, u, w):
+        x, gamma, dy = ctx.saved_tensors
+        M, D = x.shape
+        u = torch.zeros_like(x) if u is None else u.contiguous()
+        w = torch.zeros_like(gamma) if w is None else w.contiguous()
+        grad_x, rows, grad_dy = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        L.row_ln_bwd2(x, gamma.detach().contiguous(), dy, u, w, ctx.eps, grad_x, rows, grad_dy)
+        return grad_x, L.colsum(rows, M, D, _f32((D,), x.device)), grad_dy, None
+
+
 def _attention_second_order(attn, x, S, n, dt):
-    """attn(x) + x (cvivit.py:166-168; attention.py:132-182 with num_null_kv = 0, no mask / bias) as a graph that can be differentiated twice"""
+    """attn(x) + x (cvivit.py:166-168; attention.py:132-182 with num_null_kv = 0, no mask / bias) as a graph of Functions that can be differentiated
+    twice: LayerNorm, l2norm x scale and softmax carry their own second derivatives (pk_row_*), the five products are _MM / _Affine"""
     assert attn.num_null_kv == 0 and not attn.causal
     h = attn.heads
-    xn = F.layer_norm(x, (x.shape[-1],), attn.norm.gamma, attn.norm.beta, attn.norm.eps)
+    xn = _GammaLayerNorm.apply(x, attn.norm.gamma, attn.norm.beta, attn.norm.eps)
     q = mm(xn, attn.to_q.weight, False, True, dt)
     kv = mm(x, attn.to_kv.weight, False, True, dt)                       # K / V from the un-normalised rows (attention.py:140-144)
     k, v = kv.chunk(2, dim=-1)
@@ -322,10 +435,9 @@ def _attention_second_order(attn, x, S, n, dt):
     def heads(t):
         return t.reshape(S, n, h, 64).permute(0, 2, 1, 3).reshape(S * h, n, 64)
     q, k, v = heads(q), heads(k), heads(v)
-    q = F.normalize(q, dim=-1) * attn.q_scale
-    k = F.normalize(k, dim=-1) * attn.k_scale
-    sim = mm(q, k, False, True, L.F32) * attn.scale
-    p = sim.softmax(dim=-1)
+    q = _L2Scale.apply(q, attn.q_scale * float(attn.scale))              # the similarity scale rides on q's scale vector
+    k = _L2Scale.apply(k, attn.k_scale)
+    p = _Softmax.apply(mm(q, k, False, True, L.F32))
     o = mm(p, v, False, False, L.F32)
     o = o.reshape(S, h, n, 64).permute(0, 2, 1, 3).reshape(S * n, h * 64)
     return _Affine.apply(o, attn.to_out.weight, None, x, False, dt)

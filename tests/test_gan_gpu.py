@@ -154,6 +154,45 @@ def test_matrix_product_function_differentiates_twice(shape, tA, tB):
         close(o.detach().cpu(), r.detach(), 2e-4, f'_MM {name} {shape} tA={tA} tB={tB}')
 
 
+@pytest.mark.parametrize('op', ['softmax', 'l2scale', 'layernorm'])
+def test_row_ops_carry_their_second_derivatives(op):
+    """the three row-wise pieces of the discriminator's attention block (pk_row_softmax / pk_row_l2scale / pk_layernorm + pk_layernorm_bwd +
+    pk_row_ln_bwd2) against torch: value, first derivatives, and the derivatives of a function of the first derivatives (what the penalty takes)"""
+    from phenaki_pytorch_amd.discriminator import _GammaLayerNorm, _L2Scale, _Softmax
+    if op == 'softmax':
+        shapes = [(37, 64), (5, 3, 70)]
+        ref_f = lambda x, p: x.softmax(-1)                                  # noqa: E731
+        got_f = lambda x, p: _Softmax.apply(x)                              # noqa: E731
+        has_p = False
+    elif op == 'l2scale':
+        shapes = [(130, 64), (4, 9, 64)]
+        ref_f = lambda x, p: F.normalize(x, dim=-1) * p                     # noqa: E731
+        got_f = lambda x, p: _L2Scale.apply(x, p)                           # noqa: E731
+        has_p = True
+    else:
+        shapes = [(133, 128), (70, 512)]
+        ref_f = lambda x, p: F.layer_norm(x, x.shape[-1:], p, None, 1e-5)   # noqa: E731
+        got_f = lambda x, p: _GammaLayerNorm.apply(x, p, torch.zeros_like(p), 1e-5)     # noqa: E731
+        has_p = True
+    for shape in shapes:
+        x0 = torch.randn(shape, generator=g32(70)) * 1.5
+        p0 = 1 + 0.3 * torch.randn(shape[-1], generator=g32(71))
+        T = torch.randn(shape, generator=g32(72))
+
+        def run(f, dev):
+            x = x0.to(dev).requires_grad_()
+            p = p0.to(dev).requires_grad_() if has_p else None
+            y = f(x, p)
+            ins = (x, p) if has_p else (x,)
+            gs = torch.autograd.grad((y * T.to(dev)).sum() + (y ** 2).sum() * 0.5, ins, create_graph=True)
+            second = sum((gi ** 2).sum() + gi.sum() * 0.3 for gi in gs)
+            hs = torch.autograd.grad(second, ins)
+            return (y,) + tuple(gs) + tuple(hs)
+        ref, got = run(ref_f, 'cpu'), run(got_f, 'cuda')
+        for i, (r, o) in enumerate(zip(ref, got)):
+            close(o.detach().cpu(), r.detach(), 2e-4, f'{op} {shape} output {i}')
+
+
 # ------------------------------------------------------------------------------------------------ the discriminator
 
 @pytest.mark.parametrize('dtype,tol', MODES)

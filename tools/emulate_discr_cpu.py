@@ -1,5 +1,5 @@
 """Developer check (NOT a test, NOT a product path): runs the Discriminator's autograd graph (phenaki_pytorch_amd/discriminator.py) on the CPU
-with the handful of C-ABI calls it makes replaced by torch expressions, and compares logits, hinge + gradient-penalty loss and every
+with the C-ABI calls it makes replaced by torch expressions, and compares logits, hinge + gradient-penalty loss and every
 gradient with oracle/gan_oracle.py.  It validates the graph composition (weight re-ordering, transposition flags of _MM, the second-order
 closure) before GPU minutes are spent on the kernels themselves; the kernels are tested in tests/test_gan_gpu.py."""
 import os
@@ -90,7 +90,69 @@ def bmm(A, B, C, tA, tB, batch, M, N, K, *, lda, ldb, ldc, sA=0, sB=0, sC=0, acc
     return C
 
 
-EMULATED = dict(gemm=gemm, pack=pack, gemm_splitk=gemm_splitk, sum_batch=sum_batch, colsum=colsum, leaky_bwd=leaky_bwd, im2col=im2col,
+def row_softmax(a, b, c, out, mode):
+    if mode == 0:
+        out.copy_(a.softmax(-1))
+    elif mode == 1:
+        out.copy_(a * (b - (a * b).sum(-1, keepdim=True)))
+    else:
+        out.copy_(c * (b - (a * b).sum(-1, keepdim=True)) - b * (c * a).sum(-1, keepdim=True))
+    return out
+
+
+def row_l2scale(x, sc, dz, gx, gsc, o0, o1, o2, mode):
+    n = x.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    u = x / n
+    if mode == 0:
+        o0.copy_(u * sc)
+        return
+    t = dz * sc
+    a = (u * t).sum(-1, keepdim=True)
+    if mode == 1:
+        o0.copy_((t - u * a) / n)
+        o1.copy_(dz * u)
+        return
+    P = lambda v: v - u * (u * v).sum(-1, keepdim=True)               # noqa: E731
+    b = (gx * u).sum(-1, keepdim=True)
+    pg = P(gx)
+    o2.copy_(sc * pg / n + gsc * u)
+    o1.copy_(dz * pg / n)
+    o0.copy_(-(P(a * gx + b * t) + u * (gx * (t - u * a)).sum(-1, keepdim=True)) / n ** 2 + P(gsc * dz) / n)
+
+
+def _ln_parts(x, eps):
+    mu = x.mean(-1, keepdim=True)
+    sig = (((x - mu) ** 2).mean(-1, keepdim=True) + eps).sqrt()
+    return (x - mu) / sig, sig
+
+
+def layernorm(x, gamma, beta, M, D, *, out=None, out2=None, raw=None, eps=1e-5, **kw):
+    out2.copy_(F.layer_norm(x, (D,), gamma, beta, eps))
+
+
+def layernorm_bwd(x, gamma, dy, dx, M, D, *, add=None, want_beta=False, eps=1e-5):
+    xh, sig = _ln_parts(x, eps)
+    gh = dy * gamma
+    dx.copy_((gh - gh.mean(-1, keepdim=True) - xh * (gh * xh).mean(-1, keepdim=True)) / sig)
+    return (dy * xh).sum(0), None
+
+
+def row_ln_bwd2(x, gamma, dy, u, w, eps, grad_x, grad_gamma_rows, grad_dy):
+    D = x.shape[-1]
+    xh, sig = _ln_parts(x, eps)
+    gh = dy * gamma
+    c1, c2 = u.mean(-1, keepdim=True), (u * xh).mean(-1, keepdim=True)
+    m1, m2 = gh.mean(-1, keepdim=True), (gh * xh).mean(-1, keepdim=True)
+    gg = (u - c1 - xh * c2) / sig
+    grad_dy.copy_(gamma * gg + w * xh)
+    grad_gamma_rows.copy_(dy * gg)
+    S = (u * gh).sum(-1, keepdim=True) - D * c1 * m1 - D * c2 * m2
+    v = -(m2 * u + c2 * gh) / sig + w * dy
+    grad_x.copy_((v - v.mean(-1, keepdim=True) - xh * (v * xh).mean(-1, keepdim=True)) / sig - S / sig ** 2 * xh / D)
+
+
+EMULATED = dict(row_softmax=row_softmax, row_l2scale=row_l2scale, layernorm=layernorm, layernorm_bwd=layernorm_bwd, row_ln_bwd2=row_ln_bwd2,
+                gemm=gemm, pack=pack, gemm_splitk=gemm_splitk, sum_batch=sum_batch, colsum=colsum, leaky_bwd=leaky_bwd, im2col=im2col,
                 col2im=col2im, nchw_to_rows=nchw_to_rows, rows_to_nchw=rows_to_nchw, bmm=bmm, require_device=lambda t, name='tensor': None)
 
 
