@@ -112,6 +112,32 @@ def test_gan_tokenizer_state_dict_contract(golden_dir):
     assert d.discr is not None and (d.vgg is not None or any('vgg' in str(x.message) for x in w))
 
 
+def test_bench_compact_line_is_what_the_driver_parses():
+    """round 3's driver record had `parsed: null` because the stdout line had grown to 22 KB.  bench.compact_line on a REAL full report (the committed
+    round-4 one) must stay under 4 KB, be one JSON object, and carry the contract's keys plus roofline and cpu_baseline."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    full_path = os.path.join(root, 'profiles', 'bench_r04.json')
+    if not os.path.exists(full_path):
+        pytest.skip('no committed full report')
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.load(open(full_path))
+    line = json.dumps(bench.compact_line(full), separators=(',', ':'))
+    assert len(line) <= 4000 and '\n' not in line
+    d = json.loads(line)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config'):
+        assert k in d, k
+    assert d['config']['workload'].startswith('BASELINE configs[1]') and 'model' not in d['config']
+    assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(d['roofline'])
+    assert abs(d['roofline']['frac'] - d['roofline']['achieved'] / d['roofline']['peak']) < 1e-3
+    assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(d['cpu_baseline']) and d['cpu_baseline']['kind'] in ('port', 'reference')
+    assert d['parity']['dtype'] == 'bf16x3' and d['sample']['unit'] == 'tokens/s'
+
+
 def test_shape_helpers_and_schedule():
     import phenaki_pytorch_amd as P
     from phenaki_pytorch_amd.phenaki import mask_schedule
