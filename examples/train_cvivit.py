@@ -10,6 +10,7 @@ DataLoader (data.py:177-265); without it synthetic videos stand in.  One process
     python examples/train_cvivit.py --steps 20 --small --gan
 """
 import argparse
+import contextlib
 import os
 import sys
 import time
@@ -85,7 +86,10 @@ def main():
         videos = next(stream)
         opt.zero_grad(set_to_none=True)
         loss = cvivit(videos)
-        loss.backward()
+        # the generator objective also reaches discr.* through gen_loss: those gradients are dropped below (discr_opt.zero_grad), so their
+        # reducer must not start collectives for them -- a launched bucket would meet the discriminator step's own backward
+        with (discr_reducer.no_sync() if discr_reducer is not None else contextlib.nullcontext()):
+            loss.backward()
         if reducer is not None:
             reducer.finish()
         opt.step()

@@ -378,7 +378,8 @@ int pk_attn_bwd(const float* Qh, const float* Kh, const float* Vh, const void* O
  *   (3x3 / pad 1: the net convolutions; 1x1 / stride 2: conv_res; 2x2 / stride 2: Rearrange('b c (h p1) (w p2) -> b (c p1 p2) h w') + 1x1 conv);
  * pk_col2im: its adjoint in gather form (input gradient of the convolution; deterministic).
  * pk_nchw_to_rows / pk_rows_to_nchw: (B, C, H, W) <-> rows[(b, y, x)][Cp] with channels C..Cp-1 zero / dropped (mutually adjoint).
- * pk_pick_frames: pick_video_frame (cvivit.py:217-224) img[b] = video[b, :, frame[b]] (place = 0), or the adjoint into a zeroed video (place = 1).
+ * pk_pick_frames: pick_video_frame (cvivit.py:217-224) img[b] = video[b, :, frame[b]] (place = 0), or the adjoint into a zeroed video (place = 1);
+ *   frame: B device int32 indices; an index outside [0, F) reads as a zero frame / is not written (never an out-of-bounds access).
  * pk_bmm: C[z] = op(A[z]) op(B[z]) (+ C[z]) in exact f32 for any shape / leading dimension / batch stride (elements): the fallback product of the
  *   second-order graph of gradient_penalty (cvivit.py:59-73) and of the 64-token attention block inside the discriminator (cvivit.py:166-168). */
 int pk_im2col(const float* x, int B, int H, int W, int C, int kh, int kw, int stride, int pad, float* cols, long long ldc, void* stream);

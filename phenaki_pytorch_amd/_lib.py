@@ -688,6 +688,10 @@ def rows_to_nchw(rows, Cp, img):
 def pick_frames(video, frame, img, place=False):
     """img (B, C, H, W) <- video[b, :, frame[b]] (cvivit.py:217-224), or the adjoint into a zeroed video when place"""
     B, C, F, H, W = video.shape
+    # `frame` reaches the kernel as a raw `const int*`: an int64 tensor (what topk returns), a host tensor or a short one must fail here
+    if frame.dtype != torch.int32 or frame.device != video.device or not frame.is_contiguous() or frame.numel() != B:
+        raise RuntimeError(f'pick_frames: frame must be a contiguous int32 tensor of {B} indices on {video.device}, got {frame.dtype} '
+                           f'{tuple(frame.shape)} on {frame.device}')
     _check(load().pk_pick_frames(ptr(video), ptr(frame), B, C, F, H, W, ptr(img), 1 if place else 0, stream(video)), 'pk_pick_frames')
     return video if place else img
 

@@ -93,8 +93,13 @@ __global__ void frame_kernel(float* __restrict__ video, const int* __restrict__ 
     if (i >= total) return;
     const long bc = i / HW4, p = i % HW4;
     const long b = bc / C, c = bc % C;
-    f32x4* v = reinterpret_cast<f32x4*>(video) + ((b * C + c) * F + frame[b]) * HW4 + p;
+    const int f = frame[b];
     f32x4* g = reinterpret_cast<f32x4*>(img) + i;
+    if ((unsigned)f >= (unsigned)F) {                                    // an index outside [0, F) never becomes an out-of-bounds access:
+        if (!PLACE) *g = f32x4{0.f, 0.f, 0.f, 0.f};                      // the picked frame reads as zeros, the adjoint drops the write
+        return;
+    }
+    f32x4* v = reinterpret_cast<f32x4*>(video) + ((b * C + c) * F + f) * HW4 + p;
     if (PLACE) *v = *g; else *g = *v;
 }
 

@@ -452,9 +452,12 @@ class CViViT(PackedModule):
             return cvivit_discr_loss(self, video, mask=mask, apply_grad_penalty=apply_grad_penalty, return_recons=return_recons)
         if not (return_only_codebook_ids or return_recons_only):
             from .train import wants_grad
-            if wants_grad(self) or self.use_vgg_and_gan:
-                # grad mode on and trainable parameters: the tokenizer's training step (train_cvivit.py); the GAN objective
-                # needs gradients for its adaptive weight (cvivit.py:657-662), so it takes this path whenever it is asked for
+            # the GAN objective differentiates its own terms for the adaptive weight (cvivit.py:657-662) and needs the discriminator and the
+            # perceptual network: under torch.no_grad(), or on a copy_for_eval() module (both set to None, cvivit.py:415-417), forward(video)
+            # is an EVALUATION call and returns the value of the reconstruction loss (the reference raises inside autograd.grad there)
+            eval_call = self.use_vgg_and_gan and (not torch.is_grad_enabled() or self.discr is None)
+            if (wants_grad(self) or self.use_vgg_and_gan) and not eval_call:
+                # grad mode on and trainable parameters: the tokenizer's training step (train_cvivit.py)
                 from .train_cvivit import cvivit_loss_train
                 self._check_video(video, mask)
                 return cvivit_loss_train(self, video, mask=mask, return_recons=return_recons)
@@ -489,7 +492,7 @@ class CViViT(PackedModule):
         if return_only_codebook_ids:
             return self.tokenize(video)
 
-        assert return_recons_only or not (return_discr_loss or self.use_vgg_and_gan), 'forward() routes the GAN objectives to train_cvivit.py'
+        assert return_recons_only or not return_discr_loss, 'forward() routes the discriminator objective to train_cvivit.py'
         ids = self.tokenize(video).reshape(-1)
         T = 1 + (f - 1) // self.temporal_patch_size
         recon = self._decode2d(self.vq.codes_2d(ids, perm=(T, self.image_num_tokens)), b, T, temporal_rows=True)

@@ -162,8 +162,8 @@ def all_reduce_gradients(params, bucket_mb=64.0, average=True, group=None, force
     collectives even in a one-rank group (diagnostics)."""
     ws = _group_size(group)
     grads = [p.grad for p in params if p.grad is not None and p.grad.numel()]
-    if (ws == 1 and not (force and dist.is_available() and dist.is_initialized())) or not grads:
-        return 0
+    if ws <= 0 or (ws == 1 and not (force and dist.is_available() and dist.is_initialized())) or not grads:
+        return 0                                    # (ws < 0: this rank is not a member of `group`)
     bucket_elems = max(1, int(bucket_mb * (1 << 20) / 4))
     plan = bucket_plan([g.numel() for g in grads], bucket_elems)
     for idxs in plan:
@@ -185,7 +185,8 @@ class GradientReducer:
     before the collective, no copy back after it (torch DDP's gradient_as_bucket_view).  A bucket's all-reduce is started (async, on RCCL's own
     stream) the moment the last of its parameters has received its gradient, while the remaining backward kernels keep the compute stream
     busy; `finish()` -- called between `loss.backward()` and `opt.step()` -- launches what backward left incomplete (parameters that got no
-    gradient this step contribute zeros and keep `.grad = None`), waits, and averages.  Buckets are fixed at construction in REVERSE parameter
+    gradient on this rank this step contribute zeros and receive the reduced value as their `.grad`, so every replica steps them alike), waits,
+    and averages.  Buckets are fixed at construction in REVERSE parameter
     order (the order backward produces gradients in), so every rank issues the same collectives in the same order.
     With `zero_grad(set_to_none=False)` the views persist and backward accumulates straight into the arena (zero copies per step); after
     `zero_grad(set_to_none=True)` autograd hands each parameter a fresh tensor, which the hook moves into its view (one copy, half of what
@@ -221,6 +222,7 @@ class GradientReducer:
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._pending = []
+        self._absent = []
         self._enabled = True
         self.collectives = 0
         self.broadcasts = broadcast_parameters(self.params + list(buffers), group=group) if broadcast and self._active() and not force else 0
@@ -260,6 +262,7 @@ class GradientReducer:
         for i, ok in zip(self.buckets[b], have):
             if not ok:
                 self._views[i].zero_()              # no gradient on this rank this step: contributes zeros (another rank may have one)
+                self._absent.append(i)
         work = dist.all_reduce(self.arena[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append((b, work))
         self.collectives += 1
@@ -275,6 +278,11 @@ class GradientReducer:
                 work.wait()
                 if self.average and ws > 1:
                     self.arena[b].div_(ws)
+            # a parameter that got no gradient HERE may have got one on another rank: every rank must step it with the same averaged value
+            # (an optimizer skips `.grad is None`), so the reduced view becomes its gradient -- what DDP does under find_unused_parameters
+            for i in self._absent:
+                self.params[i].grad = self._views[i]
+        self._absent.clear()
         n = self.collectives
         self._pending.clear()
         self._ready = [0] * len(self.buckets)

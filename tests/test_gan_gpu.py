@@ -112,6 +112,17 @@ def test_pixel_row_and_frame_maps():
     ref = torch.zeros_like(video)
     ref[torch.arange(3), :, frame.long()] = pick
     assert torch.equal(placed, ref)
+    # the index vector reaches the kernel as a raw `const int*` -- anything but B contiguous device int32 indices is refused, and an
+    # index outside [0, F) is never an out-of-bounds access (zero frame on the way out, dropped on the way in)
+    with pytest.raises(RuntimeError, match='int32'):
+        L.pick_frames(video.cuda(), frame.long().cuda(), torch.empty(3, 3, 4, 8, device='cuda'))
+    with pytest.raises(RuntimeError, match='int32'):
+        L.pick_frames(video.cuda(), frame, torch.empty(3, 3, 4, 8, device='cuda'))
+    bad = torch.tensor([4, 5, -1], dtype=torch.int32).cuda()
+    pick2 = L.pick_frames(video.cuda(), bad, torch.full((3, 3, 4, 8), float('nan'), device='cuda')).cpu()
+    assert torch.equal(pick2[0], video[0, :, 4]) and not pick2[1:].any()
+    placed2 = L.pick_frames(torch.zeros(3, 3, 5, 4, 8, device='cuda'), bad, pick.cuda(), place=True).cpu()
+    assert torch.equal(placed2[0], ref[0]) and not placed2[1:].any()
 
 
 @pytest.mark.parametrize('tA', [False, True])
@@ -315,6 +326,18 @@ def test_gan_forward_surface():
         assert cv(video, return_only_codebook_ids=True).dtype == torch.int64
     ev = cv.copy_for_eval()
     assert ev.discr is None and ev.vgg is None and cv.discr is not None
+    # forward(video) as an EVALUATION call of a GAN-mode tokenizer -- under no_grad, and on the eval copy (no discriminator, no
+    # perceptual network) -- returns the value of the reconstruction loss instead of tripping the training path's asserts
+    cv.eval()
+    with torch.no_grad():
+        v0 = cv(video)
+        rl, rr = cv(video, return_recons=True)
+    v1 = ev(video)
+    assert v0.ndim == 0 and torch.isfinite(v0) and not v0.requires_grad and rr.shape == video.shape
+    ref_mse = torch.nn.functional.mse_loss(video, cv(video, return_recons_only=True).detach())
+    close(v0, ref_mse, 1e-4, 'no_grad forward = reconstruction loss')
+    close(v1, ref_mse, 1e-4, 'copy_for_eval forward = reconstruction loss')
+    cv.train()
     assert not any(k.startswith('vgg.') for k in cv.state_dict()) and any(k.startswith('discr.') for k in cv.state_dict())
 
 

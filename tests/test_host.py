@@ -282,13 +282,62 @@ def _grad_worker(rank, ws, port, q):
             net(xr).square().mean().backward()
         for w_, p_ in zip(want, net.parameters()):
             w_ += p_.grad / ws
-    ok = ok and all(torch.allclose(a, b, rtol=1e-5, atol=1e-7) for a, b in zip(mine, want)) and unused.grad is None
+    # (a parameter without a gradient on ANY rank ends with the reduced zeros as its .grad: every replica steps it alike)
+    ok = ok and all(torch.allclose(a, b, rtol=1e-5, atol=1e-7) for a, b in zip(mine, want)) and unused.grad is not None and not unused.grad.any()
     ok = ok and started_early >= 1 and nred == len(red.buckets) and red.collectives == 0
     # the gradients live in the flat arena: every .grad is a view of its bucket's buffer (the all-reduce ran in place, no flatten / copy-back)
     with torch.enable_grad():
         net(x).square().mean().backward()                          # accumulates INTO the views (zero_grad(set_to_none=False) regime)
     red.finish()
     ok = ok and all(p_.grad.data_ptr() == v.data_ptr() for p_, v in zip(red.params, red._views) if p_.grad is not None)
+    red.remove()
+    # a parameter with a gradient on ONE rank only must be stepped by every rank with the same averaged value
+    lone = torch.nn.Parameter(torch.ones(5))
+    both = torch.nn.Parameter(torch.ones(5))
+    red2 = GradientReducer([both, lone], bucket_mb=64., group=group, broadcast=False)
+    with torch.enable_grad():
+        ((both * 2.).sum() + ((lone * 3.).sum() if rank == 1 else 0.)).backward()
+    red2.finish()
+    ok = ok and lone.grad is not None and torch.allclose(lone.grad, torch.full((5,), 1.5)) and torch.allclose(both.grad, torch.full((5,), 2.))
+    red2.remove()
+    # two reducers whose graphs overlap -- the GAN generator objective also reaches the discriminator's parameters
+    # (examples/train_cvivit.py --gan).  Its backward runs under the discriminator reducer's no_sync(); the discriminator step then reduces normally.
+    gen, disc = torch.nn.Linear(6, 6), torch.nn.Linear(6, 1)
+    r_gen = GradientReducer(list(gen.parameters()), bucket_mb=64., group=group)
+    r_disc = GradientReducer(list(disc.parameters()), bucket_mb=64., group=group)
+    xin = torch.randn(4, 6, generator=torch.Generator().manual_seed(300 + rank))
+    try:
+        for _ in range(2):
+            gen.zero_grad(set_to_none=True)
+            with r_disc.no_sync(), torch.enable_grad():
+                disc(gen(xin)).mean().backward()                    # gradients land in disc.* too: dropped below
+            r_gen.finish()
+            disc.zero_grad(set_to_none=True)
+            with torch.enable_grad():
+                disc(gen(xin).detach()).square().mean().backward()
+            r_disc.finish()
+        want_d = []
+        for r in range(ws):
+            xr = torch.randn(4, 6, generator=torch.Generator().manual_seed(300 + r))
+            with torch.enable_grad():
+                want_d.append(torch.autograd.grad(disc(gen(xr).detach()).square().mean(), list(disc.parameters())))
+        ok = ok and all(torch.allclose(p_.grad, sum(w_[i] for w_ in want_d) / ws, rtol=1e-5, atol=1e-7) for i, p_ in enumerate(disc.parameters()))
+    except RuntimeError:
+        ok = False
+    # ... and without the guard the second backward is refused loudly instead of corrupting a bucket in flight
+    gen.zero_grad(set_to_none=True)
+    disc.zero_grad(set_to_none=True)
+    with torch.enable_grad():
+        disc(gen(xin)).mean().backward()
+    r_gen.finish()
+    refused = False
+    try:
+        with torch.enable_grad():
+            disc(gen(xin).detach()).square().mean().backward()
+    except RuntimeError as e:
+        refused = 'already being reduced' in str(e)
+    r_disc.finish()
+    ok = ok and refused
     q.put((rank, bool(ok), ncoll))
     dist.destroy_process_group()
 
