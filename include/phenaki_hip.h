@@ -148,6 +148,26 @@ int pk_lfq_encode(const float* x, int ldx, const float* wp, const float* bp, lon
 int pk_lfq_decode(const long long* ids, const float* wo, const float* bo, float* out, int M, int D, int cd,
                   const long long* ids_prime, int n_prime, int n, int pb, int pc, void* stream);
 
+/* LFQ training-mode auxiliary loss (third return of `self.vq(tokens)`, cvivit.py:570, added to the GAN generator objective at cvivit.py:666;
+ * the published vector-quantize-pytorch LFQ.forward, restated in oracle/lfq.py):
+ *   aux = w_e (mean_i H(prob_i) - gamma H(mean_i prob_i)) + w_c mean (z - sign(z) scale)^2,  prob_i = softmax over the 2^cd sign codes of
+ *   2 T <z_i, code>,  H(p) = sum -p log(max(p, 1e-5)),  z = proj (M, cd) = project_in(x).
+ * The (M, 2^cd) probability matrix is never formed: prob_i(u, v) = a_i[u] b_i[v] over the high / low halves of the bits (hi = ceil(cd / 2),
+ * lo = cd / 2; code index = sum_k bit_k 2^(cd-1-k), MSB first as the module's `mask`; alpha = 4 T scale; 2 <= cd <= 16).
+ *   pk_lfq_aux_prep:     A (M, 2^hi), B (M, 2^lo) factor rows; ent[i] = H(prob_i); commit[i] = sum_k (z_ik - sign(z_ik) scale)^2
+ *   (host: Q = A^T B by pk_bmm = M times the batch distribution)
+ *   pk_lfq_aux_codebook: hc_part[pk_lfq_aux_parts(cd)] = partial sums of H(Q inv_n); G = coef * dH/dq at q = Q inv_n  (2^hi x 2^lo)
+ *   (host: GA = B G^T, GB = A G by pk_bmm)
+ *   pk_lfq_aux_grad:     dproj (M, cd) = d aux / d z  with wen = w_e / M, wc2 = 2 w_c / (M cd), coef above = -w_e gamma / M
+ *   pk_lfq_aux_finish:   out[0] = aux, out[1] = mean_i H(prob_i), out[2] = H(batch distribution), out[3] = commitment (fixed summation order). */
+int pk_lfq_aux_parts(int cd);
+int pk_lfq_aux_prep(const float* proj, int M, int cd, float alpha, float scale, float* A, float* B, float* ent, float* commit, void* stream);
+int pk_lfq_aux_codebook(const float* Q, int cd, float inv_n, float coef, float* G, float* hc_part, void* stream);
+int pk_lfq_aux_grad(const float* proj, const float* GA, const float* GB, int M, int cd, float alpha, float scale, float wen, float wc2,
+                    float* dproj, void* stream);
+int pk_lfq_aux_finish(const float* ent, const float* commit, int M, const float* hc_part, int cd, float w_e, float gamma, float w_c, float* out,
+                      void* stream);
+
 /* Text-encoder support (reference t5.py:64-103 calls HuggingFace T5EncoderModel; the T5 v1.1 encoder layers are built
  * from pk_gemm, pk_attn_prep with q_scale = k_scale = NULL (plain dot-product attention: no l2norm, q * scale), pk_attn_fwd and these two):
  * pk_rmsnorm: T5LayerNorm, y = x * rsqrt(mean(x^2) + eps) * w (f32 statistics, no mean subtraction, no bias); rows with rowmask[row] == 0

@@ -68,8 +68,12 @@ def discr_loss(sd, cfg, video, frame, apply_grad_penalty=True):
 
 
 def generator_loss(sd, cfg, video, frame, vgg, mask=None, parts=None):
-    """CViViT.forward(video) with use_vgg_and_gan=True, cvivit.py:585-671: recon + perceptual + adaptive_weight * gen  (vq_aux_loss = 0, oracle/lfq.py)"""
-    recon = O.cvivit_reconstruct_train(sd, cfg, video)
+    """CViViT.forward(video) with use_vgg_and_gan=True, cvivit.py:585-671: recon + perceptual + vq_aux + adaptive_weight * gen
+    (vq_aux: the LFQ's training-mode entropy + commitment loss with the published defaults, oracle/lfq.py lfq_aux_loss; cfg['lfq_kwargs'] overrides)"""
+    from oracle import lfq
+    recon, proj = O.cvivit_reconstruct_train(sd, cfg, video, return_proj=True)
+    bd = {}
+    vq_aux = lfq.lfq_aux_loss(proj, breakdown=bd, **cfg.get('lfq_kwargs', {}))
     recon_loss = O._masked_mse(video, recon, mask)
     real_img, recon_img = pick_video_frame(video, frame), pick_video_frame(recon, frame)
     perceptual = F.mse_loss(vgg(real_img), vgg(recon_img))
@@ -79,5 +83,6 @@ def generator_loss(sd, cfg, video, frame, vgg, mask=None, parts=None):
     n_per = torch.autograd.grad(perceptual, last, retain_graph=True)[0].detach().norm(p=2)
     adaptive = (n_per / (n_gen + 1e-8)).clamp(max=1e4)
     if parts is not None:
-        parts.update(recon_loss=recon_loss.detach(), perceptual=perceptual.detach(), gen_loss=gen.detach(), adaptive_weight=adaptive.detach())
-    return recon_loss + perceptual + adaptive * gen
+        parts.update(recon_loss=recon_loss.detach(), perceptual=perceptual.detach(), gen_loss=gen.detach(), adaptive_weight=adaptive.detach(),
+                     vq_aux=vq_aux.detach(), **bd)
+    return recon_loss + perceptual + vq_aux + adaptive * gen

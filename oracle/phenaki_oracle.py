@@ -374,9 +374,10 @@ def cvivit_recon_loss(sd, cfg, video, mask=None):
     return el[mask[:, None, :].expand(-1, video.shape[1], -1)].mean()
 
 
-def cvivit_reconstruct_train(sd, cfg, video):
+def cvivit_reconstruct_train(sd, cfg, video, return_proj=False):
     """video -> reconstruction with the module in training mode (differentiable): the LFQ output is the straight-through
-    `proj + (sign(proj) - proj).detach()` of oracle/lfq.py, everything else as cvivit.py:518-583.  Autograd over the tensors of `sd`."""
+    `proj + (sign(proj) - proj).detach()` of oracle/lfq.py, everything else as cvivit.py:518-583.  Autograd over the tensors of `sd`.
+    return_proj: also the pre-sign projection (b, n, cd) the quantizer's auxiliary loss is taken on (oracle/lfq.py lfq_aux_loss)."""
     tokens = cvivit_patch_embed(sd, cfg, video)
     tokens = cvivit_encode(sd, cfg, tokens)
     b, t, h, w, d = tokens.shape
@@ -384,7 +385,8 @@ def cvivit_reconstruct_train(sd, cfg, video):
     q = torch.where(proj > 0, torch.ones_like(proj), -torch.ones_like(proj))
     q = proj + (q - proj).detach()
     codes = q @ sd['vq.project_out.weight'].t() + sd['vq.project_out.bias']
-    return cvivit_decode(sd, cfg, codes)
+    recon = cvivit_decode(sd, cfg, codes)
+    return (recon, proj) if return_proj else recon
 
 
 def _masked_mse(video, recon, mask):

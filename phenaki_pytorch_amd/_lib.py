@@ -44,6 +44,11 @@ SIGNATURES = {
     'pk_peg': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'pk_lfq_encode': [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P],
     'pk_lfq_decode': [_P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _P],
+    'pk_lfq_aux_parts': [_I],
+    'pk_lfq_aux_prep': [_P, _I, _I, _F, _F, _P, _P, _P, _P, _P],
+    'pk_lfq_aux_codebook': [_P, _I, _F, _F, _P, _P, _P],
+    'pk_lfq_aux_grad': [_P, _P, _P, _I, _I, _F, _F, _F, _F, _P, _P],
+    'pk_lfq_aux_finish': [_P, _P, _I, _P, _I, _F, _F, _F, _P, _P],
     'pk_layernorm_lfq': [_P, _I, _P, _P, _F, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     'pk_embed': [_P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _P],
     'pk_cpb_input': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -315,6 +320,31 @@ def lfq_decode(ids, wo, bo, out, M, D, cd, *, ids_prime=None, perm=(0, 0)):
     rc = load().pk_lfq_decode(ptr(ids), f32p(wo, 'LFQ project_out.weight'), f32p(bo, 'LFQ project_out.bias'), ptr(out), M, D, cd,
                               ptr(ids_prime), n_prime, n, perm[0], perm[1], stream(out))
     _check(rc, 'pk_lfq_decode')
+
+
+def lfq_aux(proj, *, inv_temperature=100., codebook_scale=1., entropy_loss_weight=0.1, commitment_loss_weight=0.25, diversity_gamma=1.):
+    """training-mode auxiliary loss of the LFQ for proj (M, cd) f32 = project_in(x) (the header's pk_lfq_aux_* group):
+    returns (out (4,) f32 = [aux, per-sample entropy, codebook entropy, commitment], dproj (M, cd) = d aux / d proj)."""
+    lib = load()
+    M, cd = proj.shape
+    dev = proj.device
+    hi, lo = (cd + 1) // 2, cd // 2
+    NA, NB = 1 << hi, 1 << lo
+    f32 = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+    A, B, ent, commit = f32(M, NA), f32(M, NB), f32(M), f32(M)
+    alpha = 4. * float(inv_temperature) * float(codebook_scale)
+    st = stream(proj)
+    _check(lib.pk_lfq_aux_prep(f32p(proj, 'LFQ projection'), M, cd, alpha, float(codebook_scale), ptr(A), ptr(B), ptr(ent), ptr(commit), st), 'pk_lfq_aux_prep')
+    Q = bmm(A, B, f32(NA, NB), True, False, 1, NA, NB, M, lda=NA, ldb=NB, ldc=NB)                       # A^T B = M x the batch distribution
+    G, hc = f32(NA, NB), f32(lib.pk_lfq_aux_parts(cd))
+    w_e, w_c, gamma = float(entropy_loss_weight), float(commitment_loss_weight), float(diversity_gamma)
+    _check(lib.pk_lfq_aux_codebook(ptr(Q), cd, 1. / M, -w_e * gamma / M, ptr(G), ptr(hc), st), 'pk_lfq_aux_codebook')
+    GA = bmm(B, G, f32(M, NA), False, True, 1, M, NA, NB, lda=NB, ldb=NB, ldc=NA)                      # B G^T
+    GB = bmm(A, G, f32(M, NB), False, False, 1, M, NB, NA, lda=NA, ldb=NB, ldc=NB)                     # A G
+    dproj, out = f32(M, cd), f32(4)
+    _check(lib.pk_lfq_aux_grad(ptr(proj), ptr(GA), ptr(GB), M, cd, alpha, float(codebook_scale), w_e / M, 2. * w_c / (M * cd), ptr(dproj), st), 'pk_lfq_aux_grad')
+    _check(lib.pk_lfq_aux_finish(ptr(ent), ptr(commit), M, ptr(hc), cd, w_e, gamma, w_c, ptr(out), st), 'pk_lfq_aux_finish')
+    return out, dproj
 
 
 def embed(ids, tok, pos, out, S, n, D, *, nb=None, ids_prime=None, out_t=None):

@@ -14,8 +14,11 @@ from . import _lib as L
 
 
 class LFQ(nn.Module):
-    def __init__(self, *, dim, codebook_size, codebook_scale=1.0, **_unused):
+    def __init__(self, *, dim, codebook_size, codebook_scale=1.0, entropy_loss_weight=0.1, commitment_loss_weight=0.25, diversity_gamma=1.,
+                 **_unused):
+        """the keyword arguments are the published module's (they arrive through CViViT(lookup_free_quantization_kwargs=...), cvivit.py:319)"""
         super().__init__()
+        self.entropy_loss_weight, self.commitment_loss_weight, self.diversity_gamma = entropy_loss_weight, commitment_loss_weight, diversity_gamma
         cd = int(math.log2(codebook_size))
         assert 2 ** cd == codebook_size, 'codebook size must be a power of two'
         assert dim != cd, 'the MI355X build expects dim != log2(codebook_size) (projections present)'
@@ -64,10 +67,24 @@ class LFQ(nn.Module):
             codes = codes.movedim(-1, 1)
         return codes
 
-    def forward(self, x, **_unused):
-        """(b, n, dim) -> (quantized (b, n, dim), indices (b, n) int64, aux_loss 0)  [eval semantics]"""
+    def aux_config(self, inv_temperature=100.):
+        """keyword arguments of _lib.lfq_aux for this module (published forward default inv_temperature = 100)"""
+        return dict(inv_temperature=inv_temperature, codebook_scale=self.codebook_scale, entropy_loss_weight=self.entropy_loss_weight,
+                    commitment_loss_weight=self.commitment_loss_weight, diversity_gamma=self.diversity_gamma)
+
+    def forward(self, x, inv_temperature=100., **_unused):
+        """(b, n, dim) -> (quantized (b, n, dim), indices (b, n) int64, aux_loss).  Eval mode (or grad mode off): the hard codes and aux = 0, as
+        the published module in eval().  Training mode under grad: the straight-through output and the entropy + commitment auxiliary loss,
+        both differentiable (train_cvivit._LFQFn, pk_lfq_aux_*)."""
         b, n, d = x.shape
         x2 = x.reshape(b * n, d).float().contiguous()
+        if self.training and torch.is_grad_enabled():
+            from .train_cvivit import _LFQFn
+            q, aux, _ = _LFQFn.apply(x2, self.project_in.weight, self.project_in.bias, self.project_out.weight, self.project_out.bias,
+                                     self.aux_config(inv_temperature))
+            with torch.no_grad():
+                ids = self.encode_ids(x2.detach())
+            return q.reshape(b, n, d), ids.reshape(b, n), aux
         ids = self.encode_ids(x2)
         q = self.codes_2d(ids)
         return q.reshape(b, n, d), ids.reshape(b, n), torch.zeros((), device=x.device)

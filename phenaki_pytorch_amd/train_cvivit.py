@@ -161,10 +161,12 @@ class _PatchEmbedFn(torch.autograd.Function):
 class _LFQFn(torch.autograd.Function):
     """project_out(sign(project_in(x))) with the straight-through gradient of the published LFQ (`x + (quantized - x).detach()` in
     training mode; vector_quantize_pytorch, call site cvivit.py:570): d project_in(x) = d quantized.  The projection that decides the
-    sign is the exact-f32 kernel of the inference path (pk_lfq_encode), so the codes of a training step are the ids the tokenizer emits."""
+    sign is the exact-f32 kernel of the inference path (pk_lfq_encode), so the codes of a training step are the ids the tokenizer emits.
+    aux_cfg (dict or None): also return the module's training-mode auxiliary loss (entropy + commitment terms on project_in(x), the third
+    return of `self.vq`, cvivit.py:570 -> :666) -- value and d aux / d project_in(x) come out of the pk_lfq_aux_* kernels in the forward pass."""
 
     @staticmethod
-    def forward(ctx, x, Wp, bp, Wo, bo):
+    def forward(ctx, x, Wp, bp, Wo, bo, aux_cfg=None):
         M, D = x.shape
         cd = Wp.shape[0]
         dev = x.device
@@ -174,21 +176,30 @@ class _LFQFn(torch.autograd.Function):
         q = L.sign(proj, _f32((M, cd), dev))
         y = _f32((M, D), dev)
         L.lfq_decode(ids, Wo.detach(), bo.detach(), y, M, D, cd)
-        ctx.save_for_backward(x, Wp, Wo, q)
-        return y
+        if aux_cfg is None:
+            ctx.has_aux = False
+            ctx.save_for_backward(x, Wp, Wo, q)
+            return y
+        out, dproj = L.lfq_aux(proj, **aux_cfg)
+        ctx.has_aux = True
+        ctx.save_for_backward(x, Wp, Wo, q, dproj)
+        ctx.mark_non_differentiable(out)
+        return y, out[0].clone(), out
 
     @staticmethod
-    def backward(ctx, dy):
-        x, Wp, Wo, q = ctx.saved_tensors
+    def backward(ctx, dy, daux=None, _dparts=None):
+        x, Wp, Wo, q = ctx.saved_tensors[:4]
         M, D = x.shape
         cd = Wp.shape[0]
         dev = x.device
         dy = dy.contiguous()
         dq, dWo = linear_bwd(L.F32, q, Wo.detach(), dy)                 # (M, cd), (D, cd)
         dbo = L.colsum(dy, M, D, _f32((D,), dev))
+        if ctx.has_aux and daux is not None:
+            dq = torch.addcmul(dq, ctx.saved_tensors[4], daux.reshape(1, 1).float())      # + d loss / d aux * d aux / d proj
         dx, dWp = linear_bwd(L.F32, x, Wp.detach(), dq)                 # straight through the sign: d proj = d q
         dbp = L.colsum(dq, M, cd, _f32((cd,), dev))
-        return dx, dWp, dbp, dWo, dbo
+        return dx, dWp, dbp, dWo, dbo, None
 
 
 class _PatchMSE(torch.autograd.Function):
@@ -334,7 +345,12 @@ def cvivit_loss_train(cv, video, *, mask=None, return_recons=False):
     x = transformer_train(cv.enc_temporal_transformer, x, b * hw, T, dt, video_shape=(b, T, h, w))
     # quantize (row-wise: the token order does not matter), then decode: temporal, then spatial (cvivit.py:476-516)
     vq = cv.vq
-    x = _LFQFn.apply(x, vq.project_in.weight, vq.project_in.bias, vq.project_out.weight, vq.project_out.bias)
+    vq_aux = None
+    if cv.use_vgg_and_gan and hasattr(vq, 'aux_config'):
+        # the generator objective adds the quantizer's auxiliary loss (cvivit.py:570, :666); the reconstruction-only objective never reads it
+        x, vq_aux, _ = _LFQFn.apply(x, vq.project_in.weight, vq.project_in.bias, vq.project_out.weight, vq.project_out.bias, vq.aux_config())
+    else:
+        x = _LFQFn.apply(x, vq.project_in.weight, vq.project_in.bias, vq.project_out.weight, vq.project_out.bias)
     x = transformer_train(cv.dec_temporal_transformer, x, b * hw, T, dt, video_shape=(b, T, h, w))
     x = _GatherRows.apply(x, to_spatial, to_temporal)                                 # rows '(b t) (h w)'
     x = transformer_train(cv.dec_spatial_transformer, x, b * T, hw, dt, attn_bias=bias)
@@ -369,9 +385,11 @@ def cvivit_loss_train(cv, video, *, mask=None, return_recons=False):
         else:
             # a 4-D image batch never reaches to_pixels (only to_pixels_first_frame): both gradient norms are 0 -> safe_div gives 0
             adaptive = torch.zeros((), device=dev)
-        # vq_aux_loss (cvivit.py:667) is the third return of self.vq: 0 for the LFQ of quantize.py (the entropy / commitment terms of the
-        # un-vendored vector-quantize-pytorch are not restated)
+        # cvivit.py:666: loss = recon_loss + perceptual_loss + vq_aux_loss + adaptive_weight * gen_loss (vq_aux_loss: the LFQ's entropy +
+        # commitment terms, pk_lfq_aux_*; 0 for the cosine-sim VectorQuantize at inference semantics)
         loss = loss + perceptual + adaptive * gen_loss
+        if vq_aux is not None:
+            loss = loss + vq_aux
     if not return_recons:
         return loss
     if recon is None:

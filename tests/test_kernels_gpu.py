@@ -227,6 +227,64 @@ def test_lfq_encode_decode(L):
     close(out, O.lfq_codes(sd, ids_ref), 1e-5, 'lfq codes')
 
 
+@pytest.mark.parametrize('M,cd,spread', [(40, 8, 0.02), (300, 16, 0.004), (300, 16, 1.0), (129, 5, 0.01), (64, 2, 0.05), (2000, 12, 0.006)])
+def test_lfq_aux_loss_and_gradient_match_oracle(L, M, cd, spread):
+    """the LFQ's training-mode auxiliary loss (cvivit.py:570 -> :666; oracle/lfq.py restates the published LFQ.forward, materialising the
+    (M, 2^cd) probabilities) from the factorised pk_lfq_aux_* kernels: value, its three parts, and d aux / d project_in(x) against autograd.
+    spread: scale of the projections -- ~0.005 keeps alpha z = 400 z around 1 (soft probabilities, the batch-entropy term active), 1.0 saturates
+    every bit (probabilities one-hot, everything below the 1e-5 clamp)."""
+    from oracle import lfq
+    g = torch.Generator().manual_seed(100 * cd + M)
+    z = (torch.randn(M, cd, generator=g) * spread).requires_grad_()
+    kw = dict(entropy_loss_weight=0.1, commitment_loss_weight=0.25, diversity_gamma=1.)
+    bd = {}
+    with torch.enable_grad():
+        ref = lfq.lfq_aux_loss(z, breakdown=bd, **kw)
+        ref.backward()
+    out, dz = L.lfq_aux(z.detach().cuda(), **kw)
+    out = out.cpu()
+    parts = torch.stack([ref.detach(), bd['per_sample_entropy'], bd['codebook_entropy'], bd['commitment']])
+    assert (out - parts).abs().max() <= 2e-5 * parts.abs().max(), (out, parts)
+    close(dz, z.grad, 2e-4, f'd aux / d proj (M={M}, cd={cd}, spread={spread})')
+    # other weights, temperature and scale of the published signature
+    kw2 = dict(entropy_loss_weight=0.3, commitment_loss_weight=1.0, diversity_gamma=2.5, inv_temperature=10.)
+    z2 = z.detach().clone().requires_grad_()
+    with torch.enable_grad():
+        ref2 = lfq.lfq_aux_loss(z2, **kw2)
+        ref2.backward()
+    out2, dz2 = L.lfq_aux(z2.detach().cuda(), **kw2)
+    assert abs(float(out2[0]) - float(ref2)) <= 2e-5 * max(1., abs(float(ref2)))
+    close(dz2, z2.grad, 2e-4, 'd aux / d proj, non-default weights')
+
+
+def test_lfq_module_training_forward_returns_the_auxiliary_loss():
+    """quantize.LFQ.forward in training mode under grad = the published module's: straight-through codes, ids, differentiable aux (eval: aux = 0)"""
+    import phenaki_pytorch_amd as P
+    from phenaki_pytorch_amd.quantize import LFQ
+    from oracle import lfq
+    torch.manual_seed(3)
+    m = LFQ(dim=64, codebook_size=256, entropy_loss_weight=0.2, diversity_gamma=1.5).cuda()
+    ref = lfq.LFQ(dim=64, codebook_size=256, entropy_loss_weight=0.2, diversity_gamma=1.5)
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    x = (torch.randn(2, 50, 64) * 0.05)
+    xr = x.clone().requires_grad_()
+    xg = x.cuda().requires_grad_()
+    with torch.enable_grad():
+        q, ids, aux = m.train()(xg)
+        qr, idsr, auxr = ref.train()(xr)
+        (q.square().mean() + 3. * aux).backward()
+        (qr.square().mean() + 3. * auxr).backward()
+    assert torch.equal(ids.cpu(), idsr)
+    close(q, qr, 1e-5, 'straight-through codes')
+    assert abs(float(aux) - float(auxr)) <= 2e-5 * max(1., abs(float(auxr)))
+    close(xg.grad, xr.grad, 5e-4, 'd / d x through project_in (codes + aux)')
+    for (k, a), (_, b) in zip(m.named_parameters(), ref.named_parameters()):
+        close(a.grad, b.grad, 5e-4, f'd {k}')
+    with torch.no_grad():
+        q0, ids0, aux0 = m.eval()(x.cuda())
+    assert float(aux0) == 0. and torch.equal(ids0.cpu(), idsr)
+
+
 @pytest.mark.parametrize('M,D,cd', [(4608, 512, 16), (5, 128, 8), (333, 96, 10), (100, 512, 12)])
 def test_lfq_decode_shapes(L, M, D, cd):
     """the register-resident outer-product kernel (cd 8 / 16, D/4 dividing 256) and the generic fallback"""

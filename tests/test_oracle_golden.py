@@ -440,7 +440,9 @@ def test_gan_branch_oracle_matches_reference(golden_dir):
             loss = G.generator_loss(sd, cvc, video, g[f'frame_{name}'], vgg, mask=m)
             loss.backward()
         assert abs(float(loss) - float(g[f'loss_{name}'])) <= 1e-5 * abs(float(g[f'loss_{name}'])), name
-        cvivit_grad_check(lambda k: sd[k].grad, g[f'grads_{name}'], 2e-4, 140)
+        # 5e-4 (the discriminator step above holds 2e-4): the objective now carries the LFQ's entropy term, whose logits are 400 x the
+        # projection (alpha = 4 * inv_temperature = 400) -- the encoder's f32 summation-order differences reach the small gradients amplified
+        cvivit_grad_check(lambda k: sd[k].grad, g[f'grads_{name}'], 5e-4, 140)
 
 
 @pytest.mark.parametrize('tag', ['tiny', 'base'])
