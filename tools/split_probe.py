@@ -77,7 +77,7 @@ for M in (4608, 9216):
 
     print(f'# M = {M} rows; FF1 = {M} x {2 * ip} x 512 {"LayerNorm-folded" if fold else "plain"} + GEGLU, FF2 = {M} x 512 x {ip} + residual + bf16 copy, to_out = {M} x 512 x 512')
     ref = hm.clone()
-    for name, fn, variants in (('ff1', ff1, (24, 8) if fold else (24, 9, 27, 8)), ('ff2', ff2, (8, 27, 33, 24)), ('to_out', tout, (8, 27, 24))):
+    for name, fn, variants in (('ff1', ff1, (24, 8) if fold else (24, 40, 9, 27, 8)), ('ff2', ff2, (8, 27, 33, 24)), ('to_out', tout, (8, 27, 24))):
         base = None
         for v in variants:
             try:
@@ -104,3 +104,23 @@ for M in (4608, 9216):
             us = timed(lambda: (fn(0, r, big), fn(r, M, big)))
             print(f'{name:7s} two launches of 128^2 split at row {r} (control: the cost of a second launch)   {us:7.2f} us')
     torch.cuda.synchronize()
+
+
+# ---- the ping-pong 256 x 128 loop (variant 40) against the 128 x 128 loop (24) on the big-N shapes of the hot path, plain bf16 products (no epilogue
+# extras) and FF1 + GEGLU; us per call and TFLOP/s
+print()
+print('# variant 40 (ping-pong 256x128, persistent) vs 24 (128x128, 2 workgroups per CU): M x N x K, us, TFLOP/s')
+for (M, N, K, act) in ((9216, 2736, 512, 1), (4608, 2736, 512, 1), (18432, 2736, 512, 1), (36864, 2736, 512, 1), (4608, 6144, 512, 0), (9216, 512, 1368, 0),
+                       (9216, 1536, 512, 0), (4608, 65536, 512, 0), (8192, 8192, 8192, 0)):
+    A = torch.randn(M, K, device='cuda').to(torch.bfloat16)
+    Kp = (K + 63) // 64 * 64
+    W = torch.zeros(N, Kp, device='cuda', dtype=torch.bfloat16)
+    W[:, :K] = (torch.randn(N, K, device='cuda') / K ** 0.5).to(torch.bfloat16)
+    C = torch.empty(M, N // 2 if act else N, device='cuda', dtype=torch.bfloat16)
+    row = f'{M:6d} x {N:6d} x {K:5d} {"GEGLU" if act else "plain"}:'
+    for v in (24, 40):
+        for wgs in ((None,) if v == 24 else (None,)):
+            us = timed(lambda: L.gemm(dt, A, W, M, N, K, C=C, act=L.ACT_GEGLU if act else L.ACT_NONE, variant=v))
+            row += f'   v{v} {us:8.2f} us {2 * M * N * K / us / 1e6:7.1f} TF'
+    print(row, flush=True)
+    del A, W, C
