@@ -408,7 +408,9 @@ def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this bench's encode leg (counters need their
     own rocprofv3 runs -- they cannot be collected from inside this process): profiles/pmc_traffic_rNN.json (latest round), written by
     tools/pmc_traffic.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 read correction."""
-    path = next((q for q in (os.path.join(ROOT, 'profiles', f'pmc_traffic_r{r:02d}.json') for r in (3, 2)) if os.path.exists(q)), None)
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'pmc_traffic_r[0-9][0-9].json')))       # the NEWEST round's passes
+    path = found[-1] if found else None
     if path is None:
         return None, None
     try:
@@ -729,7 +731,7 @@ def bench_cvivit_train_step(args, ws, mode):
     out = dict(metric='cvivit_train_step_frames_per_sec', value=B * 17 * ws / dt, unit='frames/s', ms_per_step=dt * 1e3, dtype=mode, batch_per_gpu=B,
                frames_per_video=17, trained_parameters=sum(p.numel() for p in params), loss_first=float(losses[0]), loss_last=float(losses[-1]),
                peak_memory_gb=torch.cuda.max_memory_allocated() / 2 ** 30, optimizer='AdamW (pk_adamw), lr 1e-4',
-               note='forward + backward + optimizer step of the tokenizer on the reconstruction loss (use_vgg_and_gan = False); the GAN / VGG terms are not built')
+               note='forward + backward + optimizer step of the tokenizer on the reconstruction loss (use_vgg_and_gan = False); the GAN objective is the cvivit_gan_step leg')
     del cv, opt
     torch.cuda.empty_cache()
     return out

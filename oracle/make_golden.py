@@ -599,14 +599,26 @@ def gan_golden(R, cfgs, tag, batch=2, frames=5):
     with torch.no_grad():
         out['hinge_discr'] = R.cvivit.hinge_discr_loss(cv.discr(fake), cv.discr(real)).clone()
     # (3) generator step, (4) with a frame mask
+    # the adaptive weight (cvivit.py:657-664) is the one scalar that scales every tokenizer gradient of the generator term: record its two gradient
+    # norms by wrapping the reference module's OWN safe_div (a module global; restored below) -- the parity tests pin it separately
+    seen = {}
+    orig_safe_div = R.cvivit.safe_div
+
+    def recording_safe_div(numer, denom, eps=1e-8):
+        seen['n_per'], seen['n_gen'] = numer.detach().clone(), denom.detach().clone()
+        return orig_safe_div(numer, denom, eps)
+    R.cvivit.safe_div = recording_safe_div
     for name, m, seed in (('gen', None, 22), ('gen_masked', mask, 23)):
         out[f'frame_{name}'] = frames_for(seed, m)
         cv.zero_grad(set_to_none=True)
         torch.manual_seed(seed)
         loss = cv(video, mask=m) if m is not None else cv(video)
         loss.backward()
+        out[f'parts_{name}'] = dict(norm_grad_perceptual=seen['n_per'], norm_grad_gen=seen['n_gen'],
+                                    adaptive_weight=(seen['n_per'] / (seen['n_gen'] + 1e-8)).clamp(max=1e4))
         out[f'loss_{name}'] = loss.detach().clone()
         out[f'grads_{name}'] = _grad_summary(cv)
+    R.cvivit.safe_div = orig_safe_div
     torch.save(out, os.path.join(OUT, f'gan_{tag}.pt'))
     print(f'gan_{tag}: discr loss {float(out["loss_discr"]):.6f} (hinge {float(out["hinge_discr"]):.6f}, {len(out["grads_discr"])} gradients), '
           f'generator loss {float(out["loss_gen"]):.6f} ({len(out["grads_gen"])} gradients), masked {float(out["loss_gen_masked"]):.6f}; '

@@ -381,7 +381,13 @@ def cvivit_loss_train(cv, video, *, mask=None, return_recons=False):
             last = lin_rest.weight                                                    # self.to_pixels[0].weight (cvivit.py:657)
             g_gen, = torch.autograd.grad(gen_loss, last, retain_graph=True)
             g_per, = torch.autograd.grad(perceptual, last, retain_graph=True)
-            adaptive = (g_per.detach().norm(p=2) / (g_gen.detach().norm(p=2) + 1e-8)).clamp_(max=1e4)
+            n_per, n_gen = g_per.detach().norm(p=2), g_gen.detach().norm(p=2)
+            adaptive = (n_per / (n_gen + 1e-8)).clamp_(max=1e4)
+            parts = cv.__dict__.get('_pk_loss_parts')
+            if isinstance(parts, dict):              # tests: the terms of the objective, so the adaptive weight is pinned by itself (cvivit.py:657-664)
+                parts.update(recon_loss=loss.detach().clone(), perceptual=perceptual.detach().clone(), gen_loss=gen_loss.detach().clone(),
+                             norm_grad_perceptual=n_per.clone(), norm_grad_gen=n_gen.clone(), adaptive_weight=adaptive.detach().clone(),
+                             vq_aux=None if vq_aux is None else vq_aux.detach().clone())
         else:
             # a 4-D image batch never reaches to_pixels (only to_pixels_first_frame): both gradient norms are 0 -> safe_div gives 0
             adaptive = torch.zeros((), device=dev)

@@ -294,9 +294,19 @@ def test_generator_gan_step_matches_reference(golden_dir, dtype, tol, kind):
     H = TINY['cvivit']['image_size']
     video = weights.synthetic_video(2, 5, H, H, seed=12).cuda()
     torch.manual_seed(22 if kind == 'gen' else 23)
+    parts = cv.__dict__['_pk_loss_parts'] = {}
     loss = cv(video, mask=g['mask'].cuda()) if kind == 'gen_masked' else cv(video)
     loss.backward()
     ref = float(g[f'loss_{kind}'])
+    # the adaptive weight (cvivit.py:657-664) is ONE scalar in front of every tokenizer gradient of the generator term -- pinned by
+    # itself, with its two gradient norms, against the values the reference's own safe_div saw (oracle/make_golden.py)
+    pg = g[f'parts_{kind}']
+    rel = {k: abs(float(parts[k]) - float(pg[k])) / abs(float(pg[k])) for k in ('norm_grad_perceptual', 'norm_grad_gen', 'adaptive_weight')}
+    record_parity('generator_gan_step_adaptive_weight', dict(dtype=dtype, kind=kind, **{k: float(parts[k]) for k in rel}, rel_err=rel,
+                                                             vq_aux=None if parts.get('vq_aux') is None else float(parts['vq_aux'])))
+    if tol is not None:
+        atol = 1e-4 if dtype == 'fp32' else 2e-3
+        assert rel['norm_grad_perceptual'] <= atol and rel['norm_grad_gen'] <= atol and rel['adaptive_weight'] <= atol, (dtype, kind, rel)
     named = dict(cv.named_parameters())
     grads = {k: v for k, v in g[f'grads_{kind}'].items() if v['norm'] > 0}
     if tol is None:
