@@ -546,6 +546,7 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
             case 9: return launch_dma<bf16x3, 4, 4, 2>(p, e, a_nrows, s);
             case 24: return launch_dma<bf16x3, 4, 2, 2, 2, 4>(p, e, a_nrows, s);
             case 27: return launch_dma<bf16x3, 4, 2, 2, 2, 2>(p, e, a_nrows, s);
+            case 40: return launch_pp<bf16x3>(p, e, a_nrows, s);                        // 256x128 ping-pong (k-tiles of 32: f32 rows / split W planes)
             default: return PK_EINVAL;
         }
     }
