@@ -289,10 +289,10 @@ void gemm_dma_kernel(const GemmOperands p, const GemmEpilogue e, int a_nrows) {
 // of the XCD-aware order (grid is a multiple of 8, so a workgroup stays on "its" XCD's chunk of row tiles), and issues the first two k-tiles of
 // its next tile before the epilogue of the current one.  Plain epilogues (bias / residual / GEGLU / LeakyReLU / bf16 copy / scatter); no LayerNorm
 // fold and no stats_out (those ride on the TN = 2 kernels).
-template <typename T>
+template <typename T, int PC>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm_pp_kernel(const GemmOperands p, const GemmEpilogue e, int a_nrows) {
-    using Tile = GemmPP<T, 4, 4, 4, 2>;
+    using Tile = GemmPP<T, 4, 4, 4, 2, PC>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int MT = (p.M + Tile::BM - 1) / Tile::BM, cmax = (MT + 7) / 8, NTn = (p.N + Tile::BN - 1) / Tile::BN;
     const int nt = (p.K + Tile::BK - 1) / Tile::BK;
@@ -332,14 +332,14 @@ void gemm_pp_kernel(const GemmOperands p, const GemmEpilogue e, int a_nrows) {
     }
 }
 
-template <typename T>
+template <typename T, int PC = 0>
 static int launch_pp(const GemmOperands& p, const GemmEpilogue& e, int a_nrows, hipStream_t s) {
-    using Tile = GemmPP<T, 4, 4, 4, 2>;
+    using Tile = GemmPP<T, 4, 4, 4, 2, PC>;
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PK_ELAUNCH;
     if (!attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, Tile::SMEM) != hipSuccess) return PK_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<T, PC>), hipFuncAttributeMaxDynamicSharedMemorySize, Tile::SMEM) != hipSuccess) return PK_ELAUNCH;
         attr_set[dev] = true;
     }
     const int MT = (p.M + Tile::BM - 1) / Tile::BM, NT = (p.N + Tile::BN - 1) / Tile::BN;
@@ -349,7 +349,7 @@ static int launch_pp(const GemmOperands& p, const GemmEpilogue& e, int a_nrows, 
     GemmOperands pp = p;
     static const int panel_env = [] { const char* e_ = getenv("PK_GEMM_PANEL"); return e_ ? atoi(e_) : -1; }();
     pp.panel = panel_env >= 0 ? panel_env : xcd_panel_rows(Tile::BM, p.K, (int)sizeof(T));
-    hipLaunchKernelGGL((gemm_pp_kernel<T>), dim3(nvb < wgs ? nvb : wgs), dim3(Tile::THREADS), Tile::SMEM, s, pp, e, a_nrows);
+    hipLaunchKernelGGL((gemm_pp_kernel<T, PC>), dim3(nvb < wgs ? nvb : wgs), dim3(Tile::THREADS), Tile::SMEM, s, pp, e, a_nrows);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }
@@ -530,7 +530,11 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
             case 24: return launch_dma<bf16, 4, 2, 2, 2, 4>(p, e, a_nrows, s);          // 128x128, 8 waves (2x4), 2 stages (64 KB: 16 waves/CU)
             case 33: return launch_dma<bf16, 2, 2, 3, 2, 2, 128, 2>(p, e, a_nrows, s);  // 64x64, 4 consumers + 2 producers, 3 stages (long K)
             case 27: return launch_dma<bf16, 4, 2, 2, 2, 2>(p, e, a_nrows, s);          // 128x64, 4 waves (wave tile 64x32), 2 stages (48 KB: 3 WG/CU)
-            case 40: return launch_pp<bf16>(p, e, a_nrows, s);                          // 256x128 ping-pong, 8 waves, 3 stages (144 KB: 1 WG/CU), persistent
+            case 40: return launch_pp<bf16, 0>(p, e, a_nrows, s);                       // 256x128 ping-pong, 8 waves, 3 stages (144 KB: 1 WG/CU), persistent
+            case 41: return launch_pp<bf16, 2>(p, e, a_nrows, s);                       // ... 2 / 3 / 4 / 6 of a wave's 6 DMA pieces issued between its MFMAs
+            case 42: return launch_pp<bf16, 3>(p, e, a_nrows, s);
+            case 43: return launch_pp<bf16, 4>(p, e, a_nrows, s);
+            case 44: return launch_pp<bf16, 6>(p, e, a_nrows, s);
             // (256x256 / 256x128 / 128x256 8-wave instantiations were measured again in round 3 against the torch.mm yardstick and removed:
             //  profiles/gemm_bigtile_r03.txt -- 552 vs 653 TFLOP/s on the vocabulary-head shape, 1081 vs 1011 at 8192^3)
             default: return PK_EINVAL;
@@ -546,7 +550,9 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
             case 9: return launch_dma<bf16x3, 4, 4, 2>(p, e, a_nrows, s);
             case 24: return launch_dma<bf16x3, 4, 2, 2, 2, 4>(p, e, a_nrows, s);
             case 27: return launch_dma<bf16x3, 4, 2, 2, 2, 2>(p, e, a_nrows, s);
-            case 40: return launch_pp<bf16x3>(p, e, a_nrows, s);                        // 256x128 ping-pong (k-tiles of 32: f32 rows / split W planes)
+            case 40: return launch_pp<bf16x3, 0>(p, e, a_nrows, s);                     // 256x128 ping-pong (k-tiles of 32: f32 rows / split W planes)
+            case 42: return launch_pp<bf16x3, 3>(p, e, a_nrows, s);
+            case 44: return launch_pp<bf16x3, 6>(p, e, a_nrows, s);
             default: return PK_EINVAL;
         }
     }

@@ -22,7 +22,7 @@
 
 namespace pk {
 
-template <typename T, int TM, int TN, int WM, int WN>
+template <typename T, int TM, int TN, int WM, int WN, int PC = 0>
 struct GemmPP {
     static constexpr int ROWB = 128, STAGES = 3;
     static constexpr int NW = WM * WN;
@@ -64,8 +64,9 @@ struct GemmPP {
         }
     }
 
-    // this wave's PPW pieces (IA of A rows, IW of W rows) of k-tile kt into ring slot `slot`
-    static __device__ __forceinline__ void issue(const GemmOperands& p, int a_nrows, const Ctx& c, int kt, int nt, int slot, char* smem) {
+    // pieces [J0, J1) of this wave's PPW pieces (0 .. IA - 1: A rows, IA .. PPW - 1: W rows) of k-tile kt into ring slot `slot`
+    // (j0 / j1 are compile-time constants at every call site: the unrolled loop folds)
+    static __device__ __forceinline__ void issue(const GemmOperands& p, int a_nrows, const Ctx& c, int kt, int nt, int slot, char* smem, int j0 = 0, int j1 = PPW) {
         const int lane = threadIdx.x & 63;
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         constexpr int SZ = (int)sizeof(T), SLOTS = ROWB / 16;
@@ -78,11 +79,11 @@ struct GemmPP {
         char* base = smem + slot * STAGE_BYTES;
         const int koff = kt * ROWB;
 #pragma unroll
-        for (int i = 0; i < IA; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(base + (wave * IA + i) * 1024), 16, cut ? bytesA : c.offA[i], koff, 0, 0);
-#pragma unroll
-        for (int i = 0; i < IW; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(base + BM * ROWB + (wave * IW + i) * 1024), 16, cut ? bytesW : c.offW[i], koff, 0, 0);
+        for (int j = 0; j < PPW; ++j) {
+            if (j < j0 || j >= j1) continue;
+            if (j < IA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(base + (wave * IA + j) * 1024), 16, cut ? bytesA : c.offA[j], koff, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(base + BM * ROWB + (wave * IW + j - IA) * 1024), 16, cut ? bytesW : c.offW[j - IA], koff, 0, 0);
+        }
     }
 
     // first k-tiles of a tile (every wave issues): called at kernel start and, for the next tile, before the current tile's epilogue
@@ -91,8 +92,12 @@ struct GemmPP {
         if (nt > 1) issue(p, a_nrows, c, 1, nt, 1, smem);
     }
 
-    static __device__ __forceinline__ void compute(const char* a, int wm, int wn, int lr, int g, f32x4 (&acc)[TM][TN]) {
+    // the wave's MFMAs on one k-tile; with PC > 0 the first PC of its DMA pieces of k-tile `kt2` are issued BETWEEN the rows of MFMAs (a piece costs
+    // ~60 cycles of issue among MFMAs the matrix pipe is still executing, 100-185 in a phase of its own: MI355X_MICROARCH.md), evenly spread
+    static __device__ __forceinline__ void compute(const GemmOperands& p, int a_nrows, const Ctx& cx, int kt2, int nt, int nslot, bool more, char* smem,
+                                                   const char* a, int wm, int wn, int lr, int g, f32x4 (&acc)[TM][TN]) {
         const char* w = a + BM * ROWB;
+        constexpr int POS = CH * TM;                                            // rows of MFMAs per k-tile
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             Frag<T> fa[TM], fw[TN];
@@ -101,10 +106,20 @@ struct GemmPP {
 #pragma unroll
             for (int j = 0; j < TN; ++j) lds_frag_w<T>(fw[j], w, wn * 16 * TN + j * 16 + lr, c, g);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = mma(fw[j], fa[i], acc[i][j]);
+                if constexpr (PC > 0) {
+#pragma unroll
+                    for (int q = 0; q < PC; ++q)
+                        if (((2 * q + 1) * POS) / (2 * PC) == c * TM + i && more) issue_one(q, p, a_nrows, cx, kt2, nt, nslot, smem);
+                }
+            }
         }
+    }
+
+    static __device__ __forceinline__ void issue_one(int q, const GemmOperands& p, int a_nrows, const Ctx& c, int kt, int nt, int slot, char* smem) {
+        issue(p, a_nrows, c, kt, nt, slot, smem, q, q + 1);
     }
 
     // main loop of one tile whose prologue() has been issued.  acc zero-initialised by the caller.  Ends with the ring dead (barrier).
@@ -126,9 +141,9 @@ struct GemmPP {
                 const bool more = kt + 2 < nt;
                 const int nslot = slot == 0 ? 2 : slot - 1;                     // (kt + 2) % 3
                 slot = slot == 2 ? 0 : slot + 1;
-                compute(a, wm, wn, lr, g, acc);                                 // phase A: this group computes, group 1 feeds the ring
+                compute(p, a_nrows, c, kt + 2, nt, nslot, more, smem, a, wm, wn, lr, g, acc);      // phase A: this group computes (+ its first PC pieces), group 1 feeds the ring
                 __builtin_amdgcn_s_barrier();
-                if (more) issue(p, a_nrows, c, kt + 2, nt, nslot, smem);        // phase B: group 1 computes, this group feeds the ring
+                if (more) issue(p, a_nrows, c, kt + 2, nt, nslot, smem, PC, PPW);                  // phase B: group 1 computes, this group feeds the ring
                 // k-tile kt + 1 must be complete before phase A(kt + 1): only this wave's pieces of kt + 2 may stay in flight
                 if (more) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();
@@ -140,9 +155,9 @@ struct GemmPP {
                 const bool more = kt + 2 < nt;
                 const int nslot = slot == 0 ? 2 : slot - 1;
                 slot = slot == 2 ? 0 : slot + 1;
-                if (more) issue(p, a_nrows, c, kt + 2, nt, nslot, smem);        // phase A
+                if (more) issue(p, a_nrows, c, kt + 2, nt, nslot, smem, PC, PPW);                  // phase A
                 __builtin_amdgcn_s_barrier();
-                compute(a, wm, wn, lr, g, acc);                                 // phase B
+                compute(p, a_nrows, c, kt + 2, nt, nslot, more, smem, a, wm, wn, lr, g, acc);      // phase B
                 if (more) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();
             }

@@ -49,7 +49,7 @@ def timed(fn):
     return statistics.median(ts[2:])
 
 
-for M in (4608, 9216):
+for M in (() if os.environ.get('PK_PROBE_SKIP_SPLIT', '0') == '1' else (4608, 9216)):
     x = torch.randn(M, D, device='cuda')
     xt = x.to(torch.bfloat16)
     o = torch.randn(M, D, device='cuda').to(torch.bfloat16)
@@ -106,21 +106,29 @@ for M in (4608, 9216):
     torch.cuda.synchronize()
 
 
-# ---- the ping-pong 256 x 128 loop (variant 40) against the 128 x 128 loop (24) on the big-N shapes of the hot path, plain bf16 products (no epilogue
-# extras) and FF1 + GEGLU; us per call and TFLOP/s
-print()
-print('# variant 40 (ping-pong 256x128, persistent) vs 24 (128x128, 2 workgroups per CU): M x N x K, us, TFLOP/s')
-for (M, N, K, act) in ((9216, 2736, 512, 1), (4608, 2736, 512, 1), (18432, 2736, 512, 1), (36864, 2736, 512, 1), (4608, 6144, 512, 0), (9216, 512, 1368, 0),
-                       (9216, 1536, 512, 0), (4608, 65536, 512, 0), (8192, 8192, 8192, 0)):
-    A = torch.randn(M, K, device='cuda').to(torch.bfloat16)
-    Kp = (K + 63) // 64 * 64
-    W = torch.zeros(N, Kp, device='cuda', dtype=torch.bfloat16)
-    W[:, :K] = (torch.randn(N, K, device='cuda') / K ** 0.5).to(torch.bfloat16)
-    C = torch.empty(M, N // 2 if act else N, device='cuda', dtype=torch.bfloat16)
-    row = f'{M:6d} x {N:6d} x {K:5d} {"GEGLU" if act else "plain"}:'
-    for v in (24, 40):
-        for wgs in ((None,) if v == 24 else (None,)):
-            us = timed(lambda: L.gemm(dt, A, W, M, N, K, C=C, act=L.ACT_GEGLU if act else L.ACT_NONE, variant=v))
-            row += f'   v{v} {us:8.2f} us {2 * M * N * K / us / 1e6:7.1f} TF'
-    print(row, flush=True)
-    del A, W, C
+# ---- the ping-pong 256 x 128 loops (variants 40-44: 0 / 2 / 3 / 4 / 6 DMA pieces of a wave issued between its MFMAs) against the 128 x 128 loops
+# (24: 8 waves, 9: 4 waves) on the big-N shapes of the hot path; bf16 and split-bf16; us per call (TFLOP/s of useful flops)
+if os.environ.get('PK_PROBE_SKIP_PP', '0') != '1':
+    print()
+    print('# ping-pong variants vs 128x128: M x N x K, us (TFLOP/s)')
+    shapes = ((9216, 2736, 512, 1), (4608, 2736, 512, 1), (18432, 2736, 512, 1), (4608, 6144, 512, 0), (9216, 1536, 512, 0), (4608, 65536, 512, 0), (8192, 8192, 4096, 0))
+    for mode, variants in (('bf16', (24, 40, 41, 42, 43, 44)), ('bf16x3', (9, 24, 40, 42, 44))):
+        for (M, N, K, act) in shapes:
+            if mode == 'bf16x3' and N * K > 40e6:
+                continue
+            A = torch.randn(M, K, device='cuda')
+            bk = 64 if mode == 'bf16' else 32
+            Kp = (K + bk - 1) // bk * bk
+            W = torch.zeros(N, Kp, device='cuda')
+            W[:, :K] = torch.randn(N, K, device='cuda') / K ** 0.5
+            if mode == 'bf16':
+                A, W, d_, ctype = A.to(torch.bfloat16), W.to(torch.bfloat16), L.BF16, torch.bfloat16
+            else:
+                W, d_, ctype = L.split_planes(W), L.BF16X3, torch.float32
+            C = torch.empty(M, N // 2 if act else N, device='cuda', dtype=ctype)
+            row = f'{mode:6s} {M:6d} x {N:6d} x {K:5d} {"GEGLU" if act else "plain"}:'
+            for v in variants:
+                us = timed(lambda: L.gemm(d_, A, W, M, N, K, C=C, act=L.ACT_GEGLU if act else L.ACT_NONE, variant=v))
+                row += f'  v{v} {us:7.2f} ({2 * M * N * K / us / 1e6:6.1f})'
+            print(row, flush=True)
+            del A, W, C
