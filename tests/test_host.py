@@ -464,6 +464,83 @@ def test_data_io_gif_roundtrip_datasets_and_collate(tmp_path):
             D.video_to_tensor(str(tmp_path / 'x.mp4'))
 
 
+class _FakeCv2:
+    """an in-memory stand-in for the two OpenCV classes the MP4 helpers use (data.py:128-181): VideoWriter keeps the uint8 (h, w, c) frames
+    it is given, VideoCapture plays them back -- a lossless "codec", so what is tested is the helpers' own frame / channel / crop logic"""
+    store = {}
+
+    @staticmethod
+    def VideoWriter_fourcc(*chars):
+        return sum(ord(c) << (8 * i) for i, c in enumerate(chars))
+
+    class VideoWriter:
+        def __init__(self, path, fourcc, fps, size):
+            self.path, self.size = path, size
+            _FakeCv2.store[path] = []
+
+        def write(self, frame):
+            assert frame.dtype.name == 'uint8' and frame.shape[:2] == (self.size[1], self.size[0])
+            _FakeCv2.store[self.path].append(frame.copy())
+
+        def release(self):
+            pass
+
+    class VideoCapture:
+        def __init__(self, path):
+            self.frames, self.i = _FakeCv2.store[path], 0
+
+        def read(self):
+            if self.i >= len(self.frames):
+                return False, None
+            self.i += 1
+            return True, self.frames[self.i - 1].copy()
+
+        def release(self):
+            pass
+
+    @staticmethod
+    def destroyAllWindows():
+        pass
+
+
+def test_mp4_helpers_match_the_reference_on_a_lossless_stand_in_codec(monkeypatch):
+    """SURVEY.md 8f row 4 (video I/O): video_to_tensor / tensor_to_video (reference data.py:128-181) go through OpenCV, which this image lacks.
+    With an in-memory cv2 stand-in both implementations -- the product's and, where /root/reference exists, the reference's own functions
+    loaded from its data.py -- write and read the same clip: identical tensors, incl. the reference's quirks (the last decoded frame is
+    dropped, `[:num_frames]` with the default -1 drops one more, crop_size crops the centre, values stay 0..255 in OpenCV's channel order)."""
+    import importlib.machinery
+    import types
+    fake = types.ModuleType('cv2')
+    fake.__spec__ = importlib.machinery.ModuleSpec('cv2', None)
+    for k in ('VideoWriter_fourcc', 'VideoWriter', 'VideoCapture', 'destroyAllWindows'):
+        setattr(fake, k, getattr(_FakeCv2, k))
+    monkeypatch.setitem(sys.modules, 'cv2', fake)
+    from phenaki_pytorch_amd import data as D
+    g = torch.Generator().manual_seed(11)
+    clip = torch.randint(0, 256, (3, 7, 24, 40), generator=g).float()
+    D.tensor_to_video(clip, 'mem://a.mp4')
+    assert len(_FakeCv2.store['mem://a.mp4']) == 7
+    full = D.video_to_tensor('mem://a.mp4', num_frames=100)
+    assert tuple(full.shape) == (3, 6, 24, 40) and torch.equal(full, clip[:, :6])                  # the final decoded frame is left out
+    assert tuple(D.video_to_tensor('mem://a.mp4').shape) == (3, 5, 24, 40)                          # default num_frames = -1: `[:, :-1]`
+    crop = D.video_to_tensor('mem://a.mp4', num_frames=4, crop_size=16)
+    assert tuple(crop.shape) == (3, 4, 16, 16) and torch.equal(crop, clip[:, :4, 4:20, 12:28])
+    ref_root = os.environ.get('PHENAKI_REFERENCE_ROOT', '/root/reference')
+    src = os.path.join(ref_root, 'phenaki_pytorch', 'data.py')
+    if os.path.exists(src):
+        # the reference's own two functions, executed from its source with the stand-in cv2 (its module-level torchvision import is not needed by them)
+        import ast
+        tree = ast.parse(open(src).read())
+        keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ('video_to_tensor', 'tensor_to_video', 'crop_center', 'exists', 'pair')]
+        ns = {}
+        exec('import cv2, torch\nimport numpy as np\nfrom einops import rearrange\n', ns)
+        exec(compile(ast.Module(body=keep, type_ignores=[]), src, 'exec'), ns)
+        ns['tensor_to_video'](clip, 'mem://ref.mp4')
+        assert all((a == b).all() for a, b in zip(_FakeCv2.store['mem://ref.mp4'], _FakeCv2.store['mem://a.mp4']))
+        for kw in (dict(), dict(num_frames=3), dict(num_frames=100, crop_size=16), dict(crop_size=(20, 10))):
+            assert torch.equal(ns['video_to_tensor']('mem://ref.mp4', **kw), D.video_to_tensor('mem://a.mp4', **kw)), kw
+
+
 def _has(mod):
     import importlib.util
     return importlib.util.find_spec(mod) is not None
