@@ -5,7 +5,6 @@
 // Two main loops share the epilogue: gemm_core.hpp (register-staged, converts f32 A on the fly) and
 // gemm_dma.hpp (LDS-DMA ring, A and W of the same type, W zero-padded along K to the k-tile).
 #include "gemm_dma.hpp"
-#include "gemm_pp.hpp"
 
 namespace pk {
 
@@ -285,75 +284,6 @@ void gemm_dma_kernel(const GemmOperands p, const GemmEpilogue e, int a_nrows) {
     }
 }
 
-// ---- the ping-pong 256 x 128 main loop (gemm_pp.hpp) as a PERSISTENT kernel: one 8-wave workgroup per CU walks the tiles vb = b, b + grid, ...
-// of the XCD-aware order (grid is a multiple of 8, so a workgroup stays on "its" XCD's chunk of row tiles), and issues the first two k-tiles of
-// its next tile before the epilogue of the current one.  Plain epilogues (bias / residual / GEGLU / LeakyReLU / bf16 copy / scatter); no LayerNorm
-// fold and no stats_out (those ride on the TN = 2 kernels).
-template <typename T, int PC>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void gemm_pp_kernel(const GemmOperands p, const GemmEpilogue e, int a_nrows) {
-    using Tile = GemmPP<T, 4, 4, 4, 2, PC>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int MT = (p.M + Tile::BM - 1) / Tile::BM, cmax = (MT + 7) / 8, NTn = (p.N + Tile::BN - 1) / Tile::BN;
-    const int nt = (p.K + Tile::BK - 1) / Tile::BK;
-    const int nvb = 8 * cmax * NTn;                              // virtual blocks of the XCD-aware map (chunk tails are empty)
-    auto decode = [&](int vb, int& m0, int& n0) -> bool {
-        const int xcd = vb & 7, idx = vb >> 3;
-        const int mstart = xcd * MT / 8, mcount = (xcd + 1) * MT / 8 - mstart;
-        int ml, ntile;
-        if (!xcd_panel_tile(idx, cmax, mcount, NTn, p.panel, ml, ntile)) return false;
-        m0 = (mstart + ml) * Tile::BM;
-        n0 = ntile * Tile::BN;
-        return true;
-    };
-    int vb = blockIdx.x, m0 = 0, n0 = 0;
-    while (vb < nvb && !decode(vb, m0, n0)) vb += gridDim.x;
-    if (vb >= nvb) return;                                       // (whole workgroup: before any barrier)
-    typename Tile::Ctx c;
-    Tile::setup(p, a_nrows, m0, n0, c);
-    Tile::prologue(p, a_nrows, c, nt, smem);
-    while (true) {
-        f32x4 acc[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-        Tile::run(p, a_nrows, c, nt, smem, acc);                 // ends with the ring dead
-        int vn = vb + gridDim.x, m1 = 0, n1 = 0;
-        while (vn < nvb && !decode(vn, m1, n1)) vn += gridDim.x;
-        const bool has_next = vn < nvb;
-        if (has_next) {                                          // the next tile's first k-tiles fly while this tile's results are stored
-            Tile::setup(p, a_nrows, m1, n1, c);
-            Tile::prologue(p, a_nrows, c, nt, smem);
-        }
-        gemm_epilogue<T, 4, 4, 2>(acc, p.M, p.N, e, m0, n0);
-        if (!has_next) break;
-        vb = vn; m0 = m1; n0 = n1;
-    }
-}
-
-template <typename T, int PC = 0>
-static int launch_pp(const GemmOperands& p, const GemmEpilogue& e, int a_nrows, hipStream_t s) {
-    using Tile = GemmPP<T, 4, 4, 4, 2, PC>;
-    static bool attr_set[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PK_ELAUNCH;
-    if (!attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<T, PC>), hipFuncAttributeMaxDynamicSharedMemorySize, Tile::SMEM) != hipSuccess) return PK_ELAUNCH;
-        attr_set[dev] = true;
-    }
-    const int MT = (p.M + Tile::BM - 1) / Tile::BM, NT = (p.N + Tile::BN - 1) / Tile::BN;
-    const int nvb = 8 * ((MT + 7) / 8) * NT;
-    static const int wgs_env = [] { const char* e_ = getenv("PK_GEMM_PP_WGS"); return e_ ? atoi(e_) : 256; }();       // tuning knob: persistent workgroups (multiple of 8)
-    const int wgs = wgs_env >= 8 ? wgs_env / 8 * 8 : 256;
-    GemmOperands pp = p;
-    static const int panel_env = [] { const char* e_ = getenv("PK_GEMM_PANEL"); return e_ ? atoi(e_) : -1; }();
-    pp.panel = panel_env >= 0 ? panel_env : xcd_panel_rows(Tile::BM, p.K, (int)sizeof(T));
-    hipLaunchKernelGGL((gemm_pp_kernel<T, PC>), dim3(nvb < wgs ? nvb : wgs), dim3(Tile::THREADS), Tile::SMEM, s, pp, e, a_nrows);
-    PK_CHECK_LAUNCH();
-    return PK_OK;
-}
-
 // split-K form of the plain LDS-DMA GEMM (training: dW = dY^T X contracts over the ROWS of the batch -- K = 4608 .. 36 864 against 64 .. 344
 // output tiles, so a single launch leaves most CUs idle): grid.y slices the contraction, slice z reads A / W from column z * Kc on and writes
 // its partial product to C + z * M * ldc; the caller adds the slices in index order (pk_sum_batch: deterministic).  A separate kernel so the
@@ -530,11 +460,8 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
             case 24: return launch_dma<bf16, 4, 2, 2, 2, 4>(p, e, a_nrows, s);          // 128x128, 8 waves (2x4), 2 stages (64 KB: 16 waves/CU)
             case 33: return launch_dma<bf16, 2, 2, 3, 2, 2, 128, 2>(p, e, a_nrows, s);  // 64x64, 4 consumers + 2 producers, 3 stages (long K)
             case 27: return launch_dma<bf16, 4, 2, 2, 2, 2>(p, e, a_nrows, s);          // 128x64, 4 waves (wave tile 64x32), 2 stages (48 KB: 3 WG/CU)
-            case 40: return launch_pp<bf16, 0>(p, e, a_nrows, s);                       // 256x128 ping-pong, 8 waves, 3 stages (144 KB: 1 WG/CU), persistent
-            case 41: return launch_pp<bf16, 2>(p, e, a_nrows, s);                       // ... 2 / 3 / 4 / 6 of a wave's 6 DMA pieces issued between its MFMAs
-            case 42: return launch_pp<bf16, 3>(p, e, a_nrows, s);
-            case 43: return launch_pp<bf16, 4>(p, e, a_nrows, s);
-            case 44: return launch_pp<bf16, 6>(p, e, a_nrows, s);
+            // (round 5: a 256x128 "ping-pong" loop -- one workgroup per CU, two 4-wave groups half an iteration apart, 3-stage 144 KB ring, persistent --
+            //  was built, measured and removed: equal to this loop at long K, 13-40 % slower at K = 512; profiles/gemm_pingpong_r05.txt)
             // (256x256 / 256x128 / 128x256 8-wave instantiations were measured again in round 3 against the torch.mm yardstick and removed:
             //  profiles/gemm_bigtile_r03.txt -- 552 vs 653 TFLOP/s on the vocabulary-head shape, 1081 vs 1011 at 8192^3)
             default: return PK_EINVAL;
@@ -550,9 +477,6 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
             case 9: return launch_dma<bf16x3, 4, 4, 2>(p, e, a_nrows, s);
             case 24: return launch_dma<bf16x3, 4, 2, 2, 2, 4>(p, e, a_nrows, s);
             case 27: return launch_dma<bf16x3, 4, 2, 2, 2, 2>(p, e, a_nrows, s);
-            case 40: return launch_pp<bf16x3, 0>(p, e, a_nrows, s);                     // 256x128 ping-pong (k-tiles of 32: f32 rows / split W planes)
-            case 42: return launch_pp<bf16x3, 3>(p, e, a_nrows, s);
-            case 44: return launch_pp<bf16x3, 6>(p, e, a_nrows, s);
             default: return PK_EINVAL;
         }
     }

@@ -77,7 +77,7 @@ for M in (() if os.environ.get('PK_PROBE_SKIP_SPLIT', '0') == '1' else (4608, 92
 
     print(f'# M = {M} rows; FF1 = {M} x {2 * ip} x 512 {"LayerNorm-folded" if fold else "plain"} + GEGLU, FF2 = {M} x 512 x {ip} + residual + bf16 copy, to_out = {M} x 512 x 512')
     ref = hm.clone()
-    for name, fn, variants in (('ff1', ff1, (24, 8) if fold else (24, 40, 9, 27, 8)), ('ff2', ff2, (8, 27, 33, 24)), ('to_out', tout, (8, 27, 24))):
+    for name, fn, variants in (('ff1', ff1, (24, 8) if fold else (24, 9, 27, 8)), ('ff2', ff2, (8, 27, 33, 24)), ('to_out', tout, (8, 27, 24))):
         base = None
         for v in variants:
             try:
@@ -106,29 +106,3 @@ for M in (() if os.environ.get('PK_PROBE_SKIP_SPLIT', '0') == '1' else (4608, 92
     torch.cuda.synchronize()
 
 
-# ---- the ping-pong 256 x 128 loops (variants 40-44: 0 / 2 / 3 / 4 / 6 DMA pieces of a wave issued between its MFMAs) against the 128 x 128 loops
-# (24: 8 waves, 9: 4 waves) on the big-N shapes of the hot path; bf16 and split-bf16; us per call (TFLOP/s of useful flops)
-if os.environ.get('PK_PROBE_SKIP_PP', '0') != '1':
-    print()
-    print('# ping-pong variants vs 128x128: M x N x K, us (TFLOP/s)')
-    shapes = ((9216, 2736, 512, 1), (4608, 2736, 512, 1), (18432, 2736, 512, 1), (4608, 6144, 512, 0), (9216, 1536, 512, 0), (4608, 65536, 512, 0), (8192, 8192, 4096, 0))
-    for mode, variants in (('bf16', (24, 40, 41, 42, 43, 44)), ('bf16x3', (9, 24, 40, 42, 44))):
-        for (M, N, K, act) in shapes:
-            if mode == 'bf16x3' and N * K > 40e6:
-                continue
-            A = torch.randn(M, K, device='cuda')
-            bk = 64 if mode == 'bf16' else 32
-            Kp = (K + bk - 1) // bk * bk
-            W = torch.zeros(N, Kp, device='cuda')
-            W[:, :K] = torch.randn(N, K, device='cuda') / K ** 0.5
-            if mode == 'bf16':
-                A, W, d_, ctype = A.to(torch.bfloat16), W.to(torch.bfloat16), L.BF16, torch.bfloat16
-            else:
-                W, d_, ctype = L.split_planes(W), L.BF16X3, torch.float32
-            C = torch.empty(M, N // 2 if act else N, device='cuda', dtype=ctype)
-            row = f'{mode:6s} {M:6d} x {N:6d} x {K:5d} {"GEGLU" if act else "plain"}:'
-            for v in variants:
-                us = timed(lambda: L.gemm(d_, A, W, M, N, K, C=C, act=L.ACT_GEGLU if act else L.ACT_NONE, variant=v))
-                row += f'  v{v} {us:7.2f} ({2 * M * N * K / us / 1e6:6.1f})'
-            print(row, flush=True)
-            del A, W, C
