@@ -404,33 +404,35 @@ class KernelProfiler:
         return rows
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this bench's encode leg (counters need their
-    own rocprofv3 runs -- they cannot be collected from inside this process): profiles/pmc_traffic_rNN.json (latest round), written by
-    tools/pmc_traffic.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 read correction."""
+def pmc_traffic(kernel, section=None):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this bench's legs (counters need their own rocprofv3 runs --
+    they cannot be collected from inside this process): the NEWEST profiles/pmc_traffic_rNN.json, written by tools/pmc_traffic.py from separate
+    --pmc FETCH_SIZE / WRITE_SIZE passes with the gfx950 x2 read correction.  section None: the bf16 encode leg; 'sample' / 'bf16x3_encode' /
+    'bf16x3_sample': the passes of that leg (the same kernel template runs other shapes there)."""
     import glob
-    found = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'pmc_traffic_r[0-9][0-9].json')))       # the NEWEST round's passes
+    found = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'pmc_traffic_r[0-9][0-9].json')))
     path = found[-1] if found else None
     if path is None:
         return None, None
     try:
-        tab = json.load(open(path))
+        doc = json.load(open(path))
     except (OSError, ValueError):
         return None, None
+    tab = doc.get('kernels', {}) if section is None else doc.get('sections', {}).get(section, {})
     key = kernel.replace(' ', '')
-    for name, rec in tab.get('kernels', {}).items():
+    for name, rec in tab.items():
         if name.replace(' ', '') == key:
-            return rec.get('hbm_bytes_per_launch'), tab.get('source')
+            return rec.get('hbm_bytes_per_launch'), f"{os.path.basename(path)}{'' if section is None else ' [' + section + ']'}: {doc.get('source')}"
     return None, None
 
 
-def roofline_of(rows, dtype, with_traffic=True):
-    """the roofline object of a leg: its dominant MFMA kernel by total time (PMC traffic: measured on the encode leg's shapes only)"""
+def roofline_of(rows, dtype, with_traffic=True, section=None):
+    """the roofline object of a leg: its dominant MFMA kernel by total time; traffic from the committed PMC passes of that leg (`section`)"""
     cand = [r for r in rows if r['bound'] == 'mfma']
     if not cand:
         return None
     r = cand[0]
-    traffic, src = pmc_traffic(r['kernel']) if with_traffic else (None, None)
+    traffic, src = pmc_traffic(r['kernel'], section) if with_traffic else (None, None)
     return {'bound': 'mfma', 'kernel': r['kernel'], 'achieved': r['achieved'], 'peak': r['peak'], 'unit': 'TFLOP/s', 'frac': r['frac'],
             'traffic': traffic, 'traffic_unit': 'fabric bytes per launch (L2 memory-side requests: Infinity-Cache hits are counted)', 'traffic_source': src,
             'launches_per_step': r['launches'], 'avg_launch_us': r['avg_us'], 'algorithmic_flops_per_launch': r['algorithmic_flops_per_launch']}
@@ -600,7 +602,8 @@ def bench_sample(ph, args, ws, B, name, want_kernels, leg='sample', runs=3):
             rows = prof.table()
         finally:
             ph.steps = steps
-        out['roofline'] = roofline_of(rows, args.dtype, with_traffic=False)
+        sec = {'bf16': 'sample', 'bf16x3': 'bf16x3_sample'}.get(args.dtype) if (leg == 'sample' and B == 8) else None      # the legs the PMC passes cover
+        out['roofline'] = roofline_of(rows, args.dtype, with_traffic=sec is not None, section=sec)
     return out, rows
 
 
@@ -803,7 +806,7 @@ def bench_parity_mode(args, ws, mode='bf16x3'):
     times, used_graph, rows = bench_encode(cv, a, ws, True)
     med = statistics.median(times)
     out = dict(dtype={'fp32': 'f32'}.get(mode, mode), metric='cvivit_encode_frames_per_sec', value=a.batch * 17 * a.steps * ws / med, unit='frames/s',
-               ms_per_step=med / a.steps * 1e3, hip_graph=used_graph, roofline=roofline_of(rows, mode, with_traffic=False),
+               ms_per_step=med / a.steps * 1e3, hip_graph=used_graph, roofline=roofline_of(rows, mode, with_traffic=mode == 'bf16x3', section='bf16x3_encode'),
                tolerance='ids bit-exact (margin-audited), logits / pixels 1e-3 vs the reference goldens (tests/test_modules_gpu.py)')
     if not args.no_sample:
         s, _ = bench_sample(ph, a, ws, args.sample_batch, f'BASELINE configs[2] in {mode}', True)

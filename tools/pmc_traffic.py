@@ -36,8 +36,7 @@ def collect(d, counter):
     return agg
 
 
-def main():
-    fetch_dir, write_dir, out = sys.argv[1:4]
+def table(fetch_dir, write_dir):
     fetch, write = collect(fetch_dir, 'FETCH_SIZE'), collect(write_dir, 'WRITE_SIZE')
     kernels = {}
     for name in sorted(set(fetch) | set(write)):
@@ -49,11 +48,26 @@ def main():
         wr = 1024.0 * kw / nw if nw else 0.0
         kernels[name] = dict(dispatches=max(nf, nw), fetch_bytes_per_launch_x2=rd, write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr,
                              note='fabric-side requests of the L2 (TCC_EA0): Infinity-Cache hits are included')
-    src = ('separate rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --encode-only --no-graph`, mean per '
-           'dispatch, FETCH_SIZE doubled (gfx950: 128-B requests tallied at 64 B), tools/pmc_traffic.py')
-    json.dump(dict(source=src, kernels=kernels), open(out, 'w'), indent=1)
-    for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'])[:30]:
-        print(f"{k[:90]:90s} n={v['dispatches']:5d} read {v['fetch_bytes_per_launch_x2'] / 1e6:8.2f} MB write {v['write_bytes_per_launch'] / 1e6:8.2f} MB")
+    return kernels
+
+
+def main():
+    """pmc_traffic.py FETCH_DIR WRITE_DIR OUT.json [SECTION FETCH_DIR WRITE_DIR ...]: the first pair is the bf16 encode leg ('kernels', what
+    bench.py's headline roofline reads); further triples add per-leg sections ('sample', 'bf16x3_encode', 'bf16x3_sample': the same kernel
+    template runs other shapes there, so their bytes per launch are kept apart)."""
+    fetch_dir, write_dir, out = sys.argv[1:4]
+    kernels = table(fetch_dir, write_dir)
+    src = ('separate rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --encode-only --no-graph` (sections: of the named leg), '
+           'mean per dispatch, FETCH_SIZE doubled (gfx950: 128-B requests tallied at 64 B), tools/pmc_traffic.py')
+    doc = dict(source=src, kernels=kernels, sections={})
+    rest = sys.argv[4:]
+    for i in range(0, len(rest) - 2, 3):
+        doc['sections'][rest[i]] = table(rest[i + 1], rest[i + 2])
+    json.dump(doc, open(out, 'w'), indent=1)
+    for sec, tab in [('encode', kernels)] + list(doc['sections'].items()):
+        print(f'-- {sec}')
+        for k, v in sorted(tab.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'])[:14]:
+            print(f"{k[:90]:90s} n={v['dispatches']:5d} read {v['fetch_bytes_per_launch_x2'] / 1e6:8.2f} MB write {v['write_bytes_per_launch'] / 1e6:8.2f} MB")
 
 
 if __name__ == '__main__':
