@@ -114,6 +114,16 @@ int pk_patch_embed_splitk(const float* video, int B, int C, int F, int H, int W,
 int pk_patch_embed_finish(const float* part, const float* stats, int nslices, int rows, int N, int K, const float* s, const float* t,
                           float eps1, const float* gamma2, const float* beta2, float eps2, float* out2, int ldo2, void* out, int ldo,
                           int remap_in, int remap_out, int remap_off, void* stream);
+/* pk_patch_embed_finish for BOTH frame groups in one launch (round 5): g[0 .. ngroups) carry the per-group fields above, every group writes the same
+ * out2 / out token buffers through its own row remap. */
+typedef struct {
+    const float* part; const float* stats; int nslices, rows, K;
+    const float* s; const float* t; float eps1;
+    const float* gamma2; const float* beta2; float eps2;
+    int remap_in, remap_out, remap_off;
+} pk_patch_finish_group;
+int pk_patch_embed_finish_groups(const pk_patch_finish_group* g, int ngroups, int N, float* out2, int ldo2, void* out, int ldo, void* stream);
+
 
 /* cvivit.py:326-334: Rearrange 'b t h w (c pt p1 p2) -> b c (t pt) (h p1) (w p2)' into frames [f0, f0 + nt*pt). */
 int pk_unpatchify(const float* pix, int ldp, float* video, int B, int C, int F, int H, int W, int f0, int nt,

@@ -38,6 +38,7 @@ SIGNATURES = {
                               _P, _I, _P, _P, _I, _I, _I,
                               _P, _I, _P, _P, _I, _I, _I, _P],
     'pk_patch_embed_finish': [_P, _P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _F, _P, _I, _P, _I, _I, _I, _I, _P],
+    'pk_patch_embed_finish_groups': [_P, _I, _I, _P, _I, _P, _I, _P],
     'pk_patch_frame_mask': [_P, _LL, _P, _LL, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'pk_unpatchify': [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'pk_sqdiff_partials': [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
@@ -275,6 +276,25 @@ def patch_embed_finish(part, stats, K, s, t, eps1, gamma2, beta2, eps2, *, out2=
                                       ptr(out2), out2.stride(-2) if out2 is not None else 0, ptr(out), out.stride(-2) if out is not None else 0,
                                       *remap, stream(part))
     _check(rc, 'pk_patch_embed_finish')
+
+
+class _PatchFinishGroup(ctypes.Structure):
+    _fields_ = [('part', _P), ('stats', _P), ('nslices', _I), ('rows', _I), ('K', _I), ('s', _P), ('t', _P), ('eps1', _F), ('gamma2', _P), ('beta2', _P),
+                ('eps2', _F), ('remap_in', _I), ('remap_out', _I), ('remap_off', _I)]
+
+
+def patch_embed_finish_groups(groups, *, out2=None, out=None):
+    """pk_patch_embed_finish for 1 or 2 frame groups in ONE launch; groups: tuples (part, stats, K, s, t, eps1, gamma2, beta2, eps2, remap)"""
+    arr = (_PatchFinishGroup * len(groups))()
+    for d, (part, stats, K, s, t, eps1, gamma2, beta2, eps2, remap) in zip(arr, groups):
+        nslices, rows, N = part.shape
+        d.part, d.stats, d.nslices, d.rows, d.K = ptr(part), ptr(stats), nslices, rows, int(K)
+        d.s, d.t, d.eps1 = f32p(s, 'folded s'), f32p(t, 'folded t'), float(eps1)
+        d.gamma2, d.beta2, d.eps2 = f32p(gamma2, 'LayerNorm weight'), f32p(beta2, 'LayerNorm bias'), float(eps2)
+        d.remap_in, d.remap_out, d.remap_off = remap
+    rc = load().pk_patch_embed_finish_groups(ctypes.cast(arr, _P), len(groups), N, ptr(out2), out2.stride(-2) if out2 is not None else 0,
+                                             ptr(out), out.stride(-2) if out is not None else 0, stream(groups[0][0]))
+    _check(rc, 'pk_patch_embed_finish_groups')
 
 
 def patch_frame_mask(src, dst, fmask, video_shape, f0, nt, pt, ph, pw):

@@ -25,6 +25,16 @@
 #include <cstdlib>
 #include "gemm_dma.hpp"
 
+// one frame group of pk_patch_embed_finish_groups (mirrors include/phenaki_hip.h)
+extern "C" {
+typedef struct {
+    const float* part; const float* stats; int nslices, rows, K;
+    const float* s; const float* t; float eps1;
+    const float* gamma2; const float* beta2; float eps2;
+    int remap_in, remap_out, remap_off;
+} pk_patch_finish_group;
+}
+
 namespace pk {
 
 struct PatchGroup {
@@ -542,9 +552,9 @@ struct PatchFinishArgs {
     float* out2; bf16* out; int ldo2, ldo;
     int remap_in, remap_out, remap_off;
 };
-__global__ __launch_bounds__(256) void patch_embed_finish_kernel(const PatchFinishArgs a) {
+__device__ __forceinline__ void patch_embed_finish_rows(const PatchFinishArgs& a, int block) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = block * 4 + (threadIdx.x >> 6);
     if (row >= a.rows) return;
     float su = 0.f, sq = 0.f;
     for (int sl = 0; sl < a.nslices; ++sl) {                 // slices in index order: deterministic
@@ -589,6 +599,13 @@ __global__ __launch_bounds__(256) void patch_embed_finish_kernel(const PatchFini
         if (a.out2) store4(a.out2 + (size_t)orow * a.ldo2 + n, v);
         if (a.out) store4(a.out + (size_t)orow * a.ldo + n, v);
     }
+}
+__global__ __launch_bounds__(256) void patch_embed_finish_kernel(const PatchFinishArgs a) { patch_embed_finish_rows(a, blockIdx.x); }
+// both frame groups of a video batch in ONE launch (round 5: the second finish launch was 5-10 us of ramp for 512 rows): blocks [0, blocks0) serve group 0
+struct PatchFinishPair { PatchFinishArgs g[2]; int blocks0; };
+__global__ __launch_bounds__(256) void patch_embed_finish_pair_kernel(const PatchFinishPair p) {
+    if ((int)blockIdx.x < p.blocks0) patch_embed_finish_rows(p.g[0], blockIdx.x);
+    else patch_embed_finish_rows(p.g[1], blockIdx.x - p.blocks0);
 }
 
 }  // namespace pk
@@ -713,6 +730,28 @@ extern "C" int pk_patch_embed_finish(const float* part, const float* stats, int 
     if (remap_in < 0 || (remap_in > 0 && (remap_out < remap_in || remap_off < 0))) return PK_EINVAL;
     PatchFinishArgs a{part, stats, nslices, rows, N, K, s, t, eps1, gamma2, beta2, eps2, out2, reinterpret_cast<bf16*>(out), ldo2, ldo, remap_in, remap_out, remap_off};
     hipLaunchKernelGGL(patch_embed_finish_kernel, dim3((rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+// the same for 1 or 2 frame groups in ONE launch: g[i] describes group i (the fields of pk_patch_embed_finish), all groups write the same out2 / out
+extern "C" int pk_patch_embed_finish_groups(const pk_patch_finish_group* g, int ngroups, int N, float* out2, int ldo2, void* out, int ldo, void* stream) {
+    if (!g || (ngroups != 1 && ngroups != 2) || (!out2 && !out) || N <= 0 || N > 512 || (N & 3)) return PK_EINVAL;
+    auto mis = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; };
+    if ((out2 && (mis(out2) || (ldo2 & 3))) || (out && ((reinterpret_cast<uintptr_t>(out) & 7) || (ldo & 3)))) return PK_EALIGN;
+    PatchFinishPair p;
+    for (int i = 0; i < ngroups; ++i) {
+        const pk_patch_finish_group& d = g[i];
+        if (!d.part || !d.stats || !d.s || !d.t || !d.gamma2 || !d.beta2 || d.nslices <= 0 || d.rows <= 0 || d.K <= 0) return PK_EINVAL;
+        if (mis(d.part) || mis(d.s) || mis(d.t) || mis(d.gamma2) || mis(d.beta2) || (reinterpret_cast<uintptr_t>(d.stats) & 7)) return PK_EALIGN;
+        if (d.remap_in < 0 || (d.remap_in > 0 && (d.remap_out < d.remap_in || d.remap_off < 0))) return PK_EINVAL;
+        p.g[i] = PatchFinishArgs{d.part, d.stats, d.nslices, d.rows, N, d.K, d.s, d.t, d.eps1, d.gamma2, d.beta2, d.eps2, out2, reinterpret_cast<bf16*>(out), ldo2, ldo,
+                                 d.remap_in, d.remap_out, d.remap_off};
+    }
+    if (ngroups == 1) p.g[1] = p.g[0];
+    p.blocks0 = (p.g[0].rows + 3) / 4;
+    const int blocks = p.blocks0 + (ngroups == 2 ? (p.g[1].rows + 3) / 4 : 0);
+    hipLaunchKernelGGL(patch_embed_finish_pair_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

@@ -24,6 +24,8 @@ from .quantize import LFQ, VectorQuantize
 _PATCH_FUSED = os.environ.get('PK_PATCH_FUSED', '1') != '0'
 # PK_PATCH_WIDE=0: the round-3 tiling of the fused patch embedding (128 x 128 tiles, pk_patch_embed + pk_layernorm) for A/B timing
 _PATCH_WIDE = os.environ.get('PK_PATCH_WIDE', '1') != '0'
+# both frame groups' pk_patch_embed_finish in one launch (0: one launch per group, the round-4 path, for A/B timing)
+_PATCH_FINISH_ONE = os.environ.get('PK_PATCH_FINISH_ONE', '1') != '0'
 _PE_SPLITK = int(os.environ.get('PK_PE_SPLITK', '4'))          # K-slices of the split-bf16 patch-embedding GEMM (1: one plain launch)
 _PE_SPLITK_FIRST = int(os.environ.get('PK_PE_SPLITK_FIRST', '8'))   # ... of its first-frame group (few rows, 64 x 64 tiles)
 
@@ -240,8 +242,13 @@ class CViViT(PackedModule):
                 spec.append((wg, part, stats, f0, ntg, ptg))
                 fin.append((part, stats, P, s_, _pe_bias(lin, t_), ln1.eps, ln2, (ntg * hw, T * hw, goff)))
             L.patch_embed_splitk(video, ph, pw, self.dim, spec)
-            for part, stats, P, s_, tb, eps1, ln2, remap in fin:
-                L.patch_embed_finish(part, stats, P, s_, tb, eps1, ln2.weight, ln2.bias, ln2.eps, out2=tokens, out=tokens_t, remap=remap)
+            if _PATCH_FINISH_ONE:
+                # round 5: both groups' slice folding + LayerNorms in ONE launch (the first-frame group is 512 rows: its own launch was all ramp)
+                L.patch_embed_finish_groups([(part, stats, P, s_, tb, eps1, ln2.weight, ln2.bias, ln2.eps, remap) for part, stats, P, s_, tb, eps1, ln2, remap in fin],
+                                            out2=tokens, out=tokens_t)
+            else:
+                for part, stats, P, s_, tb, eps1, ln2, remap in fin:
+                    L.patch_embed_finish(part, stats, P, s_, tb, eps1, ln2.weight, ln2.bias, ln2.eps, out2=tokens, out=tokens_t, remap=remap)
             self.__dict__['_pk_tokens_t'] = tokens_t
             return tokens, T
         if fused:

@@ -1290,6 +1290,11 @@ def test_patch_embed_row_panels_splitk(L, B, C, Fr, H, W, pt, ph, pw, N):
         rms = ((tokens.cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
         assert rms < 5e-3, f'offset {offset}: rms error {rms:.2e}'
         assert torch.equal(tokens_t.float().cpu(), bf(tokens.cpu())), 'the bf16 token rows are the rounding of the f32 ones'
+        # round 5: both groups folded by ONE launch (pk_patch_embed_finish_groups): bit-identical token rows
+        tok1 = torch.full_like(tokens, float('nan'))
+        tok1_t = torch.zeros_like(tokens_t)
+        L.patch_embed_finish_groups([(part, stats, P, s, t, 1e-5, g2, b2, 1e-5, remap) for part, stats, P, s, t, g2, b2, remap in fin], out2=tok1, out=tok1_t)
+        assert torch.equal(tok1, tokens) and torch.equal(tok1_t, tokens_t)
 
 
 @pytest.mark.parametrize('numel', [1, 7, 1000, 70000, 256 * 2048 * 4 + 5, 3 * 576 * 65536])
