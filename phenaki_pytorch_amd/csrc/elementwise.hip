@@ -96,71 +96,10 @@ __global__ __launch_bounds__(256) void peg_row_kernel(const float* __restrict__ 
     }
 }
 
-// Round 5: the same stencil with a whole (T, H, W) token volume of ONE sequence x ONE 16-channel slice staged in LDS (peg_row_kernel reads every input
-// 9 times through L1 / L2: 85 MB of cache traffic for the 9.4 MB it needs at B = 8, 11 us where the bytes ask for ~5).  A workgroup loads its
-// T*H*W x 64 B slab once (36.9 KB for 9 x 8 x 8), then thread (hw, channel quad) walks the time axis for its (h, w): per (dh, dw) neighbour column it
-// reads the TB + 2 time taps it needs and the 3 time weights from LDS and updates TB outputs -- 9 * (TB + 2 + 3) LDS reads per TB outputs instead of
-// 27 global row loads per output.  Blocks of consecutive slices sit on one XCD (xcd_contiguous_block): the two 16-channel slices that share a
-// 128-byte line meet in the same L2.  Results differ from peg_row_kernel only in f32 summation order.
-constexpr int PEG_CQ = 4;                 // f32x4 quads per slice: 16 channels = 64 B of every token row
-constexpr int PEG_TB = 3;                 // outputs along time per pass
-__global__ __launch_bounds__(256) void peg_seq_kernel(const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
-                                                      float* __restrict__ out, bf16* __restrict__ out_t, int B, int T, int H, int W, int D, int tfront,
-                                                      int nslices, int nwork) {
-    extern __shared__ __attribute__((aligned(16))) char peg_smem[];
-    f32x4* xs = reinterpret_cast<f32x4*>(peg_smem);                       // [T*H*W][PEG_CQ]
-    const int P = T * H * W, HW = H * W;
-    f32x4* wsm = xs + (size_t)P * PEG_CQ;                                 // [27][PEG_CQ]
-    const long v = xcd_contiguous_block(blockIdx.x, gridDim.x);
-    if (v >= nwork) return;
-    const int b = (int)(v / nslices), slice = (int)(v % nslices);
-    const int c0 = slice * PEG_CQ * 4;
-    const int tid = threadIdx.x, cq = tid & 3;
-    const float* xb = x + (size_t)b * P * D + c0;
-    for (int i = tid; i < P * PEG_CQ; i += 256) xs[i] = *reinterpret_cast<const f32x4*>(xb + (size_t)(i >> 2) * D + (i & 3) * 4);
-    if (tid < 27 * PEG_CQ) wsm[tid] = *reinterpret_cast<const f32x4*>(wt + (size_t)(tid >> 2) * D + c0 + (tid & 3) * 4);
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c0 + cq * 4);
-    __syncthreads();
-    for (int q = tid >> 2; q < HW; q += 64) {
-        const int h = q / W, w = q % W;
-        for (int t0 = 0; t0 < T; t0 += PEG_TB) {
-            f32x4 acc[PEG_TB];
-#pragma unroll
-            for (int k = 0; k < PEG_TB; ++k) acc[k] = bv + (t0 + k < T ? xs[((t0 + k) * HW + q) * PEG_CQ + cq] : f32x4{0, 0, 0, 0});     // bias + residual (attention.py:323)
-#pragma unroll
-            for (int dh = 0; dh < 3; ++dh) {
-                const int hs = h + dh - 1;
-                if (hs < 0 || hs >= H) continue;
-#pragma unroll
-                for (int dw = 0; dw < 3; ++dw) {
-                    const int ws_ = w + dw - 1;
-                    if (ws_ < 0 || ws_ >= W) continue;
-                    const int nb = hs * W + ws_;
-                    f32x4 col[PEG_TB + 2];                                // time taps t0 - tfront .. t0 - tfront + TB + 1 of the neighbour column
-#pragma unroll
-                    for (int k = 0; k < PEG_TB + 2; ++k) {
-                        const int ts = t0 - tfront + k;
-                        col[k] = (ts >= 0 && ts < T) ? xs[(ts * HW + nb) * PEG_CQ + cq] : f32x4{0, 0, 0, 0};
-                    }
-#pragma unroll
-                    for (int dt = 0; dt < 3; ++dt) {
-                        const f32x4 kv = wsm[((dt * 3 + dh) * 3 + dw) * PEG_CQ + cq];
-#pragma unroll
-                        for (int k = 0; k < PEG_TB; ++k) acc[k] += col[k + dt] * kv;      // output t0 + k reads time t0 + k + dt - tfront
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < PEG_TB; ++k) {
-                if (t0 + k >= T) break;
-                const size_t o = ((size_t)b * P + (size_t)(t0 + k) * HW + q) * D + c0 + cq * 4;
-                *reinterpret_cast<f32x4*>(out + o) = acc[k];
-                if (out_t) store4(out_t + o, acc[k]);
-            }
-        }
-    }
-}
-
+// (round 5: an LDS-staged form -- one sequence x one 16-channel slice per workgroup, the T*H*W x 64 B slab loaded once, every thread walking the time
+//  axis of its (h, w) column -- was built, measured and removed: 12.9 vs 9.4 us at (8,9,8,8,512), 16.5 vs 15.0 at 16 sequences; it wins only from
+//  64 sequences on (43 vs 48.5 us).  256 workgroups of 4 waves, each waiting on its own 37 KB, are latency-bound where peg_row_kernel's 1152
+//  workgroups are not: the 9x re-read it saves was never the bound.  profiles/peg_slab_r05.txt)
 // ---- LFQ (vector-quantize-pytorch LFQ restated in oracle/lfq.py; call sites cvivit.py:570, :439)
 // encode: proj = x @ Wp^T + bp (f32, one wave per token), ids = sum_k (proj_k > 0) << (cd-1-k)  (MSB first)
 template <int CD>
@@ -382,16 +321,6 @@ extern "C" int pk_peg(const float* x, const float* wt, const float* bias, float*
     const dim3 rgrid(xcd_padded_grid((rows + 255) / 256));
     bf16* ot = reinterpret_cast<bf16*>(out_t);
     if (ot && (reinterpret_cast<uintptr_t>(ot) & 7)) return PK_EALIGN;
-    // the LDS-staged form (one sequence x one 16-channel slice per workgroup): whenever the slab fits 64 KB and there is work for most of the chip
-    static const int seq_env = [] { const char* e = getenv("PK_PEG_SEQ"); return e ? atoi(e) : 1; }();      // tuning knob: 0 = the round-1 row kernel
-    const long slab = (long)T * H * W * PEG_CQ * 16 + 27 * PEG_CQ * 16;
-    if (seq_env && (D % (PEG_CQ * 4)) == 0 && slab <= 65536 && ((long)B * (D / (PEG_CQ * 4)) >= 192 || seq_env == 2)) {      // (2: whenever it fits -- tests)
-        const int nslices = D / (PEG_CQ * 4), nwork = B * nslices;
-        hipLaunchKernelGGL(peg_seq_kernel, dim3(xcd_padded_grid(nwork)), dim3(256), (unsigned)slab, STREAM(stream), x, wt, bias, out, ot, B, T, H, W, D,
-                           causal ? 2 : 1, nslices, nwork);
-        PK_CHECK_LAUNCH();
-        return PK_OK;
-    }
     if (W == 8) hipLaunchKernelGGL((peg_row_kernel<8>), rgrid, dim3(256), 0, STREAM(stream), x, wt, bias, out, ot, B, T, H, D, causal ? 2 : 1, rows);
     else if (W == 4) hipLaunchKernelGGL((peg_row_kernel<4>), rgrid, dim3(256), 0, STREAM(stream), x, wt, bias, out, ot, B, T, H, D, causal ? 2 : 1, rows);
     else if (W == 16) hipLaunchKernelGGL((peg_row_kernel<16>), rgrid, dim3(256), 0, STREAM(stream), x, wt, bias, out, ot, B, T, H, D, causal ? 2 : 1, rows);

@@ -208,23 +208,6 @@ def test_peg(L, causal):
     close(out, ref, 1e-5, 'peg')
 
 
-@pytest.mark.parametrize('causal', [False, True])
-@pytest.mark.parametrize('B,T,H,W,D', [(8, 9, 8, 8, 512), (16, 10, 8, 8, 512), (12, 3, 4, 8, 512), (6, 4, 9, 10, 1024), (4, 9, 8, 8, 512)])
-def test_peg_sequence_slab_kernel(L, causal, B, T, H, W, D):
-    """round 5: the LDS-staged PEG (one sequence x one 16-channel slice per workgroup, peg_seq_kernel) at the hot path's shapes -- the tokenizer's
-    (8, 9, 8, 8), the sampler's 16 sequences with a primed 10th time slice, H * W != 64, more than 64 (h, w) columns per slab; the last shape stays on
-    the row kernel (too few slabs for the chip).  Against the depthwise Conv3d of the oracle (attention.py:57-85, :323), and its bf16 copy."""
-    x = torch.randn(B * T * H * W, D, generator=g(15))
-    sd = {'dsconv.weight': torch.randn(D, 1, 3, 3, 3, generator=g(16)) * 0.2, 'dsconv.bias': torch.randn(D, generator=g(17)) * 0.1}
-    ref = O.peg(sd, '', x.reshape(B, T * H * W, D), (B, T, H, W), causal).reshape(-1, D) + x
-    wt = sd['dsconv.weight'].reshape(D, 27).t().contiguous().cuda()
-    out = torch.full_like(x, float('nan'), device='cuda')
-    out_t = torch.zeros(x.shape, device='cuda', dtype=torch.bfloat16)
-    L.peg(x.cuda(), wt, sd['dsconv.bias'].cuda(), out, B, T, H, W, D, causal, out_t=out_t)
-    close(out, ref, 1e-5, f'peg slab {B}x{T}x{H}x{W}x{D}')
-    assert torch.equal(out_t.float(), bf(out.cpu()).cuda())
-
-
 def test_lfq_encode_decode(L):
     M, D, cd = 777, 512, 16
     x = torch.randn(M, D, generator=g(18))
