@@ -250,7 +250,8 @@ class KernelProfiler:
             t = {lib.BF16: 'pk::bf16', lib.BF16X3: 'pk::bf16x3'}.get(dtype, 'float')
             label = VARIANT_KERNEL.get(v, f'gemm variant{v}').replace('TA', 'float' if a_is_f32 else t).replace('T', t)
             if kw.get('ln'):                                  # LayerNorm-folded instantiation: 64x64 or 128x128 by the same size rule
-                label = (VARIANT_KERNEL[24] if v in (24, 2, 9) else VARIANT_KERNEL[8]).replace('T', t)[:-2] + ('2>' if kw.get('ln_stats') is not None else '1>')
+                big = VARIANT_KERNEL[9] if dtype == self._lib.BF16X3 else VARIANT_KERNEL[24]        # (split-bf16 folds on its 4-wave 128 x 128 tile, gemm.hip)
+                label = (big if v in (24, 2, 9) else VARIANT_KERNEL[8]).replace('T', t)[:-2] + ('2>' if kw.get('ln_stats') is not None else '1>')
             return label, 'mfma', 2.0 * M * N * K
         if name == 'qkv_project':
             xq, xkv, wq, wkv, S, nseq, h, K = a[:8]
@@ -300,6 +301,9 @@ class KernelProfiler:
             ns, rows, N = part.shape
             outs = sum(_esz(kw.get(k)) for k in ('out2', 'out'))
             return 'patch_embed_finish_kernel', 'hbm', rows * N * (4.0 * ns + outs)
+        if name == 'patch_embed_finish_groups':          # (round 5: both frame groups' finish in one launch)
+            outs = sum(_esz(kw.get(k)) for k in ('out2', 'out'))
+            return 'patch_embed_finish_pair_kernel', 'hbm', sum(g[0].shape[1] * g[0].shape[2] * (4.0 * g[0].shape[0] + outs) for g in a[0])
         if name == 'gemm_splitk':
             dtype, A, W, M, N, K = a[:6]
             t = {lib.BF16: 'pk::bf16', lib.BF16X3: 'pk::bf16x3'}.get(dtype, 'float')
@@ -342,7 +346,7 @@ class KernelProfiler:
         self._lib = _lib
         self._orig = {}
         prof = self
-        names = ['gemm', 'patch_embed', 'patch_embed_splitk', 'patch_embed_finish', 'gemm_splitk', 'sum_batch', 'qkv_project', 'qkv_attn', 'q_attn_cached', 'attn_fwd', 'attn_small', 'vocab_sample', 'layernorm', 'layernorm_lfq', 'patchify_ln',
+        names = ['gemm', 'patch_embed', 'patch_embed_splitk', 'patch_embed_finish', 'patch_embed_finish_groups', 'gemm_splitk', 'sum_batch', 'qkv_project', 'qkv_attn', 'q_attn_cached', 'attn_fwd', 'attn_small', 'vocab_sample', 'layernorm', 'layernorm_lfq', 'patchify_ln',
                  'unpatchify', 'peg', 'lfq_encode', 'lfq_decode', 'embed', 'cfg_mix', 'critic_head', 'attn_prep', 'vocab_reduce',
                  'topk_mask', 'l2norm_rows']
 
