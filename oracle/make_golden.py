@@ -608,17 +608,29 @@ def gan_golden(R, cfgs, tag, batch=2, frames=5):
         seen['n_per'], seen['n_gen'] = numer.detach().clone(), denom.detach().clone()
         return orig_safe_div(numer, denom, eps)
     R.cvivit.safe_div = recording_safe_div
+    # ... and the two component gradients it is the ratio of (grad_layer_wrt_loss, cvivit.py:97-103; called for gen_loss first, then perceptual_loss)
+    orig_glwl = R.cvivit.grad_layer_wrt_loss
+    comp = []
+
+    def recording_glwl(loss, layer):
+        g = orig_glwl(loss, layer)
+        comp.append(g.detach().clone())
+        return g
+    R.cvivit.grad_layer_wrt_loss = recording_glwl
     for name, m, seed in (('gen', None, 22), ('gen_masked', mask, 23)):
         out[f'frame_{name}'] = frames_for(seed, m)
         cv.zero_grad(set_to_none=True)
         torch.manual_seed(seed)
+        comp.clear()
         loss = cv(video, mask=m) if m is not None else cv(video)
         loss.backward()
         out[f'parts_{name}'] = dict(norm_grad_perceptual=seen['n_per'], norm_grad_gen=seen['n_gen'],
-                                    adaptive_weight=(seen['n_per'] / (seen['n_gen'] + 1e-8)).clamp(max=1e4))
+                                    adaptive_weight=(seen['n_per'] / (seen['n_gen'] + 1e-8)).clamp(max=1e4),
+                                    grad_gen=comp[0].reshape(-1)[::7].clone(), grad_perceptual=comp[1].reshape(-1)[::7].clone())     # strided samples of the (P, dim) gradients
         out[f'loss_{name}'] = loss.detach().clone()
         out[f'grads_{name}'] = _grad_summary(cv)
     R.cvivit.safe_div = orig_safe_div
+    R.cvivit.grad_layer_wrt_loss = orig_glwl
     torch.save(out, os.path.join(OUT, f'gan_{tag}.pt'))
     print(f'gan_{tag}: discr loss {float(out["loss_discr"]):.6f} (hinge {float(out["hinge_discr"]):.6f}, {len(out["grads_discr"])} gradients), '
           f'generator loss {float(out["loss_gen"]):.6f} ({len(out["grads_gen"])} gradients), masked {float(out["loss_gen_masked"]):.6f}; '

@@ -387,6 +387,7 @@ def cvivit_loss_train(cv, video, *, mask=None, return_recons=False):
             if isinstance(parts, dict):              # tests: the terms of the objective, so the adaptive weight is pinned by itself (cvivit.py:657-664)
                 parts.update(recon_loss=loss.detach().clone(), perceptual=perceptual.detach().clone(), gen_loss=gen_loss.detach().clone(),
                              norm_grad_perceptual=n_per.clone(), norm_grad_gen=n_gen.clone(), adaptive_weight=adaptive.detach().clone(),
+                             grad_gen=g_gen.detach().clone(), grad_perceptual=g_per.detach().clone(),
                              vq_aux=None if vq_aux is None else vq_aux.detach().clone())
         else:
             # a 4-D image batch never reaches to_pixels (only to_pixels_first_frame): both gradient norms are 0 -> safe_div gives 0
