@@ -15,8 +15,8 @@ OBJ = os.path.join(HERE, 'csrc', '_obj')
 LIB = os.path.join(HERE, 'libphenaki_hip.so')
 SOURCES = ['gemm.hip', 'qkv.hip', 'qkv_attn.hip', 'norm.hip', 'patch.hip', 'patch_embed.hip', 'elementwise.hip', 'attn.hip', 'sampler.hip', 'train.hip',
            'attn_train.hip', 'conv.hip', 'lfq_aux.hip']
-HEADERS = ['common.hpp', 'gemm_core.hpp', 'gemm_dma.hpp']
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+HEADERS = ['common.hpp', 'gemm_core.hpp', 'gemm_dma.hpp', 'gemm_p8.hpp']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + os.environ.get('PK_EXTRA_HIPCC_FLAGS', '').split()
 
 
 def hipcc():

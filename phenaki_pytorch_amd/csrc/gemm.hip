@@ -5,6 +5,7 @@
 // Two main loops share the epilogue: gemm_core.hpp (register-staged, converts f32 A on the fly) and
 // gemm_dma.hpp (LDS-DMA ring, A and W of the same type, W zero-padded along K to the k-tile).
 #include "gemm_dma.hpp"
+#include "gemm_p8.hpp"
 
 namespace pk {
 
@@ -353,6 +354,88 @@ static int launch_dma(const GemmOperands& p, const GemmEpilogue& e, int a_nrows,
     return PK_OK;
 }
 
+// 256 x 256 8-phase main loop (gemm_p8.hpp), one workgroup per CU; the four quadrants of a wave go through the ordinary epilogue
+template <typename T, int FLAGS, int PH> struct P8Pick { typedef GemmP8<T, FLAGS> type; };
+template <typename T, int FLAGS> struct P8Pick<T, FLAGS, 4> { typedef GemmP4<T, FLAGS> type; };
+
+template <typename T, int FLAGS = 0, int PH = 8>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gemm_p8_kernel(const GemmOperands p, const GemmEpilogue e, int a_nrows) {
+    using Tile = typename P8Pick<T, FLAGS, PH>::type;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int MT = (p.M + Tile::BM - 1) / Tile::BM, cmax = (MT + 7) / 8, NTn = (p.N + Tile::BN - 1) / Tile::BN;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int mstart = xcd * MT / 8, mcount = (xcd + 1) * MT / 8 - mstart;
+    int m0, n0;
+    if (p.plain_map) {
+        if ((int)blockIdx.x >= MT * NTn) return;
+        m0 = (blockIdx.x % MT) * Tile::BM;
+        n0 = (blockIdx.x / MT) * Tile::BN;
+    } else {
+        int ml, ntile;
+        if (!xcd_panel_tile(idx, cmax, mcount, NTn, p.panel, ml, ntile)) return;
+        m0 = (mstart + ml) * Tile::BM;
+        n0 = ntile * Tile::BN;
+    }
+    typename Tile::Acc acc;
+    if constexpr ((FLAGS & 32) != 0) {                    // timing experiment (32x32x16 MFMA on the same operand registers): no real output
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][i][r] = 0.f;
+        Tile::run(p, a_nrows, m0, n0, smem, acc);
+        float t = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t += acc[a][b][i][r];
+        if (m0 + (int)threadIdx.x < p.M) reinterpret_cast<float*>(e.C)[(size_t)(m0 + threadIdx.x) * e.ldc + n0] = t;
+    } else {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0, 0, 0, 0};
+        Tile::run(p, a_nrows, m0, n0, smem, acc);
+        // (four explicit calls: inside a loop over (a, b) hipcc keeps the accumulators in scratch for the epilogue)
+        gemm_epilogue<T, 4, 2, 4>(acc[0][0], p.M, p.N, e, m0, n0);
+        gemm_epilogue<T, 4, 2, 4>(acc[0][1], p.M, p.N, e, m0, n0 + 128);
+        gemm_epilogue<T, 4, 2, 4>(acc[1][0], p.M, p.N, e, m0 + 128, n0);
+        gemm_epilogue<T, 4, 2, 4>(acc[1][1], p.M, p.N, e, m0 + 128, n0 + 128);
+    }
+}
+
+template <typename T, int FLAGS = 0, int PH = 8>
+static int launch_p8(const GemmOperands& p, const GemmEpilogue& e, int a_nrows, hipStream_t s) {
+    using Tile = typename P8Pick<T, FLAGS, PH>::type;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PK_ELAUNCH;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_kernel<T, FLAGS, PH>), hipFuncAttributeMaxDynamicSharedMemorySize, Tile::SMEM) != hipSuccess) return PK_ELAUNCH;
+        attr_set[dev] = true;
+    }
+    const int MT = (p.M + Tile::BM - 1) / Tile::BM, NT = (p.N + Tile::BN - 1) / Tile::BN;
+    dim3 grid(8 * ((MT + 7) / 8) * NT);
+    GemmOperands pp = p;
+    static const int panel_env = [] { const char* e_ = getenv("PK_GEMM_PANEL"); return e_ ? atoi(e_) : -1; }();
+    pp.panel = panel_env >= 0 ? panel_env : xcd_panel_rows(Tile::BM, p.K, (int)sizeof(T));
+    hipLaunchKernelGGL((gemm_p8_kernel<T, FLAGS, PH>), grid, dim3(Tile::THREADS), Tile::SMEM, s, pp, e, a_nrows);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
 }  // namespace pk
 
 using namespace pk;
@@ -448,7 +531,7 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
         return big ? launch_dma<float, 4, 2, 2, 2, 4, 128, 0, 1>(p, e, a_nrows, s) : launch_dma<float, 2, 2, 2, 2, 2, 128, 0, 1>(p, e, a_nrows, s);
     }
     // stats_out is written by the TN = 2 LDS-DMA kernels only (one 32-column chunk per wave)
-    if (stats_out && !(dma_ok && (variant == 8 || variant == 24 || variant == 27 || variant == 33 || (variant == 3 && dtype != 1)))) return PK_EINVAL;
+    if (stats_out && !(dma_ok && (variant == 8 || variant == 24 || variant == 27 || variant == 33 || variant == 50 || (variant == 3 && dtype != 1)))) return PK_EINVAL;
     // the main-loop variants that survived round 1's sweep (profiles/gemm_variants*_r01.txt; the 35 losers -- deeper rings, k-tile 32,
     // 128x256 / 256x256 tiles, other wave layouts, other producer / consumer splits -- were deleted in round 2)
     if (dtype == 1) {
@@ -460,6 +543,29 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
             case 24: return launch_dma<bf16, 4, 2, 2, 2, 4>(p, e, a_nrows, s);          // 128x128, 8 waves (2x4), 2 stages (64 KB: 16 waves/CU)
             case 33: return launch_dma<bf16, 2, 2, 3, 2, 2, 128, 2>(p, e, a_nrows, s);  // 64x64, 4 consumers + 2 producers, 3 stages (long K)
             case 27: return launch_dma<bf16, 4, 2, 2, 2, 2>(p, e, a_nrows, s);          // 128x64, 4 waves (wave tile 64x32), 2 stages (48 KB: 3 WG/CU)
+            case 50: return launch_p8<bf16, 0, 4>(p, e, a_nrows, s);                    // 256x256, 8 waves in two groups a barrier apart, 2 phases per k-tile (gemm_p8.hpp), 1 WG/CU
+#ifdef PK_P8_ABLATE
+            // tools/gemm_bench.py ablations behind profiles/gemm_p8_r06.txt (build with PK_EXTRA_HIPCC_FLAGS=-DPK_P8_ABLATE); FLAGS are listed in gemm_p8.hpp
+            case 60: return launch_p8<bf16, 0, 8>(p, e, a_nrows, s);        // the 8-phase form (16 MFMAs per phase)
+            case 61: return launch_p8<bf16, 1, 8>(p, e, a_nrows, s);
+            case 62: return launch_p8<bf16, 2, 8>(p, e, a_nrows, s);
+            case 63: return launch_p8<bf16, 3, 8>(p, e, a_nrows, s);
+            case 64: return launch_p8<bf16, 4, 8>(p, e, a_nrows, s);
+            case 68: return launch_p8<bf16, 8, 8>(p, e, a_nrows, s);
+            case 70: return launch_p8<bf16, 8, 4>(p, e, a_nrows, s);        // 2-phase form: no s_setprio
+            case 71: return launch_p8<bf16, 1, 4>(p, e, a_nrows, s);        // no in-loop DMA
+            case 72: return launch_p8<bf16, 2, 4>(p, e, a_nrows, s);        // no fragment reads
+            case 73: return launch_p8<bf16, 3, 4>(p, e, a_nrows, s);        // neither: MFMAs + barriers
+            case 74: return launch_p8<bf16, 4, 4>(p, e, a_nrows, s);        // no stagger between the wave groups
+            case 75: return launch_p8<bf16, 64, 4>(p, e, a_nrows, s);       // DMA issued, never waited for (timing only)
+            case 76: return launch_p8<bf16, 128, 4>(p, e, a_nrows, s);      // fragment reads waited for after the barrier
+            case 79: return launch_p8<bf16, 259, 4>(p, e, a_nrows, s);      // MFMAs only: no loads, no barriers
+            case 81: return launch_p8<bf16, 512, 4>(p, e, a_nrows, s);      // DMA 4 + 4 pieces per phase (timing only)
+            case 83: return launch_p8<bf16, 1024, 4>(p, e, a_nrows, s);     // a phase's reads issued before its DMA pieces
+            case 84: return launch_p8<bf16, 2048, 4>(p, e, a_nrows, s);     // half of the DMA pieces issued between the MFMAs
+            case 86: return launch_p8<bf16, 32, 4>(p, e, a_nrows, s);       // v_mfma_f32_32x32x16_bf16 on the same operand registers (timing only)
+            case 87: return launch_p8<bf16, 35, 4>(p, e, a_nrows, s);       // ... without loads
+#endif
             // (round 5: a 256x128 "ping-pong" loop -- one workgroup per CU, two 4-wave groups half an iteration apart, 3-stage 144 KB ring, persistent --
             //  was built, measured and removed: equal to this loop at long K, 13-40 % slower at K = 512; profiles/gemm_pingpong_r05.txt)
             // (256x256 / 256x128 / 128x256 8-wave instantiations were measured again in round 3 against the torch.mm yardstick and removed:

@@ -91,7 +91,7 @@ def test_gemm_geglu_leaky_gather_and_T_output(L, mode):
     close(C3, h[idx.long()], 2e-5, 'gather')
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 8, 9, 24, ('f32only', 3), ('bf16only', 27), ('bf16only', 33)])
+@pytest.mark.parametrize('variant', [0, 1, 2, 8, 9, 24, ('f32only', 3), ('bf16only', 27), ('bf16only', 33), ('bf16only', 50)])
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])
 @pytest.mark.parametrize('M,N,K', [(300, 200, 96), (1000, 520, 1368), (4608, 512, 512), (129, 2736, 512), (2100, 1160, 64)])
 def test_gemm_main_loop_variants(L, variant, mode, M, N, K):
