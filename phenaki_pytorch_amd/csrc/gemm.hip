@@ -466,6 +466,9 @@ static int auto_variant(int dtype, int a_is_f32, int M, int N, int K, int lda, i
     if (dtype != 0 && blocks128 >= t128 && blocks128 < 384 && K <= 1024) return 27;
     // split-bf16: 128x128 with 4 waves (64x64 wave tiles: every in-register A split feeds 4 column fragments): 98 vs 107 us at
     // 9216 x 2736 x 512, 185 vs 208 us at 18432 rows (tools/gemm_bench.py --mode bf16x3)
+    // long K and >= 2 rounds of 256 x 256 tiles (no hot-path shape; the library entry point is general): the two-group 256 x 256 loop of gemm_p8.hpp,
+    // 1.32-1.37 vs 1.02-1.05 PF at 8192^3 (profiles/gemm_p8_r06.txt); at K = 512 the 128 x 128 loop's two co-resident workgroups win
+    if (dtype == 1 && K >= 2048 && (long)((M + 255) / 256) * ((N + 255) / 256) >= 512) return 50;
     if (blocks128 >= t128) return dtype == 2 ? 9 : 24;                      // 128x128, 8 waves, 2 stages (16 waves/CU)
     if (K >= 2048) return dtype == 1 ? 33 : 3;      // long K (patch embed): 64x64, 3-stage ring fed by 2 producer waves (bf16) / 4 stages
     return 8;                                                               // 64x64, 2 stages (5 WG/CU)

@@ -43,6 +43,7 @@ def main():
     ap.add_argument('--variants', type=str, default='', help='comma list, default all of the mode')
     ap.add_argument('--shapes', type=str, default='', help='comma list of shape indices, default all')
     ap.add_argument('--res', action='store_true', help='add bias + f32 residual (the out-projection epilogue)')
+    ap.add_argument('--geglu', action='store_true', help='GEGLU epilogue with a T (bf16) output of N / 2 columns: what the FF1 calls of the hot path run (even N only)')
     ap.add_argument('--no-yardstick', action='store_true')
     ap.add_argument('--out', default='gpurun_out/gemm_bench.json')
     args = ap.parse_args()
@@ -69,6 +70,9 @@ def main():
         big = (M * N) >= (1 << 28)
         C = torch.empty(M, N, device='cuda', dtype=torch.bfloat16 if (big and args.mode == 'bf16') else torch.float32)
         kw = {}
+        if args.geglu and N % 2 == 0 and args.mode == 'bf16':
+            C = torch.empty(M, N // 2, device='cuda', dtype=torch.bfloat16)
+            kw = dict(bias=torch.randn(N, device='cuda'), act=L.ACT_GEGLU)
         if args.res and C.dtype == torch.float32:
             kw = dict(bias=torch.randn(N, device='cuda'), res=torch.randn(M, N, device='cuda'))
         live = {}
