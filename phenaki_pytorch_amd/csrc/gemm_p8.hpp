@@ -318,6 +318,6 @@ struct GemmP4 : GemmP8<T, FLAGS> {
 //  SLOWER than one tile per workgroup on every shape (profiles/gemm_p8_r06.txt: 8192^3 1.13-1.19 vs 1.33-1.35 PF; 36864 x 2736 x 512 with the GEGLU
 //  epilogue 211 vs 183 us, the 128 x 128 loop 148): vmcnt counts the epilogue's stores in order with the DMA pieces, so the first counted wait behind an
 //  epilogue waits for the stores' acknowledgements; the per-tile offsets no longer fit beside 128 accumulators + 64 fragment registers and have to be
-//  rebuilt per DMA piece in the load part of a phase, which is this loop's critical path.  Removed; the code is commit "persistent tile stream".)
+//  rebuilt per DMA piece in the load part of a phase, which is this loop's critical path.  Removed.)
 
 }  // namespace pk
