@@ -65,7 +65,7 @@ def parse():
     ap.add_argument('--no-parity-mode', action='store_true', help='skip the exact-f32 timing')
     ap.add_argument('--no-kernels', action='store_true', help='skip the per-kernel roofline table')
     ap.add_argument('--encode-only', action='store_true', help='only the headline leg (profiling runs)')
-    ap.add_argument('--legs', default='decode,encode_b32,sample,sample_cfg3,sample_b32,make_video,objective,train_step,cvivit_train_step,cvivit_gan_step',
+    ap.add_argument('--legs', default='decode,encode_b32,sample,sample_cfg3,sample_b32,make_video,scaling_projection,objective,train_step,cvivit_train_step,cvivit_gan_step',
                     help='comma list of the legs reported beside the headline encode leg')
     ap.add_argument('--sample-batch', type=int, default=8)
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -642,6 +642,62 @@ def bench_make_video(ph, args, ws):
                 videos_per_gpu=1, scenes=[17, 14, 14], prime_frames=5, tokens_per_video=ntok, frames_out=45)
 
 
+def bench_scaling_projection(ph, args, result):
+    """VERDICT r5 #6b -- what the 1 -> 8 GPU curves of configs[3] / configs[4] would be, PROJECTED from one-GPU measurements (no 8-GPU node was
+    ever available to this repo; these are projections and labelled so).  The path shards the batch with no collective inside the loop, so an
+    N-GPU run of a fixed job costs one GPU its per-GPU SHARE of the batch plus the one all-gather of the decoded videos:
+      t(N) = t_one_gpu(B / N) + t_all_gather(N),   strong scaling S(N) = t(1) / t(N)        (weak scaling: t_one_gpu(B) + t_all_gather(N))
+    t_one_gpu is measured here at every share; t_all_gather is MODELLED on the xGMI full mesh (7 links x ~153 GB/s per GPU, point to point):
+    'direct' = every rank writes its shard to its 7 peers over 7 links at once (shard / 153 GB/s), 'ring' = one ring over one link per
+    hop ((N - 1) shards / 153 GB/s) -- RCCL lands between the two; both are small beside the sampling loop."""
+    from phenaki_pytorch_amd import make_video_sharded
+    LINK = 153e9
+    out = {'note': 'PROJECTION from 1-GPU measurements + an xGMI model; not a multi-GPU measurement', 'xgmi_link_GBs': LINK / 1e9}
+    # ---- configs[3]: Phenaki.sample, batch 32 over N GPUs
+    t = {}
+    have = {32: result.get('sample_b32'), 8: result.get('sample'), 4: result.get('sample_cfg3')}
+    for B in (32, 16, 8, 4):
+        if have.get(B):
+            t[B] = have[B]['seconds_per_sample_call']
+        else:
+            r, _ = bench_sample(ph, args, 1, B, f'configs[3] share: {B} videos on one GPU', False, runs=2)
+            t[B] = r['seconds_per_sample_call']
+    rows = []
+    for N in (1, 2, 4, 8):
+        share = 32 // N
+        shard = share * 3 * 17 * 256 * 256 * 4.0
+        ag = dict(direct=0.0 if N == 1 else shard / LINK, ring=0.0 if N == 1 else (N - 1) * shard / LINK)
+        rows.append(dict(n_gpus=N, videos_per_gpu=share, one_gpu_seconds=t[share], all_gather_model_s=ag,
+                         strong_scaling=dict(direct=t[32] / (t[share] + ag['direct']), ring=t[32] / (t[share] + ag['ring'])),
+                         tokens_per_s=dict(direct=32 * 576 / (t[share] + ag['direct']), ring=32 * 576 / (t[share] + ag['ring']))))
+    out['configs3_sample_batch32'] = rows
+    out['configs3_weak'] = [dict(n_gpus=N, videos_per_gpu=4, tokens_per_s_ring=N * 4 * 576 / (t[4] + (0.0 if N == 1 else (N - 1) * 4 * 13369344.0 / LINK)))
+                            for N in (1, 2, 4, 8)]
+    # ---- configs[4]: make_video, batch 8 over N GPUs (one hipGraph per scene configuration when graphs are on)
+    ctx = synthetic_context(1, 12, 768, seed=3).cuda()
+    ph.encode_texts = lambda texts, output_device=None: ctx.expand(len(texts), -1, -1).contiguous()
+    ph.enable_sample_graph(not args.no_graph)
+    tm = {}
+    try:
+        for B in (8, 4, 2, 1):
+            texts = [['a', 'b', 'c']] * B
+            call = lambda: make_video_sharded(ph, texts, (17, 14, 14), 5)
+            call(); call()
+            tm[B] = statistics.median(timed_groups(lambda i: call(), 1, 3, 1))
+    finally:
+        ph.enable_sample_graph(False)
+    ntok = 576 + 2 * 448
+    rows = []
+    for N in (1, 2, 4, 8):
+        share = 8 // N
+        shard = share * 3 * 45 * 256 * 256 * 4.0
+        ring = 0.0 if N == 1 else (N - 1) * shard / LINK
+        rows.append(dict(n_gpus=N, videos_per_gpu=share, one_gpu_seconds=tm[share], all_gather_ring_model_s=ring,
+                         strong_scaling_ring=tm[8] / (tm[share] + ring), tokens_per_s_ring=8 * ntok / (tm[share] + ring)))
+    out['configs4_make_video_batch8'] = rows
+    return out
+
+
 def bench_objective(ph, args, ws):
     """SURVEY.md 8f row 1, first slice: Phenaki.forward -- the VALUE of the training objective (masked cross entropy without
     logits + token-critic BCE) on B videos' worth of token ids; videos/sec.  Reported beside the headline legs."""
@@ -908,6 +964,12 @@ def compact_line(full):
                      ('cvivit_train_step', 'ms_per_step'), ('cvivit_gan_step', 'generator_step_ms'), ('encode_b32', 'value'), ('sample_b32', 'value'), ('sample_cfg3', 'value')):
         if leg in full and key in full[leg]:
             line.setdefault('legs', {})[leg] = {key: _r(full[leg][key], 3), 'unit': full[leg].get('unit')}
+    sp = full.get('scaling_projection')
+    if sp:
+        r8 = sp['configs3_sample_batch32'][-1]
+        m8 = sp['configs4_make_video_batch8'][-1]
+        line['scaling_projection'] = {'note': 'projected from 1-GPU shares + xGMI ring model, NOT measured', 'configs3_strong_8gpu': _r(r8['strong_scaling']['ring'], 3),
+                                      'configs4_strong_8gpu': _r(m8['strong_scaling_ring'], 3)}
     line['full_report'] = 'gpurun_out/bench_full.json (also on stderr)'
     return line
 
@@ -926,7 +988,7 @@ def emit(full):
     line = json.dumps(compact_line(full), separators=(',', ':'))
     while len(line) > 4000:                                     # never let the parsed line grow past the driver's window again
         c = json.loads(line)
-        for k in ('legs', 'parity_f32', 'roofline_hbm', 'sample'):
+        for k in ('scaling_projection', 'legs', 'parity_f32', 'roofline_hbm', 'sample'):
             if k in c:
                 del c[k]
                 break
@@ -999,6 +1061,12 @@ def main():
         kernels += sb_rows or []
     if sampler and 'make_video' in legs:
         result['make_video'] = bench_make_video(ph, args, ws)
+    if sampler and 'scaling_projection' in legs and ws == 1:
+        try:
+            result['scaling_projection'] = bench_scaling_projection(ph, args, result)
+        except Exception as e:                                  # noqa: BLE001
+            print(f'[bench] scaling_projection leg failed ({type(e).__name__}: {e})', file=sys.stderr)
+            torch.cuda.synchronize()
     if sampler and 'objective' in legs:
         result['objective'] = bench_objective(ph, args, ws)
     if kernels:

@@ -617,7 +617,16 @@ def gan_golden(R, cfgs, tag, batch=2, frames=5):
         comp.append(g.detach().clone())
         return g
     R.cvivit.grad_layer_wrt_loss = recording_glwl
-    for name, m, seed in (('gen', None, 22), ('gen_masked', mask, 23)):
+    # vector_quantize_pytorch is absent, so the quantizer inside this "reference" run is oracle/lfq.py's restatement (ref_shim).  Its sign /
+    # straight-through part is elementary; its AUXILIARY loss (entropy + commitment, defaults written from the published code) is not pinned by any upstream
+    # vector.  The generator step is therefore minted twice: 'gen' / 'gen_masked' with the aux term (SELF-DERIVED for that term: the test says so and holds
+    # it to 5e-4), and 'gen_noaux' with both aux weights set to 0 -- an objective that does not depend on the restated aux formula at all (held to 2e-4).
+    from oracle import lfq as _lfq
+    out['lfq_aux'] = dict(self_derived=True, source='oracle/lfq.py (restated; vector-quantize-pytorch absent, setup.py pins >=1.11.8 only)',
+                          defaults=dict(_lfq.LFQ_DEFAULTS), log_eps=_lfq.LOG_EPS)
+    w_aux = (cv.vq.entropy_loss_weight, cv.vq.commitment_loss_weight)
+    for name, m, seed in (('gen', None, 22), ('gen_masked', mask, 23), ('gen_noaux', None, 22)):
+        cv.vq.entropy_loss_weight, cv.vq.commitment_loss_weight = (0., 0.) if name == 'gen_noaux' else w_aux
         out[f'frame_{name}'] = frames_for(seed, m)
         cv.zero_grad(set_to_none=True)
         torch.manual_seed(seed)
@@ -629,6 +638,7 @@ def gan_golden(R, cfgs, tag, batch=2, frames=5):
                                     grad_gen=comp[0].reshape(-1)[::7].clone(), grad_perceptual=comp[1].reshape(-1)[::7].clone())     # strided samples of the (P, dim) gradients
         out[f'loss_{name}'] = loss.detach().clone()
         out[f'grads_{name}'] = _grad_summary(cv)
+    cv.vq.entropy_loss_weight, cv.vq.commitment_loss_weight = w_aux
     R.cvivit.safe_div = orig_safe_div
     R.cvivit.grad_layer_wrt_loss = orig_glwl
     torch.save(out, os.path.join(OUT, f'gan_{tag}.pt'))

@@ -463,6 +463,14 @@ class CViViT(PackedModule):
             # perceptual network: under torch.no_grad(), or on a copy_for_eval() module (both set to None, cvivit.py:415-417), forward(video)
             # is an EVALUATION call and returns the value of the reconstruction loss (the reference raises inside autograd.grad there)
             eval_call = self.use_vgg_and_gan and (not torch.is_grad_enabled() or self.discr is None)
+            if eval_call and torch.is_grad_enabled() and not self.__dict__.get('_pk_warned_eval_objective'):
+                # a copy_for_eval() module called with grad mode ON returns a DIFFERENT objective than the training module (no
+                # perceptual, generator or quantizer terms; the reference raises here) -- say so once instead of silently changing it
+                import warnings
+                warnings.warn('CViViT.forward(video) on a GAN-mode module without its discriminator / perceptual network (copy_for_eval) returns '
+                              'the RECONSTRUCTION loss only, as a value without an autograd graph; the training objective needs the original module',
+                              RuntimeWarning, stacklevel=2)
+                self.__dict__['_pk_warned_eval_objective'] = True
             if (wants_grad(self) or self.use_vgg_and_gan) and not eval_call:
                 # grad mode on and trainable parameters: the tokenizer's training step (train_cvivit.py)
                 from .train_cvivit import cvivit_loss_train

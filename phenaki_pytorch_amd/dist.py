@@ -279,9 +279,20 @@ class GradientReducer:
                 if self.average and ws > 1:
                     self.arena[b].div_(ws)
             # a parameter that got no gradient HERE may have got one on another rank: every rank must step it with the same averaged value
-            # (an optimizer skips `.grad is None`), so the reduced view becomes its gradient -- what DDP does under find_unused_parameters
+            # (an optimizer skips `.grad is None`), so the reduced view becomes its gradient.  A parameter NO rank produced a gradient for keeps
+            # .grad = None -- DDP all-reduces a used-parameter bitmap for exactly this (reducer.cpp, find_unused_parameters) -- otherwise AdamW
+            # would decay it and create optimizer state under data parallelism only.  One small int32 all-reduce of the flags;
+            # only issued when some rank has an absent parameter... which no rank can know locally, so it is issued every step (a few KB).
+            used = torch.ones(len(self.params), device=self.arena[0].device, dtype=torch.int32)
+            if self._absent:
+                used[torch.tensor(self._absent, device=used.device, dtype=torch.long)] = 0
+            dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self.group)      # (not counted in `collectives`: those are the gradient buckets)
+            used = used.tolist()
             for i in self._absent:
-                self.params[i].grad = self._views[i]
+                if used[i]:
+                    self.params[i].grad = self._views[i]
+                else:
+                    self.params[i].grad = None
         self._absent.clear()
         n = self.collectives
         self._pending.clear()

@@ -69,16 +69,22 @@ class LFQ(nn.Module):
 
     def aux_config(self, inv_temperature=100.):
         """keyword arguments of _lib.lfq_aux for this module (published forward default inv_temperature = 100)"""
+        if not 2 <= self.codebook_dim <= 16:
+            # ADVICE r5: the pk_lfq_aux_* kernels factorise the 2^cd codebook distribution over two halves of <= 8 bits each (256-entry LDS tables)
+            raise ValueError(f'the LFQ training-mode auxiliary loss (entropy + commitment, pk_lfq_aux_*) is built for codebook sizes 4 .. 65536; '
+                             f'codebook_size = {self.codebook_size} (codebook_dim {self.codebook_dim}) can be run for inference and for the '
+                             'reconstruction-only objective (use_vgg_and_gan=False) only')
         return dict(inv_temperature=inv_temperature, codebook_scale=self.codebook_scale, entropy_loss_weight=self.entropy_loss_weight,
                     commitment_loss_weight=self.commitment_loss_weight, diversity_gamma=self.diversity_gamma)
 
     def forward(self, x, inv_temperature=100., **_unused):
-        """(b, n, dim) -> (quantized (b, n, dim), indices (b, n) int64, aux_loss).  Eval mode (or grad mode off): the hard codes and aux = 0, as
-        the published module in eval().  Training mode under grad: the straight-through output and the entropy + commitment auxiliary loss,
-        both differentiable (train_cvivit._LFQFn, pk_lfq_aux_*)."""
+        """(b, n, dim) -> (quantized (b, n, dim), indices (b, n) int64, aux_loss).  The published module's predicate is `self.training` alone
+        (the same predicate as the tokenizer's training step, train_cvivit.py): eval mode -> the hard codes, NO straight-through
+        gradient into project_in, aux = 0; training mode -> the straight-through output and the entropy + commitment auxiliary loss
+        (differentiable under grad mode through train_cvivit._LFQFn / pk_lfq_aux_*; under no_grad the same VALUES without a graph)."""
         b, n, d = x.shape
         x2 = x.reshape(b * n, d).float().contiguous()
-        if self.training and torch.is_grad_enabled():
+        if self.training:
             from .train_cvivit import _LFQFn
             q, aux, _ = _LFQFn.apply(x2, self.project_in.weight, self.project_in.bias, self.project_out.weight, self.project_out.bias,
                                      self.aux_config(inv_temperature))
@@ -86,7 +92,11 @@ class LFQ(nn.Module):
                 ids = self.encode_ids(x2.detach())
             return q.reshape(b, n, d), ids.reshape(b, n), aux
         ids = self.encode_ids(x2)
-        q = self.codes_2d(ids)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.project_out.parameters()):
+            from .train_cvivit import _LFQFn
+            q = _LFQFn.apply(x2, self.project_in.weight, self.project_in.bias, self.project_out.weight, self.project_out.bias, None, False)
+        else:
+            q = self.codes_2d(ids)
         return q.reshape(b, n, d), ids.reshape(b, n), torch.zeros((), device=x.device)
 
 

@@ -166,7 +166,9 @@ class _LFQFn(torch.autograd.Function):
     return of `self.vq`, cvivit.py:570 -> :666) -- value and d aux / d project_in(x) come out of the pk_lfq_aux_* kernels in the forward pass."""
 
     @staticmethod
-    def forward(ctx, x, Wp, bp, Wo, bo, aux_cfg=None):
+    def forward(ctx, x, Wp, bp, Wo, bo, aux_cfg=None, ste=True):
+        """ste = False: the published module in eval() -- hard codes, no gradient reaches project_in or x (only project_out's parameters)"""
+        ctx.ste = bool(ste)
         M, D = x.shape
         cd = Wp.shape[0]
         dev = x.device
@@ -195,11 +197,13 @@ class _LFQFn(torch.autograd.Function):
         dy = dy.contiguous()
         dq, dWo = linear_bwd(L.F32, q, Wo.detach(), dy)                 # (M, cd), (D, cd)
         dbo = L.colsum(dy, M, D, _f32((D,), dev))
+        if not ctx.ste:
+            return None, None, None, dWo, dbo, None, None
         if ctx.has_aux and daux is not None:
             dq = torch.addcmul(dq, ctx.saved_tensors[4], daux.reshape(1, 1).float())      # + d loss / d aux * d aux / d proj
         dx, dWp = linear_bwd(L.F32, x, Wp.detach(), dq)                 # straight through the sign: d proj = d q
         dbp = L.colsum(dq, M, cd, _f32((cd,), dev))
-        return dx, dWp, dbp, dWo, dbo, None
+        return dx, dWp, dbp, dWo, dbo, None, None
 
 
 class _PatchMSE(torch.autograd.Function):
@@ -346,11 +350,14 @@ def cvivit_loss_train(cv, video, *, mask=None, return_recons=False):
     # quantize (row-wise: the token order does not matter), then decode: temporal, then spatial (cvivit.py:476-516)
     vq = cv.vq
     vq_aux = None
-    if cv.use_vgg_and_gan and hasattr(vq, 'aux_config'):
+    # the published LFQ's predicate is its own `training` flag (the same predicate as quantize.LFQ.forward): in eval() it returns the hard
+    # codes with NO straight-through gradient and aux = 0, also inside a grad-mode forward of a GAN-mode tokenizer
+    vq_train = bool(getattr(vq, 'training', True))
+    if cv.use_vgg_and_gan and hasattr(vq, 'aux_config') and vq_train:
         # the generator objective adds the quantizer's auxiliary loss (cvivit.py:570, :666); the reconstruction-only objective never reads it
         x, vq_aux, _ = _LFQFn.apply(x, vq.project_in.weight, vq.project_in.bias, vq.project_out.weight, vq.project_out.bias, vq.aux_config())
     else:
-        x = _LFQFn.apply(x, vq.project_in.weight, vq.project_in.bias, vq.project_out.weight, vq.project_out.bias)
+        x = _LFQFn.apply(x, vq.project_in.weight, vq.project_in.bias, vq.project_out.weight, vq.project_out.bias, None, vq_train)
     x = transformer_train(cv.dec_temporal_transformer, x, b * hw, T, dt, video_shape=(b, T, h, w))
     x = _GatherRows.apply(x, to_spatial, to_temporal)                                 # rows '(b t) (h w)'
     x = transformer_train(cv.dec_spatial_transformer, x, b * T, hw, dt, attn_bias=bias)

@@ -284,16 +284,26 @@ def test_discriminator_step_matches_reference(golden_dir, dtype, tol):
                                                           rel_l2=worst))
 
 
-@pytest.mark.parametrize('kind', ['gen', 'gen_masked'])
+@pytest.mark.parametrize('kind', ['gen', 'gen_masked', 'gen_noaux'])
 @pytest.mark.parametrize('dtype,tol', MODES)
 def test_generator_gan_step_matches_reference(golden_dir, dtype, tol, kind):
     """loss = cvivit(video) with use_vgg_and_gan=True (reconstruction + perceptual through the caller's vgg + adaptive_weight * generator loss,
-    cvivit.py:585-671) and loss.backward(): the loss and every gradient (tokenizer AND discriminator) against the reference's"""
+    cvivit.py:585-671) and loss.backward(): the loss and every gradient (tokenizer AND discriminator) against the reference's.
+    ADVICE r5: the quantizer's AUXILIARY term of the 'gen' / 'gen_masked' goldens is SELF-DERIVED (the upstream package is absent: the minted run used
+    oracle/lfq.py, g['lfq_aux']); 'gen_noaux' is the same step with both aux weights 0, i.e. independent of the restated aux formula."""
     g = load(golden_dir, 'gan_tiny.pt')
+    assert g['lfq_aux']['self_derived']
     cv, _ = gan_product(TINY, g['discr_keys'], dtype)
+    if kind == 'gen_noaux':
+        cv.vq.entropy_loss_weight, cv.vq.commitment_loss_weight = 0., 0.
+    else:
+        # the restated upstream defaults live in ONE place (oracle/lfq.py LFQ_DEFAULTS): a different upstream pin is a one-line change there + a re-mint
+        from oracle.lfq import LFQ_DEFAULTS
+        assert g['lfq_aux']['defaults'] == LFQ_DEFAULTS
+        assert (cv.vq.entropy_loss_weight, cv.vq.commitment_loss_weight, cv.vq.diversity_gamma) == tuple(LFQ_DEFAULTS[k] for k in ('entropy_loss_weight', 'commitment_loss_weight', 'diversity_gamma'))
     H = TINY['cvivit']['image_size']
     video = weights.synthetic_video(2, 5, H, H, seed=12).cuda()
-    torch.manual_seed(22 if kind == 'gen' else 23)
+    torch.manual_seed(23 if kind == 'gen_masked' else 22)
     parts = cv.__dict__['_pk_loss_parts'] = {}
     loss = cv(video, mask=g['mask'].cuda()) if kind == 'gen_masked' else cv(video)
     loss.backward()
@@ -325,7 +335,8 @@ def test_generator_gan_step_matches_reference(golden_dir, dtype, tol, kind):
         return
     assert abs(float(loss.detach()) - ref) <= 2e-4 * abs(ref), (float(loss.detach()), ref)
     worst = golden_grad_check(lambda k: named[k].grad, grads, dtype, 140)
-    record_parity('generator_gan_step_vs_reference', dict(dtype=dtype, kind=kind, loss=float(loss.detach()), ref_loss=ref, rel_l2=worst))
+    record_parity('generator_gan_step_vs_reference', dict(dtype=dtype, kind=kind, loss=float(loss.detach()), ref_loss=ref, rel_l2=worst,
+                                                          lfq_aux_term='absent (weights 0)' if kind == 'gen_noaux' else 'self-derived golden (oracle/lfq.py restatement; upstream package absent)'))
 
 
 def test_gan_forward_surface():
