@@ -566,6 +566,8 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
             case 81: return launch_p8<bf16, 512, 4>(p, e, a_nrows, s);      // DMA 4 + 4 pieces per phase (timing only)
             case 83: return launch_p8<bf16, 1024, 4>(p, e, a_nrows, s);     // a phase's reads issued before its DMA pieces
             case 84: return launch_p8<bf16, 2048, 4>(p, e, a_nrows, s);     // half of the DMA pieces issued between the MFMAs
+            case 85: return launch_p8<bf16, 4096 + 64, 4>(p, e, a_nrows, s);   // + 4 ordinary VGPR buffer loads per k-tile between the MFMAs (timing only; vmcnt waits off: the extra loads change the counts)
+            case 88: return launch_p8<bf16, 4096 + 8192 + 64, 4>(p, e, a_nrows, s);   // + 16 of them per k-tile (what a one-wave-per-SIMD design would issue from its MFMA stream)
             case 86: return launch_p8<bf16, 32, 4>(p, e, a_nrows, s);       // v_mfma_f32_32x32x16_bf16 on the same operand registers (timing only)
             case 87: return launch_p8<bf16, 35, 4>(p, e, a_nrows, s);       // ... without loads
 #endif

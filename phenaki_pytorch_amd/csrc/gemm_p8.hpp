@@ -53,7 +53,15 @@ struct GemmP8 {
         char* smem;
         int piece0;                                       // wave * 2: first DMA piece of a half-tile this wave issues
         int rdA, rdB;                                     // per-lane LDS byte offsets of the fragment reads inside a half-tile, chunk 0 (chunk 1: ^ 64)
+        u32x4 rawA;                                       // (timing experiments) the A descriptor as plain dwords for inline-asm buffer loads
+        mutable f32x4 junk[4];
     };
+
+    // FLAGS & 4096 (timing only): what an ORDINARY 16-byte-per-lane buffer load to VGPRs costs a wave that is issuing MFMAs (the staging path of a one-wave-per-
+    // SIMD design).  Inline asm: the compiler sees no memory operation and inserts no s_waitcnt; the destination is kept alive and never read.
+    static __device__ __forceinline__ void vgpr_load(const Ctx& c, f32x4& dst, uint32_t voff, int koff) {
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(c.rawA), "s"(koff) : "memory");
+    }
 
     // half-tile TYPE (0: B0, 1: A0, 2: B1, 3: A1) of k-tile kt into ring slot SLOT
     static __device__ __forceinline__ void issue(const int TYPE, const int SLOT, const Ctx& c, int kt, bool inloop = true, const int pieces = 3) {
@@ -165,6 +173,10 @@ struct GemmP8 {
         c.bytesA = (uint32_t)a_nrows * (uint32_t)p.lda * SZ;
         c.bytesW = (uint32_t)p.N * (uint32_t)p.ldw * SZ;
         c.rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, c.bytesA, 0x00020000);
+        {
+            const uint64_t ab = reinterpret_cast<uint64_t>(p.A);
+            c.rawA = u32x4{(uint32_t)ab, (uint32_t)(ab >> 32) & 0xFFFFu, c.bytesA, 0x00020000u};
+        }
         c.rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, c.bytesW, 0x00020000);
         const int lrow = lane >> 3, lslot = lane & 7, srcslot = lslot ^ (lrow & 7);
 #pragma unroll
@@ -278,6 +290,12 @@ struct GemmP4 : GemmP8<T, FLAGS> {
         P::bar();
         if (FLAGS & 128) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
         P::quad(acc[0][0], fa, fb0);
+        if (FLAGS & 4096) {                               // timing only: EXTRA ordinary VGPR loads among the MFMAs (2 or, with & 8192, 8 per phase)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < ((FLAGS & 8192) ? 8 : 2); ++u) P::vgpr_load(c, c.junk[u & 3], c.offA[u & 1][(u >> 1) & 1], ((kt + 1) % c.nt) * P::ROWB);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         P::quad(acc[0][1], fa, fb1);
         P::bar();
         // ---- phase 1
@@ -289,6 +307,12 @@ struct GemmP4 : GemmP8<T, FLAGS> {
         P::bar();
         if (FLAGS & 128) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
         P::quad(acc[1][1], fa, fb1);
+        if (FLAGS & 4096) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < ((FLAGS & 8192) ? 8 : 2); ++u) P::vgpr_load(c, c.junk[u & 3], c.offA[u & 1][(u >> 1) & 1], ((kt + 1) % c.nt) * P::ROWB);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         P::quad(acc[1][0], fa, fb0);
         P::bar();
     }
@@ -313,6 +337,9 @@ struct GemmP4 : GemmP8<T, FLAGS> {
     }
 };
 
+// (GemmP4b -- ALL 24 fragment reads of a k-tile in phase 0 (+32 VGPRs: 250), ALL 8 DMA pieces of k-tile t + 2 in phase 1, one vmcnt(8) per k-tile -- was built on the
+//  reading that a DMA piece beside ds_read traffic is what makes a load part long; bit-identical, 1.323 vs 1.309 PF at 8192^3 and equal on the K = 512 shapes: no gain,
+//  removed.  profiles/gemm_p8_r06.txt.)
 // (A persistent tile-stream form of this loop -- one workgroup per CU walking a tile list with the ring running on across tile boundaries, the next
 //  tile's first k-tiles prefetched under the current tile's last, a register-lean epilogue between -- was built in round 6, parity-green, and measured
 //  SLOWER than one tile per workgroup on every shape (profiles/gemm_p8_r06.txt: 8192^3 1.13-1.19 vs 1.33-1.35 PF; 36864 x 2736 x 512 with the GEGLU
