@@ -358,7 +358,7 @@ static int launch_dma(const GemmOperands& p, const GemmEpilogue& e, int a_nrows,
 template <typename T, int FLAGS, int PH> struct P8Pick { typedef GemmP8<T, FLAGS> type; };
 template <typename T, int FLAGS> struct P8Pick<T, FLAGS, 4> { typedef GemmP4<T, FLAGS> type; };
 
-template <typename T, int FLAGS = 0, int PH = 8>
+template <typename T, int FLAGS = 0, int PH = 8, int LNF = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm_p8_kernel(const GemmOperands p, const GemmEpilogue e, int a_nrows) {
     using Tile = typename P8Pick<T, FLAGS, PH>::type;
@@ -407,23 +407,53 @@ void gemm_p8_kernel(const GemmOperands p, const GemmEpilogue e, int a_nrows) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0, 0, 0, 0};
-        Tile::run(p, a_nrows, m0, n0, smem, acc);
-        // (four explicit calls: inside a loop over (a, b) hipcc keeps the accumulators in scratch for the epilogue)
-        gemm_epilogue<T, 4, 2, 4>(acc[0][0], p.M, p.N, e, m0, n0);
-        gemm_epilogue<T, 4, 2, 4>(acc[0][1], p.M, p.N, e, m0, n0 + 128);
-        gemm_epilogue<T, 4, 2, 4>(acc[1][0], p.M, p.N, e, m0 + 128, n0);
-        gemm_epilogue<T, 4, 2, 4>(acc[1][1], p.M, p.N, e, m0 + 128, n0 + 128);
+        if constexpr (LNF == 2) {
+            // LayerNorm folded into this GEMM with the row statistics its producer left (e.ln_stats; see gemm_dma_kernel): 512 threads = 2 per tile row,
+            // each prefetches half of the row's partials ahead of the main loop; sums, the pair fold and the hand-over through LDS happen after it
+            constexpr int NPRE = 8;
+            const int srow = threadIdx.x >> 1, sq2 = threadIdx.x & 1;
+            const int per = (e.stats_np + 1) / 2, c0 = sq2 * per, c1 = min(c0 + per, e.stats_np);
+            const float2* st = reinterpret_cast<const float2*>(e.ln_stats) + (size_t)min(m0 + srow, p.M - 1) * e.stats_np;
+            float su = 0.f, sq = 0.f;
+            for (int c = c0 + NPRE; c < c1; ++c) { const float2 pr = st[c]; su += pr.x; sq += pr.y; }      // K > 512 only
+            float2 pre[NPRE];
+#pragma unroll
+            for (int u = 0; u < NPRE; ++u) pre[u] = c0 + u < c1 ? st[c0 + u] : float2{0.f, 0.f};
+            Tile::run(p, a_nrows, m0, n0, smem, acc);         // ends with a workgroup barrier: the ring is dead
+#pragma unroll
+            for (int u = 0; u < NPRE; ++u) { su += pre[u].x; sq += pre[u].y; }
+            su += __shfl_xor(su, 1); sq += __shfl_xor(sq, 1);
+            float2* ls = reinterpret_cast<float2*>(smem);
+            if (sq2 == 0) ls[srow] = float2{su, sq};
+            __syncthreads();
+            const int lane = threadIdx.x & 63, wr = threadIdx.x >> 8;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                float rsum[4], rsq[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const float2 pr = ls[a * 128 + wr * 64 + i * 16 + (lane & 15)]; rsum[i] = pr.x; rsq[i] = pr.y; }
+                gemm_epilogue<T, 4, 2, 4, true>(acc[a][0], p.M, p.N, e, m0 + a * 128, n0, rsum, rsq, p.K);
+                gemm_epilogue<T, 4, 2, 4, true>(acc[a][1], p.M, p.N, e, m0 + a * 128, n0 + 128, rsum, rsq, p.K);
+            }
+        } else {
+            Tile::run(p, a_nrows, m0, n0, smem, acc);
+            // (four explicit calls: inside a loop over (a, b) hipcc keeps the accumulators in scratch for the epilogue)
+            gemm_epilogue<T, 4, 2, 4>(acc[0][0], p.M, p.N, e, m0, n0);
+            gemm_epilogue<T, 4, 2, 4>(acc[0][1], p.M, p.N, e, m0, n0 + 128);
+            gemm_epilogue<T, 4, 2, 4>(acc[1][0], p.M, p.N, e, m0 + 128, n0);
+            gemm_epilogue<T, 4, 2, 4>(acc[1][1], p.M, p.N, e, m0 + 128, n0 + 128);
+        }
     }
 }
 
-template <typename T, int FLAGS = 0, int PH = 8>
+template <typename T, int FLAGS = 0, int PH = 8, int LNF = 0>
 static int launch_p8(const GemmOperands& p, const GemmEpilogue& e, int a_nrows, hipStream_t s) {
     using Tile = typename P8Pick<T, FLAGS, PH>::type;
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PK_ELAUNCH;
     if (!attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_kernel<T, FLAGS, PH>), hipFuncAttributeMaxDynamicSharedMemorySize, Tile::SMEM) != hipSuccess) return PK_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_kernel<T, FLAGS, PH, LNF>), hipFuncAttributeMaxDynamicSharedMemorySize, Tile::SMEM) != hipSuccess) return PK_ELAUNCH;
         attr_set[dev] = true;
     }
     const int MT = (p.M + Tile::BM - 1) / Tile::BM, NT = (p.N + Tile::BN - 1) / Tile::BN;
@@ -431,7 +461,7 @@ static int launch_p8(const GemmOperands& p, const GemmEpilogue& e, int a_nrows, 
     GemmOperands pp = p;
     static const int panel_env = [] { const char* e_ = getenv("PK_GEMM_PANEL"); return e_ ? atoi(e_) : -1; }();
     pp.panel = panel_env >= 0 ? panel_env : xcd_panel_rows(Tile::BM, p.K, (int)sizeof(T));
-    hipLaunchKernelGGL((gemm_p8_kernel<T, FLAGS, PH>), grid, dim3(Tile::THREADS), Tile::SMEM, s, pp, e, a_nrows);
+    hipLaunchKernelGGL((gemm_p8_kernel<T, FLAGS, PH, LNF>), grid, dim3(Tile::THREADS), Tile::SMEM, s, pp, e, a_nrows);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }
@@ -523,6 +553,11 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
         // LayerNorm-folded GEMM: LDS-DMA main loop only (the statistics come from its A fragments), vector epilogue, 64x64 / 128x128 tiles
         if (!dma_ok || !v || !al16(ln_s) || !al16(ln_t) || a_rows) return PK_EINVAL;
         const bool big = variant == 24 || variant == 2 || variant == 9;
+#ifdef PK_P8_ABLATE
+        if (ln_stats && variant == 50 && dtype != 0) {         // the two-group 256 x 256 loop with the producer's row statistics (measured, not used: see below)
+            return dtype == 1 ? launch_p8<bf16, 0, 4, 2>(p, e, a_nrows, s) : launch_p8<bf16x3, 0, 4, 2>(p, e, a_nrows, s);
+        }
+#endif
         if (ln_stats) {
             if (dtype == 1) return big ? launch_dma<bf16, 4, 2, 2, 2, 4, 128, 0, 2>(p, e, a_nrows, s) : launch_dma<bf16, 2, 2, 2, 2, 2, 128, 0, 2>(p, e, a_nrows, s);
             // split-bf16 (round 4): the 4-wave 128x128 tile of that mode (2 threads per row fetch the partials)
@@ -588,6 +623,12 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
             case 9: return launch_dma<bf16x3, 4, 4, 2>(p, e, a_nrows, s);
             case 24: return launch_dma<bf16x3, 4, 2, 2, 2, 4>(p, e, a_nrows, s);
             case 27: return launch_dma<bf16x3, 4, 2, 2, 2, 2>(p, e, a_nrows, s);
+#ifdef PK_P8_ABLATE
+            // the 256 x 256 two-group loop on the (hi | lo) operand images (gemm_p8.hpp, SPLIT): bit-identical to variant 24, measured in round 6 and NOT used --
+            // split-bf16 is bound by its three MFMAs per product, not by the fill: 8192^3 390 vs 352 TF-equivalent, FF1 at 9216 rows 111 vs 104 us, at 4608 rows
+            // 107 vs 61 us (profiles/gemm_p8_r06.txt)
+            case 50: return launch_p8<bf16x3, 0, 4>(p, e, a_nrows, s);
+#endif
             default: return PK_EINVAL;
         }
     }

@@ -31,7 +31,10 @@ namespace pk {
 // 8 no s_setprio, 16 fragment reads retired BEFORE the phase's first barrier
 template <typename T, int FLAGS = 0>
 struct GemmP8 {
-    static_assert(sizeof(T) == 2, "bf16 operands");
+    // T = bf16: both operand tiles hold bf16 (k-tile 64).  T = bf16x3 (split-bf16, common.hpp): the A tile holds f32 rows (k-tile 32), split into (hi, lo) planes in
+    // registers right after the ds_reads -- in the LOAD part of a phase, beside the partner's MFMAs -- and the W tile holds the host-packed planes [hi x 32 | lo x 32];
+    // a fragment pair is three MFMAs, so a phase carries 48 of them against the same 64 KB of DMA per k-tile: the fill bytes per MFMA cycle are 2/3 of bf16's.
+    static constexpr bool SPLIT = sizeof(T) == 4;
     static constexpr int BM = 256, BN = 256, THREADS = 512, ROWB = 128;
     static constexpr int BK = ROWB / (int)sizeof(T);
     static constexpr int CH = BK / 32;
@@ -80,14 +83,34 @@ struct GemmP8 {
         }
     }
 
+    // NF = 4: A fragments (rows of the wave's 64-row sub-tile), NF = 2: W fragments (its 32 columns)
     template <int SLOT, int NF>
     static __device__ __forceinline__ void read_frags(const Ctx& c, int rd, Frag<T> (&f)[NF][CH], bool inloop = true) {
         if ((FLAGS & 2) && inloop) return;
         const char* s = c.smem + SLOT * HALF;
+        if constexpr (!SPLIT) {
 #pragma unroll
-        for (int i = 0; i < NF; ++i)
+            for (int i = 0; i < NF; ++i)
 #pragma unroll
-            for (int ch = 0; ch < CH; ++ch) f[i][ch].v = *reinterpret_cast<const u32x4*>(s + ((rd + i * 16 * ROWB) ^ (ch * 64)));
+                for (int ch = 0; ch < CH; ++ch) f[i][ch].v = *reinterpret_cast<const u32x4*>(s + ((rd + i * 16 * ROWB) ^ (ch * 64)));
+        } else if constexpr (NF == 2) {
+            // W planes: k = g*8 .. +7 of a row is slot g (hi) and slot 4 + g (lo), both ^ (row & 7): the lo slot is the hi slot ^ 4, i.e. byte ^ 64
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                f[i][0].hi = *reinterpret_cast<const u32x4*>(s + (rd + i * 16 * ROWB));
+                f[i][0].lo = *reinterpret_cast<const u32x4*>(s + ((rd + i * 16 * ROWB) ^ 64));
+            }
+        } else {
+            // f32 A rows: k = g*8 .. +7 is slots 2g, 2g + 1 (^ (row & 7)): the second is the first ^ 1, i.e. byte ^ 16.  All reads first, then the splits.
+            f32x4 lo4[NF], hi4[NF];
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                lo4[i] = *reinterpret_cast<const f32x4*>(s + (rd + i * 16 * ROWB));
+                hi4[i] = *reinterpret_cast<const f32x4*>(s + ((rd + i * 16 * ROWB) ^ 16));
+            }
+#pragma unroll
+            for (int i = 0; i < NF; ++i) split8(lo4[i], hi4[i], f[i][0].hi, f[i][0].lo);
+        }
     }
 
     static __device__ __forceinline__ void quad(f32x4 (&q)[4][2], const Frag<T> (&fa)[4][CH], const Frag<T> (&fb)[2][CH]) {
@@ -196,7 +219,7 @@ struct GemmP8 {
         const int ktail_bytes = (p.K * SZ) % ROWB;
         c.slot_in_tail = ktail_bytes == 0 || srcslot * 16 < ktail_bytes;
         // fragment reads: row (base + lr) of a half-tile, 16-B slot (ch*4 + g) ^ (row & 7); row bases are multiples of 16, so row & 7 = lr & 7
-        c.rdA = (wr * 64 + lr) * ROWB + ((g ^ (lr & 7)) << 4);
+        c.rdA = (wr * 64 + lr) * ROWB + (((SPLIT ? 2 * g : g) ^ (lr & 7)) << 4);
         c.rdB = (wc * 32 + lr) * ROWB + ((g ^ (lr & 7)) << 4);
     }
 

@@ -70,8 +70,8 @@ def main():
         big = (M * N) >= (1 << 28)
         C = torch.empty(M, N, device='cuda', dtype=torch.bfloat16 if (big and args.mode == 'bf16') else torch.float32)
         kw = {}
-        if args.geglu and N % 2 == 0 and args.mode == 'bf16':
-            C = torch.empty(M, N // 2, device='cuda', dtype=torch.bfloat16)
+        if args.geglu and N % 2 == 0 and args.mode in ('bf16', 'bf16x3'):
+            C = torch.empty(M, N // 2, device='cuda', dtype=torch.bfloat16 if args.mode == 'bf16' else torch.float32)
             kw = dict(bias=torch.randn(N, device='cuda'), act=L.ACT_GEGLU)
         if args.res and C.dtype == torch.float32:
             kw = dict(bias=torch.randn(N, device='cuda'), res=torch.randn(M, N, device='cuda'))
