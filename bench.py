@@ -219,7 +219,7 @@ def capture(fn):
 VARIANT_KERNEL = {1: 'gemm_kernel<T,TA,2,2>', 2: 'gemm_kernel<T,TA,4,4>', 3: 'gemm_dma_kernel<T,2,2,2,2,4,128,0,0>',
                   8: 'gemm_dma_kernel<T,2,2,2,2,2,128,0,0>', 9: 'gemm_dma_kernel<T,4,4,2,2,2,128,0,0>',
                   24: 'gemm_dma_kernel<T,4,2,2,4,2,128,0,0>', 27: 'gemm_dma_kernel<T,4,2,2,2,2,128,0,0>',
-                  33: 'gemm_dma_kernel<T,2,2,2,2,3,128,2,0>'}
+                  33: 'gemm_dma_kernel<T,2,2,2,2,3,128,2,0>', 50: 'gemm_p8_kernel<T,0,4,0>'}
 
 
 def _esz(t):

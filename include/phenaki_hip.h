@@ -46,8 +46,9 @@ int pk_gemm(int dtype, int a_is_f32, const void* A, int lda, const void* W, int 
             const float* bias, const float* res, int ldr, void* C, int ldc, int out_is_f32, int act,
             const int* a_rows, void* stream);
 
-/* pk_gemm with an explicit main-loop variant (0 = automatic; 1/2 = register-staged 64x64 / 128x128 tiles; 8, 9, 24, 33, 3 = the
- * LDS-DMA ring variants that survived the round-1 sweep, see csrc/gemm.hip) and the number of physical rows behind a gathered A (bounds of the DMA descriptor).
+/* pk_gemm with an explicit main-loop variant (0 = automatic; 1/2 = register-staged 64x64 / 128x128 tiles; 8, 9, 24, 27, 33, 3 = the
+ * LDS-DMA ring variants that survived the round-1 sweep; 50 (bf16, round 6) = the 256x256 two-group loop of csrc/gemm_p8.hpp, what `automatic` picks for
+ * K >= 2048 with >= 512 such tiles; see csrc/gemm.hip) and the number of physical rows behind a gathered A (bounds of the DMA descriptor).
  * The DMA variants need A in T and ldw >= K rounded up to the k-tile (64 bf16 / 32 f32) with zero padding.
  * C2 (bf16 [M][ldc2], or NULL): a second copy of an f32 result for the next GEMM's LDS-DMA operand (dtype 1 only).
  * ln_s / ln_t ([N] f32, or both NULL): the LayerNorm that precedes this nn.Linear in the reference (attention.py:47,142,
