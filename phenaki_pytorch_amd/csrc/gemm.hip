@@ -584,6 +584,8 @@ extern "C" int pk_gemm_ex(int dtype, int a_is_f32, const void* A, int lda, const
             case 50: return launch_p8<bf16, 0, 4>(p, e, a_nrows, s);                    // 256x256, 8 waves in two groups a barrier apart, 2 phases per k-tile (gemm_p8.hpp), 1 WG/CU
 #ifdef PK_P8_ABLATE
             // tools/gemm_bench.py ablations behind profiles/gemm_p8_r06.txt (build with PK_EXTRA_HIPCC_FLAGS=-DPK_P8_ABLATE); FLAGS are listed in gemm_p8.hpp
+            case 55: return launch_dma<bf16, 8, 8, 2, 2, 2>(p, e, a_nrows, s);   // ONE wave per SIMD: 256 x 256 tile, 4 waves of 128 x 128 (256 accumulator registers), the plain 2-stage ring
+            case 56: return launch_dma<bf16, 8, 4, 3, 2, 2>(p, e, a_nrows, s);   // 256 x 128, 4 waves of 128 x 64, 3 stages (144 KB)
             case 60: return launch_p8<bf16, 0, 8>(p, e, a_nrows, s);        // the 8-phase form (16 MFMAs per phase)
             case 61: return launch_p8<bf16, 1, 8>(p, e, a_nrows, s);
             case 62: return launch_p8<bf16, 2, 8>(p, e, a_nrows, s);
