@@ -378,7 +378,8 @@ int pk_bce_head(const float* e, long long lde, const float* w, const float* b, c
  * Kc = K / splits (a multiple of the k-tile), z < splits, as `splits` partial (M, N) f32 matrices at C + z * M * ldc; add them with pk_sum_batch.
  * A: T for dtype 1, f32 for dtype 0 / 2; W: the operand image of the dtype.
  * bias ([N] or NULL) is added by slice 0 only (the sum of the slices carries it once); tile 0: 64 x 64 tiles, 1: 128 x 128 (long K-slices of a large
- * (M, N): the patch-embedding product of the exact-f32 / split-bf16 modes, K = 6144). */
+ * (M, N): the patch-embedding product of the exact-f32 / split-bf16 modes, K = 6144), 2 (dtype 1 only, round 6): 256 x 256 tiles on the two-group loop of
+ * csrc/gemm_p8.hpp -- few tiles, long K. */
 int pk_gemm_splitk(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, int splits, float* C, int ldc,
                    const float* bias, int tile, void* stream);
 /* AdamW / Adam update of one parameter tensor (reference optimizer.py:11-37 hands MaskGit's parameters to torch.optim.AdamW / Adam):

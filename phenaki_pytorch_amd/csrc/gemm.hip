@@ -466,6 +466,52 @@ static int launch_p8(const GemmOperands& p, const GemmEpilogue& e, int a_nrows, 
     return PK_OK;
 }
 
+// split-K form of the two-group 256 x 256 loop (bf16; pk_gemm_splitk tile = 2): grid.y slices the contraction exactly like gemm_dma_splitk_kernel; for products whose
+// 256 x 256 tiles are far fewer than the CUs while K is long (the patch-embedding shape 4096 x 512 x 6144: 32 tiles x 8 slices of 12 k-tiles)
+template <typename T>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gemm_p8_splitk_kernel(GemmOperands p, GemmEpilogue e, int a_nrows, long batch_a, long batch_w, long batch_c) {
+    using Tile = GemmP4<T, 0>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int z = blockIdx.y;
+    p.A = reinterpret_cast<const char*>(p.A) + (size_t)z * batch_a;
+    p.W = reinterpret_cast<const char*>(p.W) + (size_t)z * batch_w;
+    e.C = reinterpret_cast<char*>(e.C) + (size_t)z * batch_c;
+    if (z != 0) e.bias = nullptr;
+    const int MT = (p.M + Tile::BM - 1) / Tile::BM, NTn = (p.N + Tile::BN - 1) / Tile::BN;
+    if ((int)blockIdx.x >= MT * NTn) return;
+    const int m0 = (blockIdx.x % MT) * Tile::BM, n0 = (blockIdx.x / MT) * Tile::BN;
+    typename Tile::Acc acc;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0, 0, 0, 0};
+    Tile::run(p, a_nrows, m0, n0, smem, acc);
+    gemm_epilogue<T, 4, 2, 4>(acc[0][0], p.M, p.N, e, m0, n0);
+    gemm_epilogue<T, 4, 2, 4>(acc[0][1], p.M, p.N, e, m0, n0 + 128);
+    gemm_epilogue<T, 4, 2, 4>(acc[1][0], p.M, p.N, e, m0 + 128, n0);
+    gemm_epilogue<T, 4, 2, 4>(acc[1][1], p.M, p.N, e, m0 + 128, n0 + 128);
+}
+
+static int launch_p8_splitk(const GemmOperands& p, const GemmEpilogue& e, int a_nrows, int splits, long ba, long bw, long bc, hipStream_t s) {
+    using Tile = GemmP4<bf16, 0>;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PK_ELAUNCH;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p8_splitk_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, Tile::SMEM) != hipSuccess) return PK_ELAUNCH;
+        attr_set[dev] = true;
+    }
+    const int MT = (p.M + Tile::BM - 1) / Tile::BM, NT = (p.N + Tile::BN - 1) / Tile::BN;
+    hipLaunchKernelGGL((gemm_p8_splitk_kernel<bf16>), dim3(MT * NT, splits), dim3(Tile::THREADS), Tile::SMEM, s, p, e, a_nrows, ba, bw, bc);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
 }  // namespace pk
 
 using namespace pk;
@@ -675,7 +721,7 @@ extern "C" int pk_gemm(int dtype, int a_is_f32, const void* A, int lda, const vo
 extern "C" int pk_gemm_splitk(int dtype, const void* A, int lda, const void* W, int ldw, int M, int N, int K, int splits, float* C, int ldc,
                               const float* bias, int tile, void* stream) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || splits < 1 || splits > 64 || (dtype != 0 && dtype != 1 && dtype != 2)) return PK_EINVAL;
-    if (tile != 0 && tile != 1) return PK_EINVAL;
+    if (tile != 0 && tile != 1 && !(tile == 2 && dtype == 1)) return PK_EINVAL;      // tile 2: 256 x 256 two-group loop, bf16 only
     const int bk = dtype == 1 ? 64 : 32, esz = dtype == 1 ? 2 : 4;
     if (K % (splits * bk) || (N & 3) || (ldc & 3) || ldc < N) return PK_EINVAL;
     if (!al16(A) || !al16(W) || !al16(C) || (bias && !al16(bias)) || lda % (16 / esz) || ldw % (16 / esz)) return PK_EALIGN;
@@ -685,6 +731,7 @@ extern "C" int pk_gemm_splitk(int dtype, const void* A, int lda, const void* W, 
     GemmEpilogue e{bias, nullptr, C, 0, ldc, 1, ACT_NONE, 1};
     const long ba = (long)Kc * esz, bw = (long)Kc * esz, bc = (long)M * ldc * 4;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (tile == 2) return launch_p8_splitk(p, e, M, splits, ba, bw, bc, s);
     if (tile == 1) {                                       // 128 x 128 tiles: half the fill bytes per flop; for LONG K-slices of a big (M, N)
         if (dtype == 1) return launch_splitk<bf16, 4, 4>(p, e, M, splits, ba, bw, bc, s);
         if (dtype == 2) return launch_splitk<bf16x3, 4, 4>(p, e, M, splits, ba, bw, bc, s);

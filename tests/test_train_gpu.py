@@ -586,3 +586,16 @@ def test_gemm_splitk_matches_plain_product(dtype, tol):
         out = torch.empty((N, K), device='cuda')
         L.sum_batch(part, splits, out, N * K)
         close(out.cpu(), want + bias, tol, f'split-K x{splits}, 128-wide tiles + bias ({dtype})')
+    # round 6: 256 x 256 tiles on the two-group loop (bf16 only; the other operand types are refused)
+    for splits in (2, 4):
+        if Mp % (splits * q):
+            continue
+        part = torch.full((splits, N * K), float('nan'), device='cuda')
+        if dtype != 'bf16':
+            with pytest.raises(RuntimeError):
+                L.gemm_splitk(dt, dyT, xT, N, K, Mp, splits, part, tile=2)
+            break
+        L.gemm_splitk(dt, dyT, xT, N, K, Mp, splits, part, bias=bias.cuda(), tile=2)
+        out = torch.empty((N, K), device='cuda')
+        L.sum_batch(part, splits, out, N * K)
+        close(out.cpu(), want + bias, tol, f'split-K x{splits}, 256-wide tiles + bias ({dtype})')

@@ -44,6 +44,7 @@ def main():
     ap.add_argument('--shapes', type=str, default='', help='comma list of shape indices, default all')
     ap.add_argument('--res', action='store_true', help='add bias + f32 residual (the out-projection epilogue)')
     ap.add_argument('--geglu', action='store_true', help='GEGLU epilogue with a T (bf16) output of N / 2 columns: what the FF1 calls of the hot path run (even N only)')
+    ap.add_argument('--splitk256', type=int, default=0, help='also time pk_gemm_splitk(tile=2) with this many K-slices + pk_sum_batch (bf16, f32 C)')
     ap.add_argument('--no-yardstick', action='store_true')
     ap.add_argument('--out', default='gpurun_out/gemm_bench.json')
     args = ap.parse_args()
@@ -92,6 +93,19 @@ def main():
             yard = {'mm(A, W^T view)': lambda: torch.mm(Ay, Wy.t()), 'mm(A, Wt contiguous)': lambda: torch.mm(Ay, Wt)}
             for f in yard.values():
                 f()
+        # split-K on the 256 x 256 two-group loop (pk_gemm_splitk tile = 2 + pk_sum_batch): for shapes with few tiles and a long K
+        if args.mode == 'bf16' and args.splitk256 and C.dtype == torch.float32 and not kw and K % (64 * args.splitk256) == 0:
+            part = torch.empty(args.splitk256, M * N, device='cuda')
+
+            def sk(part=part):
+                L.gemm_splitk(dt, A, W, M, N, K, args.splitk256, part, tile=2)
+                L.sum_batch(part, args.splitk256, C, M * N)
+            sk()
+            if K <= 8192 and M * N <= (1 << 22):
+                ref = (A.double() @ W[:, :K].double().t()).float()
+                assert (C - ref).abs().max() <= 3e-5 * ref.abs().max(), 'split-K 256 result differs from the f64 product'
+            yard = dict(yard)
+            yard[f'splitK{args.splitk256} x 256^2 + sum'] = sk
         torch.cuda.synchronize()
         times = {k: [] for k in list(live) + list(yard)}
         iters = max(2, args.iters // 8) if M * N * K > 1e11 else args.iters
