@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-4 evidence on ONE box: full GPU tests (parity records), smoke, the bench exactly as the driver runs it, the split-bf16 first-frame split-K A/B,
+# round evidence on ONE box: full GPU tests (parity records), smoke, the bench exactly as the driver runs it, the split-bf16 first-frame split-K A/B,
 # rocprofv3 kernel stats (encode leg, all legs, training legs) and the PMC traffic passes
 set -u
 cd "$(dirname "$0")/.."
