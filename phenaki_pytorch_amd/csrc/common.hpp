@@ -220,7 +220,13 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 template <typename T> __device__ __forceinline__ float gelu_for(float x);
 template <> __device__ __forceinline__ float gelu_for<float>(float x) { return gelu_erf(x); }
 template <> __device__ __forceinline__ float gelu_for<bf16>(float x) { return gelu_erf_fast(x); }
+// split-bf16: the products in front of this GELU carry ~1e-5 relative error; the 1.5e-7 absolute error of the rational erf is two orders below that, and libm's branchy
+// erff was 20 % of the FF1 launch in that mode (round 6 A/B, profiles/parity_gelu_r06.txt).  PK_X3_EXACT_GELU: the round-5 behaviour, for that A/B.
+#ifdef PK_X3_EXACT_GELU
 template <> __device__ __forceinline__ float gelu_for<bf16x3>(float x) { return gelu_erf(x); }
+#else
+template <> __device__ __forceinline__ float gelu_for<bf16x3>(float x) { return gelu_erf_fast(x); }
+#endif
 
 // ---- counter-based uniform noise shared by the sampler kernels and their tests -------------
 // u = hash(seed, stream, index) mapped to [0, 1) with 24 bits, the same granularity torch's
