@@ -252,6 +252,11 @@ int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void* Vt, const
                 int bias_ld, const unsigned char* kmask, const float* slopes, int causal, void* O, int ldo,
                 int out_is_f32, int S, int h, int nq, int n_kv, int nnull, const float* bias_tab, int tab_len,
                 const int* pos_code, int code_off, int tab_run4, float score_bound, void* stream);
+/* The training forward (attention.py:157-182 under autograd): the same product, and lse[(s h + hh) nq + i] = log sum_j exp(score row i) for the
+ * backward kernels (pk_attn_bwd with bit 1 of its flag word set skips the pass that recomputed it).  LDS-free kernel; no bias table / score bound. */
+int pk_attn_fwd_lse(int dtype, const void* Qp, const void* Kp, const void* Vt, const float* bias, long bias_hstride,
+                    int bias_ld, const unsigned char* kmask, const float* slopes, int causal, void* O, int ldo,
+                    int out_is_f32, int S, int h, int nq, int n_kv, int nnull, float* lse, void* stream);
 /* score_bound: an upper bound of sim + bias over every (head, query, key), or NaN.  q^ and k^ are unit vectors times q_scale / k_scale,
  * so |sim| <= scale * max_d |q_scale_d k_scale_d| and the caller knows the maximum of its bias: with a finite bound (and no key
  * mask, not causal, bf16, >= 64 queries and keys) the softmax numerators are p = 2^(s log2(e) - ceil(bound log2(e))) -- no running
@@ -337,9 +342,22 @@ int pk_critic_head(const float* x, int ldx, const float* w, const float* b, int 
  *   elements per row; kind 0 f32, 1 bf16, 2 the split-bf16 image (128-byte aligned, ldo % 32 == 0).  dX = dY W takes W^T, dW = dY^T X takes
  *   dY^T as A and X^T as the "W" operand (the contraction index of pk_gemm is the contiguous one). */
 int pk_pack(const float* src, long long lds, const int* rows, int R, int K, int transpose, void* out, long long ldo, int Kp, int kind, void* stream);
+/* Several pk_pack jobs in ONE launch (round 6; the reference has no counterpart: under autograd each of these is an ATen transpose / cast inside
+ * F.linear's backward, attention.py:45-53, :117-119).  A job = one output block, flags = transpose | kind << 1, alignment rules of pk_pack except
+ * that `out` may be any 16-byte aligned position inside a 128-byte aligned kind-2 image (a column block of it); tile0 / tiles_x are filled in by
+ * the library.  pk_pack_multi: count <= 8 HOST jobs, carried in the kernel arguments (the activation transposes of one backward block).
+ * pk_pack_table_prepare + pk_pack_table: any number of jobs -- prepare fills a HOST array and returns the tile count of the launch (< 0: error),
+ * the caller keeps a copy in DEVICE memory and replays it every step (the persistent operand images of a Transformer's weights). */
+typedef struct PkPackJob {
+    const float* src; void* out; long long lds, ldo; int R, K, Kp, flags, tile0, tiles_x;
+} PkPackJob;
+int pk_pack_multi(const void* jobs, int count, void* stream);
+int pk_pack_table_prepare(void* jobs, int count);
+int pk_pack_table(const void* dev_table, int count, int tiles, void* stream);
 /* rows (or NULL) gathers SOURCE rows: out[r][k] = src[rows[k]][r] (transpose) / src[rows[r]][k].   pk_scatter_rows: dst[rows[m]] = src[m], m < M */
 int pk_scatter_rows(const float* src, long long lds, const int* rows, float* dst, long long ldd, int M, int D, void* stream);
-/* out[c] (accumulate ? += : =) scale * sum_r src[r][c], two deterministic stages; work: pk_colsum_parts(M) * N floats */
+/* out[c] (accumulate ? += : =) scale * sum_r src[r][c], two deterministic stages (one launch when M <= 1024 and the rows are float4-addressable,
+ * or M <= 256: the per-block partials of the backward kernels); work: pk_colsum_parts(M) * N floats */
 int pk_colsum_parts(int M);
 int pk_colsum(const float* src, long long ld, int M, int N, float scale, float* out, int accumulate, float* work, void* stream);
 /* LayerNorm backward (attention.py:29-36, :47): dx = [add +] rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma; pg / pb (pb may be NULL):
@@ -370,6 +388,9 @@ int pk_bias_gather(const float* tab, int ldt, const int* code, int off, float* o
 int pk_bias_scatter(const float* dbias, const int* code, int off, float* dtab, int ldt, int heads, int n, void* stream);
 /* out[e] = sum_s src[s * stride + e], e < E (E % 4 == 0) */
 int pk_sum_batch(const float* src, long long stride, int S, float* out, long long E, void* stream);
+/* count <= 8 pk_sum_batch jobs in one launch (E4 = E / 4; blk0 is filled in by the library): the K-slice partials of one block's weight gradients */
+typedef struct PkSumJob { const float* src; float* out; long long stride, E4; int S, blk0; } PkSumJob;
+int pk_sum_batch_multi(const void* jobs, int count, void* stream);
 /* critic head + BCE-with-logits forward and backward in one pass (phenaki_pytorch.py:246-249, :673-676): logits / loss_rows (M) optional;
  * labels NULL: logits only; de = dz w with dz = (sigmoid(z) - y) scale; pw (pk_ln_bwd_parts(M), D) / pb (pk_ln_bwd_parts(M)) partials of dw / db */
 int pk_bce_head(const float* e, long long lde, const float* w, const float* b, const float* labels, float scale, const float* scale_dev, float* logits, float* loss_rows,
@@ -393,7 +414,10 @@ int pk_adamw_multi(const long long* table, int count, float lr, float beta1, flo
  * pk_attn_bwd: dQh / dKh / dVh from those, the forward output O (f32 or bf16) and dO; bias (heads, n, n_kv) / kmask (S, n_kv) cover the real keys;
  * dS (S heads, n, n_kv; optional) = the score gradient for the position-bias gradient (pk_sum_batch over S); lse / Drow: (S heads n) scratch;
  *   causal (attention.py:166-172, the C-ViViT temporal transformers): ALiBi slopes [heads] over all nnull + n keys and the causal mask;
- *   split_bf16 = 1: the tile products on the bf16 matrix cores from (hi, lo) splits of the f32 operands (the bf16x3 / bf16 modes), 0: exact f32.
+ *   split_bf16: a flag word -- bit 0: the tile products on the bf16 matrix cores from (hi, lo) splits of the f32 operands (the bf16x3 / bf16 modes),
+ *   else exact f32; bit 1: `lse` already holds every row's log-sum-exp (pk_attn_fwd_lse), else it is scratch the first kernel fills.
+ *   pq / pk may be the two 64-column halves of ONE (1024, 128) buffer (pk == pq + 64: rows are then 128 floats apart) so that one pk_colsum finishes
+ *   both; likewise pg / pb of pk_layernorm_bwd (pb == pg + D: rows 2 D apart).
  * pk_attn_train_prep_bwd: back through l2norm / scales / null keys: dq, dkv, partials pq / pk (1024, 64) of dq_scale / dk_scale, dnull (heads, 2 nnull, 64). */
 int pk_attn_train_prep(const float* q, long long ldq, const float* kv, long long ldkv, const float* null_kv, const float* q_scale, const float* k_scale,
                        float scale, float* Qh, float* Kh, float* Vh, int S, int heads, int n, int n_kv, int nnull, void* stream);

@@ -59,6 +59,7 @@ SIGNATURES = {
     'pk_qkv_attn': [_I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _L, _I, _P, _I, _P, _I, _P, _P],
     'pk_q_attn_cached': [_I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P],
     'pk_attn_fwd': [_I, _P, _P, _P, _P, _L, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _F, _P],
+    'pk_attn_fwd_lse': [_I, _P, _P, _P, _P, _L, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     'pk_attn_small': [_P, _I, _P, _I, _P, _P, _F, _P, _L, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     'pk_cfg_mix': [_P, _I, _I, _I, _I, _P, _I, _F, _I, _P, _I, _I, _I, _P],
     'pk_vocab_ntiles': [_I],
@@ -87,6 +88,10 @@ SIGNATURES = {
     'pk_bias_gather': [_P, _I, _P, _I, _P, _I, _I, _P],
     'pk_bias_scatter': [_P, _P, _I, _P, _I, _I, _I, _P],
     'pk_sum_batch': [_P, _LL, _I, _P, _LL, _P],
+    'pk_sum_batch_multi': [_P, _I, _P],
+    'pk_pack_multi': [_P, _I, _P],
+    'pk_pack_table_prepare': [_P, _I],
+    'pk_pack_table': [_P, _I, _I, _P],
     'pk_bce_head': [_P, _LL, _P, _P, _P, _F, _P, _P, _P, _P, _LL, _P, _P, _I, _I, _P],
     'pk_attn_train_prep': [_P, _LL, _P, _LL, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'pk_attn_train_prep_bwd': [_P, _LL, _P, _LL, _P, _P, _P, _F, _P, _P, _P, _P, _LL, _P, _LL, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -447,15 +452,22 @@ def q_attn_cached(xq, wq, S, n, h, K, q_scale, scale, Kp, Vt, nk_pad, n_kv, nnul
 
 
 def attn_fwd(dtype, Qp, Kp, Vt, O, S, h, nq, n_kv, nnull, *, bias=None, kmask=None, slopes=None, causal=False, bias_table=None,
-             score_bound=None):
+             score_bound=None, lse=None):
     """bias: full (h, nq, n_kv) f32 tensor, or bias_table = (tab (h, L) f32, pos_code (n,) int32, offset, ...): the relative-position
-    form.  score_bound: upper bound of sim + bias (python float) -> fixed-offset softmax; None: running-max flash loop."""
+    form.  score_bound: upper bound of sim + bias (python float) -> fixed-offset softmax; None: running-max flash loop.
+    lse ((S h nq,) f32; the training forward): also write every row's log-sum-exp for pk_attn_bwd."""
     tab, codes, off = bias_table[:3] if bias_table is not None else (None, None, 0)
     run4 = 1 if (bias_table is not None and len(bias_table) > 5 and bias_table[5]) else 0
     if bias is not None:
         bh, bld = bias.stride(0), bias.stride(1)
     else:
         bh, bld = 0, 0
+    if lse is not None:
+        assert bias_table is None and score_bound is None
+        rc = load().pk_attn_fwd_lse(dtype, ptr(Qp), ptr(Kp), ptr(Vt), ptr(bias), bh, bld, ptr(kmask), f32p(slopes, 'ALiBi slopes'),
+                                    1 if causal else 0, ptr(O), O.stride(-2), 1 if O.dtype == torch.float32 else 0, S, h, nq, n_kv, nnull, ptr(lse), stream(O))
+        _check(rc, 'pk_attn_fwd_lse')
+        return
     rc = load().pk_attn_fwd(dtype, ptr(Qp), ptr(Kp), ptr(Vt), ptr(bias), bh, bld, ptr(kmask), f32p(slopes, 'ALiBi slopes'),
                             1 if causal else 0, ptr(O), O.stride(-2), 1 if O.dtype == torch.float32 else 0,
                             S, h, nq, n_kv, nnull, f32p(tab, 'bias table'), tab.shape[1] if tab is not None else 0, ptr(codes), off, run4,
@@ -538,6 +550,57 @@ def pack(src, R, K, transpose, out, Kp, kind, rows=None):
     return out
 
 
+class PackJob(ctypes.Structure):
+    """include/phenaki_hip.h PkPackJob"""
+    _fields_ = [('src', ctypes.c_void_p), ('out', ctypes.c_void_p), ('lds', ctypes.c_longlong), ('ldo', ctypes.c_longlong), ('R', ctypes.c_int),
+                ('K', ctypes.c_int), ('Kp', ctypes.c_int), ('flags', ctypes.c_int), ('tile0', ctypes.c_int), ('tiles_x', ctypes.c_int)]
+
+
+class SumJob(ctypes.Structure):
+    """include/phenaki_hip.h PkSumJob"""
+    _fields_ = [('src', ctypes.c_void_p), ('out', ctypes.c_void_p), ('stride', ctypes.c_longlong), ('E4', ctypes.c_longlong), ('S', ctypes.c_int),
+                ('blk0', ctypes.c_int)]
+
+
+def pack_job(src, R, K, transpose, out, Kp, kind, *, src_ld=None, out_ptr=None, out_ld=None):
+    """one job of pack_multi / PackTable: out (R rows, Kp columns) = src or src^T (the OUTPUT has R rows and K data columns).  out_ptr / out_ld:
+    a block inside a larger image (byte address of its first element, row pitch in elements)."""
+    return PackJob(src.data_ptr(), out.data_ptr() if out_ptr is None else out_ptr, src.stride(-2) if src_ld is None else src_ld,
+                   out.stride(-2) if out_ld is None else out_ld, R, K, Kp, (1 if transpose else 0) | (kind << 1), 0, 0)
+
+
+def pack_multi(jobs, like):
+    """up to 8 pack jobs per launch (more: several launches)"""
+    for i in range(0, len(jobs), 8):
+        chunk = jobs[i:i + 8]
+        arr = (PackJob * len(chunk))(*chunk)
+        _check(load().pk_pack_multi(ctypes.addressof(arr), len(chunk), stream(like)), 'pk_pack_multi')
+
+
+class PackTable:
+    """a job list kept in device memory and replayed with ONE launch (`run`): the operand images of a module's weights, re-packed every step"""
+
+    def __init__(self, jobs, device):
+        arr = (PackJob * len(jobs))(*jobs)
+        tiles = load().pk_pack_table_prepare(ctypes.addressof(arr), len(jobs))
+        if tiles < 0:
+            _check(int(tiles), 'pk_pack_table_prepare')
+        self.count, self.tiles = len(jobs), int(tiles)
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+
+    def run(self):
+        _check(load().pk_pack_table(ptr(self.table), self.count, self.tiles, stream(self.table)), 'pk_pack_table')
+
+
+def sum_batch_multi(jobs):
+    """jobs: [(part (S, >= E) f32, S, out, E)]: out[e] = sum_s part[s][e], up to 8 per launch"""
+    for i in range(0, len(jobs), 8):
+        chunk = jobs[i:i + 8]
+        arr = (SumJob * len(chunk))(*[SumJob(p.data_ptr(), o.data_ptr(), p.stride(0), E // 4, S, 0) for p, S, o, E in chunk])
+        assert all(E % 4 == 0 for _, _, _, E in chunk)
+        _check(load().pk_sum_batch_multi(ctypes.addressof(arr), len(chunk), stream(chunk[0][0])), 'pk_sum_batch_multi')
+
+
 def scatter_rows(src, rows, dst, M, D):
     rc = load().pk_scatter_rows(ptr(src), src.stride(-2), ptr(rows), ptr(dst), dst.stride(-2), M, D, stream(src))
     _check(rc, 'pk_scatter_rows')
@@ -555,14 +618,13 @@ def colsum(src, M, N, out, *, scale=1.0, accumulate=False, ld=None):
 def layernorm_bwd(x, gamma, dy, dx, M, D, *, add=None, want_beta=False, eps=1e-5):
     """dx = [add +] LN backward; returns (dgamma, dbeta | None)"""
     P = load().pk_ln_bwd_parts(M)
-    pg = torch.empty((P, D), device=x.device, dtype=torch.float32)
-    pb = torch.empty((P, D), device=x.device, dtype=torch.float32) if want_beta else None
+    # dgamma | dbeta partials as the two halves of one (P, 2 D) buffer (the kernel recognises pb == pg + D): one column sum finishes both
+    pgb = torch.empty((P, 2 * D if want_beta else D), device=x.device, dtype=torch.float32)
     rc = load().pk_layernorm_bwd(ptr(x), x.stride(-2), f32p(gamma, 'LayerNorm gamma'), ptr(dy), dy.stride(-2), ptr(add), add.stride(-2) if add is not None else 0,
-                                 ptr(dx), dx.stride(-2), ptr(pg), ptr(pb), eps, M, D, stream(x))
+                                 ptr(dx), dx.stride(-2), ptr(pgb), pgb.data_ptr() + 4 * D if want_beta else None, eps, M, D, stream(x))
     _check(rc, 'pk_layernorm_bwd')
-    dg = colsum(pg, P, D, torch.empty((D,), device=x.device, dtype=torch.float32))
-    db = colsum(pb, P, D, torch.empty((D,), device=x.device, dtype=torch.float32)) if want_beta else None
-    return dg, db
+    out = colsum(pgb, P, pgb.shape[1], torch.empty((pgb.shape[1],), device=x.device, dtype=torch.float32))
+    return (out[:D], out[D:]) if want_beta else (out, None)
 
 
 def geglu(h, goff, out, M, F):
@@ -662,24 +724,25 @@ def attn_train_prep(q, kv, null_kv, q_scale, k_scale, scale, Qh, Kh, Vh, S, h, n
 def attn_train_prep_bwd(q, kv, null_kv, q_scale, k_scale, scale, dQh, dKh, dVh, dq, dkv, S, h, n, n_kv, nnull):
     """-> (dq_scale (64,), dk_scale (64,), dnull_kv | None); dq / dkv are overwritten"""
     dev = q.device
-    pq = torch.empty((ATTN_PREP_BWD_PARTS, 64), device=dev, dtype=torch.float32)
-    pk = torch.empty((ATTN_PREP_BWD_PARTS, 64), device=dev, dtype=torch.float32)
+    pqk = torch.empty((ATTN_PREP_BWD_PARTS, 128), device=dev, dtype=torch.float32)     # dq_scale | dk_scale partials (the kernel recognises pk == pq + 64)
     dnull = torch.empty((h, 2 * nnull, 64), device=dev, dtype=torch.float32) if nnull else None
     rc = load().pk_attn_train_prep_bwd(ptr(q), q.stride(-2), ptr(kv), kv.stride(-2), f32p(null_kv, 'null_kv') if nnull else None, f32p(q_scale, 'q_scale'),
                                        f32p(k_scale, 'k_scale'), scale, ptr(dQh), ptr(dKh), ptr(dVh), ptr(dq), dq.stride(-2), ptr(dkv), dkv.stride(-2),
-                                       ptr(pq), ptr(pk), ptr(dnull), S, h, n, n_kv, nnull, stream(q))
+                                       ptr(pqk), pqk.data_ptr() + 256, ptr(dnull), S, h, n, n_kv, nnull, stream(q))
     _check(rc, 'pk_attn_train_prep_bwd')
-    dqs = colsum(pq, ATTN_PREP_BWD_PARTS, 64, torch.empty((64,), device=dev, dtype=torch.float32))
-    dks = colsum(pk, ATTN_PREP_BWD_PARTS, 64, torch.empty((64,), device=dev, dtype=torch.float32))
-    return dqs, dks, dnull
+    out = colsum(pqk, ATTN_PREP_BWD_PARTS, 128, torch.empty((128,), device=dev, dtype=torch.float32))
+    return out[:64], out[64:], dnull
 
 
-def attn_bwd(Qh, Kh, Vh, O, dO, dQh, dKh, dVh, S, h, n, n_kv, nnull, *, bias=None, kmask=None, dS=None, slopes=None, causal=False, split_bf16=False):
+def attn_bwd(Qh, Kh, Vh, O, dO, dQh, dKh, dVh, S, h, n, n_kv, nnull, *, bias=None, kmask=None, dS=None, slopes=None, causal=False, split_bf16=False, lse=None):
+    """lse ((S h n,) f32 from attn_fwd(lse=...)): the backward skips its own log-sum-exp pass"""
     dev = Qh.device
-    lse = torch.empty((S * h * n,), device=dev, dtype=torch.float32)
+    flags = (1 if split_bf16 else 0) | (2 if lse is not None else 0)
+    if lse is None:
+        lse = torch.empty((S * h * n,), device=dev, dtype=torch.float32)
     drow = torch.empty((S * h * n,), device=dev, dtype=torch.float32)
     rc = load().pk_attn_bwd(ptr(Qh), ptr(Kh), ptr(Vh), ptr(O), O.stride(-2), 1 if O.dtype == torch.bfloat16 else 0, ptr(dO), dO.stride(-2), ptr(bias), ptr(kmask),
-                            f32p(slopes, 'ALiBi slopes') if causal else None, 1 if causal else 0, ptr(dQh), ptr(dKh), ptr(dVh), ptr(dS), ptr(lse), ptr(drow), S, h, n, n_kv, nnull, 1 if split_bf16 else 0, stream(Qh))
+                            f32p(slopes, 'ALiBi slopes') if causal else None, 1 if causal else 0, ptr(dQh), ptr(dKh), ptr(dVh), ptr(dS), ptr(lse), ptr(drow), S, h, n, n_kv, nnull, flags, stream(Qh))
     _check(rc, 'pk_attn_bwd')
 
 

@@ -131,6 +131,9 @@ struct AttnArgs {
     // needed: ~40 % of the VALU work of a key tile.  An integer shift of the exponent leaves every mantissa -- hence the bf16
     // rounding of p -- independent of the tiling.  off2 < 0: running-max softmax.
     float off2;
+    // training forward (LDS-free kernel only): lse[(s h + hh) nq + i] = log sum_j exp(score[i][j]) for the backward kernels (round 6: they recomputed
+    // it with one extra pass over the keys); null: not written
+    float* lse;
 };
 
 constexpr float ATTN_LOG2E = 1.4426950408889634f;
@@ -359,6 +362,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((QF == 2 &&
                 const f32x4 v = o[qf][df] * inv;
                 if (p.out_f32) store4(Of + off, v); else store4(Ot + off, v);
             }
+            if (p.lse && g == 0) p.lse[(size_t)sh * p.nq + qi] = m[qf] + __logf(lt);
         }
     }
 }
@@ -899,18 +903,18 @@ extern "C" int pk_debug_attn_timeline(unsigned long long* out, int n, int clear)
 }
 #endif
 
-extern "C" int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void* Vt,
-                           const float* bias, long bias_hstride, int bias_ld, const unsigned char* kmask,
-                           const float* slopes, int causal, void* O, int ldo, int out_is_f32,
-                           int S, int h, int nq, int n_kv, int nnull, const float* bias_tab, int tab_len, const int* pos_code,
-                           int code_off, int tab_run4, float score_bound, void* stream) {
+static int attn_fwd_impl(int dtype, const void* Qp, const void* Kp, const void* Vt,
+                         const float* bias, long bias_hstride, int bias_ld, const unsigned char* kmask,
+                         const float* slopes, int causal, void* O, int ldo, int out_is_f32,
+                         int S, int h, int nq, int n_kv, int nnull, const float* bias_tab, int tab_len, const int* pos_code,
+                         int code_off, int tab_run4, float score_bound, float* lse, void* stream) {
     if (!Qp || !Kp || !Vt || !O || S <= 0 || h <= 0) return PK_EINVAL;
     if (bias_tab && (bias || !pos_code || tab_len <= 0 || nnull != 0 || nq != n_kv || causal || kmask)) return PK_EINVAL;
     if (ldo & 3) return PK_EALIGN;
     int nq_pad, nk_pad;
     if (int rc = pk_attn_pads(nq, n_kv, nnull, &nq_pad, &nk_pad)) return rc;
     AttnArgs a{Qp, Kp, Vt, bias, bias_hstride, bias_ld, kmask, slopes, O, ldo, out_is_f32, S, h, nq, n_kv, nnull, nq_pad, nk_pad, causal, 0,
-               bias_tab, tab_len, pos_code, code_off, tab_run4, -1.f};
+               bias_tab, tab_len, pos_code, code_off, tab_run4, -1.f, lse};
     a.bias_vec = (bias && nnull == 0 && (bias_ld & 3) == 0 && (bias_hstride & 3) == 0 &&
                   (reinterpret_cast<uintptr_t>(bias) & 15) == 0) ? 1 : 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -922,7 +926,7 @@ extern "C" int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void
     const long waves = (long)S * h * (nq_pad / (16 * QF));
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     static const int use_lds = [] { const char* e = getenv("PK_ATTN_LDS"); return e ? atoi(e) : 1; }();   // tuning knob
-    if (dtype == 1 && use_lds && nnull + n_kv >= 64 && nq >= 64 &&
+    if (dtype == 1 && use_lds && !lse && nnull + n_kv >= 64 && nq >= 64 &&
         (size_t)S * h * nk_pad * 128 < 0xFFFFFFF0ull) {
         // measured on maskgit self-attention (S*h = 128, n = 576, bias): 16 query rows per wave + bias prefetch 41.2 us,
         // 32 rows per wave 44.5 us (its prefetch spills: 77 us); with a single key tile (n = 64) there is nothing to
@@ -969,7 +973,7 @@ extern "C" int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void
         PK_CHECK_LAUNCH();
         return PK_OK;
     }
-    if (dtype == 2 && use_lds && nnull + n_kv >= 64 && nq >= 128 && score_bound == score_bound && fabsf(score_bound) < 1e4f && !kmask && !causal && !bias &&
+    if (dtype == 2 && use_lds && !lse && nnull + n_kv >= 64 && nq >= 128 && score_bound == score_bound && fabsf(score_bound) < 1e4f && !kmask && !causal && !bias &&
         out_is_f32 && (size_t)S * h * nk_pad * 256 < 0xFFFFFFF0ull &&
         !((reinterpret_cast<uintptr_t>(Qp) | reinterpret_cast<uintptr_t>(Kp) | reinterpret_cast<uintptr_t>(Vt)) & 127)) {
         // split-bf16 images, fixed-offset softmax (round 3): the same LDS-staged kernel on tiles twice as large (64 KB ring + the bias table:
@@ -1012,6 +1016,25 @@ extern "C" int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void
     } else return PK_EINVAL;
     PK_CHECK_LAUNCH();
     return PK_OK;
+}
+
+extern "C" int pk_attn_fwd(int dtype, const void* Qp, const void* Kp, const void* Vt,
+                           const float* bias, long bias_hstride, int bias_ld, const unsigned char* kmask,
+                           const float* slopes, int causal, void* O, int ldo, int out_is_f32,
+                           int S, int h, int nq, int n_kv, int nnull, const float* bias_tab, int tab_len, const int* pos_code,
+                           int code_off, int tab_run4, float score_bound, void* stream) {
+    return attn_fwd_impl(dtype, Qp, Kp, Vt, bias, bias_hstride, bias_ld, kmask, slopes, causal, O, ldo, out_is_f32, S, h, nq, n_kv, nnull, bias_tab, tab_len,
+                         pos_code, code_off, tab_run4, score_bound, nullptr, stream);
+}
+// the training forward: the same product through the LDS-free kernel, which also writes lse (S h, nq) = the log-sum-exp of every score row --
+// pk_attn_bwd (flags bit 1) then skips its own pass over the keys for it.  No bias table / fixed-offset form here.
+extern "C" int pk_attn_fwd_lse(int dtype, const void* Qp, const void* Kp, const void* Vt,
+                               const float* bias, long bias_hstride, int bias_ld, const unsigned char* kmask,
+                               const float* slopes, int causal, void* O, int ldo, int out_is_f32,
+                               int S, int h, int nq, int n_kv, int nnull, float* lse, void* stream) {
+    if (!lse) return PK_EINVAL;
+    return attn_fwd_impl(dtype, Qp, Kp, Vt, bias, bias_hstride, bias_ld, kmask, slopes, causal, O, ldo, out_is_f32, S, h, nq, n_kv, nnull, nullptr, 0,
+                         nullptr, 0, 0, __builtin_nanf(""), lse, stream);
 }
 
 // attention.py:128-182 for short self-attention sequences (n <= 64, no null keys) straight from the projection outputs:

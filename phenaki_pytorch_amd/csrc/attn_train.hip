@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void attn_train_prep_bwd_kernel(const float* _
     __syncthreads();
     if (wv < 2) {
         float* dst = wv == 0 ? pq : pk_;
-        dst[(long)blockIdx.x * 64 + lane] = (red[wv][0][lane] + red[wv][1][lane]) + (red[wv][2][lane] + red[wv][3][lane]);
+        const long pst = (pk_ == pq + 64) ? 128 : 64;                    // the two halves of one (parts, 128) buffer: one pk_colsum finishes both
+        dst[(long)blockIdx.x * pst + lane] = (red[wv][0][lane] + red[wv][1][lane]) + (red[wv][2][lane] + red[wv][3][lane]);
     }
 }
 // dnull_kv[h][2 j + {0, 1}][d] = sum over the sequences of the null key's l2norm backward / of dV at the null slot (one wave per (h, j))
@@ -187,6 +188,7 @@ struct AttnBwdArgs {
     // (sequence, head) groups -- the fields above then describe VIRTUAL heads (S = number of tiles, heads = 1, n = nkt = pack_g * pack_n rows of the
     // flat [S*h][n][64] arrays) and scores exist only inside a group (block-diagonal); act_heads / act_groups = the real heads / S * heads.
     int pack_n, pack_g, act_heads, act_groups, pack_inv;     // pack_inv = 65536 / pack_n + 1: row / pack_n = (row * pack_inv) >> 16 for row < 64
+    int have_lse;                                            // lse was written by the forward (pk_attn_fwd_lse): kernel Q skips its own pass over the keys
 };
 
 // element offset of row vr (of this workgroup's virtual head sh) in the heads-merged O / dO matrices, or -1 beyond the data
@@ -351,10 +353,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int ntl = (p.nkt + 63) / 64;
     const float* Kbase = p.Kh + (long)sh * p.nkt * 64;
     const float* Vbase = p.Vh + (long)sh * p.nkt * 64;
-    // ---- pass 1: log-sum-exp of every row (online, per lane over its 4 rows x 16 columns per tile; lanes of a row merged at the end)
+    // ---- pass 1: log-sum-exp of every row (online, per lane over its 4 rows x 16 columns per tile; lanes of a row merged at the end) -- unless the
+    // forward kernel handed it over (round 6, have_lse: a quarter of this kernel's products at n = 576)
     float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, l[4] = {0.f, 0.f, 0.f, 0.f};
     const int klive = p.pack_n ? nlive : p.nkt;
     f32x4 kreg[4], vreg[4];
+    float lse[4];
+    if (p.have_lse) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gi = i0 + m0 + kq * 4 + i;
+            lse[i] = gi < nlive ? p.lse[(long)sh * p.n + gi] : 0.f;
+        }
+    } else {
     fetch_tile<64>(kreg, Kbase, 64, 0, klive);
     for (int kt = 0; kt < ntl; ++kt) {
         __syncthreads();                                          // the previous tile's readers are done
@@ -374,7 +385,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 mx[i] = mn;
             }
     }
-    float lse[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -388,6 +398,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         lse[i] = mx[i] + __logf(l[i]);
         const int gi = i0 + m0 + kq * 4 + i;
         if (r == 0 && gi < nlive) p.lse[(long)sh * p.n + gi] = lse[i];
+    }
     }
     // ---- pass 2: dS and dQ^
     f32x4 accQ[4] = PK_ZERO4;
@@ -548,7 +559,8 @@ extern "C" int pk_attn_train_prep_bwd(const float* q, long ldq, const float* kv,
 // O: the forward output (M = S n rows, ldo elements per row; o_bf16 = 1: bf16), dO its gradient (f32).  bias (heads, n, n_kv) / kmask (S, n_kv)
 // cover the REAL keys (the nnull leading null keys carry no bias and are never masked, attention.py:151-158).  dS (S heads, n, n_kv) optional.
 // causal (self-attention, attention.py:166-172): ALiBi with slopes [heads] over all nnull + n keys, then key j > nnull + i masked.
-// lse / Drow: (S heads n) f32 scratch
+// lse / Drow: (S heads n) f32 scratch.  split_bf16 is a flag word: bit 0 = split-bf16 tile products, bit 1 = lse already holds the log-sum-exp of
+// every score row (written by pk_attn_fwd_lse in the forward pass): kernel Q then skips its own pass over the keys.
 extern "C" int pk_attn_bwd(const float* Qh, const float* Kh, const float* Vh, const void* O, long ldo, int o_bf16, const float* dO, long lddo,
                            const float* bias, const unsigned char* kmask, const float* slopes, int causal, float* dQh, float* dKh, float* dVh, float* dS,
                            float* lse, float* Drow, int S, int heads, int n, int n_kv, int nnull, int split_bf16, void* stream) {
@@ -556,8 +568,11 @@ extern "C" int pk_attn_bwd(const float* Qh, const float* Kh, const float* Vh, co
     if (!al16(Qh) || !al16(Kh) || !al16(Vh) || !al16(dO) || (lddo & 3) || !al16(O) || (ldo & (o_bf16 ? 7 : 3))) return PK_EALIGN;
     if ((long)S * heads > 0x7fffffffL / 64) return PK_EINVAL;
     if (causal && (!slopes || n != n_kv)) return PK_EINVAL;
-    AttnBwdArgs p{Qh, Kh, Vh, O, ldo, o_bf16, dO, lddo, bias, kmask, slopes, causal, dQh, dKh, dVh, dS, lse, Drow, S, heads, n, nnull + n_kv, nnull, 0, 0, heads, S * heads, 0};
+    const int have_lse = (split_bf16 >> 1) & 1;                         // flags: bit 0 split-bf16 tile products, bit 1 lse (S heads, n) given by pk_attn_fwd_lse
+    split_bf16 &= 1;
+    AttnBwdArgs p{Qh, Kh, Vh, O, ldo, o_bf16, dO, lddo, bias, kmask, slopes, causal, dQh, dKh, dVh, dS, lse, Drow, S, heads, n, nnull + n_kv, nnull, 0, 0, heads, S * heads, 0, have_lse};
     static const bool pack_on = !(getenv("PK_ATTN_BWD_PACK") && getenv("PK_ATTN_BWD_PACK")[0] == '0');      // A/B switch
+    // (the packed layout re-indexes the rows: lse is laid out [S heads][n], the flat index of a packed row is the same (S h n contiguous) -> usable as is)
     if (pack_on && nnull == 0 && n == n_kv && n <= 32 && !dS) {
         // short self-attention (the C-ViViT temporal transformers: n = 9 at 512 sequences x 8 heads): 64 / n whole (sequence, head) groups per tile
         // instead of one -- the flat [S*h][n][64] arrays are the same memory either way

@@ -14,10 +14,9 @@ static inline int nblocks(long total) { long b = (total + 255) / 256; return (in
 // out[r][k] = (TR ? src[k][r] : src[r][k]) for k < K, 0 for K <= k < Kp; rows (optional) gathers SOURCE rows (src[rows[k]][r] / src[rows[r]][k]).   The dW product of a Linear, dW = dY^T X, takes BOTH its operands
 // through this kernel (A = dY^T, "W" = X^T: the contraction index of pk_gemm is the contiguous one), dX = dY W takes W^T.
 template <typename TO, bool TR>
-__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src, long lds_, const int* __restrict__ rows, int R, int K, int Kp,
-                                                   TO* __restrict__ out, long ldo) {
-    __shared__ float tile[64][65];
-    const int r0 = blockIdx.y * 64, k0 = blockIdx.x * 64, t = threadIdx.x;
+__device__ __forceinline__ void pack_tile(float (*tile)[65], const float* __restrict__ src, long lds_, const int* __restrict__ rows, int R, int K, int Kp,
+                                          TO* __restrict__ out, long ldo, int bx, int by) {
+    const int r0 = by * 64, k0 = bx * 64, t = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (TR) {
@@ -42,6 +41,59 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src
         if (r < R && k < Kp) store4(out + (long)r * ldo + k, f32x4{tile[rr][kk], tile[rr][kk + 1], tile[rr][kk + 2], tile[rr][kk + 3]});
     }
 }
+template <typename TO, bool TR>
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ src, long lds_, const int* __restrict__ rows, int R, int K, int Kp,
+                                                   TO* __restrict__ out, long ldo) {
+    __shared__ float tile[64][65];
+    pack_tile<TO, TR>(tile, src, lds_, rows, R, K, Kp, out, ldo, blockIdx.x, blockIdx.y);
+}
+
+// ---- several pk_pack jobs in ONE launch (round 6: the training step issued ~440 single-matrix packs of 5-9 us each) -------------------------
+// A job is one output block: out (R rows, columns [0, Kp)) = src or src^T, zero for K <= column < Kp; `tile0` = the launch-wide index of its first
+// 64 x 64 tile, `tiles_x` = ceil(Kp / 64).  Two carriers of the job list: by value in the kernel arguments (<= PACK_JOBS jobs: the activation
+// transposes of one backward block, pointers change every call) and a table in device memory (the persistent operand images of a whole
+// Transformer's projection weights, written once per model and re-run every step: pk_pack_table).
+struct PackJob {
+    const float* src; void* out; long lds_, ldo; int R, K, Kp, flags /* bit 0 transpose, bits 1-2 kind */, tile0, tiles_x;
+};
+constexpr int PACK_JOBS = 8;
+struct PackJobs { PackJob j[PACK_JOBS]; };
+
+__device__ __forceinline__ void pack_job_tile(float (*tile)[65], const PackJob& d, int rel) {
+    const int bx = rel % d.tiles_x, by = rel / d.tiles_x;
+    const int kind = d.flags >> 1;
+    const bool tr = d.flags & 1;
+    if (kind == 0) {
+        if (tr) pack_tile<float, true>(tile, d.src, d.lds_, nullptr, d.R, d.K, d.Kp, reinterpret_cast<float*>(d.out), d.ldo, bx, by);
+        else pack_tile<float, false>(tile, d.src, d.lds_, nullptr, d.R, d.K, d.Kp, reinterpret_cast<float*>(d.out), d.ldo, bx, by);
+    } else if (kind == 1) {
+        if (tr) pack_tile<bf16, true>(tile, d.src, d.lds_, nullptr, d.R, d.K, d.Kp, reinterpret_cast<bf16*>(d.out), d.ldo, bx, by);
+        else pack_tile<bf16, false>(tile, d.src, d.lds_, nullptr, d.R, d.K, d.Kp, reinterpret_cast<bf16*>(d.out), d.ldo, bx, by);
+    } else {
+        if (tr) pack_tile<bf16x3p, true>(tile, d.src, d.lds_, nullptr, d.R, d.K, d.Kp, reinterpret_cast<bf16x3p*>(d.out), d.ldo, bx, by);
+        else pack_tile<bf16x3p, false>(tile, d.src, d.lds_, nullptr, d.R, d.K, d.Kp, reinterpret_cast<bf16x3p*>(d.out), d.ldo, bx, by);
+    }
+}
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJobs a, int count) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.x;
+    int i = 0;
+#pragma unroll
+    for (int c = 1; c < PACK_JOBS; ++c)
+        if (c < count && b >= a.j[c].tile0) i = c;
+    pack_job_tile(tile, a.j[i], b - a.j[i].tile0);
+}
+__global__ __launch_bounds__(256) void pack_table_kernel(const PackJob* __restrict__ table, int count) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.x;
+    int lo = 0, hi = count - 1;                                       // last job whose tile0 <= b (uniform over the block: scalar loads)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].tile0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const PackJob d = table[lo];
+    pack_job_tile(tile, d, b - d.tile0);
+}
 
 // ---- pk_colsum: out[c] (+)= scale * sum_r src[r][c], two deterministic stages -------------------------------------------------------
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ src, long ld, int M, int N, float* __restrict__ part, int rpb) {
@@ -61,6 +113,42 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     float s = 0.f;
     for (int p = 0; p < P; ++p) s += part[(long)p * N + c];
     out[c] = accumulate ? out[c] + scale * s : scale * s;
+}
+
+// one-launch form for short inputs (round 6: the per-block partials of ln_bwd / peg_wgrad / attn_train_prep_bwd / bce_head are 144 ... 1024 rows --
+// the two-stage form spent two 5-6 us launches on each of the step's 141 column sums).  A block owns 64 columns; 16 row lanes x 16 float4 column
+// lanes (V4) or 4 row lanes x 64 columns; the lanes' sums are folded in lane order, so the result is as reproducible as the two-stage one.
+template <bool V4>
+__global__ __launch_bounds__(256) void colsum_one_kernel(const float* __restrict__ src, long ld, int M, int N, float scale, float* __restrict__ out, int accumulate) {
+    __shared__ f32x4 red[16][16];
+    const int t = threadIdx.x;
+    if (V4) {
+        const int cl = t & 15, rl = t >> 4, c = blockIdx.x * 64 + cl * 4;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (c < N)
+            for (int r = rl; r < M; r += 16) a += *reinterpret_cast<const f32x4*>(src + (long)r * ld + c);
+        red[rl][cl] = a;
+        __syncthreads();
+        if (rl == 0 && c < N) {
+            f32x4 s = red[0][cl];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) s += red[i][cl];
+            f32x4* o = reinterpret_cast<f32x4*>(out + c);
+            *o = accumulate ? *o + s * scale : s * scale;
+        }
+    } else {
+        float* redf = reinterpret_cast<float*>(&red[0][0]);
+        const int cl = t & 63, rl = t >> 6, c = blockIdx.x * 64 + cl;
+        float a = 0.f;
+        if (c < N)
+            for (int r = rl; r < M; r += 4) a += src[(long)r * ld + c];
+        redf[rl * 64 + cl] = a;
+        __syncthreads();
+        if (rl == 0 && c < N) {
+            const float s = (redf[cl] + redf[64 + cl]) + (redf[128 + cl] + redf[192 + cl]);
+            out[c] = accumulate ? out[c] + scale * s : scale * s;
+        }
+    }
 }
 
 // ---- LayerNorm backward (attention.py:29-36 gamma-only LayerNorm and nn.LayerNorm of the feed-forward, attention.py:47) ------------
@@ -138,9 +226,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         for (int i = 0; i < VMAX; ++i) red[wv][lane + i * 64] = pass == 0 ? ag[i] : ab[i];
         __syncthreads();
         float* dst = pass == 0 ? pg : pb;
+        const long pst = (pb == pg + D) ? 2 * D : D;                      // pg | pb as the halves of one (parts, 2 D) buffer: one pk_colsum for both
         for (int c = threadIdx.x; c < nv; c += 256) {
             const f32x4 s4 = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-            *reinterpret_cast<f32x4*>(dst + (long)blockIdx.x * D + c * 4) = s4;
+            *reinterpret_cast<f32x4*>(dst + (long)blockIdx.x * pst + c * 4) = s4;
         }
     }
 }
@@ -340,6 +429,24 @@ __global__ __launch_bounds__(256) void sum_batch_kernel(const float* __restrict_
     }
 }
 
+// several pk_sum_batch jobs in ONE launch (the K-slice partials of the weight gradients of one backward block): blk0 = first block of the job
+struct SumJob { const float* src; float* out; long stride, E4; int S, blk0; };
+constexpr int SUM_JOBS = 8;
+struct SumJobs { SumJob j[SUM_JOBS]; };
+__global__ __launch_bounds__(256) void sum_batch_jobs_kernel(const SumJobs a, int count) {
+    const int b = blockIdx.x;
+    int i = 0;
+#pragma unroll
+    for (int c = 1; c < SUM_JOBS; ++c)
+        if (c < count && b >= a.j[c].blk0) i = c;
+    const SumJob d = a.j[i];
+    const long idx = (long)(b - d.blk0) * 256 + threadIdx.x;
+    if (idx >= d.E4) return;
+    f32x4 s = *reinterpret_cast<const f32x4*>(d.src + idx * 4);
+    for (int k = 1; k < d.S; ++k) s += *reinterpret_cast<const f32x4*>(d.src + (long)k * d.stride + idx * 4);
+    *reinterpret_cast<f32x4*>(d.out + idx * 4) = s;
+}
+
 // ---- critic head + BCE-with-logits, forward and backward in one pass (phenaki_pytorch.py:246-249 / :306-336 to_pred, :673-676) --------------
 // logit = e . w + b;  loss_row = max(z, 0) - z y + log(1 + exp(-|z|));  dz = (sigmoid(z) - y) * scale;  de = dz * w;  dw / db as block partials
 __global__ __launch_bounds__(256) void bce_head_kernel(const float* __restrict__ e, long lde, const float* __restrict__ w, const float* __restrict__ b,
@@ -462,12 +569,67 @@ extern "C" int pk_pack(const float* src, long lds_, const int* rows, int R, int 
     return PK_OK;
 }
 
+// `count` pack jobs in one launch.  jobs: HOST array of `count` PkPackJob (include/phenaki_hip.h; tile0 / tiles_x are filled in here).
+// count <= 8: the jobs travel in the kernel arguments.
+static int pack_job_check(const PackJob& d) {
+    const int kind = d.flags >> 1;
+    if (!d.src || !d.out || d.R <= 0 || d.K <= 0 || d.Kp < d.K || d.ldo < d.Kp || kind < 0 || kind > 2) return PK_EINVAL;
+    if ((d.Kp & 3) || (d.ldo & 3) || (reinterpret_cast<uintptr_t>(d.out) & 15) || (kind == 2 && (d.ldo & 31))) return PK_EALIGN;
+    return PK_OK;
+}
+extern "C" int pk_pack_multi(const void* jobs, int count, void* stream) {
+    if (!jobs || count <= 0 || count > PACK_JOBS) return PK_EINVAL;
+    PackJobs a;
+    int tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        a.j[i] = reinterpret_cast<const PackJob*>(jobs)[i];
+        const int rc = pack_job_check(a.j[i]);
+        if (rc != PK_OK) return rc;
+        a.j[i].tiles_x = (a.j[i].Kp + 63) / 64;
+        a.j[i].tile0 = tiles;
+        tiles += a.j[i].tiles_x * ((a.j[i].R + 63) / 64);
+    }
+    for (int i = count; i < PACK_JOBS; ++i) a.j[i] = a.j[0];
+    hipLaunchKernelGGL(pack_jobs_kernel, dim3(tiles), dim3(256), 0, STREAM(stream), a, count);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+// fill tile0 / tiles_x of a HOST job array (any count) and return the launch's tile count (< 0: error code) -- the caller copies the array to
+// device memory once and replays it with pk_pack_table every step
+extern "C" int pk_pack_table_prepare(void* jobs, int count) {
+    if (!jobs || count <= 0) return PK_EINVAL;
+    PackJob* j = reinterpret_cast<PackJob*>(jobs);
+    long tiles = 0;
+    for (int i = 0; i < count; ++i) {
+        const int rc = pack_job_check(j[i]);
+        if (rc != PK_OK) return rc;
+        j[i].tiles_x = (j[i].Kp + 63) / 64;
+        j[i].tile0 = (int)tiles;
+        tiles += (long)j[i].tiles_x * ((j[i].R + 63) / 64);
+        if (tiles > 0x7fffffffL) return PK_EINVAL;
+    }
+    return (int)tiles;
+}
+extern "C" int pk_pack_table(const void* dev_table, int count, int tiles, void* stream) {
+    if (!dev_table || count <= 0 || tiles <= 0) return PK_EINVAL;
+    hipLaunchKernelGGL(pack_table_kernel, dim3((unsigned)tiles), dim3(256), 0, STREAM(stream), reinterpret_cast<const PackJob*>(dev_table), count);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
 // out[c] (+)= scale * sum_r src[r][c];  work: >= P * N floats, P = pk_colsum_parts(M)
 extern "C" int pk_colsum_parts(int M) { int p = (M + 63) / 64; return p < 1 ? 1 : (p > 256 ? 256 : p); }
 extern "C" int pk_colsum(const float* src, long ld, int M, int N, float scale, float* out, int accumulate, float* work, void* stream) {
     if (!src || !out || !work || M <= 0 || N <= 0) return PK_EINVAL;
-    const int P = pk_colsum_parts(M), rpb = (M + P - 1) / P;
     hipStream_t s = STREAM(stream);
+    const bool v4 = !(N & 3) && !(ld & 3) && al16(src) && al16(out);
+    if (M <= (v4 ? 1024 : 256)) {                                        // short input (block partials of another kernel): one launch
+        if (v4) hipLaunchKernelGGL((colsum_one_kernel<true>), dim3((N + 63) / 64), dim3(256), 0, s, src, ld, M, N, scale, out, accumulate);
+        else hipLaunchKernelGGL((colsum_one_kernel<false>), dim3((N + 63) / 64), dim3(256), 0, s, src, ld, M, N, scale, out, accumulate);
+        PK_CHECK_LAUNCH();
+        return PK_OK;
+    }
+    const int P = pk_colsum_parts(M), rpb = (M + P - 1) / P;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, P), dim3(256), 0, s, src, ld, M, N, work, rpb);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, work, P, N, scale, out, accumulate);
     PK_CHECK_LAUNCH();
@@ -475,7 +637,9 @@ extern "C" int pk_colsum(const float* src, long ld, int M, int N, float scale, f
 }
 
 // dx = [add +] LayerNorm backward; pg / pb (pb may be null: the gamma-only LayerNorm's beta is a buffer): (pk_ln_bwd_parts(M), D) partials
-extern "C" int pk_ln_bwd_parts(int M) { int p = (M + 31) / 32; return p < 1 ? 1 : (p > 512 ? 512 : p); }
+// 8 rows per block up to 1024 blocks (round 6: 32 rows per block = 144 blocks of 4 waves at M = 4608, half the CUs idle and 8 dependent rows per wave:
+// 25.8 us for 38 MB; the partials stay within pk_colsum's one-launch bound)
+extern "C" int pk_ln_bwd_parts(int M) { int p = (M + 7) / 8; return p < 1 ? 1 : (p > 1024 ? 1024 : p); }
 extern "C" int pk_layernorm_bwd(const float* x, long ldx, const float* gamma, const float* dy, long lddy, const float* add, long ldadd,
                                 float* dx, long lddx, float* pg, float* pb, float eps, int M, int D, void* stream) {
     if (!x || !gamma || !dy || !dx || !pg || M <= 0 || D <= 0 || D > 1024) return PK_EINVAL;
@@ -596,6 +760,26 @@ extern "C" int pk_sum_batch(const float* src, long stride, int S, float* out, lo
     if (!src || !out || S <= 0 || E <= 0) return PK_EINVAL;
     if ((E & 3) || (stride & 3) || !al16(src) || !al16(out)) return PK_EALIGN;
     hipLaunchKernelGGL(sum_batch_kernel, dim3(nblocks(E >> 2)), dim3(256), 0, STREAM(stream), src, stride, S, out, E >> 2);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+// `count` (<= 8) pk_sum_batch jobs in one launch.  jobs: HOST array of PkSumJob (blk0 is filled in here)
+extern "C" int pk_sum_batch_multi(const void* jobs, int count, void* stream) {
+    if (!jobs || count <= 0 || count > SUM_JOBS) return PK_EINVAL;
+    SumJobs a;
+    long blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        a.j[i] = reinterpret_cast<const SumJob*>(jobs)[i];
+        SumJob& d = a.j[i];
+        if (!d.src || !d.out || d.S <= 0 || d.E4 <= 0) return PK_EINVAL;
+        if ((d.stride & 3) || !al16(d.src) || !al16(d.out)) return PK_EALIGN;
+        d.blk0 = (int)blocks;
+        blocks += (d.E4 + 255) / 256;
+    }
+    if (blocks > 0x7fffffffL) return PK_EINVAL;
+    for (int i = count; i < SUM_JOBS; ++i) a.j[i] = a.j[0];
+    hipLaunchKernelGGL(sum_batch_jobs_kernel, dim3((unsigned)blocks), dim3(256), 0, STREAM(stream), a, count);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

@@ -23,6 +23,7 @@ dW = dY^T X through pk_gemm on pk_pack(dY^T) and pk_pack(X^T) (contraction over 
 Limits (asserted): dropout 0 (the reference default).  The tokenizer's own reconstruction step is train_cvivit.py.
 """
 import math
+import weakref
 
 import torch
 
@@ -60,19 +61,20 @@ def pack_operand(src, dtype, *, transpose=False, side='w', rows=None, nrows=None
     return L.pack(src, R, K, transpose, out, Kp, kind, rows=rows)
 
 
-def linear_fwd(dtype, x, W, *, bias=None, res=None, act=L.ACT_NONE):
-    """x (M, K) f32 @ W (N, K)^T [+ bias] [+ res] -> (M, N) f32"""
+def linear_fwd(dtype, x, W, *, bias=None, res=None, act=L.ACT_NONE, Wimg=None):
+    """x (M, K) f32 @ W (N, K)^T [+ bias] [+ res] -> (M, N) f32.  Wimg: the operand image of W when the caller holds one (WeightImages)"""
     M, K = x.shape
     N = W.shape[0]
     y = _f32((M, N), x.device)
-    L.gemm(dtype, x, pack_operand(W, dtype), M, N, K, C=y, bias=bias, res=res, act=act)
+    L.gemm(dtype, x, Wimg if Wimg is not None else pack_operand(W, dtype), M, N, K, C=y, bias=bias, res=res, act=act)
     return y
 
 
-def _weight_grad_gemm(dtype, dyT, xT, N, K, Mp, dW):
+def _weight_grad_gemm(dtype, dyT, xT, N, K, Mp, dW, defer=None):
     """dW (N, K) = dyT (N, Mp) @ xT (K, Mp)^T: the contraction runs over the rows of the batch (Mp = 4608 at B = 8) while the output has only
     ceil(N / 64) ceil(K / 64) tiles -- 64 for a 512 x 512 projection on 256 CUs -- so the product is cut into K-slices (pk_gemm_splitk) that are
-    added in index order (pk_sum_batch: deterministic)."""
+    added in index order (pk_sum_batch: deterministic).  defer (list): the slice sum is queued there instead of launched -- the caller adds the
+    slices of all its weight gradients with ONE pk_sum_batch_multi (`_flush_sums`)."""
     q = _q(dtype)
     tiles = ((N + 63) // 64) * ((K + 63) // 64)
     splits = 1
@@ -88,24 +90,145 @@ def _weight_grad_gemm(dtype, dyT, xT, N, K, Mp, dW):
         return
     part = torch.empty((splits, N * K), device=dW.device, dtype=torch.float32)
     L.gemm_splitk(dtype, dyT, xT, N, K, Mp, splits, part)
-    L.sum_batch(part, splits, dW, N * K)
+    if defer is not None and (N * K) % 4 == 0:
+        defer.append((part, splits, dW, N * K))
+    else:
+        L.sum_batch(part, splits, dW, N * K)
 
 
-def linear_bwd(dtype, x, W, dy, *, need_dx=True, add=None, need_dw=True, dw_out=None):
-    """gradients of y = x W^T: dx = dy W [+ add] (M, K), dW = dy^T x (N, K).  dw_out: preallocated (N, K) destination (may be a row slice)."""
+def _flush_sums(defer):
+    if defer:
+        L.sum_batch_multi(defer)
+        defer.clear()
+
+
+def transposes(dtype, items):
+    """[(src (M, C) f32 rows, side 'a' | 'w')] -> [src^T as the (C, Mp) operand image of that side]: the activation transposes a backward block
+    needs for its weight gradients, laid down by ONE pk_pack_multi launch (round 6: one pk_pack launch each before)"""
+    q = _q(dtype)
+    jobs, outs = [], []
+    for src, side in items:
+        M, C = src.shape
+        Mp = round_up(M, q)
+        kind = L.kind_of(dtype) if side == 'w' else (1 if dtype == L.BF16 else 0)
+        out = torch.empty((C, Mp), device=src.device, dtype=torch.bfloat16 if kind == 1 else torch.float32)
+        jobs.append(L.pack_job(src, C, M, True, out, Mp, kind))
+        outs.append(out)
+    L.pack_multi(jobs, items[0][0])
+    return outs
+
+
+def linear_bwd(dtype, x, W, dy, *, need_dx=True, add=None, need_dw=True, dw_out=None, Wt=None, dyT=None, xT=None, defer=None):
+    """gradients of y = x W^T: dx = dy W [+ add] (M, K), dW = dy^T x (N, K).  dw_out: preallocated (N, K) destination (may be a row slice).
+    Wt: the (K, Kp(N)) operand image of W^T when the caller holds one (`WeightImages`); dyT / xT: the transposed operand images of `transposes`;
+    defer: see _weight_grad_gemm."""
     M, K = x.shape
     N = W.shape[0]
     dx = dW = None
     if need_dx:
         dx = _f32((M, K), x.device)
-        L.gemm(dtype, dy, pack_operand(W, dtype, transpose=True), M, K, N, C=dx, res=add)
+        L.gemm(dtype, dy, Wt if Wt is not None else pack_operand(W, dtype, transpose=True), M, K, N, C=dx, res=add)
     if need_dw:
         Mp = round_up(M, _q(dtype))
-        dyT = pack_operand(dy, dtype, transpose=True, side='a')          # (N, Mp)
-        xT = pack_operand(x, dtype, transpose=True)                      # (K, Mp)
+        if dyT is None:
+            dyT, xT = transposes(dtype, [(dy, 'a'), (x, 'w')])          # (N, Mp), (K, Mp)
         dW = dw_out if dw_out is not None else _f32((N, K), x.device)
-        _weight_grad_gemm(dtype, dyT, xT, N, K, Mp, dW)
+        _weight_grad_gemm(dtype, dyT, xT, N, K, Mp, dW, defer)
     return dx, dW
+
+
+class WeightImages:
+    """The operand images of a module's projection weights in one compute dtype -- for every Linear both the forward image of W and the image of
+    W^T its backward multiplies by -- held in persistent buffers and re-packed by ONE launch per pass (`refresh`, pk_pack_table).  Round 6: the
+    training step issued ~220 single-matrix pk_pack launches of 5-9 us for these (every weight twice per step).  The pad rows / columns of an image
+    are zeroed once at allocation and never written again.  Images are tied to the storage of the parameters they were built for (`key`)."""
+
+    def __init__(self, dtype, device):
+        self.dtype, self.device = dtype, device
+        self.q, self.kind = _q(dtype), L.kind_of(dtype)
+        self.td = torch.bfloat16 if self.kind == 1 else torch.float32
+        self.jobs, self.table, self.params = [], None, []
+
+    def _image(self, rows, cols):
+        return torch.zeros((rows, round_up(cols, self.q)), device=self.device, dtype=self.td)
+
+    def _job(self, src, R, K, transpose, out, Kp=None):
+        """out (R rows): columns [0, K) from src / src^T, zero up to Kp (default: the whole padded row of a full image)"""
+        self.jobs.append(L.pack_job(src, R, K, transpose, out, out.shape[-1] if Kp is None else Kp, self.kind))
+
+    def both(self, w):
+        """w (N, K) -> (image of W: (N, Kp(K)), image of W^T: (K, Kp(N)))"""
+        w = w.detach()
+        N, K = w.shape
+        f, t = self._image(N, K), self._image(K, N)
+        self._job(w, N, K, False, f)
+        self._job(w, K, N, True, t)
+        self.params.append(w)
+        return f, t
+
+    def feedforward(self, w1, w2):
+        """the GEGLU feed-forward's layouts (see _FFBlock): w1p (2 Fp, Kp(D)) value rows [0, F) | gate rows [Fp, Fp + F); w1t (D, Kp(2 Fp)) its
+        transpose; w2 (D, Kp(F)); w2t (Fp, Kp(D)) with zero pad rows"""
+        w1, w2 = w1.detach(), w2.detach()
+        D, F = w2.shape
+        Fp = round_up(F, 8)
+        w1p, w1t = self._image(2 * Fp, D), self._image(D, 2 * Fp)
+        self._job(w1[:F], F, D, False, w1p[:F])
+        self._job(w1[F:], F, D, False, w1p[Fp:Fp + F])
+        self._job(w1[:F], D, F, True, w1t[:, :Fp], Fp)
+        self._job(w1[F:], D, F, True, w1t[:, Fp:2 * Fp], Fp)
+        w2f, w2t = self._image(D, F), self._image(Fp, D)
+        self._job(w2, D, F, False, w2f)
+        self._job(w2, F, D, True, w2t[:F])
+        self.params += [w1, w2]
+        return dict(w1p=w1p, w1t=w1t, w2=w2f, w2t=w2t)
+
+    def key(self):
+        return tuple((p.data_ptr(), tuple(p.shape)) for p in self.params)
+
+    def refresh(self):
+        if len(self.jobs) <= 8:                                          # one block's weights (a direct caller): the jobs travel in the kernel arguments
+            L.pack_multi(self.jobs, self.params[0])
+            return
+        if self.table is None:
+            self.table = L.PackTable(self.jobs, self.device)
+        self.table.run()
+
+
+# module -> {compute dtype: WeightImages}; outside the module so that deepcopy (EMA, copy_for_eval) and state_dict never see the images
+_IMAGES = weakref.WeakKeyDictionary()
+
+
+def transformer_images(tr, dtype):
+    """the WeightImages of a Transformer (attention.py:277-332), built on first use and rebuilt when a parameter's storage changed"""
+    cache = _IMAGES.setdefault(tr, {})
+    wi = cache.get(dtype)
+    if wi is not None and wi._key == wi.key():
+        return wi
+    dev = next(tr.parameters()).device
+    wi = WeightImages(dtype, dev)
+    wi.layers = []
+    for peg, self_attn, cross_attn, ff in tr.layers:
+        rec = {}
+        for name, at in (('sa', self_attn), ('ca', cross_attn)):
+            rec[name] = None if at is None else dict(wq=wi.both(at.to_q.weight), wkv=wi.both(at.to_kv.weight), wo=wi.both(at.to_out.weight))
+        rec['ff'] = wi.feedforward(ff[1].weight, ff[4].weight)
+        wi.layers.append(rec)
+    wi._key = wi.key()
+    cache[dtype] = wi
+    return wi
+
+
+def linear_images(lin, dtype):
+    """(image of W, image of W^T) of one Linear (the vocabulary head), same caching rule as transformer_images"""
+    cache = _IMAGES.setdefault(lin, {})
+    wi = cache.get(dtype)
+    if wi is None or wi._key != wi.key():
+        wi = WeightImages(dtype, lin.weight.device)
+        wi.pair = wi.both(lin.weight)
+        wi._key = wi.key()
+        cache[dtype] = wi
+    return wi
 
 
 # ------------------------------------------------------------------------------------------------------------ blocks
@@ -132,80 +255,76 @@ class _LayerNormFn(torch.autograd.Function):
 
 
 class _FFBlock(torch.autograd.Function):
-    """x + Linear(inner, dim)(GEGLU(Linear(dim, 2 inner)(nn.LayerNorm(x))))   (attention.py:45-52 + the residual of :330)"""
+    """x + Linear(inner, dim)(GEGLU(Linear(dim, 2 inner)(nn.LayerNorm(x))))   (attention.py:45-52 + the residual of :330).
+    img: the block's entry of `WeightImages.feedforward` (None: the four weight images are packed here, per call)."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, w1, w2, dtype, eps):
+    def _images(w1, w2, dtype, dev):
+        wi = WeightImages(dtype, dev)
+        img = wi.feedforward(w1, w2)
+        wi.refresh()
+        return img
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w1, w2, dtype, eps, img):
         M, D = x.shape
         F = w2.shape[1]
         Fp = round_up(F, 8)
         dev = x.device
+        if img is None:
+            img = _FFBlock._images(w1, w2, dtype, dev)
         xn = _f32((M, D), dev)
         L.layernorm(x, ln_w, ln_b, M, D, out2=xn, eps=eps)
         # value rows [0, F) and gate rows [Fp, Fp + F) of the K-padded 2 Fp-row weight image; the pad rows stay zero -> h pad columns are 0
-        q = _q(dtype)
-        Kp = round_up(D, q)
-        kind = L.kind_of(dtype)
-        w1p = torch.zeros((2 * Fp, Kp), device=dev, dtype=torch.bfloat16 if kind == 1 else torch.float32)
-        L.pack(w1[:F], F, D, False, w1p[:F], Kp, kind)
-        L.pack(w1[F:], F, D, False, w1p[Fp:Fp + F], Kp, kind)
         h = _f32((M, 2 * Fp), dev)
-        L.gemm(dtype, xn, w1p, M, 2 * Fp, D, C=h)
+        L.gemm(dtype, xn, img['w1p'], M, 2 * Fp, D, C=h)
         a = _f32((M, Fp), dev)
         L.geglu(h, Fp, a, M, Fp)
         y = _f32((M, D), dev)
-        L.gemm(dtype, a, pack_operand(w2, dtype), M, D, Fp, C=y, res=x)
+        L.gemm(dtype, a, img['w2'], M, D, Fp, C=y, res=x)
         ctx.save_for_backward(x, ln_w, w1, w2, xn, h, a)
-        ctx.dtype, ctx.eps, ctx.Fp = dtype, eps, Fp
+        ctx.dtype, ctx.eps, ctx.Fp, ctx.img = dtype, eps, Fp, img
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, ln_w, w1, w2, xn, h, a = ctx.saved_tensors
-        dtype, Fp = ctx.dtype, ctx.Fp
+        dtype, Fp, img = ctx.dtype, ctx.Fp, ctx.img
         M, D = x.shape
         F = w2.shape[1]
         dev = x.device
         dy = dy.contiguous()
         q = _q(dtype)
         Mp = round_up(M, q)
+        sums = []
         # ---- second Linear: da = dy W2 (pad columns: zero rows of the W2^T image), dW2 = dy^T a
-        w2t = torch.zeros((Fp, round_up(D, q)), device=dev, dtype=torch.bfloat16 if L.kind_of(dtype) == 1 else torch.float32)
-        L.pack(w2, F, D, True, w2t, round_up(D, q), L.kind_of(dtype))
         da = _f32((M, Fp), dev)
-        L.gemm(dtype, dy, w2t, M, Fp, D, C=da)
-        dyT = pack_operand(dy, dtype, transpose=True, side='a')           # (D, Mp)
-        aT = pack_operand(a, dtype, transpose=True)                       # (Fp, Mp)
+        L.gemm(dtype, dy, img['w2t'], M, Fp, D, C=da)
+        dyT, aT = transposes(dtype, [(dy, 'a'), (a, 'w')])                # (D, Mp), (Fp, Mp)
         dW2 = None if F % 4 else _f32((D, F), dev)
+        dW2p = None
         if F % 4:                                                        # inner 1365: the product on the padded width (a's pad columns are zero), then the slice
             dW2p = _f32((D, Fp), dev)
-            _weight_grad_gemm(dtype, dyT, aT, D, Fp, Mp, dW2p)
-            dW2 = dW2p[:, :F].contiguous()
+            _weight_grad_gemm(dtype, dyT, aT, D, Fp, Mp, dW2p, sums)
         else:
-            _weight_grad_gemm(dtype, dyT, aT, D, F, Mp, dW2)
+            _weight_grad_gemm(dtype, dyT, aT, D, F, Mp, dW2, sums)
         # ---- GEGLU
         dh = _f32((M, 2 * Fp), dev)
         L.geglu_bwd(h, Fp, da, dh, M, Fp)
         # ---- first Linear: dxn = dh W1 (the padded layout, transposed), dW1 = dh^T xn in two row groups (value | gate)
-        kind = L.kind_of(dtype)
-        Kp2 = round_up(2 * Fp, q)
-        w1t = torch.empty((D, Kp2), device=dev, dtype=torch.bfloat16 if kind == 1 else torch.float32)
-        # out[d][k] = w1pad[k][d] with w1pad = the (2 Fp, D) row layout of the forward pass (value rows [0, F), gate rows [Fp, Fp + F), pad rows 0)
-        st = _zeros((2 * Fp, D), dev)
-        L.pack(w1[:F], F, D, False, st[:F], D, 0)
-        L.pack(w1[F:], F, D, False, st[Fp:Fp + F], D, 0)
-        L.pack(st, D, 2 * Fp, True, w1t, Kp2, kind)
         dxn = _f32((M, D), dev)
-        L.gemm(dtype, dh, w1t, M, D, 2 * Fp, C=dxn)
-        dhT = pack_operand(dh, dtype, transpose=True, side='a')           # (2 Fp, Mp)
-        xnT = pack_operand(xn, dtype, transpose=True)                     # (D, Mp)
+        L.gemm(dtype, dh, img['w1t'], M, D, 2 * Fp, C=dxn)
+        dhT, xnT = transposes(dtype, [(dh, 'a'), (xn, 'w')])              # (2 Fp, Mp), (D, Mp)
         dW1 = _f32((2 * F, D), dev)
-        _weight_grad_gemm(dtype, dhT[:F], xnT, F, D, Mp, dW1[:F])
-        _weight_grad_gemm(dtype, dhT[Fp:Fp + F], xnT, F, D, Mp, dW1[F:])
+        _weight_grad_gemm(dtype, dhT[:F], xnT, F, D, Mp, dW1[:F], sums)
+        _weight_grad_gemm(dtype, dhT[Fp:Fp + F], xnT, F, D, Mp, dW1[F:], sums)
+        _flush_sums(sums)
+        if dW2p is not None:
+            dW2 = dW2p[:, :F].contiguous()
         # ---- LayerNorm + residual
         dx = _f32((M, D), dev)
         dg, db = L.layernorm_bwd(x, ln_w.detach(), dxn, dx, M, D, add=dy, want_beta=True, eps=ctx.eps)
-        return dx, dg, db, dW1, dW2, None, None
+        return dx, dg, db, dW1, dW2, None, None, None
 
 
 class _PEGBlock(torch.autograd.Function):
@@ -240,7 +359,12 @@ class _AttnBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, context, gamma, beta, cgamma, cbeta, wq, wkv, null_kv, q_scale, k_scale, wo, bias, kmask, meta):
-        dtype, S, n, n_ctx, heads, scale, eps, slopes = meta
+        dtype, S, n, n_ctx, heads, scale, eps, slopes, img = meta
+        if img is None:                                                  # a direct caller (no WeightImages of the whole Transformer): pack here
+            wi = WeightImages(dtype, x.device)
+            img = dict(wq=wi.both(wq), wkv=wi.both(wkv), wo=wi.both(wo))
+            wi.refresh()
+            meta = meta[:-1] + (img,)
         dev = x.device
         M, D = x.shape
         inner = wq.shape[0]
@@ -258,8 +382,8 @@ class _AttnBlock(torch.autograd.Function):
                 src = context
         else:
             src = x
-        q = linear_fwd(dtype, xn, wq)
-        kv = linear_fwd(dtype, src, wkv)
+        q = linear_fwd(dtype, xn, wq, Wimg=img['wq'][0])
+        kv = linear_fwd(dtype, src, wkv, Wimg=img['wkv'][0])
         td = L.tdtype(dtype)
         nq_pad, nk_pad = L.attn_pads(n, n_kv, nnull)
         Qp = torch.empty((S * heads * nq_pad * 64,), device=dev, dtype=td)
@@ -267,17 +391,20 @@ class _AttnBlock(torch.autograd.Function):
         Vt = torch.empty((S * heads * nk_pad * 64,), device=dev, dtype=td)
         L.attn_prep(dtype, q, kv, null_kv.detach(), q_scale.detach(), k_scale.detach(), float(scale), Qp, Kp, Vt, S, heads, n, n_kv, nnull)
         o = _f32((M, inner), dev)
-        L.attn_fwd(dtype, Qp, Kp, Vt, o, S, heads, n, n_kv, nnull, bias=bias, kmask=kmask, slopes=slopes, causal=slopes is not None)
+        # every score row's log-sum-exp: the backward kernels start from it.  Not in the bf16 mode: its forward scores come from bf16 operands, the
+        # backward recomputes them from split f32 ones -- P = exp(s - lse) must use the lse of the SAME scores, so that mode keeps the extra pass
+        lse = _f32((S * heads * n,), dev) if dtype != L.BF16 else None
+        L.attn_fwd(dtype, Qp, Kp, Vt, o, S, heads, n, n_kv, nnull, bias=bias, kmask=kmask, slopes=slopes, causal=slopes is not None, lse=lse)
         y = _f32((M, D), dev)
-        L.gemm(dtype, o, pack_operand(wo, dtype), M, D, inner, C=y, res=x)
-        ctx.save_for_backward(x, context, gamma, cgamma, wq, wkv, null_kv, q_scale, k_scale, wo, bias, kmask, xn, src, q, kv, o)
+        L.gemm(dtype, o, img['wo'][0], M, D, inner, C=y, res=x)
+        ctx.save_for_backward(x, context, gamma, cgamma, wq, wkv, null_kv, q_scale, k_scale, wo, bias, kmask, xn, src, q, kv, o, lse)
         ctx.meta = meta
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, context, gamma, cgamma, wq, wkv, null_kv, q_scale, k_scale, wo, bias, kmask, xn, src, q, kv, o = ctx.saved_tensors
-        dtype, S, n, n_ctx, heads, scale, eps, slopes = ctx.meta
+        x, context, gamma, cgamma, wq, wkv, null_kv, q_scale, k_scale, wo, bias, kmask, xn, src, q, kv, o, lse = ctx.saved_tensors
+        dtype, S, n, n_ctx, heads, scale, eps, slopes, img = ctx.meta
         dev = x.device
         M, D = x.shape
         inner = wq.shape[0]
@@ -286,8 +413,10 @@ class _AttnBlock(torch.autograd.Function):
         n_kv = n_ctx if is_cross else n
         nkt = nnull + n_kv
         dy = dy.contiguous()
+        sums = []
         # ---- to_out
-        do, dWo = linear_bwd(dtype, o, wo, dy)
+        dyT, oT = transposes(dtype, [(dy, 'a'), (o, 'w')])
+        do, dWo = linear_bwd(dtype, o, wo, dy, Wt=img['wo'][1], dyT=dyT, xT=oT, defer=sums)
         # ---- attention core
         Qh, Kh, Vh = _f32((S * heads * n, 64), dev), _f32((S * heads * nkt, 64), dev), _f32((S * heads * nkt, 64), dev)
         L.attn_train_prep(q, kv, null_kv.detach(), q_scale.detach(), k_scale.detach(), float(scale), Qh, Kh, Vh, S, heads, n, n_kv, nnull)
@@ -295,7 +424,7 @@ class _AttnBlock(torch.autograd.Function):
         want_dbias = bias is not None and ctx.needs_input_grad[12]
         dS = _f32((S, heads * n * n_kv), dev) if want_dbias else None
         L.attn_bwd(Qh, Kh, Vh, o, do, dQh, dKh, dVh, S, heads, n, n_kv, nnull, bias=bias, kmask=kmask, dS=dS, slopes=slopes, causal=slopes is not None,
-                   split_bf16=dtype != L.F32)
+                   split_bf16=dtype != L.F32, lse=lse)
         dbias = None
         if want_dbias:
             dbias = _f32(tuple(bias.shape), dev)
@@ -306,12 +435,14 @@ class _AttnBlock(torch.autograd.Function):
         if dnull is None:
             dnull = torch.zeros_like(null_kv)
         # ---- projections, LayerNorms, residual
-        dxn, dWq = linear_bwd(dtype, xn, wq, dq)
+        dqT, xnT, dkvT, srcT = transposes(dtype, [(dq, 'a'), (xn, 'w'), (dkv, 'a'), (src, 'w')])
+        dxn, dWq = linear_bwd(dtype, xn, wq, dq, Wt=img['wq'][1], dyT=dqT, xT=xnT, defer=sums)
         dx = _f32((M, D), dev)
         dcg = dctx = None
         if is_cross:
             need_ctx = ctx.needs_input_grad[1]
-            dsrc, dWkv = linear_bwd(dtype, src, wkv, dkv, need_dx=(cgamma is not None) or need_ctx)
+            dsrc, dWkv = linear_bwd(dtype, src, wkv, dkv, need_dx=(cgamma is not None) or need_ctx, Wt=img['wkv'][1], dyT=dkvT, xT=srcT, defer=sums)
+            _flush_sums(sums)
             if cgamma is not None:
                 dctx = _f32(tuple(context.shape), dev)
                 dcg, _ = L.layernorm_bwd(context, cgamma.detach(), dsrc, dctx, context.shape[0], context.shape[1], eps=eps)
@@ -319,7 +450,8 @@ class _AttnBlock(torch.autograd.Function):
                 dctx = dsrc
             dg, _ = L.layernorm_bwd(x, gamma.detach(), dxn, dx, M, D, add=dy, eps=eps)
         else:
-            t, dWkv = linear_bwd(dtype, x, wkv, dkv, add=dy)               # dy + dkv Wkv: K / V read the un-normalised x
+            t, dWkv = linear_bwd(dtype, x, wkv, dkv, add=dy, Wt=img['wkv'][1], dyT=dkvT, xT=srcT, defer=sums)   # dy + dkv Wkv: K / V read the un-normalised x
+            _flush_sums(sums)
             dg, _ = L.layernorm_bwd(x, gamma.detach(), dxn, dx, M, D, add=t, eps=eps)
         return dx, dctx, dg, None, dcg, None, dWq, dWkv, dnull, dqs, dks, dWo, dbias, None, None
 
@@ -444,7 +576,8 @@ class _VocabCrossEntropy(torch.autograd.Function):
     """mean over the selected rows of CE(E[rows] W^T + b, targets[rows]); the (rows, V) logits are never stored (phenaki_pytorch.py:640-643)"""
 
     @staticmethod
-    def forward(ctx, embeds, weight, bias, targets, rows, dtype, slab):
+    def forward(ctx, embeds, weight, bias, targets, rows, dtype, slab, imgs=None):
+        """imgs: (image of W, image of W^T) from `linear_images` (already refreshed), else packed here"""
         L.require_device(embeds, 'embeds')
         R, D = embeds.shape
         V = weight.shape[0]
@@ -459,7 +592,7 @@ class _VocabCrossEntropy(torch.autograd.Function):
         else:
             A = torch.empty((M, D), device=dev, dtype=td)
             L.pack(E, M, D, False, A, D, 1 if td == torch.bfloat16 else 0, rows=rows)
-        Wp = _operand(weight.detach().float(), dtype)
+        Wp = imgs[0] if imgs is not None else _operand(weight.detach().float(), dtype)
         b = bias.detach().float().contiguous() if bias is not None else torch.zeros((V,), device=dev)
         tg = targets.detach().long().contiguous()
         partials = torch.empty((5 * L.vocab_ntiles(V) * M,), device=dev, dtype=torch.float32)
@@ -470,7 +603,7 @@ class _VocabCrossEntropy(torch.autograd.Function):
         # A (the gathered operand rows) and Wp (the packed vocabulary weight: 64-134 MB at V = 65 536) go through save_for_backward like the rest,
         # so they are released when autograd frees the saved tensors and take part in its version checks
         ctx.save_for_backward(E, weight, b, tg, lse, rows, A, Wp)
-        ctx.dtype, ctx.slab, ctx.has_bias = dtype, slab, bias is not None
+        ctx.dtype, ctx.slab, ctx.has_bias, ctx.Wt = dtype, slab, bias is not None, (imgs[1] if imgs is not None else None)
         return L.colsum(loss_rows.view(M, 1), M, 1, torch.empty((1,), device=dev, dtype=torch.float32), scale=1.0 / M).reshape(())
 
     @staticmethod
@@ -487,7 +620,7 @@ class _VocabCrossEntropy(torch.autograd.Function):
         scale = 1.0 / M
         gdev = grad_out.detach().float().reshape(1).contiguous()         # the upstream gradient is read on the device: no host sync in backward
         # operands of the two gradient products (W-side images: rows = output features, K along the contraction)
-        Wt = pack_operand(weight.detach(), dtype, transpose=True)               # (D, Vp): dE = g @ W   -> "W" operand = W^T, K = vocabulary
+        Wt = ctx.Wt if ctx.Wt is not None else pack_operand(weight.detach(), dtype, transpose=True)   # (D, Vp): dE = g @ W   -> "W" operand = W^T, K = vocabulary
         Af = A.float() if A.dtype != torch.float32 else A
         Et = pack_operand(Af, dtype, transpose=True)                             # (D, Mp): dW = g^T @ E -> "W" operand = E^T, K = rows
         dE = torch.empty((M, D), device=dev, dtype=torch.float32)
@@ -512,7 +645,7 @@ class _VocabCrossEntropy(torch.autograd.Function):
             full = _zeros((R, D), dev)
             L.scatter_rows(dE, rows, full, M, D)
             dE = full
-        return dE, dW, (db if ctx.has_bias else None), None, None, None, None
+        return dE, dW, (db if ctx.has_bias else None), None, None, None, None, None
 
 
 class _Linear(torch.autograd.Function):
@@ -587,29 +720,29 @@ def vocab_cross_entropy(embeds, weight, bias, targets, compute_dtype='bf16x3', s
     loss is taken over (None: all).  slab: vocabulary columns per backward step (a multiple of 64)."""
     assert slab % 64 == 0 and slab > 0
     assert weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0, 'vocabulary size and embedding width must be multiples of 8'
-    return _VocabCrossEntropy.apply(embeds, weight, bias, targets, rows, resolve_dtype(compute_dtype), int(slab))
+    return _VocabCrossEntropy.apply(embeds, weight, bias, targets, rows, resolve_dtype(compute_dtype), int(slab), None)
 
 
 def layernorm_train(ln: LayerNorm, x2d):
     return _LayerNormFn.apply(x2d, ln.gamma, ln.beta, ln.eps)
 
 
-def feedforward_train(ff: FeedForwardSeq, x2d, dtype):
+def feedforward_train(ff: FeedForwardSeq, x2d, dtype, img=None):
     ln, lin1, lin2 = ff[0], ff[1], ff[4]
     assert ff[3].p == 0., 'the training kernels are built for ff_dropout = 0 (the reference default)'
-    return _FFBlock.apply(x2d, ln.weight, ln.bias, lin1.weight, lin2.weight, dtype, ln.eps)
+    return _FFBlock.apply(x2d, ln.weight, ln.bias, lin1.weight, lin2.weight, dtype, ln.eps, img)
 
 
 def peg_train(peg: PEG, x2d, shape):
     return _PEGBlock.apply(x2d, peg.dsconv.weight, peg.dsconv.bias, tuple(shape), peg.causal)
 
 
-def attention_train(attn: Attention, x2d, S, n, dtype, *, context2d=None, n_ctx=None, attn_bias=None, kmask=None):
+def attention_train(attn: Attention, x2d, S, n, dtype, *, context2d=None, n_ctx=None, attn_bias=None, kmask=None, img=None):
     assert attn.attn_dropout.p == 0., 'the training kernels are built for attn_dropout = 0 (the reference default)'
     assert not (attn.causal and context2d is not None), 'causal attention is self-attention (attention.py:166-172)'
     cn = attn.context_norm if isinstance(attn.context_norm, LayerNorm) else None
     slopes = attn.rel_pos_bias.slopes.reshape(-1).contiguous() if attn.causal else None     # ALiBi + causal mask inside the kernels
-    meta = (dtype, S, n, n_ctx, attn.heads, float(attn.scale), attn.norm.eps, slopes)
+    meta = (dtype, S, n, n_ctx, attn.heads, float(attn.scale), attn.norm.eps, slopes, img)
     return _AttnBlock.apply(x2d, context2d, attn.norm.gamma, attn.norm.beta, cn.gamma if (cn is not None and context2d is not None) else None,
                             cn.beta if cn is not None else None, attn.to_q.weight, attn.to_kv.weight, attn.null_kv, attn.q_scale, attn.k_scale,
                             attn.to_out.weight, attn_bias, kmask, meta)
@@ -631,13 +764,15 @@ def transformer_train(tr, x2d, S, n, dtype, *, video_shape=None, attn_bias=None,
                       cross_attn_context_mask=None):
     """attention.py:315-332 on (S n, D) f32 rows, every block an autograd Function"""
     x = x2d
-    for peg, self_attn, cross_attn, ff in tr.layers:
+    wi = transformer_images(tr, dtype)
+    wi.refresh()                                                         # ONE launch: every projection weight of the stack, W and W^T images
+    for (peg, self_attn, cross_attn, ff), img in zip(tr.layers, wi.layers):
         if exists(peg):
             x = peg_train(peg, x, video_shape)
-        x = attention_train(self_attn, x, S, n, dtype, attn_bias=attn_bias, kmask=self_attn_mask)
+        x = attention_train(self_attn, x, S, n, dtype, attn_bias=attn_bias, kmask=self_attn_mask, img=img['sa'])
         if exists(cross_attn) and exists(context2d):
-            x = attention_train(cross_attn, x, S, n, dtype, context2d=context2d, n_ctx=n_ctx, kmask=cross_attn_context_mask)
-        x = feedforward_train(ff, x, dtype)
+            x = attention_train(cross_attn, x, S, n, dtype, context2d=context2d, n_ctx=n_ctx, kmask=cross_attn_context_mask, img=img['ca'])
+        x = feedforward_train(ff, x, dtype, img['ff'])
     return layernorm_train(tr.norm_out, x)
 
 
@@ -771,9 +906,13 @@ def phenaki_loss(ph, videos=None, *, texts=None, video_codebook_ids=None, video_
         e = trunk_train(mg, masked_input, patch_shape, context=text_embeds, text_mask=text_mask, video_mask=video_mask, use_bias=True,
                         use_cross=not mg.unconditional, alpha=mg.gradient_shrink_alpha)
     loss = None
-    if not only_train_critic:
-        loss = _VocabCrossEntropy.apply(e, mg.to_logits.weight, mg.to_logits.bias, ids.reshape(-1), rows, dt, 2048)
     need_critic = exists(critic) and not only_train_generator
+    head = None
+    if mg.to_logits.weight.dtype == torch.float32 and mg.to_logits.weight.is_contiguous():
+        head = linear_images(mg.to_logits, dt)                           # W and W^T images of the vocabulary head, one launch for both
+        head.refresh()
+    if not only_train_critic:
+        loss = _VocabCrossEntropy.apply(e, mg.to_logits.weight, mg.to_logits.bias, ids.reshape(-1), rows, dt, 2048, head.pair if head is not None else None)
     if not need_critic:
         return loss
     # the critic's input: gumbel-sampled predictions at every position (phenaki_pytorch.py:653-659), no gradient through the ids
@@ -781,7 +920,7 @@ def phenaki_loss(ph, videos=None, *, texts=None, video_codebook_ids=None, video_
         M = b * n
         ed = e.detach()
         A = ed.to(L.tdtype(dt)) if L.tdtype(dt) != torch.float32 else ed
-        w_logits = pack_operand(mg.to_logits.weight.detach(), dt)
+        w_logits = head.pair[0] if head is not None else pack_operand(mg.to_logits.weight.detach(), dt)
         partials = torch.empty((5 * L.vocab_ntiles(V) * M,), device=device, dtype=torch.float32)
         U = draws['gumbel_u'].to(device).float().contiguous() if 'gumbel_u' in draws else None
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if U is None else 0

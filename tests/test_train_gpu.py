@@ -68,6 +68,67 @@ def test_pack_colsum_scatter_kernels():
     assert torch.equal(dst[r4.long()], s4) and float(dst.abs().sum()) == pytest.approx(float(s4.abs().sum()), rel=1e-6)
 
 
+def _unsplit(out, kind, R, Kp):
+    """an operand image of pk_pack back as f32 (kind 2: hi + lo planes of each 32-element block)"""
+    if kind == 2:
+        img = out.view(torch.bfloat16).view(R, Kp // 32, 2, 32).float()
+        return (img[:, :, 0] + img[:, :, 1]).reshape(R, Kp)
+    return out.float()
+
+
+def test_multi_job_pack_sum_and_one_launch_colsum():
+    """round 6: pk_pack_multi / pk_pack_table (several operand images per launch, incl. column / row blocks inside a larger image),
+    pk_sum_batch_multi, and pk_colsum's one-launch form -- each against the single-job entry point or a float64 sum"""
+    from phenaki_pytorch_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+    mats = [torch.randn(r, c, generator=g).cuda() for r, c in ((133, 71), (64, 64), (300, 1365), (7, 520), (1365, 96), (96, 40), (200, 33), (65, 129), (31, 17), (512, 512))]
+    for kind, q in ((0, 32), (1, 64), (2, 32)):
+        td = torch.bfloat16 if kind == 1 else torch.float32
+        jobs, outs, want = [], [], []
+        for i, m in enumerate(mats):
+            tr = i % 2 == 1
+            R, K = (m.shape[1], m.shape[0]) if tr else tuple(m.shape)
+            Kp = (K + q - 1) // q * q
+            out = torch.full((R, Kp), 7.0, device='cuda', dtype=td)
+            ref = torch.full((R, Kp), 7.0, device='cuda', dtype=td)
+            L.pack(m, R, K, tr, ref, Kp, kind)
+            jobs.append(L.pack_job(m, R, K, tr, out, Kp, kind))
+            outs.append(out)
+            want.append(ref)
+        L.pack_multi(jobs, mats[0])                                 # 10 jobs: two launches (8 + 2)
+        for o, w in zip(outs, want):
+            assert torch.equal(o.view(torch.int16 if kind == 1 else torch.int32), w.view(torch.int16 if kind == 1 else torch.int32))
+        # the device-table form, with blocks inside a zero-initialised image: rows [0, 40) and [48, 88) <- two matrices, and a transposed column block
+        a, b = torch.randn(40, 100, generator=g).cuda(), torch.randn(40, 100, generator=g).cuda()
+        Kp = (100 + q - 1) // q * q
+        img = torch.zeros((96, Kp), device='cuda', dtype=td)
+        Kq = (96 + q - 1) // q * q
+        imgT = torch.zeros((100, Kq), device='cuda', dtype=td)
+        tab = L.PackTable([L.pack_job(a, 40, 100, False, img[:40], Kp, kind), L.pack_job(b, 40, 100, False, img[48:88], Kp, kind),
+                           L.pack_job(a, 100, 40, True, imgT[:, :48], 40, kind), L.pack_job(b, 100, 40, True, imgT[:, 48:96], 40, kind)], 'cuda')
+        for _ in range(2):                                           # replayed: same bytes
+            tab.run()
+        tol = 0 if kind == 0 else (4e-3 if kind == 1 else 2e-5)
+        got, gotT = _unsplit(img, kind, 96, Kp), _unsplit(imgT, kind, 100, Kq)
+        full = torch.zeros((96, 100), device='cuda')
+        full[:40], full[48:88] = a, b
+        assert (got[:, :100] - full).abs().max() <= tol * 4 and (got[:, 100:] == 0).all()
+        assert (gotT[:, :96] - full.t()).abs().max() <= tol * 4 and (gotT[:, 96:] == 0).all()
+    parts = [torch.randn(s, e, generator=g).cuda() for s, e in ((8, 512 * 512), (4, 1368 * 512), (2, 64), (8, 1365 * 512))]
+    outs = [torch.empty(p_.shape[1], device='cuda') for p_ in parts]
+    L.sum_batch_multi([(p_, p_.shape[0], o, p_.shape[1]) for p_, o in zip(parts, outs)])
+    for p_, o in zip(parts, outs):
+        ref = torch.empty_like(o)
+        L.sum_batch(p_, p_.shape[0], ref, p_.shape[1])
+        assert torch.equal(o, ref)
+    for M, N in ((144, 512), (288, 27 * 512), (1024, 128), (144, 1), (200, 33), (1000, 1024)):
+        src = torch.randn(M, N, generator=g).cuda()
+        cs = L.colsum(src, M, N, torch.empty(N, device='cuda'), scale=0.25)
+        close(cs.cpu(), 0.25 * src.cpu().double().sum(0).float(), 1e-5, f'colsum one launch {M}x{N}')
+        cs2 = L.colsum(src, M, N, cs.clone(), accumulate=True)
+        close((cs2 - cs).cpu(), src.cpu().double().sum(0).float(), 1e-4, f'colsum one launch accumulate {M}x{N}')
+
+
 @pytest.mark.parametrize('D', [512, 768, 64])
 def test_layernorm_backward(D):
     from phenaki_pytorch_amd import _lib as L

@@ -15,6 +15,21 @@ if sys.argv[1] == '--summary':
     print(f'# {path}: {tot / 1e6 / steps:.2f} ms of kernel time and {n / steps:.0f} launches per step ({steps} steps incl. 2 warm-up)')
     for r in rows[:45]:
         print(f"{float(r['TotalDurationNs']) / tot * 100:5.1f}%  {int(r['Calls']) / steps:7.1f} / step x {float(r['AverageNs']) / 1e3:8.1f} us  {r['Name'][:130]}")
+    # the attention kernels by grid size (self-attention n = 576 vs the 14-key cross-attention share one kernel name)
+    tr = glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True)
+    if tr:
+        import collections
+        acc = collections.defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(tr[0])):
+            nm = r['Kernel_Name']
+            if 'attn' not in nm:
+                continue
+            key = (nm[:60], r.get('Grid_Size_X', r.get('Grid_Size', '?')))
+            acc[key][0] += 1
+            acc[key][1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+        print('# attention kernels by grid size (threads): launches per step x average us')
+        for (nm, grid), (n_, us) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+            print(f'{n_ / steps:7.1f} / step x {us / n_:8.1f} us  grid {grid:>8}  {nm}')
     sys.exit(0)
 
 import torch  # noqa: E402
