@@ -427,6 +427,12 @@ int pk_attn_train_prep_bwd(const float* q, long long ldq, const float* kv, long 
 int pk_attn_bwd(const float* Qh, const float* Kh, const float* Vh, const void* O, long long ldo, int o_bf16, const float* dO, long long lddo,
                 const float* bias, const unsigned char* kmask, const float* slopes, int causal, float* dQh, float* dKh, float* dVh, float* dS,
                 float* lse, float* Drow, int S, int heads, int n, int n_kv, int nnull, int split_bf16, void* stream);
+/* the same with a workspace of pk_attn_bwd_work(...) floats (0: none needed): with few key tiles (cross-attention on 14 keys: one tile per head) the
+ * query tiles of a key tile are dealt to several workgroups whose partial dK^ / dV slabs are added in index order (deterministic). */
+int pk_attn_bwd_work(int S, int heads, int n, int n_kv, int nnull);
+int pk_attn_bwd_ws(const float* Qh, const float* Kh, const float* Vh, const void* O, long long ldo, int o_bf16, const float* dO, long long lddo,
+                   const float* bias, const unsigned char* kmask, const float* slopes, int causal, float* dQh, float* dKh, float* dVh, float* dS,
+                   float* lse, float* Drow, int S, int heads, int n, int n_kv, int nnull, int split_bf16, float* work, long long work_floats, void* stream);
 
 /* ---- the tokenizer's adversarial branch: cvivit.py:59-213 (Discriminator), :604-671 (hinge / gradient penalty / adaptive weight).
  * Images are CHANNELS-LAST pixel rows x[(b, y, x)][c] (f32, C % 4 == 0), so every nn.Conv2d (cvivit.py:115-127, 191) is pk_gemm on a patch matrix:

@@ -99,6 +99,8 @@ SIGNATURES = {
     'pk_adamw': [_P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _LL, _P],
     'pk_adamw_multi': [_P, _I, _F, _F, _F, _F, _F, _I, _P],
     'pk_attn_bwd': [_P, _P, _P, _P, _LL, _I, _P, _LL, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    'pk_attn_bwd_ws': [_P, _P, _P, _P, _LL, _I, _P, _LL, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _LL, _P],
+    'pk_attn_bwd_work': [_I, _I, _I, _I, _I],
     'pk_im2col': [_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _LL, _P],
     'pk_col2im': [_P, _LL, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     'pk_nchw_to_rows': [_P, _I, _I, _I, _I, _I, _P, _P],
@@ -741,8 +743,11 @@ def attn_bwd(Qh, Kh, Vh, O, dO, dQh, dKh, dVh, S, h, n, n_kv, nnull, *, bias=Non
     if lse is None:
         lse = torch.empty((S * h * n,), device=dev, dtype=torch.float32)
     drow = torch.empty((S * h * n,), device=dev, dtype=torch.float32)
-    rc = load().pk_attn_bwd(ptr(Qh), ptr(Kh), ptr(Vh), ptr(O), O.stride(-2), 1 if O.dtype == torch.bfloat16 else 0, ptr(dO), dO.stride(-2), ptr(bias), ptr(kmask),
-                            f32p(slopes, 'ALiBi slopes') if causal else None, 1 if causal else 0, ptr(dQh), ptr(dKh), ptr(dVh), ptr(dS), ptr(lse), ptr(drow), S, h, n, n_kv, nnull, flags, stream(Qh))
+    nwork = load().pk_attn_bwd_work(S, h, n, n_kv, nnull)                  # few key tiles: partial dK / dV slabs of the query-tile groups
+    work = torch.empty((nwork,), device=dev, dtype=torch.float32) if nwork > 0 else None
+    rc = load().pk_attn_bwd_ws(ptr(Qh), ptr(Kh), ptr(Vh), ptr(O), O.stride(-2), 1 if O.dtype == torch.bfloat16 else 0, ptr(dO), dO.stride(-2), ptr(bias), ptr(kmask),
+                               f32p(slopes, 'ALiBi slopes') if causal else None, 1 if causal else 0, ptr(dQh), ptr(dKh), ptr(dVh), ptr(dS), ptr(lse), ptr(drow), S, h, n, n_kv, nnull, flags,
+                               ptr(work), nwork if nwork > 0 else 0, stream(Qh))
     _check(rc, 'pk_attn_bwd')
 
 

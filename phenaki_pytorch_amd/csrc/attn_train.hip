@@ -189,6 +189,10 @@ struct AttnBwdArgs {
     // flat [S*h][n][64] arrays) and scores exist only inside a group (block-diagonal); act_heads / act_groups = the real heads / S * heads.
     int pack_n, pack_g, act_heads, act_groups, pack_inv;     // pack_inv = 65536 / pack_n + 1: row / pack_n = (row * pack_inv) >> 16 for row < 64
     int have_lse;                                            // lse was written by the forward (pk_attn_fwd_lse): kernel Q skips its own pass over the keys
+    // kernel KV with few key tiles (cross-attention: 14 keys = ONE tile per head, 64 workgroups walking 18 query tiles each, 75 us): the query tiles
+    // are dealt to kv_split workgroups per key tile, each writing its partial dK^ / dV to kv_part (+ kv_split slabs of the dKh layout, dV behind dK);
+    // the host adds the slabs in index order (deterministic).  kv_split <= 1: one workgroup per key tile writes dKh / dVh itself.
+    int kv_split, kv_chunk; float* kv_part;
 };
 
 // element offset of row vr (of this workgroup's virtual head sh) in the heads-merged O / dO matrices, or -1 beyond the data
@@ -302,6 +306,8 @@ __device__ __forceinline__ bool score(const AttnBwdArgs& p, int s, int h, int gi
 // are fetched into registers while the current one is being multiplied.
 // 2 waves per SIMD (two workgroups per CU, which the 70 KB of LDS allow): without the bound the compiler took 255 VGPRs + 42 AGPRs = ONE wave per
 // SIMD -- 256 resident workgroups, so the 576 of a B = 8 step ran in three rounds
+// (round 6, measured and removed: a variant whose dS rows shared the V tile's LDS -- 52 KB and a 168-register cap, three workgroups per CU so that the 576
+// workgroups of a B = 8 step run in one round instead of 512 + 64 -- spilled 210 VGPRs and lost: training step 30.13 vs 29.34 ms same-box.)
 template <bool X3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_q_kernel(const AttnBwdArgs p) {
     typedef typename OpFragOf<X3>::type OF;
@@ -451,7 +457,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     float* lse_s = PS + 64 * TLQ; float* D_s = lse_s + QT;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
     const int ntl = (p.nkt + 63) / 64;
-    const int kt = blockIdx.x % ntl, sh = blockIdx.x / ntl, h = sh % p.heads, s = sh / p.heads;
+    const int G = p.kv_split > 1 ? p.kv_split : 1;
+    const int gq = blockIdx.x % G, tile = blockIdx.x / G;
+    const int kt = tile % ntl, sh = tile / ntl, h = sh % p.heads, s = sh / p.heads;
     const int j0 = kt * 64, m0 = wv * 16;
     const int nlive = live_rows(p, sh), klive = p.pack_n ? nlive : p.nkt;
     Frag<float> fk[2], fv[2];
@@ -462,12 +470,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int c = 0; c < 2; ++c) { to_operand(fkx[c], fk[c]); to_operand(fvx[c], fv[c]); }
     f32x4 accK[4] = PK_ZERO4;
     f32x4 accV[4] = PK_ZERO4;
-    const int nqt = (p.n + QT - 1) / QT;
+    const int nqt_all = (p.n + QT - 1) / QT;
+    const int qt0 = G > 1 ? gq * p.kv_chunk : 0;
+    const int nqt = G > 1 ? (qt0 + p.kv_chunk < nqt_all ? qt0 + p.kv_chunk : nqt_all) : nqt_all;
     const float* Qbase = p.Qh + (long)sh * p.n * 64;
     f32x4 qreg[2], dreg[2];
-    fetch_tile<QT>(qreg, Qbase, 64, 0, nlive);
-    fetch_tile_merged<QT>(dreg, p.dO, p.lddo, p, sh, 0);
-    for (int qt = 0; qt < nqt; ++qt) {
+    fetch_tile<QT>(qreg, Qbase, 64, qt0 * QT, nlive);
+    fetch_tile_merged<QT>(dreg, p.dO, p.lddo, p, sh, qt0 * QT);
+    for (int qt = qt0; qt < nqt; ++qt) {
         const int i0 = qt * QT;
         __syncthreads();                                          // the previous tile's readers are done
         stash_tile<QT>(qreg, Qs, TLD, Qt, TLQ);
@@ -515,8 +525,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int i = 0; i < 4; ++i) {
             const int gj = j0 + m0 + kq * 4 + i;
             if (gj < klive) {
-                p.dKh[((long)sh * p.nkt + gj) * 64 + nb * 16 + r] = accK[nb][i];
-                p.dVh[((long)sh * p.nkt + gj) * 64 + nb * 16 + r] = accV[nb][i];
+                const long o = ((long)sh * p.nkt + gj) * 64 + nb * 16 + r;
+                if (G > 1) {
+                    const long slab = (long)p.S * p.heads * p.nkt * 64;
+                    p.kv_part[(long)gq * slab + o] = accK[nb][i];
+                    p.kv_part[(long)(G + gq) * slab + o] = accV[nb][i];
+                } else {
+                    p.dKh[o] = accK[nb][i];
+                    p.dVh[o] = accV[nb][i];
+                }
             }
         }
 }
@@ -561,9 +578,38 @@ extern "C" int pk_attn_train_prep_bwd(const float* q, long ldq, const float* kv,
 // causal (self-attention, attention.py:166-172): ALiBi with slopes [heads] over all nnull + n keys, then key j > nnull + i masked.
 // lse / Drow: (S heads n) f32 scratch.  split_bf16 is a flag word: bit 0 = split-bf16 tile products, bit 1 = lse already holds the log-sum-exp of
 // every score row (written by pk_attn_fwd_lse in the forward pass): kernel Q then skips its own pass over the keys.
+extern "C" int pk_sum_batch_multi(const void* jobs, int count, void* stream);
+namespace { struct SumJobHost { const float* src; float* out; long stride, E4; int S, blk0; }; }   // = PkSumJob (include/phenaki_hip.h)
+
+// floats of workspace pk_attn_bwd_ws wants for the shape (0: the query tiles are not dealt out)
+static int kv_split_of(int S, int heads, int n, int nkt, int* chunk) {
+    const int ntl = (nkt + 63) / 64, nqt = (n + QT - 1) / QT;
+    const long wgs = (long)S * heads * ntl;
+    int G = (int)(768 / (wgs > 0 ? wgs : 1));
+    if (G < 2 || nqt < 2) { *chunk = nqt; return 1; }
+    if (G > nqt) G = nqt;
+    *chunk = (nqt + G - 1) / G;
+    return (nqt + *chunk - 1) / *chunk;
+}
+extern "C" int pk_attn_bwd_work(int S, int heads, int n, int n_kv, int nnull) {
+    if (S <= 0 || heads <= 0 || n <= 0 || n_kv <= 0 || nnull < 0) return PK_EINVAL;
+    int chunk;
+    const int G = kv_split_of(S, heads, n, nnull + n_kv, &chunk);
+    return G > 1 ? (int)(2L * G * S * heads * (nnull + n_kv) * 64) : 0;          // G > 1 only below 384 key tiles: < 2^24 floats
+}
+extern "C" int pk_attn_bwd_ws(const float* Qh, const float* Kh, const float* Vh, const void* O, long ldo, int o_bf16, const float* dO, long lddo,
+                              const float* bias, const unsigned char* kmask, const float* slopes, int causal, float* dQh, float* dKh, float* dVh, float* dS,
+                              float* lse, float* Drow, int S, int heads, int n, int n_kv, int nnull, int split_bf16, float* work, long work_floats, void* stream);
 extern "C" int pk_attn_bwd(const float* Qh, const float* Kh, const float* Vh, const void* O, long ldo, int o_bf16, const float* dO, long lddo,
                            const float* bias, const unsigned char* kmask, const float* slopes, int causal, float* dQh, float* dKh, float* dVh, float* dS,
                            float* lse, float* Drow, int S, int heads, int n, int n_kv, int nnull, int split_bf16, void* stream) {
+    return pk_attn_bwd_ws(Qh, Kh, Vh, O, ldo, o_bf16, dO, lddo, bias, kmask, slopes, causal, dQh, dKh, dVh, dS, lse, Drow, S, heads, n, n_kv, nnull, split_bf16,
+                          nullptr, 0, stream);
+}
+// work (pk_attn_bwd_work floats, or NULL): lets kernel KV deal the query tiles of a key tile to several workgroups when there are few key tiles
+extern "C" int pk_attn_bwd_ws(const float* Qh, const float* Kh, const float* Vh, const void* O, long ldo, int o_bf16, const float* dO, long lddo,
+                              const float* bias, const unsigned char* kmask, const float* slopes, int causal, float* dQh, float* dKh, float* dVh, float* dS,
+                              float* lse, float* Drow, int S, int heads, int n, int n_kv, int nnull, int split_bf16, float* work, long work_floats, void* stream) {
     if (!Qh || !Kh || !Vh || !O || !dO || !dQh || !dKh || !dVh || !lse || !Drow || S <= 0 || heads <= 0 || n <= 0 || n_kv <= 0 || nnull < 0) return PK_EINVAL;
     if (!al16(Qh) || !al16(Kh) || !al16(Vh) || !al16(dO) || (lddo & 3) || !al16(O) || (ldo & (o_bf16 ? 7 : 3))) return PK_EALIGN;
     if ((long)S * heads > 0x7fffffffL / 64) return PK_EINVAL;
@@ -593,7 +639,15 @@ extern "C" int pk_attn_bwd(const float* Qh, const float* Kh, const float* Vh, co
         attr_done = true;
     }
     const int nqt = (p.n + 63) / 64, nktt = (p.nkt + 63) / 64;
-    const dim3 gq((unsigned)((long)p.S * p.heads * nqt)), gk((unsigned)((long)p.S * p.heads * nktt));
+    if (work && !p.pack_n) {
+        int chunk;
+        const int G = kv_split_of(p.S, p.heads, p.n, p.nkt, &chunk);
+        if (G > 1) {
+            if (work_floats < 2L * G * p.S * p.heads * p.nkt * 64 || !al16(work)) return PK_EINVAL;
+            p.kv_split = G; p.kv_chunk = chunk; p.kv_part = work;
+        }
+    }
+    const dim3 gq((unsigned)((long)p.S * p.heads * nqt)), gk((unsigned)((long)p.S * p.heads * nktt * (p.kv_split > 1 ? p.kv_split : 1)));
     static const bool split_on = !(getenv("PK_ATTN_BWD_SPLIT") && getenv("PK_ATTN_BWD_SPLIT")[0] == '0');     // A/B switch
     if (split_bf16 && split_on) {
         hipLaunchKernelGGL(attn_bwd_q_kernel<true>, gq, dim3(256), 4 * TSZ * 4, s, p);
@@ -603,5 +657,10 @@ extern "C" int pk_attn_bwd(const float* Qh, const float* Kh, const float* Vh, co
         hipLaunchKernelGGL(attn_bwd_kv_kernel<false>, gk, dim3(256), KV_SMEM, s, p);
     }
     PK_CHECK_LAUNCH();
+    if (p.kv_split > 1) {                                                // dK^ / dV = the slabs added in index order (one launch for both)
+        const long slab = (long)p.S * p.heads * p.nkt * 64;
+        SumJobHost jobs[2] = {{work, dKh, slab, slab / 4, p.kv_split, 0}, {work + (long)p.kv_split * slab, dVh, slab, slab / 4, p.kv_split, 0}};
+        return pk_sum_batch_multi(jobs, 2, stream);
+    }
     return PK_OK;
 }

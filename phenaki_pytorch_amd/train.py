@@ -23,12 +23,17 @@ dW = dY^T X through pk_gemm on pk_pack(dY^T) and pk_pack(X^T) (contraction over 
 Limits (asserted): dropout 0 (the reference default).  The tokenizer's own reconstruction step is train_cvivit.py.
 """
 import math
+import os
 import weakref
 
 import torch
 
 from . import _lib as L
 from .attention import (Attention, FeedForwardSeq, LayerNorm, PEG, compute_dtype_of, exists, pack_linear_weight, resolve_dtype, round_up)
+
+
+# vocabulary columns per step of the cross-entropy backward (a multiple of 64; tuning knob PK_CE_SLAB, DESIGN 5.1)
+CE_SLAB = int(os.environ.get('PK_CE_SLAB', '2048'))
 
 
 def _q(dtype):
@@ -912,7 +917,7 @@ def phenaki_loss(ph, videos=None, *, texts=None, video_codebook_ids=None, video_
         head = linear_images(mg.to_logits, dt)                           # W and W^T images of the vocabulary head, one launch for both
         head.refresh()
     if not only_train_critic:
-        loss = _VocabCrossEntropy.apply(e, mg.to_logits.weight, mg.to_logits.bias, ids.reshape(-1), rows, dt, 2048, head.pair if head is not None else None)
+        loss = _VocabCrossEntropy.apply(e, mg.to_logits.weight, mg.to_logits.bias, ids.reshape(-1), rows, dt, CE_SLAB, head.pair if head is not None else None)
     if not need_critic:
         return loss
     # the critic's input: gumbel-sampled predictions at every position (phenaki_pytorch.py:653-659), no gradient through the ids

@@ -16,6 +16,13 @@ ab)     # same-box A/B against an export of the previous tree under _ab_old/ (al
     done
   done
   ;;
+env)    # same-box A/B of environment switches of THIS tree:  env "PK_X=0" "PK_X=1" ...
+  for i in 1 2; do
+    for e in "$@"; do
+      echo "== $e"; env $e timeout 300 python tools/train_time.py --mode bf16x3 --loss 2>&1 | tail -2
+    done
+  done
+  ;;
 census) # launches and kernel time per step
   R=$GRAFT_REPO_ROOT
   cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/census -o c -- python $R/tools/train_census.py ${1:-bf16x3} 6 > $R/gpurun_out/census_run.log 2>&1
