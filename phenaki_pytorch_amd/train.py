@@ -33,7 +33,7 @@ from .attention import (Attention, FeedForwardSeq, LayerNorm, PEG, compute_dtype
 
 
 # vocabulary columns per step of the cross-entropy backward (a multiple of 64; tuning knob PK_CE_SLAB)
-CE_SLAB = int(os.environ.get('PK_CE_SLAB', '2048'))
+CE_SLAB = int(os.environ.get('PK_CE_SLAB', '8192'))
 
 
 def _q(dtype):
@@ -581,8 +581,11 @@ class _VocabCrossEntropy(torch.autograd.Function):
     """mean over the selected rows of CE(E[rows] W^T + b, targets[rows]); the (rows, V) logits are never stored (phenaki_pytorch.py:640-643)"""
 
     @staticmethod
-    def forward(ctx, embeds, weight, bias, targets, rows, dtype, slab, imgs=None):
-        """imgs: (image of W, image of W^T) from `linear_images` (already refreshed), else packed here"""
+    def forward(ctx, embeds, weight, bias, targets, rows, dtype, slab, imgs=None, shared=None):
+        """imgs: (image of W, image of W^T) from `linear_images` (already refreshed), else packed here.  shared: (partials, M_all) of a
+        pk_vocab_sample call with need_lse over ALL rows of `embeds` on the same weight image (the critic's gumbel sampling of the training step,
+        phenaki_pytorch.py:653-655): its per-tile (max, sum-exp) statistics are temperature- and noise-free, so the rows of this loss take theirs
+        from it instead of a second pass over the vocabulary."""
         L.require_device(embeds, 'embeds')
         R, D = embeds.shape
         V = weight.shape[0]
@@ -600,8 +603,18 @@ class _VocabCrossEntropy(torch.autograd.Function):
         Wp = imgs[0] if imgs is not None else _operand(weight.detach().float(), dtype)
         b = bias.detach().float().contiguous() if bias is not None else torch.zeros((V,), device=dev)
         tg = targets.detach().long().contiguous()
-        partials = torch.empty((5 * L.vocab_ntiles(V) * M,), device=dev, dtype=torch.float32)
-        L.vocab_sample(dtype, A, Wp, b, M, V, D, 1.0, None, None, 0, True, partials, no_noise=True)
+        nt = L.vocab_ntiles(V)
+        partials = torch.empty((5 * nt * M,), device=dev, dtype=torch.float32)
+        if shared is not None:
+            pa, M_all = shared
+            stats = pa.view(5, nt, M_all)[3:5]                            # (max | sum-exp) planes, [tile][row]
+            dst = partials.view(5, nt, M)[3:5]
+            if rows is None:
+                dst.copy_(stats)
+            else:
+                torch.index_select(stats, 2, rows.long(), out=dst)
+        else:
+            L.vocab_sample(dtype, A, Wp, b, M, V, D, 1.0, None, None, 0, True, partials, no_noise=True)
         loss_rows = torch.empty((M,), device=dev, dtype=torch.float32)
         lse = torch.empty((M,), device=dev, dtype=torch.float32)
         L.vocab_ce(dtype, partials, M, V, A, Wp, b, D, tg, rows, loss_rows, lse=lse)
@@ -650,7 +663,7 @@ class _VocabCrossEntropy(torch.autograd.Function):
             full = _zeros((R, D), dev)
             L.scatter_rows(dE, rows, full, M, D)
             dE = full
-        return dE, dW, (db if ctx.has_bias else None), None, None, None, None, None
+        return dE, dW, (db if ctx.has_bias else None), None, None, None, None, None, None
 
 
 class _Linear(torch.autograd.Function):
@@ -725,7 +738,7 @@ def vocab_cross_entropy(embeds, weight, bias, targets, compute_dtype='bf16x3', s
     loss is taken over (None: all).  slab: vocabulary columns per backward step (a multiple of 64)."""
     assert slab % 64 == 0 and slab > 0
     assert weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0, 'vocabulary size and embedding width must be multiples of 8'
-    return _VocabCrossEntropy.apply(embeds, weight, bias, targets, rows, resolve_dtype(compute_dtype), int(slab), None)
+    return _VocabCrossEntropy.apply(embeds, weight, bias, targets, rows, resolve_dtype(compute_dtype), int(slab), None, None)
 
 
 def layernorm_train(ln: LayerNorm, x2d):
@@ -916,20 +929,27 @@ def phenaki_loss(ph, videos=None, *, texts=None, video_codebook_ids=None, video_
     if mg.to_logits.weight.dtype == torch.float32 and mg.to_logits.weight.is_contiguous():
         head = linear_images(mg.to_logits, dt)                           # W and W^T images of the vocabulary head, one launch for both
         head.refresh()
+    partials = None
+    M = b * n
+    if need_critic:
+        # the critic's input: gumbel-sampled predictions at every position (phenaki_pytorch.py:653-659), no gradient through the ids.  ONE pass over
+        # the vocabulary serves both this argmax and the cross entropy above it in the reference (round 6): the pass keeps the noise-free
+        # (max, sum-exp) statistics of every row next to the noisy argmax
+        with torch.no_grad():
+            ed = e.detach()
+            A = ed.to(L.tdtype(dt)) if L.tdtype(dt) != torch.float32 else ed
+            w_logits = head.pair[0] if head is not None else pack_operand(mg.to_logits.weight.detach(), dt)
+            partials = torch.empty((5 * L.vocab_ntiles(V) * M,), device=device, dtype=torch.float32)
+            U = draws['gumbel_u'].to(device).float().contiguous() if 'gumbel_u' in draws else None
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if U is None else 0
+            share = (not only_train_critic) and head is not None and mg.to_logits.bias is not None
+            L.vocab_sample(dt, A, w_logits, mg.to_logits.bias.detach(), M, V, D, float(ph.critic_train_sample_temperature), U, None, seed, share, partials)
     if not only_train_critic:
-        loss = _VocabCrossEntropy.apply(e, mg.to_logits.weight, mg.to_logits.bias, ids.reshape(-1), rows, dt, CE_SLAB, head.pair if head is not None else None)
+        loss = _VocabCrossEntropy.apply(e, mg.to_logits.weight, mg.to_logits.bias, ids.reshape(-1), rows, dt, CE_SLAB, head.pair if head is not None else None,
+                                        (partials, M) if (need_critic and share) else None)
     if not need_critic:
         return loss
-    # the critic's input: gumbel-sampled predictions at every position (phenaki_pytorch.py:653-659), no gradient through the ids
     with torch.no_grad():
-        M = b * n
-        ed = e.detach()
-        A = ed.to(L.tdtype(dt)) if L.tdtype(dt) != torch.float32 else ed
-        w_logits = head.pair[0] if head is not None else pack_operand(mg.to_logits.weight.detach(), dt)
-        partials = torch.empty((5 * L.vocab_ntiles(V) * M,), device=device, dtype=torch.float32)
-        U = draws['gumbel_u'].to(device).float().contiguous() if 'gumbel_u' in draws else None
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if U is None else 0
-        L.vocab_sample(dt, A, w_logits, mg.to_logits.bias.detach(), M, V, D, float(ph.critic_train_sample_temperature), U, None, seed, False, partials)
         pred = torch.empty((M,), device=device, dtype=torch.long)
         L.vocab_reduce(partials, M, V, None, None, None, pred, None, False)
         pred = pred.view(b, n)
