@@ -17,20 +17,34 @@ template <typename TO, bool TR>
 __device__ __forceinline__ void pack_tile(float (*tile)[65], const float* __restrict__ src, long lds_, const int* __restrict__ rows, int R, int K, int Kp,
                                           TO* __restrict__ out, long ldo, int bx, int by) {
     const int r0 = by * 64, k0 = bx * 64, t = threadIdx.x;
+    // 16-byte source loads when the rows allow it (round 6: four 4-byte loads per thread kept the transposes of a backward block at 1.9 TB/s)
+    const bool vec = !(lds_ & 3) && !(reinterpret_cast<uintptr_t>(src) & 15);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (TR) {
             const int kk = (t >> 4) + 16 * i, rr = (t & 15) * 4;
             const int k = k0 + kk, r = r0 + rr;
             const long sk = (k < K) ? (rows ? rows[k] : k) : 0;          // source row (optionally gathered)
+            if (vec && k < K && r + 3 < R) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src + sk * lds_ + r);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tile[rr + j][kk] = (k < K && r + j < R) ? src[sk * lds_ + r + j] : 0.f;
+                for (int j = 0; j < 4; ++j) tile[rr + j][kk] = v[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tile[rr + j][kk] = (k < K && r + j < R) ? src[sk * lds_ + r + j] : 0.f;
+            }
         } else {
             const int rr = (t >> 4) + 16 * i, kk = (t & 15) * 4;
             const int k = k0 + kk, r = r0 + rr;
             const long sr = (r < R) ? (rows ? rows[r] : r) : 0;
+            if (vec && r < R && k + 3 < K) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src + sr * lds_ + k);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tile[rr][kk + j] = (r < R && k + j < K) ? src[sr * lds_ + k + j] : 0.f;
+                for (int j = 0; j < 4; ++j) tile[rr][kk + j] = v[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tile[rr][kk + j] = (r < R && k + j < K) ? src[sr * lds_ + k + j] : 0.f;
+            }
         }
     }
     __syncthreads();
@@ -120,19 +134,27 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 // lanes (V4) or 4 row lanes x 64 columns; the lanes' sums are folded in lane order, so the result is as reproducible as the two-stage one.
 template <bool V4>
 __global__ __launch_bounds__(256) void colsum_one_kernel(const float* __restrict__ src, long ld, int M, int N, float scale, float* __restrict__ out, int accumulate) {
-    __shared__ f32x4 red[16][16];
+    __shared__ f32x4 red[64][4];
     const int t = threadIdx.x;
     if (V4) {
-        const int cl = t & 15, rl = t >> 4, c = blockIdx.x * 64 + cl * 4;
+        // 16 columns per block (4 float4 lanes) x 64 row lanes: 32 blocks for a 512-column partial matrix (64 columns per block left 8 workgroups
+        // walking 36 rows each: 12 us); the 64 lanes of a column are folded in a fixed order (16 lanes per thread, then 4 partial sums)
+        const int cl = t & 3, rl = t >> 2, c = blockIdx.x * 16 + cl * 4;
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
         if (c < N)
-            for (int r = rl; r < M; r += 16) a += *reinterpret_cast<const f32x4*>(src + (long)r * ld + c);
+            for (int r = rl; r < M; r += 64) a += *reinterpret_cast<const f32x4*>(src + (long)r * ld + c);
         red[rl][cl] = a;
         __syncthreads();
-        if (rl == 0 && c < N) {
-            f32x4 s = red[0][cl];
+        if (t < 16) {                                                  // thread (part p, column lane cl): row lanes 16 p .. 16 p + 15
+            const int p = t >> 2;
+            f32x4 s = red[16 * p][cl];
 #pragma unroll
-            for (int i = 1; i < 16; ++i) s += red[i][cl];
+            for (int i = 1; i < 16; ++i) s += red[16 * p + i][cl];
+            red[16 * p][cl] = s;                                       // (only this thread reads rows 16 p .. 16 p + 15 of column lane cl)
+        }
+        __syncthreads();
+        if (t < 4 && c < N) {
+            const f32x4 s = (red[0][cl] + red[16][cl]) + (red[32][cl] + red[48][cl]);
             f32x4* o = reinterpret_cast<f32x4*>(out + c);
             *o = accumulate ? *o + s * scale : s * scale;
         }
@@ -325,14 +347,17 @@ __global__ __launch_bounds__(256) void peg_bwd_kernel(const float* __restrict__ 
     }
 }
 // dW[tap][d] = sum_pos dy[pos][d] * x[pos + tap offset][d] as per-block partials part[block][27][D]
+// grid.y = 3: block (b, dt) accumulates the 9 taps of temporal offset dt (round 6: 27 accumulators per thread = 108 VGPRs at one wave per SIMD and
+// 288 blocks left the tap loads' latency exposed, 69 us for 64 M multiply-adds)
 __global__ __launch_bounds__(256) void peg_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
                                                         int B, int T, int H, int W, int D, int tfront, long rows, int rpb) {
     __shared__ f32x4 red[256];
     const int dv = D >> 2, nl = 256 / dv;
     const int cq = threadIdx.x % dv, rl = threadIdx.x / dv, c = cq * 4;
-    f32x4 acc[27];
+    const int dt = blockIdx.y;
+    f32x4 acc[9];
 #pragma unroll
-    for (int k = 0; k < 27; ++k) acc[k] = f32x4{0, 0, 0, 0};
+    for (int k = 0; k < 9; ++k) acc[k] = f32x4{0, 0, 0, 0};
     const long rb = (long)blockIdx.x * rpb, re = rb + rpb < rows ? rb + rpb : rows;
     if (rl < nl)
         for (long pos = rb + rl; pos < re; pos += nl) {
@@ -340,31 +365,29 @@ __global__ __launch_bounds__(256) void peg_wgrad_kernel(const float* __restrict_
             const int w = (int)(p % W); p /= W;
             const int h = (int)(p % H); p /= H;
             const int t = (int)(p % T); const int b = (int)(p / T);
+            const int ts = t + dt - tfront;
+            if (ts < 0 || ts >= T) continue;
             const f32x4 g = *reinterpret_cast<const f32x4*>(dy + pos * D + c);
 #pragma unroll
-            for (int dt = 0; dt < 3; ++dt) {
-                const int ts = t + dt - tfront;
+            for (int dh = 0; dh < 3; ++dh) {
+                const int hs = h + dh - 1;
 #pragma unroll
-                for (int dh = 0; dh < 3; ++dh) {
-                    const int hs = h + dh - 1;
-#pragma unroll
-                    for (int dw = 0; dw < 3; ++dw) {
-                        const int ws = w + dw - 1;
-                        if (ts >= 0 && ts < T && hs >= 0 && hs < H && ws >= 0 && ws < W)
-                            acc[(dt * 3 + dh) * 3 + dw] += g * *reinterpret_cast<const f32x4*>(x + ((((long)b * T + ts) * H + hs) * W + ws) * D + c);
-                    }
+                for (int dw = 0; dw < 3; ++dw) {
+                    const int ws = w + dw - 1;
+                    if (hs >= 0 && hs < H && ws >= 0 && ws < W)
+                        acc[dh * 3 + dw] += g * *reinterpret_cast<const f32x4*>(x + ((((long)b * T + ts) * H + hs) * W + ws) * D + c);
                 }
             }
         }
 #pragma unroll
-    for (int k = 0; k < 27; ++k) {
+    for (int k = 0; k < 9; ++k) {
         __syncthreads();
         red[threadIdx.x] = acc[k];
         __syncthreads();
         if (rl == 0) {
             f32x4 s = red[cq];
             for (int l = 1; l < nl; ++l) s += red[l * dv + cq];
-            *reinterpret_cast<f32x4*>(part + ((long)blockIdx.x * 27 + k) * D + c) = s;
+            *reinterpret_cast<f32x4*>(part + ((long)blockIdx.x * 27 + dt * 9 + k) * D + c) = s;
         }
     }
 }
@@ -623,8 +646,8 @@ extern "C" int pk_colsum(const float* src, long ld, int M, int N, float scale, f
     if (!src || !out || !work || M <= 0 || N <= 0) return PK_EINVAL;
     hipStream_t s = STREAM(stream);
     const bool v4 = !(N & 3) && !(ld & 3) && al16(src) && al16(out);
-    if (M <= (v4 ? 1024 : 256)) {                                        // short input (block partials of another kernel): one launch
-        if (v4) hipLaunchKernelGGL((colsum_one_kernel<true>), dim3((N + 63) / 64), dim3(256), 0, s, src, ld, M, N, scale, out, accumulate);
+    if (M <= (v4 ? 8192 : 256)) {                                        // short input (block partials of another kernel, a batch's rows): one launch
+        if (v4) hipLaunchKernelGGL((colsum_one_kernel<true>), dim3((N + 15) / 16), dim3(256), 0, s, src, ld, M, N, scale, out, accumulate);
         else hipLaunchKernelGGL((colsum_one_kernel<false>), dim3((N + 63) / 64), dim3(256), 0, s, src, ld, M, N, scale, out, accumulate);
         PK_CHECK_LAUNCH();
         return PK_OK;
@@ -715,7 +738,7 @@ extern "C" int pk_peg_bwd(const float* dy, const float* x, const float* wt, floa
     if (part) {
         const int P = pk_peg_wgrad_parts(rows);
         const int rpb = (int)((rows + P - 1) / P);
-        hipLaunchKernelGGL(peg_wgrad_kernel, dim3(P), dim3(256), 0, s, dy, x, part, B, T, H, W, D, causal ? 2 : 1, rows, rpb);
+        hipLaunchKernelGGL(peg_wgrad_kernel, dim3(P, 3), dim3(256), 0, s, dy, x, part, B, T, H, W, D, causal ? 2 : 1, rows, rpb);
     }
     PK_CHECK_LAUNCH();
     return PK_OK;

@@ -7,29 +7,39 @@ import os
 import sys
 
 if sys.argv[1] == '--summary':
+    # steady state only: every step is preceded by a marker launch (torch.cuda._sleep); the first two marked steps (optimizer-state
+    # allocation, first-use set-up) and everything before the first marker (model construction) are left out
+    import collections
     d, steps = sys.argv[2], int(sys.argv[3])
-    path = glob.glob(os.path.join(d, '**', '*kernel_stats.csv'), recursive=True)[0]
-    rows = list(csv.DictReader(open(path)))
-    tot = sum(float(r['TotalDurationNs']) for r in rows)
-    n = sum(int(r['Calls']) for r in rows)
-    print(f'# {path}: {tot / 1e6 / steps:.2f} ms of kernel time and {n / steps:.0f} launches per step ({steps} steps incl. 2 warm-up)')
-    for r in rows[:45]:
-        print(f"{float(r['TotalDurationNs']) / tot * 100:5.1f}%  {int(r['Calls']) / steps:7.1f} / step x {float(r['AverageNs']) / 1e3:8.1f} us  {r['Name'][:130]}")
+    tr = glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True)[0]
+    rows = sorted(csv.DictReader(open(tr)), key=lambda r: int(r['Start_Timestamp']))
+    marks = [i for i, r in enumerate(rows) if 'sleep' in r['Kernel_Name'].lower() or 'spin' in r['Kernel_Name'].lower()]
+    assert len(marks) == steps, f'{len(marks)} markers for {steps} steps'
+    skip = 2
+    body = [r for r in rows[marks[skip]:] if not ('sleep' in r['Kernel_Name'].lower() or 'spin' in r['Kernel_Name'].lower())]
+    ns = steps - skip
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    for r in body:
+        a = acc[r['Kernel_Name']]
+        a[0] += 1
+        a[1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    tot = sum(v[1] for v in acc.values())
+    n = sum(v[0] for v in acc.values())
+    print(f'# {tr}: {tot / 1e3 / ns:.2f} ms of kernel time and {n / ns:.0f} launches per step (steady state: steps {skip + 1}..{steps} of {steps})')
+    for nm, (c, us) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:48]:
+        print(f'{us / tot * 100:5.1f}%  {c / ns:7.1f} / step x {us / c:8.1f} us  {nm[:130]}')
     # the attention kernels by grid size (self-attention n = 576 vs the 14-key cross-attention share one kernel name)
-    tr = glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True)
-    if tr:
-        import collections
-        acc = collections.defaultdict(lambda: [0, 0.0])
-        for r in csv.DictReader(open(tr[0])):
-            nm = r['Kernel_Name']
-            if 'attn' not in nm:
-                continue
-            key = (nm[:60], r.get('Grid_Size_X', r.get('Grid_Size', '?')))
-            acc[key][0] += 1
-            acc[key][1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-        print('# attention kernels by grid size (threads): launches per step x average us')
-        for (nm, grid), (n_, us) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
-            print(f'{n_ / steps:7.1f} / step x {us / n_:8.1f} us  grid {grid:>8}  {nm}')
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    for r in body:
+        nm = r['Kernel_Name']
+        if 'attn' not in nm:
+            continue
+        key = (nm[:60], r.get('Grid_Size_X', r.get('Grid_Size', '?')))
+        acc[key][0] += 1
+        acc[key][1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    print('# attention kernels by grid size (threads): launches per step x average us')
+    for (nm, grid), (n_, us) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+        print(f'{n_ / ns:7.1f} / step x {us / n_:8.1f} us  grid {grid:>8}  {nm}')
     sys.exit(0)
 
 import torch  # noqa: E402
@@ -50,6 +60,7 @@ params = [p for p in list(mg.parameters()) + list(cr.parameters()) if p.requires
 opt = P.get_optimizer(params, lr=1e-4, wd=1e-2)
 torch.manual_seed(0)
 for i in range(steps):
+    torch.cuda._sleep(1000)                                  # step marker for --summary
     with torch.enable_grad():
         opt.zero_grad(set_to_none=True)
         loss = ph(video_codebook_ids=ids, text_embeds=ctx)
