@@ -36,10 +36,6 @@ from .attention import (Attention, FeedForwardSeq, LayerNorm, PEG, compute_dtype
 CE_SLAB = int(os.environ.get('PK_CE_SLAB', '8192'))
 
 
-# experiment knob: weight-gradient products on 128 x 128 tiles with up to this many workgroups (0: the 64 x 64 tiles)
-WGRAD_TILE128 = int(os.environ.get('PK_WGRAD_TILE128', '0'))
-
-
 def _q(dtype):
     return 64 if dtype == L.BF16 else 32
 
@@ -85,17 +81,6 @@ def _weight_grad_gemm(dtype, dyT, xT, N, K, Mp, dW, defer=None):
     added in index order (pk_sum_batch: deterministic).  defer (list): the slice sum is queued there instead of launched -- the caller adds the
     slices of all its weight gradients with ONE pk_sum_batch_multi (`_flush_sums`)."""
     q = _q(dtype)
-    if WGRAD_TILE128 and N >= 128 and K >= 128 and K % 4 == 0 and dW.is_contiguous():
-        t128 = ((N + 127) // 128) * ((K + 127) // 128)
-        for cand in (32, 16, 8, 4, 2):
-            if t128 * cand <= WGRAD_TILE128 and Mp % (cand * q) == 0 and Mp // cand >= 4 * q:
-                part = torch.empty((cand, N * K), device=dW.device, dtype=torch.float32)
-                L.gemm_splitk(dtype, dyT, xT, N, K, Mp, cand, part, tile=1)
-                if defer is not None and (N * K) % 4 == 0:
-                    defer.append((part, cand, dW, N * K))
-                else:
-                    L.sum_batch(part, cand, dW, N * K)
-                return
     tiles = ((N + 63) // 64) * ((K + 63) // 64)
     splits = 1
     if K % 4 == 0 and dW.is_contiguous():
