@@ -431,8 +431,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 float sc, ds = 0.f;
                 if (score(p, s, h, gi, j, accS[nb][i], sc)) ds = __expf(sc - lse[i]) * (accP[nb][i] - Dl[i]);
                 Ps[(m0 + kq * 4 + i) * TLD + nb * 16 + r] = ds;
-                if (p.dS && gi < p.n && j >= p.nnull && j < p.nkt) p.dS[((long)sh * p.n + gi) * nreal + (j - p.nnull)] = ds;
             }
+        if (p.dS) {
+            // the score gradient leaves through the wave's own LDS rows (round 6): 16 lanes x 16 bytes = one whole 256-byte row segment per store
+            // instead of 16 four-byte stores per lane in the accumulator layout (85 MB per layer at n = 576: kernel Q 190 vs 115 us without dS)
+            const int col = (lane & 15) * 4, j = kt * 64 + col, jr = j - p.nnull;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = m0 + u * 4 + (lane >> 4), gi = i0 + row;
+                if (gi >= p.n) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(Ps + row * TLD + col);
+                float* dst = p.dS + ((long)sh * p.n + gi) * nreal + jr;
+                if (jr >= 0 && j + 3 < p.nkt && !(nreal & 3) && !(jr & 3)) *reinterpret_cast<f32x4*>(dst) = v;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (jr + e >= 0 && j + e < p.nkt) dst[e] = v[e];
+                }
+            }
+        }
         // this wave's 16 rows of Ps are its own: no workgroup barrier before reading them back.  dQ^[i][d] += sum_j dS[i][j] K^T[d][j]
         mma_ldsA<4, 2, OF>(Ps, TLD, m0, Kt, TLD, accQ, lane);
     }

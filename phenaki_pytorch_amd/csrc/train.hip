@@ -121,6 +121,27 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     __syncthreads();
     if (rl == 0 && c < N) part[(long)blockIdx.y * N + c] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
 }
+// float4-addressable rows (round 6): 16 columns x 64 row lanes per block like colsum_one_kernel -- a 64-column gradient over 524 288 pixel rows (the
+// discriminator's convolution biases) was 256 blocks of 64 active column lanes reading 4 bytes each: 64 us for 134 MB
+__global__ __launch_bounds__(256) void colsum_partial4_kernel(const float* __restrict__ src, long ld, int M, int N, float* __restrict__ part, int rpb) {
+    __shared__ f32x4 red[64][4];
+    const int t = threadIdx.x, cl = t & 3, rl = t >> 2, c = blockIdx.x * 16 + cl * 4;
+    const int rb = blockIdx.y * rpb, re = min(M, rb + rpb);
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (c < N)
+        for (int r = rb + rl; r < re; r += 64) a += *reinterpret_cast<const f32x4*>(src + (long)r * ld + c);
+    red[rl][cl] = a;
+    __syncthreads();
+    if (t < 16) {
+        const int p = t >> 2;
+        f32x4 s = red[16 * p][cl];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) s += red[16 * p + i][cl];
+        red[16 * p][cl] = s;
+    }
+    __syncthreads();
+    if (t < 4 && c < N) *reinterpret_cast<f32x4*>(part + (long)blockIdx.y * N + c) = (red[0][cl] + red[16][cl]) + (red[32][cl] + red[48][cl]);
+}
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int P, int N, float scale, float* __restrict__ out, int accumulate) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= N) return;
@@ -653,6 +674,12 @@ extern "C" int pk_colsum(const float* src, long ld, int M, int N, float scale, f
         return PK_OK;
     }
     const int P = pk_colsum_parts(M), rpb = (M + P - 1) / P;
+    if (v4 && al16(work)) {                                              // both stages on 16 x 64 blocks (the second one = the one-launch kernel over the partials)
+        hipLaunchKernelGGL(colsum_partial4_kernel, dim3((N + 15) / 16, P), dim3(256), 0, s, src, ld, M, N, work, rpb);
+        hipLaunchKernelGGL((colsum_one_kernel<true>), dim3((N + 15) / 16), dim3(256), 0, s, work, (long)N, P, N, scale, out, accumulate);
+        PK_CHECK_LAUNCH();
+        return PK_OK;
+    }
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, P), dim3(256), 0, s, src, ld, M, N, work, rpb);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, work, P, N, scale, out, accumulate);
     PK_CHECK_LAUNCH();

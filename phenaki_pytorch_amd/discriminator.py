@@ -27,7 +27,7 @@ from torch import nn
 
 from . import _lib as L
 from .attention import Attention, PackedModule, compute_dtype_of, round_up
-from .train import _f32, _q, _weight_grad_gemm, attention_train, pack_operand
+from .train import _f32, _q, _weight_grad_gemm, attention_train, pack_operand, transposes
 
 LEAK = 0.1            # leaky_relu(p = 0.1), cvivit.py:74-75: the slope pk_gemm's act 2 epilogue applies
 CPAD = 8              # image channels are padded to a multiple of 8: the patch matrix rows stay 16-byte aligned, K % 8 == 0
@@ -75,8 +75,7 @@ def _mm_raw(A, B, tA, tB, dtype):
         if not tB and K >= 4 * _q(dtype) and M % 4 == 0:
             # A^T B, contraction over the K rows both operands share: the weight-gradient shape (split-K, added in index order)
             Kp = round_up(K, _q(dtype))
-            AT = pack_operand(A, dtype, transpose=True, side='a')          # (M, Kp)
-            BT = pack_operand(B, dtype, transpose=True)                    # (N, Kp)
+            AT, BT = transposes(dtype, [(A, 'a'), (B, 'w')])               # (M, Kp), (N, Kp): one launch for both
             _weight_grad_gemm(dtype, AT, BT, M, N, Kp, out)
             return out
     return L.bmm(A, B, out, tA, tB, 1, M, N, K, lda=A.stride(0), ldb=B.stride(0), ldc=N)

@@ -25,7 +25,7 @@ env)    # same-box A/B of environment switches of THIS tree:  env "PK_X=0" "PK_X
   ;;
 census) # launches and kernel time per step
   R=$GRAFT_REPO_ROOT
-  cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/census -o c -- python $R/tools/train_census.py ${1:-bf16x3} 6 > $R/gpurun_out/census_run.log 2>&1
-  cd $R && python tools/train_census.py --summary gpurun_out/census 6 | tee gpurun_out/train_step_census_r06.txt | head -90
+  rm -rf $R/gpurun_out/census; cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/census -o c -- python $R/tools/train_census.py ${1:-bf16x3} 6 ${2:-phenaki} > $R/gpurun_out/census_run.log 2>&1
+  cd $R && tail -2 gpurun_out/census_run.log && python tools/train_census.py --summary gpurun_out/census 6 | tee gpurun_out/train_step_census_r06_${2:-phenaki}.txt | head -${3:-90}
   ;;
 esac

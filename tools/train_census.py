@@ -48,7 +48,37 @@ from bench import build_models, synthetic_context  # noqa: E402
 import phenaki_pytorch_amd as P  # noqa: E402
 
 mode, steps = sys.argv[1], int(sys.argv[2])
+leg = sys.argv[3] if len(sys.argv) > 3 else 'phenaki'
 B = 8
+if leg != 'phenaki':
+    # the tokenizer's steps (bench.py cvivit_train_step / cvivit_gan_step bodies): 'cvivit' reconstruction step, 'gan_gen' / 'gan_discr' the two halves of a GAN step
+    from torch import nn
+    from bench import BASELINE_CFG, synthetic_video
+    torch.manual_seed(0)
+    gan = leg != 'cvivit'
+    vgg = None
+    if gan:
+        vgg = nn.Sequential(nn.AvgPool2d(4), nn.Flatten(), nn.Linear(3 * 64 * 64, 64), nn.Tanh(), nn.Linear(64, 32))
+        for q in vgg.parameters():
+            q.requires_grad_(False)
+    cv = P.CViViT(use_vgg_and_gan=gan, vgg=vgg, **BASELINE_CFG['cvivit']).cuda().train()
+    P.set_compute_dtype(cv, mode)
+    video = synthetic_video(B, 17, 256, 5).cuda()
+    if leg == 'gan_discr':
+        params = [p for p in cv.discr.parameters() if p.requires_grad]
+    else:
+        params = [p for n, p in cv.named_parameters() if p.requires_grad and not n.startswith('discr.')]
+    opt = P.get_optimizer(params, lr=1e-4, wd=0.)
+    for i in range(steps):
+        torch.cuda._sleep(1000)
+        with torch.enable_grad():
+            opt.zero_grad(set_to_none=True)
+            loss = cv(video, return_discr_loss=True, apply_grad_penalty=True) if leg == 'gan_discr' else cv(video)
+            loss.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    print('loss', float(loss))
+    sys.exit(0)
 cv, mg, cr, ph = build_models(mode, True)
 for m in (mg, cr):
     m.train()
