@@ -31,6 +31,16 @@ def pack(src, R, K, transpose, out, Kp, kind, rows=None):
     return out
 
 
+def pack_job(src, R, K, transpose, out, Kp, kind, **kw):
+    assert not kw
+    return (src, R, K, transpose, out, Kp, kind)
+
+
+def pack_multi(jobs, like):
+    for j in jobs:
+        pack(*j)
+
+
 def gemm_splitk(dtype, A, W, M, N, K, splits, C, bias=None, tile=0):
     Kc = K // splits
     for s in range(splits):
@@ -152,7 +162,7 @@ def row_ln_bwd2(x, gamma, dy, u, w, eps, grad_x, grad_gamma_rows, grad_dy):
 
 
 EMULATED = dict(row_softmax=row_softmax, row_l2scale=row_l2scale, layernorm=layernorm, layernorm_bwd=layernorm_bwd, row_ln_bwd2=row_ln_bwd2,
-                gemm=gemm, pack=pack, gemm_splitk=gemm_splitk, sum_batch=sum_batch, colsum=colsum, leaky_bwd=leaky_bwd, im2col=im2col,
+                gemm=gemm, pack=pack, pack_job=pack_job, pack_multi=pack_multi, gemm_splitk=gemm_splitk, sum_batch=sum_batch, colsum=colsum, leaky_bwd=leaky_bwd, im2col=im2col,
                 col2im=col2im, nchw_to_rows=nchw_to_rows, rows_to_nchw=rows_to_nchw, bmm=bmm, require_device=lambda t, name='tensor': None)
 
 
