@@ -388,6 +388,9 @@ int pk_bias_gather(const float* tab, int ldt, const int* code, int off, float* o
 int pk_bias_scatter(const float* dbias, const int* code, int off, float* dtab, int ldt, int heads, int n, void* stream);
 /* out[e] = sum_s src[s * stride + e], e < E (E % 4 == 0) */
 int pk_sum_batch(const float* src, long long stride, int S, float* out, long long E, void* stream);
+/* count <= 8 short column sums in one launch (the one-launch form of pk_colsum: M <= 8192, N % 4 == 0, 16-byte aligned rows; blk0 filled in by the library) */
+typedef struct PkColsumJob { const float* src; float* out; long long ld; int M, N, blk0; float scale; } PkColsumJob;
+int pk_colsum_multi(const void* jobs, int count, void* stream);
 /* count <= 8 pk_sum_batch jobs in one launch (E4 = E / 4; blk0 is filled in by the library): the K-slice partials of one block's weight gradients */
 typedef struct PkSumJob { const float* src; float* out; long long stride, E4; int S, blk0; } PkSumJob;
 int pk_sum_batch_multi(const void* jobs, int count, void* stream);

@@ -89,6 +89,7 @@ SIGNATURES = {
     'pk_bias_scatter': [_P, _P, _I, _P, _I, _I, _I, _P],
     'pk_sum_batch': [_P, _LL, _I, _P, _LL, _P],
     'pk_sum_batch_multi': [_P, _I, _P],
+    'pk_colsum_multi': [_P, _I, _P],
     'pk_pack_multi': [_P, _I, _P],
     'pk_pack_table_prepare': [_P, _I],
     'pk_pack_table': [_P, _I, _I, _P],
@@ -594,6 +595,29 @@ class PackTable:
         _check(load().pk_pack_table(ptr(self.table), self.count, self.tiles, stream(self.table)), 'pk_pack_table')
 
 
+class ColsumJob(ctypes.Structure):
+    """include/phenaki_hip.h PkColsumJob"""
+    _fields_ = [('src', ctypes.c_void_p), ('out', ctypes.c_void_p), ('ld', ctypes.c_longlong), ('M', ctypes.c_int), ('N', ctypes.c_int), ('blk0', ctypes.c_int),
+                ('scale', ctypes.c_float)]
+
+
+def colsum_multi(jobs):
+    """jobs: [(src (M, N) f32 rows, M, N, out (N,))]: out[c] = sum_r src[r][c] for each, up to 8 per launch (M <= 8192, N % 4 == 0)"""
+    for i in range(0, len(jobs), 8):
+        chunk = jobs[i:i + 8]
+        arr = (ColsumJob * len(chunk))(*[ColsumJob(s_.data_ptr(), o.data_ptr(), s_.stride(-2), M, N, 0, 1.0) for s_, M, N, o in chunk])
+        _check(load().pk_colsum_multi(ctypes.addressof(arr), len(chunk), stream(chunk[0][0])), 'pk_colsum_multi')
+
+
+def colsum_deferred(src, M, N, out, defer):
+    """pk_colsum now, or -- when the caller collects the column sums of a whole backward block (defer: a list) and the shape fits the one-launch
+    form -- queued for ONE colsum_multi launch"""
+    if defer is not None and M <= 8192 and N % 4 == 0 and src.stride(-2) % 4 == 0:
+        defer.append((src, M, N, out))
+        return out
+    return colsum(src, M, N, out)
+
+
 def sum_batch_multi(jobs):
     """jobs: [(part (S, >= E) f32, S, out, E)]: out[e] = sum_s part[s][e], up to 8 per launch"""
     for i in range(0, len(jobs), 8):
@@ -617,15 +641,15 @@ def colsum(src, M, N, out, *, scale=1.0, accumulate=False, ld=None):
     return out
 
 
-def layernorm_bwd(x, gamma, dy, dx, M, D, *, add=None, want_beta=False, eps=1e-5):
-    """dx = [add +] LN backward; returns (dgamma, dbeta | None)"""
+def layernorm_bwd(x, gamma, dy, dx, M, D, *, add=None, want_beta=False, eps=1e-5, defer=None):
+    """dx = [add +] LN backward; returns (dgamma, dbeta | None).  defer (list): the column sum of the partials is queued there (colsum_multi)"""
     P = load().pk_ln_bwd_parts(M)
     # dgamma | dbeta partials as the two halves of one (P, 2 D) buffer (the kernel recognises pb == pg + D): one column sum finishes both
     pgb = torch.empty((P, 2 * D if want_beta else D), device=x.device, dtype=torch.float32)
     rc = load().pk_layernorm_bwd(ptr(x), x.stride(-2), f32p(gamma, 'LayerNorm gamma'), ptr(dy), dy.stride(-2), ptr(add), add.stride(-2) if add is not None else 0,
                                  ptr(dx), dx.stride(-2), ptr(pgb), pgb.data_ptr() + 4 * D if want_beta else None, eps, M, D, stream(x))
     _check(rc, 'pk_layernorm_bwd')
-    out = colsum(pgb, P, pgb.shape[1], torch.empty((pgb.shape[1],), device=x.device, dtype=torch.float32))
+    out = colsum_deferred(pgb, P, pgb.shape[1], torch.empty((pgb.shape[1],), device=x.device, dtype=torch.float32), defer)
     return (out[:D], out[D:]) if want_beta else (out, None)
 
 
@@ -663,7 +687,7 @@ def leaky_bwd(y, dy, dz, M, N, slope=0.1):
     _check(rc, 'pk_leaky_bwd')
 
 
-def peg_bwd(dy, x, wt, dx, B, T, H, W, D, causal, want_wgrad=True):
+def peg_bwd(dy, x, wt, dx, B, T, H, W, D, causal, want_wgrad=True, defer=None):
     """dx = dy + transposed stencil; returns the (27, D) tap gradient (or None)"""
     rows = B * T * H * W
     part = None
@@ -674,7 +698,7 @@ def peg_bwd(dy, x, wt, dx, B, T, H, W, D, causal, want_wgrad=True):
     _check(rc, 'pk_peg_bwd')
     if part is None:
         return None
-    return colsum(part, part.shape[0], 27 * D, torch.empty((27 * D,), device=dy.device, dtype=torch.float32)).view(27, D)
+    return colsum_deferred(part, part.shape[0], 27 * D, torch.empty((27 * D,), device=dy.device, dtype=torch.float32), defer).view(27, D)
 
 
 def embed_bwd(dy, ids, alpha, dtok, dpos, S, n, D):
@@ -723,7 +747,7 @@ def attn_train_prep(q, kv, null_kv, q_scale, k_scale, scale, Qh, Kh, Vh, S, h, n
     _check(rc, 'pk_attn_train_prep')
 
 
-def attn_train_prep_bwd(q, kv, null_kv, q_scale, k_scale, scale, dQh, dKh, dVh, dq, dkv, S, h, n, n_kv, nnull):
+def attn_train_prep_bwd(q, kv, null_kv, q_scale, k_scale, scale, dQh, dKh, dVh, dq, dkv, S, h, n, n_kv, nnull, defer=None):
     """-> (dq_scale (64,), dk_scale (64,), dnull_kv | None); dq / dkv are overwritten"""
     dev = q.device
     pqk = torch.empty((ATTN_PREP_BWD_PARTS, 128), device=dev, dtype=torch.float32)     # dq_scale | dk_scale partials (the kernel recognises pk == pq + 64)
@@ -732,7 +756,7 @@ def attn_train_prep_bwd(q, kv, null_kv, q_scale, k_scale, scale, dQh, dKh, dVh, 
                                        f32p(k_scale, 'k_scale'), scale, ptr(dQh), ptr(dKh), ptr(dVh), ptr(dq), dq.stride(-2), ptr(dkv), dkv.stride(-2),
                                        ptr(pqk), pqk.data_ptr() + 256, ptr(dnull), S, h, n, n_kv, nnull, stream(q))
     _check(rc, 'pk_attn_train_prep_bwd')
-    out = colsum(pqk, ATTN_PREP_BWD_PARTS, 128, torch.empty((128,), device=dev, dtype=torch.float32))
+    out = colsum_deferred(pqk, ATTN_PREP_BWD_PARTS, 128, torch.empty((128,), device=dev, dtype=torch.float32), defer)
     return out[:64], out[64:], dnull
 
 

@@ -732,6 +732,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) =
                 const f32x4 v = o[qf][df] * inv;
                 if (p.out_f32) store4(Of + off, v); else store4(Ot + off, v);
             }
+            // training forward: the row's log-sum-exp for the backward kernels (fixed-offset form: p = 2^(s log2e - off2))
+            if (p.lse && g == 0) p.lse[(size_t)sh * p.nq + qi] = FIX ? (p.off2 + __log2f(lt)) * 0.69314718055994530942f : m[qf] + __logf(lt);
         }
     }
 }
@@ -1000,6 +1002,26 @@ static int attn_fwd_impl(int dtype, const void* Qp, const void* Kp, const void* 
         }
         PK_CHECK_LAUNCH();
         return PK_OK;
+    }
+    if (dtype == 2 && lse && use_lds && nnull == 0 && nq == n_kv && nq >= 128 && !kmask && !causal && out_is_f32 && !bias_tab &&
+        (!bias || a.bias_vec) && (size_t)S * h * nk_pad * 256 < 0xFFFFFFF0ull &&
+        !((reinterpret_cast<uintptr_t>(Qp) | reinterpret_cast<uintptr_t>(Kp) | reinterpret_cast<uintptr_t>(Vt)) & 127)) {
+        // training forward, split-bf16 (round 6): the LDS-staged kernel in its RUNNING-MAX form (the fixed-offset form needs a score bound on the
+        // host, i.e. a read-back of the learnable scales / the bias table's extremes every step) with the position bias as a matrix; it also
+        // writes lse.  The LDS-free kernel it replaces streams K / V^T through L1 per wave: 104-120 us at S h = 64, n = 576.
+        static const bool on = !(getenv("PK_ATTN_TRAIN_LDS") && getenv("PK_ATTN_TRAIN_LDS")[0] == '0');      // A/B switch
+        if (on) {
+            static bool attr = false;
+            if (!attr) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_lds_kernel<2, false, false, false, bf16x3p>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return PK_ELAUNCH;
+                attr = true;
+            }
+            const int qblocks = (nq_pad + 127) / 128;
+            hipLaunchKernelGGL((attn_fwd_lds_kernel<2, false, false, false, bf16x3p>), dim3((unsigned)(S * h * qblocks)), block, (size_t)2 * 32768, s, a,
+                               (uint32_t)((size_t)S * h * nk_pad * 256));
+            PK_CHECK_LAUNCH();
+            return PK_OK;
+        }
     }
     if (bias_tab) return PK_EINVAL;                       // the table form exists in the LDS-staged kernel only
     if (dtype == 1) {

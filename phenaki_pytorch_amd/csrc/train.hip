@@ -153,32 +153,51 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 // one-launch form for short inputs (round 6: the per-block partials of ln_bwd / peg_wgrad / attn_train_prep_bwd / bce_head are 144 ... 1024 rows --
 // the two-stage form spent two 5-6 us launches on each of the step's 141 column sums).  A block owns 64 columns; 16 row lanes x 16 float4 column
 // lanes (V4) or 4 row lanes x 64 columns; the lanes' sums are folded in lane order, so the result is as reproducible as the two-stage one.
+// 16 columns per block (4 float4 lanes) x 64 row lanes: 32 blocks for a 512-column partial matrix (64 columns per block left 8 workgroups walking 36
+// rows each: 12 us); the 64 lanes of a column are folded in a fixed order (16 lanes per thread, then 4 partial sums)
+__device__ __forceinline__ void colsum16_block(f32x4 (*red)[4], const float* __restrict__ src, long ld, int M, int N, float scale, float* __restrict__ out,
+                                               int accumulate, int bx) {
+    const int t = threadIdx.x;
+    const int cl = t & 3, rl = t >> 2, c = bx * 16 + cl * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (c < N)
+        for (int r = rl; r < M; r += 64) a += *reinterpret_cast<const f32x4*>(src + (long)r * ld + c);
+    red[rl][cl] = a;
+    __syncthreads();
+    if (t < 16) {                                                      // thread (part p, column lane cl): row lanes 16 p .. 16 p + 15
+        const int p = t >> 2;
+        f32x4 s = red[16 * p][cl];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) s += red[16 * p + i][cl];
+        red[16 * p][cl] = s;                                           // (only this thread reads rows 16 p .. 16 p + 15 of column lane cl)
+    }
+    __syncthreads();
+    if (t < 4 && c < N) {
+        const f32x4 s = (red[0][cl] + red[16][cl]) + (red[32][cl] + red[48][cl]);
+        f32x4* o = reinterpret_cast<f32x4*>(out + c);
+        *o = accumulate ? *o + s * scale : s * scale;
+    }
+}
+// several short column sums in ONE launch (the partial buffers a backward block's kernels leave behind: dgamma, dq_scale | dk_scale, PEG taps, ...)
+struct ColsumJob { const float* src; float* out; long ld; int M, N, blk0; float scale; };
+constexpr int COLSUM_JOBS = 8;
+struct ColsumJobs { ColsumJob j[COLSUM_JOBS]; };
+__global__ __launch_bounds__(256) void colsum_jobs_kernel(const ColsumJobs a, int count) {
+    __shared__ f32x4 red[64][4];
+    const int b = blockIdx.x;
+    int i = 0;
+#pragma unroll
+    for (int c = 1; c < COLSUM_JOBS; ++c)
+        if (c < count && b >= a.j[c].blk0) i = c;
+    const ColsumJob d = a.j[i];
+    colsum16_block(red, d.src, d.ld, d.M, d.N, d.scale, d.out, 0, b - d.blk0);
+}
 template <bool V4>
 __global__ __launch_bounds__(256) void colsum_one_kernel(const float* __restrict__ src, long ld, int M, int N, float scale, float* __restrict__ out, int accumulate) {
     __shared__ f32x4 red[64][4];
     const int t = threadIdx.x;
     if (V4) {
-        // 16 columns per block (4 float4 lanes) x 64 row lanes: 32 blocks for a 512-column partial matrix (64 columns per block left 8 workgroups
-        // walking 36 rows each: 12 us); the 64 lanes of a column are folded in a fixed order (16 lanes per thread, then 4 partial sums)
-        const int cl = t & 3, rl = t >> 2, c = blockIdx.x * 16 + cl * 4;
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        if (c < N)
-            for (int r = rl; r < M; r += 64) a += *reinterpret_cast<const f32x4*>(src + (long)r * ld + c);
-        red[rl][cl] = a;
-        __syncthreads();
-        if (t < 16) {                                                  // thread (part p, column lane cl): row lanes 16 p .. 16 p + 15
-            const int p = t >> 2;
-            f32x4 s = red[16 * p][cl];
-#pragma unroll
-            for (int i = 1; i < 16; ++i) s += red[16 * p + i][cl];
-            red[16 * p][cl] = s;                                       // (only this thread reads rows 16 p .. 16 p + 15 of column lane cl)
-        }
-        __syncthreads();
-        if (t < 4 && c < N) {
-            const f32x4 s = (red[0][cl] + red[16][cl]) + (red[32][cl] + red[48][cl]);
-            f32x4* o = reinterpret_cast<f32x4*>(out + c);
-            *o = accumulate ? *o + s * scale : s * scale;
-        }
+        colsum16_block(red, src, ld, M, N, scale, out, accumulate, blockIdx.x);
     } else {
         float* redf = reinterpret_cast<float*>(&red[0][0]);
         const int cl = t & 63, rl = t >> 6, c = blockIdx.x * 64 + cl;
@@ -810,6 +829,26 @@ extern "C" int pk_sum_batch(const float* src, long stride, int S, float* out, lo
     if (!src || !out || S <= 0 || E <= 0) return PK_EINVAL;
     if ((E & 3) || (stride & 3) || !al16(src) || !al16(out)) return PK_EALIGN;
     hipLaunchKernelGGL(sum_batch_kernel, dim3(nblocks(E >> 2)), dim3(256), 0, STREAM(stream), src, stride, S, out, E >> 2);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+// `count` (<= 8) short column sums in one launch: out[c] = scale * sum_{r < M} src[r][c], M <= 8192, N % 4 == 0, float4-addressable rows (the
+// one-launch form of pk_colsum).  jobs: HOST array of PkColsumJob (blk0 is filled in here)
+extern "C" int pk_colsum_multi(const void* jobs, int count, void* stream) {
+    if (!jobs || count <= 0 || count > COLSUM_JOBS) return PK_EINVAL;
+    ColsumJobs a;
+    long blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        a.j[i] = reinterpret_cast<const ColsumJob*>(jobs)[i];
+        ColsumJob& d = a.j[i];
+        if (!d.src || !d.out || d.M <= 0 || d.M > 8192 || d.N <= 0) return PK_EINVAL;
+        if ((d.N & 3) || (d.ld & 3) || !al16(d.src) || !al16(d.out)) return PK_EALIGN;
+        d.blk0 = (int)blocks;
+        blocks += (d.N + 15) / 16;
+    }
+    for (int i = count; i < COLSUM_JOBS; ++i) a.j[i] = a.j[0];
+    hipLaunchKernelGGL(colsum_jobs_kernel, dim3((unsigned)blocks), dim3(256), 0, STREAM(stream), a, count);
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

@@ -353,8 +353,11 @@ class _PEGBlock(torch.autograd.Function):
         M, D = x.shape
         dy = dy.contiguous()
         dx = _f32((M, D), x.device)
-        dtaps = L.peg_bwd(dy, x, taps, dx, b, t, h, w, D, ctx.causal)
-        dbias = L.colsum(dy, M, D, _f32((D,), x.device))
+        cs = []                                                          # the tap partials and the bias gradient: one column-sum launch
+        dtaps = L.peg_bwd(dy, x, taps, dx, b, t, h, w, D, ctx.causal, defer=cs)
+        dbias = L.colsum_deferred(dy, M, D, _f32((D,), x.device), cs)
+        if cs:
+            L.colsum_multi(cs)
         return dx, dtaps.t().contiguous().reshape(ctx.wshape), dbias, None, None
 
 
@@ -435,8 +438,9 @@ class _AttnBlock(torch.autograd.Function):
             dbias = _f32(tuple(bias.shape), dev)
             L.sum_batch(dS, S, dbias, heads * n * n_kv)
         dq, dkv = _f32((M, inner), dev), _f32(tuple(kv.shape), dev)
+        cs = []                                                          # dq_scale | dk_scale and the LayerNorm gains: one column-sum launch at the end
         dqs, dks, dnull = L.attn_train_prep_bwd(q, kv, null_kv.detach(), q_scale.detach(), k_scale.detach(), float(scale), dQh, dKh, dVh, dq, dkv,
-                                                S, heads, n, n_kv, nnull)
+                                                S, heads, n, n_kv, nnull, defer=cs)
         if dnull is None:
             dnull = torch.zeros_like(null_kv)
         # ---- projections, LayerNorms, residual
@@ -450,14 +454,16 @@ class _AttnBlock(torch.autograd.Function):
             _flush_sums(sums)
             if cgamma is not None:
                 dctx = _f32(tuple(context.shape), dev)
-                dcg, _ = L.layernorm_bwd(context, cgamma.detach(), dsrc, dctx, context.shape[0], context.shape[1], eps=eps)
+                dcg, _ = L.layernorm_bwd(context, cgamma.detach(), dsrc, dctx, context.shape[0], context.shape[1], eps=eps, defer=cs)
             else:
                 dctx = dsrc
-            dg, _ = L.layernorm_bwd(x, gamma.detach(), dxn, dx, M, D, add=dy, eps=eps)
+            dg, _ = L.layernorm_bwd(x, gamma.detach(), dxn, dx, M, D, add=dy, eps=eps, defer=cs)
         else:
             t, dWkv = linear_bwd(dtype, x, wkv, dkv, add=dy, Wt=img['wkv'][1], dyT=dkvT, xT=srcT, defer=sums)   # dy + dkv Wkv: K / V read the un-normalised x
             _flush_sums(sums)
-            dg, _ = L.layernorm_bwd(x, gamma.detach(), dxn, dx, M, D, add=t, eps=eps)
+            dg, _ = L.layernorm_bwd(x, gamma.detach(), dxn, dx, M, D, add=t, eps=eps, defer=cs)
+        if cs:
+            L.colsum_multi(cs)
         return dx, dctx, dg, None, dcg, None, dWq, dWkv, dnull, dqs, dks, dWo, dbias, None, None
 
 
