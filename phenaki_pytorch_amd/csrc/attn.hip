@@ -1014,11 +1014,19 @@ static int attn_fwd_impl(int dtype, const void* Qp, const void* Kp, const void* 
             static bool attr = false;
             if (!attr) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_lds_kernel<2, false, false, false, bf16x3p>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return PK_ELAUNCH;
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_lds_kernel<3, false, false, false, bf16x3p>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return PK_ELAUNCH;
                 attr = true;
             }
-            const int qblocks = (nq_pad + 127) / 128;
-            hipLaunchKernelGGL((attn_fwd_lds_kernel<2, false, false, false, bf16x3p>), dim3((unsigned)(S * h * qblocks)), block, (size_t)2 * 32768, s, a,
-                               (uint32_t)((size_t)S * h * nk_pad * 256));
+            // one workgroup per CU (the 64 KB ring, one wave per SIMD): 128-row workgroups are 5 per head at n = 576, i.e. 320 for the 64 (sequence, head)
+            // pairs of a B = 8 step = two rounds on 256 CUs; 192-row workgroups (48 rows per wave) are 192 = one round
+            static const int n_cu = [] { int dev = 0, cus = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256; return cus > 0 ? cus : 256; }();
+            static const int qf_env = [] { const char* e = getenv("PK_ATTN_TRAIN_QF"); return e ? atoi(e) : 0; }();
+            const long wg2 = (long)S * h * ((nq_pad + 127) / 128), wg3 = (long)S * h * ((nq_pad + 191) / 192);
+            const bool three = qf_env ? qf_env == 3 : (wg2 > n_cu && wg3 <= n_cu);
+            if (three) hipLaunchKernelGGL((attn_fwd_lds_kernel<3, false, false, false, bf16x3p>), dim3((unsigned)wg3), block, (size_t)2 * 32768, s, a,
+                                          (uint32_t)((size_t)S * h * nk_pad * 256));
+            else hipLaunchKernelGGL((attn_fwd_lds_kernel<2, false, false, false, bf16x3p>), dim3((unsigned)wg2), block, (size_t)2 * 32768, s, a,
+                                    (uint32_t)((size_t)S * h * nk_pad * 256));
             PK_CHECK_LAUNCH();
             return PK_OK;
         }
