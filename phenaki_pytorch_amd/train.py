@@ -107,9 +107,12 @@ def _flush_sums(defer):
         defer.clear()
 
 
-def transposes(dtype, items):
+def transposes(dtype, items, casts=()):
     """[(src (M, C) f32 rows, side 'a' | 'w')] -> [src^T as the (C, Mp) operand image of that side]: the activation transposes a backward block
-    needs for its weight gradients, laid down by ONE pk_pack_multi launch (round 6: one pk_pack launch each before)"""
+    needs for its weight gradients, laid down by ONE pk_pack_multi launch (round 6: one pk_pack launch each before).
+    casts: f32 row matrices that are also the A operand of a product of the block -- in the bf16 mode their bf16 copies are written by the same
+    launch (the GEMM then takes the LDS-DMA main loop instead of the register-staged f32-A kernel); returned after the transposes, in order
+    (the tensors themselves in the other modes, whose GEMMs read f32 A operands)."""
     q = _q(dtype)
     jobs, outs = [], []
     for src, side in items:
@@ -119,20 +122,37 @@ def transposes(dtype, items):
         out = torch.empty((C, Mp), device=src.device, dtype=torch.bfloat16 if kind == 1 else torch.float32)
         jobs.append(L.pack_job(src, C, M, True, out, Mp, kind))
         outs.append(out)
-    L.pack_multi(jobs, items[0][0])
+    for src in casts:
+        if dtype == L.BF16 and src.dtype == torch.float32 and src.shape[1] % 8 == 0 and src.shape[0] >= 256:
+            out = torch.empty(tuple(src.shape), device=src.device, dtype=torch.bfloat16)
+            jobs.append(L.pack_job(src, src.shape[0], src.shape[1], False, out, src.shape[1], 1))
+            outs.append(out)
+        else:
+            outs.append(src)
+    if jobs:
+        L.pack_multi(jobs, jobs_like(items, casts))
     return outs
 
 
-def linear_bwd(dtype, x, W, dy, *, need_dx=True, add=None, need_dw=True, dw_out=None, Wt=None, dyT=None, xT=None, defer=None):
+def jobs_like(items, casts):
+    return items[0][0] if items else casts[0]
+
+
+def a_operand(dtype, x):
+    """the A-operand form of f32 rows x: a bf16 copy in the bf16 mode (one cast launch), x itself otherwise"""
+    return transposes(dtype, [], [x])[0]
+
+
+def linear_bwd(dtype, x, W, dy, *, need_dx=True, add=None, need_dw=True, dw_out=None, Wt=None, dyT=None, xT=None, defer=None, dyA=None):
     """gradients of y = x W^T: dx = dy W [+ add] (M, K), dW = dy^T x (N, K).  dw_out: preallocated (N, K) destination (may be a row slice).
     Wt: the (K, Kp(N)) operand image of W^T when the caller holds one (`WeightImages`); dyT / xT: the transposed operand images of `transposes`;
-    defer: see _weight_grad_gemm."""
+    defer: see _weight_grad_gemm.  dyA: dy as the A operand of dx = dy W (its bf16 copy in the bf16 mode, `transposes(..., casts=[dy])`)."""
     M, K = x.shape
     N = W.shape[0]
     dx = dW = None
     if need_dx:
         dx = _f32((M, K), x.device)
-        L.gemm(dtype, dy, Wt if Wt is not None else pack_operand(W, dtype, transpose=True), M, K, N, C=dx, res=add)
+        L.gemm(dtype, dyA if dyA is not None else dy, Wt if Wt is not None else pack_operand(W, dtype, transpose=True), M, K, N, C=dx, res=add)
     if need_dw:
         Mp = round_up(M, _q(dtype))
         if dyT is None:
@@ -279,14 +299,15 @@ class _FFBlock(torch.autograd.Function):
         if img is None:
             img = _FFBlock._images(w1, w2, dtype, dev)
         xn = _f32((M, D), dev)
-        L.layernorm(x, ln_w, ln_b, M, D, out2=xn, eps=eps)
+        xa = torch.empty((M, D), device=dev, dtype=torch.bfloat16) if dtype == L.BF16 else None    # bf16 mode: the A operand of the first Linear, from the same launch
+        L.layernorm(x, ln_w, ln_b, M, D, out=xa, out2=xn, eps=eps)
         # value rows [0, F) and gate rows [Fp, Fp + F) of the K-padded 2 Fp-row weight image; the pad rows stay zero -> h pad columns are 0
         h = _f32((M, 2 * Fp), dev)
-        L.gemm(dtype, xn, img['w1p'], M, 2 * Fp, D, C=h)
+        L.gemm(dtype, xa if xa is not None else xn, img['w1p'], M, 2 * Fp, D, C=h)
         a = _f32((M, Fp), dev)
         L.geglu(h, Fp, a, M, Fp)
         y = _f32((M, D), dev)
-        L.gemm(dtype, a, img['w2'], M, D, Fp, C=y, res=x)
+        L.gemm(dtype, a_operand(dtype, a), img['w2'], M, D, Fp, C=y, res=x)
         ctx.save_for_backward(x, ln_w, w1, w2, xn, h, a)
         ctx.dtype, ctx.eps, ctx.Fp, ctx.img = dtype, eps, Fp, img
         return y
@@ -303,9 +324,9 @@ class _FFBlock(torch.autograd.Function):
         Mp = round_up(M, q)
         sums = []
         # ---- second Linear: da = dy W2 (pad columns: zero rows of the W2^T image), dW2 = dy^T a
+        dyT, aT, dyA = transposes(dtype, [(dy, 'a'), (a, 'w')], [dy])     # (D, Mp), (Fp, Mp)
         da = _f32((M, Fp), dev)
-        L.gemm(dtype, dy, img['w2t'], M, Fp, D, C=da)
-        dyT, aT = transposes(dtype, [(dy, 'a'), (a, 'w')])                # (D, Mp), (Fp, Mp)
+        L.gemm(dtype, dyA, img['w2t'], M, Fp, D, C=da)
         dW2 = None if F % 4 else _f32((D, F), dev)
         dW2p = None
         if F % 4:                                                        # inner 1365: the product on the padded width (a's pad columns are zero), then the slice
@@ -317,9 +338,9 @@ class _FFBlock(torch.autograd.Function):
         dh = _f32((M, 2 * Fp), dev)
         L.geglu_bwd(h, Fp, da, dh, M, Fp)
         # ---- first Linear: dxn = dh W1 (the padded layout, transposed), dW1 = dh^T xn in two row groups (value | gate)
+        dhT, xnT, dhA = transposes(dtype, [(dh, 'a'), (xn, 'w')], [dh])   # (2 Fp, Mp), (D, Mp)
         dxn = _f32((M, D), dev)
-        L.gemm(dtype, dh, img['w1t'], M, D, 2 * Fp, C=dxn)
-        dhT, xnT = transposes(dtype, [(dh, 'a'), (xn, 'w')])              # (2 Fp, Mp), (D, Mp)
+        L.gemm(dtype, dhA, img['w1t'], M, D, 2 * Fp, C=dxn)
         dW1 = _f32((2 * F, D), dev)
         _weight_grad_gemm(dtype, dhT[:F], xnT, F, D, Mp, dW1[:F], sums)
         _weight_grad_gemm(dtype, dhT[Fp:Fp + F], xnT, F, D, Mp, dW1[F:], sums)
@@ -380,7 +401,10 @@ class _AttnBlock(torch.autograd.Function):
         is_cross = context is not None
         n_kv = n_ctx if is_cross else n
         xn = _f32((M, D), dev)
-        L.layernorm(x, gamma, beta, M, D, out2=xn, eps=eps)
+        # bf16 mode: the A operands of to_q (LayerNorm output) and of the self-attention's to_kv (the un-normalised x) as bf16 copies from the same launch
+        xa = torch.empty((M, D), device=dev, dtype=torch.bfloat16) if dtype == L.BF16 else None
+        xr = torch.empty((M, D), device=dev, dtype=torch.bfloat16) if (dtype == L.BF16 and context is None) else None
+        L.layernorm(x, gamma, beta, M, D, out=xa, out2=xn, raw=xr, eps=eps)
         if is_cross:
             Mk, Dk = context.shape
             if cgamma is not None:
@@ -390,8 +414,8 @@ class _AttnBlock(torch.autograd.Function):
                 src = context
         else:
             src = x
-        q = linear_fwd(dtype, xn, wq, Wimg=img['wq'][0])
-        kv = linear_fwd(dtype, src, wkv, Wimg=img['wkv'][0])
+        q = linear_fwd(dtype, xa if xa is not None else xn, wq, Wimg=img['wq'][0])
+        kv = linear_fwd(dtype, xr if xr is not None else src, wkv, Wimg=img['wkv'][0])
         td = L.tdtype(dtype)
         nq_pad, nk_pad = L.attn_pads(n, n_kv, nnull)
         Qp = torch.empty((S * heads * nq_pad * 64,), device=dev, dtype=td)
@@ -404,7 +428,7 @@ class _AttnBlock(torch.autograd.Function):
         lse = _f32((S * heads * n,), dev) if dtype != L.BF16 else None
         L.attn_fwd(dtype, Qp, Kp, Vt, o, S, heads, n, n_kv, nnull, bias=bias, kmask=kmask, slopes=slopes, causal=slopes is not None, lse=lse)
         y = _f32((M, D), dev)
-        L.gemm(dtype, o, img['wo'][0], M, D, inner, C=y, res=x)
+        L.gemm(dtype, a_operand(dtype, o), img['wo'][0], M, D, inner, C=y, res=x)
         ctx.save_for_backward(x, context, gamma, cgamma, wq, wkv, null_kv, q_scale, k_scale, wo, bias, kmask, xn, src, q, kv, o, lse)
         ctx.meta = meta
         return y
@@ -423,8 +447,8 @@ class _AttnBlock(torch.autograd.Function):
         dy = dy.contiguous()
         sums = []
         # ---- to_out
-        dyT, oT = transposes(dtype, [(dy, 'a'), (o, 'w')])
-        do, dWo = linear_bwd(dtype, o, wo, dy, Wt=img['wo'][1], dyT=dyT, xT=oT, defer=sums)
+        dyT, oT, dyA = transposes(dtype, [(dy, 'a'), (o, 'w')], [dy])
+        do, dWo = linear_bwd(dtype, o, wo, dy, Wt=img['wo'][1], dyT=dyT, xT=oT, defer=sums, dyA=dyA)
         # ---- attention core
         Qh, Kh, Vh = _f32((S * heads * n, 64), dev), _f32((S * heads * nkt, 64), dev), _f32((S * heads * nkt, 64), dev)
         L.attn_train_prep(q, kv, null_kv.detach(), q_scale.detach(), k_scale.detach(), float(scale), Qh, Kh, Vh, S, heads, n, n_kv, nnull)
@@ -444,13 +468,13 @@ class _AttnBlock(torch.autograd.Function):
         if dnull is None:
             dnull = torch.zeros_like(null_kv)
         # ---- projections, LayerNorms, residual
-        dqT, xnT, dkvT, srcT = transposes(dtype, [(dq, 'a'), (xn, 'w'), (dkv, 'a'), (src, 'w')])
-        dxn, dWq = linear_bwd(dtype, xn, wq, dq, Wt=img['wq'][1], dyT=dqT, xT=xnT, defer=sums)
+        dqT, xnT, dkvT, srcT, dqA, dkvA = transposes(dtype, [(dq, 'a'), (xn, 'w'), (dkv, 'a'), (src, 'w')], [dq, dkv])
+        dxn, dWq = linear_bwd(dtype, xn, wq, dq, Wt=img['wq'][1], dyT=dqT, xT=xnT, defer=sums, dyA=dqA)
         dx = _f32((M, D), dev)
         dcg = dctx = None
         if is_cross:
             need_ctx = ctx.needs_input_grad[1]
-            dsrc, dWkv = linear_bwd(dtype, src, wkv, dkv, need_dx=(cgamma is not None) or need_ctx, Wt=img['wkv'][1], dyT=dkvT, xT=srcT, defer=sums)
+            dsrc, dWkv = linear_bwd(dtype, src, wkv, dkv, need_dx=(cgamma is not None) or need_ctx, Wt=img['wkv'][1], dyT=dkvT, xT=srcT, defer=sums, dyA=dkvA)
             _flush_sums(sums)
             if cgamma is not None:
                 dctx = _f32(tuple(context.shape), dev)
@@ -459,7 +483,7 @@ class _AttnBlock(torch.autograd.Function):
                 dctx = dsrc
             dg, _ = L.layernorm_bwd(x, gamma.detach(), dxn, dx, M, D, add=dy, eps=eps, defer=cs)
         else:
-            t, dWkv = linear_bwd(dtype, x, wkv, dkv, add=dy, Wt=img['wkv'][1], dyT=dkvT, xT=srcT, defer=sums)   # dy + dkv Wkv: K / V read the un-normalised x
+            t, dWkv = linear_bwd(dtype, x, wkv, dkv, add=dy, Wt=img['wkv'][1], dyT=dkvT, xT=srcT, defer=sums, dyA=dkvA)   # dy + dkv Wkv: K / V read the un-normalised x
             _flush_sums(sums)
             dg, _ = L.layernorm_bwd(x, gamma.detach(), dxn, dx, M, D, add=t, eps=eps, defer=cs)
         if cs:

@@ -13,6 +13,9 @@ echo "== kernel trace: whole bench (no cpu / parity mode)"; date
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $P/all -o all -- python bench.py --no-cpu --no-parity-mode --no-kernels --groups 3 --legs decode,sample,sample_cfg3,make_video,objective > $P/all.json 2> $P/all.err; echo rc=$?
 echo "== kernel trace: training legs (Phenaki step in bf16x3 + bf16, tokenizer step, tokenizer GAN step)"; date
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $P/train -o train -- python bench.py --no-cpu --no-parity-mode --no-kernels --groups 2 --legs train_step,cvivit_train_step,cvivit_gan_step > $P/train.json 2> $P/train.err; echo rc=$?
+echo "== steady-state launch census of the Phenaki training step (bf16x3; tools/train_census.py)"; date
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$P/census -o c -- python $OLDPWD/tools/train_census.py bf16x3 6 phenaki > $OLDPWD/$P/census.log 2>&1 ); echo rc=$?
+python tools/train_census.py --summary $P/census 6 > $P/train_step_census_$R.txt; head -12 $P/train_step_census_$R.txt
 echo "== PMC FETCH_SIZE"; date
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch -o p -- python bench.py --encode-only --no-graph --no-kernels --groups 1 --steps 3 --warmup 1 > /dev/null 2> $P/pmc_fetch.err; echo rc=$?
 echo "== PMC WRITE_SIZE"; date
