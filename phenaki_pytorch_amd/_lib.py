@@ -760,10 +760,11 @@ def attn_train_prep_bwd(q, kv, null_kv, q_scale, k_scale, scale, dQh, dKh, dVh, 
     return out[:64], out[64:], dnull
 
 
-def attn_bwd(Qh, Kh, Vh, O, dO, dQh, dKh, dVh, S, h, n, n_kv, nnull, *, bias=None, kmask=None, dS=None, slopes=None, causal=False, split_bf16=False, lse=None):
-    """lse ((S h n,) f32 from attn_fwd(lse=...)): the backward skips its own log-sum-exp pass"""
+def attn_bwd(Qh, Kh, Vh, O, dO, dQh, dKh, dVh, S, h, n, n_kv, nnull, *, bias=None, kmask=None, dS=None, slopes=None, causal=False, split_bf16=False, lse=None,
+             bf16_products=False):
+    """lse ((S h n,) f32 from attn_fwd(lse=...)): the backward skips its own log-sum-exp pass.  bf16_products: single bf16 MFMA products (the bf16 mode)"""
     dev = Qh.device
-    flags = (1 if split_bf16 else 0) | (2 if lse is not None else 0)
+    flags = (1 if split_bf16 else 0) | (2 if lse is not None else 0) | (4 if bf16_products else 0)
     if lse is None:
         lse = torch.empty((S * h * n,), device=dev, dtype=torch.float32)
     drow = torch.empty((S * h * n,), device=dev, dtype=torch.float32)

@@ -928,7 +928,7 @@ static int attn_fwd_impl(int dtype, const void* Qp, const void* Kp, const void* 
     const long waves = (long)S * h * (nq_pad / (16 * QF));
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     static const int use_lds = [] { const char* e = getenv("PK_ATTN_LDS"); return e ? atoi(e) : 1; }();   // tuning knob
-    if (dtype == 1 && use_lds && !lse && nnull + n_kv >= 64 && nq >= 64 &&
+    if (dtype == 1 && use_lds && (!lse || (!bias_tab && !(score_bound == score_bound))) && nnull + n_kv >= 64 && nq >= 64 &&
         (size_t)S * h * nk_pad * 128 < 0xFFFFFFF0ull) {
         // measured on maskgit self-attention (S*h = 128, n = 576, bias): 16 query rows per wave + bias prefetch 41.2 us,
         // 32 rows per wave 44.5 us (its prefetch spills: 77 us); with a single key tile (n = 64) there is nothing to

@@ -134,10 +134,16 @@ __global__ __launch_bounds__(64) void null_kv_bwd_kernel(const float* __restrict
 // LDS as ready-made (hi | lo) bf16 planes (split once per workgroup when stashed, no conversions in the inner loops) was built and measured
 // too: no further gain (the loops wait on LDS / barriers, not on the VALU splits), so the simpler f32 tiles stay.
 // ~2^-17 relative per product, as everywhere else in the bf16x3 mode.  X3 = false: exact f32 (the 'fp32' mode).
-template <bool X3> struct OpFragOf { typedef Frag<float> type; };
-template <> struct OpFragOf<true> { typedef Frag<bf16x3p> type; };
+// X3 = 2 (round 6, the bf16 compute mode only): ONE bf16 MFMA per block on the RNE-rounded fragments -- the products the bf16 forward kernels make of
+// the same q^ / k^ / v, so the forward's log-sum-exp is the backward's too; a third of the MFMAs and 4 instead of 24 conversion instructions per fragment.
+template <int X3> struct OpFragOf { typedef Frag<float> type; };
+template <> struct OpFragOf<1> { typedef Frag<bf16x3p> type; };
+template <> struct OpFragOf<2> { typedef Frag<bf16> type; };
 __device__ __forceinline__ void to_operand(Frag<float>& o, const Frag<float>& f) { o = f; }
 __device__ __forceinline__ void to_operand(Frag<bf16x3p>& o, const Frag<float>& f) { split8(f.lo, f.hi, o.hi, o.lo); }
+__device__ __forceinline__ void to_operand(Frag<bf16>& o, const Frag<float>& f) {
+    o.v = u32x4{pack_bf2(f.lo[0], f.lo[1]), pack_bf2(f.lo[2], f.lo[3]), pack_bf2(f.hi[0], f.hi[1]), pack_bf2(f.hi[2], f.hi[3])};
+}
 
 template <int NBLK, int NCHUNK, typename OF>
 __device__ __forceinline__ void mma_regA(const OF (&a)[NCHUNK], const float* Bs, int ldb, f32x4 (&acc)[NBLK], int lane) {
@@ -308,7 +314,7 @@ __device__ __forceinline__ bool score(const AttnBwdArgs& p, int s, int h, int gi
 // SIMD -- 256 resident workgroups, so the 576 of a B = 8 step ran in three rounds
 // (round 6, measured and removed: a variant whose dS rows shared the V tile's LDS -- 52 KB and a 168-register cap, three workgroups per CU so that the 576
 // workgroups of a B = 8 step run in one round instead of 512 + 64 -- spilled 210 VGPRs and lost: training step 30.13 vs 29.34 ms same-box.)
-template <bool X3>
+template <int X3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_q_kernel(const AttnBwdArgs p) {
     typedef typename OpFragOf<X3>::type OF;
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -466,7 +472,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // LDS holds q^ [32][68], dO [32][68] (B operands of the TRANSPOSED scores S^T[j][i], dP^T[j][i]), their transposes [64][36] (B operands of
 // dV = P^T dO, dK^ = dS^T q^) and one wave-private [64][36] buffer that carries P^T and then dS^T (46 KB: three workgroups per CU).
 constexpr int QT = 32, TLQ = 36;
-template <bool X3>
+template <int X3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_kv_kernel(const AttnBwdArgs p) {
     typedef typename OpFragOf<X3>::type OF;
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -631,7 +637,8 @@ extern "C" int pk_attn_bwd_ws(const float* Qh, const float* Kh, const float* Vh,
     if (!al16(Qh) || !al16(Kh) || !al16(Vh) || !al16(dO) || (lddo & 3) || !al16(O) || (ldo & (o_bf16 ? 7 : 3))) return PK_EALIGN;
     if ((long)S * heads > 0x7fffffffL / 64) return PK_EINVAL;
     if (causal && (!slopes || n != n_kv)) return PK_EINVAL;
-    const int have_lse = (split_bf16 >> 1) & 1;                         // flags: bit 0 split-bf16 tile products, bit 1 lse (S heads, n) given by pk_attn_fwd_lse
+    const int have_lse = (split_bf16 >> 1) & 1;                         // flags: bit 0 split-bf16 tile products, bit 1 lse (S heads, n) given by pk_attn_fwd_lse,
+    const bool bf16_products = (split_bf16 >> 2) & 1;                   // bit 2: single bf16 products (the bf16 compute mode)
     split_bf16 &= 1;
     AttnBwdArgs p{Qh, Kh, Vh, O, ldo, o_bf16, dO, lddo, bias, kmask, slopes, causal, dQh, dKh, dVh, dS, lse, Drow, S, heads, n, nnull + n_kv, nnull, 0, 0, heads, S * heads, 0, have_lse};
     static const bool pack_on = !(getenv("PK_ATTN_BWD_PACK") && getenv("PK_ATTN_BWD_PACK")[0] == '0');      // A/B switch
@@ -649,10 +656,12 @@ extern "C" int pk_attn_bwd_ws(const float* Qh, const float* Kh, const float* Vh,
     hipStream_t s = STREAM(stream);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TSZ * 4) != hipSuccess) return PK_ELAUNCH;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TSZ * 4) != hipSuccess) return PK_ELAUNCH;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, KV_SMEM) != hipSuccess) return PK_ELAUNCH;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, KV_SMEM) != hipSuccess) return PK_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TSZ * 4) != hipSuccess) return PK_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TSZ * 4) != hipSuccess) return PK_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TSZ * 4) != hipSuccess) return PK_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kv_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, KV_SMEM) != hipSuccess) return PK_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kv_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, KV_SMEM) != hipSuccess) return PK_ELAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kv_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, KV_SMEM) != hipSuccess) return PK_ELAUNCH;
         attr_done = true;
     }
     const int nqt = (p.n + 63) / 64, nktt = (p.nkt + 63) / 64;
@@ -666,12 +675,15 @@ extern "C" int pk_attn_bwd_ws(const float* Qh, const float* Kh, const float* Vh,
     }
     const dim3 gq((unsigned)((long)p.S * p.heads * nqt)), gk((unsigned)((long)p.S * p.heads * nktt * (p.kv_split > 1 ? p.kv_split : 1)));
     static const bool split_on = !(getenv("PK_ATTN_BWD_SPLIT") && getenv("PK_ATTN_BWD_SPLIT")[0] == '0');     // A/B switch
-    if (split_bf16 && split_on) {
-        hipLaunchKernelGGL(attn_bwd_q_kernel<true>, gq, dim3(256), 4 * TSZ * 4, s, p);
-        hipLaunchKernelGGL(attn_bwd_kv_kernel<true>, gk, dim3(256), KV_SMEM, s, p);
+    if (bf16_products) {
+        hipLaunchKernelGGL(attn_bwd_q_kernel<2>, gq, dim3(256), 4 * TSZ * 4, s, p);
+        hipLaunchKernelGGL(attn_bwd_kv_kernel<2>, gk, dim3(256), KV_SMEM, s, p);
+    } else if (split_bf16 && split_on) {
+        hipLaunchKernelGGL(attn_bwd_q_kernel<1>, gq, dim3(256), 4 * TSZ * 4, s, p);
+        hipLaunchKernelGGL(attn_bwd_kv_kernel<1>, gk, dim3(256), KV_SMEM, s, p);
     } else {
-        hipLaunchKernelGGL(attn_bwd_q_kernel<false>, gq, dim3(256), 4 * TSZ * 4, s, p);
-        hipLaunchKernelGGL(attn_bwd_kv_kernel<false>, gk, dim3(256), KV_SMEM, s, p);
+        hipLaunchKernelGGL(attn_bwd_q_kernel<0>, gq, dim3(256), 4 * TSZ * 4, s, p);
+        hipLaunchKernelGGL(attn_bwd_kv_kernel<0>, gk, dim3(256), KV_SMEM, s, p);
     }
     PK_CHECK_LAUNCH();
     if (p.kv_split > 1) {                                                // dK^ / dV = the slabs added in index order (one launch for both)

@@ -36,6 +36,11 @@ from .attention import (Attention, FeedForwardSeq, LayerNorm, PEG, compute_dtype
 CE_SLAB = int(os.environ.get('PK_CE_SLAB', '8192'))
 
 
+# bf16 mode: the attention backward's tile products as single bf16 MFMAs on the operands the bf16 forward kernels multiply (0: split-bf16 products of the f32
+# operands, and a log-sum-exp pass of their own); knob PK_ATTN_BWD_BF16, DESIGN 5.1
+ATTN_BWD_BF16 = os.environ.get('PK_ATTN_BWD_BF16', '0') != '0'
+
+
 def _q(dtype):
     return 64 if dtype == L.BF16 else 32
 
@@ -425,7 +430,7 @@ class _AttnBlock(torch.autograd.Function):
         o = _f32((M, inner), dev)
         # every score row's log-sum-exp: the backward kernels start from it.  Not in the bf16 mode: its forward scores come from bf16 operands, the
         # backward recomputes them from split f32 ones -- P = exp(s - lse) must use the lse of the SAME scores, so that mode keeps the extra pass
-        lse = _f32((S * heads * n,), dev) if dtype != L.BF16 else None
+        lse = _f32((S * heads * n,), dev) if (dtype != L.BF16 or ATTN_BWD_BF16) else None
         L.attn_fwd(dtype, Qp, Kp, Vt, o, S, heads, n, n_kv, nnull, bias=bias, kmask=kmask, slopes=slopes, causal=slopes is not None, lse=lse)
         y = _f32((M, D), dev)
         L.gemm(dtype, a_operand(dtype, o), img['wo'][0], M, D, inner, C=y, res=x)
@@ -456,7 +461,7 @@ class _AttnBlock(torch.autograd.Function):
         want_dbias = bias is not None and ctx.needs_input_grad[12]
         dS = _f32((S, heads * n * n_kv), dev) if want_dbias else None
         L.attn_bwd(Qh, Kh, Vh, o, do, dQh, dKh, dVh, S, heads, n, n_kv, nnull, bias=bias, kmask=kmask, dS=dS, slopes=slopes, causal=slopes is not None,
-                   split_bf16=dtype != L.F32, lse=lse)
+                   split_bf16=dtype != L.F32, lse=lse, bf16_products=(dtype == L.BF16 and ATTN_BWD_BF16))
         dbias = None
         if want_dbias:
             dbias = _f32(tuple(bias.shape), dev)
