@@ -38,7 +38,7 @@ CE_SLAB = int(os.environ.get('PK_CE_SLAB', '8192'))
 
 # bf16 mode: the attention backward's tile products as single bf16 MFMAs on the operands the bf16 forward kernels multiply (0: split-bf16 products of the f32
 # operands, and a log-sum-exp pass of their own); knob PK_ATTN_BWD_BF16, DESIGN 5.1
-ATTN_BWD_BF16 = os.environ.get('PK_ATTN_BWD_BF16', '0') != '0'
+ATTN_BWD_BF16 = os.environ.get('PK_ATTN_BWD_BF16', '1') != '0'
 
 
 def _q(dtype):
@@ -428,8 +428,9 @@ class _AttnBlock(torch.autograd.Function):
         Vt = torch.empty((S * heads * nk_pad * 64,), device=dev, dtype=td)
         L.attn_prep(dtype, q, kv, null_kv.detach(), q_scale.detach(), k_scale.detach(), float(scale), Qp, Kp, Vt, S, heads, n, n_kv, nnull)
         o = _f32((M, inner), dev)
-        # every score row's log-sum-exp: the backward kernels start from it.  Not in the bf16 mode: its forward scores come from bf16 operands, the
-        # backward recomputes them from split f32 ones -- P = exp(s - lse) must use the lse of the SAME scores, so that mode keeps the extra pass
+        # every score row's log-sum-exp: the backward kernels start from it.  P = exp(s - lse) must use the lse of the SAME scores: in the bf16 mode the
+        # forward's scores are products of bf16 operands, so the hand-over needs the backward's single-bf16-product form (ATTN_BWD_BF16); with the
+        # split-bf16 backward (PK_ATTN_BWD_BF16=0) that mode keeps the extra pass
         lse = _f32((S * heads * n,), dev) if (dtype != L.BF16 or ATTN_BWD_BF16) else None
         L.attn_fwd(dtype, Qp, Kp, Vt, o, S, heads, n, n_kv, nnull, bias=bias, kmask=kmask, slopes=slopes, causal=slopes is not None, lse=lse)
         y = _f32((M, D), dev)

@@ -121,7 +121,14 @@ def test_multi_job_pack_sum_and_one_launch_colsum():
         ref = torch.empty_like(o)
         L.sum_batch(p_, p_.shape[0], ref, p_.shape[1])
         assert torch.equal(o, ref)
-    for M, N in ((144, 512), (288, 27 * 512), (1024, 128), (144, 1), (200, 33), (1000, 1024)):
+    srcs = [torch.randn(m_, n_, generator=g).cuda() for m_, n_ in ((576, 512), (1024, 128), (288, 27 * 64), (4608, 512), (96, 768))]
+    outs = [torch.empty(x_.shape[1], device='cuda') for x_ in srcs]
+    L.colsum_multi([(x_, x_.shape[0], x_.shape[1], o) for x_, o in zip(srcs, outs)])
+    for x_, o in zip(srcs, outs):
+        close(o.cpu(), x_.cpu().double().sum(0).float(), 1e-5, f'colsum_multi {tuple(x_.shape)}')
+        ref = L.colsum(x_, x_.shape[0], x_.shape[1], torch.empty(x_.shape[1], device='cuda'))
+        assert torch.equal(o, ref), 'the multi-job form adds in the same order as the one-launch form'
+    for M, N in ((144, 512), (288, 27 * 512), (1024, 128), (144, 1), (200, 33), (1000, 1024), (9000, 64), (9000, 6)):
         src = torch.randn(M, N, generator=g).cuda()
         cs = L.colsum(src, M, N, torch.empty(N, device='cuda'), scale=0.25)
         close(cs.cpu(), 0.25 * src.cpu().double().sum(0).float(), 1e-5, f'colsum one launch {M}x{N}')
