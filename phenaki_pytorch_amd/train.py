@@ -177,7 +177,7 @@ class WeightImages:
         self.dtype, self.device = dtype, device
         self.q, self.kind = _q(dtype), L.kind_of(dtype)
         self.td = torch.bfloat16 if self.kind == 1 else torch.float32
-        self.jobs, self.table, self.params = [], None, []
+        self.jobs, self.table, self.params, self.live = [], None, [], []
 
     def _image(self, rows, cols):
         return torch.zeros((rows, round_up(cols, self.q)), device=self.device, dtype=self.td)
@@ -188,6 +188,7 @@ class WeightImages:
 
     def both(self, w):
         """w (N, K) -> (image of W: (N, Kp(K)), image of W^T: (K, Kp(N)))"""
+        self.live.append(w)
         w = w.detach()
         N, K = w.shape
         f, t = self._image(N, K), self._image(K, N)
@@ -199,6 +200,7 @@ class WeightImages:
     def feedforward(self, w1, w2):
         """the GEGLU feed-forward's layouts (see _FFBlock): w1p (2 Fp, Kp(D)) value rows [0, F) | gate rows [Fp, Fp + F); w1t (D, Kp(2 Fp)) its
         transpose; w2 (D, Kp(F)); w2t (Fp, Kp(D)) with zero pad rows"""
+        self.live += [w1, w2]
         w1, w2 = w1.detach(), w2.detach()
         D, F = w2.shape
         Fp = round_up(F, 8)
@@ -214,7 +216,8 @@ class WeightImages:
         return dict(w1p=w1p, w1t=w1t, w2=w2f, w2t=w2t)
 
     def key(self):
-        return tuple((p.data_ptr(), tuple(p.shape)) for p in self.params)
+        """storage identity of the LIVE parameters (a `.data = ...` / `.to()` moves them: the job table then points at dead storage)"""
+        return tuple((p.data_ptr(), tuple(p.shape)) for p in self.live)
 
     def refresh(self):
         if len(self.jobs) <= 8:                                          # one block's weights (a direct caller): the jobs travel in the kernel arguments

@@ -152,6 +152,56 @@ def test_layernorm_backward(D):
     close(db.cpu(), bl.grad, 1e-4, 'ln dbeta')
 
 
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16x3'])
+def test_weight_images_follow_the_parameters(dtype):
+    """round 6: the persistent W / W^T operand images of a Transformer (train.WeightImages) are refreshed every pass and rebuilt when a parameter
+    moves to other storage; deepcopy / state_dict never see them.  A stale image would reproduce the OLD gradients."""
+    import copy
+    import phenaki_pytorch_amd as P
+    from phenaki_pytorch_amd import train as T
+    from phenaki_pytorch_amd.attention import resolve_dtype
+    torch.manual_seed(5)
+    D, S, n = 128, 3, 40
+    tr = P.attention.Transformer(dim=D, depth=2, heads=2, has_cross_attn=True, dim_context=96).cuda()
+    dt = resolve_dtype(dtype)
+    x = torch.randn(S * n, D).cuda()
+    ctx = torch.randn(S * 5, 96).cuda()
+    G = torch.randn(S * n, D).cuda()
+
+    def grads(mod):
+        for p_ in mod.parameters():
+            p_.grad = None
+        xc = x.clone().requires_grad_()
+        with torch.enable_grad():
+            y = T.transformer_train(mod, xc, S, n, dt, context2d=ctx, n_ctx=5)
+        y.backward(G)
+        return {k: v.grad.clone() for k, v in mod.named_parameters() if v.grad is not None}, y.detach()
+
+    g1, y1 = grads(tr)
+    g1b, y1b = grads(tr)                                               # replay on the same images: same bytes
+    assert torch.equal(y1, y1b) and all(torch.equal(g1[k], g1b[k]) for k in g1)
+    assert not any('image' in k or 'pk_' in k for k in tr.state_dict())
+    # in-place update (what the optimizer does): same storage, new values -> the refresh must pick them up
+    with torch.no_grad():
+        for p_ in tr.parameters():
+            if p_.ndim == 2:
+                p_.mul_(1.25)
+    fresh = copy.deepcopy(tr)                                          # a new module: its own images, built from the updated values
+    g2, y2 = grads(tr)
+    gf, yf = grads(fresh)
+    assert not torch.equal(y1, y2)
+    assert torch.equal(y2, yf) and all(torch.equal(g2[k], gf[k]) for k in g2), 'images not refreshed after an in-place parameter update'
+    # new storage (what .to() / a reload by assignment does) with new values
+    with torch.no_grad():
+        for p_ in tr.parameters():
+            if p_.ndim == 2:
+                p_.data = (p_.data * 0.8).clone()
+    fresh = copy.deepcopy(tr)
+    g3, y3 = grads(tr)
+    gf, yf = grads(fresh)
+    assert torch.equal(y3, yf) and all(torch.equal(g3[k], gf[k]) for k in g3), 'images not rebuilt after the parameters moved to other storage'
+
+
 @pytest.mark.parametrize('dtype,tol', MODES)
 def test_feedforward_block_gradients(dtype, tol):
     """x + FeedForward(x) (attention.py:45-52, inner 1365 -> padded 1368 inside the block) vs torch autograd of the oracle"""
