@@ -232,12 +232,13 @@ def test_feedforward_block_gradients(dtype, tol):
 
 
 @pytest.mark.parametrize('dtype,tol', MODES)
-@pytest.mark.parametrize('case', ['self_bias', 'cross_null_mask', 'self_mask', 'causal_short', 'causal_long', 'causal_packed', 'packed_mask'])
+@pytest.mark.parametrize('case', ['self_bias', 'self_bias_long', 'self_long', 'cross_null_mask', 'self_mask', 'causal_short', 'causal_long', 'causal_packed', 'packed_mask'])
 def test_attention_block_gradients(case, dtype, tol):
     """x + Attention(x) (attention.py:89-182): position bias gradient, null keys, key mask, l2norm / learned scales; n = 70 (ragged tiles);
     causal_*: ALiBi over the null + real keys and the causal mask (the C-ViViT temporal transformers: n = 9, and n = 70 across key tiles);
     *packed*: no null keys and n <= 32 -- pk_attn_bwd packs 64 / n whole (sequence, head) groups into one tile (80 groups of 9 rows = 11 full
-    tiles + a partial one; 22 groups of 12 rows with a key mask)"""
+    tiles + a partial one; 22 groups of 12 rows with a key mask); *_long (round 6): n = 200 >= 128 without a key mask -- the training forward runs on the
+    LDS-staged kernels there (split-bf16: running-max form with the bias as a matrix, ragged last key tile) and hands the backward its log-sum-exp"""
     import phenaki_pytorch_amd as P
     from phenaki_pytorch_amd.train import attention_train
     from phenaki_pytorch_amd.attention import resolve_dtype
@@ -250,6 +251,8 @@ def test_attention_block_gradients(case, dtype, tol):
         S, n = 40, 9
     elif case == 'packed_mask':
         S, n = 11, 12
+    elif case.endswith('_long'):
+        S, n = 2, 200
     nnull = 2 if (cross or (causal and not packed)) else 0
     attn = P.attention.Attention(dim=D, dim_context=96 if cross else None, heads=heads, num_null_kv=nnull, causal=causal)
     with torch.no_grad():
@@ -270,8 +273,10 @@ def test_attention_block_gradients(case, dtype, tol):
         mask = torch.rand(S, n_ctx) > 0.3
         mask[:, 0] = True
         sd['context_norm.beta'] = attn.context_norm.beta.detach()
-    elif case == 'self_bias':
+    elif case in ('self_bias', 'self_bias_long'):
         bias = _leaf(torch.randn(heads, n, n))
+    elif case == 'self_long':
+        pass
     elif not causal:
         mask = torch.rand(S, n) > 0.2
         mask[:, 0] = True
