@@ -391,6 +391,8 @@ int pk_sum_batch(const float* src, long long stride, int S, float* out, long lon
 /* count <= 8 short column sums in one launch (the one-launch form of pk_colsum: M <= 8192, N % 4 == 0, 16-byte aligned rows; blk0 filled in by the library) */
 typedef struct PkColsumJob { const float* src; float* out; long long ld; int M, N, blk0; float scale; } PkColsumJob;
 int pk_colsum_multi(const void* jobs, int count, void* stream);
+/* both job lists of a backward block (<= 8 each, either may be empty) in ONE launch */
+int pk_reduce_multi(const void* sum_jobs, int nsum, const void* col_jobs, int ncol, void* stream);
 /* count <= 8 pk_sum_batch jobs in one launch (E4 = E / 4; blk0 is filled in by the library): the K-slice partials of one block's weight gradients */
 typedef struct PkSumJob { const float* src; float* out; long long stride, E4; int S, blk0; } PkSumJob;
 int pk_sum_batch_multi(const void* jobs, int count, void* stream);

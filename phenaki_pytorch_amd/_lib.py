@@ -90,6 +90,7 @@ SIGNATURES = {
     'pk_sum_batch': [_P, _LL, _I, _P, _LL, _P],
     'pk_sum_batch_multi': [_P, _I, _P],
     'pk_colsum_multi': [_P, _I, _P],
+    'pk_reduce_multi': [_P, _I, _P, _I, _P],
     'pk_pack_multi': [_P, _I, _P],
     'pk_pack_table_prepare': [_P, _I],
     'pk_pack_table': [_P, _I, _I, _P],
@@ -607,6 +608,20 @@ def colsum_multi(jobs):
         chunk = jobs[i:i + 8]
         arr = (ColsumJob * len(chunk))(*[ColsumJob(s_.data_ptr(), o.data_ptr(), s_.stride(-2), M, N, 0, 1.0) for s_, M, N, o in chunk])
         _check(load().pk_colsum_multi(ctypes.addressof(arr), len(chunk), stream(chunk[0][0])), 'pk_colsum_multi')
+
+
+def reduce_multi(sum_jobs, col_jobs):
+    """the K-slice sums (sum_batch_multi's job tuples) and the short column sums (colsum_multi's) of a backward block in ONE launch"""
+    if len(sum_jobs) > 8 or len(col_jobs) > 8 or not sum_jobs or not col_jobs:
+        if sum_jobs:
+            sum_batch_multi(sum_jobs)
+        if col_jobs:
+            colsum_multi(col_jobs)
+        return
+    assert all(E % 4 == 0 for _, _, _, E in sum_jobs)
+    sa = (SumJob * len(sum_jobs))(*[SumJob(p.data_ptr(), o.data_ptr(), p.stride(0), E // 4, S, 0) for p, S, o, E in sum_jobs])
+    ca = (ColsumJob * len(col_jobs))(*[ColsumJob(s_.data_ptr(), o.data_ptr(), s_.stride(-2), M, N, 0, 1.0) for s_, M, N, o in col_jobs])
+    _check(load().pk_reduce_multi(ctypes.addressof(sa), len(sum_jobs), ctypes.addressof(ca), len(col_jobs), stream(sum_jobs[0][0])), 'pk_reduce_multi')
 
 
 def colsum_deferred(src, M, N, out, defer):

@@ -510,6 +510,32 @@ __global__ __launch_bounds__(256) void sum_batch_jobs_kernel(const SumJobs a, in
     *reinterpret_cast<f32x4*>(d.out + idx * 4) = s;
 }
 
+// the K-slice sums AND the short column sums of a backward block in ONE launch (round 6): blocks [0, nsum) run the sum jobs, the rest the column sums
+__global__ __launch_bounds__(256) void reduce_jobs_kernel(const SumJobs a, int nsum_jobs, int nsum_blocks, const ColsumJobs c, int ncol_jobs) {
+    __shared__ f32x4 red[64][4];
+    const int b = blockIdx.x;
+    if (b < nsum_blocks) {
+        int i = 0;
+#pragma unroll
+        for (int k = 1; k < SUM_JOBS; ++k)
+            if (k < nsum_jobs && b >= a.j[k].blk0) i = k;
+        const SumJob d = a.j[i];
+        const long idx = (long)(b - d.blk0) * 256 + threadIdx.x;
+        if (idx >= d.E4) return;
+        f32x4 s = *reinterpret_cast<const f32x4*>(d.src + idx * 4);
+        for (int k = 1; k < d.S; ++k) s += *reinterpret_cast<const f32x4*>(d.src + (long)k * d.stride + idx * 4);
+        *reinterpret_cast<f32x4*>(d.out + idx * 4) = s;
+        return;
+    }
+    const int bc = b - nsum_blocks;
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < COLSUM_JOBS; ++k)
+        if (k < ncol_jobs && bc >= c.j[k].blk0) i = k;
+    const ColsumJob d = c.j[i];
+    colsum16_block(red, d.src, d.ld, d.M, d.N, d.scale, d.out, 0, bc - d.blk0);
+}
+
 // ---- critic head + BCE-with-logits, forward and backward in one pass (phenaki_pytorch.py:246-249 / :306-336 to_pred, :673-676) --------------
 // logit = e . w + b;  loss_row = max(z, 0) - z y + log(1 + exp(-|z|));  dz = (sigmoid(z) - y) * scale;  de = dz * w;  dw / db as block partials
 __global__ __launch_bounds__(256) void bce_head_kernel(const float* __restrict__ e, long lde, const float* __restrict__ w, const float* __restrict__ b,
@@ -601,6 +627,40 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamMulti a, flo
     const long n = a.n[t];
 #pragma unroll
     for (int u = 0; u < ADAM_CHUNK / 256; ++u) {
+        const long i = base + u * 256 + threadIdx.x;
+        if (i >= n) break;
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
+        p[i] = p[i] * (1.0f - lr * wd) - (lr / bc1) * (mi / denom);
+    }
+}
+
+// the LARGE tensors of a step (>= 256 Ki elements: every projection weight, the embedding tables) several per launch (round 6): the block -> tensor
+// map is a prefix array of block counts carried by value (no per-block table, so the grid is not limited by the kernel-argument size as in
+// adamw_multi_kernel: a block still owns only 1024 elements, 4 per thread, and the launch streams like the one-tensor kernel)
+constexpr int ADAM_BIG_T = 32, ADAM_BIG_CHUNK = 1024;
+struct AdamBig {
+    float* p[ADAM_BIG_T]; const float* g[ADAM_BIG_T]; float* m[ADAM_BIG_T]; float* v[ADAM_BIG_T];
+    long n[ADAM_BIG_T];
+    int blk0[ADAM_BIG_T];
+};
+__global__ __launch_bounds__(256) void adamw_big_kernel(const AdamBig a, int count, float lr, float b1, float b2, float eps, float wd, float bc1, float rsqrt_bc2) {
+    const int b = blockIdx.x;
+    int t = 0;
+#pragma unroll
+    for (int c = 1; c < ADAM_BIG_T; ++c)
+        if (c < count && b >= a.blk0[c]) t = c;
+    float* __restrict__ p = a.p[t];
+    const float* __restrict__ g = a.g[t];
+    float* __restrict__ m = a.m[t];
+    float* __restrict__ v = a.v[t];
+    const long n = a.n[t], base = (long)(b - a.blk0[t]) * ADAM_BIG_CHUNK;
+#pragma unroll
+    for (int u = 0; u < ADAM_BIG_CHUNK / 256; ++u) {
         const long i = base + u * 256 + threadIdx.x;
         if (i >= n) break;
         const float gi = g[i];
@@ -855,6 +915,36 @@ extern "C" int pk_colsum_multi(const void* jobs, int count, void* stream) {
     return PK_OK;
 }
 
+// both job lists of a backward block (<= 8 each; either may be empty) in one launch: pk_sum_batch_multi + pk_colsum_multi
+extern "C" int pk_reduce_multi(const void* sum_jobs, int nsum, const void* col_jobs, int ncol, void* stream) {
+    if (nsum < 0 || ncol < 0 || nsum > SUM_JOBS || ncol > COLSUM_JOBS || (nsum > 0 && !sum_jobs) || (ncol > 0 && !col_jobs) || nsum + ncol == 0) return PK_EINVAL;
+    SumJobs a;
+    ColsumJobs c;
+    long sb = 0, cb = 0;
+    for (int i = 0; i < nsum; ++i) {
+        a.j[i] = reinterpret_cast<const SumJob*>(sum_jobs)[i];
+        SumJob& d = a.j[i];
+        if (!d.src || !d.out || d.S <= 0 || d.E4 <= 0) return PK_EINVAL;
+        if ((d.stride & 3) || !al16(d.src) || !al16(d.out)) return PK_EALIGN;
+        d.blk0 = (int)sb;
+        sb += (d.E4 + 255) / 256;
+    }
+    for (int i = 0; i < ncol; ++i) {
+        c.j[i] = reinterpret_cast<const ColsumJob*>(col_jobs)[i];
+        ColsumJob& d = c.j[i];
+        if (!d.src || !d.out || d.M <= 0 || d.M > 8192 || d.N <= 0) return PK_EINVAL;
+        if ((d.N & 3) || (d.ld & 3) || !al16(d.src) || !al16(d.out)) return PK_EALIGN;
+        d.blk0 = (int)cb;
+        cb += (d.N + 15) / 16;
+    }
+    if (sb + cb > 0x7fffffffL) return PK_EINVAL;
+    for (int i = nsum; i < SUM_JOBS; ++i) a.j[i] = a.j[nsum > 0 ? 0 : i];
+    for (int i = ncol; i < COLSUM_JOBS; ++i) c.j[i] = c.j[ncol > 0 ? 0 : i];
+    hipLaunchKernelGGL(reduce_jobs_kernel, dim3((unsigned)(sb + cb)), dim3(256), 0, STREAM(stream), a, nsum, (int)sb, c, ncol);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
 // `count` (<= 8) pk_sum_batch jobs in one launch.  jobs: HOST array of PkSumJob (blk0 is filled in here)
 extern "C" int pk_sum_batch_multi(const void* jobs, int count, void* stream) {
     if (!jobs || count <= 0 || count > SUM_JOBS) return PK_EINVAL;
@@ -900,6 +990,15 @@ extern "C" int pk_adamw_multi(const long long* table, int count, float lr, float
         if (nb > 0) hipLaunchKernelGGL(adamw_multi_kernel, dim3(nb), dim3(256), 0, s, a, lr, beta1, beta2, eps, wd, bc1, rs);
         nt = 0; nb = 0;
     };
+    // large tensors: up to ADAM_BIG_T per launch (A/B switch PK_ADAMW_BIG=0: one launch per tensor, the round-3 form)
+    static const bool big_multi = !(getenv("PK_ADAMW_BIG") && getenv("PK_ADAMW_BIG")[0] == '0');
+    AdamBig big;
+    int bt = 0;
+    long bblocks = 0;
+    auto flush_big = [&]() {
+        if (bt > 0) hipLaunchKernelGGL(adamw_big_kernel, dim3((unsigned)bblocks), dim3(256), 0, s, big, bt, lr, beta1, beta2, eps, wd, bc1, rs);
+        bt = 0; bblocks = 0;
+    };
     for (int i = 0; i < count; ++i) {
         const long long* e = table + 5 * (long)i;
         float* p = reinterpret_cast<float*>(e[0]);
@@ -909,7 +1008,15 @@ extern "C" int pk_adamw_multi(const long long* table, int count, float lr, float
         const long n = e[4];
         if (!p || !g || !m || !v || n <= 0) return PK_EINVAL;
         if (n >= 262144) {
-            hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(n)), dim3(256), 0, s, p, g, m, v, lr, beta1, beta2, eps, wd, bc1, rs, n);
+            if (!big_multi) {
+                hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(n)), dim3(256), 0, s, p, g, m, v, lr, beta1, beta2, eps, wd, bc1, rs, n);
+                continue;
+            }
+            const long nbk = (n + ADAM_BIG_CHUNK - 1) / ADAM_BIG_CHUNK;
+            if (bt == ADAM_BIG_T || bblocks + nbk > 0x7fffffffL) flush_big();
+            big.p[bt] = p; big.g[bt] = g; big.m[bt] = m; big.v[bt] = v; big.n[bt] = n; big.blk0[bt] = (int)bblocks;
+            bblocks += nbk;
+            ++bt;
             continue;
         }
         const int chunks = (int)((n + ADAM_CHUNK - 1) / ADAM_CHUNK);
@@ -922,6 +1029,7 @@ extern "C" int pk_adamw_multi(const long long* table, int count, float lr, float
         }
     }
     flush();
+    flush_big();
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

@@ -352,12 +352,13 @@ class _FFBlock(torch.autograd.Function):
         dW1 = _f32((2 * F, D), dev)
         _weight_grad_gemm(dtype, dhT[:F], xnT, F, D, Mp, dW1[:F], sums)
         _weight_grad_gemm(dtype, dhT[Fp:Fp + F], xnT, F, D, Mp, dW1[F:], sums)
-        _flush_sums(sums)
+        # ---- LayerNorm + residual; the K-slice sums of the three weight gradients and the dgamma | dbeta column sum leave in one launch
+        cs = []
+        dx = _f32((M, D), dev)
+        dg, db = L.layernorm_bwd(x, ln_w.detach(), dxn, dx, M, D, add=dy, want_beta=True, eps=ctx.eps, defer=cs)
+        L.reduce_multi(sums, cs)
         if dW2p is not None:
             dW2 = dW2p[:, :F].contiguous()
-        # ---- LayerNorm + residual
-        dx = _f32((M, D), dev)
-        dg, db = L.layernorm_bwd(x, ln_w.detach(), dxn, dx, M, D, add=dy, want_beta=True, eps=ctx.eps)
         return dx, dg, db, dW1, dW2, None, None, None
 
 
@@ -484,7 +485,6 @@ class _AttnBlock(torch.autograd.Function):
         if is_cross:
             need_ctx = ctx.needs_input_grad[1]
             dsrc, dWkv = linear_bwd(dtype, src, wkv, dkv, need_dx=(cgamma is not None) or need_ctx, Wt=img['wkv'][1], dyT=dkvT, xT=srcT, defer=sums, dyA=dkvA)
-            _flush_sums(sums)
             if cgamma is not None:
                 dctx = _f32(tuple(context.shape), dev)
                 dcg, _ = L.layernorm_bwd(context, cgamma.detach(), dsrc, dctx, context.shape[0], context.shape[1], eps=eps, defer=cs)
@@ -493,10 +493,8 @@ class _AttnBlock(torch.autograd.Function):
             dg, _ = L.layernorm_bwd(x, gamma.detach(), dxn, dx, M, D, add=dy, eps=eps, defer=cs)
         else:
             t, dWkv = linear_bwd(dtype, x, wkv, dkv, add=dy, Wt=img['wkv'][1], dyT=dkvT, xT=srcT, defer=sums, dyA=dkvA)   # dy + dkv Wkv: K / V read the un-normalised x
-            _flush_sums(sums)
             dg, _ = L.layernorm_bwd(x, gamma.detach(), dxn, dx, M, D, add=t, eps=eps, defer=cs)
-        if cs:
-            L.colsum_multi(cs)
+        L.reduce_multi(sums, cs)                                         # the K-slice sums of dWo / dWq / dWkv and the column sums: one launch
         return dx, dctx, dg, None, dcg, None, dWq, dWkv, dnull, dqs, dks, dWo, dbias, None, None
 
 
