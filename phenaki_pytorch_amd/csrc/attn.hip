@@ -41,9 +41,9 @@ __device__ __forceinline__ float group16_sum(float v) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void prep_q_kernel(const PrepArgs p) {
+__device__ __forceinline__ void prep_q_block(const PrepArgs& p, long bid) {
     const int l16 = threadIdx.x & 15;
-    const long r = (long)blockIdx.x * 16 + (threadIdx.x >> 4);          // row index over (s, hh, i) incl. pad rows
+    const long r = bid * 16 + (threadIdx.x >> 4);                        // row index over (s, hh, i) incl. pad rows
     const long total = (long)p.S * p.h * p.nq_pad;
     if (r >= total) return;
     const int i = (int)(r % p.nq_pad);
@@ -67,13 +67,12 @@ __global__ __launch_bounds__(256) void prep_q_kernel(const PrepArgs p) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void prep_kv_kernel(const PrepArgs p) {
+__device__ __forceinline__ void prep_kv_block(const PrepArgs& p, float (*vt)[65], int bid) {
     // one block per (s, hh, 64-key tile); thread -> (key = tid >> 4 (+16 per pass), 4 head dims)
-    __shared__ float vt[64][65];
     const int l16 = threadIdx.x & 15;
     const int tiles = (p.nk_pad + 63) / 64;
-    const int kt = blockIdx.x % tiles;
-    const int sh = blockIdx.x / tiles;
+    const int kt = bid % tiles;
+    const int sh = bid / tiles;
     const int hh = sh % p.h, s = sh / p.h;
     const int nk = p.nnull + p.n_kv;
     T* Kp = reinterpret_cast<T*>(p.Kp) + (size_t)sh * p.nk_pad * DH;
@@ -109,6 +108,14 @@ __global__ __launch_bounds__(256) void prep_kv_kernel(const PrepArgs p) {
             store4(Vt + (size_t)d * p.nk_pad + kt * 64 + jl, o);
         }
     }
+}
+
+// both operand-image kernels in ONE launch (round 6): blocks [0, nqb) lay down the Q^ image, the rest the K^ / V^T images
+template <typename T>
+__global__ __launch_bounds__(256) void prep_qkv_kernel(const PrepArgs p, int nqb) {
+    __shared__ float vt[64][65];
+    if ((int)blockIdx.x < nqb) prep_q_block<T>(p, blockIdx.x);
+    else prep_kv_block<T>(p, vt, (int)blockIdx.x - nqb);
 }
 
 struct AttnArgs {
@@ -880,18 +887,16 @@ extern "C" int pk_attn_prep(int dtype, const float* q, int ldq, const float* kv,
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long qrows = (long)S * h * nq_pad;
     const int tiles = (nk_pad + 63) / 64;
+    const unsigned nqb = (unsigned)((qrows + 15) / 16), nkb = kv ? (unsigned)(S * h * tiles) : 0u;
     if (dtype == 1) {
-        hipLaunchKernelGGL((prep_q_kernel<bf16>), dim3((unsigned)((qrows + 15) / 16)), dim3(256), 0, s, p);
-        if (kv) hipLaunchKernelGGL((prep_kv_kernel<bf16>), dim3((unsigned)(S * h * tiles)), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((prep_qkv_kernel<bf16>), dim3(nqb + nkb), dim3(256), 0, s, p, (int)nqb);
     } else if (dtype == 0) {
-        hipLaunchKernelGGL((prep_q_kernel<float>), dim3((unsigned)((qrows + 15) / 16)), dim3(256), 0, s, p);
-        if (kv) hipLaunchKernelGGL((prep_kv_kernel<float>), dim3((unsigned)(S * h * tiles)), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((prep_qkv_kernel<float>), dim3(nqb + nkb), dim3(256), 0, s, p, (int)nqb);
     } else if (dtype == 2) {
         // split-bf16: the images are pre-split (hi | lo) bf16 planes in 128-byte blocks of 32 elements (common.hpp bf16x3p); same sizes
         // as the f32 images; rows are 64 / nk_pad (% 32 == 0) elements, the bases must sit on a 128-byte boundary
         if ((reinterpret_cast<uintptr_t>(Qp) & 127) || (kv && ((reinterpret_cast<uintptr_t>(Kp) | reinterpret_cast<uintptr_t>(Vt)) & 127))) return PK_EALIGN;
-        hipLaunchKernelGGL((prep_q_kernel<bf16x3p>), dim3((unsigned)((qrows + 15) / 16)), dim3(256), 0, s, p);
-        if (kv) hipLaunchKernelGGL((prep_kv_kernel<bf16x3p>), dim3((unsigned)(S * h * tiles)), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((prep_qkv_kernel<bf16x3p>), dim3(nqb + nkb), dim3(256), 0, s, p, (int)nqb);
     } else return PK_EINVAL;
     PK_CHECK_LAUNCH();
     return PK_OK;

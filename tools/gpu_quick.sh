@@ -10,6 +10,7 @@ for i in 1 2; do
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu --no-parity-mode --no-kernels --no-graph --groups 5 > gpurun_out/r2_bench_quick.json 2> gpurun_out/r2_bench_quick.err
 python - <<PY
 import json
-d=json.load(open('gpurun_out/r2_bench_quick.json')); print('encode ms', round(d['ms_per_step'],4), 'decode', round(d['decode'].get('ms_per_step'),4), 'sample', d['sample']['seconds_by_launch_mode'], 'cfg3', round(d['sample_cfg3']['seconds_per_sample_call'],5), 'mv', round(d['make_video']['wall_clock_s'],4))
+d=json.load(open('gpurun_out/r2_bench_quick.json')); legs=d.get('legs', {})
+print('encode ms', round(d['ms_per_step'],4), 'sample', d.get('sample', {}).get('value'), 'legs', {k: v.get('value', v.get('ms_per_step')) for k, v in legs.items()})
 PY
 done
