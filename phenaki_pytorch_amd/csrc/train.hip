@@ -441,12 +441,26 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int c = (int)(idx % dv) * 4;
         const int p = (int)(idx / dv);
-        f32x4 a = f32x4{0, 0, 0, 0};
+        f32x4 a = f32x4{0, 0, 0, 0}, run = a;
+        long long cur = -1;
+        // consecutive sequences with the SAME id at this position (the mask id collects most rows) are summed before the atomics: the hot row sees
+        // one add per run instead of one per sequence
         for (int s = 0; s < S; ++s) {
             const f32x4 g = *reinterpret_cast<const f32x4*>(dy + ((long)s * n + p) * D + c) * alpha;
             a += g;
-            float* dst = dtok + ids[(long)s * n + p] * D + c;
-            atomicAdd(dst, g[0]); atomicAdd(dst + 1, g[1]); atomicAdd(dst + 2, g[2]); atomicAdd(dst + 3, g[3]);
+            const long long id = ids[(long)s * n + p];
+            if (id != cur) {
+                if (cur >= 0) {
+                    float* dst = dtok + cur * D + c;
+                    atomicAdd(dst, run[0]); atomicAdd(dst + 1, run[1]); atomicAdd(dst + 2, run[2]); atomicAdd(dst + 3, run[3]);
+                }
+                cur = id;
+                run = g;
+            } else run += g;
+        }
+        if (cur >= 0) {
+            float* dst = dtok + cur * D + c;
+            atomicAdd(dst, run[0]); atomicAdd(dst + 1, run[1]); atomicAdd(dst + 2, run[2]); atomicAdd(dst + 3, run[3]);
         }
         *reinterpret_cast<f32x4*>(dpos + (long)p * D + c) = a;
     }
