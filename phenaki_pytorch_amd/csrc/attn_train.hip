@@ -22,35 +22,47 @@ constexpr int TLD = 68;                        // LDS tile row stride (floats)
 constexpr int TSZ = 64 * TLD;                  // one 64 x 64 tile
 
 // ---- f32 operand images of one attention call: Qh [S*h][n][64], Kh / Vh [S*h][nkt][64], nkt = nnull + n_kv --------------------------
+// 16 lanes per row, 4 consecutive head dims (one 16-byte access) per lane, the row's sums by a 4-step xor shuffle inside the 16-lane group -- the
+// arrangement (and summation order) of the forward's prep_q / prep_kv kernels (round 6: one 4-byte access per lane and a 64-lane reduction per row
+// before: 18 / 24 us for 56 / 85 MB)
+__device__ __forceinline__ float g16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+    return v;
+}
+__device__ __forceinline__ float sumsq4(const f32x4& x) { return (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]); }
+__device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) { return (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]); }
+
 __global__ __launch_bounds__(256) void attn_train_prep_kernel(const float* __restrict__ q, long ldq, const float* __restrict__ kv, long ldkv,
                                                               const float* __restrict__ null_kv, const float* __restrict__ q_scale,
                                                               const float* __restrict__ k_scale, float scale, float* __restrict__ Qh,
                                                               float* __restrict__ Kh, float* __restrict__ Vh, int S, int heads, int n, int n_kv,
                                                               int nnull, long tasks) {
-    const int lane = threadIdx.x & 63;
+    const int l16 = threadIdx.x & 15, c = l16 * 4;
     const int nkt = nnull + n_kv, inner = heads * 64;
     const long nq = (long)S * heads * n;
-    for (long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6); t < tasks; t += (long)gridDim.x * 4) {
+    const f32x4 qs = *reinterpret_cast<const f32x4*>(q_scale + c), ks = *reinterpret_cast<const f32x4*>(k_scale + c);
+    for (long t = (long)blockIdx.x * 16 + (threadIdx.x >> 4); t < tasks; t += (long)gridDim.x * 16) {
         if (t < nq) {
             const int i = (int)(t % n), h = (int)((t / n) % heads), s = (int)(t / ((long)n * heads));
-            const float x = q[((long)s * n + i) * ldq + h * 64 + lane];
-            const float inv = 1.0f / fmaxf(sqrtf(wave_sum(x * x)), 1e-12f);
-            Qh[t * 64 + lane] = x * inv * q_scale[lane] * scale;
+            const f32x4 x = *reinterpret_cast<const f32x4*>(q + ((long)s * n + i) * ldq + h * 64 + c);
+            const float inv = scale / fmaxf(sqrtf(g16_sum(sumsq4(x))), 1e-12f);
+            *reinterpret_cast<f32x4*>(Qh + t * 64 + c) = x * inv * qs;
         } else {
             const long u = t - nq;
             const int j = (int)(u % nkt), h = (int)((u / nkt) % heads), s = (int)(u / ((long)nkt * heads));
-            float k, v;
+            f32x4 k, v;
             if (j < nnull) {
-                k = null_kv[((long)h * 2 * nnull + 2 * j) * 64 + lane];
-                v = null_kv[((long)h * 2 * nnull + 2 * j + 1) * 64 + lane];
+                k = *reinterpret_cast<const f32x4*>(null_kv + ((long)h * 2 * nnull + 2 * j) * 64 + c);
+                v = *reinterpret_cast<const f32x4*>(null_kv + ((long)h * 2 * nnull + 2 * j + 1) * 64 + c);
             } else {
-                const float* row = kv + ((long)s * n_kv + (j - nnull)) * ldkv + h * 64 + lane;
-                k = row[0];
-                v = row[inner];
+                const float* row = kv + ((long)s * n_kv + (j - nnull)) * ldkv + h * 64 + c;
+                k = *reinterpret_cast<const f32x4*>(row);
+                v = *reinterpret_cast<const f32x4*>(row + inner);
             }
-            const float inv = 1.0f / fmaxf(sqrtf(wave_sum(k * k)), 1e-12f);
-            Kh[u * 64 + lane] = k * inv * k_scale[lane];
-            Vh[u * 64 + lane] = v;
+            const float inv = 1.0f / fmaxf(sqrtf(g16_sum(sumsq4(k))), 1e-12f);
+            *reinterpret_cast<f32x4*>(Kh + u * 64 + c) = k * inv * ks;
+            *reinterpret_cast<f32x4*>(Vh + u * 64 + c) = v;
         }
     }
 }
@@ -62,46 +74,50 @@ __global__ __launch_bounds__(256) void attn_train_prep_bwd_kernel(const float* _
                                                                   const float* __restrict__ dKh, const float* __restrict__ dVh, float* __restrict__ dq,
                                                                   long lddq, float* __restrict__ dkv, long lddkv, float* __restrict__ pq,
                                                                   float* __restrict__ pk_, int S, int heads, int n, int n_kv, int nnull, long tasks) {
-    __shared__ float red[2][4][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ f32x4 red[2][16][16];
+    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4, c = l16 * 4;
     const int nkt = nnull + n_kv, inner = heads * 64;
     const long nq = (long)S * heads * n;
-    const float qs = q_scale[lane], ks = k_scale[lane];
-    float aq = 0.f, ak = 0.f;
-    for (long t = (long)blockIdx.x * 4 + wv; t < tasks; t += (long)gridDim.x * 4) {
+    const f32x4 qs = *reinterpret_cast<const f32x4*>(q_scale + c), ks = *reinterpret_cast<const f32x4*>(k_scale + c);
+    f32x4 aq = {0.f, 0.f, 0.f, 0.f}, ak = aq;
+    for (long t = (long)blockIdx.x * 16 + grp; t < tasks; t += (long)gridDim.x * 16) {
         if (t < nq) {
             const int i = (int)(t % n), h = (int)((t / n) % heads), s = (int)(t / ((long)n * heads));
-            const float x = q[((long)s * n + i) * ldq + h * 64 + lane];
-            const float inv = 1.0f / fmaxf(sqrtf(wave_sum(x * x)), 1e-12f);
-            const float xn = x * inv, g = dQh[t * 64 + lane];
+            const f32x4 x = *reinterpret_cast<const f32x4*>(q + ((long)s * n + i) * ldq + h * 64 + c);
+            const float inv = 1.0f / fmaxf(sqrtf(g16_sum(sumsq4(x))), 1e-12f);
+            const f32x4 xn = x * inv, g = *reinterpret_cast<const f32x4*>(dQh + t * 64 + c);
             aq += g * xn * scale;
-            const float dn = g * qs * scale;
-            const float dot = wave_sum(dn * xn);
-            dq[((long)s * n + i) * lddq + h * 64 + lane] = (dn - xn * dot) * inv;
+            const f32x4 dn = g * qs * scale;
+            const float dot = g16_sum(dot4(dn, xn));
+            *reinterpret_cast<f32x4*>(dq + ((long)s * n + i) * lddq + h * 64 + c) = (dn - xn * dot) * inv;
         } else {
             const long u = t - nq;
             const int j = (int)(u % nkt), h = (int)((u / nkt) % heads), s = (int)(u / ((long)nkt * heads));
-            const float k = j < nnull ? null_kv[((long)h * 2 * nnull + 2 * j) * 64 + lane]
-                                      : kv[((long)s * n_kv + (j - nnull)) * ldkv + h * 64 + lane];
-            const float inv = 1.0f / fmaxf(sqrtf(wave_sum(k * k)), 1e-12f);
-            const float kn = k * inv, g = dKh[u * 64 + lane];
+            const f32x4 k = j < nnull ? *reinterpret_cast<const f32x4*>(null_kv + ((long)h * 2 * nnull + 2 * j) * 64 + c)
+                                      : *reinterpret_cast<const f32x4*>(kv + ((long)s * n_kv + (j - nnull)) * ldkv + h * 64 + c);
+            const float inv = 1.0f / fmaxf(sqrtf(g16_sum(sumsq4(k))), 1e-12f);
+            const f32x4 kn = k * inv, g = *reinterpret_cast<const f32x4*>(dKh + u * 64 + c);
             ak += g * kn;
             if (j >= nnull) {
-                const float dn = g * ks;
-                const float dot = wave_sum(dn * kn);
-                float* row = dkv + ((long)s * n_kv + (j - nnull)) * lddkv + h * 64 + lane;
-                row[0] = (dn - kn * dot) * inv;
-                row[inner] = dVh[u * 64 + lane];
+                const f32x4 dn = g * ks;
+                const float dot = g16_sum(dot4(dn, kn));
+                float* row = dkv + ((long)s * n_kv + (j - nnull)) * lddkv + h * 64 + c;
+                *reinterpret_cast<f32x4*>(row) = (dn - kn * dot) * inv;
+                *reinterpret_cast<f32x4*>(row + inner) = *reinterpret_cast<const f32x4*>(dVh + u * 64 + c);
             }
         }
     }
-    red[0][wv][lane] = aq;
-    red[1][wv][lane] = ak;
+    red[0][grp][l16] = aq;
+    red[1][grp][l16] = ak;
     __syncthreads();
-    if (wv < 2) {
-        float* dst = wv == 0 ? pq : pk_;
+    if (threadIdx.x < 32) {                                              // thread (which = tid >> 4, column lane l16): the 16 row groups in order
+        const int which = threadIdx.x >> 4;
+        f32x4 sum = red[which][0][l16];
+#pragma unroll
+        for (int g2 = 1; g2 < 16; ++g2) sum += red[which][g2][l16];
+        float* dst = which == 0 ? pq : pk_;
         const long pst = (pk_ == pq + 64) ? 128 : 64;                    // the two halves of one (parts, 128) buffer: one pk_colsum finishes both
-        dst[(long)blockIdx.x * pst + lane] = (red[wv][0][lane] + red[wv][1][lane]) + (red[wv][2][lane] + red[wv][3][lane]);
+        *reinterpret_cast<f32x4*>(dst + (long)blockIdx.x * pst + c) = sum;
     }
 }
 // dnull_kv[h][2 j + {0, 1}][d] = sum over the sequences of the null key's l2norm backward / of dV at the null slot (one wave per (h, j))
@@ -571,8 +587,9 @@ static constexpr int KV_SMEM = (2 * QT * TLD + 3 * 64 * TLQ + 2 * QT) * 4;
 extern "C" int pk_attn_train_prep(const float* q, long ldq, const float* kv, long ldkv, const float* null_kv, const float* q_scale, const float* k_scale,
                                   float scale, float* Qh, float* Kh, float* Vh, int S, int heads, int n, int n_kv, int nnull, void* stream) {
     if (!q || !kv || !q_scale || !k_scale || !Qh || !Kh || !Vh || S <= 0 || heads <= 0 || n <= 0 || n_kv <= 0 || nnull < 0 || (nnull > 0 && !null_kv)) return PK_EINVAL;
+    if ((ldq & 3) || (ldkv & 3) || !al16(q) || !al16(kv) || !al16(q_scale) || !al16(k_scale) || !al16(Qh) || !al16(Kh) || !al16(Vh) || (nnull > 0 && !al16(null_kv))) return PK_EALIGN;
     const long tasks = (long)S * heads * (n + nnull + n_kv);
-    long blocks = (tasks + 3) / 4;
+    long blocks = (tasks + 15) / 16;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(attn_train_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, STREAM(stream), q, ldq, kv, ldkv, null_kv, q_scale, k_scale, scale, Qh, Kh, Vh,
                        S, heads, n, n_kv, nnull, tasks);
@@ -586,6 +603,8 @@ extern "C" int pk_attn_train_prep_bwd(const float* q, long ldq, const float* kv,
                                       float* pq, float* pk_, float* dnull, int S, int heads, int n, int n_kv, int nnull, void* stream) {
     if (!q || !kv || !q_scale || !k_scale || !dQh || !dKh || !dVh || !dq || !dkv || !pq || !pk_ || S <= 0 || heads <= 0 || n <= 0 || n_kv <= 0 || nnull < 0 ||
         (nnull > 0 && (!null_kv || !dnull))) return PK_EINVAL;
+    if ((ldq & 3) || (ldkv & 3) || (lddq & 3) || (lddkv & 3) || !al16(q) || !al16(kv) || !al16(q_scale) || !al16(k_scale) || !al16(dQh) || !al16(dKh) || !al16(dVh) ||
+        !al16(dq) || !al16(dkv) || !al16(pq) || !al16(pk_) || (nnull > 0 && !al16(null_kv))) return PK_EALIGN;
     const long tasks = (long)S * heads * (n + nnull + n_kv);
     hipStream_t s = STREAM(stream);
     hipLaunchKernelGGL(attn_train_prep_bwd_kernel, dim3(1024), dim3(256), 0, s, q, ldq, kv, ldkv, null_kv, q_scale, k_scale, scale, dQh, dKh, dVh,
