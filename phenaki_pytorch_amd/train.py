@@ -20,6 +20,10 @@ Every block of the trunk is ONE torch.autograd.Function whose forward and backwa
 Activations and gradients are f32 in HBM (288 GB: every block keeps what its backward needs instead of recomputing it); the GEMMs run in the
 module's compute dtype ('fp32' | 'bf16x3' | 'bf16').  Matrix products of the backward pass: dX = dY W through pk_gemm on pk_pack(W^T),
 dW = dY^T X through pk_gemm on pk_pack(dY^T) and pk_pack(X^T) (contraction over the rows, zero-padded to the k-tile).
+Round 6 (launch count): the W / W^T images of a whole Transformer are persistent and refreshed by ONE launch per pass (`WeightImages`,
+pk_pack_table); the activation transposes of a backward block leave in one launch (`transposes`, pk_pack_multi), its K-slice sums and column sums
+in another (L.reduce_multi); the forward attention hands its log-sum-exp to the backward kernels (pk_attn_fwd_lse); the critic's gumbel sample and
+the cross entropy share one pass over the vocabulary (`_VocabCrossEntropy(shared=...)`).
 Limits (asserted): dropout 0 (the reference default).  The tokenizer's own reconstruction step is train_cvivit.py.
 """
 import math
@@ -84,7 +88,7 @@ def _weight_grad_gemm(dtype, dyT, xT, N, K, Mp, dW, defer=None):
     """dW (N, K) = dyT (N, Mp) @ xT (K, Mp)^T: the contraction runs over the rows of the batch (Mp = 4608 at B = 8) while the output has only
     ceil(N / 64) ceil(K / 64) tiles -- 64 for a 512 x 512 projection on 256 CUs -- so the product is cut into K-slices (pk_gemm_splitk) that are
     added in index order (pk_sum_batch: deterministic).  defer (list): the slice sum is queued there instead of launched -- the caller adds the
-    slices of all its weight gradients with ONE pk_sum_batch_multi (`_flush_sums`)."""
+    slices (and the column sums) of a whole backward block in ONE launch, `L.reduce_multi`."""
     q = _q(dtype)
     tiles = ((N + 63) // 64) * ((K + 63) // 64)
     splits = 1
@@ -104,12 +108,6 @@ def _weight_grad_gemm(dtype, dyT, xT, N, K, Mp, dW, defer=None):
         defer.append((part, splits, dW, N * K))
     else:
         L.sum_batch(part, splits, dW, N * K)
-
-
-def _flush_sums(defer):
-    if defer:
-        L.sum_batch_multi(defer)
-        defer.clear()
 
 
 def transposes(dtype, items, casts=()):
@@ -135,12 +133,8 @@ def transposes(dtype, items, casts=()):
         else:
             outs.append(src)
     if jobs:
-        L.pack_multi(jobs, jobs_like(items, casts))
+        L.pack_multi(jobs, items[0][0] if items else casts[0])
     return outs
-
-
-def jobs_like(items, casts):
-    return items[0][0] if items else casts[0]
 
 
 def a_operand(dtype, x):
