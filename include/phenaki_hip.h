@@ -378,6 +378,7 @@ int pk_mul(const float* a, const float* b, float* out, long long n, void* stream
 int pk_leaky_bwd(const float* y, long long ldy, const float* dy, long long lddy, float* dz, long long lddz, int M, int N, float slope, void* stream);
 /* PEG backward (attention.py:57-85 + residual :323): dx = dy + transposed stencil of dy; part (NULL: skip): (pk_peg_wgrad_parts(rows), 27, D)
  * partial tap gradients sum dy[pos] x[pos + tap], finished by pk_colsum over 27 D columns (the conv bias gradient is pk_colsum of dy) */
+int pk_peg_adjoint(const float* dy, const float* wt, float* dx, int B, int T, int H, int W, int D, int causal, void* stream);   /* dx only, W in {4, 8, 16} (else PK_EINVAL) */
 int pk_peg_wgrad_parts(long long rows);
 int pk_peg_bwd(const float* dy, const float* x, const float* wt, float* dx, float* part, int B, int T, int H, int W, int D, int causal, void* stream);
 /* token + position embedding backward (phenaki_pytorch.py:194-199, alpha = gradient_shrink_alpha): dpos (n, D) overwritten, dtok (zeroed by

@@ -89,6 +89,7 @@ SIGNATURES = {
     'pk_bias_scatter': [_P, _P, _I, _P, _I, _I, _I, _P],
     'pk_sum_batch': [_P, _LL, _I, _P, _LL, _P],
     'pk_sum_batch_multi': [_P, _I, _P],
+    'pk_peg_adjoint': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'pk_colsum_multi': [_P, _I, _P],
     'pk_reduce_multi': [_P, _I, _P, _I, _P],
     'pk_pack_multi': [_P, _I, _P],

@@ -46,10 +46,12 @@ __global__ __launch_bounds__(256) void peg_kernel(const float* __restrict__ x, c
 
 // same stencil, one thread per (b, t, h, 4 channels) producing the whole W-row: every input row segment is loaded once
 // and reused by its 3 taps, and the 27 weight vectors are loaded once per thread (3x fewer L2 reads than peg_kernel)
+// flip (round 6): the ADJOINT stencil for the backward pass, dx = dy + conv^T(dy) -- tap (dt, dh, dw) reads weight 26 - tap (all three axes mirrored) and the
+// caller passes tfront' = 2 - tfront and no bias: the same row-reusing loop instead of the training step's own 27-gather kernel (23 -> 10 us)
 template <int WW>
 __global__ __launch_bounds__(256) void peg_row_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                       const float* __restrict__ bias, float* __restrict__ out, bf16* __restrict__ out_t,
-                                                      int B, int T, int H, int D, int tfront, long total) {
+                                                      int B, int T, int H, int D, int tfront, long total, int flip = 0) {
     const int dv = D >> 2;
     // XCD-contiguous order (common.hpp): a stencil row's 9 neighbour rows then sit in the SAME XCD's L2 -- 19.2 -> 13.3 us
     // at (16,9,8,8,512), bit-identical output (tools/peg_bench.hip)
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void peg_row_kernel(const float* __restrict__ 
     long p = idx / dv;
     const int h = (int)(p % H); p /= H;
     const int t = (int)(p % T); const int b = (int)(p / T);
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c);
+    const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 acc[WW];
 #pragma unroll
     for (int w = 0; w < WW; ++w) acc[w] = bv;
@@ -75,9 +77,10 @@ __global__ __launch_bounds__(256) void peg_row_kernel(const float* __restrict__ 
             f32x4 xr[WW];
 #pragma unroll
             for (int w = 0; w < WW; ++w) xr[w] = *reinterpret_cast<const f32x4*>(row + (size_t)w * D);
-            const f32x4 k0 = *reinterpret_cast<const f32x4*>(wt + (size_t)((dt * 3 + dh) * 3 + 0) * D + c);
-            const f32x4 k1 = *reinterpret_cast<const f32x4*>(wt + (size_t)((dt * 3 + dh) * 3 + 1) * D + c);
-            const f32x4 k2 = *reinterpret_cast<const f32x4*>(wt + (size_t)((dt * 3 + dh) * 3 + 2) * D + c);
+            const int tb = (dt * 3 + dh) * 3;
+            const f32x4 k0 = *reinterpret_cast<const f32x4*>(wt + (size_t)(flip ? 26 - tb : tb) * D + c);
+            const f32x4 k1 = *reinterpret_cast<const f32x4*>(wt + (size_t)(flip ? 25 - tb : tb + 1) * D + c);
+            const f32x4 k2 = *reinterpret_cast<const f32x4*>(wt + (size_t)(flip ? 24 - tb : tb + 2) * D + c);
 #pragma unroll
             for (int w = 0; w < WW; ++w) {
                 if (w > 0) acc[w] += xr[w - 1] * k0;
@@ -325,6 +328,21 @@ extern "C" int pk_peg(const float* x, const float* wt, const float* bias, float*
     else if (W == 4) hipLaunchKernelGGL((peg_row_kernel<4>), rgrid, dim3(256), 0, STREAM(stream), x, wt, bias, out, ot, B, T, H, D, causal ? 2 : 1, rows);
     else if (W == 16) hipLaunchKernelGGL((peg_row_kernel<16>), rgrid, dim3(256), 0, STREAM(stream), x, wt, bias, out, ot, B, T, H, D, causal ? 2 : 1, rows);
     else hipLaunchKernelGGL(peg_kernel, dim3(nblocks(total)), dim3(256), 0, STREAM(stream), x, wt, bias, out, ot, B, T, H, W, D, causal ? 2 : 1, total);
+    PK_CHECK_LAUNCH();
+    return PK_OK;
+}
+
+// the adjoint stencil on the row kernel (W in {4, 8, 16}); returns PK_EINVAL for other widths (the caller keeps its gather kernel)
+extern "C" int pk_peg_adjoint(const float* dy, const float* wt, float* dx, int B, int T, int H, int W, int D, int causal, void* stream) {
+    if (!dy || !wt || !dx || B <= 0 || T <= 0 || H <= 0 || D <= 0 || dy == dx) return PK_EINVAL;
+    if (D & 3) return PK_EALIGN;
+    const long rows = (long)B * T * H * (D >> 2);
+    const dim3 rgrid(xcd_padded_grid((rows + 255) / 256));
+    const int tf = 2 - (causal ? 2 : 1);
+    if (W == 8) hipLaunchKernelGGL((peg_row_kernel<8>), rgrid, dim3(256), 0, STREAM(stream), dy, wt, nullptr, dx, nullptr, B, T, H, D, tf, rows, 1);
+    else if (W == 4) hipLaunchKernelGGL((peg_row_kernel<4>), rgrid, dim3(256), 0, STREAM(stream), dy, wt, nullptr, dx, nullptr, B, T, H, D, tf, rows, 1);
+    else if (W == 16) hipLaunchKernelGGL((peg_row_kernel<16>), rgrid, dim3(256), 0, STREAM(stream), dy, wt, nullptr, dx, nullptr, B, T, H, D, tf, rows, 1);
+    else return PK_EINVAL;
     PK_CHECK_LAUNCH();
     return PK_OK;
 }

@@ -846,6 +846,7 @@ extern "C" int pk_sign(const float* z, float value, float* out, long n, void* st
     return PK_OK;
 }
 
+extern "C" int pk_peg_adjoint(const float* dy, const float* wt, float* dx, int B, int T, int H, int W, int D, int causal, void* stream);
 // dx = dy + transposed stencil of dy;  part: (pk_peg_wgrad_parts(rows), 27, D) partial tap gradients (finish with pk_colsum over 27 * D columns)
 // ~16 positions per block (2 row lanes at D = 512): 288 blocks at 4608 positions -- 36 blocks of 128 positions left 7 of 8 CUs idle (346 us)
 extern "C" int pk_peg_wgrad_parts(long rows) { long p = (rows + 15) / 16; return (int)(p < 1 ? 1 : (p > 1024 ? 1024 : p)); }
@@ -856,7 +857,9 @@ extern "C" int pk_peg_bwd(const float* dy, const float* x, const float* wt, floa
     if (part && (dv > 256 || 256 % dv)) return PK_EINVAL;
     hipStream_t s = STREAM(stream);
     const long rows = (long)B * T * H * W, total = rows * dv;
-    hipLaunchKernelGGL(peg_bwd_kernel, dim3(nblocks(total)), dim3(256), 0, s, dy, wt, dx, B, T, H, W, D, causal ? 2 : 1, total);
+    // dx: the adjoint stencil on the forward's row kernel where it exists (W in {4, 8, 16}), else the 27-gather kernel
+    if (pk_peg_adjoint(dy, wt, dx, B, T, H, W, D, causal, stream) != PK_OK)
+        hipLaunchKernelGGL(peg_bwd_kernel, dim3(nblocks(total)), dim3(256), 0, s, dy, wt, dx, B, T, H, W, D, causal ? 2 : 1, total);
     if (part) {
         const int P = pk_peg_wgrad_parts(rows);
         const int rpb = (int)((rows + P - 1) / P);
